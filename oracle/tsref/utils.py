@@ -1,0 +1,10 @@
+"""torchsparse/utils/utils.py (v1.4.0) -- make_ntuple.  TEST INFRASTRUCTURE."""
+
+
+def make_ntuple(x, ndim):
+    if isinstance(x, int):
+        x = tuple([x] * ndim)
+    elif isinstance(x, list):
+        x = tuple(x)
+    assert isinstance(x, tuple) and len(x) == ndim, x
+    return x

@@ -1,0 +1,255 @@
+"""Generate the golden fixtures under tests/golden/.  Runs ONLY in the build container: it
+imports the reference's own Python files from /root/reference (which do not exist on the GPU
+box) on top of the CPU oracle, and commits inputs + expected outputs as small .npz/.json data.
+
+  python tests/golden/make_golden.py            # all fixtures
+  python tests/golden/make_golden.py model      # just one group: model | scoring | selection
+
+What each fixture pins
+  model_small.npz     reference network/spvcnn.py + network/minkunet.py (unchanged files) run on
+                      oracle.tsref: logits/feat for a seeded ~3 k-point scan (eval), one train
+                      step (loss + gradient norms), every kernel map the forward builds.
+  state_dict_*.json   the checkpoint compatibility surface (keys, shapes, dtypes).
+  scoring_small.npz   reference score/sv_level/LiDAL.py::worker_func run unchanged on synthetic
+                      frames; also asserts oracle.scoring_ref reproduces it (the oracle PIN).
+  selection_small.npz reference score/sv_level/LiDAL.py __main__ run unchanged in a temp
+                      Processing_files tree (10 sequences); asserts oracle.scoring_ref.select
+                      reproduces the written sv_flag files.
+"""
+import json
+import os
+import pickle
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from weights import fill_state_dict, state_dict_signature  # noqa: E402
+
+
+def _import_reference_models():
+    from oracle.install import install_as_torchsparse
+    ts = install_as_torchsparse()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from network.spvcnn import SPVCNN
+    from network.minkunet import MinkUNet
+    return ts, SPVCNN, MinkUNet
+
+
+def make_model():
+    ts, SPVCNN, MinkUNet = _import_reference_models()
+    from lidal_amd import synth
+    torch.set_num_threads(8)
+    batch = synth.make_train_batch(n_frames=2, n_points=1600, seed=7122)
+    coords = torch.from_numpy(batch['coords_v_b'])
+    feats = torch.from_numpy(batch['feats_v_b'])
+    labels = torch.from_numpy(batch['labels_v_b'])
+    out = {'coords': batch['coords_v_b'], 'feats': batch['feats_v_b'],
+           'labels': batch['labels_v_b']}
+    for name, cls in (('spvcnn', SPVCNN), ('minkunet', MinkUNet)):
+        model = fill_state_dict(cls(19))
+        with open(os.path.join(HERE, 'state_dict_%s.json' % name), 'w') as f:
+            json.dump(state_dict_signature(model), f)
+        model.eval()
+        x = ts.SparseTensor(feats.clone(), coords.clone())
+        with torch.no_grad():
+            logits, feat = model(x)
+        out[name + '_logits'] = logits.numpy()
+        out[name + '_feat'] = feat.numpy()
+        if name == 'minkunet':                      # every kernel map of the U-Net
+            for key, km in x.kmaps.items():
+                tag = 's%d_k%d_c%d' % (key[0][0], key[1][0], key[2][0])
+                out['kmap_%s_nbmaps' % tag] = km[0].numpy().astype(np.int32)
+                out['kmap_%s_nbsizes' % tag] = km[1].numpy().astype(np.int32)
+            for s, c in x.cmaps.items():
+                out['cmap_s%d' % s[0]] = c.numpy().astype(np.int32)
+        # one training step (train.py:127-140); dropout off so CPU and GPU RNG cannot differ
+        model = fill_state_dict(cls(19))
+        model.train()
+        if hasattr(model, 'dropout'):
+            model.dropout.p = 0.0
+        opt = torch.optim.Adam(model.parameters())
+        opt.zero_grad()
+        logits, _ = model(ts.SparseTensor(feats.clone(), coords.clone()))
+        loss = torch.nn.functional.cross_entropy(logits, labels, ignore_index=255,
+                                                 reduction='mean')
+        loss.backward()
+        out[name + '_train_loss'] = np.float32(loss.item())
+        out[name + '_train_logits'] = logits.detach().numpy()
+        gkeys = ['stem.0.kernel', 'stage2.1.net.0.kernel', 'stage4.2.net.3.kernel',
+                 'up1.0.net.0.kernel', 'up4.1.1.net.3.kernel', 'classifier.0.weight',
+                 'stage1.0.net.1.weight']
+        named = dict(model.named_parameters())
+        out[name + '_grad_keys'] = np.array(gkeys)
+        out[name + '_grad_norms'] = np.array([named[k].grad.norm().item() for k in gkeys],
+                                             dtype=np.float64)
+        out[name + '_grad_stem'] = named['stem.0.kernel'].grad.numpy()
+        out[name + '_grad_up1dc'] = named['up1.0.net.0.kernel'].grad.numpy()[:, :8, :8].copy()
+        print(name, 'loss', loss.item(), 'logits', tuple(logits.shape))
+    np.savez_compressed(os.path.join(HERE, 'model_small.npz'), **out)
+
+
+def _stub_nuscenes(tmp):
+    d = os.path.join(tmp, 'stubs', 'nuscenes', 'utils')
+    os.makedirs(d)
+    open(os.path.join(tmp, 'stubs', 'nuscenes', '__init__.py'), 'w').close()
+    open(os.path.join(d, '__init__.py'), 'w').close()
+    with open(os.path.join(d, 'splits.py'), 'w') as f:
+        f.write('def create_splits_scenes():\n    return {"train": []}\n')
+    return os.path.join(tmp, 'stubs')
+
+
+def _synthetic_probs(rng, world, n_classes=19):
+    """Spatially coherent class probabilities: a smooth function of world position + noise,
+    so neighbouring frames mostly agree (realistic KL / entropy ranges)."""
+    w = rng.standard_normal((3, n_classes)) * 0.35
+    logit = world @ w + rng.standard_normal((world.shape[0], n_classes)) * 0.7
+    logit = logit - logit.max(1, keepdims=True)
+    p = np.exp(logit)
+    return (p / p.sum(1, keepdims=True)).astype(np.float32)
+
+
+def make_scoring():
+    from lidal_amd import synth
+    from oracle import scoring_ref
+    from sklearn.neighbors import KDTree
+    n_frames, P, nei_num, dis = 27, 400, 24, 0.1
+    frames = synth.make_sequence(n_frames, n_points=P, seed=11, step=0.02, n_beams=16, n_az=128)
+    rng = np.random.default_rng(5)
+    # thin scans would never match within 0.1 m, so half of every frame re-observes a shared
+    # static point set with small jitter (matches + near-ties around the threshold)
+    shared = frames[0]['world'][: P // 2].copy()
+    probs, worlds = [], []
+    for f in frames:
+        wc = f['world'].copy()
+        wc[: P // 2] = shared + rng.normal(0, 0.04, size=shared.shape)
+        worlds.append(wc)
+        probs.append(_synthetic_probs(np.random.default_rng(99), wc))
+    tmp = tempfile.mkdtemp()
+    stubs = _stub_nuscenes(tmp)
+    sys.path.insert(0, stubs)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import score.sv_level.LiDAL as L          # the reference file, unchanged
+    prob_files, kd_files, sv_files = [], [], []
+    for i, f in enumerate(frames):
+        pf = os.path.join(tmp, 'prob_%06d.npy' % i)
+        np.save(pf, probs[i])
+        kf = os.path.join(tmp, 'kd_%06d.pickle' % i)
+        with open(kf, 'wb') as fh:
+            pickle.dump(KDTree(worlds[i]), fh)
+        sf = os.path.join(tmp, 'sv_%06d.pickle' % i)
+        with open(sf, 'wb') as fh:
+            pickle.dump((f['sv_id'], f['sv2point']), fh)
+        prob_files.append(pf), kd_files.append(kf), sv_files.append(sf)
+    L.init_worker(False, nei_num, dis, '00', prob_files, kd_files, sv_files)
+    out = {'nei_num': nei_num, 'dis_thresh': dis,
+           'probs': np.stack(probs), 'worlds': np.stack(worlds),
+           'sv2point': np.stack([np.stack(f['sv2point']) for f in frames])}
+    ref_d, ref_e, ref_n, ref_c = [], [], [], []
+    for i in range(n_frames):
+        sv_id, d, e, n, c = L.worker_func(i)
+        od, oe, on, oc, pd, pe = scoring_ref.score_frame(i, probs, worlds, frames[i]['sv2point'],
+                                                         nei_num, dis, return_points=True)
+        assert np.array_equal(d, od) and np.array_equal(e, oe), 'oracle != reference worker_func'
+        assert np.array_equal(n, on) and np.array_equal(c, oc)
+        ref_d.append(d), ref_e.append(e), ref_n.append(n), ref_c.append(c)
+        if i == 0:
+            out['interd_points_f0'] = pd
+            out['intere_points_f0'] = pe
+    out.update(sv_interds=np.stack(ref_d), sv_interes=np.stack(ref_e),
+               sv_pnums=np.stack(ref_n), sv_centers=np.stack(ref_c))
+    np.savez_compressed(os.path.join(HERE, 'scoring_small.npz'), **out)
+    print('scoring: oracle == reference worker_func on', n_frames, 'frames;',
+          'mean interd', float(np.mean(ref_d)), 'mean intere', float(np.mean(ref_e)))
+
+
+def make_selection():
+    from lidal_amd import synth
+    from oracle import scoring_ref
+    from sklearn.neighbors import KDTree
+    seqs = ['00', '01', '02', '03', '04', '05', '06', '07', '09', '10']   # LiDAL.py:125
+    n_frames, P, n_sv = 25, 160, 20
+    tmp = tempfile.mkdtemp()
+    stubs = _stub_nuscenes(tmp)
+    base = os.path.join(tmp, 'Processing_files', 'SK')
+    rng = np.random.default_rng(3)
+    all_flags, all_probs, all_worlds, all_sv = [], [], [], []
+    gid = 0
+    for s_i, seq in enumerate(seqs):
+        frames = synth.make_sequence(n_frames, n_points=P, seed=100 + s_i, step=0.6,
+                                     n_beams=8, n_az=64, n_sv=n_sv)
+        shared = frames[0]['world'][: P // 2].copy()
+        for d in ('prob_map/SPVCNN/fr/0r', 'kdtree', 'super_voxel/KMeans', 'sv_flag/KMeans/0r'):
+            os.makedirs(os.path.join(base, d, seq))
+        for i, f in enumerate(frames):
+            wc = f['world'].copy()
+            wc[: P // 2] = shared + rng.normal(0, 0.04, size=shared.shape) + [0.6 * i, 0, 0]
+            prob = _synthetic_probs(np.random.default_rng(7 + s_i), wc)
+            flags = (rng.random(n_sv) < 0.1).astype(np.int64)
+            flags[rng.random(n_sv) < 0.1] = 2
+            sv_id = np.arange(gid, gid + n_sv, dtype=np.int64)
+            gid += n_sv
+            name = '%06d' % i
+            np.save(os.path.join(base, 'prob_map/SPVCNN/fr/0r', seq, name + '.npy'), prob)
+            with open(os.path.join(base, 'kdtree', seq, name + '.pickle'), 'wb') as fh:
+                pickle.dump(KDTree(wc), fh)
+            with open(os.path.join(base, 'super_voxel/KMeans', seq, name + '.pickle'), 'wb') as fh:
+                pickle.dump((sv_id, f['sv2point']), fh)
+            np.save(os.path.join(base, 'sv_flag/KMeans/0r', seq, name + '.npy'), flags)
+            all_flags.append(flags), all_probs.append(prob), all_worlds.append(wc)
+            all_sv.append(f['sv2point'])
+    env = dict(os.environ, PYTHONPATH=stubs + ':' + REF)
+    r = subprocess.run([sys.executable, '-m', 'score.sv_level.LiDAL', '--dataset_name', 'SK',
+                        '--model_name', 'SPVCNN', '--r_id', '1'], cwd=tmp, env=env,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    new_flags = []
+    for seq in seqs:
+        for i in range(n_frames):
+            new_flags.append(np.load(os.path.join(base, 'sv_flag/KMeans/SPVCNN/LiDAL/1r', seq,
+                                                  '%06d.npy' % i)))
+    sv_pnums = np.load(os.path.join(base, 'super_voxel/KMeans/sv_pnums.npy'))
+    sv_centers = np.load(os.path.join(base, 'super_voxel/KMeans/sv_centers.npy'))
+    # oracle: score every frame, then select
+    d_all, e_all = [], []
+    for s_i in range(len(seqs)):
+        lo = s_i * n_frames
+        pr, wo = all_probs[lo:lo + n_frames], all_worlds[lo:lo + n_frames]
+        for i in range(n_frames):
+            d, e, n, c = scoring_ref.score_frame(i, pr, wo, all_sv[lo + i], 24, 0.1)
+            d_all.append(d), e_all.append(e)
+            assert np.array_equal(n, sv_pnums[(lo + i) * n_sv:(lo + i + 1) * n_sv])
+            assert np.array_equal(c + np.float32(s_i * 1000.0),
+                                  sv_centers[(lo + i) * n_sv:(lo + i + 1) * n_sv])
+    flags_in = np.concatenate(all_flags)
+    sel = scoring_ref.select(flags_in, np.concatenate(d_all), np.concatenate(e_all), sv_pnums,
+                             sv_centers, 2349559532)
+    assert np.array_equal(sel, np.concatenate(new_flags)), 'oracle select != reference __main__'
+    np.savez_compressed(os.path.join(HERE, 'selection_small.npz'), flags_in=flags_in,
+                        sv_interds=np.concatenate(d_all), sv_interes=np.concatenate(e_all),
+                        sv_pnums=sv_pnums, sv_centers=sv_centers,
+                        flags_out=np.concatenate(new_flags), train_point_num=2349559532)
+    print('selection: oracle == reference __main__;', int((sel == 1).sum()), 'labelled,',
+          int((sel == 2).sum()), 'pseudo-labelled of', sel.size)
+
+
+if __name__ == '__main__':
+    assert os.path.isdir(REF), 'make_golden.py needs /root/reference (build container only)'
+    which = sys.argv[1:] or ['model', 'scoring', 'selection']
+    if 'model' in which:
+        make_model()
+    if 'scoring' in which:
+        make_scoring()
+    if 'selection' in which:
+        make_selection()

@@ -1,0 +1,161 @@
+/* lidal_amd.h -- C-ABI of liblidal_amd.so, the MI355X (gfx950) backend of the LiDAL sparse-voxel
+ * hot path.
+ *
+ * Every entry point replaces one function of the pybind module `torchsparse.backend`
+ * (torchsparse==1.4.0, pinned at /root/reference/docs/requirements.txt:191; not vendored in the
+ * reference) or one block of reference Python that runs on the hot path.  The "replaces" lines
+ * cite the reference call site (relative to /root/reference) that reaches it.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - the caller owns every buffer (inputs, outputs, workspace); nothing is allocated here;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and returns;
+ *     counts that the host needs are written to device memory (`*_dev`) for the caller to read;
+ *   - return value: 0 = OK, non-zero = error, message via lidal_last_error() (thread local);
+ *   - no exceptions cross the boundary, no torch types in any signature;
+ *   - dtype codes: 0 = float32, 1 = bfloat16 (features and weights; accumulation is always f32).
+ */
+#ifndef LIDAL_AMD_H
+#define LIDAL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIDAL_F32 0
+#define LIDAL_BF16 1
+
+const char* lidal_last_error(void);
+int lidal_version(void);
+
+/* ---- hashing ------------------------------------------------------------------------------ */
+/* replaces backend.hash_cuda  (F.sphash(coords): network/utils.py:17,42-47,75).
+ * coords i32 [n,4] = (x,y,z,batch) -> out i64 [n]: FNV-1a-64 over the four 32-bit words folded to
+ * 60 bits. */
+int lidal_hash(const int32_t* coords, int64_t n, int64_t* out, void* stream);
+/* replaces backend.kernel_hash_cuda  (F.sphash(coords, offsets): network/utils.py:70-74).
+ * offsets i32 [k,3]; out i64 [k,n], hash of (xyz + offset_k, batch). */
+int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t* offsets, int k,
+                      int64_t* out, void* stream);
+
+/* replaces backend.hash_query_cuda  (F.sphashquery: network/utils.py:19,48,76).
+ * Open-addressing table of 64-bit keys in HBM; value = index of the FIRST occurrence of the key
+ * (the CPU dense_hash_map::insert semantics).  Keys must be < 2^63 (sphash output is 60 bit). */
+int64_t lidal_hash_table_bytes(int64_t n_keys);
+int lidal_hash_table_build(const int64_t* keys, int64_t n, void* table, int64_t table_bytes,
+                           void* stream);
+/* out[i] = position of q[i] in the keys the table was built from, or -1. */
+int lidal_hash_table_query(const void* table, int64_t table_bytes, const int64_t* q, int64_t nq,
+                           int64_t* out, void* stream);
+
+/* ---- sorted unique / downsample ------------------------------------------------------------- */
+/* replaces torch.unique(pc_hash) in network/utils.py:18 (sorted unique of i64 keys).
+ * out [n] capacity; n_out_dev i64[1]. */
+int64_t lidal_unique_workspace_bytes(int64_t n);
+int lidal_unique_sorted_i64(const int64_t* keys, int64_t n, int64_t* out, int64_t* n_out_dev,
+                            void* ws, int64_t ws_bytes, void* stream);
+/* replaces F.spdownsample (torchsparse/nn/functional/downsample.py; reached from the four
+ * stride-2 convs, network/spvcnn.py:28,34,40,46): xyz floored to multiples of `sample_stride`
+ * (= conv stride x tensor stride), unique rows sorted by (batch,x,y,z).
+ * Requires 0 <= x,y,z < 65536 and 0 <= batch < 32768.  out i32 [n,4] capacity. */
+int64_t lidal_downsample_workspace_bytes(int64_t n);
+int lidal_downsample(const int32_t* coords, int64_t n, int sx, int sy, int sz, int32_t* out,
+                     int64_t* n_out_dev, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- kernel map (rule) building -------------------------------------------------------------- */
+/* replaces the cache-miss branch of F.conv3d (torchsparse/nn/functional/conv.py): kernel_hash +
+ * hash_query + nonzero.  `table` was built from sphash(in_coords).
+ *   nbr_out  i32 [k, n_out]     input row feeding output row j through offset k, or -1
+ *                               (in_coord = out_coord + offset_k)
+ *   nbmaps   i32 [k*n_out, 2]   capacity; rows (in_idx, out_idx) grouped by k, ascending out_idx
+ *                               -- bit-exact torchsparse order
+ *   nbsizes  i32 [k],  koff i64 [k+1] exclusive prefix of nbsizes (koff[k] = total rules). */
+int64_t lidal_kmap_workspace_bytes(int64_t n_out, int k);
+int lidal_kmap_build(const void* table, int64_t table_bytes, const int32_t* out_coords,
+                     int64_t n_out, const int32_t* offsets, int k, int32_t* nbr_out,
+                     int32_t* nbmaps, int32_t* nbsizes, int64_t* koff, void* ws, int64_t ws_bytes,
+                     void* stream);
+/* nbr_in i32 [k, n_in]: output row fed by input row i through offset k, or -1 (inverse table, used
+ * by data-gradient and transposed convolution). */
+int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr_in, int64_t n_in,
+                      void* stream);
+
+/* ---- point <-> voxel ------------------------------------------------------------------------- */
+/* replaces backend.count_cuda (F.spcount: network/utils.py:20,49). out i32 [m] (zeroed here). */
+int lidal_count(const int32_t* idx, int64_t n, int32_t* out, int64_t m, void* stream);
+/* replaces backend.voxelize_forward_cuda / voxelize_backward_cuda (F.spvoxelize:
+ * network/utils.py:22,25,56).  out[idx[i]] += feat[i] / counts[idx[i]]; f32 only. */
+int lidal_voxelize_fwd(const float* feat, const int32_t* idx, const int32_t* counts, float* out,
+                       int64_t n, int64_t m, int c, void* stream);
+int lidal_voxelize_bwd(const float* gout, const int32_t* idx, const int32_t* counts, float* gin,
+                       int64_t n, int64_t m, int c, void* stream);
+/* replaces backend.devoxelize_forward_cuda / devoxelize_backward_cuda (F.spdevoxelize:
+ * network/utils.py:83,95).  idx i32 [n,8], w f32 [n,8]; out[i] = sum_k w[i,k] feat[idx[i,k]]. */
+int lidal_devoxelize_fwd(const float* feat, const int32_t* idx, const float* w, float* out,
+                         int64_t n, int64_t m, int c, void* stream);
+int lidal_devoxelize_bwd(const float* gout, const int32_t* idx, const float* w, float* gin,
+                         int64_t n, int64_t m, int c, void* stream);
+/* replaces F.calc_ti_weights (torchsparse/nn/functional/devoxelize.py; network/utils.py:77):
+ * coords f32 [n, cstride>=3], idx i64 [8,n] -> w f32 [n,8] and idx32 i32 [n,8] (both already
+ * transposed as network/utils.py:78-79 does). */
+int lidal_ti_weights(const float* coords, int cstride, const int64_t* idx, int64_t n, float scale,
+                     float* w, int32_t* idx32, void* stream);
+
+/* ---- sparse convolution ---------------------------------------------------------------------- */
+/* Weight re-layout (+ optional cast): W [k][ci][co] -> Wt [k][co][ci]. */
+int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int wt_dtype, int k, int ci,
+                           int co, void* stream);
+/* replaces backend.convolution_forward_cuda and the data-gradient half of
+ * convolution_backward_cuda (every spnn.Conv3d.forward/backward, 49 per model pass).
+ * Output-stationary fused gather-GEMM-accumulate:
+ *     out[j, :] = sum_k  in[ nbr[kk][j], : ] * Wk[k]^T,   kk = kflip ? K-1-k : k
+ * with Wk laid out [k][co][ci] (reduction dim contiguous), nbr i32 [k, n_out] (-1 = no rule).
+ * No atomics: each output row is written exactly once => bitwise reproducible. */
+int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, void* out,
+                     int64_t n_out, int ci, int co, int k, int kflip, int dtype, void* stream);
+/* replaces the weight-gradient half of backend.convolution_backward_cuda:
+ *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
+ * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  `partial` f32 [splits][k][ca][cb] scratch;
+ * reduced in a fixed order => bitwise reproducible. */
+int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs, const int64_t* koff,
+                     int a_col, float* gw, float* partial, int splits, int k, int ca, int cb,
+                     int dtype, void* stream);
+
+/* ---- probability inference post-processing ------------------------------------------------- */
+/* replaces score/prob_inference.py:100-113: logits f32 [nv, c] of `reps` collated views,
+ * inverse i64 [reps*p] (voxel row of every point in every view) -> prob f32 [p,c] = mean over
+ * views of softmax(logits[inverse]), pred i64 [p] = argmax. */
+int lidal_view_mean_softmax(const float* logits, const int64_t* inverse, int reps, int64_t p,
+                            int c, float* prob, int64_t* pred, void* stream);
+
+/* ---- inter-frame divergence / entropy scoring ---------------------------------------------- */
+/* Uniform-grid nearest-neighbour structure over one frame's world-frame points (replaces the
+ * pickled sklearn KDTree of dataset/prepare_kdtree_sk.py:83 as used by
+ * score/sv_level/LiDAL.py:52-66).  cell = match radius.
+ *   pts f64 [p,3];  grid bytes from lidal_nn_grid_bytes(p). */
+int64_t lidal_nn_grid_bytes(int64_t p);
+int64_t lidal_nn_grid_workspace_bytes(int64_t p);
+int lidal_nn_grid_build(const double* pts, int64_t p, double cell, void* grid, int64_t grid_bytes,
+                        void* ws, int64_t ws_bytes, void* stream);
+/* replaces score/sv_level/LiDAL.py:59-81 for one query frame against `n_nei` neighbour frames
+ * (host arrays of device pointers, in the reference's neighbour order):
+ *   interd f64 [p] (mean KL over matched neighbours), intere f32 [p] (entropy of the mean
+ *   probability), map_count i32 [p] (matches). */
+int lidal_interframe_score(const double* q_pts, const float* q_prob, int64_t p, int c,
+                           const void* const* nei_grids_host, const double* const* nei_pts_host,
+                           const float* const* nei_prob_host, const int64_t* nei_p_host,
+                           int n_nei, double dis_thresh, double* interd, float* intere,
+                           int32_t* map_count, void* stream);
+/* replaces score/sv_level/LiDAL.py:91-98: per-supervoxel means over point lists given as CSR
+ * (sv_ptr i64 [s+1], sv_idx i64 [sv_ptr[s]]).  sv_interd f32 [s], sv_intere f32 [s],
+ * sv_center f32 [s,3]. */
+int lidal_supervoxel_reduce(const double* interd, const float* intere, const double* pts,
+                            const int64_t* sv_ptr, const int64_t* sv_idx, int s, float* sv_interd,
+                            float* sv_intere, float* sv_center, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDAL_AMD_H */

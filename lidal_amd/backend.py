@@ -1,0 +1,102 @@
+"""ctypes binding of liblidal_amd.so (include/lidal_amd.h) for torch device tensors.
+
+This is the only place that touches the shared library.  There is NO CPU fallback: if the
+library is missing, or a tensor is not on the GPU, the call raises.  (The CPU restatement of the
+path lives in oracle/ and is test infrastructure only.)
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblidal_amd.so')
+
+F32, BF16 = 0, 1
+_lib = None
+
+_vp, _i32, _i64, _f32, _f64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                               ctypes.c_double)
+
+# name -> (restype, argtypes): every symbol include/lidal_amd.h declares
+SIGNATURES = {
+    'lidal_last_error': (ctypes.c_char_p, []),
+    'lidal_version': (_i32, []),
+    'lidal_hash': (_i32, [_vp, _i64, _vp, _vp]),
+    'lidal_kernel_hash': (_i32, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    'lidal_hash_table_bytes': (_i64, [_i64]),
+    'lidal_hash_table_build': (_i32, [_vp, _i64, _vp, _i64, _vp]),
+    'lidal_hash_table_query': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    'lidal_unique_workspace_bytes': (_i64, [_i64]),
+    'lidal_unique_sorted_i64': (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    'lidal_downsample_workspace_bytes': (_i64, [_i64]),
+    'lidal_downsample': (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    'lidal_kmap_workspace_bytes': (_i64, [_i64, _i32]),
+    'lidal_kmap_build': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64,
+                                _vp]),
+    'lidal_kmap_invert': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp]),
+    'lidal_count': (_i32, [_vp, _i64, _vp, _i64, _vp]),
+    'lidal_voxelize_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    'lidal_voxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    'lidal_devoxelize_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    'lidal_devoxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    'lidal_ti_weights': (_i32, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp]),
+    'lidal_conv_weight_pack': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'lidal_conv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                _vp]),
+    'lidal_view_mean_softmax': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    'lidal_nn_grid_bytes': (_i64, [_i64]),
+    'lidal_nn_grid_workspace_bytes': (_i64, [_i64]),
+    'lidal_nn_grid_build': (_i32, [_vp, _i64, _f64, _vp, _i64, _vp, _i64, _vp]),
+    'lidal_interframe_score': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp,
+                                      _vp, _vp, _vp]),
+    'lidal_supervoxel_reduce': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+}
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'lidal_amd: %s is missing -- build it with `python -m lidal_amd.build` '
+                '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the .so lacks a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('lidal_amd.%s failed (%d): %s' %
+                           (what, rc, lib().lidal_last_error().decode()))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                'lidal_amd operators run on the GPU only (got a %s tensor); the CPU restatement '
+                'is oracle/ and is test infrastructure, not a fallback' % t.device)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError('lidal_amd: unsupported feature dtype %s (float32 / bfloat16 only)' % dt)

@@ -1,0 +1,505 @@
+// Sparse 3D convolution for gfx950: fused gather -> MFMA GEMM -> accumulate, output-stationary.
+//
+// Dataflow (lidal_conv_apply).  One workgroup (4 waves) owns BM = 128 consecutive OUTPUT rows and
+// a BN-wide slice of the output channels, and walks the K kernel offsets:
+//
+//   per offset k   1. the 128 entries nbr[k][r0 .. r0+127] (input row or -1) are read coalesced
+//                     and COMPACTED with a wave ballot + prefix sum into an LDS list of the
+//                     rows that have a rule  (on LiDAR surfaces ~25 % of the 27 offsets are
+//                     occupied, so dense tiles would waste ~4x of the MFMA work);
+//                  2. W[k] (reduction dim contiguous, pre-packed) is staged into LDS once for
+//                     the whole workgroup;
+//                  3. groups of 16 compacted rows x 16*NBW output channels form MFMA items that
+//                     the four waves share.  A-fragments are gathered STRAIGHT from HBM/L2 into
+//                     registers (16 B per lane, 64 B contiguous per row, no LDS round trip:
+//                     every A element is used by exactly one wave); B-fragments are
+//                     ds_read_b128 from the staged weights;  v_mfma_f32_16x16x4_f32 (exact f32)
+//                     or v_mfma_f32_16x16x32_bf16;
+//                  4. the 16x16 results are added into the f32 output tile held in LDS at the
+//                     rows the compaction recorded (rows are unique inside one offset and a
+//                     barrier separates offsets => fixed summation order).
+//   finally         the LDS tile is written to HBM once, coalesced.  No atomics anywhere, so
+//                   results are bitwise reproducible and every output byte is written once.
+//
+// The same kernel serves forward, data-gradient and transposed convolution: only the neighbour
+// table and the weight layout differ (see lidal_amd/nn/functional/conv.py).
+//
+// lidal_conv_wgrad: gw[k] = A_k^T B_k over the rule list of offset k, as a split-K MFMA GEMM
+// (workgroup = (split, k, channel tile)); gathered rows are staged through LDS (converted to
+// f32), f32 partial slabs are reduced in a fixed order by a second kernel.
+#include "common.h"
+
+using namespace lidal;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int BM = 128;          // output rows per workgroup
+constexpr int NTHREADS = 256;
+constexpr int NWAVES = 4;
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int VEC = 4;    // elements per 16-byte lane load
+  static constexpr int CH = 16;    // reduction elements consumed per lane-load round (4 lane groups)
+  typedef f32x4 frag;
+  __device__ static frag zero() { return frag{0.f, 0.f, 0.f, 0.f}; }
+  __device__ static float to_f32(float v) { return v; }
+  __device__ static float from_f32(float v) { return v; }
+};
+template <> struct DT<__bf16> {
+  static constexpr int VEC = 8;
+  static constexpr int CH = 32;
+  typedef bf16x8 frag;
+  __device__ static frag zero() {
+    frag z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+    return z;
+  }
+  __device__ static float to_f32(__bf16 v) { return (float)v; }
+  __device__ static __bf16 from_f32(float v) { return (__bf16)v; }
+};
+
+template <typename T>
+__device__ __forceinline__ typename DT<T>::frag load_frag_guarded(const T* p, int valid_elems) {
+  // valid_elems: how many of the VEC elements starting at p are inside the row
+  typedef typename DT<T>::frag frag;
+  if (valid_elems >= DT<T>::VEC) return *reinterpret_cast<const frag*>(p);
+  frag f = DT<T>::zero();
+#pragma unroll
+  for (int e = 0; e < DT<T>::VEC; ++e)
+    if (e < valid_elems) f[e] = p[e];
+  return f;
+}
+
+__device__ __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// conv_apply
+// ------------------------------------------------------------------------------------------
+// LDS layout (dynamic): [accum f32 BM x ASTRIDE][weights T BN x WSTRIDE][cidx int BM][crow int BM]
+template <typename T, int NBW, int NSPLIT, int ROW_BYTES>
+__global__ void __launch_bounds__(NTHREADS)
+conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
+                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip) {
+  constexpr int BN = 16 * NBW * NSPLIT;
+  constexpr int VEC = DT<T>::VEC;
+  constexpr int CH = DT<T>::CH;
+  constexpr int KC = ROW_BYTES / (int)sizeof(T);        // staged reduction elements per pass
+  constexpr int MAXCC = KC / CH;                         // A lane-loads per pass (4)
+  constexpr int WSTRIDE = KC + VEC;                      // +16 B pad
+  constexpr int ASTRIDE = BN + 16;
+  typedef typename DT<T>::frag frag;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* accum = reinterpret_cast<float*>(smem);
+  T* wl = reinterpret_cast<T*>(smem + sizeof(float) * BM * ASTRIDE);
+  int* cidx = reinterpret_cast<int*>(smem + sizeof(float) * BM * ASTRIDE + sizeof(T) * BN * WSTRIDE);
+  int* crow = cidx + BM;
+  __shared__ int wave_cnt[NWAVES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int row16 = lane & 15;
+  const int gsel = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  for (int i = tid; i < BM * ASTRIDE; i += NTHREADS) accum[i] = 0.f;
+
+  for (int k = 0; k < K; ++k) {
+    const int kk = kflip ? (K - 1 - k) : k;
+    // ---- 1. compaction of the rows that have a rule for this offset
+    int idx = -1;
+    if (tid < BM && r0 + tid < n_out) idx = nbr[(int64_t)kk * n_out + r0 + tid];
+    const bool keep = idx >= 0;
+    const unsigned long long m = __ballot(keep);
+    const int rank = ballot_rank(m);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();   // also: every wave is done with the previous offset's lists / weights
+    int off = 0, n_k = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) {
+      int c = wave_cnt[w];
+      if (w < wave) off += c;
+      n_k += c;
+    }
+    if (n_k == 0) { __syncthreads(); continue; }
+    if (keep) { cidx[off + rank] = idx; crow[off + rank] = tid; }
+    const int ngroups = (n_k + 15) >> 4;
+    const int nitems = ngroups * NSPLIT;
+
+    for (int c0 = 0; c0 < ci; c0 += KC) {
+      const int kc = min(KC, ci - c0);
+      // ---- 2. stage Wk[k][n0 .. n0+BN][c0 .. c0+kc] -> LDS (zero padded to a multiple of CH)
+      if (c0 > 0) __syncthreads();           // previous pass's readers are done
+      {
+        const int kc_pad = ((kc + CH - 1) / CH) * CH;
+        const int segs = kc_pad / VEC;       // 16-byte segments per row
+        const T* wsrc = wk + ((int64_t)k * co + n0) * ci + c0;
+        for (int sidx = tid; sidx < BN * segs; sidx += NTHREADS) {
+          int col = sidx / segs, sg = sidx - col * segs;
+          int x = sg * VEC;
+          frag v = DT<T>::zero();
+          if (n0 + col < co) v = load_frag_guarded<T>(wsrc + (int64_t)col * ci + x, kc - x);
+          *reinterpret_cast<frag*>(wl + col * WSTRIDE + x) = v;
+        }
+      }
+      __syncthreads();
+      // ---- 3. MFMA items
+      for (int item = wave; item < nitems; item += NWAVES) {
+        const int g = item / NSPLIT, h = item - g * NSPLIT;
+        const int p = g * 16 + row16;
+        const int src = (p < n_k) ? cidx[p] : -1;
+        frag a[MAXCC];
+#pragma unroll
+        for (int cc = 0; cc < MAXCC; ++cc) {
+          a[cc] = DT<T>::zero();
+          const int x = cc * CH + gsel * VEC;
+          if (cc * CH < kc && src >= 0 && x < kc)
+            a[cc] = load_frag_guarded<T>(in + (int64_t)src * ci + c0 + x, kc - x);
+        }
+        f32x4 acc[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* wbase = wl + ((h * NBW) * 16 + row16) * WSTRIDE + gsel * VEC;
+#pragma unroll
+        for (int cc = 0; cc < MAXCC; ++cc) {
+          if (cc * CH < kc) {
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+              frag b = *reinterpret_cast<const frag*>(wbase + nb * 16 * WSTRIDE + cc * CH);
+              mma(acc[nb], a[cc], b);
+            }
+          }
+        }
+        // ---- 4. accumulate into the LDS output tile (row = 4*gsel + r of the group)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pr = g * 16 + gsel * 4 + r;
+          if (pr < n_k) {
+            float* dst = accum + crow[pr] * ASTRIDE + (h * NBW) * 16 + row16;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) dst[nb * 16] += acc[nb][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: LDS tile -> HBM, coalesced along channels
+  __syncthreads();
+  constexpr int SEG = 4;   // channels per thread store
+  const int segs = BN / SEG;
+  for (int i = tid; i < BM * segs; i += NTHREADS) {
+    int r = i / segs, cseg = (i - r * segs) * SEG;
+    int64_t row = r0 + r;
+    if (row >= n_out) continue;
+    const float* srcp = accum + r * ASTRIDE + cseg;
+    T* dst = out + row * co + n0 + cseg;
+    if (n0 + cseg + SEG <= co) {
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{srcp[0], srcp[1], srcp[2], srcp[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < SEG; ++e) dst[e] = DT<T>::from_f32(srcp[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < SEG; ++e)
+        if (n0 + cseg + e < co) dst[e] = DT<T>::from_f32(srcp[e]);
+    }
+  }
+}
+
+template <typename T, int NBW, int NSPLIT, int ROW_BYTES>
+int launch_conv_apply(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
+                      int ci, int co, int K, int kflip, hipStream_t s) {
+  constexpr int BN = 16 * NBW * NSPLIT;
+  constexpr int KC = ROW_BYTES / (int)sizeof(T);
+  constexpr int WSTRIDE = KC + DT<T>::VEC;
+  constexpr int ASTRIDE = BN + 16;
+  const size_t lds = sizeof(float) * BM * ASTRIDE + sizeof(T) * BN * WSTRIDE + sizeof(int) * 2 * BM;
+  auto kern = conv_apply_kernel<T, NBW, NSPLIT, ROW_BYTES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
+  kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, (T*)out, n_out, ci, co, K,
+                                   kflip);
+  LIDAL_CHECK_LAUNCH("lidal_conv_apply");
+  return 0;
+}
+
+template <typename T, int ROW_BYTES>
+int dispatch_conv_tile(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
+                       int ci, int co, int K, int kflip, hipStream_t s) {
+  // BN = 16*NBW*NSPLIT output channels per workgroup; grid.y covers the rest.
+  if (co <= 32)
+    return launch_conv_apply<T, 1, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  if (co <= 64)
+    return launch_conv_apply<T, 2, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  if (co % 128 != 0 && (co % 96 == 0 || co < 128))
+    return launch_conv_apply<T, 3, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  return launch_conv_apply<T, 4, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+}
+
+template <typename T>
+int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
+                        int ci, int co, int K, int kflip, hipStream_t s) {
+  // staged reduction bytes per pass: 192 when the row is a multiple of 192 but not of 256 bytes
+  // (ci = 96 f32 -> two passes of 48; ci = 96 bf16 -> one pass), else 256.
+  const int row_bytes = ci * (int)sizeof(T);
+  if (row_bytes % 192 == 0 && row_bytes % 256 != 0)
+    return dispatch_conv_tile<T, 192>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_tile<T, 256>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight pack: W[k][ci][co] -> Wt[k][co][ci] (+cast)
+// ------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) weight_pack_kernel(const TI* __restrict__ w,
+                                                          TO* __restrict__ wt, int K, int ci,
+                                                          int co) {
+  __shared__ float tile[32][33];
+  const int k = blockIdx.z;
+  const int i0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const TI* src = w + (int64_t)k * ci * co;
+  TO* dst = wt + (int64_t)k * ci * co;
+  for (int r = ty; r < 32; r += 8) {
+    int i = i0 + r, o = o0 + tx;
+    tile[r][tx] = (i < ci && o < co) ? DT<TI>::to_f32(src[(int64_t)i * co + o]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int o = o0 + r, i = i0 + tx;
+    if (o < co && i < ci) dst[(int64_t)o * ci + i] = DT<TO>::from_f32(tile[tx][r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: gw[k][ca][cb] = sum_p a[pa(p)][:]^T b[pb(p)][:]
+// ------------------------------------------------------------------------------------------
+constexpr int BP = 32;   // rules per staging step
+
+// workgroup tile: (2*MI*16) x (2*NI*16) of gw[k]; waves as 2 x 2.
+template <typename T, int MI, int NI>
+__global__ void __launch_bounds__(NTHREADS)
+conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* __restrict__ pairs,
+                  const int64_t* __restrict__ koff, int a_col, float* __restrict__ partial,
+                  int K, int ca, int cb, int tiles_b) {
+  constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
+  constexpr int SA = TA + 4, SB = TB + 4;      // LDS row strides (floats)
+  __shared__ __attribute__((aligned(16))) float la[BP * SA];
+  __shared__ __attribute__((aligned(16))) float lb[BP * SB];
+  __shared__ int pa[BP], pb[BP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row16 = lane & 15, gsel = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int split = blockIdx.x, nsplit = gridDim.x;
+  const int k = blockIdx.y;
+  const int ta = blockIdx.z / tiles_b, tb = blockIdx.z - ta * tiles_b;
+  const int ca0 = ta * TA, cb0 = tb * TB;
+
+  const int64_t beg = koff[k], end = koff[k + 1];
+  const int64_t nk = end - beg;
+  int64_t chunk = (nk + nsplit - 1) / nsplit;
+  chunk = ((chunk + BP - 1) / BP) * BP;
+  const int64_t p_beg = beg + (int64_t)split * chunk;
+  const int64_t p_end = (p_beg + chunk < end) ? (p_beg + chunk) : end;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t p0 = p_beg; p0 < p_end; p0 += BP) {
+    __syncthreads();
+    if (tid < BP) {
+      int2 pr = (p0 + tid < p_end) ? pairs[p0 + tid] : make_int2(-1, -1);
+      pa[tid] = a_col ? pr.y : pr.x;
+      pb[tid] = a_col ? pr.x : pr.y;
+    }
+    __syncthreads();
+    // stage gathered rows as f32: 4 consecutive channels per thread per step
+    for (int i = tid; i < BP * (TA / 4); i += NTHREADS) {
+      int p = i / (TA / 4), c = (i - p * (TA / 4)) * 4;
+      int src = pa[p];
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (src >= 0) {
+        const T* ptr = a + (int64_t)src * ca + ca0 + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ca0 + c + e < ca) v[e] = DT<T>::to_f32(ptr[e]);
+      }
+      *reinterpret_cast<f32x4*>(la + p * SA + c) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    for (int i = tid; i < BP * (TB / 4); i += NTHREADS) {
+      int p = i / (TB / 4), c = (i - p * (TB / 4)) * 4;
+      int src = pb[p];
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (src >= 0) {
+        const T* ptr = b + (int64_t)src * cb + cb0 + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb0 + c + e < cb) v[e] = DT<T>::to_f32(ptr[e]);
+      }
+      *reinterpret_cast<f32x4*>(lb + p * SB + c) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < BP / 4; ++ks) {
+      const int p = ks * 4 + gsel;
+      float af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = la[p * SA + (wr * MI + mi) * 16 + row16];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = lb[p * SB + (wc * NI + ni) * 16 + row16];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  // partial[split][k][ca][cb]; D: col = lane&15, row = 4*(lane>>4) + r
+  float* dst = partial + ((int64_t)split * K + k) * ca * cb;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = ca0 + (wr * MI + mi) * 16 + gsel * 4 + r;
+        int j = cb0 + (wc * NI + ni) * 16 + row16;
+        if (i < ca && j < cb) dst[(int64_t)i * cb + j] = acc[mi][ni][r];
+      }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                           float* __restrict__ gw, int64_t n,
+                                                           int splits) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int sp = 0; sp < splits; ++sp) s += partial[(int64_t)sp * n + i];
+  gw[i] = s;
+}
+
+template <typename T, int MI, int NI>
+int launch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* koff, int a_col,
+                 float* partial, int splits, int K, int ca, int cb, hipStream_t s) {
+  constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
+  int tiles_a = (int)cdiv(ca, TA), tiles_b = (int)cdiv(cb, TB);
+  dim3 grid((unsigned)splits, (unsigned)K, (unsigned)(tiles_a * tiles_b));
+  conv_wgrad_kernel<T, MI, NI><<<grid, NTHREADS, 0, s>>>((const T*)a, (const T*)b,
+                                                         (const int2*)pairs, koff, a_col, partial,
+                                                         K, ca, cb, tiles_b);
+  LIDAL_CHECK_LAUNCH("lidal_conv_wgrad");
+  return 0;
+}
+
+static inline int pick_blocks(int c) {   // 16-wide blocks per wave along one dim (x2 waves)
+  if (c <= 32) return 1;
+  if (c <= 64) return 2;
+  if (c % 128 == 0) return 4;
+  if (c % 96 == 0 || c < 128) return 3;
+  return 4;
+}
+
+template <typename T>
+int dispatch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* koff, int a_col,
+                   float* partial, int splits, int K, int ca, int cb, hipStream_t s) {
+  int mi = pick_blocks(ca), ni = pick_blocks(cb);
+#define WG_CASE(M, N) \
+  if (mi == M && ni == N) return launch_wgrad<T, M, N>(a, b, pairs, koff, a_col, partial, splits, K, ca, cb, s);
+  WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
+  WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4)
+  WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4)
+  WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4)
+#undef WG_CASE
+  set_error("wgrad: no tile for %d x %d", ca, cb);
+  return 2;
+}
+
+}  // namespace
+
+extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int wt_dtype, int k,
+                                      int ci, int co, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (k == 0 || ci == 0 || co == 0) return 0;
+  dim3 grid((unsigned)cdiv(co, 32), (unsigned)cdiv(ci, 32), (unsigned)k);
+  if (w_dtype == LIDAL_F32 && wt_dtype == LIDAL_F32)
+    weight_pack_kernel<float, float><<<grid, 256, 0, s>>>((const float*)w, (float*)wt, k, ci, co);
+  else if (w_dtype == LIDAL_F32 && wt_dtype == LIDAL_BF16)
+    weight_pack_kernel<float, __bf16><<<grid, 256, 0, s>>>((const float*)w, (__bf16*)wt, k, ci, co);
+  else if (w_dtype == LIDAL_BF16 && wt_dtype == LIDAL_BF16)
+    weight_pack_kernel<__bf16, __bf16><<<grid, 256, 0, s>>>((const __bf16*)w, (__bf16*)wt, k, ci, co);
+  else if (w_dtype == LIDAL_BF16 && wt_dtype == LIDAL_F32)
+    weight_pack_kernel<__bf16, float><<<grid, 256, 0, s>>>((const __bf16*)w, (float*)wt, k, ci, co);
+  else {
+    set_error("weight_pack: bad dtypes %d %d", w_dtype, wt_dtype);
+    return 2;
+  }
+  LIDAL_CHECK_LAUNCH("lidal_conv_weight_pack");
+  return 0;
+}
+
+extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, void* out,
+                                int64_t n_out, int ci, int co, int k, int kflip, int dtype,
+                                void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out == 0 || co == 0) return 0;
+  LIDAL_REQUIRE(ci > 0 && k > 0, "conv_apply: bad shape ci=%d k=%d", ci, k);
+  if (dtype == LIDAL_F32) {
+    LIDAL_REQUIRE(ci % 4 == 0 && co % 4 == 0, "conv_apply f32: channels must be multiples of 4");
+    return dispatch_conv_apply<float>(in, wk, nbr, out, n_out, ci, co, k, kflip, s);
+  }
+  if (dtype == LIDAL_BF16) {
+    LIDAL_REQUIRE((ci % 8 == 0 || ci < 8) && co % 4 == 0,
+                  "conv_apply bf16: ci must be a multiple of 8 (or < 8), co a multiple of 4");
+    return dispatch_conv_apply<__bf16>(in, wk, nbr, out, n_out, ci, co, k, kflip, s);
+  }
+  set_error("conv_apply: bad dtype %d", dtype);
+  return 2;
+}
+
+extern "C" int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs,
+                                const int64_t* koff, int a_col, float* gw, float* partial,
+                                int splits, int k, int ca, int cb, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (k == 0 || ca == 0 || cb == 0) return 0;
+  LIDAL_REQUIRE(splits >= 1, "wgrad: splits must be >= 1");
+  int rc;
+  if (dtype == LIDAL_F32)
+    rc = dispatch_wgrad<float>(a, b, pairs, koff, a_col, partial, splits, k, ca, cb, s);
+  else if (dtype == LIDAL_BF16)
+    rc = dispatch_wgrad<__bf16>(a, b, pairs, koff, a_col, partial, splits, k, ca, cb, s);
+  else {
+    set_error("wgrad: bad dtype %d", dtype);
+    return 2;
+  }
+  if (rc) return rc;
+  int64_t n = (int64_t)k * ca * cb;
+  wgrad_reduce_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>(partial, gw, n, splits);
+  LIDAL_CHECK_LAUNCH("wgrad_reduce");
+  return 0;
+}

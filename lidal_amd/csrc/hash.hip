@@ -1,0 +1,112 @@
+// sphash / kernel hash / hash-table build + query for gfx950.
+//
+// HBM-bound integer work: every kernel reads the [n,4] int32 coordinate rows as one 16-byte
+// load per lane (coalesced 1 KiB per wave instruction) and writes 8-byte hashes.
+#include "common.h"
+
+using namespace lidal;
+
+__global__ void __launch_bounds__(256) hash_kernel(const int4* __restrict__ coords, int64_t n,
+                                                   int64_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int4 c = coords[i];
+    out[i] = fnv60(c.x, c.y, c.z, c.w);
+  }
+}
+
+// out [k, n]: thread per row, loops over the k offsets (held in SGPRs via uniform loads) so the
+// coordinate row is read from HBM once and each of the k output rows is written coalesced.
+__global__ void __launch_bounds__(256) kernel_hash_kernel(const int4* __restrict__ coords,
+                                                          int64_t n,
+                                                          const int* __restrict__ offsets, int k,
+                                                          int64_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int4 c = coords[i];
+    for (int kk = 0; kk < k; ++kk) {
+      int ox = offsets[kk * 3 + 0], oy = offsets[kk * 3 + 1], oz = offsets[kk * 3 + 2];
+      out[(int64_t)kk * n + i] = fnv60(c.x + ox, c.y + oy, c.z + oz, c.w);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) table_insert_kernel(const int64_t* __restrict__ keys,
+                                                           int64_t n, TableView t) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t key = (uint64_t)keys[i];
+    uint64_t s = slot_of(key, t.mask);
+    while (true) {
+      unsigned long long prev = atomicCAS(&t.keys[s], (unsigned long long)kEmptyKey,
+                                          (unsigned long long)key);
+      if (prev == kEmptyKey || prev == key) {
+        atomicMin(&t.vals[s], (int)i);   // first occurrence wins, independent of arrival order
+        break;
+      }
+      s = (s + 1) & t.mask;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) table_query_kernel(TableView t,
+                                                          const int64_t* __restrict__ q,
+                                                          int64_t nq, int64_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nq; i += stride) out[i] = (int64_t)table_lookup(t, (uint64_t)q[i]);
+}
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
+  int64_t g = cdiv(n, block);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+extern "C" int lidal_hash(const int32_t* coords, int64_t n, int64_t* out, void* stream) {
+  if (n == 0) return 0;
+  hash_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>((const int4*)coords, n, out);
+  LIDAL_CHECK_LAUNCH("lidal_hash");
+  return 0;
+}
+
+extern "C" int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t* offsets, int k,
+                                 int64_t* out, void* stream) {
+  if (n == 0 || k == 0) return 0;
+  kernel_hash_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>((const int4*)coords, n,
+                                                                    offsets, k, out);
+  LIDAL_CHECK_LAUNCH("lidal_kernel_hash");
+  return 0;
+}
+
+extern "C" int64_t lidal_hash_table_bytes(int64_t n_keys) {
+  return table_capacity(n_keys) * 12;
+}
+
+extern "C" int lidal_hash_table_build(const int64_t* keys, int64_t n, void* table,
+                                      int64_t table_bytes, void* stream) {
+  LIDAL_REQUIRE(table_bytes >= lidal_hash_table_bytes(n), "hash table too small: %lld < %lld",
+                (long long)table_bytes, (long long)lidal_hash_table_bytes(n));
+  TableView t = table_view(table, table_bytes);
+  int64_t cap = (int64_t)t.mask + 1;
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_HIP(hipMemsetAsync(t.keys, 0xFF, cap * 8, s));
+  LIDAL_HIP(hipMemsetAsync(t.vals, 0x7F, cap * 4, s));   // 0x7F7F7F7F > any index
+  if (n == 0) return 0;
+  table_insert_kernel<<<grid_for(n), 256, 0, s>>>(keys, n, t);
+  LIDAL_CHECK_LAUNCH("lidal_hash_table_build");
+  return 0;
+}
+
+extern "C" int lidal_hash_table_query(const void* table, int64_t table_bytes, const int64_t* q,
+                                      int64_t nq, int64_t* out, void* stream) {
+  if (nq == 0) return 0;
+  TableView t = table_view(table, table_bytes);
+  table_query_kernel<<<grid_for(nq), 256, 0, (hipStream_t)stream>>>(t, q, nq, out);
+  LIDAL_CHECK_LAUNCH("lidal_hash_table_query");
+  return 0;
+}

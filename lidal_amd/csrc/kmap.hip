@@ -1,0 +1,358 @@
+// Sorted-unique, coordinate downsample and kernel-map (rule) construction for gfx950.
+//
+// Everything here is order-preserving: torchsparse's rule order is (k, out_idx) ascending and
+// the output-coordinate order is the sorted order of torch.unique, so compaction is done with
+// wave ballots + prefix sums (never atomic append).  Pattern used three times below:
+//   pass 1  per-block count of kept elements           (ballot popcount)
+//   pass 2  exclusive scan of the block counts         (one workgroup)
+//   pass 3  per-block ordered compaction               (ballot rank + wave offsets in LDS)
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+using namespace lidal;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kItems = 4;                    // elements per thread
+constexpr int kTile = kBlock * kItems;       // elements per workgroup
+
+// Exclusive scan of `counts[n]` (int) -> offsets[n] (int64), total -> offsets[n].
+__global__ void __launch_bounds__(1024) scan_counts_kernel(const int* __restrict__ counts,
+                                                           int64_t n,
+                                                           int64_t* __restrict__ offsets) {
+  __shared__ int64_t wave_sum[16];
+  __shared__ int64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t base = 0; base < n; base += 1024) {
+    int64_t i = base + threadIdx.x;
+    int64_t v = (i < n) ? counts[i] : 0;
+    int64_t incl = v;                         // inclusive scan inside the wave
+    for (int d = 1; d < 64; d <<= 1) {
+      int64_t t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int64_t wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += wave_sum[w];
+    int64_t carry = carry_s;
+    if (i < n) offsets[i] = carry + wave_off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[n] = carry_s;
+}
+
+// block-level ordered rank: returns the exclusive rank of this thread's kept element among the
+// kept elements of the whole block iteration, and the iteration total through *total.
+__device__ __forceinline__ int block_rank(bool keep, int* wave_cnt /*[4] LDS*/, int* total) {
+  unsigned long long m = __ballot(keep);
+  int r = ballot_rank(m);
+  int wave = threadIdx.x >> 6;
+  if (lane_id() == 0) wave_cnt[wave] = __popcll(m);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    int c = wave_cnt[w];
+    if (w < wave) off += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return off + r;
+}
+
+// ---------------- sorted unique of u64 keys ----------------
+__global__ void __launch_bounds__(kBlock) head_count_kernel(const uint64_t* __restrict__ s,
+                                                            int64_t n, int* __restrict__ counts) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int64_t base = (int64_t)blockIdx.x * kTile;
+  int c = 0;
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    int64_t i = base + it * kBlock + threadIdx.x;
+    bool head = (i < n) && (i == 0 || s[i] != s[i - 1]);
+    c += __popcll(__ballot(head));
+  }
+  if (lane_id() == 0) atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = cnt;
+}
+
+__global__ void __launch_bounds__(kBlock) head_compact_kernel(const uint64_t* __restrict__ s,
+                                                              int64_t n,
+                                                              const int64_t* __restrict__ offsets,
+                                                              int64_t nblocks,
+                                                              int64_t* __restrict__ out,
+                                                              int64_t* __restrict__ n_out) {
+  __shared__ int wave_cnt[kBlock / 64];
+  int64_t base = (int64_t)blockIdx.x * kTile;
+  int64_t pos = offsets[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    int64_t i = base + it * kBlock + threadIdx.x;
+    uint64_t v = (i < n) ? s[i] : 0;
+    bool head = (i < n) && (i == 0 || v != s[i - 1]);
+    int tot;
+    int r = block_rank(head, wave_cnt, &tot);
+    if (head) out[pos + r] = (int64_t)v;
+    pos += tot;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = offsets[nblocks];
+}
+
+struct UniqueWs {
+  uint64_t* sorted;
+  int* counts;
+  int64_t* offsets;
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  int64_t total;
+};
+
+UniqueWs carve_unique_ws(void* ws, int64_t n) {
+  UniqueWs u;
+  int64_t nblocks = cdiv(n > 0 ? n : 1, kTile);
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_keys((void*)nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                           (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+  char* p = (char*)ws;
+  int64_t o = 0;
+  u.sorted = (uint64_t*)(p + o); o += align_up(8 * (n > 0 ? n : 1), 256);
+  u.counts = (int*)(p + o);      o += align_up(4 * nblocks, 256);
+  u.offsets = (int64_t*)(p + o); o += align_up(8 * (nblocks + 1), 256);
+  u.sort_tmp = (void*)(p + o);   o += align_up((int64_t)tmp, 256);
+  u.sort_tmp_bytes = tmp;
+  u.total = o;
+  return u;
+}
+
+int unique_sorted_u64(const uint64_t* keys, int64_t n, int64_t* out, int64_t* n_out_dev, void* ws,
+                      int64_t ws_bytes, int end_bit, hipStream_t s) {
+  if (n == 0) {
+    LIDAL_HIP(hipMemsetAsync(n_out_dev, 0, 8, s));
+    return 0;
+  }
+  UniqueWs u = carve_unique_ws(ws, n);
+  LIDAL_REQUIRE(ws_bytes >= u.total, "unique workspace too small: %lld < %lld",
+                (long long)ws_bytes, (long long)u.total);
+  size_t tmp = u.sort_tmp_bytes;
+  LIDAL_HIP(rocprim::radix_sort_keys(u.sort_tmp, tmp, keys, u.sorted, (size_t)n, 0, end_bit, s));
+  int64_t nblocks = cdiv(n, kTile);
+  head_count_kernel<<<(int)nblocks, kBlock, 0, s>>>(u.sorted, n, u.counts);
+  LIDAL_CHECK_LAUNCH("head_count");
+  scan_counts_kernel<<<1, 1024, 0, s>>>(u.counts, nblocks, u.offsets);
+  LIDAL_CHECK_LAUNCH("scan_counts");
+  head_compact_kernel<<<(int)nblocks, kBlock, 0, s>>>(u.sorted, n, u.offsets, nblocks, out,
+                                                       n_out_dev);
+  LIDAL_CHECK_LAUNCH("head_compact");
+  return 0;
+}
+
+// ---------------- downsample: pack (b,x,y,z) -> u64, unique, unpack ----------------
+__global__ void __launch_bounds__(256) pack_coords_kernel(const int4* __restrict__ coords,
+                                                          int64_t n, int sx, int sy, int sz,
+                                                          uint64_t* __restrict__ keys) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  // floor division: coordinates are non-negative on this path (checked by the caller)
+  uint64_t x = (uint64_t)((c.x / sx) * sx), y = (uint64_t)((c.y / sy) * sy),
+           z = (uint64_t)((c.z / sz) * sz), b = (uint64_t)c.w;
+  keys[i] = (b << 48) | (x << 32) | (y << 16) | z;
+}
+
+__global__ void __launch_bounds__(256) unpack_coords_kernel(const int64_t* __restrict__ keys,
+                                                            const int64_t* __restrict__ n_dev,
+                                                            int4* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n_dev) return;
+  uint64_t k = (uint64_t)keys[i];
+  int4 c;
+  c.w = (int)(k >> 48);
+  c.x = (int)((k >> 32) & 0xFFFF);
+  c.y = (int)((k >> 16) & 0xFFFF);
+  c.z = (int)(k & 0xFFFF);
+  out[i] = c;
+}
+
+// ---------------- kernel map ----------------
+// pass 1: probe.  One thread owns kItems output rows and walks all K offsets, so a coordinate
+// row is read once; nbr_out[k][j] stores are coalesced along j.
+__global__ void __launch_bounds__(kBlock) kmap_probe_kernel(TableView t,
+                                                            const int4* __restrict__ coords,
+                                                            int64_t n_out,
+                                                            const int* __restrict__ offsets, int K,
+                                                            int* __restrict__ nbr_out,
+                                                            int* __restrict__ counts,
+                                                            int64_t nblocks) {
+  extern __shared__ int cnt[];   // [K]
+  for (int k = threadIdx.x; k < K; k += kBlock) cnt[k] = 0;
+  __syncthreads();
+  int64_t base = (int64_t)blockIdx.x * kTile;
+  int4 c[kItems];
+  bool ok[kItems];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    int64_t j = base + it * kBlock + threadIdx.x;
+    ok[it] = j < n_out;
+    c[it] = ok[it] ? coords[j] : make_int4(0, 0, 0, 0);
+  }
+  for (int k = 0; k < K; ++k) {
+    int ox = offsets[k * 3 + 0], oy = offsets[k * 3 + 1], oz = offsets[k * 3 + 2];
+    int found = 0;
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      int64_t j = base + it * kBlock + threadIdx.x;
+      int r = -1;
+      if (ok[it]) {
+        r = table_lookup(t, (uint64_t)fnv60(c[it].x + ox, c[it].y + oy, c[it].z + oz, c[it].w));
+        nbr_out[(int64_t)k * n_out + j] = r;
+      }
+      found += __popcll(__ballot(r >= 0));
+    }
+    if (lane_id() == 0) atomicAdd(&cnt[k], found);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += kBlock) counts[(int64_t)k * nblocks + blockIdx.x] = cnt[k];
+}
+
+// pass 3: ordered compaction of (in_idx, out_idx) pairs, block (b, k).
+__global__ void __launch_bounds__(kBlock) kmap_compact_kernel(const int* __restrict__ nbr_out,
+                                                              int64_t n_out,
+                                                              const int64_t* __restrict__ offsets,
+                                                              int64_t nblocks,
+                                                              int2* __restrict__ nbmaps) {
+  __shared__ int wave_cnt[kBlock / 64];
+  int k = blockIdx.y;
+  int64_t base = (int64_t)blockIdx.x * kTile;
+  int64_t pos = offsets[(int64_t)k * nblocks + blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    int64_t j = base + it * kBlock + threadIdx.x;
+    int r = (j < n_out) ? nbr_out[(int64_t)k * n_out + j] : -1;
+    int tot;
+    int rank = block_rank(r >= 0, wave_cnt, &tot);
+    if (r >= 0) nbmaps[pos + rank] = make_int2(r, (int)j);
+    pos += tot;
+  }
+}
+
+__global__ void kmap_sizes_kernel(const int64_t* __restrict__ offsets, int64_t nblocks, int K,
+                                  int* __restrict__ nbsizes, int64_t* __restrict__ koff) {
+  int k = threadIdx.x;
+  if (k < K) {
+    int64_t a = offsets[(int64_t)k * nblocks], b = offsets[(int64_t)(k + 1) * nblocks];
+    nbsizes[k] = (int)(b - a);
+    koff[k] = a;
+  }
+  if (k == K) koff[K] = offsets[(int64_t)K * nblocks];
+}
+
+__global__ void __launch_bounds__(256) kmap_invert_kernel(const int* __restrict__ nbr_out,
+                                                          int64_t n_out, int K,
+                                                          int* __restrict__ nbr_in, int64_t n_in) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (j >= n_out) return;
+  int i = nbr_out[(int64_t)k * n_out + j];
+  if (i >= 0) nbr_in[(int64_t)k * n_in + i] = (int)j;
+}
+
+}  // namespace
+
+extern "C" int64_t lidal_unique_workspace_bytes(int64_t n) {
+  return carve_unique_ws(nullptr, n).total + 256;
+}
+
+extern "C" int lidal_unique_sorted_i64(const int64_t* keys, int64_t n, int64_t* out,
+                                       int64_t* n_out_dev, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+  return unique_sorted_u64((const uint64_t*)keys, n, out, n_out_dev, ws, ws_bytes, 64,
+                           (hipStream_t)stream);
+}
+
+extern "C" int lidal_downsample(const int32_t* coords, int64_t n, int sx, int sy, int sz,
+                                int32_t* out, int64_t* n_out_dev, void* ws, int64_t ws_bytes,
+                                void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(sx > 0 && sy > 0 && sz > 0, "downsample: bad stride");
+  if (n == 0) {
+    LIDAL_HIP(hipMemsetAsync(n_out_dev, 0, 8, s));
+    return 0;
+  }
+  // workspace: [packed keys 8n][unique keys 8n][unique ws]
+  int64_t kb = align_up(8 * n, 256);
+  int64_t need = 2 * kb + lidal_unique_workspace_bytes(n);
+  LIDAL_REQUIRE(ws_bytes >= need, "downsample workspace too small: %lld < %lld",
+                (long long)ws_bytes, (long long)need);
+  uint64_t* packed = (uint64_t*)ws;
+  int64_t* uniq = (int64_t*)((char*)ws + kb);
+  void* uws = (char*)ws + 2 * kb;
+  pack_coords_kernel<<<(int)cdiv(n, 256), 256, 0, s>>>((const int4*)coords, n, sx, sy, sz, packed);
+  LIDAL_CHECK_LAUNCH("pack_coords");
+  int rc = unique_sorted_u64(packed, n, uniq, n_out_dev, uws, ws_bytes - 2 * kb, 63, s);
+  if (rc) return rc;
+  unpack_coords_kernel<<<(int)cdiv(n, 256), 256, 0, s>>>(uniq, n_out_dev, (int4*)out);
+  LIDAL_CHECK_LAUNCH("unpack_coords");
+  return 0;
+}
+
+extern "C" int64_t lidal_downsample_workspace_bytes(int64_t n) {
+  return 2 * align_up(8 * (n > 0 ? n : 1), 256) + lidal_unique_workspace_bytes(n);
+}
+
+extern "C" int64_t lidal_kmap_workspace_bytes(int64_t n_out, int k) {
+  int64_t nblocks = cdiv(n_out > 0 ? n_out : 1, kTile);
+  return align_up(4 * nblocks * k, 256) + align_up(8 * (nblocks * k + 1), 256) + 256;
+}
+
+extern "C" int lidal_kmap_build(const void* table, int64_t table_bytes, const int32_t* out_coords,
+                                int64_t n_out, const int32_t* offsets, int k, int32_t* nbr_out,
+                                int32_t* nbmaps, int32_t* nbsizes, int64_t* koff, void* ws,
+                                int64_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(k > 0 && k <= 1023, "kmap: bad kernel volume %d", k);
+  if (n_out == 0) {
+    LIDAL_HIP(hipMemsetAsync(nbsizes, 0, 4 * k, s));
+    LIDAL_HIP(hipMemsetAsync(koff, 0, 8 * (k + 1), s));
+    return 0;
+  }
+  LIDAL_REQUIRE(ws_bytes >= lidal_kmap_workspace_bytes(n_out, k), "kmap workspace too small");
+  int64_t nblocks = cdiv(n_out, kTile);
+  int* counts = (int*)ws;
+  int64_t* offs = (int64_t*)((char*)ws + align_up(4 * nblocks * k, 256));
+  TableView t = table_view(table, table_bytes);
+  kmap_probe_kernel<<<(int)nblocks, kBlock, k * sizeof(int), s>>>(
+      t, (const int4*)out_coords, n_out, offsets, k, nbr_out, counts, nblocks);
+  LIDAL_CHECK_LAUNCH("kmap_probe");
+  scan_counts_kernel<<<1, 1024, 0, s>>>(counts, nblocks * k, offs);
+  LIDAL_CHECK_LAUNCH("kmap_scan");
+  kmap_compact_kernel<<<dim3((unsigned)nblocks, (unsigned)k), kBlock, 0, s>>>(
+      nbr_out, n_out, offs, nblocks, (int2*)nbmaps);
+  LIDAL_CHECK_LAUNCH("kmap_compact");
+  kmap_sizes_kernel<<<1, 1024, 0, s>>>(offs, nblocks, k, nbsizes, koff);
+  LIDAL_CHECK_LAUNCH("kmap_sizes");
+  return 0;
+}
+
+extern "C" int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr_in,
+                                 int64_t n_in, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_in > 0) LIDAL_HIP(hipMemsetAsync(nbr_in, 0xFF, 4 * n_in * k, s));
+  if (n_out == 0 || n_in == 0) return 0;
+  kmap_invert_kernel<<<dim3((unsigned)cdiv(n_out, 256), (unsigned)k), 256, 0, s>>>(
+      nbr_out, n_out, k, nbr_in, n_in);
+  LIDAL_CHECK_LAUNCH("kmap_invert");
+  return 0;
+}

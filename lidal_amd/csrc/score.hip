@@ -1,0 +1,374 @@
+// Probability-inference post-processing and LiDAL inter-frame divergence / entropy scoring
+// for gfx950.  Replaces score/prob_inference.py:100-113 and score/sv_level/LiDAL.py:59-98.
+//
+// All kernels are HBM/L2-bound gathers over [points, classes] f32 rows (76-byte rows for 19
+// classes); the arithmetic follows numpy/scipy's float widths and summation orders
+// (f32 pairwise-8 row sums, f64 KL terms rounded to f32, f64 divergence accumulator).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+using namespace lidal;
+
+namespace {
+
+constexpr int MAXC = 32;    // classes (19 SemanticKITTI, 16 nuScenes)
+
+// numpy's pairwise float32 add-reduce of n <= 128 contiguous values (n = number of classes)
+__device__ __forceinline__ float np_sum_f32(const float* a, int n) {
+  if (n < 8) {
+    float r = 0.f;
+    for (int i = 0; i < n; ++i) r = __fadd_rn(r, a[i]);
+    return r;
+  }
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
+  float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                        __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+  for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+  return res;
+}
+
+// ---------------- view-mean softmax ----------------
+__global__ void __launch_bounds__(256) view_mean_softmax_kernel(const float* __restrict__ logits,
+                                                                const int64_t* __restrict__ inverse,
+                                                                int reps, int64_t p, int c,
+                                                                float* __restrict__ prob,
+                                                                int64_t* __restrict__ pred) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  float acc[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
+  for (int v = 0; v < reps; ++v) {
+    const float* row = logits + inverse[(int64_t)v * p + i] * c;
+    float x[MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < c) { x[j] = row[j]; mx = fmaxf(mx, x[j]); }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < c) { x[j] = expf(x[j] - mx); s += x[j]; }
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < c) acc[j] = (v == 0) ? (x[j] / s) : __fadd_rn(acc[j], x[j] / s);
+  }
+  float best = -INFINITY;
+  int arg = 0;
+  const float inv = (float)reps;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j)
+    if (j < c) {
+      float m = acc[j] / inv;
+      prob[i * c + j] = m;
+      if (m > best) { best = m; arg = j; }
+    }
+  pred[i] = arg;
+}
+
+// ---------------- uniform grid for radius-limited nearest neighbour ----------------
+// grid buffer: [header 64 B][table 12*cap][sorted_keys 8*p][sorted_idx 4*p]
+struct GridHeader {
+  int64_t p;
+  int64_t cap;
+  double cell;
+  double inv_cell_unused;
+};
+
+struct GridView {
+  TableView t;
+  const uint64_t* keys;
+  const int* idx;
+  int64_t p;
+  double cell;
+};
+
+constexpr int64_t kBias = 1 << 20;
+
+__device__ __forceinline__ uint64_t cell_key(int64_t ix, int64_t iy, int64_t iz) {
+  return ((uint64_t)(ix + kBias) << 42) | ((uint64_t)(iy + kBias) << 21) | (uint64_t)(iz + kBias);
+}
+
+static inline int64_t grid_cap(int64_t p) { return table_capacity(p); }
+
+static inline GridView grid_view(const void* grid, int64_t p, int64_t cap, double cell) {
+  GridView g;
+  char* base = (char*)grid + 64;
+  g.t.keys = (unsigned long long*)base;
+  g.t.vals = (int*)(base + cap * 8);
+  g.t.mask = (uint64_t)cap - 1;
+  g.keys = (const uint64_t*)(base + cap * 12);
+  g.idx = (const int*)(base + cap * 12 + align_up(8 * p, 256));
+  g.p = p;
+  g.cell = cell;
+  return g;
+}
+
+__global__ void __launch_bounds__(256) grid_keys_kernel(const double* __restrict__ pts, int64_t p,
+                                                        double cell, uint64_t* __restrict__ keys,
+                                                        int* __restrict__ idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  int64_t ix = (int64_t)floor(pts[i * 3 + 0] / cell), iy = (int64_t)floor(pts[i * 3 + 1] / cell),
+          iz = (int64_t)floor(pts[i * 3 + 2] / cell);
+  keys[i] = cell_key(ix, iy, iz);
+  idx[i] = (int)i;
+}
+
+__global__ void __launch_bounds__(256) grid_heads_kernel(const uint64_t* __restrict__ skeys,
+                                                         int64_t p, TableView t) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  uint64_t key = skeys[i];
+  if (i > 0 && skeys[i - 1] == key) return;
+  uint64_t s = slot_of(key, t.mask);
+  while (true) {       // cell keys are unique among heads
+    unsigned long long prev = atomicCAS(&t.keys[s], (unsigned long long)kEmptyKey,
+                                        (unsigned long long)key);
+    if (prev == kEmptyKey) { t.vals[s] = (int)i; break; }
+    s = (s + 1) & t.mask;
+  }
+}
+
+// nearest point of the grid's frame within the 27 cells around q; returns index or -1, *d2out
+__device__ __forceinline__ int grid_nearest(const GridView& g, const double* __restrict__ npts,
+                                            double qx, double qy, double qz, double* d2out) {
+  int64_t cx = (int64_t)floor(qx / g.cell), cy = (int64_t)floor(qy / g.cell),
+          cz = (int64_t)floor(qz / g.cell);
+  double best = INFINITY;
+  int arg = -1;
+  for (int dx = -1; dx <= 1; ++dx)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dz = -1; dz <= 1; ++dz) {
+        uint64_t key = cell_key(cx + dx, cy + dy, cz + dz);
+        int start = table_lookup(g.t, key);
+        if (start < 0) continue;
+        for (int64_t s = start; s < g.p && g.keys[s] == key; ++s) {
+          int j = g.idx[s];
+          double ex = npts[(int64_t)j * 3 + 0] - qx, ey = npts[(int64_t)j * 3 + 1] - qy,
+                 ez = npts[(int64_t)j * 3 + 2] - qz;
+          double d2 = __dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez));
+          if (d2 < best || (d2 == best && j < arg)) { best = d2; arg = j; }
+        }
+      }
+  *d2out = best;
+  return arg;
+}
+
+constexpr int MAXNEI = 32;
+struct NeiArgs {
+  const void* grid[MAXNEI];
+  const double* pts[MAXNEI];
+  const float* prob[MAXNEI];
+  int64_t p[MAXNEI];
+  int64_t cap[MAXNEI];
+  int n;
+};
+
+__global__ void __launch_bounds__(256)
+interframe_kernel(const double* __restrict__ q_pts, const float* __restrict__ q_prob, int64_t p,
+                  int c, NeiArgs nei, double dis_thresh, double* __restrict__ interd,
+                  float* __restrict__ intere, int* __restrict__ map_count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  const double qx = q_pts[i * 3 + 0], qy = q_pts[i * 3 + 1], qz = q_pts[i * 3 + 2];
+  float q[MAXC], sum[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    q[j] = (j < c) ? q_prob[i * c + j] : 0.f;
+    sum[j] = q[j];
+  }
+  const float eps = 0.00001f;
+  double div = 0.0;
+  int cnt = 0;
+  for (int n = 0; n < nei.n; ++n) {
+    GridView g;
+    {
+      char* base = (char*)nei.grid[n] + 64;
+      g.t.keys = (unsigned long long*)base;
+      g.t.vals = (int*)(base + nei.cap[n] * 8);
+      g.t.mask = (uint64_t)nei.cap[n] - 1;
+      g.keys = (const uint64_t*)(base + nei.cap[n] * 12);
+      g.idx = (const int*)(base + nei.cap[n] * 12 + ((8 * nei.p[n] + 255) / 256) * 256);
+      g.p = nei.p[n];
+      g.cell = dis_thresh;
+    }
+    double d2;
+    int j = grid_nearest(g, nei.pts[n], qx, qy, qz, &d2);
+    if (j < 0 || !(sqrt(d2) <= dis_thresh)) continue;
+    const float* np = nei.prob[n] + (int64_t)j * c;
+    float term[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k)
+      if (k < c) {
+        float nv = np[k];
+        sum[k] = __fadd_rn(sum[k], nv);
+        double x = (double)__fadd_rn(q[k], eps), y = (double)__fadd_rn(nv, eps);
+        // scipy.special.kl_div(x, y) = x log(x/y) - x + y  (x, y > 0 here), f32 result
+        term[k] = (float)(x * log(x / y) - x + y);
+      }
+    div += (double)np_sum_f32(term, c);
+    cnt += 1;
+  }
+  // sum_prob /= map_count (f64 divide, f32 store); entropy = scipy.stats.entropy(sum_prob)
+  float pk[MAXC];
+  const double mc = (double)(cnt + 1);
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k)
+    if (k < c) pk[k] = (float)((double)sum[k] / mc);
+  float tot = np_sum_f32(pk, c);
+  float ent[MAXC];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k)
+    if (k < c) {
+      float v = pk[k] / tot;
+      ent[k] = (v > 0.f) ? (float)(-(double)v * log((double)v)) : 0.f;
+    }
+  intere[i] = np_sum_f32(ent, c);
+  interd[i] = (cnt > 0) ? div / (double)cnt : div;
+  map_count[i] = cnt;
+}
+
+// ---------------- per-supervoxel means ----------------
+__global__ void __launch_bounds__(256)
+supervoxel_reduce_kernel(const double* __restrict__ interd, const float* __restrict__ intere,
+                         const double* __restrict__ pts, const int64_t* __restrict__ sv_ptr,
+                         const int64_t* __restrict__ sv_idx, float* __restrict__ sv_interd,
+                         float* __restrict__ sv_intere, float* __restrict__ sv_center) {
+  __shared__ double red[5][256];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int64_t beg = sv_ptr[s], end = sv_ptr[s + 1];
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int64_t t = beg + tid; t < end; t += 256) {
+    int64_t i = sv_idx[t];
+    a[0] += interd[i];
+    a[1] += (double)intere[i];
+    a[2] += pts[i * 3 + 0];
+    a[3] += pts[i * 3 + 1];
+    a[4] += pts[i * 3 + 2];
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) red[k][tid] = a[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double n = (double)(end - beg);
+    sv_interd[s] = (float)(red[0][0] / n);
+    sv_intere[s] = (float)(red[1][0] / n);
+    sv_center[s * 3 + 0] = (float)(red[2][0] / n);
+    sv_center[s * 3 + 1] = (float)(red[3][0] / n);
+    sv_center[s * 3 + 2] = (float)(red[4][0] / n);
+  }
+}
+
+size_t sort_pairs_tmp_bytes(int64_t p) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const uint64_t*)nullptr,
+                                  (uint64_t*)nullptr, (const int*)nullptr, (int*)nullptr,
+                                  (size_t)(p > 0 ? p : 1), 0, 63, (hipStream_t)0);
+  return tmp;
+}
+
+}  // namespace
+
+extern "C" int lidal_view_mean_softmax(const float* logits, const int64_t* inverse, int reps,
+                                       int64_t p, int c, float* prob, int64_t* pred,
+                                       void* stream) {
+  LIDAL_REQUIRE(c > 0 && c <= MAXC, "view_mean_softmax: classes must be in 1..%d", MAXC);
+  LIDAL_REQUIRE(reps > 0, "view_mean_softmax: reps must be positive");
+  if (p == 0) return 0;
+  view_mean_softmax_kernel<<<(unsigned)cdiv(p, 256), 256, 0, (hipStream_t)stream>>>(
+      logits, inverse, reps, p, c, prob, pred);
+  LIDAL_CHECK_LAUNCH("lidal_view_mean_softmax");
+  return 0;
+}
+
+extern "C" int64_t lidal_nn_grid_bytes(int64_t p) {
+  int64_t q = p > 0 ? p : 1;
+  return 64 + grid_cap(q) * 12 + align_up(8 * q, 256) + align_up(4 * q, 256);
+}
+
+extern "C" int64_t lidal_nn_grid_workspace_bytes(int64_t p) {
+  int64_t q = p > 0 ? p : 1;
+  return align_up(8 * q, 256) + align_up(4 * q, 256) + align_up((int64_t)sort_pairs_tmp_bytes(q), 256);
+}
+
+extern "C" int lidal_nn_grid_build(const double* pts, int64_t p, double cell, void* grid,
+                                   int64_t grid_bytes, void* ws, int64_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(cell > 0, "nn_grid_build: cell must be positive");
+  LIDAL_REQUIRE(grid_bytes >= lidal_nn_grid_bytes(p), "nn grid buffer too small");
+  LIDAL_REQUIRE(ws_bytes >= lidal_nn_grid_workspace_bytes(p), "nn grid workspace too small");
+  int64_t q = p > 0 ? p : 1;
+  int64_t cap = grid_cap(q);
+  char* base = (char*)grid + 64;
+  LIDAL_HIP(hipMemsetAsync(base, 0xFF, cap * 8, s));
+  LIDAL_HIP(hipMemsetAsync(base + cap * 8, 0xFF, cap * 4, s));
+  if (p == 0) return 0;
+  uint64_t* keys = (uint64_t*)ws;
+  int* idx = (int*)((char*)ws + align_up(8 * q, 256));
+  void* tmp = (char*)ws + align_up(8 * q, 256) + align_up(4 * q, 256);
+  size_t tmp_bytes = sort_pairs_tmp_bytes(q);
+  uint64_t* skeys = (uint64_t*)(base + cap * 12);
+  int* sidx = (int*)(base + cap * 12 + align_up(8 * q, 256));
+  grid_keys_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(pts, p, cell, keys, idx);
+  LIDAL_CHECK_LAUNCH("grid_keys");
+  LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, idx, sidx, (size_t)p, 0, 63, s));
+  TableView t;
+  t.keys = (unsigned long long*)base;
+  t.vals = (int*)(base + cap * 8);
+  t.mask = (uint64_t)cap - 1;
+  grid_heads_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(skeys, p, t);
+  LIDAL_CHECK_LAUNCH("grid_heads");
+  return 0;
+}
+
+extern "C" int lidal_interframe_score(const double* q_pts, const float* q_prob, int64_t p, int c,
+                                      const void* const* nei_grids_host,
+                                      const double* const* nei_pts_host,
+                                      const float* const* nei_prob_host, const int64_t* nei_p_host,
+                                      int n_nei, double dis_thresh, double* interd, float* intere,
+                                      int32_t* map_count, void* stream) {
+  LIDAL_REQUIRE(c > 0 && c <= MAXC, "interframe_score: classes must be in 1..%d", MAXC);
+  LIDAL_REQUIRE(n_nei >= 0 && n_nei <= MAXNEI, "interframe_score: at most %d neighbours", MAXNEI);
+  if (p == 0) return 0;
+  NeiArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = n_nei;
+  for (int n = 0; n < n_nei; ++n) {
+    a.grid[n] = nei_grids_host[n];
+    a.pts[n] = nei_pts_host[n];
+    a.prob[n] = nei_prob_host[n];
+    a.p[n] = nei_p_host[n];
+    a.cap[n] = grid_cap(nei_p_host[n] > 0 ? nei_p_host[n] : 1);
+  }
+  interframe_kernel<<<(unsigned)cdiv(p, 256), 256, 0, (hipStream_t)stream>>>(
+      q_pts, q_prob, p, c, a, dis_thresh, interd, intere, map_count);
+  LIDAL_CHECK_LAUNCH("lidal_interframe_score");
+  return 0;
+}
+
+extern "C" int lidal_supervoxel_reduce(const double* interd, const float* intere,
+                                       const double* pts, const int64_t* sv_ptr,
+                                       const int64_t* sv_idx, int s, float* sv_interd,
+                                       float* sv_intere, float* sv_center, void* stream) {
+  if (s == 0) return 0;
+  supervoxel_reduce_kernel<<<(unsigned)s, 256, 0, (hipStream_t)stream>>>(
+      interd, intere, pts, sv_ptr, sv_idx, sv_interd, sv_intere, sv_center);
+  LIDAL_CHECK_LAUNCH("lidal_supervoxel_reduce");
+  return 0;
+}

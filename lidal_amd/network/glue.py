@@ -1,0 +1,69 @@
+"""Point <-> voxel exchange of SPVCNN (counterparts of /root/reference/network/utils.py:13-102),
+composed from the HIP operators.  Results (indices, weights, features) follow the reference
+expression by expression; the caches live on the PointTensor exactly as upstream keeps them so
+the stride-1 tables built after the stem are re-used by the last up-stage.
+"""
+import torch
+
+from .. import PointTensor, SparseTensor
+from ..nn import functional as F
+from ..nn.utils import get_kernel_offsets
+
+__all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point']
+
+
+def _floor_to_stride(z, s):
+    """(floor(xyz / s).int() * s, batch.int()) as one int32 [N,4] tensor (utils.py:44-47,72-75)."""
+    xyz = torch.floor(z.C[:, :3] / s).int() * s
+    return torch.cat([xyz, z.C[:, -1].int().view(-1, 1)], 1)
+
+
+def initial_voxelize(z, init_res, after_res):
+    """utils.py:13-33: re-voxelise the points at `after_res`; the voxel order is the SORTED order
+    of the distinct 60-bit coordinate hashes (torch.unique at :18)."""
+    new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
+    floored = torch.floor(new_float_coord)
+    pc_hash = F.sphash(floored.int())
+    sparse_hash = F.unique_sorted(pc_hash)
+    idx_query = F.sphashquery(pc_hash, sparse_hash)
+    counts = F.spcount(idx_query.int(), len(sparse_hash))
+    inserted_coords = torch.round(F.spvoxelize(floored, idx_query, counts)).int()
+    inserted_feat = F.spvoxelize(z.F, idx_query, counts)
+    new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
+    new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
+    z.additional_features['idx_query'][1] = idx_query
+    z.additional_features['counts'][1] = counts
+    z.C = new_float_coord
+    return new_tensor
+
+
+def point_to_voxel(x, z):
+    """utils.py:38-61: mean of the point features falling into each voxel of x."""
+    cache_i, cache_c = z.additional_features['idx_query'], z.additional_features['counts']
+    if cache_i.get(x.s) is None:
+        pc_hash = F.sphash(_floor_to_stride(z, x.s[0]))
+        idx_query = F.sphashquery(pc_hash, F.sphash(x.C))
+        cache_i[x.s] = idx_query
+        cache_c[x.s] = F.spcount(idx_query.int(), x.C.shape[0])
+    new_tensor = SparseTensor(F.spvoxelize(z.F, cache_i[x.s], cache_c[x.s]), x.C, x.s)
+    new_tensor.cmaps = x.cmaps
+    new_tensor.kmaps = x.kmaps
+    return new_tensor
+
+
+def voxel_to_point(x, z, nearest=False):
+    """utils.py:66-102: trilinear interpolation of the 8 surrounding voxels of x at each point."""
+    if z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
+        off = get_kernel_offsets(2, x.s, 1, device=z.F.device)
+        old_hash = F.sphash(_floor_to_stride(z, x.s[0]), off)          # [8, N]
+        idx_query = F.sphashquery(old_hash, F.sphash(x.C.to(z.F.device)))
+        weights, idx_query = F.ti_weights_and_index(z.C, idx_query, scale=x.s[0])   # [N,8] both
+        if nearest:
+            weights[:, 1:] = 0.
+            idx_query[:, 1:] = -1
+        z.idx_query[x.s] = idx_query
+        z.weights[x.s] = weights
+    new_feat = F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s])
+    new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+    new_tensor.additional_features = z.additional_features
+    return new_tensor

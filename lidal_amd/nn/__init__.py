@@ -1,0 +1,72 @@
+"""torchsparse.nn modules used by the reference (network/utils.py:109-117, network/spvcnn.py:21-25):
+Conv3d (parameter `kernel` [K, Cin, Cout], the checkpoint compatibility surface), BatchNorm
+(an nn.BatchNorm1d over .feats), ReLU."""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..tensor import SparseTensor
+from ..utils import make_ntuple
+from . import functional, utils
+from .functional import conv3d
+
+__all__ = ['Conv3d', 'BatchNorm', 'ReLU', 'functional', 'utils']
+
+
+def fapply(input, fn, *args, **kwargs):
+    out = SparseTensor(fn(input.feats, *args, **kwargs), input.coords, input.stride)
+    out.cmaps = input.cmaps
+    out.kmaps = input.kmaps
+    return out
+
+
+class Conv3d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1,
+                 bias=False, transposed=False):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = make_ntuple(kernel_size, ndim=3)
+        self.stride = make_ntuple(stride, ndim=3)
+        self.dilation = dilation
+        self.transposed = transposed
+        self.kernel_volume = int(np.prod(self.kernel_size))
+        shape = ((self.kernel_volume, in_channels, out_channels) if self.kernel_volume > 1
+                 else (in_channels, out_channels))
+        self.kernel = nn.Parameter(torch.zeros(*shape))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def extra_repr(self):
+        s = '{in_channels}, {out_channels}, kernel_size={kernel_size}'
+        if self.stride != (1,) * 3:
+            s += ', stride={stride}'
+        if self.transposed:
+            s += ', transposed=True'
+        return s.format(**self.__dict__)
+
+    def reset_parameters(self):
+        fan = (self.out_channels if self.transposed else self.in_channels) * self.kernel_volume
+        std = 1 / math.sqrt(fan)
+        self.kernel.data.uniform_(-std, std)
+        if self.bias is not None:
+            self.bias.data.uniform_(-std, std)
+
+    def forward(self, input):
+        return conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
+                      stride=self.stride, dilation=self.dilation, transposed=self.transposed)
+
+
+class BatchNorm(nn.BatchNorm1d):
+    def forward(self, input):
+        return fapply(input, super().forward)
+
+
+class ReLU(nn.ReLU):
+    def forward(self, input):
+        return fapply(input, super().forward)

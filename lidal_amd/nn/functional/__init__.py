@@ -1,0 +1,13 @@
+"""torchsparse.nn.functional surface used by the reference (network/utils.py:2):
+sphash, sphashquery, spcount, spvoxelize, spdevoxelize, calc_ti_weights, spdownsample, conv3d."""
+from .conv import KernelMap, build_kernel_map, conv3d
+from .count import spcount
+from .devoxelize import calc_ti_weights, spdevoxelize, ti_weights_and_index
+from .downsample import spdownsample, unique_sorted
+from .hash import sphash
+from .query import HashTable, sphashquery
+from .voxelize import spvoxelize
+
+__all__ = ['sphash', 'sphashquery', 'HashTable', 'spcount', 'spvoxelize', 'spdevoxelize',
+           'calc_ti_weights', 'ti_weights_and_index', 'spdownsample', 'unique_sorted', 'conv3d',
+           'KernelMap', 'build_kernel_map']

@@ -1,0 +1,211 @@
+"""F.conv3d (torchsparse/nn/functional/conv.py v1.4.0) on the HIP backend.
+
+Reached from every spnn.Conv3d.forward (network/utils.py:110-114,129-133,147-155,163-164;
+network/spvcnn.py:22,24).  Three cases, as upstream:
+  * 1x1x1 stride 1          -> feats @ weight (dense library GEMM, as upstream)
+  * regular / strided       -> kernel map looked up in input.kmaps, built on a miss
+  * transposed              -> re-uses the map of the matching strided conv with roles swapped
+
+KernelMap holds what torchsparse keeps ([nbmaps, nbsizes, (n_in, n_out)], same order and
+values) plus the neighbour tables the output-stationary kernel consumes:
+  nbr_out [K, n_out]  input row feeding output row j through offset k (-1: none)
+  nbr_in  [K, n_in]   output row fed by input row i through offset k (built lazily)
+"""
+import torch
+from torch.autograd import Function
+
+from ... import backend as B
+from ...tensor import SparseTensor
+from ...utils import make_ntuple
+from ..utils import get_kernel_offsets
+from .downsample import spdownsample
+from .hash import sphash
+from .query import HashTable
+
+__all__ = ['conv3d', 'KernelMap', 'build_kernel_map']
+
+
+class KernelMap:
+    def __init__(self, nbmaps_cap, nbsizes, koff, nbr_out, sizes, volume, symmetric):
+        self._nbmaps_cap = nbmaps_cap        # i32 [K*n_out, 2] capacity buffer
+        self.nbsizes = nbsizes               # i32 [K] (device)
+        self.koff = koff                     # i64 [K+1] (device), koff[K] = total rules
+        self.nbr_out = nbr_out               # i32 [K, n_out]
+        self.sizes = sizes                   # (n_in, n_out)
+        self.volume = volume
+        self.symmetric = symmetric           # odd kernel, stride 1: nbr_in[k] == nbr_out[K-1-k]
+        self._nbr_in = None
+        self._total = None
+
+    @property
+    def total(self):
+        if self._total is None:
+            self._total = int(self.koff[-1].item())
+        return self._total
+
+    @property
+    def nbmaps(self):
+        """i32 [M, 2] = (in_idx, out_idx), grouped by offset, ascending out_idx (torchsparse)."""
+        return self._nbmaps_cap[:self.total]
+
+    @property
+    def nbr_in(self):
+        if self._nbr_in is None:
+            n_in, n_out = self.sizes
+            t = torch.empty((self.volume, n_in), dtype=torch.int, device=self.nbr_out.device)
+            B.check(B.lib().lidal_kmap_invert(B.ptr(self.nbr_out), n_out, self.volume, B.ptr(t),
+                                              n_in, B.stream()), 'kmap_invert')
+            self._nbr_in = t
+        return self._nbr_in
+
+    def __getitem__(self, i):                # torchsparse's [nbmaps, nbsizes, sizes] list view
+        return (self.nbmaps, self.nbsizes, self.sizes)[i]
+
+
+def build_kernel_map(coords, in_stride, kernel_size, stride):
+    """Cache-miss branch of upstream conv3d.  Returns (KernelMap, out_coords)."""
+    B.require_gpu(coords)
+    assert coords.dtype == torch.int
+    coords = coords.contiguous()
+    dev = coords.device
+    offsets = get_kernel_offsets(kernel_size, stride=in_stride, device=dev)
+    volume = offsets.shape[0]
+    table = HashTable(sphash(coords))
+    out_coords = coords
+    if any(s > 1 for s in stride):
+        out_coords = spdownsample(coords, stride, kernel_size, in_stride)
+    n_in, n_out = coords.shape[0], out_coords.shape[0]
+    nbr_out = torch.empty((volume, n_out), dtype=torch.int, device=dev)
+    nbmaps = torch.empty((volume * n_out, 2), dtype=torch.int, device=dev)
+    nbsizes = torch.empty(volume, dtype=torch.int, device=dev)
+    koff = torch.empty(volume + 1, dtype=torch.int64, device=dev)
+    ws_bytes = B.lib().lidal_kmap_workspace_bytes(n_out, volume)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    B.check(B.lib().lidal_kmap_build(B.ptr(table.buf), table.nbytes, B.ptr(out_coords), n_out,
+                                     B.ptr(offsets), volume, B.ptr(nbr_out), B.ptr(nbmaps),
+                                     B.ptr(nbsizes), B.ptr(koff), B.ptr(ws), ws_bytes,
+                                     B.stream()), 'kmap_build')
+    symmetric = (volume % 2 == 1) and all(s == 1 for s in stride)
+    return KernelMap(nbmaps, nbsizes, koff, nbr_out, (n_in, n_out), volume, symmetric), out_coords
+
+
+def _pack_weight(weight, dtype):
+    """[K, ci, co] (any float dtype) -> [K, co, ci] in `dtype` (reduction dim contiguous)."""
+    k, ci, co = weight.shape
+    w = weight.detach().contiguous()
+    wt = torch.empty((k, co, ci), dtype=dtype, device=w.device)
+    B.check(B.lib().lidal_conv_weight_pack(B.ptr(w), B.dtype_code(w.dtype), B.ptr(wt),
+                                           B.dtype_code(dtype), k, ci, co, B.stream()),
+            'conv_weight_pack')
+    return wt
+
+
+def _apply(feats, wk, table, n_out, kflip):
+    """out[j] = sum_k feats[table[kk][j]] @ wk[k]^T with wk [K, co, ci]."""
+    k, co, ci = wk.shape
+    out = torch.empty((n_out, co), dtype=feats.dtype, device=feats.device)
+    B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(table), B.ptr(out), n_out, ci,
+                                     co, k, int(kflip), B.dtype_code(feats.dtype), B.stream()),
+            'conv_apply')
+    return out
+
+
+def _wgrad_splits(total_rules, volume, ca, cb):
+    """Enough (split, k, tile) workgroups to cover the 256 CUs a few times over."""
+    def tile(c):
+        return 32 if c <= 32 else 64 if c <= 64 else 128 if c % 128 == 0 else 96 if (c % 96 == 0 or c < 128) else 128
+    tiles = -(-ca // tile(ca)) * -(-cb // tile(cb))
+    per_k = max(1, total_rules // max(volume, 1))
+    want = max(1, 2048 // (volume * tiles))
+    return int(max(1, min(want, per_k // 64 + 1, 64)))
+
+
+class ConvolutionFunction(Function):
+    @staticmethod
+    def forward(ctx, feats, weight, kmap, transposed):
+        B.require_gpu(feats, weight)
+        cdtype = torch.bfloat16 if torch.is_autocast_enabled() else feats.dtype
+        if cdtype not in (torch.float32, torch.bfloat16):
+            cdtype = torch.float32
+        x = feats.contiguous().to(cdtype)
+        n_in, n_out = kmap.sizes
+        if not transposed:
+            table, rows = kmap.nbr_out, n_out
+        else:
+            table, rows = kmap.nbr_in, n_in
+        out = _apply(x, _pack_weight(weight, cdtype), table, rows, 0)
+        ctx.kmap = kmap
+        ctx.transposed = transposed
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, weight = ctx.saved_tensors
+        kmap, transposed = ctx.kmap, ctx.transposed
+        g = grad_output.contiguous().to(x.dtype)
+        n_in, n_out = kmap.sizes
+        grad_in = grad_w = None
+        if ctx.needs_input_grad[0]:
+            # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci, reduction over co, and
+            # weight [K, ci, co] already has the reduction dim contiguous.
+            wk = weight.detach().contiguous().to(x.dtype)
+            if not transposed:
+                if kmap.symmetric:
+                    grad_in = _apply(g, wk, kmap.nbr_out, n_in, 1)
+                else:
+                    grad_in = _apply(g, wk, kmap.nbr_in, n_in, 0)
+            else:
+                grad_in = _apply(g, wk, kmap.nbr_out, n_out, 0)
+        if ctx.needs_input_grad[1]:
+            k, ci, co = weight.shape
+            splits = _wgrad_splits(kmap.volume * max(n_out, 1) // 4, k, ci, co)
+            gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
+            partial = torch.empty((splits, k, ci, co), dtype=torch.float32, device=x.device)
+            B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), B.ptr(kmap._nbmaps_cap),
+                                             B.ptr(kmap.koff), 1 if transposed else 0, B.ptr(gw),
+                                             B.ptr(partial), splits, k, ci, co,
+                                             B.dtype_code(x.dtype), B.stream()), 'conv_wgrad')
+            grad_w = gw.to(weight.dtype)
+        return grad_in, grad_w, None, None
+
+
+def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False):
+    feats, coords = input.feats, input.coords
+    kernel_size = make_ntuple(kernel_size, ndim=3)
+    stride = make_ntuple(stride, ndim=3)
+    dilation = make_ntuple(dilation, ndim=3)
+
+    if kernel_size == (1, 1, 1) and stride == (1, 1, 1) and dilation == (1, 1, 1):
+        B.require_gpu(feats)
+        feats = feats.matmul(weight)
+        if bias is not None:
+            feats = feats + bias
+        output = SparseTensor(feats, coords, input.stride)
+    elif not transposed:
+        if dilation != (1, 1, 1):
+            raise NotImplementedError('dilated sparse conv is not on the LiDAL path')
+        key = (input.stride, kernel_size, stride, dilation)
+        kmap = input.kmaps.get(key)
+        out_stride = tuple(input.stride[k] * stride[k] for k in range(3))
+        if kmap is None:
+            kmap, out_coords = build_kernel_map(coords, input.stride, kernel_size, stride)
+            input.kmaps[key] = kmap
+            if any(s > 1 for s in stride):
+                input.cmaps.setdefault(out_stride, out_coords)
+        out_coords = coords if all(s == 1 for s in stride) else input.cmaps[out_stride]
+        feats = ConvolutionFunction.apply(feats, weight, kmap, False)
+        if bias is not None:
+            feats = feats + bias
+        output = SparseTensor(feats, out_coords, out_stride)
+    else:
+        tensor_stride = tuple(input.stride[k] // stride[k] for k in range(3))
+        kmap = input.kmaps[(tensor_stride, kernel_size, stride, dilation)]
+        feats = ConvolutionFunction.apply(feats, weight, kmap, True)
+        if bias is not None:
+            feats = feats + bias
+        output = SparseTensor(feats, input.cmaps[tensor_stride], tensor_stride)
+    output.cmaps = input.cmaps
+    output.cmaps.setdefault(output.stride, output.coords)
+    output.kmaps = input.kmaps
+    return output

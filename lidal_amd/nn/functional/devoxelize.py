@@ -1,0 +1,62 @@
+"""F.spdevoxelize and F.calc_ti_weights (torchsparse/nn/functional/devoxelize.py;
+network/utils.py:77-83,95): 8-corner trilinear voxel -> point interpolation."""
+import torch
+from torch.autograd import Function
+
+from ... import backend as B
+
+__all__ = ['spdevoxelize', 'calc_ti_weights', 'ti_weights_and_index']
+
+
+def ti_weights_and_index(coords, idx_query, scale=1):
+    """Fused form used by lidal_amd.network: returns (w f32 [N,8], idx i32 [N,8]), i.e.
+    calc_ti_weights(...).transpose(0,1) and idx_query.transpose(0,1) of network/utils.py:77-79
+    in one pass."""
+    B.require_gpu(coords, idx_query)
+    coords = coords.contiguous().float()
+    idx_query = idx_query.contiguous()
+    assert idx_query.dtype == torch.int64 and idx_query.shape[0] == 8
+    n = coords.shape[0]
+    w = torch.empty((n, 8), dtype=torch.float32, device=coords.device)
+    idx32 = torch.empty((n, 8), dtype=torch.int, device=coords.device)
+    B.check(B.lib().lidal_ti_weights(B.ptr(coords), coords.shape[1], B.ptr(idx_query), n,
+                                     float(scale), B.ptr(w), B.ptr(idx32), B.stream()),
+            'ti_weights')
+    return w, idx32
+
+
+def calc_ti_weights(coords, idx_query, scale=1):
+    """torchsparse signature: returns w [8, N] (the caller transposes)."""
+    w, _ = ti_weights_and_index(coords, idx_query, scale)
+    return w.transpose(0, 1).contiguous()
+
+
+class DevoxelizeFunction(Function):
+    @staticmethod
+    def forward(ctx, feats, coords, weights):
+        B.require_gpu(feats, coords, weights)
+        in_dtype = feats.dtype
+        feats = feats.contiguous().float()
+        coords = coords.contiguous().int()
+        weights = weights.contiguous().float()
+        m, c = feats.shape
+        n = coords.shape[0]
+        out = torch.empty((n, c), dtype=torch.float32, device=feats.device)
+        B.check(B.lib().lidal_devoxelize_fwd(B.ptr(feats), B.ptr(coords), B.ptr(weights),
+                                             B.ptr(out), n, m, c, B.stream()), 'devoxelize_fwd')
+        ctx.for_backwards = (coords, weights, m, in_dtype)
+        return out.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords, weights, m, in_dtype = ctx.for_backwards
+        g = grad_output.contiguous().float()
+        n, c = g.shape
+        gin = torch.empty((m, c), dtype=torch.float32, device=g.device)
+        B.check(B.lib().lidal_devoxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(weights), B.ptr(gin),
+                                             n, m, c, B.stream()), 'devoxelize_bwd')
+        return gin.to(in_dtype), None, None
+
+
+def spdevoxelize(feats, coords, weights):
+    return DevoxelizeFunction.apply(feats, coords, weights)

@@ -1,0 +1,45 @@
+"""F.spdownsample (torchsparse/nn/functional/downsample.py) and the sorted unique of hashes that
+network/utils.py:18 takes with torch.unique.  Both produce SORTED output (that order defines the
+voxel row order of every coarser level), so they are radix-sort + ordered compaction on device."""
+import torch
+
+from ... import backend as B
+from ...utils import make_ntuple
+
+__all__ = ['spdownsample', 'unique_sorted']
+
+
+def unique_sorted(keys):
+    """Sorted unique of an i64 key vector (== torch.unique(keys) for non-negative keys)."""
+    B.require_gpu(keys)
+    keys = keys.contiguous().view(-1)
+    assert keys.dtype == torch.int64
+    n = keys.numel()
+    out = torch.empty(n, dtype=torch.int64, device=keys.device)
+    n_out = torch.empty(1, dtype=torch.int64, device=keys.device)
+    ws_bytes = B.lib().lidal_unique_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=keys.device)
+    B.check(B.lib().lidal_unique_sorted_i64(B.ptr(keys), n, B.ptr(out), B.ptr(n_out), B.ptr(ws),
+                                            ws_bytes, B.stream()), 'unique_sorted_i64')
+    return out[:int(n_out.item())]
+
+
+def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
+    stride = make_ntuple(stride, ndim=3)
+    kernel_size = make_ntuple(kernel_size, ndim=3)
+    tensor_stride = make_ntuple(tensor_stride, ndim=3)
+    if not all(stride[k] in [1, kernel_size[k]] for k in range(3)):
+        raise NotImplementedError('spdownsample: only stride in {1, kernel_size} is on the LiDAL '
+                                  'path (network/spvcnn.py:28,34,40,46 use 2/2)')
+    B.require_gpu(coords)
+    assert coords.dtype == torch.int and coords.shape[1] == 4
+    coords = coords.contiguous()
+    n = coords.shape[0]
+    ss = [stride[k] * tensor_stride[k] for k in range(3)]
+    out = torch.empty((n, 4), dtype=torch.int, device=coords.device)
+    n_out = torch.empty(1, dtype=torch.int64, device=coords.device)
+    ws_bytes = B.lib().lidal_downsample_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=coords.device)
+    B.check(B.lib().lidal_downsample(B.ptr(coords), n, ss[0], ss[1], ss[2], B.ptr(out),
+                                     B.ptr(n_out), B.ptr(ws), ws_bytes, B.stream()), 'downsample')
+    return out[:int(n_out.item())]

@@ -1,0 +1,36 @@
+"""F.sphashquery (torchsparse/nn/functional/query.py; network/utils.py:19,48,76).
+
+HashTable is the reusable half (build once, probe many); sphashquery is the one-shot API."""
+import torch
+
+from ... import backend as B
+
+__all__ = ['sphashquery', 'HashTable']
+
+
+class HashTable:
+    """Open-addressing table of i64 keys in HBM; value = index of the first occurrence."""
+
+    def __init__(self, references):
+        B.require_gpu(references)
+        references = references.contiguous().view(-1)
+        assert references.dtype == torch.int64
+        self.n = references.numel()
+        self.nbytes = B.lib().lidal_hash_table_bytes(self.n)
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=references.device)
+        B.check(B.lib().lidal_hash_table_build(B.ptr(references), self.n, B.ptr(self.buf),
+                                               self.nbytes, B.stream()), 'hash_table_build')
+
+    def query(self, queries):
+        B.require_gpu(queries)
+        sizes = queries.size()
+        q = queries.contiguous().view(-1)
+        assert q.dtype == torch.int64
+        out = torch.empty_like(q)
+        B.check(B.lib().lidal_hash_table_query(B.ptr(self.buf), self.nbytes, B.ptr(q), q.numel(),
+                                               B.ptr(out), B.stream()), 'hash_table_query')
+        return out.view(*sizes)
+
+
+def sphashquery(queries, references):
+    return HashTable(references).query(queries)

@@ -1,0 +1,39 @@
+"""F.spvoxelize (torchsparse/nn/functional/voxelize.py; network/utils.py:22,25,56):
+mean-pool point rows into voxel rows, with the matching backward."""
+import torch
+from torch.autograd import Function
+
+from ... import backend as B
+
+__all__ = ['spvoxelize']
+
+
+class VoxelizeFunction(Function):
+    @staticmethod
+    def forward(ctx, feats, coords, counts):
+        B.require_gpu(feats, coords, counts)
+        in_dtype = feats.dtype
+        feats = feats.contiguous().float()
+        coords = coords.contiguous().int()
+        counts = counts.contiguous().int()
+        n, c = feats.shape
+        m = counts.shape[0]
+        out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
+        B.check(B.lib().lidal_voxelize_fwd(B.ptr(feats), B.ptr(coords), B.ptr(counts), B.ptr(out),
+                                           n, m, c, B.stream()), 'voxelize_fwd')
+        ctx.for_backwards = (coords, counts, n, in_dtype)
+        return out.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords, counts, n, in_dtype = ctx.for_backwards
+        g = grad_output.contiguous().float()
+        m, c = g.shape
+        gin = torch.empty((n, c), dtype=torch.float32, device=g.device)
+        B.check(B.lib().lidal_voxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(counts), B.ptr(gin),
+                                           n, m, c, B.stream()), 'voxelize_bwd')
+        return gin.to(in_dtype), None, None
+
+
+def spvoxelize(feats, coords, counts):
+    return VoxelizeFunction.apply(feats, coords, counts)

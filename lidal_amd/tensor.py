@@ -1,0 +1,78 @@
+"""SparseTensor / PointTensor containers with the torchsparse 1.4.0 surface the reference uses
+(network/utils.py:27-31,58-59,84-99; network/spvcnn.py:114,131; train.py:134).
+
+coords are int32 [N,4] = (x, y, z, batch) -- batch LAST -- kept as multiples of the tensor
+stride; `cmaps` maps stride -> coords and `kmaps` maps (stride, kernel, conv stride, dilation) ->
+lidal_amd.nn.functional.conv.KernelMap; both dicts are shared by every tensor derived from one
+input so a kernel map is built once per resolution level.
+"""
+from .utils import make_ntuple
+
+__all__ = ['SparseTensor', 'PointTensor']
+
+
+class SparseTensor:
+    def __init__(self, feats, coords, stride=1):
+        self.feats = feats
+        self.coords = coords
+        self.stride = make_ntuple(stride, ndim=3)
+        self.cmaps = {}
+        self.kmaps = {}
+
+    F = property(lambda self: self.feats, lambda self, v: setattr(self, 'feats', v))
+    C = property(lambda self: self.coords, lambda self, v: setattr(self, 'coords', v))
+    s = property(lambda self: self.stride, lambda self, v: setattr(self, 'stride', v))
+
+    def _map(self, fn):
+        self.coords = fn(self.coords)
+        self.feats = fn(self.feats)
+        return self
+
+    def cpu(self):
+        return self._map(lambda t: t.cpu())
+
+    def cuda(self):
+        return self._map(lambda t: t.cuda())
+
+    def detach(self):
+        return self._map(lambda t: t.detach())
+
+    def to(self, device, non_blocking=True):
+        return self._map(lambda t: t.to(device, non_blocking=non_blocking))
+
+    def __add__(self, other):
+        out = SparseTensor(self.feats + other.feats, self.coords, self.stride)
+        out.cmaps = self.cmaps
+        out.kmaps = self.kmaps
+        return out
+
+
+class PointTensor:
+    def __init__(self, feats, coords, idx_query=None, weights=None):
+        self.F = feats
+        self.C = coords
+        self.idx_query = idx_query if idx_query is not None else {}
+        self.weights = weights if weights is not None else {}
+        self.additional_features = {'idx_query': {}, 'counts': {}}
+
+    def _map(self, fn):
+        self.F = fn(self.F)
+        self.C = fn(self.C)
+        return self
+
+    def cpu(self):
+        return self._map(lambda t: t.cpu())
+
+    def cuda(self):
+        return self._map(lambda t: t.cuda())
+
+    def detach(self):
+        return self._map(lambda t: t.detach())
+
+    def to(self, device, non_blocking=True):
+        return self._map(lambda t: t.to(device, non_blocking=non_blocking))
+
+    def __add__(self, other):
+        out = PointTensor(self.F + other.F, self.C, self.idx_query, self.weights)
+        out.additional_features = self.additional_features
+        return out

@@ -1,0 +1,24 @@
+"""One training iteration, the counterpart of /root/reference/train.py:127-140:
+zero_grad -> model(SparseTensor) -> cross_entropy(ignore_index=255, mean) -> backward -> Adam.step.
+"""
+import torch
+
+from . import SparseTensor
+
+__all__ = ['train_step', 'forward_backward']
+
+
+def forward_backward(model, feats_v_b, coords_v_b, labels_v_b, autocast=False):
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+        logits, _ = model(SparseTensor(feats_v_b, coords_v_b))
+    loss = torch.nn.functional.cross_entropy(logits.float(), labels_v_b, ignore_index=255,
+                                             reduction='mean')
+    loss.backward()
+    return loss, logits
+
+
+def train_step(model, optimizer, feats_v_b, coords_v_b, labels_v_b, autocast=False):
+    optimizer.zero_grad()
+    loss, logits = forward_backward(model, feats_v_b, coords_v_b, labels_v_b, autocast)
+    optimizer.step()
+    return loss.detach(), logits.detach()

@@ -1,0 +1,294 @@
+"""Parity of every HIP operator with the CPU oracle (oracle.tsref) on the same seeded inputs.
+Integer / index results are compared bit-exactly; f32 features within 1e-4 relative
+(BASELINE.json north_star); bf16 within bf16 rounding of the f32 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.tsref.nn import functional as RF          # noqa: E402  (checker only)
+from oracle.tsref.nn.utils import get_kernel_offsets as ref_offsets  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _F():
+    from lidal_amd.nn import functional as F
+    return F
+
+
+def _coords(n, extent=60, batches=2, seed=0, stride=1):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.randint(0, extent, (n * 2, 3), generator=g, dtype=torch.int32) * stride
+    b = torch.randint(0, batches, (n * 2, 1), generator=g, dtype=torch.int32)
+    c = torch.unique(torch.cat([c, b], 1), dim=0)
+    c = c[torch.randperm(c.shape[0], generator=g)][:n]
+    return c.contiguous()
+
+
+def _surface_coords(n_side=70, batches=2, seed=0):
+    """voxels on a wavy 2-D sheet: ~9 of 27 neighbours occupied, like LiDAR surfaces."""
+    g = torch.Generator().manual_seed(seed)
+    xs, ys = torch.meshgrid(torch.arange(n_side), torch.arange(n_side), indexing='ij')
+    out = []
+    for b in range(batches):
+        z = (8 + 4 * torch.sin(xs / 7.0 + b) + 3 * torch.cos(ys / 5.0)).floor().int()
+        c = torch.stack([xs.int() + 100, ys.int() + 50, z + 20, torch.full_like(z, b)], -1)
+        out.append(c.reshape(-1, 4))
+    c = torch.cat(out)
+    return c[torch.randperm(c.shape[0], generator=g)].contiguous().int()
+
+
+def _relerr(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 1000, 50001])
+def test_sphash(n):
+    F = _F()
+    c = _coords(max(n, 1), extent=8191, seed=n)[:n]
+    assert torch.equal(F.sphash(c.to(DEV)).cpu(), RF.sphash(c))
+    for ks, st in ((3, 1), (2, 2), (3, 4)):
+        off = ref_offsets(ks, st)
+        assert torch.equal(F.sphash(c.to(DEV), off.to(DEV)).cpu(), RF.sphash(c, off))
+
+
+def test_sphash_known_answers():
+    F = _F()
+    c = torch.tensor([[0, 0, 0, 0], [1, 2, 3, 0], [4095, 4096, 8191, 4], [100, 200, 300, 7]],
+                     dtype=torch.int)
+    assert F.sphash(c.to(DEV)).cpu().tolist() == [947293587111810033, 1043245732202901914,
+                                                  482871551030584986, 15305659009498132]
+
+
+def test_sphash_rejects_cpu_and_wrong_dtype():
+    F = _F()
+    with pytest.raises(RuntimeError):
+        F.sphash(torch.zeros((4, 4), dtype=torch.int))
+    with pytest.raises(AssertionError):
+        F.sphash(torch.zeros((4, 4), dtype=torch.int64, device=DEV))
+
+
+@pytest.mark.parametrize('nq,nr', [(0, 10), (10, 0), (1000, 1000), (100000, 30000)])
+def test_sphashquery(nq, nr):
+    F = _F()
+    g = torch.Generator().manual_seed(nq + nr)
+    refs = torch.randint(0, 2 ** 59, (nr,), generator=g, dtype=torch.int64)
+    q = torch.randint(0, 2 ** 59, (nq,), generator=g, dtype=torch.int64)
+    if nr and nq:
+        q[::2] = refs[torch.randint(0, nr, (q[::2].numel(),), generator=g)]
+    out = F.sphashquery(q.to(DEV), refs.to(DEV)).cpu()
+    assert torch.equal(out, RF.sphashquery(q, refs))
+
+
+def test_sphashquery_duplicates_first_wins_and_shape():
+    F = _F()
+    refs = torch.tensor([5, 9, 5, 7, 9, 9, 1], dtype=torch.int64)
+    q = torch.tensor([[9, 5], [1, 2], [7, 9]], dtype=torch.int64)
+    out = F.sphashquery(q.to(DEV), refs.to(DEV)).cpu()
+    assert out.tolist() == [[1, 0], [6, -1], [3, 1]]
+    assert torch.equal(out, RF.sphashquery(q, refs))
+
+
+@pytest.mark.parametrize('n', [1, 5, 4096, 70001])
+def test_unique_sorted(n):
+    F = _F()
+    g = torch.Generator().manual_seed(n)
+    k = torch.randint(0, max(2, n // 2), (n,), generator=g, dtype=torch.int64) * 1234567891
+    assert torch.equal(F.unique_sorted(k.to(DEV)).cpu(), torch.unique(k))
+    h = RF.sphash(_coords(n, seed=n))
+    assert torch.equal(F.unique_sorted(h.to(DEV)).cpu(), torch.unique(h))
+
+
+@pytest.mark.parametrize('ts', [1, 2, 8])
+def test_spdownsample(ts):
+    F = _F()
+    c = _coords(20000, extent=300, batches=3, seed=ts, stride=ts)
+    ref = RF.spdownsample(c, 2, 2, ts)
+    out = F.spdownsample(c.to(DEV), 2, 2, ts).cpu()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('ks,stride,ts', [(3, 1, 1), (2, 2, 1), (3, 1, 4), (2, 2, 2)])
+def test_kernel_map_bit_exact(ks, stride, ts):
+    F = _F()
+    c = _surface_coords(60, seed=ks + ts)
+    c[:, :3] = c[:, :3] // ts * ts
+    c = torch.unique(c, dim=0)
+    c = c[torch.randperm(c.shape[0], generator=torch.Generator().manual_seed(1))].contiguous()
+    st = (stride,) * 3
+    nbmaps, nbsizes, sizes, out_coords, results = RF.build_kmap(c, (ts,) * 3, (ks,) * 3, st)
+    kmap, oc = F.build_kernel_map(c.to(DEV), (ts,) * 3, (ks,) * 3, st)
+    assert kmap.sizes == sizes
+    assert torch.equal(oc.cpu(), out_coords)
+    assert torch.equal(kmap.nbsizes.cpu().long(), nbsizes)
+    assert torch.equal(kmap.nbmaps.cpu().long(), nbmaps)
+    assert torch.equal(kmap.nbr_out.cpu().long(), results)
+    assert kmap.total == int(nbsizes.sum())
+    # inverse table: nbr_in[k][i] = j  <=>  nbr_out[k][j] = i
+    nbr_in = kmap.nbr_in.cpu()
+    exp = torch.full_like(nbr_in, -1)
+    kk, jj = torch.nonzero(results != -1, as_tuple=True)
+    exp[kk, results[kk, jj]] = jj.int()
+    assert torch.equal(nbr_in, exp)
+    if kmap.symmetric:
+        assert torch.equal(nbr_in, kmap.nbr_out.cpu().flip(0))
+
+
+def test_spcount_voxelize_devoxelize():
+    F = _F()
+    g = torch.Generator().manual_seed(3)
+    n, m = 30000, 7000
+    idx = torch.randint(-1, m, (n,), generator=g, dtype=torch.int64)
+    counts_ref = RF.spcount(idx.int(), m)
+    counts = F.spcount(idx.int().to(DEV), m)
+    assert torch.equal(counts.cpu(), counts_ref)
+    for c in (4, 32, 96):
+        feats = torch.randn(n, c, generator=g)
+        f_ref = feats.clone().requires_grad_(True)
+        o_ref = RF.spvoxelize(f_ref, idx, counts_ref)
+        f_gpu = feats.to(DEV).requires_grad_(True)
+        o_gpu = F.spvoxelize(f_gpu, idx.to(DEV), counts)
+        assert _relerr(o_gpu.cpu(), o_ref) < 1e-5
+        go = torch.randn(m, c, generator=g)
+        o_ref.backward(go)
+        o_gpu.backward(go.to(DEV))
+        assert _relerr(f_gpu.grad.cpu(), f_ref.grad) < 1e-5
+    # devoxelize
+    idx8 = torch.randint(-1, m, (n, 8), generator=g, dtype=torch.int32)
+    w = torch.rand(n, 8, generator=g)
+    for c in (32, 96, 256):
+        vf = torch.randn(m, c, generator=g)
+        v_ref = vf.clone().requires_grad_(True)
+        o_ref = RF.spdevoxelize(v_ref, idx8, w)
+        v_gpu = vf.to(DEV).requires_grad_(True)
+        o_gpu = F.spdevoxelize(v_gpu, idx8.to(DEV), w.to(DEV))
+        assert _relerr(o_gpu.cpu(), o_ref) < 1e-5
+        go = torch.randn(n, c, generator=g)
+        o_ref.backward(go)
+        o_gpu.backward(go.to(DEV))
+        assert _relerr(v_gpu.grad.cpu(), v_ref.grad) < 1e-4
+
+
+@pytest.mark.parametrize('scale', [1, 2, 8])
+def test_calc_ti_weights(scale):
+    F = _F()
+    g = torch.Generator().manual_seed(scale)
+    n = 20000
+    coords = torch.rand(n, 4, generator=g) * 200
+    idx = torch.randint(-1, 500, (8, n), generator=g, dtype=torch.int64)
+    ref = RF.calc_ti_weights(coords, idx, scale)
+    out = F.calc_ti_weights(coords.to(DEV), idx.to(DEV), scale).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-6
+    w, i32 = F.ti_weights_and_index(coords.to(DEV), idx.to(DEV), scale)
+    assert torch.equal(i32.cpu().long(), idx.t())
+    assert (w.cpu() - ref.t()).abs().max().item() < 2e-6
+
+
+def _conv_case(ci, co, ks, stride, transposed, dtype, seed=0, n_side=48):
+    """Run one conv fwd+bwd on GPU and on the oracle (f32).  Returns relative errors."""
+    import lidal_amd
+    from lidal_amd.nn import functional as F
+    from oracle import tsref
+    g = torch.Generator().manual_seed(seed)
+    c = _surface_coords(n_side, seed=seed)
+    if transposed:      # input lives on the coarse level; the map comes from the strided conv
+        fine_ref = tsref.SparseTensor(torch.zeros(c.shape[0], 4), c, 1)
+        fine_gpu = lidal_amd.SparseTensor(torch.zeros(c.shape[0], 4, device=DEV), c.to(DEV), 1)
+        fine_ref.cmaps[(1, 1, 1)] = fine_ref.C      # as the stem conv's output would have
+        fine_gpu.cmaps[(1, 1, 1)] = fine_gpu.C
+        wd = torch.randn(ks ** 3, 4, 4, generator=g)
+        x_ref = RF.conv3d(fine_ref, wd, ks, stride=stride)
+        x_gpu = F.conv3d(fine_gpu, wd.to(DEV), ks, stride=stride)
+        assert torch.equal(x_gpu.C.cpu(), x_ref.C)
+        n = x_ref.C.shape[0]
+    else:
+        n = c.shape[0]
+    feats = torch.randn(n, ci, generator=g)
+    fan = ci * ks ** 3
+    weight = (torch.rand(ks ** 3, ci, co, generator=g) * 2 - 1) / fan ** 0.5 * 3 ** 0.5
+    f_ref = feats.clone().requires_grad_(True)
+    w_ref = weight.clone().requires_grad_(True)
+    f_gpu = feats.to(DEV).to(dtype).requires_grad_(True)
+    w_gpu = weight.to(DEV).to(dtype).requires_grad_(True)
+    if transposed:
+        x_ref.feats, x_gpu.feats = f_ref, f_gpu
+        o_ref = RF.conv3d(x_ref, w_ref, ks, stride=stride, transposed=True)
+        o_gpu = F.conv3d(x_gpu, w_gpu, ks, stride=stride, transposed=True)
+    else:
+        o_ref = RF.conv3d(tsref.SparseTensor(f_ref, c, 1), w_ref, ks, stride=stride)
+        o_gpu = F.conv3d(lidal_amd.SparseTensor(f_gpu, c.to(DEV), 1), w_gpu, ks, stride=stride)
+    assert torch.equal(o_gpu.C.cpu(), o_ref.C) and o_gpu.s == o_ref.s
+    go = torch.randn(o_ref.F.shape, generator=g)
+    o_ref.F.backward(go)
+    o_gpu.F.backward(go.to(DEV).to(dtype))
+    return (_relerr(o_gpu.F.detach().float().cpu(), o_ref.F.detach()),
+            _relerr(f_gpu.grad.float().cpu(), f_ref.grad),
+            _relerr(w_gpu.grad.float().cpu(), w_ref.grad))
+
+
+CONV_SHAPES = [(4, 32), (32, 32), (32, 64), (64, 64), (96, 96), (128, 96), (64, 128), (192, 128),
+               (256, 256), (384, 256)]
+
+
+@pytest.mark.parametrize('ci,co', CONV_SHAPES)
+def test_conv3d_k3_f32(ci, co):
+    errs = _conv_case(ci, co, 3, 1, False, torch.float32, seed=ci + co,
+                      n_side=48 if ci * co < 256 * 256 else 30)
+    assert max(errs) < 1e-4, errs
+
+
+@pytest.mark.parametrize('ci,co', [(32, 32), (64, 64), (128, 128), (256, 256)])
+def test_conv3d_strided_and_transposed_f32(ci, co):
+    errs = _conv_case(ci, co, 2, 2, False, torch.float32, seed=ci)
+    assert max(errs) < 1e-4, errs
+    errs = _conv_case(ci, co if co != 256 else 128, 2, 2, True, torch.float32, seed=ci + 1)
+    assert max(errs) < 1e-4, errs
+
+
+@pytest.mark.parametrize('ci,co', [(4, 32), (32, 32), (96, 96), (128, 96), (192, 128), (384, 256)])
+def test_conv3d_k3_bf16(ci, co):
+    errs = _conv_case(ci, co, 3, 1, False, torch.bfloat16, seed=ci + co, n_side=40)
+    # inputs, weights, outputs rounded to bf16 (2^-8 relative each), f32 accumulation
+    assert max(errs) < 3e-2, errs
+
+
+def test_conv3d_deterministic_and_1x1():
+    import lidal_amd
+    from lidal_amd.nn import functional as F
+    g = torch.Generator().manual_seed(5)
+    c = _surface_coords(40, seed=5).to(DEV)
+    feats = torch.randn(c.shape[0], 64, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(27, 64, 96, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    outs = []
+    for _ in range(2):
+        feats.grad = w.grad = None
+        o = F.conv3d(lidal_amd.SparseTensor(feats, c, 1), w, 3)
+        o.F.square().sum().backward()
+        outs.append((o.F.detach().clone(), feats.grad.clone(), w.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), 'conv fwd/bwd must be bitwise reproducible'
+    w1 = torch.randn(64, 32, generator=g).to(DEV)
+    o1 = F.conv3d(lidal_amd.SparseTensor(feats.detach(), c, 1), w1, 1)
+    assert _relerr(o1.F.cpu(), feats.detach().cpu() @ w1.cpu()) < 1e-4
+
+
+def test_conv3d_dense_grid_equals_torch_conv3d():
+    """Oracle-independent property: on a fully occupied grid a k3 sparse conv equals
+    torch.nn.functional.conv3d (interior voxels) with the weight re-laid out x-fastest."""
+    import lidal_amd
+    from lidal_amd.nn import functional as F
+    g = torch.Generator().manual_seed(9)
+    D, ci, co = 10, 32, 32
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(D), torch.arange(D), indexing='ij')
+    c = torch.stack([xx, yy, zz, torch.zeros_like(xx)], -1).reshape(-1, 4).int()
+    feats = torch.randn(c.shape[0], ci, generator=g)
+    w = torch.randn(27, ci, co, generator=g) * 0.1
+    out = F.conv3d(lidal_amd.SparseTensor(feats.to(DEV), c.to(DEV), 1), w.to(DEV), 3).F.cpu()
+    vol = feats.reshape(D, D, D, ci).permute(3, 0, 1, 2)[None]            # [1,ci,z,y,x]
+    wt = w.reshape(3, 3, 3, ci, co).permute(4, 3, 0, 1, 2)                # [co,ci,kz,ky,kx]
+    dense = torch.nn.functional.conv3d(vol, wt, padding=1)[0].permute(1, 2, 3, 0).reshape(-1, co)
+    assert _relerr(out, dense) < 1e-4

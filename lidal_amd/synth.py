@@ -190,14 +190,17 @@ def angular_supervoxels(points, n_sv=20):
     return [np.sort(chunk).astype(np.int64) for chunk in np.array_split(order, n_sv)]
 
 
-def make_sequence(n_frames, n_points=120000, seed=7122, step=1.0, n_sv=20, n_beams=64, n_az=2048):
-    """Frames along a straight ego path.  Returns a list of dicts with
-    points f32 [P,3] (sensor frame), intensity f32 [P], world f64 [P,3], sv_id i64 [n_sv]
-    (global ids, frame-major), sv2point (list of i64 arrays)."""
-    rng = np.random.default_rng(seed)
-    world = make_world(seed, length=max(400.0, n_frames * step + 100.0))
+def make_sequence(n_frames, n_points=120000, seed=7122, step=1.0, n_sv=20, n_beams=64, n_az=2048,
+                  start=0, total=None):
+    """Frames [start, start + n_frames) of a sequence of `total` frames along a straight ego path
+    (every frame has its own RNG stream, so ranks can generate disjoint blocks of one sequence).
+    Returns a list of dicts with points f32 [P,3] (sensor frame), intensity f32 [P],
+    world f64 [P,3], sv_id i64 [n_sv] (global ids, frame-major), sv2point (list of i64 arrays)."""
+    total = total if total is not None else start + n_frames
+    world = make_world(seed, length=max(400.0, total * step + 100.0))
     frames = []
-    for f in range(n_frames):
+    for f in range(start, start + n_frames):
+        rng = np.random.default_rng([seed, f])
         ox = 10.0 + step * f
         pts, inten = raycast_scan(world, (ox, 0.0), rng, n_beams=n_beams, n_az=n_az,
                                   n_points=n_points)

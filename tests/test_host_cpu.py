@@ -1,0 +1,131 @@
+"""CPU tests of the shipped package's host logic: the C-ABI library loads and exports every
+symbol include/lidal_amd.h declares, operators refuse CPU tensors (no fallback), containers /
+modules / model definitions keep the reference's surface, selection matches the reference's
+flags, synthetic inputs follow the reference's input contract."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from lidal_amd import backend as B
+    header = open(os.path.join(ROOT, 'include', 'lidal_amd.h')).read()
+    declared = set(re.findall(r'\b(lidal_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 29
+    handle = ctypes.CDLL(B.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert declared == set(B.SIGNATURES), declared ^ set(B.SIGNATURES)
+    assert B.lib().lidal_version() >= 100
+    assert B.lib().lidal_hash_table_bytes(1000) == 2048 * 12
+    assert B.lib().lidal_last_error() is not None
+
+
+def test_operators_have_no_cpu_fallback():
+    from lidal_amd.nn import functional as F
+    c = torch.zeros((4, 4), dtype=torch.int)
+    for call in (lambda: F.sphash(c),
+                 lambda: F.sphashquery(torch.zeros(3, dtype=torch.int64), torch.zeros(3, dtype=torch.int64)),
+                 lambda: F.spcount(torch.zeros(3, dtype=torch.int), 2),
+                 lambda: F.spvoxelize(torch.zeros(3, 4), torch.zeros(3, dtype=torch.int), torch.ones(2, dtype=torch.int)),
+                 lambda: F.spdevoxelize(torch.zeros(3, 4), torch.zeros((3, 8), dtype=torch.int), torch.zeros(3, 8)),
+                 lambda: F.spdownsample(c),
+                 lambda: F.build_kernel_map(c, (1, 1, 1), (3, 3, 3), (1, 1, 1))):
+        with pytest.raises(RuntimeError, match='GPU only'):
+            call()
+    import lidal_amd
+    with pytest.raises(RuntimeError, match='GPU only'):
+        F.conv3d(lidal_amd.SparseTensor(torch.zeros(4, 4), c), torch.zeros(27, 4, 8), 3)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'lidal_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), os.path.join(dirpath, f)
+
+
+def test_containers_and_modules_surface():
+    import lidal_amd
+    import lidal_amd.nn as spnn
+    from lidal_amd.nn.utils import get_kernel_offsets
+    x = lidal_amd.SparseTensor(torch.ones(3, 2), torch.zeros((3, 4), dtype=torch.int), 2)
+    assert x.s == (2, 2, 2) and x.F is x.feats and x.C is x.coords
+    y = x + x
+    assert y.cmaps is x.cmaps and y.kmaps is x.kmaps and torch.equal(y.F, 2 * x.F)
+    x.F = torch.zeros(3, 5)
+    assert x.feats.shape == (3, 5)
+    z = lidal_amd.PointTensor(torch.ones(3, 2), torch.zeros(3, 4))
+    assert z.idx_query == {} and z.additional_features == {'idx_query': {}, 'counts': {}}
+    assert lidal_amd.cat([y, y]).F.shape == (3, 4)
+    conv = spnn.Conv3d(4, 8, kernel_size=3)
+    assert tuple(conv.kernel.shape) == (27, 4, 8) and conv.bias is None
+    assert conv.kernel.abs().max() <= 1 / (4 * 27) ** 0.5
+    assert tuple(spnn.Conv3d(4, 8, kernel_size=1).kernel.shape) == (4, 8)
+    assert tuple(spnn.Conv3d(8, 4, kernel_size=2, stride=2, transposed=True).kernel.shape) == (8, 8, 4)
+    assert isinstance(spnn.BatchNorm(8), torch.nn.BatchNorm1d)
+    assert get_kernel_offsets(2, (2, 2, 2)).dtype == torch.int
+
+
+def test_models_keep_reference_state_dict_surface(golden_dir):
+    from lidal_amd.network import SPVCNN, MinkUNet
+    from weights import fill_state_dict, state_dict_signature
+    for name, cls, n_params in (('spvcnn', SPVCNN, 21778003), ('minkunet', MinkUNet, 21723315)):
+        model = cls(19)
+        assert sum(p.numel() for p in model.parameters()) == n_params
+        ref = json.load(open(os.path.join(golden_dir, 'state_dict_%s.json' % name)))
+        assert [[k, list(s), d] for k, s, d in state_dict_signature(model)] == ref
+        fill_state_dict(model)      # strict=True load of a reference-shaped checkpoint
+
+
+def test_selection_matches_reference_flags(golden_dir):
+    from lidal_amd.score import select
+    g = np.load(os.path.join(golden_dir, 'selection_small.npz'))
+    out = select(g['flags_in'], g['sv_interds'], g['sv_interes'], g['sv_pnums'], g['sv_centers'],
+                 int(g['train_point_num']))
+    assert np.array_equal(out, g['flags_out'])
+    # budget branch (never binding with the reference's hard-coded 2.3e9 points): a tiny budget
+    # must stop each pass early and still agree with the oracle restatement
+    from oracle import scoring_ref
+    small = int(g['sv_pnums'][:40].sum() * 100)
+    a = select(g['flags_in'], g['sv_interds'], g['sv_interes'], g['sv_pnums'], g['sv_centers'], small)
+    b = scoring_ref.select(g['flags_in'], g['sv_interds'], g['sv_interes'], g['sv_pnums'],
+                           g['sv_centers'], small)
+    assert np.array_equal(a, b) and 0 < (a == 1).sum() < (out == 1).sum()
+
+
+def test_neighbour_ids_match_oracle():
+    from lidal_amd.score import neighbour_ids
+    from oracle import scoring_ref
+    for n_frames, nei in ((25, 24), (40, 24), (30, 10), (11, 10)):
+        for i in range(n_frames):
+            assert neighbour_ids(i, n_frames, nei) == scoring_ref.neighbour_ids(i, n_frames, nei)
+
+
+def test_synthetic_inputs_follow_reference_contract():
+    from lidal_amd import synth
+    b = synth.make_train_batch(n_frames=2, n_points=3000, seed=1)
+    c, f, l = b['coords_v_b'], b['feats_v_b'], b['labels_v_b']
+    assert c.dtype == np.int32 and c.shape[1] == 4 and f.dtype == np.float32 and f.shape[1] == 4
+    assert l.dtype == np.int64 and set(np.unique(l)) <= set(range(19)) | {255}
+    assert c[:, :3].min() >= 0 and c[:, :3].max() < 8192 and set(np.unique(c[:, 3])) == {0, 1}
+    for bi in (0, 1):                               # np.unique(axis=0): sorted, distinct rows
+        rows = c[c[:, 3] == bi, :3]
+        assert len(np.unique(rows, axis=0)) == len(rows)
+        assert np.array_equal(rows, rows[np.lexsort(rows.T[::-1])])
+    rng = np.random.default_rng(0)
+    pts, inten = synth.raycast_scan(synth.make_world(2), (15.0, 0.0), rng, n_beams=16, n_az=64)
+    sb = synth.make_score_batch(pts, inten, rng, inf_reps=3)
+    inv = sb['inverse_indices_b']
+    assert inv.shape[0] == 3 * pts.shape[0] and inv.max() == sb['coords_v_b'].shape[0] - 1
+    seq = synth.make_sequence(3, n_points=500, seed=2, n_beams=8, n_az=128)
+    assert seq[1]['world'].dtype == np.float64 and len(seq[1]['sv2point']) == 20
+    assert sorted(np.concatenate(seq[1]['sv2point']).tolist()) == list(range(500))

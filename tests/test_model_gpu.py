@@ -1,0 +1,116 @@
+"""Model-level parity: the build's SPVCNN / MinkUNet on the HIP path against golden outputs of
+the REFERENCE's own network/spvcnn.py + network/minkunet.py (run unchanged on the CPU oracle in
+the build container by tests/golden/make_golden.py).  Tolerance: 1e-4 relative (north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _load(golden_dir):
+    return np.load(os.path.join(golden_dir, 'model_small.npz'))
+
+
+def _models():
+    from lidal_amd.network import SPVCNN, MinkUNet
+    return {'spvcnn': SPVCNN, 'minkunet': MinkUNet}
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_eval_forward_matches_reference_golden(name, golden_dir):
+    import lidal_amd
+    from weights import fill_state_dict, state_dict_signature
+    g = _load(golden_dir)
+    model = fill_state_dict(_models()[name](19))
+    sig = json.load(open(os.path.join(golden_dir, 'state_dict_%s.json' % name)))
+    assert [[k, list(s), d] for k, s, d in state_dict_signature(model)] == sig
+    model = model.to(DEV).eval()
+    x = lidal_amd.SparseTensor(torch.from_numpy(g['feats']).to(DEV),
+                               torch.from_numpy(g['coords']).to(DEV))
+    with torch.no_grad():
+        logits, feat = model(x)
+    assert _rel(logits.cpu().numpy(), g[name + '_logits']) < 1e-4
+    assert _rel(feat.cpu().numpy(), g[name + '_feat']) < 1e-4
+    assert np.array_equal(logits.argmax(1).cpu().numpy(), g[name + '_logits'].argmax(1))
+
+
+def test_kernel_maps_match_reference_golden(golden_dir):
+    """Every kernel map the U-Net builds: rule lists bit-exact, level coordinates bit-exact."""
+    import lidal_amd
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    model = fill_state_dict(_models()['minkunet'](19)).to(DEV).eval()
+    x = lidal_amd.SparseTensor(torch.from_numpy(g['feats']).to(DEV),
+                               torch.from_numpy(g['coords']).to(DEV))
+    with torch.no_grad():
+        model(x)
+    seen = 0
+    for key, km in x.kmaps.items():
+        tag = 's%d_k%d_c%d' % (key[0][0], key[1][0], key[2][0])
+        assert np.array_equal(km.nbmaps.cpu().numpy(), g['kmap_%s_nbmaps' % tag]), tag
+        assert np.array_equal(km.nbsizes.cpu().numpy(), g['kmap_%s_nbsizes' % tag]), tag
+        seen += 1
+    assert seen == 9            # 5 k3 maps + 4 k2s2 maps
+    for s, c in x.cmaps.items():
+        assert np.array_equal(c.cpu().numpy(), g['cmap_s%d' % s[0]]), s
+
+
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_train_step_matches_reference_golden(name, golden_dir):
+    """train.py:127-140 (forward, CE ignore 255, backward): loss, logits, gradients against the
+    reference model files run in float64 on the oracle (see make_golden.py for why f64)."""
+    from lidal_amd.train_step import forward_backward
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    model = fill_state_dict(_models()[name](19)).to(DEV).train()
+    if hasattr(model, 'dropout'):
+        model.dropout.p = 0.0
+    loss, logits = forward_backward(model, torch.from_numpy(g['feats']).to(DEV),
+                                    torch.from_numpy(g['coords']).to(DEV),
+                                    torch.from_numpy(g['labels']).to(DEV))
+    assert abs(loss.item() - float(g[name + '_train_loss'])) < 1e-4 * abs(float(g[name + '_train_loss']))
+    assert _rel(logits.detach().cpu().numpy(), g[name + '_train_logits']) < 1e-4
+    named = dict(model.named_parameters())
+    norms = np.array([named[k].grad.norm().item() for k in g[name + '_grad_keys']])
+    assert np.abs(norms / g[name + '_grad_norms'] - 1).max() < 1e-4, norms / g[name + '_grad_norms']
+    assert _rel(named['stem.0.kernel'].grad.cpu().numpy(), g[name + '_grad_stem']) < 5e-4
+    assert _rel(named['up1.0.net.0.kernel'].grad.cpu().numpy()[:, :8, :8], g[name + '_grad_up1dc']) < 5e-4
+
+
+def test_bf16_autocast_close_to_f32(golden_dir):
+    """The bench configuration (bf16 conv operands, f32 accumulate / BN / loss) stays close to the
+    f32 golden: argmax agreement and a bf16-sized logit error."""
+    import lidal_amd
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    model = fill_state_dict(_models()['minkunet'](19)).to(DEV).eval()
+    x = lidal_amd.SparseTensor(torch.from_numpy(g['feats']).to(DEV),
+                               torch.from_numpy(g['coords']).to(DEV))
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        logits, _ = model(x)
+    ref = g['minkunet_logits']
+    assert _rel(logits.float().cpu().numpy(), ref) < 0.08
+    agree = (logits.argmax(1).cpu().numpy() == ref.argmax(1)).mean()
+    assert agree > 0.9, agree
+
+
+def test_reference_style_import_alias():
+    """`import torchsparse` resolves to this package after install_as_torchsparse()."""
+    import lidal_amd
+    lidal_amd.install_as_torchsparse()
+    import torchsparse
+    import torchsparse.nn as spnn
+    import torchsparse.nn.functional as F
+    from torchsparse import PointTensor, SparseTensor  # noqa: F401
+    from torchsparse.nn.utils import get_kernel_offsets  # noqa: F401
+    assert torchsparse is lidal_amd and hasattr(spnn, 'Conv3d') and hasattr(F, 'sphashquery')

@@ -1,0 +1,117 @@
+"""Scoring parity on the GPU: the fused view-mean softmax and the inter-frame divergence /
+entropy scorer against (a) golden outputs of the REFERENCE's own worker_func
+(tests/golden/scoring_small.npz) and (b) the CPU oracle on fresh seeded frames."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _bank(probs, worlds, dis):
+    from lidal_amd.score import FrameBank
+    bank = FrameBank(dis)
+    for p, w in zip(probs, worlds):
+        bank.add(torch.from_numpy(np.ascontiguousarray(w)).to(DEV),
+                 torch.from_numpy(np.ascontiguousarray(p)).to(DEV))
+    return bank
+
+
+def test_interframe_matches_reference_worker_func(golden_dir):
+    from lidal_amd.score import interframe
+    g = np.load(os.path.join(golden_dir, 'scoring_small.npz'))
+    nei, dis = int(g['nei_num']), float(g['dis_thresh'])
+    bank = _bank(g['probs'], g['worlds'], dis)
+    n_frames = len(bank)
+    interd, intere, cnt = interframe.score_points(bank, 0, nei)
+    ref_d, ref_e = g['interd_points_f0'], g['intere_points_f0']
+    assert np.abs(interd.cpu().numpy() - ref_d).max() <= 1e-4 * max(np.abs(ref_d).max(), 1e-12)
+    assert np.abs(intere.cpu().numpy() - ref_e).max() <= 1e-4 * np.abs(ref_e).max()
+    assert int((cnt > 0).sum()) > 50          # the fixture really exercises matches
+    for i in range(n_frames):
+        ptr, idx, lens = interframe.sv_csr(list(g['sv2point'][i]), DEV)
+        d, e, c = interframe.score_frame(bank, i, ptr, idx, nei)
+        assert np.allclose(d.cpu().numpy(), g['sv_interds'][i], rtol=1e-4, atol=1e-7), i
+        assert np.allclose(e.cpu().numpy(), g['sv_interes'][i], rtol=1e-4, atol=1e-7), i
+        assert np.allclose(c.cpu().numpy(), g['sv_centers'][i], rtol=1e-5, atol=1e-5), i
+        assert np.array_equal(lens, g['sv_pnums'][i])
+
+
+def test_interframe_matches_oracle_on_ragged_frames():
+    """Frames of different sizes, 10-neighbour window (BASELINE.json config 5)."""
+    from lidal_amd import synth
+    from lidal_amd.score import interframe
+    from oracle import scoring_ref
+    frames = synth.make_sequence(13, n_points=None, seed=3, step=0.8, n_beams=24, n_az=256)
+    rng = np.random.default_rng(0)
+    probs, worlds = [], []
+    for f in frames:
+        keep = rng.random(f['world'].shape[0]) < rng.uniform(0.6, 1.0)
+        w = f['world'][keep]
+        lg = rng.standard_normal((w.shape[0], 19)) + np.sin(w[:, :1] * 0.7) * 2
+        p = np.exp(lg - lg.max(1, keepdims=True))
+        probs.append((p / p.sum(1, keepdims=True)).astype(np.float32))
+        worlds.append(w)
+    bank = _bank(probs, worlds, 0.1)
+    matched = 0
+    for i in (0, 6, 12):
+        sv2point = synth.angular_supervoxels(worlds[i].astype(np.float32), 20)
+        rd, re, rn, rc, pd, pe = scoring_ref.score_frame(i, probs, worlds, sv2point, 10, 0.1,
+                                                         return_points=True)
+        interd, intere, cnt = interframe.score_points(bank, i, 10)
+        matched += int((cnt > 0).sum())
+        assert np.abs(interd.cpu().numpy() - pd).max() <= 1e-4 * max(np.abs(pd).max(), 1e-12)
+        assert np.abs(intere.cpu().numpy() - pe).max() <= 1e-4 * np.abs(pe).max()
+        ptr, idx, _ = interframe.sv_csr(sv2point, DEV)
+        d, e, c = interframe.score_frame(bank, i, ptr, idx, 10)
+        assert np.allclose(d.cpu().numpy(), rd, rtol=1e-4, atol=1e-7)
+        assert np.allclose(e.cpu().numpy(), re, rtol=1e-4, atol=1e-7)
+    assert matched > 1000
+
+
+def test_view_mean_softmax_matches_oracle():
+    from lidal_amd.score.prob_inference import view_mean_softmax
+    from oracle.harness_ref import inference_post
+    g = torch.Generator().manual_seed(0)
+    reps, p, c, nv = 8, 5000, 19, 3000
+    logits = torch.randn(reps * nv, c, generator=g) * 3
+    inverse = torch.cat([torch.randint(0, nv, (p,), generator=g) + v * nv for v in range(reps)])
+    prob_ref, pred_ref = inference_post(logits, inverse, reps)
+    prob, pred = view_mean_softmax(logits.to(DEV), inverse.to(DEV), reps)
+    assert np.abs(prob.cpu().numpy() - prob_ref).max() <= 1e-4 * np.abs(prob_ref).max()
+    assert (pred.cpu().numpy() == pred_ref).mean() > 0.999
+
+
+def test_prob_inference_end_to_end_vs_oracle():
+    """8 augmented views of one small frame through MinkUNet + fused post-processing vs the oracle
+    model + score/prob_inference.py:100-113 restatement."""
+    import lidal_amd
+    from lidal_amd import synth
+    from lidal_amd.network import MinkUNet
+    from lidal_amd.score import infer_frame
+    from oracle import harness_ref
+    from oracle.models_ref import MinkUNetRef
+    from weights import fill_state_dict
+    rng = np.random.default_rng(1)
+    world = synth.make_world(5)
+    pts, inten = synth.raycast_scan(world, (20.0, 0.0), rng, n_beams=16, n_az=128)
+    batch = synth.make_score_batch(pts, inten, rng, inf_reps=8)
+    coords = torch.from_numpy(batch['coords_v_b'])
+    feats = torch.from_numpy(batch['feats_v_b'])
+    inverse = torch.from_numpy(batch['inverse_indices_b'])
+    model = fill_state_dict(MinkUNet(19)).eval()
+    sd = model.state_dict()
+    prob, pred = infer_frame(model.to(DEV), coords.to(DEV), feats.to(DEV), inverse.to(DEV), 8)
+    # oracle: the same architecture restated on the CPU operators (oracle/models_ref.py)
+    ref_model = MinkUNetRef(19)
+    ref_model.load_state_dict(sd, strict=True)
+    ref_model.eval()
+    with torch.no_grad():
+        logits_ref, _ = harness_ref.forward(ref_model, feats, coords)
+    prob_ref, pred_ref = harness_ref.inference_post(logits_ref, inverse, 8)
+    assert prob.shape == prob_ref.shape
+    assert np.abs(prob.cpu().numpy() - prob_ref).max() <= 1e-4 * np.abs(prob_ref).max() + 1e-6
+    assert (pred.cpu().numpy() == pred_ref).mean() > 0.995

@@ -109,7 +109,7 @@ int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int wt_dtype, i
                            int co, void* stream);
 /* replaces backend.convolution_forward_cuda and the data-gradient half of
  * convolution_backward_cuda (every spnn.Conv3d.forward/backward, 49 per model pass).
- * Output-stationary fused gather-GEMM-accumulate:
+ * Output-stationary fused gather-GEMM with register accumulators:
  *     out[j, :] = sum_k  in[ nbr[kk][j], : ] * Wk[k]^T,   kk = kflip ? K-1-k : k
  * with Wk laid out [k][co][ci] (reduction dim contiguous), nbr i32 [k, n_out] (-1 = no rule).
  * No atomics: each output row is written exactly once => bitwise reproducible. */

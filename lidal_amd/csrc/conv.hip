@@ -1,25 +1,25 @@
 // Sparse 3D convolution for gfx950: fused gather -> MFMA GEMM -> accumulate, output-stationary.
 //
 // Dataflow (lidal_conv_apply).  One workgroup (4 waves) owns BM = 128 consecutive OUTPUT rows and
-// a BN-wide slice of the output channels, and walks the K kernel offsets:
+// a BN-wide slice of the output channels; each wave owns 32 of those rows (two 16-row MFMA groups)
+// and keeps their f32 accumulators in registers while the workgroup walks the K kernel offsets:
 //
-//   per offset k   1. the 128 entries nbr[k][r0 .. r0+127] (input row or -1) are read coalesced
-//                     and COMPACTED with a wave ballot + prefix sum into an LDS list of the
-//                     rows that have a rule  (on LiDAR surfaces ~25 % of the 27 offsets are
-//                     occupied, so dense tiles would waste ~4x of the MFMA work);
-//                  2. W[k] (reduction dim contiguous, pre-packed) is staged into LDS once for
-//                     the whole workgroup;
-//                  3. groups of 16 compacted rows x 16*NBW output channels form MFMA items that
-//                     the four waves share.  A-fragments are gathered STRAIGHT from HBM/L2 into
-//                     registers (16 B per lane, 64 B contiguous per row, no LDS round trip:
-//                     every A element is used by exactly one wave); B-fragments are
-//                     ds_read_b128 from the staged weights;  v_mfma_f32_16x16x4_f32 (exact f32)
-//                     or v_mfma_f32_16x16x32_bf16;
-//                  4. the 16x16 results are added into the f32 output tile held in LDS at the
-//                     rows the compaction recorded (rows are unique inside one offset and a
-//                     barrier separates offsets => fixed summation order).
-//   finally         the LDS tile is written to HBM once, coalesced.  No atomics anywhere, so
-//                   results are bitwise reproducible and every output byte is written once.
+//   prologue       the wave's slice of the neighbour table nbr[k][rows] (input row or -1) is read
+//                  once, coalesced, into LDS;
+//   per offset k   1. W[k] (reduction dim contiguous, pre-packed) is staged into LDS once for the
+//                     whole workgroup, double-buffered: global->registers before the MFMAs of the
+//                     current offset, registers->LDS after them, ONE barrier per offset;
+//                  2. A-fragments are gathered STRAIGHT from HBM/L2 into registers (16 B per lane,
+//                     64 B contiguous per gathered row, zero for rows without a rule; no LDS round
+//                     trip: every A element is used by exactly one wave), one offset ahead of use;
+//                  3. B-fragments are ds_read_b128 from the staged weights and feed both row
+//                     groups: v_mfma_f32_16x16x32_bf16 or v_mfma_f32_16x16x4_f32 (exact f32);
+//                     a row group with no rule at this offset skips its MFMAs;
+//   epilogue       accumulators -> wave-private LDS tile -> whole output rows, 16-byte stores.
+//
+// No atomics and no LDS accumulation: each output row is produced by one wave in a fixed offset
+// order, so results are bitwise reproducible and every output byte is written exactly once.
+// LDS holds only the two weight slabs + the index slices (< 64 KB), so 2-3 workgroups share a CU.
 //
 // The same kernel serves forward, data-gradient and transposed convolution: only the neighbour
 // table and the weight layout differ (see lidal_amd/nn/functional/conv.py).
@@ -86,157 +86,201 @@ __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b
 // ------------------------------------------------------------------------------------------
 // conv_apply
 // ------------------------------------------------------------------------------------------
-// LDS layout (dynamic): [accum f32 BM x ASTRIDE][weights T BN x WSTRIDE][cidx int BM][crow int BM]
-template <typename T, int NBW, int NSPLIT, int ROW_BYTES>
+constexpr int MAXK = 32;         // kernel volume limit (27 and 8 on this path)
+constexpr int G = 2;             // 16-row groups per wave  => BM = 4 waves * G * 16 = 128 rows
+
+// Timing-only ablation builds (scripts/ablate_conv.py): -DLIDAL_ABLATE=<mask> removes one cost at a
+// time; results are wrong by construction.  1: no A gather  2: no weight staging  4: no MFMA
+// 16: no epilogue store
+#ifndef LIDAL_ABLATE
+#define LIDAL_ABLATE 0
+#endif
+
+// LDS layout (dynamic): weights T [2][BN][WSTRIDE] | nidx int [4 waves][K][G*16]
+// (the weight region is re-used as the epilogue staging tile)
+template <typename T, int NB, int ROW_BYTES>
 __global__ void __launch_bounds__(NTHREADS)
 conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
                   T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip) {
-  constexpr int BN = 16 * NBW * NSPLIT;
+  constexpr int BN = 16 * NB;
   constexpr int VEC = DT<T>::VEC;
   constexpr int CH = DT<T>::CH;
   constexpr int KC = ROW_BYTES / (int)sizeof(T);        // staged reduction elements per pass
-  constexpr int MAXCC = KC / CH;                         // A lane-loads per pass (4)
+  constexpr int MAXCC = KC / CH;                         // A lane-loads per pass and row group
   constexpr int WSTRIDE = KC + VEC;                      // +16 B pad
-  constexpr int ASTRIDE = BN + 16;
+  constexpr int SEGS = KC / VEC;                         // 16-byte segments per staged weight row
+  constexpr int WPT = (BN * SEGS + NTHREADS - 1) / NTHREADS;   // staged segments per thread
+  constexpr int RW = G * 16;                             // rows per wave
+  constexpr int ESTRIDE = BN + VEC;                      // epilogue tile row stride (elements)
+  constexpr int WREGION = (2 * BN * WSTRIDE > NWAVES * RW * ESTRIDE) ? 2 * BN * WSTRIDE
+                                                                       : NWAVES * RW * ESTRIDE;
   typedef typename DT<T>::frag frag;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* accum = reinterpret_cast<float*>(smem);
-  T* wl = reinterpret_cast<T*>(smem + sizeof(float) * BM * ASTRIDE);
-  int* cidx = reinterpret_cast<int*>(smem + sizeof(float) * BM * ASTRIDE + sizeof(T) * BN * WSTRIDE);
-  int* crow = cidx + BM;
-  __shared__ int wave_cnt[NWAVES];
+  T* wl = reinterpret_cast<T*>(smem);
+  int* nidx_all = reinterpret_cast<int*>(smem + sizeof(T) * WREGION);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int row16 = lane & 15;
   const int gsel = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * BM;
+  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * RW;   // first row of this wave
   const int n0 = blockIdx.y * BN;
+  const int npass = (ci + KC - 1) / KC;
+  const int nphase = K * npass;
+  int* nidx = nidx_all + wave * K * RW;                      // [K][RW], wave-private
 
-  for (int i = tid; i < BM * ASTRIDE; i += NTHREADS) accum[i] = 0.f;
-
-  for (int k = 0; k < K; ++k) {
+  // ---- 0. this wave's slice of the neighbour table -> LDS (K*RW independent coalesced loads)
+  for (int i = lane; i < K * RW; i += 64) {
+    const int k = i / RW, r = i - k * RW;
     const int kk = kflip ? (K - 1 - k) : k;
-    // ---- 1. compaction of the rows that have a rule for this offset
-    int idx = -1;
-    if (tid < BM && r0 + tid < n_out) idx = nbr[(int64_t)kk * n_out + r0 + tid];
-    const bool keep = idx >= 0;
-    const unsigned long long m = __ballot(keep);
-    const int rank = ballot_rank(m);
-    if (lane == 0) wave_cnt[wave] = __popcll(m);
-    __syncthreads();   // also: every wave is done with the previous offset's lists / weights
-    int off = 0, n_k = 0;
-#pragma unroll
-    for (int w = 0; w < NWAVES; ++w) {
-      int c = wave_cnt[w];
-      if (w < wave) off += c;
-      n_k += c;
-    }
-    if (n_k == 0) { __syncthreads(); continue; }
-    if (keep) { cidx[off + rank] = idx; crow[off + rank] = tid; }
-    const int ngroups = (n_k + 15) >> 4;
-    const int nitems = ngroups * NSPLIT;
+    nidx[i] = (r0 + r < n_out) ? nbr[(int64_t)kk * n_out + r0 + r] : -1;
+  }
 
-    for (int c0 = 0; c0 < ci; c0 += KC) {
-      const int kc = min(KC, ci - c0);
-      // ---- 2. stage Wk[k][n0 .. n0+BN][c0 .. c0+kc] -> LDS (zero padded to a multiple of CH)
-      if (c0 > 0) __syncthreads();           // previous pass's readers are done
-      {
-        const int kc_pad = ((kc + CH - 1) / CH) * CH;
-        const int segs = kc_pad / VEC;       // 16-byte segments per row
-        const T* wsrc = wk + ((int64_t)k * co + n0) * ci + c0;
-        for (int sidx = tid; sidx < BN * segs; sidx += NTHREADS) {
-          int col = sidx / segs, sg = sidx - col * segs;
-          int x = sg * VEC;
-          frag v = DT<T>::zero();
-          if (n0 + col < co) v = load_frag_guarded<T>(wsrc + (int64_t)col * ci + x, kc - x);
-          *reinterpret_cast<frag*>(wl + col * WSTRIDE + x) = v;
+  // weight slab of phase p -> registers (issue early) -> LDS buffer (write late)
+  frag wreg[WPT];
+  auto stage_load = [&](int p) {
+    const int k = p / npass, c0 = (p - k * npass) * KC;
+    const int kc = min(KC, ci - c0);
+    const T* wsrc = wk + ((int64_t)k * co + n0) * ci + c0;
+#pragma unroll
+    for (int t = 0; t < WPT; ++t) {
+      const int sidx = tid + t * NTHREADS;
+      const int col = sidx / SEGS, x = (sidx - col * SEGS) * VEC;
+      wreg[t] = DT<T>::zero();
+      if (!(LIDAL_ABLATE & 2))
+        if (sidx < BN * SEGS && n0 + col < co && x < kc)
+          wreg[t] = load_frag_guarded<T>(wsrc + (int64_t)col * ci + x, kc - x);
+    }
+  };
+  auto stage_store = [&](int buf) {
+    T* dstw = wl + buf * BN * WSTRIDE;
+#pragma unroll
+    for (int t = 0; t < WPT; ++t) {
+      const int sidx = tid + t * NTHREADS;
+      const int col = sidx / SEGS, x = (sidx - col * SEGS) * VEC;
+      if (sidx < BN * SEGS) *reinterpret_cast<frag*>(dstw + col * WSTRIDE + x) = wreg[t];
+    }
+  };
+  // A fragments of phase p: for each row group 16 gathered input rows x kc channels, straight to
+  // VGPRs (16 B per lane, 64 B contiguous per row); `present` = ballot of rows that have a rule
+  auto load_a = [&](frag (&a)[G][MAXCC], unsigned long long (&present)[G], int p) {
+    const int k = p / npass, c0 = (p - k * npass) * KC;
+    const int kc = min(KC, ci - c0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int src = nidx[k * RW + g * 16 + row16];
+      present[g] = __ballot(src >= 0);
+#pragma unroll
+      for (int cc = 0; cc < MAXCC; ++cc) {
+        a[g][cc] = DT<T>::zero();
+        const int x = cc * CH + gsel * VEC;
+        if (!(LIDAL_ABLATE & 1))
+          if (src >= 0 && x < kc)
+            a[g][cc] = load_frag_guarded<T>(in + (int64_t)src * ci + c0 + x, kc - x);
+      }
+    }
+  };
+
+  f32x4 acc[G][NB];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();            // slab 0 and the neighbour slices are visible
+
+  frag a_cur[G][MAXCC], a_nxt[G][MAXCC];
+  unsigned long long pres_cur[G], pres_nxt[G];
+  load_a(a_cur, pres_cur, 0);
+
+  for (int p = 0; p < nphase; ++p) {
+    const int k = p / npass, c0 = (p - k * npass) * KC;
+    const int kc = min(KC, ci - c0);
+    const T* wbuf = wl + (p & 1) * BN * WSTRIDE;
+    const bool more = p + 1 < nphase;
+    // ---- next phase's weight slab and A fragments go in flight before this phase's MFMAs
+    if (more) {
+      stage_load(p + 1);
+      load_a(a_nxt, pres_nxt, p + 1);
+    }
+    // ---- MFMAs: every B fragment read from LDS feeds the G row groups (skipped when a group has
+    //      no rule for this offset); accumulators stay in registers for all K offsets
+    if (!(LIDAL_ABLATE & 4)) {
+      const T* wbase = wbuf + row16 * WSTRIDE + gsel * VEC;
+#pragma unroll
+      for (int cc = 0; cc < MAXCC; ++cc) {
+        if (cc * CH < kc) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            frag b = *reinterpret_cast<const frag*>(wbase + nb * 16 * WSTRIDE + cc * CH);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              if (pres_cur[g] != 0ull) mma(acc[g][nb], a_cur[g][cc], b);
+          }
         }
       }
-      __syncthreads();
-      // ---- 3. MFMA items
-      for (int item = wave; item < nitems; item += NWAVES) {
-        const int g = item / NSPLIT, h = item - g * NSPLIT;
-        const int p = g * 16 + row16;
-        const int src = (p < n_k) ? cidx[p] : -1;
-        frag a[MAXCC];
+    }
+    if (more) {
+      stage_store((p + 1) & 1);
 #pragma unroll
-        for (int cc = 0; cc < MAXCC; ++cc) {
-          a[cc] = DT<T>::zero();
-          const int x = cc * CH + gsel * VEC;
-          if (cc * CH < kc && src >= 0 && x < kc)
-            a[cc] = load_frag_guarded<T>(in + (int64_t)src * ci + c0 + x, kc - x);
-        }
-        f32x4 acc[NBW];
+      for (int g = 0; g < G; ++g) {
+        pres_cur[g] = pres_nxt[g];
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const T* wbase = wl + ((h * NBW) * 16 + row16) * WSTRIDE + gsel * VEC;
-#pragma unroll
-        for (int cc = 0; cc < MAXCC; ++cc) {
-          if (cc * CH < kc) {
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) {
-              frag b = *reinterpret_cast<const frag*>(wbase + nb * 16 * WSTRIDE + cc * CH);
-              mma(acc[nb], a[cc], b);
-            }
-          }
-        }
-        // ---- 4. accumulate into the LDS output tile (row = 4*gsel + r of the group)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int pr = g * 16 + gsel * 4 + r;
-          if (pr < n_k) {
-            float* dst = accum + crow[pr] * ASTRIDE + (h * NBW) * 16 + row16;
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) dst[nb * 16] += acc[nb][r];
-          }
-        }
+        for (int cc = 0; cc < MAXCC; ++cc) a_cur[g][cc] = a_nxt[g][cc];
       }
     }
     __syncthreads();
   }
 
-  // ---- epilogue: LDS tile -> HBM, coalesced along channels
-  __syncthreads();
-  constexpr int SEG = 4;   // channels per thread store
-  const int segs = BN / SEG;
-  for (int i = tid; i < BM * segs; i += NTHREADS) {
-    int r = i / segs, cseg = (i - r * segs) * SEG;
-    int64_t row = r0 + r;
-    if (row >= n_out) continue;
-    const float* srcp = accum + r * ASTRIDE + cseg;
-    T* dst = out + row * co + n0 + cseg;
-    if (n0 + cseg + SEG <= co) {
-      if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{srcp[0], srcp[1], srcp[2], srcp[3]};
-      } else {
+  // ---- epilogue: accumulators (D layout: col = lane&15, row = 4*(lane>>4) + r) -> wave-private
+  //      LDS tile in T -> whole rows to HBM with 16-byte stores
+  if (LIDAL_ABLATE & 16) return;
+  T* et = wl + wave * RW * ESTRIDE;
 #pragma unroll
-        for (int e = 0; e < SEG; ++e) dst[e] = DT<T>::from_f32(srcp[e]);
-      }
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        et[(g * 16 + gsel * 4 + r) * ESTRIDE + nb * 16 + row16] = DT<T>::from_f32(acc[g][nb][r]);
+  __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): wave-private tile written
+  constexpr int RSEGS = BN / VEC;                          // 16-byte segments per row
+  for (int i = lane; i < RW * RSEGS; i += 64) {
+    const int r = i / RSEGS, cseg = (i - r * RSEGS) * VEC;
+    const int64_t row = r0 + r;
+    if (row >= n_out) continue;
+    T* dst = out + row * co + n0 + cseg;
+    const T* srcp = et + r * ESTRIDE + cseg;
+    if (n0 + cseg + VEC <= co) {
+      *reinterpret_cast<frag*>(dst) = *reinterpret_cast<const frag*>(srcp);
     } else {
 #pragma unroll
-      for (int e = 0; e < SEG; ++e)
-        if (n0 + cseg + e < co) dst[e] = DT<T>::from_f32(srcp[e]);
+      for (int e = 0; e < VEC; ++e)
+        if (n0 + cseg + e < co) dst[e] = srcp[e];
     }
   }
 }
 
-template <typename T, int NBW, int NSPLIT, int ROW_BYTES>
+template <typename T, int NB, int ROW_BYTES>
 int launch_conv_apply(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
                       int ci, int co, int K, int kflip, hipStream_t s) {
-  constexpr int BN = 16 * NBW * NSPLIT;
+  constexpr int BN = 16 * NB;
   constexpr int KC = ROW_BYTES / (int)sizeof(T);
   constexpr int WSTRIDE = KC + DT<T>::VEC;
-  constexpr int ASTRIDE = BN + 16;
-  const size_t lds = sizeof(float) * BM * ASTRIDE + sizeof(T) * BN * WSTRIDE + sizeof(int) * 2 * BM;
-  auto kern = conv_apply_kernel<T, NBW, NSPLIT, ROW_BYTES>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  constexpr int ESTRIDE = BN + DT<T>::VEC;
+  constexpr int WREGION = (2 * BN * WSTRIDE > NWAVES * G * 16 * ESTRIDE) ? 2 * BN * WSTRIDE
+                                                                           : NWAVES * G * 16 * ESTRIDE;
+  const size_t lds = sizeof(T) * WREGION + (size_t)NWAVES * K * G * 16 * sizeof(int);
+  auto kern = conv_apply_kernel<T, NB, ROW_BYTES>;
+  static size_t attr_set = 0;
+  if (attr_set < lds) {
     LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set = lds;
   }
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
   kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, (T*)out, n_out, ci, co, K,
@@ -248,14 +292,12 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, void* out,
 template <typename T, int ROW_BYTES>
 int dispatch_conv_tile(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
                        int ci, int co, int K, int kflip, hipStream_t s) {
-  // BN = 16*NBW*NSPLIT output channels per workgroup; grid.y covers the rest.
-  if (co <= 32)
-    return launch_conv_apply<T, 1, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
-  if (co <= 64)
-    return launch_conv_apply<T, 2, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  // BN = 16*NB output channels per workgroup; grid.y covers the rest.
+  if (co <= 32) return launch_conv_apply<T, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  if (co <= 64) return launch_conv_apply<T, 4, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
   if (co % 128 != 0 && (co % 96 == 0 || co < 128))
-    return launch_conv_apply<T, 3, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
-  return launch_conv_apply<T, 4, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 6, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  return launch_conv_apply<T, 8, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
 }
 
 template <typename T>
@@ -468,7 +510,7 @@ extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* n
                                 void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out == 0 || co == 0) return 0;
-  LIDAL_REQUIRE(ci > 0 && k > 0, "conv_apply: bad shape ci=%d k=%d", ci, k);
+  LIDAL_REQUIRE(ci > 0 && k > 0 && k <= MAXK, "conv_apply: bad shape ci=%d k=%d", ci, k);
   if (dtype == LIDAL_F32) {
     LIDAL_REQUIRE(ci % 4 == 0 && co % 4 == 0, "conv_apply f32: channels must be multiples of 4");
     return dispatch_conv_apply<float>(in, wk, nbr, out, n_out, ci, co, k, kflip, s);

@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(256) kmap_invert_kernel(const int* __restrict_
   if (i >= 0) nbr_in[(int64_t)k * n_in + i] = (int)j;
 }
 
+
 }  // namespace
 
 extern "C" int64_t lidal_unique_workspace_bytes(int64_t n) {

@@ -7,7 +7,7 @@ network/spvcnn.py:22,24).  Three cases, as upstream:
   * transposed              -> re-uses the map of the matching strided conv with roles swapped
 
 KernelMap holds what torchsparse keeps ([nbmaps, nbsizes, (n_in, n_out)], same order and
-values) plus the neighbour tables the output-stationary kernel consumes:
+values) plus what the output-stationary kernel consumes:
   nbr_out [K, n_out]  input row feeding output row j through offset k (-1: none)
   nbr_in  [K, n_in]   output row fed by input row i through offset k (built lazily)
 """
@@ -100,9 +100,10 @@ def _pack_weight(weight, dtype):
     return wt
 
 
-def _apply(feats, wk, table, n_out, kflip):
-    """out[j] = sum_k feats[table[kk][j]] @ wk[k]^T with wk [K, co, ci]."""
+def _apply(feats, wk, table, kflip):
+    """out[j] = sum_k feats[table[kk][j]] @ wk[k]^T with wk [K, co, ci], table i32 [K, n_out]."""
     k, co, ci = wk.shape
+    n_out = table.shape[1]
     out = torch.empty((n_out, co), dtype=feats.dtype, device=feats.device)
     B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(table), B.ptr(out), n_out, ci,
                                      co, k, int(kflip), B.dtype_code(feats.dtype), B.stream()),
@@ -129,11 +130,8 @@ class ConvolutionFunction(Function):
             cdtype = torch.float32
         x = feats.contiguous().to(cdtype)
         n_in, n_out = kmap.sizes
-        if not transposed:
-            table, rows = kmap.nbr_out, n_out
-        else:
-            table, rows = kmap.nbr_in, n_in
-        out = _apply(x, _pack_weight(weight, cdtype), table, rows, 0)
+        table = kmap.nbr_in if transposed else kmap.nbr_out
+        out = _apply(x, _pack_weight(weight, cdtype), table, 0)
         ctx.kmap = kmap
         ctx.transposed = transposed
         ctx.save_for_backward(x, weight)
@@ -152,11 +150,11 @@ class ConvolutionFunction(Function):
             wk = weight.detach().contiguous().to(x.dtype)
             if not transposed:
                 if kmap.symmetric:
-                    grad_in = _apply(g, wk, kmap.nbr_out, n_in, 1)
+                    grad_in = _apply(g, wk, kmap.nbr_out, 1)
                 else:
-                    grad_in = _apply(g, wk, kmap.nbr_in, n_in, 0)
+                    grad_in = _apply(g, wk, kmap.nbr_in, 0)
             else:
-                grad_in = _apply(g, wk, kmap.nbr_out, n_out, 0)
+                grad_in = _apply(g, wk, kmap.nbr_out, 0)
         if ctx.needs_input_grad[1]:
             k, ci, co = weight.shape
             splits = _wgrad_splits(kmap.volume * max(n_out, 1) // 4, k, ci, co)

@@ -117,11 +117,12 @@ int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, void* o
                      int64_t n_out, int ci, int co, int k, int kflip, int dtype, void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
- * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  `partial` f32 [splits][k][ca][cb] scratch;
- * reduced in a fixed order => bitwise reproducible. */
+ * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  Split-K: offset k with nk rules is cut into
+ * min(splits, ceil(nk / target_chunk)) slabs; `partial` f32 [splits][k][ca][cb] scratch holds the
+ * slabs, which are reduced in a fixed order => bitwise reproducible. */
 int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs, const int64_t* koff,
-                     int a_col, float* gw, float* partial, int splits, int k, int ca, int cb,
-                     int dtype, void* stream);
+                     int a_col, float* gw, float* partial, int splits, int target_chunk, int k,
+                     int ca, int cb, int dtype, void* stream);
 
 /* ---- probability inference post-processing ------------------------------------------------- */
 /* replaces score/prob_inference.py:100-113: logits f32 [nv, c] of `reps` collated views,

@@ -43,7 +43,7 @@ SIGNATURES = {
     'lidal_ti_weights': (_i32, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp]),
     'lidal_conv_weight_pack': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
-    'lidal_conv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+    'lidal_conv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                 _vp]),
     'lidal_view_mean_softmax': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'lidal_nn_grid_bytes': (_i64, [_i64]),

@@ -338,14 +338,24 @@ __global__ void __launch_bounds__(256) weight_pack_kernel(const TI* __restrict__
 // ------------------------------------------------------------------------------------------
 // wgrad: gw[k][ca][cb] = sum_p a[pa(p)][:]^T b[pb(p)][:]
 // ------------------------------------------------------------------------------------------
-constexpr int BP = 32;   // rules per staging step
+constexpr int BP = 32;   // rules per staging step (f32 kernel)
+
+// Split-K policy shared by both wgrad kernels and the reducer: offset k with nk rules is cut into
+// ceil(nk / target_chunk) slabs (at least 1, at most the `splits` slabs the caller allocated), so
+// the centre offset (every row has a rule) gets proportionally more workgroups than the others.
+__host__ __device__ __forceinline__ int splits_for(int64_t nk, int max_splits, int target_chunk) {
+  int64_t s = (nk + target_chunk - 1) / target_chunk;
+  if (s < 1) s = 1;
+  if (s > max_splits) s = max_splits;
+  return (int)s;
+}
 
 // workgroup tile: (2*MI*16) x (2*NI*16) of gw[k]; waves as 2 x 2.
 template <typename T, int MI, int NI>
 __global__ void __launch_bounds__(NTHREADS)
 conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* __restrict__ pairs,
                   const int64_t* __restrict__ koff, int a_col, float* __restrict__ partial,
-                  int K, int ca, int cb, int tiles_b) {
+                  int K, int ca, int cb, int tiles_b, int target_chunk) {
   constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
   constexpr int SA = TA + 4, SB = TB + 4;      // LDS row strides (floats)
   __shared__ __attribute__((aligned(16))) float la[BP * SA];
@@ -362,7 +372,9 @@ conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* 
 
   const int64_t beg = koff[k], end = koff[k + 1];
   const int64_t nk = end - beg;
-  int64_t chunk = (nk + nsplit - 1) / nsplit;
+  const int used = splits_for(nk, nsplit, target_chunk);
+  if (split >= used) return;                   // the reducer only reads `used` slabs of offset k
+  int64_t chunk = (nk + used - 1) / used;
   chunk = ((chunk + BP - 1) / BP) * BP;
   const int64_t p_beg = beg + (int64_t)split * chunk;
   const int64_t p_end = (p_beg + chunk < end) ? (p_beg + chunk) : end;
@@ -437,24 +449,200 @@ conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* 
 }
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial,
-                                                           float* __restrict__ gw, int64_t n,
-                                                           int splits) {
+                                                           const int64_t* __restrict__ koff,
+                                                           float* __restrict__ gw, int K,
+                                                           int64_t per_k, int splits,
+                                                           int target_chunk) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= (int64_t)K * per_k) return;
+  const int k = (int)(i / per_k);
+  const int used = splits_for(koff[k + 1] - koff[k], splits, target_chunk);
   float s = 0.f;
-  for (int sp = 0; sp < splits; ++sp) s += partial[(int64_t)sp * n + i];
+  for (int sp = 0; sp < used; ++sp) s += partial[(int64_t)sp * K * per_k + i];   // fixed order
   gw[i] = s;
+}
+
+// ---- bf16 wgrad: v_mfma_f32_16x16x32_bf16 with both operands read TRANSPOSED from LDS ----------
+// gw[k][i][j] = sum_p A[p][i] B[p][j]: the reduction index p (rule) is the LDS tile ROW of both
+// gathered operands, while the MFMA wants 8 consecutive p per lane.  ds_read_b64_tr_b16 delivers
+// exactly that from the row-major tiles the 16-byte gathers produce, so no transposing store is
+// needed.  BPB = 64 rules per step (two MFMA k-steps), LDS tiles double-buffered, gathered rows of
+// the next step are in flight in registers while this step's MFMAs run; one barrier per step.
+constexpr int BPB = 64;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+template <int MI, int NI>
+__global__ void __launch_bounds__(NTHREADS)
+conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
+                       const int2* __restrict__ pairs, const int64_t* __restrict__ koff, int a_col,
+                       float* __restrict__ partial, int K, int ca, int cb, int tiles_b,
+                       int target_chunk) {
+  constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
+  constexpr int SA = TA + 8, SB = TB + 8;              // LDS row strides (bf16), +16 B pad
+  constexpr int SEG_A = TA / 8, SEG_B = TB / 8;        // 16-byte segments per gathered row
+  constexpr int PT_A = (BPB * SEG_A) / NTHREADS, PT_B = (BPB * SEG_B) / NTHREADS;
+  static_assert((BPB * SEG_A) % NTHREADS == 0 && (BPB * SEG_B) % NTHREADS == 0, "tile/threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* la = reinterpret_cast<__bf16*>(smem);                       // [2][BPB][SA]
+  __bf16* lb = la + 2 * BPB * SA;                                     // [2][BPB][SB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row16 = lane & 15, gsel = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int split = blockIdx.x, nsplit = gridDim.x;
+  const int k = blockIdx.y;
+  const int ta = blockIdx.z / tiles_b, tb = blockIdx.z - ta * tiles_b;
+  const int ca0 = ta * TA, cb0 = tb * TB;
+
+  const int64_t beg = koff[k], end = koff[k + 1];
+  const int64_t nk = end - beg;
+  const int used = splits_for(nk, nsplit, target_chunk);
+  if (split >= used) return;
+  int64_t chunk = (nk + used - 1) / used;
+  chunk = ((chunk + BPB - 1) / BPB) * BPB;
+  const int64_t p_beg = beg + (int64_t)split * chunk;
+  const int64_t p_end = (p_beg + chunk < end) ? (p_beg + chunk) : end;
+  const int nsteps = (int)((p_end - p_beg + BPB - 1) / BPB);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: thread t owns segments t, t+256, ... of the [BPB][SEG] tile; row = seg / SEG
+  bf16x8 ra[PT_A], rb[PT_B];
+  int ia[PT_A], ib[PT_B];                   // gathered row ids of the step being loaded
+  auto load_ids = [&](int step) {
+    const int64_t p0 = p_beg + (int64_t)step * BPB;
+#pragma unroll
+    for (int t = 0; t < PT_A; ++t) {
+      const int row = (tid + t * NTHREADS) / SEG_A;
+      int2 pr = (p0 + row < p_end) ? pairs[p0 + row] : make_int2(-1, -1);
+      ia[t] = a_col ? pr.y : pr.x;
+    }
+#pragma unroll
+    for (int t = 0; t < PT_B; ++t) {
+      const int row = (tid + t * NTHREADS) / SEG_B;
+      int2 pr = (p0 + row < p_end) ? pairs[p0 + row] : make_int2(-1, -1);
+      ib[t] = a_col ? pr.x : pr.y;
+    }
+  };
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int t = 0; t < PT_A; ++t) {
+      const int sg = tid + t * NTHREADS, c = (sg % SEG_A) * 8;
+      ra[t] = DT<__bf16>::zero();
+      if (ia[t] >= 0 && ca0 + c < ca)
+        ra[t] = load_frag_guarded<__bf16>(a + (int64_t)ia[t] * ca + ca0 + c, ca - ca0 - c);
+    }
+#pragma unroll
+    for (int t = 0; t < PT_B; ++t) {
+      const int sg = tid + t * NTHREADS, c = (sg % SEG_B) * 8;
+      rb[t] = DT<__bf16>::zero();
+      if (ib[t] >= 0 && cb0 + c < cb)
+        rb[t] = load_frag_guarded<__bf16>(b + (int64_t)ib[t] * cb + cb0 + c, cb - cb0 - c);
+    }
+  };
+  auto store_rows = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < PT_A; ++t) {
+      const int sg = tid + t * NTHREADS, row = sg / SEG_A, c = (sg % SEG_A) * 8;
+      *reinterpret_cast<bf16x8*>(la + (buf * BPB + row) * SA + c) = ra[t];
+    }
+#pragma unroll
+    for (int t = 0; t < PT_B; ++t) {
+      const int sg = tid + t * NTHREADS, row = sg / SEG_B, c = (sg % SEG_B) * 8;
+      *reinterpret_cast<bf16x8*>(lb + (buf * BPB + row) * SB + c) = rb[t];
+    }
+  };
+
+  if (nsteps > 0) {
+    load_ids(0);
+    load_rows();
+    if (nsteps > 1) load_ids(1);
+    store_rows(0);
+  }
+  __syncthreads();
+
+  // transposed-read addressing (T10): lane 4q+pp of each 16-lane group supplies the address of tile
+  // row (8*gsel + q [+4]) at columns 4*pp..4*pp+3 of the 16-column block; lane i receives column i.
+  const int q = row16 >> 2, pp = row16 & 3;
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) {
+      load_rows();                                   // rows of step+1 (ids loaded a step earlier)
+      if (step + 2 < nsteps) load_ids(step + 2);
+    }
+    const __bf16* ta_ = la + buf * BPB * SA;
+    const __bf16* tb_ = lb + buf * BPB * SB;
+#pragma unroll
+    for (int ks = 0; ks < BPB / 32; ++ks) {
+      const int prow = ks * 32 + 8 * gsel + q;
+      bf16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const __bf16* base = ta_ + prow * SA + (wr * MI + mi) * 16 + 4 * pp;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(base));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(base + 4 * SA));
+        af[mi] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const __bf16* base = tb_ + prow * SB + (wc * NI + ni) * 16 + 4 * pp;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(base));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(base + 4 * SB));
+        bf[ni] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (step + 1 < nsteps) store_rows(buf ^ 1);
+    __syncthreads();
+  }
+  float* dst = partial + ((int64_t)split * K + k) * ca * cb;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = ca0 + (wr * MI + mi) * 16 + gsel * 4 + r;
+        int j = cb0 + (wc * NI + ni) * 16 + row16;
+        if (i < ca && j < cb) dst[(int64_t)i * cb + j] = acc[mi][ni][r];
+      }
 }
 
 template <typename T, int MI, int NI>
 int launch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* koff, int a_col,
-                 float* partial, int splits, int K, int ca, int cb, hipStream_t s) {
+                 float* partial, int splits, int target_chunk, int K, int ca, int cb,
+                 hipStream_t s) {
   constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
   int tiles_a = (int)cdiv(ca, TA), tiles_b = (int)cdiv(cb, TB);
   dim3 grid((unsigned)splits, (unsigned)K, (unsigned)(tiles_a * tiles_b));
-  conv_wgrad_kernel<T, MI, NI><<<grid, NTHREADS, 0, s>>>((const T*)a, (const T*)b,
-                                                         (const int2*)pairs, koff, a_col, partial,
-                                                         K, ca, cb, tiles_b);
+  if constexpr (sizeof(T) == 2) {
+    const size_t lds = 2 * BPB * ((TA + 8) + (TB + 8)) * sizeof(__bf16);
+    auto kern = conv_wgrad_bf16_kernel<MI, NI>;
+    static size_t attr_set = 0;
+    if (attr_set < lds) {
+      LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = lds;
+    }
+    kern<<<grid, NTHREADS, lds, s>>>((const __bf16*)a, (const __bf16*)b, (const int2*)pairs, koff,
+                                     a_col, partial, K, ca, cb, tiles_b, target_chunk);
+  } else {
+    conv_wgrad_kernel<T, MI, NI><<<grid, NTHREADS, 0, s>>>((const T*)a, (const T*)b,
+                                                           (const int2*)pairs, koff, a_col, partial,
+                                                           K, ca, cb, tiles_b, target_chunk);
+  }
   LIDAL_CHECK_LAUNCH("lidal_conv_wgrad");
   return 0;
 }
@@ -469,10 +657,11 @@ static inline int pick_blocks(int c) {   // 16-wide blocks per wave along one di
 
 template <typename T>
 int dispatch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* koff, int a_col,
-                   float* partial, int splits, int K, int ca, int cb, hipStream_t s) {
+                   float* partial, int splits, int target_chunk, int K, int ca, int cb,
+                   hipStream_t s) {
   int mi = pick_blocks(ca), ni = pick_blocks(cb);
 #define WG_CASE(M, N) \
-  if (mi == M && ni == N) return launch_wgrad<T, M, N>(a, b, pairs, koff, a_col, partial, splits, K, ca, cb, s);
+  if (mi == M && ni == N) return launch_wgrad<T, M, N>(a, b, pairs, koff, a_col, partial, splits, target_chunk, K, ca, cb, s);
   WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
   WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4)
   WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4)
@@ -526,22 +715,25 @@ extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* n
 
 extern "C" int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs,
                                 const int64_t* koff, int a_col, float* gw, float* partial,
-                                int splits, int k, int ca, int cb, int dtype, void* stream) {
+                                int splits, int target_chunk, int k, int ca, int cb, int dtype,
+                                void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (k == 0 || ca == 0 || cb == 0) return 0;
-  LIDAL_REQUIRE(splits >= 1, "wgrad: splits must be >= 1");
+  LIDAL_REQUIRE(splits >= 1 && target_chunk >= 64, "wgrad: splits >= 1 and target_chunk >= 64");
   int rc;
   if (dtype == LIDAL_F32)
-    rc = dispatch_wgrad<float>(a, b, pairs, koff, a_col, partial, splits, k, ca, cb, s);
+    rc = dispatch_wgrad<float>(a, b, pairs, koff, a_col, partial, splits, target_chunk, k, ca, cb, s);
   else if (dtype == LIDAL_BF16)
-    rc = dispatch_wgrad<__bf16>(a, b, pairs, koff, a_col, partial, splits, k, ca, cb, s);
+    rc = dispatch_wgrad<__bf16>(a, b, pairs, koff, a_col, partial, splits, target_chunk, k, ca, cb, s);
   else {
     set_error("wgrad: bad dtype %d", dtype);
     return 2;
   }
   if (rc) return rc;
   int64_t n = (int64_t)k * ca * cb;
-  wgrad_reduce_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>(partial, gw, n, splits);
+  wgrad_reduce_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>(partial, koff, gw, k,
+                                                             (int64_t)ca * cb, splits,
+                                                             target_chunk);
   LIDAL_CHECK_LAUNCH("wgrad_reduce");
   return 0;
 }

@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) devoxelize_fwd_kernel(const float* __rest
     int pos = idx[i * 8 + k];
     if (pos < 0 || pos >= m) continue;
     float wk = w[i * 8 + k];
+    if (wk == 0.f) continue;        // exact zeros: points on a cell face/corner (all of stride 1)
     const float* src = feat + (int64_t)pos * c + j;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] += wk * src[v];
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(256) devoxelize_bwd_kernel(const float* __rest
     int pos = idx[i * 8 + k];
     if (pos < 0 || pos >= m) continue;
     float wk = w[i * 8 + k];
+    if (wk == 0.f) continue;
     float* dst = gin + (int64_t)pos * c + j;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) atomicAdd(&dst[v], wk * g[v]);

@@ -111,14 +111,12 @@ def _apply(feats, wk, table, kflip):
     return out
 
 
-def _wgrad_splits(total_rules, volume, ca, cb):
-    """Enough (split, k, tile) workgroups to cover the 256 CUs a few times over."""
-    def tile(c):
-        return 32 if c <= 32 else 64 if c <= 64 else 128 if c % 128 == 0 else 96 if (c % 96 == 0 or c < 128) else 128
-    tiles = -(-ca // tile(ca)) * -(-cb // tile(cb))
-    per_k = max(1, total_rules // max(volume, 1))
-    want = max(1, 2048 // (volume * tiles))
-    return int(max(1, min(want, per_k // 64 + 1, 64)))
+WGRAD_CHUNK = 4096      # rules per split-K slab (lidal_conv_wgrad target_chunk)
+
+
+def _wgrad_splits(n_rows):
+    """Upper bound of slabs per offset: no offset has more rules than the table has rows."""
+    return int(max(1, min(256, -(-n_rows // WGRAD_CHUNK))))
 
 
 class ConvolutionFunction(Function):
@@ -157,12 +155,12 @@ class ConvolutionFunction(Function):
                 grad_in = _apply(g, wk, kmap.nbr_out, 0)
         if ctx.needs_input_grad[1]:
             k, ci, co = weight.shape
-            splits = _wgrad_splits(kmap.volume * max(n_out, 1) // 4, k, ci, co)
+            splits = _wgrad_splits(max(n_in, n_out))
             gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
             partial = torch.empty((splits, k, ci, co), dtype=torch.float32, device=x.device)
             B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), B.ptr(kmap._nbmaps_cap),
                                              B.ptr(kmap.koff), 1 if transposed else 0, B.ptr(gw),
-                                             B.ptr(partial), splits, k, ci, co,
+                                             B.ptr(partial), splits, WGRAD_CHUNK, k, ci, co,
                                              B.dtype_code(x.dtype), B.stream()), 'conv_wgrad')
             grad_w = gw.to(weight.dtype)
         return grad_in, grad_w, None, None

@@ -97,6 +97,17 @@ int lidal_devoxelize_fwd(const float* feat, const int32_t* idx, const float* w, 
                          int64_t n, int64_t m, int c, void* stream);
 int lidal_devoxelize_bwd(const float* gout, const int32_t* idx, const float* w, float* gin,
                          int64_t n, int64_t m, int c, void* stream);
+/* Atomic-free, bitwise reproducible forms of the two scatter sums above.  A point->voxel index
+ * idx i32 [n_entries] (n_entries = n for voxelize, 8n for devoxelize: entry = point*8 + corner) is
+ * transposed once into per-voxel contributor lists: order i32 [n_entries] (entries sorted by voxel,
+ * ascending inside a voxel; entries with idx < 0 or weight 0 at the end), seg_ptr i64 [m+1]. */
+int64_t lidal_invlist_workspace_bytes(int64_t n_entries);
+int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n_entries, int64_t m,
+                        int32_t* order, int64_t* seg_ptr, void* ws, int64_t ws_bytes, void* stream);
+int lidal_voxelize_fwd_sorted(const float* feat, const int32_t* order, const int64_t* seg_ptr,
+                              const int32_t* counts, float* out, int64_t m, int c, void* stream);
+int lidal_devoxelize_bwd_sorted(const float* gout, const int32_t* order, const int64_t* seg_ptr,
+                                const float* w, float* gin, int64_t m, int c, void* stream);
 /* replaces F.calc_ti_weights (torchsparse/nn/functional/devoxelize.py; network/utils.py:77):
  * coords f32 [n, cstride>=3], idx i64 [8,n] -> w f32 [n,8] and idx32 i32 [n,8] (both already
  * transposed as network/utils.py:78-79 does). */

@@ -3,6 +3,10 @@
 // All HBM-bound gathers / scatters over [rows, C] f32 feature matrices.  A thread owns a float4
 // chunk of one row (C is a multiple of 4 on this path: 4, 32, 96, 128, 256), so every access is
 // a 16-byte load/store and a row is covered by C/4 consecutive lanes.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "common.h"
 
 using namespace lidal;
@@ -173,6 +177,118 @@ __global__ void __launch_bounds__(256) ti_weights_kernel(const float* __restrict
 }
 
 
+
+// ---------------- inverse (contributor) lists: atomic-free, reproducible scatter sums ----------
+// A point->voxel index idx[e] (e = point, or point*8+corner) is transposed once into per-voxel
+// lists: `order` = entries sorted by voxel (stable radix sort => ascending e inside a voxel),
+// seg_ptr[v] = first position of voxel v.  Scatter-adds then become per-voxel gathers of whole
+// rows in a fixed order: no float atomics (chip-wide atomic rate is ~1.3 TB/s against ~5.5 TB/s
+// for gathered rows) and bitwise reproducible sums.
+__global__ void __launch_bounds__(256) inv_keys_kernel(const int* __restrict__ idx,
+                                                       const float* __restrict__ w, int64_t n,
+                                                       int64_t m, unsigned* __restrict__ keys,
+                                                       int* __restrict__ vals) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  int v = idx[e];
+  bool ok = v >= 0 && v < m && (w == nullptr || w[e] != 0.f);
+  keys[e] = ok ? (unsigned)v : (unsigned)m;
+  vals[e] = (int)e;
+}
+
+__global__ void __launch_bounds__(256) inv_segptr_kernel(const unsigned* __restrict__ skeys,
+                                                         int64_t n, int64_t m,
+                                                         int64_t* __restrict__ seg_ptr) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > m) return;
+  int64_t lo = 0, hi = n;                      // lower_bound(skeys, v)
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)skeys[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  seg_ptr[v] = lo;
+}
+
+// out[v][:] = sum_{j in list(v)} scale(j) * src[row(j)][:]
+//   voxelize:   row = e,      scale = 1 / counts[v]
+//   devox bwd:  row = e >> 3, scale = w[e]
+// One wave per voxel; LPR lanes cover a row with float4 each, the 64/LPR lane groups take list
+// elements round-robin (4 independent row loads in flight per lane), fixed xor-tree at the end.
+template <int LPR, bool DEVOX>
+__global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restrict__ src,
+                                                          const int* __restrict__ order,
+                                                          const int64_t* __restrict__ seg_ptr,
+                                                          const float* __restrict__ w,
+                                                          const int* __restrict__ counts,
+                                                          float* __restrict__ out, int64_t m,
+                                                          int c) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= m) return;
+  const int l = lane % LPR, grp = lane / LPR;
+  const bool act = 4 * l < c;
+  const int64_t beg = seg_ptr[v], end = seg_ptr[v + 1];
+  float inv = 1.f;
+  if (!DEVOX) { int cv = counts[v]; inv = cv > 0 ? (float)cv : 1.f; }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t j = beg + grp;
+  for (; j + 3 * RPW < end; j += 4 * RPW) {
+    int e[4]; float sc[4]; float4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = order[j + u * RPW];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t row = DEVOX ? (e[u] >> 3) : e[u];
+      sc[u] = DEVOX ? w[e[u]] : 1.f;
+      x[u] = act ? *reinterpret_cast<const float4*>(src + row * c + 4 * l) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (DEVOX) { acc.x += sc[u] * x[u].x; acc.y += sc[u] * x[u].y; acc.z += sc[u] * x[u].z; acc.w += sc[u] * x[u].w; }
+      else { acc.x += x[u].x / inv; acc.y += x[u].y / inv; acc.z += x[u].z / inv; acc.w += x[u].w / inv; }
+    }
+  }
+  for (; j < end; j += RPW) {
+    const int e = order[j];
+    const int64_t row = DEVOX ? (e >> 3) : e;
+    const float sc = DEVOX ? w[e] : 1.f;
+    float4 x = act ? *reinterpret_cast<const float4*>(src + row * c + 4 * l) : make_float4(0, 0, 0, 0);
+    if (DEVOX) { acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w; }
+    else { acc.x += x.x / inv; acc.y += x.y / inv; acc.z += x.z / inv; acc.w += x.w / inv; }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+    acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+  }
+  if (grp == 0 && act) *reinterpret_cast<float4*>(out + v * c + 4 * l) = acc;
+}
+
+size_t inv_sort_tmp_bytes(int64_t n) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr,
+                                  (const int*)nullptr, (int*)nullptr, (size_t)(n > 0 ? n : 1), 0,
+                                  32, (hipStream_t)0);
+  return tmp;
+}
+
+template <bool DEVOX>
+int launch_segment_sum(const float* src, const int* order, const int64_t* seg_ptr, const float* w,
+                       const int* counts, float* out, int64_t m, int c, hipStream_t s) {
+  unsigned grid = (unsigned)cdiv(m, 4);
+  if (c <= 32)
+    segment_sum_kernel<8, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+  else if (c <= 64)
+    segment_sum_kernel<16, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+  else if (c <= 128)
+    segment_sum_kernel<32, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+  else
+    segment_sum_kernel<64, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+  LIDAL_CHECK_LAUNCH("segment_sum");
+  return 0;
+}
+
 }  // namespace
 
 #define DISPATCH_VEC(kernel, c, total_rows, ...)                                             \
@@ -241,4 +357,52 @@ extern "C" int lidal_ti_weights(const float* coords, int cstride, const int64_t*
   ti_weights_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>(coords, cstride, idx, n, scale, w, idx32);
   LIDAL_CHECK_LAUNCH("lidal_ti_weights");
   return 0;
+}
+
+extern "C" int64_t lidal_invlist_workspace_bytes(int64_t n_entries) {
+  int64_t q = n_entries > 0 ? n_entries : 1;
+  return 2 * align_up(4 * q, 256) + align_up(4 * q, 256) + align_up((int64_t)inv_sort_tmp_bytes(q), 256) + 256;
+}
+
+extern "C" int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n_entries, int64_t m,
+                                   int32_t* order, int64_t* seg_ptr, void* ws, int64_t ws_bytes,
+                                   void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(m >= 0 && m < 0x7FFFFFFF, "invlist: bad voxel count");
+  if (n_entries == 0) {
+    LIDAL_HIP(hipMemsetAsync(seg_ptr, 0, 8 * (m + 1), s));
+    return 0;
+  }
+  LIDAL_REQUIRE(ws_bytes >= lidal_invlist_workspace_bytes(n_entries), "invlist workspace too small");
+  int64_t q = n_entries;
+  unsigned* keys = (unsigned*)ws;
+  unsigned* skeys = (unsigned*)((char*)ws + align_up(4 * q, 256));
+  int* vals = (int*)((char*)ws + 2 * align_up(4 * q, 256));
+  void* tmp = (char*)ws + 3 * align_up(4 * q, 256);
+  size_t tmp_bytes = inv_sort_tmp_bytes(q);
+  inv_keys_kernel<<<(unsigned)cdiv(q, 256), 256, 0, s>>>(idx, w, q, m, keys, vals);
+  LIDAL_CHECK_LAUNCH("inv_keys");
+  int bits = 1;
+  while ((1ll << bits) <= m) ++bits;
+  LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, order, (size_t)q, 0, bits, s));
+  inv_segptr_kernel<<<(unsigned)cdiv(m + 1, 256), 256, 0, s>>>(skeys, q, m, seg_ptr);
+  LIDAL_CHECK_LAUNCH("inv_segptr");
+  return 0;
+}
+
+extern "C" int lidal_voxelize_fwd_sorted(const float* feat, const int32_t* order,
+                                         const int64_t* seg_ptr, const int32_t* counts, float* out,
+                                         int64_t m, int c, void* stream) {
+  if (m == 0 || c == 0) return 0;
+  LIDAL_REQUIRE(c % 4 == 0, "voxelize_fwd_sorted: channels must be a multiple of 4");
+  return launch_segment_sum<false>(feat, order, seg_ptr, nullptr, counts, out, m, c,
+                                   (hipStream_t)stream);
+}
+
+extern "C" int lidal_devoxelize_bwd_sorted(const float* gout, const int32_t* order,
+                                           const int64_t* seg_ptr, const float* w, float* gin,
+                                           int64_t m, int c, void* stream) {
+  if (m == 0 || c == 0) return 0;
+  LIDAL_REQUIRE(c % 4 == 0, "devoxelize_bwd_sorted: channels must be a multiple of 4");
+  return launch_segment_sum<true>(gout, order, seg_ptr, w, nullptr, gin, m, c, (hipStream_t)stream);
 }

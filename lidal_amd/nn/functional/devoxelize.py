@@ -4,6 +4,7 @@ import torch
 from torch.autograd import Function
 
 from ... import backend as B
+from .invlist import inverse_lists
 
 __all__ = ['spdevoxelize', 'calc_ti_weights', 'ti_weights_and_index']
 
@@ -37,8 +38,10 @@ class DevoxelizeFunction(Function):
         B.require_gpu(feats, coords, weights)
         in_dtype = feats.dtype
         feats = feats.contiguous().float()
-        coords = coords.contiguous().int()
-        weights = weights.contiguous().float()
+        if coords.dtype != torch.int or not coords.is_contiguous():
+            coords = coords.contiguous().int()
+        if weights.dtype != torch.float32 or not weights.is_contiguous():
+            weights = weights.contiguous().float()
         m, c = feats.shape
         n = coords.shape[0]
         out = torch.empty((n, c), dtype=torch.float32, device=feats.device)
@@ -53,8 +56,14 @@ class DevoxelizeFunction(Function):
         g = grad_output.contiguous().float()
         n, c = g.shape
         gin = torch.empty((m, c), dtype=torch.float32, device=g.device)
-        B.check(B.lib().lidal_devoxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(weights), B.ptr(gin),
-                                             n, m, c, B.stream()), 'devoxelize_bwd')
+        if c % 4 == 0:      # ordered per-voxel gather: no atomics, reproducible
+            order, seg_ptr = inverse_lists(coords, m, weights)
+            B.check(B.lib().lidal_devoxelize_bwd_sorted(B.ptr(g), B.ptr(order), B.ptr(seg_ptr),
+                                                        B.ptr(weights), B.ptr(gin), m, c,
+                                                        B.stream()), 'devoxelize_bwd_sorted')
+        else:
+            B.check(B.lib().lidal_devoxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(weights),
+                                                 B.ptr(gin), n, m, c, B.stream()), 'devoxelize_bwd')
         return gin.to(in_dtype), None, None
 
 

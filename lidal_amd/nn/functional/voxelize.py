@@ -4,6 +4,7 @@ import torch
 from torch.autograd import Function
 
 from ... import backend as B
+from .invlist import inverse_lists
 
 __all__ = ['spvoxelize']
 
@@ -14,13 +15,23 @@ class VoxelizeFunction(Function):
         B.require_gpu(feats, coords, counts)
         in_dtype = feats.dtype
         feats = feats.contiguous().float()
-        coords = coords.contiguous().int()
+        idx32 = getattr(coords, '_lidal_i32', None)        # int32 view cached on the index tensor
+        if idx32 is None:
+            idx32 = coords.contiguous().int()
+            coords._lidal_i32 = idx32
         counts = counts.contiguous().int()
         n, c = feats.shape
         m = counts.shape[0]
         out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
-        B.check(B.lib().lidal_voxelize_fwd(B.ptr(feats), B.ptr(coords), B.ptr(counts), B.ptr(out),
-                                           n, m, c, B.stream()), 'voxelize_fwd')
+        if c % 4 == 0:      # ordered per-voxel gather: no atomics, reproducible
+            order, seg_ptr = inverse_lists(idx32, m)
+            B.check(B.lib().lidal_voxelize_fwd_sorted(B.ptr(feats), B.ptr(order), B.ptr(seg_ptr),
+                                                      B.ptr(counts), B.ptr(out), m, c, B.stream()),
+                    'voxelize_fwd_sorted')
+        else:
+            B.check(B.lib().lidal_voxelize_fwd(B.ptr(feats), B.ptr(idx32), B.ptr(counts),
+                                               B.ptr(out), n, m, c, B.stream()), 'voxelize_fwd')
+        coords = idx32
         ctx.for_backwards = (coords, counts, n, in_dtype)
         return out.to(in_dtype)
 

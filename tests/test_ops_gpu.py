@@ -292,3 +292,38 @@ def test_conv3d_dense_grid_equals_torch_conv3d():
     wt = w.reshape(3, 3, 3, ci, co).permute(4, 3, 0, 1, 2)                # [co,ci,kz,ky,kx]
     dense = torch.nn.functional.conv3d(vol, wt, padding=1)[0].permute(1, 2, 3, 0).reshape(-1, co)
     assert _relerr(out, dense) < 1e-4
+
+
+def test_voxelize_devoxelize_are_reproducible_and_skewed_lists():
+    """The scatter sums run as ordered per-voxel gathers: bitwise identical across runs, also with
+    very uneven voxel populations (one voxel receiving thousands of points)."""
+    F = _F()
+    g = torch.Generator().manual_seed(11)
+    n, m, c = 50000, 300, 128
+    idx = torch.randint(0, m, (n,), generator=g, dtype=torch.int64)
+    idx[:20000] = 7                                   # heavy voxel
+    idx[20000:20010] = -1
+    counts_ref = RF.spcount(idx.int(), m)
+    feats = torch.randn(n, c, generator=g)
+    ref = RF.spvoxelize(feats, idx, counts_ref)
+    outs = []
+    for _ in range(2):
+        i_dev = idx.to(DEV)
+        outs.append(F.spvoxelize(feats.to(DEV), i_dev, F.spcount(i_dev.int(), m)))
+    assert torch.equal(outs[0], outs[1])
+    assert _relerr(outs[0].cpu(), ref) < 1e-5
+    idx8 = torch.randint(-1, m, (n, 8), generator=g, dtype=torch.int32)
+    idx8[:, 0] = 3
+    w = torch.rand(n, 8, generator=g)
+    w[::3, 2] = 0.0
+    vf = torch.randn(m, c, generator=g)
+    v_ref = vf.clone().requires_grad_(True)
+    go = torch.randn(n, c, generator=g)
+    RF.spdevoxelize(v_ref, idx8, w).backward(go)
+    grads = []
+    for _ in range(2):
+        v = vf.to(DEV).requires_grad_(True)
+        F.spdevoxelize(v, idx8.to(DEV), w.to(DEV)).backward(go.to(DEV))
+        grads.append(v.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert _relerr(grads[0].cpu(), v_ref.grad) < 1e-4

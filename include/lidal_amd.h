@@ -135,6 +135,25 @@ int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs, const i
                      int a_col, float* gw, float* partial, int splits, int target_chunk, int k,
                      int ca, int cb, int dtype, void* stream);
 
+/* ---- batch normalisation over rows ------------------------------------------------------------ */
+/* replaces the torch.nn.BatchNorm1d kernels behind spnn.BatchNorm (network/utils.py:115; 49 per
+ * model) for x [n, c] row-major, dtype f32 or bf16 (statistics always f32).  Training forward:
+ * biased batch variance for normalisation, running stats updated with `momentum` and the unbiased
+ * variance (running_* may be NULL); save_mean / save_invstd f32 [c] feed the backward.
+ * c must be a multiple of 4 (f32) / 8 (bf16). */
+int64_t lidal_bn_workspace_bytes(int64_t n, int c);
+int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, void* y, float* save_mean, float* save_invstd, void* ws,
+                       int64_t ws_bytes, void* stream);
+int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
+                      const float* beta, const float* running_mean, const float* running_var,
+                      float eps, void* y, void* stream);
+/* dx may be NULL (only parameter gradients wanted). */
+int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n, int c, const float* gamma,
+                 const float* save_mean, const float* save_invstd, void* dx, float* grad_gamma,
+                 float* grad_beta, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- probability inference post-processing ------------------------------------------------- */
 /* replaces score/prob_inference.py:100-113: logits f32 [nv, c] of `reps` collated views,
  * inverse i64 [reps*p] (voxel row of every point in every view) -> prob f32 [p,c] = mean over

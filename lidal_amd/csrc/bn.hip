@@ -1,0 +1,389 @@
+// BatchNorm over the rows of a [N, C] feature matrix (spnn.BatchNorm = nn.BatchNorm1d on .feats,
+// network/utils.py:115, 49 instances per model) for gfx950.
+//
+// HBM-bound: training forward reads x twice (statistics, normalise) and writes y once; backward
+// reads x and dy twice and writes dx once.  All accesses are 16-byte lane loads covering whole
+// rows; per-channel reductions are hierarchical (thread -> LDS tree -> per-workgroup partial ->
+// one combining workgroup) with Chan's parallel-variance merge on SHIFTED sums, so the variance does
+// not cancel when |mean| >> std, and the order is fixed (bitwise reproducible, no atomics).
+#include "common.h"
+
+using namespace lidal;
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int ROWS_PER_WG = 1024;      // rows a workgroup reduces per partial
+
+template <typename T> struct IO;
+template <> struct IO<float> {
+  static constexpr int VEC = 4;
+  typedef float4 vec;
+  __device__ static void unpack(const vec& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+  __device__ static vec pack(const float (&f)[4]) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+template <> struct IO<__bf16> {
+  static constexpr int VEC = 8;
+  typedef bf16x8_t vec;
+  __device__ static void unpack(const vec& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
+  __device__ static vec pack(const float (&f)[8]) {
+    vec v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
+    return v;
+  }
+};
+
+// merge (nb, mb, M2b) into (na, ma, M2a)  -- Chan et al.
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& m2a, float nb, float mb,
+                                           float m2b) {
+  if (nb == 0.f) return;
+  float n = na + nb;
+  float d = mb - ma;
+  ma = ma + d * (nb / n);
+  m2a = m2a + m2b + d * d * (na * nb / n);
+  na = n;
+}
+
+// Thread layout shared by every kernel below: thread t of a 256-thread workgroup owns channel
+// group cg = t % CG (VEC consecutive channels = one 16-byte access) and row lane rl = t / CG; the
+// workgroup owns rows [blockIdx.x * ROWS_PER_WG, ...) and row lane rl walks rows rl, rl+RPI, ...
+// (RPI = 256 / CG rows per sweep).  Consecutive threads touch consecutive 16-byte pieces of a row,
+// then the next row: fully coalesced, and no per-element div/mod.
+
+// LDS tree sum over the row lanes of each channel group: v[tid*VEC+i] += ... ; result in rl == 0
+template <int VEC>
+__device__ __forceinline__ void tree_sum_rows(float* v, int tid, int cg_n, int rpi, int rl) {
+  int span = 1;
+  while (span < rpi) span <<= 1;
+  for (int s = span >> 1; s >= 1; s >>= 1) {
+    __syncthreads();
+    if (rl < s && rl + s < rpi) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[tid * VEC + i] += v[(tid + s * cg_n) * VEC + i];
+    }
+  }
+  __syncthreads();
+}
+
+// ---- statistics: per-workgroup partial (count, mean, M2) per channel ----
+// All threads of the workgroup shift by the SAME value (the slab's first row), so inside the slab
+// plain sums of (x-K) and (x-K)^2 can be added; only slabs are merged with Chan's formula.
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_stats_partial_kernel(const T* __restrict__ x, int64_t n,
+                                                              int c, float* __restrict__ part) {
+  constexpr int VEC = IO<T>::VEC;
+  extern __shared__ float sh[];                 // [2][NT][VEC]
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
+  const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
+  const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
+  float shift[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { shift[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+  if (rl < rpi) {
+    IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r_beg * c + cg * VEC), shift);
+    for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
+      float f[VEC];
+      IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { float d = f[i] - shift[i]; s1[i] += d; s2[i] += d * d; }
+    }
+  }
+  float* a1 = sh; float* a2 = sh + NT * VEC;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { a1[tid * VEC + i] = s1[i]; a2[tid * VEC + i] = s2[i]; }
+  tree_sum_rows<VEC>(a1, tid, cg_n, rpi, rl);
+  tree_sum_rows<VEC>(a2, tid, cg_n, rpi, rl);
+  if (rl == 0) {
+    const float cnt = (float)(r_end - r_beg);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float t1 = a1[tid * VEC + i], t2 = a2[tid * VEC + i];
+      float d = t1 / cnt, m2 = t2 - t1 * d;
+      float* dst = part + ((int64_t)blockIdx.x * c + cg * VEC + i) * 3;
+      dst[0] = cnt; dst[1] = shift[i] + d; dst[2] = m2 < 0.f ? 0.f : m2;
+    }
+  }
+}
+
+// One workgroup folds the slab partials of 8 channels: 32 lanes per channel each merge a strided
+// subset in order, then a fixed LDS tree merges the 32 lanes.  Writes mean / invstd and updates the
+// running statistics exactly as torch.nn.BatchNorm1d (biased var to normalise, unbiased for
+// running_var).
+__global__ void __launch_bounds__(NT) bn_stats_final_kernel(const float* __restrict__ part,
+                                                            int nparts, int c, float eps,
+                                                            float momentum,
+                                                            float* __restrict__ mean,
+                                                            float* __restrict__ invstd,
+                                                            float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var) {
+  __shared__ float sn[NT], sm[NT], sq[NT];
+  const int tid = threadIdx.x, cl = tid & 7, pl = tid >> 3;      // 8 channels x 32 lanes
+  const int ch = blockIdx.x * 8 + cl;
+  float na = 0.f, ma = 0.f, qa = 0.f;
+  if (ch < c)
+    for (int p = pl; p < nparts; p += 32) {
+      const float* s = part + ((int64_t)p * c + ch) * 3;
+      if (na == 0.f) { na = s[0]; ma = s[1]; qa = s[2]; }
+      else chan_merge(na, ma, qa, s[0], s[1], s[2]);
+    }
+  sn[tid] = na; sm[tid] = ma; sq[tid] = qa;
+  for (int s = 16; s >= 1; s >>= 1) {
+    __syncthreads();
+    if (pl < s) {
+      float nb = sn[tid + s * 8], mb = sm[tid + s * 8], qb = sq[tid + s * 8];
+      float n0 = sn[tid], m0 = sm[tid], q0 = sq[tid];
+      if (n0 == 0.f) { n0 = nb; m0 = mb; q0 = qb; }
+      else chan_merge(n0, m0, q0, nb, mb, qb);
+      sn[tid] = n0; sm[tid] = m0; sq[tid] = q0;
+    }
+  }
+  __syncthreads();
+  if (pl == 0 && ch < c) {
+    na = sn[tid]; ma = sm[tid]; qa = sq[tid];
+    float var = na > 0.f ? qa / na : 0.f;
+    mean[ch] = ma;
+    invstd[ch] = 1.f / sqrtf(var + eps);
+    if (running_mean != nullptr) {
+      float unbiased = na > 1.f ? qa / (na - 1.f) : var;
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * ma;
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+    }
+  }
+}
+
+// y = (x - mean) * invstd * gamma + beta  ==  x * sc + sh   (per-channel sc, sh held in registers)
+template <typename T, bool VAR_IN>
+__global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, int64_t n, int c,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ istd_or_var,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      T* __restrict__ y) {
+  constexpr int VEC = IO<T>::VEC;
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
+  if (rl >= rpi) return;
+  const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
+  const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
+  float mu[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = cg * VEC + i;
+    float is = VAR_IN ? 1.f / sqrtf(istd_or_var[ch] + eps) : istd_or_var[ch];
+    mu[i] = mean[ch];
+    sc[i] = is * (gamma ? gamma[ch] : 1.f);
+    sh[i] = beta ? beta[ch] : 0.f;
+  }
+  for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
+    float f[VEC];
+    IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
+    *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
+  }
+}
+
+// backward partials: per workgroup and channel  sum(dy), sum(dy * xhat)
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict__ x,
+                                                            const T* __restrict__ dy, int64_t n,
+                                                            int c, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            float* __restrict__ part) {
+  constexpr int VEC = IO<T>::VEC;
+  extern __shared__ float sh[];                 // [2][NT][VEC]
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
+  const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
+  const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
+  float a[VEC], b[VEC], mu[VEC], is[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; }
+  if (rl < rpi) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { mu[i] = mean[cg * VEC + i]; is[i] = invstd[cg * VEC + i]; }
+    for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
+      float fx[VEC], fd[VEC];
+      IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), fx);
+      IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), fd);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { a[i] += fd[i]; b[i] += fd[i] * ((fx[i] - mu[i]) * is[i]); }
+    }
+  }
+  float* sa = sh; float* sb = sh + NT * VEC;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { sa[tid * VEC + i] = a[i]; sb[tid * VEC + i] = b[i]; }
+  tree_sum_rows<VEC>(sa, tid, cg_n, rpi, rl);
+  tree_sum_rows<VEC>(sb, tid, cg_n, rpi, rl);
+  if (rl == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float* dst = part + ((int64_t)blockIdx.x * c + cg * VEC + i) * 2;
+      dst[0] = sa[tid * VEC + i]; dst[1] = sb[tid * VEC + i];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT) bn_bwd_final_kernel(const float* __restrict__ part,
+                                                          int nparts, int c,
+                                                          float* __restrict__ sum_dy,
+                                                          float* __restrict__ sum_dy_xhat) {
+  __shared__ float sa[NT], sb[NT];
+  const int tid = threadIdx.x, cl = tid & 7, pl = tid >> 3;
+  const int ch = blockIdx.x * 8 + cl;
+  float a = 0.f, b = 0.f;
+  if (ch < c)
+    for (int p = pl; p < nparts; p += 32) {
+      a += part[((int64_t)p * c + ch) * 2];
+      b += part[((int64_t)p * c + ch) * 2 + 1];
+    }
+  sa[tid] = a; sb[tid] = b;
+  for (int s = 16; s >= 1; s >>= 1) {
+    __syncthreads();
+    if (pl < s) { sa[tid] += sa[tid + s * 8]; sb[tid] += sb[tid + s * 8]; }
+  }
+  __syncthreads();
+  if (pl == 0 && ch < c) {
+    sum_dy[ch] = sa[tid];            // = grad_beta
+    sum_dy_xhat[ch] = sb[tid];       // = grad_gamma
+  }
+}
+
+// dx = gamma * invstd * (dy - sum_dy/n - xhat * sum_dy_xhat/n)
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
+                                                       const T* __restrict__ dy, int64_t n, int c,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ sum_dy,
+                                                       const float* __restrict__ sum_dy_xhat,
+                                                       T* __restrict__ dx) {
+  constexpr int VEC = IO<T>::VEC;
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
+  if (rl >= rpi) return;
+  const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
+  const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
+  const float inv_n = 1.f / (float)n;
+  float mu[VEC], is[VEC], gs[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = cg * VEC + i;
+    mu[i] = mean[ch]; is[i] = invstd[ch];
+    gs[i] = (gamma ? gamma[ch] : 1.f) * is[i];
+    k1[i] = sum_dy[ch] * inv_n; k2[i] = sum_dy_xhat[ch] * inv_n;
+  }
+  for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
+    float fx[VEC], fd[VEC];
+    IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), fx);
+    IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), fd);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) fd[i] = gs[i] * (fd[i] - k1[i] - (fx[i] - mu[i]) * is[i] * k2[i]);
+    *reinterpret_cast<typename IO<T>::vec*>(dx + r * c + cg * VEC) = IO<T>::pack(fd);
+  }
+}
+
+static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, ROWS_PER_WG); }
+template <typename T>
+int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
+                 float momentum, float* rm, float* rv, void* y, float* mean, float* invstd,
+                 float* part, hipStream_t s) {
+  constexpr int VEC = IO<T>::VEC;
+  int np = nparts_for(n);
+  bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>((const T*)x, n, c, part);
+  LIDAL_CHECK_LAUNCH("bn_stats_partial");
+  bn_stats_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
+                                                             invstd, rm, rv);
+  LIDAL_CHECK_LAUNCH("bn_stats_final");
+  bn_apply_kernel<T, false><<<np, NT, 0, s>>>((const T*)x, n, c, mean, invstd,
+                                                                   gamma, beta, eps, (T*)y);
+  LIDAL_CHECK_LAUNCH("bn_apply");
+  return 0;
+}
+
+template <typename T>
+int bn_bwd(const void* x, const void* dy, int64_t n, int c, const float* gamma, const float* mean,
+           const float* invstd, void* dx, float* ggamma, float* gbeta, float* part, hipStream_t s) {
+  constexpr int VEC = IO<T>::VEC;
+  int np = nparts_for(n);
+  bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>((const T*)x, (const T*)dy,
+                                                                        n, c, mean, invstd, part);
+  LIDAL_CHECK_LAUNCH("bn_bwd_partial");
+  bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gbeta, ggamma);
+  LIDAL_CHECK_LAUNCH("bn_bwd_final");
+  if (dx != nullptr) {
+    bn_bwd_dx_kernel<T><<<np, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean,
+                                                              invstd, gamma, gbeta, ggamma, (T*)dx);
+    LIDAL_CHECK_LAUNCH("bn_bwd_dx");
+  }
+  return 0;
+}
+
+}  // namespace
+
+static int bn_check(int64_t n, int c, int dtype) {
+  int vec = dtype == LIDAL_BF16 ? 8 : 4;
+  LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16, "bn: bad dtype %d", dtype);
+  LIDAL_REQUIRE(c > 0 && c % vec == 0 && c / vec <= NT, "bn: channels %d must be a multiple of %d and <= %d",
+                c, vec, NT * vec);
+  LIDAL_REQUIRE(n >= 0, "bn: bad row count");
+  return 0;
+}
+
+extern "C" int64_t lidal_bn_workspace_bytes(int64_t n, int c) {
+  return (int64_t)nparts_for(n) * c * 3 * sizeof(float) + 256;
+}
+
+extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
+                                  const float* beta, float eps, float momentum,
+                                  float* running_mean, float* running_var, void* y,
+                                  float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
+                                  void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  LIDAL_REQUIRE(n > 0, "bn_train_fwd: needs at least one row");
+  LIDAL_REQUIRE(ws_bytes >= lidal_bn_workspace_bytes(n, c), "bn workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LIDAL_F32)
+    return bn_train_fwd<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, y,
+                               save_mean, save_invstd, (float*)ws, s);
+  return bn_train_fwd<__bf16>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, y,
+                              save_mean, save_invstd, (float*)ws, s);
+}
+
+extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
+                                 const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, void* y, void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LIDAL_F32)
+    bn_apply_kernel<float, true><<<nparts_for(n), NT, 0, s>>>(
+        (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, (float*)y);
+  else
+    bn_apply_kernel<__bf16, true><<<nparts_for(n), NT, 0, s>>>(
+        (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, (__bf16*)y);
+  LIDAL_CHECK_LAUNCH("lidal_bn_eval_fwd");
+  return 0;
+}
+
+extern "C" int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n, int c,
+                            const float* gamma, const float* save_mean, const float* save_invstd,
+                            void* dx, float* grad_gamma, float* grad_beta, void* ws,
+                            int64_t ws_bytes, void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  LIDAL_REQUIRE(n > 0, "bn_bwd: needs at least one row");
+  LIDAL_REQUIRE(ws_bytes >= lidal_bn_workspace_bytes(n, c), "bn workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LIDAL_F32)
+    return bn_bwd<float>(x, dy, n, c, gamma, save_mean, save_invstd, dx, grad_gamma, grad_beta,
+                         (float*)ws, s);
+  return bn_bwd<__bf16>(x, dy, n, c, gamma, save_mean, save_invstd, dx, grad_gamma, grad_beta,
+                        (float*)ws, s);
+}

@@ -12,7 +12,7 @@ from ..utils import make_ntuple
 from . import functional, utils
 from .functional import conv3d
 
-__all__ = ['Conv3d', 'BatchNorm', 'ReLU', 'functional', 'utils']
+__all__ = ['Conv3d', 'BatchNorm', 'BatchNorm1d', 'ReLU', 'functional', 'utils']
 
 
 def fapply(input, fn, *args, **kwargs):
@@ -62,7 +62,26 @@ class Conv3d(nn.Module):
                       stride=self.stride, dilation=self.dilation, transposed=self.transposed)
 
 
-class BatchNorm(nn.BatchNorm1d):
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d on a [N, C] tensor, routed to the HIP kernels (lidal_bn_*) whenever the
+    configuration is the standard one (GPU, f32/bf16, affine, running statistics); anything else
+    falls through to torch's own implementation.  Parameters / buffers are nn.BatchNorm1d's, so
+    state_dict keys are unchanged."""
+
+    def forward(self, feats):
+        from .functional import norm
+        if (not norm.supported(feats, self.weight, self.bias) or not self.track_running_stats
+                or self.momentum is None):
+            return super().forward(feats)
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return norm.batch_norm_rows(feats, self.weight, self.bias, self.running_mean,
+                                    self.running_var, self.training, self.momentum, self.eps)
+
+
+class BatchNorm(BatchNorm1d):
+    """spnn.BatchNorm: BatchNorm1d applied to the .feats of a SparseTensor."""
+
     def forward(self, input):
         return fapply(input, super().forward)
 

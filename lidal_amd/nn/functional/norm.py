@@ -1,0 +1,80 @@
+"""Batch normalisation over the rows of a [N, C] feature matrix on the HIP backend
+(lidal_bn_* in include/lidal_amd.h).  Same arithmetic contract as torch.nn.functional.batch_norm:
+biased batch variance for normalisation, running statistics updated with the unbiased variance."""
+import torch
+from torch.autograd import Function
+
+from ... import backend as B
+
+__all__ = ['batch_norm_rows', 'supported']
+
+
+def supported(x, weight, bias):
+    if not x.is_cuda or x.dim() != 2 or weight is None or bias is None:
+        return False
+    if x.dtype == torch.float32:
+        vec = 4
+    elif x.dtype == torch.bfloat16:
+        vec = 8
+    else:
+        return False
+    c = x.shape[1]
+    return x.shape[0] > 1 and c % vec == 0 and c // vec <= 256 and weight.dtype == torch.float32
+
+
+def _ws(n, c, dev):
+    nbytes = B.lib().lidal_bn_workspace_bytes(n, c)
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+
+
+class BatchNormRows(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+        x = x.contiguous()
+        n, c = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        code = B.dtype_code(x.dtype)
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            invstd = torch.empty(c, dtype=torch.float32, device=dev)
+            ws, nbytes = _ws(n, c, dev)
+            B.check(B.lib().lidal_bn_train_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
+                                               float(momentum), B.ptr(running_mean),
+                                               B.ptr(running_var), B.ptr(y), B.ptr(mean),
+                                               B.ptr(invstd), B.ptr(ws), nbytes, B.stream()),
+                    'bn_train_fwd')
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+            B.check(B.lib().lidal_bn_eval_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b),
+                                              B.ptr(running_mean), B.ptr(running_var), float(eps),
+                                              B.ptr(y), B.stream()), 'bn_eval_fwd')
+        ctx.training = training
+        ctx.save_for_backward(x, w, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w, mean, invstd = ctx.saved_tensors
+        n, c = x.shape
+        g = grad_out.contiguous().to(x.dtype)
+        if not ctx.training:            # eval-mode backward (not on the LiDAL path): plain torch
+            xhat = (x.float() - mean) * invstd
+            gf = g.float()
+            return ((gf * (w * invstd)).to(x.dtype), (gf * xhat).sum(0), gf.sum(0), None, None,
+                    None, None, None)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        gg = torch.empty(c, dtype=torch.float32, device=x.device)
+        gb = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws, nbytes = _ws(n, c, x.device)
+        B.check(B.lib().lidal_bn_bwd(B.ptr(x), B.ptr(g), B.dtype_code(x.dtype), n, c, B.ptr(w),
+                                     B.ptr(mean), B.ptr(invstd), B.ptr(dx), B.ptr(gg), B.ptr(gb),
+                                     B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
+        return dx, gg, gb, None, None, None, None, None
+
+
+def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps):
+    return BatchNormRows.apply(x, weight, bias, running_mean, running_var, training, momentum, eps)

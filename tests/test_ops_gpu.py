@@ -327,3 +327,41 @@ def test_voxelize_devoxelize_are_reproducible_and_skewed_lists():
         grads.append(v.grad.clone())
     assert torch.equal(grads[0], grads[1])
     assert _relerr(grads[0].cpu(), v_ref.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dtype,c,n', [(torch.float32, 32, 5000), (torch.float32, 96, 70001),
+                                       (torch.float32, 256, 1500), (torch.bfloat16, 96, 30000),
+                                       (torch.bfloat16, 384, 2049), (torch.float32, 4, 100)])
+def test_batch_norm_rows_matches_torch(dtype, c, n):
+    """spnn.BatchNorm on the HIP kernels vs torch.nn.BatchNorm1d in f64 on the CPU: output,
+    running statistics, dx / dgamma / dbeta; train and eval; large mean / small variance column."""
+    import lidal_amd.nn as spnn
+    g = torch.Generator().manual_seed(c + n)
+    x = torch.randn(n, c, generator=g) * 2 + 0.5
+    x[:, 1] = x[:, 1] * 0.05 + 10.0                      # |mean| >> std: shifted sums must hold
+    go = torch.randn(n, c, generator=g)
+    ref = torch.nn.BatchNorm1d(c).double()
+    mine = spnn.BatchNorm1d(c).to(DEV)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        ref.bias.copy_(torch.randn(c, generator=g) * 0.1)
+        mine.weight.copy_(ref.weight.float())
+        mine.bias.copy_(ref.bias.float())
+    xq = x.to(dtype)                                     # both sides see the same rounded input
+    xr = xq.double().requires_grad_(True)
+    xg = xq.to(DEV).requires_grad_(True)
+    yr = ref(xr)
+    yg = mine(xg)
+    assert yg.dtype == dtype
+    yr.backward(go.to(dtype).double())
+    yg.backward(go.to(dtype).to(DEV))
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert _relerr(yg.float().cpu(), yr) < tol
+    assert _relerr(xg.grad.float().cpu(), xr.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
+    assert _relerr(mine.weight.grad.cpu(), ref.weight.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert _relerr(mine.bias.grad.cpu(), ref.bias.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert _relerr(mine.running_mean.cpu(), ref.running_mean) < 1e-5
+    assert _relerr(mine.running_var.cpu(), ref.running_var) < 1e-4
+    assert int(mine.num_batches_tracked) == 1
+    ref.eval(), mine.eval()
+    assert _relerr(mine(xq.to(DEV)).float().cpu(), ref(xq.double())) < tol

@@ -36,7 +36,6 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int BM = 128;          // output rows per workgroup
 constexpr int NTHREADS = 256;
 constexpr int NWAVES = 4;
 
@@ -87,7 +86,11 @@ __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b
 // conv_apply
 // ------------------------------------------------------------------------------------------
 constexpr int MAXK = 32;         // kernel volume limit (27 and 8 on this path)
-constexpr int G = 2;             // 16-row groups per wave  => BM = 4 waves * G * 16 = 128 rows
+#ifndef LIDAL_G
+#define LIDAL_G 2
+#endif
+constexpr int G = LIDAL_G;       // 16-row groups per wave  => BM = 4 waves * G * 16 rows
+constexpr int BM = NWAVES * G * 16;   // output rows per workgroup
 
 // Timing-only ablation builds (scripts/ablate_conv.py): -DLIDAL_ABLATE=<mask> removes one cost at a
 // time; results are wrong by construction.  1: no A gather  2: no weight staging  4: no MFMA
@@ -303,12 +306,16 @@ int dispatch_conv_tile(const void* in, const void* wk, const int* nbr, void* out
 template <typename T>
 int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
                         int ci, int co, int K, int kflip, hipStream_t s) {
-  // staged reduction bytes per pass: 192 when the row is a multiple of 192 but not of 256 bytes
-  // (ci = 96 f32 -> two passes of 48; ci = 96 bf16 -> one pass), else 256.
+  // staged reduction bytes per pass: 128 (more workgroups per CU beat longer passes: measured in
+  // profiles/README.md), except rows that are a multiple of 192 but not of 128 bytes (ci = 96
+  // bf16 -> one pass of 96 instead of 64 + 32).
   const int row_bytes = ci * (int)sizeof(T);
-  if (row_bytes % 192 == 0 && row_bytes % 256 != 0)
+#ifdef LIDAL_ROWB_OVERRIDE
+  return dispatch_conv_tile<T, LIDAL_ROWB_OVERRIDE>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+#endif
+  if (row_bytes % 192 == 0 && row_bytes % 128 != 0)
     return dispatch_conv_tile<T, 192>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
-  return dispatch_conv_tile<T, 256>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_tile<T, 128>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ def dist_setup(args):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get('BENCH_FORCE_DDP'):
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     assert world == args.gpus, 'launch with --nproc-per-node == --gpus (got %d vs %d)' % (world, args.gpus)
     return world, rank, torch.device('cuda', local)
@@ -106,7 +106,7 @@ def bench_train(args, world, rank, dev):
     torch.manual_seed(7122)
     model = (SPVCNN if args.model == 'spvcnn' else MinkUNet)(19).to(dev).train()
     net = model
-    if world > 1:
+    if world > 1 or os.environ.get('BENCH_FORCE_DDP'):
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
     opt = torch.optim.Adam(net.parameters())
     autocast = args.dtype == 'bf16'
@@ -285,7 +285,7 @@ def main():
         line['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -130,7 +130,10 @@ int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, void* o
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
  * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  Split-K: offset k with nk rules is cut into
  * min(splits, ceil(nk / target_chunk)) slabs; `partial` f32 [splits][k][ca][cb] scratch holds the
- * slabs, which are reduced in a fixed order => bitwise reproducible. */
+ * slabs, which are reduced in a fixed order => bitwise reproducible.
+ * pairs == NULL means the identity rule list (row p with row p): the weight gradient of a dense
+ * [n, ca]^T x [n, cb] product (1x1x1 convolutions and the point-branch Linear layers), where a
+ * library GEMM would run its whole n-long reduction in a handful of workgroups. */
 int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs, const int64_t* koff,
                      int a_col, float* gw, float* partial, int splits, int target_chunk, int k,
                      int ca, int cb, int dtype, void* stream);

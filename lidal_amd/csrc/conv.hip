@@ -395,7 +395,8 @@ conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* 
   for (int64_t p0 = p_beg; p0 < p_end; p0 += BP) {
     __syncthreads();
     if (tid < BP) {
-      int2 pr = (p0 + tid < p_end) ? pairs[p0 + tid] : make_int2(-1, -1);
+      int2 pr = make_int2(-1, -1);
+      if (p0 + tid < p_end) pr = pairs ? pairs[p0 + tid] : make_int2((int)(p0 + tid), (int)(p0 + tid));
       pa[tid] = a_col ? pr.y : pr.x;
       pb[tid] = a_col ? pr.x : pr.y;
     }
@@ -525,13 +526,15 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
 #pragma unroll
     for (int t = 0; t < PT_A; ++t) {
       const int row = (tid + t * NTHREADS) / SEG_A;
-      int2 pr = (p0 + row < p_end) ? pairs[p0 + row] : make_int2(-1, -1);
+      int2 pr = make_int2(-1, -1);
+      if (p0 + row < p_end) pr = pairs ? pairs[p0 + row] : make_int2((int)(p0 + row), (int)(p0 + row));
       ia[t] = a_col ? pr.y : pr.x;
     }
 #pragma unroll
     for (int t = 0; t < PT_B; ++t) {
       const int row = (tid + t * NTHREADS) / SEG_B;
-      int2 pr = (p0 + row < p_end) ? pairs[p0 + row] : make_int2(-1, -1);
+      int2 pr = make_int2(-1, -1);
+      if (p0 + row < p_end) pr = pairs ? pairs[p0 + row] : make_int2((int)(p0 + row), (int)(p0 + row));
       ib[t] = a_col ? pr.x : pr.y;
     }
   };

@@ -79,7 +79,7 @@ class SPVCNN(_SparseUNet):
         self.pres = 0.05
         self.vres = 0.05
         self.point_transforms = nn.ModuleList([
-            nn.Sequential(nn.Linear(a, b), spnn.BatchNorm1d(b), nn.ReLU(True))
+            nn.Sequential(spnn.Linear(a, b), spnn.BatchNorm1d(b), nn.ReLU(True))
             for a, b in ((cs[0], cs[4]), (cs[4], cs[6]), (cs[6], cs[8]))])
         self.weight_initialization()
         self.dropout = nn.Dropout(0.3, True)

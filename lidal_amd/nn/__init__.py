@@ -12,7 +12,7 @@ from ..utils import make_ntuple
 from . import functional, utils
 from .functional import conv3d
 
-__all__ = ['Conv3d', 'BatchNorm', 'BatchNorm1d', 'ReLU', 'functional', 'utils']
+__all__ = ['Conv3d', 'BatchNorm', 'BatchNorm1d', 'Linear', 'ReLU', 'functional', 'utils']
 
 
 def fapply(input, fn, *args, **kwargs):
@@ -60,6 +60,17 @@ class Conv3d(nn.Module):
     def forward(self, input):
         return conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
                       stride=self.stride, dilation=self.dilation, transposed=self.transposed)
+
+
+class Linear(nn.Linear):
+    """nn.Linear on a [N, C] tensor whose weight gradient runs on the split-K MFMA kernel (see
+    functional/dense.py); parameters are nn.Linear's, so state_dict keys are unchanged."""
+
+    def forward(self, x):
+        if not x.is_cuda or x.dim() != 2:
+            return super().forward(x)
+        from .functional.dense import rows_linear
+        return rows_linear(x, self.weight, self.bias)
 
 
 class BatchNorm1d(nn.BatchNorm1d):

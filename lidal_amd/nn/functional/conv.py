@@ -174,9 +174,8 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
 
     if kernel_size == (1, 1, 1) and stride == (1, 1, 1) and dilation == (1, 1, 1):
         B.require_gpu(feats)
-        feats = feats.matmul(weight)
-        if bias is not None:
-            feats = feats + bias
+        from .dense import rows_matmul
+        feats = rows_matmul(feats, weight, bias)
         output = SparseTensor(feats, coords, input.stride)
     elif not transposed:
         if dilation != (1, 1, 1):

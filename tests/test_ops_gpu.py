@@ -365,3 +365,38 @@ def test_batch_norm_rows_matches_torch(dtype, c, n):
     assert int(mine.num_batches_tracked) == 1
     ref.eval(), mine.eval()
     assert _relerr(mine(xq.to(DEV)).float().cpu(), ref(xq.double())) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dense_rows_matmul_and_linear(dtype):
+    """1x1x1 conv / point-branch Linear: forward, dx and the split-K weight gradient vs f64."""
+    import lidal_amd.nn as spnn
+    from lidal_amd.nn.functional.dense import rows_matmul
+    g = torch.Generator().manual_seed(3)
+    n, ci, co = 50001, 128, 96
+    x = torch.randn(n, ci, generator=g).to(dtype)
+    w = (torch.randn(ci, co, generator=g) * 0.1)
+    go = torch.randn(n, co, generator=g).to(dtype)
+    xr = x.double().requires_grad_(True)
+    wr = w.to(dtype).double().requires_grad_(True)
+    (xr @ wr).backward(go.double())
+    xg = x.to(DEV).requires_grad_(True)
+    wg = w.to(dtype).to(DEV).requires_grad_(True)
+    y = rows_matmul(xg, wg)
+    y.backward(go.to(DEV))
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert _relerr(y.float().cpu(), (xr @ wr).detach()) < tol
+    assert _relerr(xg.grad.float().cpu(), xr.grad) < tol
+    assert _relerr(wg.grad.float().cpu(), wr.grad) < tol
+    lin = spnn.Linear(ci, 32).to(DEV)
+    ref = torch.nn.Linear(ci, 32).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in lin.state_dict().items()})
+    xl = x.float().to(DEV).requires_grad_(True)
+    out = lin(xl)
+    out.square().sum().backward()
+    xl_r = x.double().requires_grad_(True)
+    ref(xl_r).square().sum().backward()
+    assert _relerr(out.detach().cpu(), ref(xl_r).detach()) < 1e-4
+    assert _relerr(lin.weight.grad.cpu(), ref.weight.grad) < 1e-4
+    assert _relerr(lin.bias.grad.cpu(), ref.bias.grad) < 1e-4
+    assert _relerr(xl.grad.cpu(), xl_r.grad) < 1e-4

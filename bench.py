@@ -141,13 +141,14 @@ def roofline_conv(args, coords, dev, reps=20):
     ci = co = 96
     kmap, _ = F.build_kernel_map(coords, (1, 1, 1), (3, 3, 3), (1, 1, 1))
     n, m = coords.shape[0], kmap.total
+    order = kmap.order_out
     x = torch.randn(n, ci, device=dev).to(dtype)
     wk = (torch.randn(27, co, ci, device=dev) * 0.02).to(dtype)
     out = torch.empty((n, co), dtype=dtype, device=dev)
 
     def launch():
-        B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(kmap.nbr_out), B.ptr(out), n,
-                                         ci, co, 27, 0, B.dtype_code(dtype), B.stream()), 'conv')
+        B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
+                                         B.ptr(out), n, ci, co, 27, 0, B.dtype_code(dtype), B.stream()), 'conv')
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -82,6 +82,14 @@ int lidal_kmap_build(const void* table, int64_t table_bytes, const int32_t* out_
 int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr_in, int64_t n_in,
                       void* stream);
 
+/* Row order for lidal_conv_apply: rows of nbr [k, n_rows] sorted by their occupancy pattern (bit j set
+ * iff nbr[j][row] >= 0; stable, so ties keep row order).  perm i32 [n_rows] (sorted position ->
+ * row), nbr_perm i32 [k, n_rows] = nbr[:, perm].  With it a 16-row MFMA group / 128-row tile only
+ * touches the offsets of its own pattern. */
+int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows);
+int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32_t* perm, int32_t* nbr_perm,
+                     void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- point <-> voxel ------------------------------------------------------------------------- */
 /* replaces backend.count_cuda (F.spcount: network/utils.py:20,49). out i32 [m] (zeroed here). */
 int lidal_count(const int32_t* idx, int64_t n, int32_t* out, int64_t m, void* stream);
@@ -121,11 +129,13 @@ int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int wt_dtype, i
 /* replaces backend.convolution_forward_cuda and the data-gradient half of
  * convolution_backward_cuda (every spnn.Conv3d.forward/backward, 49 per model pass).
  * Output-stationary fused gather-GEMM with register accumulators:
- *     out[j, :] = sum_k  in[ nbr[kk][j], : ] * Wk[k]^T,   kk = kflip ? K-1-k : k
- * with Wk laid out [k][co][ci] (reduction dim contiguous), nbr i32 [k, n_out] (-1 = no rule).
+ *     out[row(j), :] = sum_k  in[ nbr[kk][j], : ] * Wk[k]^T,   kk = kflip ? K-1-k : k
+ * with Wk laid out [k][co][ci] (reduction dim contiguous), nbr i32 [k, n_out] (-1 = no rule) and
+ * row(j) = perm ? perm[j] : j  (pass lidal_kmap_order's perm together with its permuted table).
  * No atomics: each output row is written exactly once => bitwise reproducible. */
-int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, void* out,
-                     int64_t n_out, int ci, int co, int k, int kflip, int dtype, void* stream);
+int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const int32_t* perm,
+                     void* out, int64_t n_out, int ci, int co, int k, int kflip, int dtype,
+                     void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
  * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  Split-K: offset k with nk rules is cut into

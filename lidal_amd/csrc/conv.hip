@@ -36,8 +36,11 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int NTHREADS = 256;
-constexpr int NWAVES = 4;
+#ifndef LIDAL_NWAVES
+#define LIDAL_NWAVES 4
+#endif
+constexpr int NWAVES = LIDAL_NWAVES;     // waves per conv_apply workgroup
+constexpr int NTHREADS = 64 * NWAVES;
 
 template <typename T> struct DT;
 template <> struct DT<float> {
@@ -104,7 +107,8 @@ constexpr int BM = NWAVES * G * 16;   // output rows per workgroup
 template <typename T, int NB, int ROW_BYTES>
 __global__ void __launch_bounds__(NTHREADS)
 conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
-                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip) {
+                  const int* __restrict__ perm, T* __restrict__ out, int64_t n_out, int ci, int co,
+                  int K, int kflip) {
   constexpr int BN = 16 * NB;
   constexpr int VEC = DT<T>::VEC;
   constexpr int CH = DT<T>::CH;
@@ -131,8 +135,10 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   const int64_t r0 = (int64_t)blockIdx.x * BM + wave * RW;   // first row of this wave
   const int n0 = blockIdx.y * BN;
   const int npass = (ci + KC - 1) / KC;
-  const int nphase = K * npass;
   int* nidx = nidx_all + wave * K * RW;                      // [K][RW], wave-private
+  __shared__ unsigned tile_mask;
+  __shared__ int act_k[MAXK];
+  if (tid == 0) tile_mask = 0u;
 
   // ---- 0. this wave's slice of the neighbour table -> LDS (K*RW independent coalesced loads)
   for (int i = lane; i < K * RW; i += 64) {
@@ -140,11 +146,32 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     const int kk = kflip ? (K - 1 - k) : k;
     nidx[i] = (r0 + r < n_out) ? nbr[(int64_t)kk * n_out + r0 + r] : -1;
   }
+  __syncthreads();
+  // offsets that have at least one rule in this 128-row tile (rows are pre-sorted by occupancy
+  // pattern, so most tiles use only a few of the K offsets): only those are staged and multiplied
+  {
+    unsigned wmask = 0u;
+    for (int k = 0; k < K; ++k) {
+      const int v = (lane < RW) ? nidx[k * RW + lane] : -1;
+      if (__ballot(v >= 0) != 0ull) wmask |= 1u << k;
+    }
+    if (lane == 0 && wmask) atomicOr(&tile_mask, wmask);
+  }
+  __syncthreads();
+  const unsigned tmask = tile_mask;
+  const int n_act = __popc(tmask);
+  if (tid == 0) {
+    int j = 0;
+    for (int k = 0; k < K; ++k)
+      if (tmask & (1u << k)) act_k[j++] = k;
+  }
+  const int nphase = n_act * npass;
 
   // weight slab of phase p -> registers (issue early) -> LDS buffer (write late)
   frag wreg[WPT];
   auto stage_load = [&](int p) {
-    const int k = p / npass, c0 = (p - k * npass) * KC;
+    const int q = p / npass, c0 = (p - q * npass) * KC;
+    const int k = act_k[q];
     const int kc = min(KC, ci - c0);
     const T* wsrc = wk + ((int64_t)k * co + n0) * ci + c0;
 #pragma unroll
@@ -169,7 +196,8 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   // A fragments of phase p: for each row group 16 gathered input rows x kc channels, straight to
   // VGPRs (16 B per lane, 64 B contiguous per row); `present` = ballot of rows that have a rule
   auto load_a = [&](frag (&a)[G][MAXCC], unsigned long long (&present)[G], int p) {
-    const int k = p / npass, c0 = (p - k * npass) * KC;
+    const int q = p / npass, c0 = (p - q * npass) * KC;
+    const int k = act_k[q];
     const int kc = min(KC, ci - c0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -192,16 +220,20 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();            // slab 0 and the neighbour slices are visible
-
+  __syncthreads();            // act_k visible
   frag a_cur[G][MAXCC], a_nxt[G][MAXCC];
   unsigned long long pres_cur[G], pres_nxt[G];
-  load_a(a_cur, pres_cur, 0);
+#pragma unroll
+  for (int g = 0; g < G; ++g) pres_cur[g] = 0ull;
+  if (nphase > 0) {
+    stage_load(0);
+    stage_store(0);
+    load_a(a_cur, pres_cur, 0);
+  }
+  __syncthreads();            // slab 0 visible
 
   for (int p = 0; p < nphase; ++p) {
-    const int k = p / npass, c0 = (p - k * npass) * KC;
+    const int c0 = (p % npass) * KC;
     const int kc = min(KC, ci - c0);
     const T* wbuf = wl + (p & 1) * BN * WSTRIDE;
     const bool more = p + 1 < nphase;
@@ -254,8 +286,8 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   constexpr int RSEGS = BN / VEC;                          // 16-byte segments per row
   for (int i = lane; i < RW * RSEGS; i += 64) {
     const int r = i / RSEGS, cseg = (i - r * RSEGS) * VEC;
-    const int64_t row = r0 + r;
-    if (row >= n_out) continue;
+    if (r0 + r >= n_out) continue;
+    const int64_t row = perm ? (int64_t)perm[r0 + r] : r0 + r;
     T* dst = out + row * co + n0 + cseg;
     const T* srcp = et + r * ESTRIDE + cseg;
     if (n0 + cseg + VEC <= co) {
@@ -269,8 +301,8 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
 }
 
 template <typename T, int NB, int ROW_BYTES>
-int launch_conv_apply(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
-                      int ci, int co, int K, int kflip, hipStream_t s) {
+int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
+                      int64_t n_out, int ci, int co, int K, int kflip, hipStream_t s) {
   constexpr int BN = 16 * NB;
   constexpr int KC = ROW_BYTES / (int)sizeof(T);
   constexpr int WSTRIDE = KC + DT<T>::VEC;
@@ -286,36 +318,36 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, void* out,
     attr_set = lds;
   }
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
-  kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, (T*)out, n_out, ci, co, K,
-                                   kflip);
+  kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, perm, (T*)out, n_out, ci, co,
+                                   K, kflip);
   LIDAL_CHECK_LAUNCH("lidal_conv_apply");
   return 0;
 }
 
 template <typename T, int ROW_BYTES>
-int dispatch_conv_tile(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
-                       int ci, int co, int K, int kflip, hipStream_t s) {
+int dispatch_conv_tile(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
+                       int64_t n_out, int ci, int co, int K, int kflip, hipStream_t s) {
   // BN = 16*NB output channels per workgroup; grid.y covers the rest.
-  if (co <= 32) return launch_conv_apply<T, 2, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
-  if (co <= 64) return launch_conv_apply<T, 4, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  if (co <= 32) return launch_conv_apply<T, 2, ROW_BYTES>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  if (co <= 64) return launch_conv_apply<T, 4, ROW_BYTES>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
   if (co % 128 != 0 && (co % 96 == 0 || co < 128))
-    return launch_conv_apply<T, 6, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
-  return launch_conv_apply<T, 8, ROW_BYTES>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 6, ROW_BYTES>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  return launch_conv_apply<T, 8, ROW_BYTES>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
 }
 
 template <typename T>
-int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, void* out, int64_t n_out,
-                        int ci, int co, int K, int kflip, hipStream_t s) {
+int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
+                        int64_t n_out, int ci, int co, int K, int kflip, hipStream_t s) {
   // staged reduction bytes per pass: 128 (more workgroups per CU beat longer passes: measured in
   // profiles/README.md), except rows that are a multiple of 192 but not of 128 bytes (ci = 96
   // bf16 -> one pass of 96 instead of 64 + 32).
   const int row_bytes = ci * (int)sizeof(T);
 #ifdef LIDAL_ROWB_OVERRIDE
-  return dispatch_conv_tile<T, LIDAL_ROWB_OVERRIDE>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_tile<T, LIDAL_ROWB_OVERRIDE>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
 #endif
   if (row_bytes % 192 == 0 && row_bytes % 128 != 0)
-    return dispatch_conv_tile<T, 192>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
-  return dispatch_conv_tile<T, 128>(in, wk, nbr, out, n_out, ci, co, K, kflip, s);
+    return dispatch_conv_tile<T, 192>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_tile<T, 128>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -345,6 +377,7 @@ __global__ void __launch_bounds__(256) weight_pack_kernel(const TI* __restrict__
 // ------------------------------------------------------------------------------------------
 // wgrad: gw[k][ca][cb] = sum_p a[pa(p)][:]^T b[pb(p)][:]
 // ------------------------------------------------------------------------------------------
+constexpr int WTHREADS = 256;   // wgrad workgroups: 4 waves as 2 x 2
 constexpr int BP = 32;   // rules per staging step (f32 kernel)
 
 // Split-K policy shared by both wgrad kernels and the reducer: offset k with nk rules is cut into
@@ -359,7 +392,7 @@ __host__ __device__ __forceinline__ int splits_for(int64_t nk, int max_splits, i
 
 // workgroup tile: (2*MI*16) x (2*NI*16) of gw[k]; waves as 2 x 2.
 template <typename T, int MI, int NI>
-__global__ void __launch_bounds__(NTHREADS)
+__global__ void __launch_bounds__(WTHREADS)
 conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* __restrict__ pairs,
                   const int64_t* __restrict__ koff, int a_col, float* __restrict__ partial,
                   int K, int ca, int cb, int tiles_b, int target_chunk) {
@@ -402,7 +435,7 @@ conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* 
     }
     __syncthreads();
     // stage gathered rows as f32: 4 consecutive channels per thread per step
-    for (int i = tid; i < BP * (TA / 4); i += NTHREADS) {
+    for (int i = tid; i < BP * (TA / 4); i += WTHREADS) {
       int p = i / (TA / 4), c = (i - p * (TA / 4)) * 4;
       int src = pa[p];
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -414,7 +447,7 @@ conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* 
       }
       *reinterpret_cast<f32x4*>(la + p * SA + c) = f32x4{v[0], v[1], v[2], v[3]};
     }
-    for (int i = tid; i < BP * (TB / 4); i += NTHREADS) {
+    for (int i = tid; i < BP * (TB / 4); i += WTHREADS) {
       int p = i / (TB / 4), c = (i - p * (TB / 4)) * 4;
       int src = pb[p];
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -480,7 +513,7 @@ constexpr int BPB = 64;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 template <int MI, int NI>
-__global__ void __launch_bounds__(NTHREADS)
+__global__ void __launch_bounds__(WTHREADS)
 conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
                        const int2* __restrict__ pairs, const int64_t* __restrict__ koff, int a_col,
                        float* __restrict__ partial, int K, int ca, int cb, int tiles_b,
@@ -488,8 +521,8 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
   constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
   constexpr int SA = TA + 8, SB = TB + 8;              // LDS row strides (bf16), +16 B pad
   constexpr int SEG_A = TA / 8, SEG_B = TB / 8;        // 16-byte segments per gathered row
-  constexpr int PT_A = (BPB * SEG_A) / NTHREADS, PT_B = (BPB * SEG_B) / NTHREADS;
-  static_assert((BPB * SEG_A) % NTHREADS == 0 && (BPB * SEG_B) % NTHREADS == 0, "tile/threads");
+  constexpr int PT_A = (BPB * SEG_A) / WTHREADS, PT_B = (BPB * SEG_B) / WTHREADS;
+  static_assert((BPB * SEG_A) % WTHREADS == 0 && (BPB * SEG_B) % WTHREADS == 0, "tile/threads");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* la = reinterpret_cast<__bf16*>(smem);                       // [2][BPB][SA]
   __bf16* lb = la + 2 * BPB * SA;                                     // [2][BPB][SB]
@@ -525,14 +558,14 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
     const int64_t p0 = p_beg + (int64_t)step * BPB;
 #pragma unroll
     for (int t = 0; t < PT_A; ++t) {
-      const int row = (tid + t * NTHREADS) / SEG_A;
+      const int row = (tid + t * WTHREADS) / SEG_A;
       int2 pr = make_int2(-1, -1);
       if (p0 + row < p_end) pr = pairs ? pairs[p0 + row] : make_int2((int)(p0 + row), (int)(p0 + row));
       ia[t] = a_col ? pr.y : pr.x;
     }
 #pragma unroll
     for (int t = 0; t < PT_B; ++t) {
-      const int row = (tid + t * NTHREADS) / SEG_B;
+      const int row = (tid + t * WTHREADS) / SEG_B;
       int2 pr = make_int2(-1, -1);
       if (p0 + row < p_end) pr = pairs ? pairs[p0 + row] : make_int2((int)(p0 + row), (int)(p0 + row));
       ib[t] = a_col ? pr.x : pr.y;
@@ -541,14 +574,14 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
   auto load_rows = [&]() {
 #pragma unroll
     for (int t = 0; t < PT_A; ++t) {
-      const int sg = tid + t * NTHREADS, c = (sg % SEG_A) * 8;
+      const int sg = tid + t * WTHREADS, c = (sg % SEG_A) * 8;
       ra[t] = DT<__bf16>::zero();
       if (ia[t] >= 0 && ca0 + c < ca)
         ra[t] = load_frag_guarded<__bf16>(a + (int64_t)ia[t] * ca + ca0 + c, ca - ca0 - c);
     }
 #pragma unroll
     for (int t = 0; t < PT_B; ++t) {
-      const int sg = tid + t * NTHREADS, c = (sg % SEG_B) * 8;
+      const int sg = tid + t * WTHREADS, c = (sg % SEG_B) * 8;
       rb[t] = DT<__bf16>::zero();
       if (ib[t] >= 0 && cb0 + c < cb)
         rb[t] = load_frag_guarded<__bf16>(b + (int64_t)ib[t] * cb + cb0 + c, cb - cb0 - c);
@@ -557,12 +590,12 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
   auto store_rows = [&](int buf) {
 #pragma unroll
     for (int t = 0; t < PT_A; ++t) {
-      const int sg = tid + t * NTHREADS, row = sg / SEG_A, c = (sg % SEG_A) * 8;
+      const int sg = tid + t * WTHREADS, row = sg / SEG_A, c = (sg % SEG_A) * 8;
       *reinterpret_cast<bf16x8*>(la + (buf * BPB + row) * SA + c) = ra[t];
     }
 #pragma unroll
     for (int t = 0; t < PT_B; ++t) {
-      const int sg = tid + t * NTHREADS, row = sg / SEG_B, c = (sg % SEG_B) * 8;
+      const int sg = tid + t * WTHREADS, row = sg / SEG_B, c = (sg % SEG_B) * 8;
       *reinterpret_cast<bf16x8*>(lb + (buf * BPB + row) * SB + c) = rb[t];
     }
   };
@@ -646,10 +679,10 @@ int launch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = lds;
     }
-    kern<<<grid, NTHREADS, lds, s>>>((const __bf16*)a, (const __bf16*)b, (const int2*)pairs, koff,
+    kern<<<grid, WTHREADS, lds, s>>>((const __bf16*)a, (const __bf16*)b, (const int2*)pairs, koff,
                                      a_col, partial, K, ca, cb, tiles_b, target_chunk);
   } else {
-    conv_wgrad_kernel<T, MI, NI><<<grid, NTHREADS, 0, s>>>((const T*)a, (const T*)b,
+    conv_wgrad_kernel<T, MI, NI><<<grid, WTHREADS, 0, s>>>((const T*)a, (const T*)b,
                                                            (const int2*)pairs, koff, a_col, partial,
                                                            K, ca, cb, tiles_b, target_chunk);
   }
@@ -704,20 +737,20 @@ extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int 
   return 0;
 }
 
-extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, void* out,
-                                int64_t n_out, int ci, int co, int k, int kflip, int dtype,
-                                void* stream) {
+extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr,
+                                const int32_t* perm, void* out, int64_t n_out, int ci, int co, int k,
+                                int kflip, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out == 0 || co == 0) return 0;
   LIDAL_REQUIRE(ci > 0 && k > 0 && k <= MAXK, "conv_apply: bad shape ci=%d k=%d", ci, k);
   if (dtype == LIDAL_F32) {
     LIDAL_REQUIRE(ci % 4 == 0 && co % 4 == 0, "conv_apply f32: channels must be multiples of 4");
-    return dispatch_conv_apply<float>(in, wk, nbr, out, n_out, ci, co, k, kflip, s);
+    return dispatch_conv_apply<float>(in, wk, nbr, perm, out, n_out, ci, co, k, kflip, s);
   }
   if (dtype == LIDAL_BF16) {
     LIDAL_REQUIRE((ci % 8 == 0 || ci < 8) && co % 4 == 0,
                   "conv_apply bf16: ci must be a multiple of 8 (or < 8), co a multiple of 4");
-    return dispatch_conv_apply<__bf16>(in, wk, nbr, out, n_out, ci, co, k, kflip, s);
+    return dispatch_conv_apply<__bf16>(in, wk, nbr, perm, out, n_out, ci, co, k, kflip, s);
   }
   set_error("conv_apply: bad dtype %d", dtype);
   return 2;

@@ -270,6 +270,42 @@ __global__ void __launch_bounds__(256) kmap_invert_kernel(const int* __restrict_
 }
 
 
+
+// ---------------- occupancy-pattern row order for the output-stationary conv kernel -------------
+// mask[j] = bit k set iff nbr[k][j] >= 0.  Sorting the rows by this K-bit pattern puts rows with
+// the same set of occupied offsets next to each other, so a 16-row MFMA group (and a 128-row tile)
+// needs only the offsets of ITS pattern: on LiDAR surfaces the non-empty (group, offset) fraction
+// drops from 0.5-0.8 to ~0.23 (waste 1.3x instead of 3-4.5x).  Output: perm (sorted position ->
+// row) and the table permuted into that order.
+__global__ void __launch_bounds__(256) row_mask_kernel(const int* __restrict__ nbr, int64_t n,
+                                                       int K, unsigned* __restrict__ keys,
+                                                       int* __restrict__ vals) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  unsigned m = 0u;
+  for (int k = 0; k < K; ++k)
+    if (nbr[(int64_t)k * n + j] >= 0) m |= 1u << k;
+  keys[j] = m;
+  vals[j] = (int)j;
+}
+
+__global__ void __launch_bounds__(256) permute_table_kernel(const int* __restrict__ nbr, int64_t n,
+                                                            const int* __restrict__ perm,
+                                                            int* __restrict__ nbr_perm) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (r >= n) return;
+  nbr_perm[(int64_t)k * n + r] = nbr[(int64_t)k * n + perm[r]];
+}
+
+size_t mask_sort_tmp_bytes(int64_t n) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr,
+                                  (const int*)nullptr, (int*)nullptr, (size_t)(n > 0 ? n : 1), 0,
+                                  32, (hipStream_t)0);
+  return tmp;
+}
+
 }  // namespace
 
 extern "C" int64_t lidal_unique_workspace_bytes(int64_t n) {
@@ -355,5 +391,31 @@ extern "C" int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, i
   kmap_invert_kernel<<<dim3((unsigned)cdiv(n_out, 256), (unsigned)k), 256, 0, s>>>(
       nbr_out, n_out, k, nbr_in, n_in);
   LIDAL_CHECK_LAUNCH("kmap_invert");
+  return 0;
+}
+
+extern "C" int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows) {
+  int64_t q = n_rows > 0 ? n_rows : 1;
+  return 3 * align_up(4 * q, 256) + align_up((int64_t)mask_sort_tmp_bytes(q), 256) + 256;
+}
+
+extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32_t* perm,
+                                int32_t* nbr_perm, void* ws, int64_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(k > 0 && k <= 32, "kmap_order: kernel volume %d must be <= 32", k);
+  if (n_rows == 0) return 0;
+  LIDAL_REQUIRE(ws_bytes >= lidal_kmap_order_workspace_bytes(n_rows), "kmap_order ws too small");
+  int64_t q = n_rows, a = align_up(4 * q, 256);
+  unsigned* keys = (unsigned*)ws;
+  unsigned* skeys = (unsigned*)((char*)ws + a);
+  int* vals = (int*)((char*)ws + 2 * a);
+  void* tmp = (char*)ws + 3 * a;
+  size_t tmp_bytes = mask_sort_tmp_bytes(q);
+  row_mask_kernel<<<(unsigned)cdiv(q, 256), 256, 0, s>>>(nbr, q, k, keys, vals);
+  LIDAL_CHECK_LAUNCH("row_mask");
+  LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, perm, (size_t)q, 0, k, s));
+  permute_table_kernel<<<dim3((unsigned)cdiv(q, 256), (unsigned)k), 256, 0, s>>>(nbr, q, perm,
+                                                                                 nbr_perm);
+  LIDAL_CHECK_LAUNCH("permute_table");
   return 0;
 }

@@ -10,6 +10,7 @@ KernelMap holds what torchsparse keeps ([nbmaps, nbsizes, (n_in, n_out)], same o
 values) plus what the output-stationary kernel consumes:
   nbr_out [K, n_out]  input row feeding output row j through offset k (-1: none)
   nbr_in  [K, n_in]   output row fed by input row i through offset k (built lazily)
+  order_out/order_in  RowOrder: the tables with rows sorted by occupancy pattern (built lazily)
 """
 import torch
 from torch.autograd import Function
@@ -22,7 +23,23 @@ from .downsample import spdownsample
 from .hash import sphash
 from .query import HashTable
 
-__all__ = ['conv3d', 'KernelMap', 'build_kernel_map']
+__all__ = ['conv3d', 'KernelMap', 'RowOrder', 'build_kernel_map']
+
+
+class RowOrder:
+    """A neighbour table re-ordered by occupancy pattern (lidal_kmap_order): `perm` maps sorted
+    position -> row, `table` = nbr[:, perm].  Built once per table, shared by every conv using it."""
+
+    def __init__(self, nbr):
+        k, n = nbr.shape
+        dev = nbr.device
+        self.n_rows = n
+        self.perm = torch.empty(max(n, 1), dtype=torch.int, device=dev)
+        self.table = torch.empty((k, n), dtype=torch.int, device=dev)
+        ws_bytes = B.lib().lidal_kmap_order_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        B.check(B.lib().lidal_kmap_order(B.ptr(nbr), n, k, B.ptr(self.perm), B.ptr(self.table),
+                                         B.ptr(ws), ws_bytes, B.stream()), 'kmap_order')
 
 
 class KernelMap:
@@ -36,6 +53,8 @@ class KernelMap:
         self.symmetric = symmetric           # odd kernel, stride 1: nbr_in[k] == nbr_out[K-1-k]
         self._nbr_in = None
         self._total = None
+        self._order_out = None
+        self._order_in = None
 
     @property
     def total(self):
@@ -57,6 +76,18 @@ class KernelMap:
                                               n_in, B.stream()), 'kmap_invert')
             self._nbr_in = t
         return self._nbr_in
+
+    @property
+    def order_out(self):
+        if self._order_out is None:
+            self._order_out = RowOrder(self.nbr_out)
+        return self._order_out
+
+    @property
+    def order_in(self):
+        if self._order_in is None:
+            self._order_in = RowOrder(self.nbr_in)
+        return self._order_in
 
     def __getitem__(self, i):                # torchsparse's [nbmaps, nbsizes, sizes] list view
         return (self.nbmaps, self.nbsizes, self.sizes)[i]
@@ -100,14 +131,14 @@ def _pack_weight(weight, dtype):
     return wt
 
 
-def _apply(feats, wk, table, kflip):
-    """out[j] = sum_k feats[table[kk][j]] @ wk[k]^T with wk [K, co, ci], table i32 [K, n_out]."""
+def _apply(feats, wk, order, kflip):
+    """out[j] = sum_k feats[nbr[kk][j]] @ wk[k]^T with wk [K, co, ci]; `order` = RowOrder(nbr)."""
     k, co, ci = wk.shape
-    n_out = table.shape[1]
+    n_out = order.n_rows
     out = torch.empty((n_out, co), dtype=feats.dtype, device=feats.device)
-    B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(table), B.ptr(out), n_out, ci,
-                                     co, k, int(kflip), B.dtype_code(feats.dtype), B.stream()),
-            'conv_apply')
+    B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
+                                     B.ptr(out), n_out, ci, co, k, int(kflip),
+                                     B.dtype_code(feats.dtype), B.stream()), 'conv_apply')
     return out
 
 
@@ -128,8 +159,8 @@ class ConvolutionFunction(Function):
             cdtype = torch.float32
         x = feats.contiguous().to(cdtype)
         n_in, n_out = kmap.sizes
-        table = kmap.nbr_in if transposed else kmap.nbr_out
-        out = _apply(x, _pack_weight(weight, cdtype), table, 0)
+        order = kmap.order_in if transposed else kmap.order_out
+        out = _apply(x, _pack_weight(weight, cdtype), order, 0)
         ctx.kmap = kmap
         ctx.transposed = transposed
         ctx.save_for_backward(x, weight)
@@ -148,11 +179,11 @@ class ConvolutionFunction(Function):
             wk = weight.detach().contiguous().to(x.dtype)
             if not transposed:
                 if kmap.symmetric:
-                    grad_in = _apply(g, wk, kmap.nbr_out, 1)
+                    grad_in = _apply(g, wk, kmap.order_out, 1)
                 else:
-                    grad_in = _apply(g, wk, kmap.nbr_in, 0)
+                    grad_in = _apply(g, wk, kmap.order_in, 0)
             else:
-                grad_in = _apply(g, wk, kmap.nbr_out, 0)
+                grad_in = _apply(g, wk, kmap.order_out, 0)
         if ctx.needs_input_grad[1]:
             k, ci, co = weight.shape
             splits = _wgrad_splits(max(n_in, n_out))

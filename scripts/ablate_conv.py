@@ -11,10 +11,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'scripts', '_abl')
-VARIANTS = {'base': [], 'rowb64': ['-DLIDAL_ROWB_OVERRIDE=64'], 'rowb256': ['-DLIDAL_ROWB_OVERRIDE=256'],
-            'g3': ['-DLIDAL_G=3'],
-            'noA': ['-DLIDAL_ABLATE=1'], 'noW': ['-DLIDAL_ABLATE=2'], 'noMFMA': ['-DLIDAL_ABLATE=4'],
-            'skeleton': ['-DLIDAL_ABLATE=7']}
+VARIANTS = {'base': [], 'nw8': ['-DLIDAL_NWAVES=8'], 'nw16': ['-DLIDAL_NWAVES=16'], 'g4': ['-DLIDAL_G=4'],
+            'nw8g1': ['-DLIDAL_NWAVES=8', '-DLIDAL_G=1'],
+            }
 # (level stride, ci, co): the heavy layer families of the U-Net
 SHAPES = [(1, 32, 32), (1, 96, 96), (2, 32, 32), (4, 128, 128), (4, 64, 64), (8, 256, 256),
           (8, 384, 256), (16, 256, 256)]
@@ -50,7 +49,7 @@ def run():
         lib = ctypes.CDLL(os.path.join(OUT, 'conv_%s.so' % name))
         lib.lidal_conv_apply.restype, lib.lidal_conv_apply.argtypes = sig
         libs[name] = lib.lidal_conv_apply
-    print('%-22s' % 'shape (rows, rules)' + ''.join('%11s' % n for n in VARIANTS))
+    print('%-22s' % 'shape (rows, rules)' + ''.join('%11s' % (n[:5] + '+sort') for n in VARIANTS))
     for stride, ci, co in SHAPES:
         c = levels[stride]
         kmap, _ = F.build_kernel_map(c, (stride,) * 3, (3, 3, 3), (1, 1, 1))
@@ -60,11 +59,17 @@ def run():
         out = torch.empty((n, co), dtype=dtype, device='cuda')
         row = 's%d %d->%d (%dk,%dk)' % (stride, ci, co, n // 1000, kmap.total // 1000)
         times = []
-        for name, fn in libs.items():
+        order = kmap.order_out
+        for name, fn in [(n_ + m_, f_) for n_, f_ in libs.items() for m_ in ('+sort',)]:
+            tab, prm = (order.table, order.perm) if name.endswith('+sort') else (kmap.nbr_out, None)
             def launch():
-                rc = fn(B.ptr(x), B.ptr(wk), B.ptr(kmap.nbr_out), B.ptr(out), n, ci, co, 27, 0,
+                rc = fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(out), n, ci, co, 27, 0,
                         B.dtype_code(dtype), B.stream())
                 assert rc == 0
+            if fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(out), n, ci, co, 27, 0,
+                  B.dtype_code(dtype), B.stream()) != 0:
+                times.append(float('nan'))
+                continue
             for _ in range(2):
                 launch()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

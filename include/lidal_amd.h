@@ -155,17 +155,24 @@ int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs, const i
  * variance (running_* may be NULL); save_mean / save_invstd f32 [c] feed the backward.
  * c must be a multiple of 4 (f32) / 8 (bf16). */
 int64_t lidal_bn_workspace_bytes(int64_t n, int c);
+/* `relu` != 0 fuses the ReLU that follows the normalisation in the model (forward: max(y, 0);
+ * backward: dy is taken where y > 0, y recomputed from x). */
 int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean,
-                       float* running_var, void* y, float* save_mean, float* save_invstd, void* ws,
-                       int64_t ws_bytes, void* stream);
+                       float* running_var, int relu, void* y, float* save_mean, float* save_invstd,
+                       void* ws, int64_t ws_bytes, void* stream);
 int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                       const float* beta, const float* running_mean, const float* running_var,
-                      float eps, void* y, void* stream);
+                      float eps, int relu, void* y, void* stream);
 /* dx may be NULL (only parameter gradients wanted). */
 int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n, int c, const float* gamma,
-                 const float* save_mean, const float* save_invstd, void* dx, float* grad_gamma,
-                 float* grad_beta, void* ws, int64_t ws_bytes, void* stream);
+                 const float* beta, int relu, const float* save_mean, const float* save_invstd,
+                 void* dx, float* grad_gamma, float* grad_beta, void* ws, int64_t ws_bytes,
+                 void* stream);
+/* Column sums of x [n, c] -> out f32 [c] (bias gradients of the 1x1 / Linear layers);
+ * ws >= lidal_bn_workspace_bytes(n, c) + 12*c bytes. */
+int lidal_colsum(const void* x, int dtype, int64_t n, int c, float* out, void* ws,
+                 int64_t ws_bytes, void* stream);
 
 /* ---- probability inference post-processing ------------------------------------------------- */
 /* replaces score/prob_inference.py:100-113: logits f32 [nv, c] of `reps` collated views,

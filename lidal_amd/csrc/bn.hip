@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
                                                       const float* __restrict__ istd_or_var,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
-                                                      T* __restrict__ y) {
+                                                      int relu, T* __restrict__ y) {
   constexpr int VEC = IO<T>::VEC;
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
@@ -184,7 +184,10 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
     float f[VEC];
     IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), f);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
+    for (int i = 0; i < VEC; ++i) {
+      f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
+      if (relu) f[i] = fmaxf(f[i], 0.f);
+    }
     *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
   }
 }
@@ -195,25 +198,35 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
                                                             const T* __restrict__ dy, int64_t n,
                                                             int c, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
-                                                            float* __restrict__ part) {
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            int relu, float* __restrict__ part) {
   constexpr int VEC = IO<T>::VEC;
   extern __shared__ float sh[];                 // [2][NT][VEC]
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
   const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
   const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
-  float a[VEC], b[VEC], mu[VEC], is[VEC];
+  float a[VEC], b[VEC], mu[VEC], is[VEC], ga[VEC], be[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; }
+  for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; ga[i] = 1.f; be[i] = 0.f; }
   if (rl < rpi) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { mu[i] = mean[cg * VEC + i]; is[i] = invstd[cg * VEC + i]; }
+    for (int i = 0; i < VEC; ++i) {
+      mu[i] = mean[cg * VEC + i]; is[i] = invstd[cg * VEC + i];
+      if (gamma) ga[i] = gamma[cg * VEC + i];
+      if (beta) be[i] = beta[cg * VEC + i];
+    }
     for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
       float fx[VEC], fd[VEC];
       IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), fx);
       IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), fd);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { a[i] += fd[i]; b[i] += fd[i] * ((fx[i] - mu[i]) * is[i]); }
+      for (int i = 0; i < VEC; ++i) {
+        const float xhat = (fx[i] - mu[i]) * is[i];
+        if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;      // fused ReLU: dy where y > 0
+        a[i] += fd[i]; b[i] += fd[i] * xhat;
+      }
     }
   }
   float* sa = sh; float* sb = sh + NT * VEC;
@@ -262,6 +275,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int relu,
                                                        const float* __restrict__ sum_dy,
                                                        const float* __restrict__ sum_dy_xhat,
                                                        T* __restrict__ dx) {
@@ -272,12 +286,12 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
   const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
   const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
   const float inv_n = 1.f / (float)n;
-  float mu[VEC], is[VEC], gs[VEC], k1[VEC], k2[VEC];
+  float mu[VEC], is[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     const int ch = cg * VEC + i;
     mu[i] = mean[ch]; is[i] = invstd[ch];
-    gs[i] = (gamma ? gamma[ch] : 1.f) * is[i];
+    ga[i] = gamma ? gamma[ch] : 1.f; be[i] = beta ? beta[ch] : 0.f;
     k1[i] = sum_dy[ch] * inv_n; k2[i] = sum_dy_xhat[ch] * inv_n;
   }
   for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
@@ -285,7 +299,11 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
     IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), fx);
     IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), fd);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) fd[i] = gs[i] * (fd[i] - k1[i] - (fx[i] - mu[i]) * is[i] * k2[i]);
+    for (int i = 0; i < VEC; ++i) {
+      const float xhat = (fx[i] - mu[i]) * is[i];
+      if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
+      fd[i] = ga[i] * is[i] * (fd[i] - k1[i] - xhat * k2[i]);
+    }
     *reinterpret_cast<typename IO<T>::vec*>(dx + r * c + cg * VEC) = IO<T>::pack(fd);
   }
 }
@@ -293,8 +311,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
 static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, ROWS_PER_WG); }
 template <typename T>
 int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-                 float momentum, float* rm, float* rv, void* y, float* mean, float* invstd,
-                 float* part, hipStream_t s) {
+                 float momentum, float* rm, float* rv, int relu, void* y, float* mean,
+                 float* invstd, float* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
   bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>((const T*)x, n, c, part);
@@ -302,25 +320,26 @@ int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const floa
   bn_stats_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
                                                              invstd, rm, rv);
   LIDAL_CHECK_LAUNCH("bn_stats_final");
-  bn_apply_kernel<T, false><<<np, NT, 0, s>>>((const T*)x, n, c, mean, invstd,
-                                                                   gamma, beta, eps, (T*)y);
+  bn_apply_kernel<T, false><<<np, NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma, beta, eps,
+                                               relu, (T*)y);
   LIDAL_CHECK_LAUNCH("bn_apply");
   return 0;
 }
 
 template <typename T>
-int bn_bwd(const void* x, const void* dy, int64_t n, int c, const float* gamma, const float* mean,
-           const float* invstd, void* dx, float* ggamma, float* gbeta, float* part, hipStream_t s) {
+int bn_bwd(const void* x, const void* dy, int64_t n, int c, const float* gamma, const float* beta,
+           int relu, const float* mean, const float* invstd, void* dx, float* ggamma, float* gbeta,
+           float* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
-  bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>((const T*)x, (const T*)dy,
-                                                                        n, c, mean, invstd, part);
+  bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>(
+      (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part);
   LIDAL_CHECK_LAUNCH("bn_bwd_partial");
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gbeta, ggamma);
   LIDAL_CHECK_LAUNCH("bn_bwd_final");
   if (dx != nullptr) {
-    bn_bwd_dx_kernel<T><<<np, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean,
-                                                              invstd, gamma, gbeta, ggamma, (T*)dx);
+    bn_bwd_dx_kernel<T><<<np, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd, gamma,
+                                           beta, relu, gbeta, ggamma, (T*)dx);
     LIDAL_CHECK_LAUNCH("bn_bwd_dx");
   }
   return 0;
@@ -343,7 +362,7 @@ extern "C" int64_t lidal_bn_workspace_bytes(int64_t n, int c) {
 
 extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                                   const float* beta, float eps, float momentum,
-                                  float* running_mean, float* running_var, void* y,
+                                  float* running_mean, float* running_var, int relu, void* y,
                                   float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
                                   void* stream) {
   if (int rc = bn_check(n, c, dtype)) return rc;
@@ -351,39 +370,68 @@ extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, co
   LIDAL_REQUIRE(ws_bytes >= lidal_bn_workspace_bytes(n, c), "bn workspace too small");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
-    return bn_train_fwd<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, y,
-                               save_mean, save_invstd, (float*)ws, s);
-  return bn_train_fwd<__bf16>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, y,
-                              save_mean, save_invstd, (float*)ws, s);
+    return bn_train_fwd<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var,
+                               relu, y, save_mean, save_invstd, (float*)ws, s);
+  return bn_train_fwd<__bf16>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, relu,
+                              y, save_mean, save_invstd, (float*)ws, s);
 }
 
 extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                                  const float* beta, const float* running_mean,
-                                 const float* running_var, float eps, void* y, void* stream) {
+                                 const float* running_var, float eps, int relu, void* y,
+                                 void* stream) {
   if (int rc = bn_check(n, c, dtype)) return rc;
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
     bn_apply_kernel<float, true><<<nparts_for(n), NT, 0, s>>>(
-        (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, (float*)y);
+        (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, (float*)y);
   else
     bn_apply_kernel<__bf16, true><<<nparts_for(n), NT, 0, s>>>(
-        (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, (__bf16*)y);
+        (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, (__bf16*)y);
   LIDAL_CHECK_LAUNCH("lidal_bn_eval_fwd");
   return 0;
 }
 
 extern "C" int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n, int c,
-                            const float* gamma, const float* save_mean, const float* save_invstd,
-                            void* dx, float* grad_gamma, float* grad_beta, void* ws,
-                            int64_t ws_bytes, void* stream) {
+                            const float* gamma, const float* beta, int relu,
+                            const float* save_mean, const float* save_invstd, void* dx,
+                            float* grad_gamma, float* grad_beta, void* ws, int64_t ws_bytes,
+                            void* stream) {
   if (int rc = bn_check(n, c, dtype)) return rc;
   LIDAL_REQUIRE(n > 0, "bn_bwd: needs at least one row");
   LIDAL_REQUIRE(ws_bytes >= lidal_bn_workspace_bytes(n, c), "bn workspace too small");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
-    return bn_bwd<float>(x, dy, n, c, gamma, save_mean, save_invstd, dx, grad_gamma, grad_beta,
-                         (float*)ws, s);
-  return bn_bwd<__bf16>(x, dy, n, c, gamma, save_mean, save_invstd, dx, grad_gamma, grad_beta,
-                        (float*)ws, s);
+    return bn_bwd<float>(x, dy, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
+                         grad_beta, (float*)ws, s);
+  return bn_bwd<__bf16>(x, dy, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
+                        grad_beta, (float*)ws, s);
+}
+
+// Column sums of a [n, c] matrix (bias gradients of the dense layers): the backward partial/final
+// pair with mean = 0, invstd = 1 yields sum(dy) in the first output.
+extern "C" int lidal_colsum(const void* x, int dtype, int64_t n, int c, float* out, void* ws,
+                            int64_t ws_bytes, void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  LIDAL_REQUIRE(n > 0, "colsum: needs at least one row");
+  LIDAL_REQUIRE(ws_bytes >= lidal_bn_workspace_bytes(n, c) + 3 * (int64_t)c * 4, "colsum ws too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)ws;
+  float* zeros = (float*)((char*)ws + (lidal_bn_workspace_bytes(n, c) / 4) * 4);
+  float* ones = zeros + c;
+  float* scratch = ones + c;
+  LIDAL_HIP(hipMemsetAsync(zeros, 0, 4 * c, s));
+  int np = nparts_for(n);
+  // mean = 0, invstd = (any finite): only the first sum is used
+  if (dtype == LIDAL_F32)
+    bn_bwd_partial_kernel<float><<<np, NT, 2 * NT * 4 * sizeof(float), s>>>(
+        (const float*)x, (const float*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part);
+  else
+    bn_bwd_partial_kernel<__bf16><<<np, NT, 2 * NT * 8 * sizeof(float), s>>>(
+        (const __bf16*)x, (const __bf16*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part);
+  LIDAL_CHECK_LAUNCH("colsum_partial");
+  bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, out, scratch);
+  LIDAL_CHECK_LAUNCH("colsum_final");
+  return 0;
 }

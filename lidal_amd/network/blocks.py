@@ -15,12 +15,21 @@ def _conv_bn(inc, outc, ks, stride=1, transposed=False):
             spnn.BatchNorm(outc)]
 
 
+def conv_bn_relu(inc, outc, ks, stride=1, transposed=False):
+    """Conv3d -> BatchNorm -> ReLU as three Sequential slots (indices 0, 1, 2 as in the reference, so
+    `net.1.weight` etc. keep their names); the ReLU is computed inside the BatchNorm kernels and
+    slot 2 is an Identity."""
+    conv, bn = _conv_bn(inc, outc, ks, stride, transposed)
+    bn.fused_relu = True
+    return [conv, bn, nn.Identity()]
+
+
 class BasicConvolutionBlock(nn.Module):
     """Conv3d -> BatchNorm -> ReLU."""
 
     def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
         super().__init__()
-        self.net = nn.Sequential(*_conv_bn(inc, outc, ks, stride), spnn.ReLU(True))
+        self.net = nn.Sequential(*conv_bn_relu(inc, outc, ks, stride))
 
     def forward(self, x):
         return self.net(x)
@@ -31,8 +40,7 @@ class BasicDeconvolutionBlock(nn.Module):
 
     def __init__(self, inc, outc, ks=3, stride=1):
         super().__init__()
-        self.net = nn.Sequential(*_conv_bn(inc, outc, ks, stride, transposed=True),
-                                 spnn.ReLU(True))
+        self.net = nn.Sequential(*conv_bn_relu(inc, outc, ks, stride, transposed=True))
 
     def forward(self, x):
         return self.net(x)
@@ -43,8 +51,7 @@ class ResidualBlock(nn.Module):
 
     def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
         super().__init__()
-        self.net = nn.Sequential(*_conv_bn(inc, outc, ks, stride), spnn.ReLU(True),
-                                 *_conv_bn(outc, outc, ks, 1))
+        self.net = nn.Sequential(*conv_bn_relu(inc, outc, ks, stride), *_conv_bn(outc, outc, ks, 1))
         if inc == outc and stride == 1:
             self.downsample = nn.Identity()
         else:

@@ -10,7 +10,8 @@ from torch import nn
 
 from .. import PointTensor, cat
 from .. import nn as spnn
-from .blocks import BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock
+from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock,
+                     conv_bn_relu)
 from .glue import initial_voxelize, point_to_voxel, voxel_to_point
 
 __all__ = ['SPVCNN', 'MinkUNet']
@@ -25,10 +26,7 @@ class _SparseUNet(nn.Module):
         super().__init__()
         cs = [int(cr * c) for c in CHANNELS]
         self.cs = cs
-        self.stem = nn.Sequential(
-            spnn.Conv3d(4, cs[0], kernel_size=3, stride=1), spnn.BatchNorm(cs[0]), spnn.ReLU(True),
-            spnn.Conv3d(cs[0], cs[0], kernel_size=3, stride=1), spnn.BatchNorm(cs[0]),
-            spnn.ReLU(True))
+        self.stem = nn.Sequential(*conv_bn_relu(4, cs[0], 3), *conv_bn_relu(cs[0], cs[0], 3))
         for i in range(1, 5):          # encoder: stride-2 conv then two residual blocks
             setattr(self, 'stage%d' % i, nn.Sequential(
                 BasicConvolutionBlock(cs[i - 1], cs[i - 1], ks=2, stride=2, dilation=1),
@@ -40,7 +38,7 @@ class _SparseUNet(nn.Module):
                 BasicDeconvolutionBlock(cs[3 + i], cs[4 + i], ks=2, stride=2),
                 nn.Sequential(ResidualBlock(cs[4 + i] + skip, cs[4 + i], ks=3, stride=1, dilation=1),
                               ResidualBlock(cs[4 + i], cs[4 + i], ks=3, stride=1, dilation=1))]))
-        self.classifier = nn.Sequential(nn.Linear(cs[8], class_num))
+        self.classifier = nn.Sequential(spnn.Linear(cs[8], class_num))
 
     def weight_initialization(self):
         for m in self.modules():
@@ -79,8 +77,10 @@ class SPVCNN(_SparseUNet):
         self.pres = 0.05
         self.vres = 0.05
         self.point_transforms = nn.ModuleList([
-            nn.Sequential(spnn.Linear(a, b), spnn.BatchNorm1d(b), nn.ReLU(True))
+            nn.Sequential(spnn.Linear(a, b), spnn.BatchNorm1d(b), nn.Identity())   # ReLU fused in BN
             for a, b in ((cs[0], cs[4]), (cs[4], cs[6]), (cs[6], cs[8]))])
+        for seq in self.point_transforms:
+            seq[1].fused_relu = True
         self.weight_initialization()
         self.dropout = nn.Dropout(0.3, True)
 

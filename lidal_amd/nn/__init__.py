@@ -79,15 +79,19 @@ class BatchNorm1d(nn.BatchNorm1d):
     falls through to torch's own implementation.  Parameters / buffers are nn.BatchNorm1d's, so
     state_dict keys are unchanged."""
 
+    fused_relu = False      # set by lidal_amd.network where a ReLU directly follows the norm
+
     def forward(self, feats):
         from .functional import norm
         if (not norm.supported(feats, self.weight, self.bias) or not self.track_running_stats
                 or self.momentum is None):
-            return super().forward(feats)
+            out = super().forward(feats)
+            return torch.relu(out) if self.fused_relu else out
         if self.training:
             self.num_batches_tracked.add_(1)
         return norm.batch_norm_rows(feats, self.weight, self.bias, self.running_mean,
-                                    self.running_var, self.training, self.momentum, self.eps)
+                                    self.running_var, self.training, self.momentum, self.eps,
+                                    self.fused_relu)
 
 
 class BatchNorm(BatchNorm1d):

@@ -46,35 +46,58 @@ def _ok(x, ca, cb):
             and cb % vec == 0 and x.shape[0] > 0)
 
 
+def _vec(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
 class RowsMatmul(Function):
-    """y = x @ w  (+ bias), w [Cin, Cout]."""
+    """y = x @ w  (+ bias), w [Cin, Cout].  A Cout that is not a multiple of the 16-byte vector
+    width (the 19-class classifier) is zero-padded internally so that forward, weight gradient and
+    bias gradient all stay on the vectorised kernels; the caller sees exactly [N, Cout]."""
 
     @staticmethod
     def forward(ctx, x, w, bias):
         cdtype = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
         xc = x.contiguous().to(cdtype)
         wc = w.detach().to(cdtype)
+        co = wc.shape[1]
+        pad = (-co) % _vec(cdtype) if xc.is_cuda else 0
+        if pad:
+            wc = torch.nn.functional.pad(wc, (0, pad))
         y = xc @ wc
         if bias is not None:
-            y = y + bias.detach().to(cdtype)
+            b = bias.detach().to(cdtype)
+            y = y + (torch.nn.functional.pad(b, (0, pad)) if pad else b)
         ctx.save_for_backward(xc, w)
         ctx.has_bias = bias is not None
-        return y
+        ctx.pad = pad
+        return y[:, :co] if pad else y
 
     @staticmethod
     def backward(ctx, g):
         xc, w = ctx.saved_tensors
-        g = g.contiguous().to(xc.dtype)
+        g = g.to(xc.dtype)
+        co = w.shape[1]
+        if ctx.pad:
+            g = torch.nn.functional.pad(g, (0, ctx.pad))
+        g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = g @ w.detach().to(xc.dtype).t()
+            wc = w.detach().to(xc.dtype)
+            if ctx.pad:
+                wc = torch.nn.functional.pad(wc, (0, ctx.pad))
+            gx = g @ wc.t()
         if ctx.needs_input_grad[1]:
             if _ok(xc, xc.shape[1], g.shape[1]):
-                gw = _wgrad_dense(xc, g).to(w.dtype)
+                gw = _wgrad_dense(xc, g)[:, :co].to(w.dtype)
             else:
-                gw = (xc.float().t() @ g.float()).to(w.dtype)
+                gw = (xc.float().t() @ g.float())[:, :co].to(w.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.float().sum(0)
+            from .norm import column_sum
+            if g.is_cuda and g.shape[1] % _vec(g.dtype) == 0 and g.shape[1] // _vec(g.dtype) <= 256:
+                gb = column_sum(g)[:co]
+            else:
+                gb = g.float().sum(0)[:co]
         return gx, gw, gb
 
 

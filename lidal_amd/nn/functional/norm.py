@@ -6,7 +6,7 @@ from torch.autograd import Function
 
 from ... import backend as B
 
-__all__ = ['batch_norm_rows', 'supported']
+__all__ = ['batch_norm_rows', 'column_sum', 'supported']
 
 
 def supported(x, weight, bias):
@@ -29,7 +29,7 @@ def _ws(n, c, dev):
 
 class BatchNormRows(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
         x = x.contiguous()
         n, c = x.shape
         dev = x.device
@@ -42,7 +42,7 @@ class BatchNormRows(Function):
             ws, nbytes = _ws(n, c, dev)
             B.check(B.lib().lidal_bn_train_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
                                                float(momentum), B.ptr(running_mean),
-                                               B.ptr(running_var), B.ptr(y), B.ptr(mean),
+                                               B.ptr(running_var), int(relu), B.ptr(y), B.ptr(mean),
                                                B.ptr(invstd), B.ptr(ws), nbytes, B.stream()),
                     'bn_train_fwd')
         else:
@@ -50,31 +50,49 @@ class BatchNormRows(Function):
             invstd = torch.rsqrt(running_var + eps)
             B.check(B.lib().lidal_bn_eval_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b),
                                               B.ptr(running_mean), B.ptr(running_var), float(eps),
-                                              B.ptr(y), B.stream()), 'bn_eval_fwd')
+                                              int(relu), B.ptr(y), B.stream()), 'bn_eval_fwd')
         ctx.training = training
-        ctx.save_for_backward(x, w, mean, invstd)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, w, b, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, w, mean, invstd = ctx.saved_tensors
+        x, w, b, mean, invstd = ctx.saved_tensors
         n, c = x.shape
         g = grad_out.contiguous().to(x.dtype)
         if not ctx.training:            # eval-mode backward (not on the LiDAL path): plain torch
             xhat = (x.float() - mean) * invstd
             gf = g.float()
+            if ctx.relu:
+                gf = gf * ((xhat * w + b) > 0)
             return ((gf * (w * invstd)).to(x.dtype), (gf * xhat).sum(0), gf.sum(0), None, None,
-                    None, None, None)
+                    None, None, None, None)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         gg = torch.empty(c, dtype=torch.float32, device=x.device)
         gb = torch.empty(c, dtype=torch.float32, device=x.device)
         ws, nbytes = _ws(n, c, x.device)
         B.check(B.lib().lidal_bn_bwd(B.ptr(x), B.ptr(g), B.dtype_code(x.dtype), n, c, B.ptr(w),
-                                     B.ptr(mean), B.ptr(invstd), B.ptr(dx), B.ptr(gg), B.ptr(gb),
+                                     B.ptr(b), int(ctx.relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),
+                                     B.ptr(gg), B.ptr(gb),
                                      B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
-        return dx, gg, gb, None, None, None, None, None
+        return dx, gg, gb, None, None, None, None, None, None
 
 
-def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps):
-    return BatchNormRows.apply(x, weight, bias, running_mean, running_var, training, momentum, eps)
+def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps,
+                    relu=False):
+    return BatchNormRows.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
+                               relu)
+
+
+def column_sum(x):
+    """f32 [C] column sums of x [N, C] (f32 / bf16), hierarchical and reproducible."""
+    x = x.contiguous()
+    n, c = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    nbytes = B.lib().lidal_bn_workspace_bytes(n, c) + 12 * c
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().lidal_colsum(B.ptr(x), B.dtype_code(x.dtype), n, c, B.ptr(out), B.ptr(ws),
+                                 nbytes, B.stream()), 'colsum')
+    return out

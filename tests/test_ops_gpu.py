@@ -365,6 +365,20 @@ def test_batch_norm_rows_matches_torch(dtype, c, n):
     assert int(mine.num_batches_tracked) == 1
     ref.eval(), mine.eval()
     assert _relerr(mine(xq.to(DEV)).float().cpu(), ref(xq.double())) < tol
+    # fused ReLU (the form the model uses): y = relu(bn(x)), backward masks dy where y <= 0
+    ref.train(), mine.train()
+    mine.fused_relu = True
+    xr2 = xq.double().requires_grad_(True)
+    xg2 = xq.to(DEV).requires_grad_(True)
+    ref.zero_grad(), mine.zero_grad()
+    yr2 = torch.relu(ref(xr2))
+    yg2 = mine(xg2)
+    yr2.backward(go.to(dtype).double())
+    yg2.backward(go.to(dtype).to(DEV))
+    assert _relerr(yg2.float().cpu(), yr2.detach()) < tol
+    assert _relerr(xg2.grad.float().cpu(), xr2.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
+    assert _relerr(mine.weight.grad.cpu(), ref.weight.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert _relerr(mine.bias.grad.cpu(), ref.bias.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -388,8 +402,8 @@ def test_dense_rows_matmul_and_linear(dtype):
     assert _relerr(y.float().cpu(), (xr @ wr).detach()) < tol
     assert _relerr(xg.grad.float().cpu(), xr.grad) < tol
     assert _relerr(wg.grad.float().cpu(), wr.grad) < tol
-    lin = spnn.Linear(ci, 32).to(DEV)
-    ref = torch.nn.Linear(ci, 32).double()
+    lin = spnn.Linear(ci, 19).to(DEV)            # 19 classes: padded internally to the vector width
+    ref = torch.nn.Linear(ci, 19).double()
     ref.load_state_dict({k: v.double().cpu() for k, v in lin.state_dict().items()})
     xl = x.float().to(DEV).requires_grad_(True)
     out = lin(xl)

@@ -27,6 +27,8 @@
 // lidal_conv_wgrad: gw[k] = A_k^T B_k over the rule list of offset k, as a split-K MFMA GEMM
 // (workgroup = (split, k, channel tile)); gathered rows are staged through LDS (converted to
 // f32), f32 partial slabs are reduced in a fixed order by a second kernel.
+#include <type_traits>
+
 #include "common.h"
 
 using namespace lidal;
@@ -85,6 +87,11 @@ __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
 
+// 512 bytes of zeros in device memory: lanes without a rule (or past the channel range) load from
+// here instead of branching around the load, so every gather is an unconditional 16-byte load whose
+// result is first touched by the MFMA (no exec-masked control flow, no early vmcnt waits).
+__device__ __attribute__((aligned(16))) unsigned char g_zero_page[512];
+
 // ------------------------------------------------------------------------------------------
 // conv_apply
 // ------------------------------------------------------------------------------------------
@@ -104,7 +111,11 @@ constexpr int BM = NWAVES * G * 16;   // output rows per workgroup
 
 // LDS layout (dynamic): weights T [2][BN][WSTRIDE] | nidx int [4 waves][K][G*16]
 // (the weight region is re-used as the epilogue staging tile)
-template <typename T, int NB, int ROW_BYTES>
+// GUARD = the channel count is not a multiple of the 16-byte vector (only the 4-channel bf16 stem):
+// loads then fall back to element-wise guarded code.  Everywhere else every lane load is either
+// wholly inside the row or wholly masked, which keeps the gathers branch-free and un-serialised
+// (the guarded form made hipcc wait vmcnt(0) after every load).
+template <typename T, int NB, int ROW_BYTES, bool GUARD>
 __global__ void __launch_bounds__(NTHREADS)
 conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
                   const int* __restrict__ perm, T* __restrict__ out, int64_t n_out, int ci, int co,
@@ -178,10 +189,14 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     for (int t = 0; t < WPT; ++t) {
       const int sidx = tid + t * NTHREADS;
       const int col = sidx / SEGS, x = (sidx - col * SEGS) * VEC;
-      wreg[t] = DT<T>::zero();
-      if (!(LIDAL_ABLATE & 2))
-        if (sidx < BN * SEGS && n0 + col < co && x < kc)
-          wreg[t] = load_frag_guarded<T>(wsrc + (int64_t)col * ci + x, kc - x);
+      const bool ok = sidx < BN * SEGS && n0 + col < co && x < kc && !(LIDAL_ABLATE & 2);
+      if constexpr (GUARD) {
+        wreg[t] = DT<T>::zero();
+        if (ok) wreg[t] = load_frag_guarded<T>(wsrc + (int64_t)col * ci + x, kc - x);
+      } else {
+        const T* p = ok ? wsrc + (int64_t)col * ci + x : reinterpret_cast<const T*>(g_zero_page);
+        wreg[t] = *reinterpret_cast<const frag*>(p);
+      }
     }
   };
   auto stage_store = [&](int buf) {
@@ -205,11 +220,15 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
       present[g] = __ballot(src >= 0);
 #pragma unroll
       for (int cc = 0; cc < MAXCC; ++cc) {
-        a[g][cc] = DT<T>::zero();
         const int x = cc * CH + gsel * VEC;
-        if (!(LIDAL_ABLATE & 1))
-          if (src >= 0 && x < kc)
-            a[g][cc] = load_frag_guarded<T>(in + (int64_t)src * ci + c0 + x, kc - x);
+        const bool ok = src >= 0 && x < kc && !(LIDAL_ABLATE & 1);
+        if constexpr (GUARD) {
+          a[g][cc] = DT<T>::zero();
+          if (ok) a[g][cc] = load_frag_guarded<T>(in + (int64_t)src * ci + c0 + x, kc - x);
+        } else {
+          const T* p = ok ? in + (int64_t)src * ci + c0 + x : reinterpret_cast<const T*>(g_zero_page);
+          a[g][cc] = *reinterpret_cast<const frag*>(p);
+        }
       }
     }
   };
@@ -300,7 +319,7 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   }
 }
 
-template <typename T, int NB, int ROW_BYTES>
+template <typename T, int NB, int ROW_BYTES, bool GUARD>
 int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
                       int64_t n_out, int ci, int co, int K, int kflip, hipStream_t s) {
   constexpr int BN = 16 * NB;
@@ -310,7 +329,7 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
   constexpr int WREGION = (2 * BN * WSTRIDE > NWAVES * G * 16 * ESTRIDE) ? 2 * BN * WSTRIDE
                                                                            : NWAVES * G * 16 * ESTRIDE;
   const size_t lds = sizeof(T) * WREGION + (size_t)NWAVES * K * G * 16 * sizeof(int);
-  auto kern = conv_apply_kernel<T, NB, ROW_BYTES>;
+  auto kern = conv_apply_kernel<T, NB, ROW_BYTES, GUARD>;
   static size_t attr_set = 0;
   if (attr_set < lds) {
     LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -324,15 +343,17 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
   return 0;
 }
 
-template <typename T, int ROW_BYTES>
-int dispatch_conv_tile(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
+template <typename T, int ROW_BYTES, bool GUARD>
+int dispatch_conv_cols(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
                        int64_t n_out, int ci, int co, int K, int kflip, hipStream_t s) {
   // BN = 16*NB output channels per workgroup; grid.y covers the rest.
-  if (co <= 32) return launch_conv_apply<T, 2, ROW_BYTES>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
-  if (co <= 64) return launch_conv_apply<T, 4, ROW_BYTES>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  if (co <= 32)
+    return launch_conv_apply<T, 2, ROW_BYTES, GUARD>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  if (co <= 64)
+    return launch_conv_apply<T, 4, ROW_BYTES, GUARD>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
   if (co % 128 != 0 && (co % 96 == 0 || co < 128))
-    return launch_conv_apply<T, 6, ROW_BYTES>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
-  return launch_conv_apply<T, 8, ROW_BYTES>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 6, ROW_BYTES, GUARD>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  return launch_conv_apply<T, 8, ROW_BYTES, GUARD>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
 }
 
 template <typename T>
@@ -342,12 +363,14 @@ int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, const in
   // profiles/README.md), except rows that are a multiple of 192 but not of 128 bytes (ci = 96
   // bf16 -> one pass of 96 instead of 64 + 32).
   const int row_bytes = ci * (int)sizeof(T);
+  if (ci % DT<T>::VEC != 0)       // irregular channel count (4-channel bf16 stem): guarded loads
+    return dispatch_conv_cols<T, 128, true>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
 #ifdef LIDAL_ROWB_OVERRIDE
-  return dispatch_conv_tile<T, LIDAL_ROWB_OVERRIDE>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_cols<T, LIDAL_ROWB_OVERRIDE, false>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
 #endif
   if (row_bytes % 192 == 0 && row_bytes % 128 != 0)
-    return dispatch_conv_tile<T, 192>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
-  return dispatch_conv_tile<T, 128>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+    return dispatch_conv_cols<T, 192, false>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_cols<T, 128, false>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -21,7 +21,10 @@ def _floor_to_stride(z, s):
 def initial_voxelize(z, init_res, after_res):
     """utils.py:13-33: re-voxelise the points at `after_res`; the voxel order is the SORTED order
     of the distinct 60-bit coordinate hashes (torch.unique at :18)."""
-    new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
+    # true IEEE division: torch's GPU `tensor / python_scalar` multiplies by the reciprocal, which
+    # leaves voxel centres 1e-7 off the integers the CPU path produces (SURVEY.md H8)
+    res = torch.full((), after_res, dtype=z.C.dtype, device=z.C.device)
+    new_float_coord = torch.cat([(z.C[:, :3] * init_res) / res, z.C[:, -1].view(-1, 1)], 1)
     floored = torch.floor(new_float_coord)
     pc_hash = F.sphash(floored.int())
     sparse_hash = F.unique_sorted(pc_hash)

@@ -98,11 +98,14 @@ def test_fullsize_point_voxel_properties(scan):
     ref = coords[:, 3].long() * 2 ** 42 + coords[:, 0].long() * 2 ** 28 + coords[:, 1].long() * 2 ** 14 + coords[:, 2].long()
     assert torch.equal(torch.sort(rows)[0], torch.sort(ref)[0])
     z0 = voxel_to_point(x0, z)
-    assert torch.allclose(z0.F, feats, rtol=1e-6, atol=1e-6)  # stride-1 trilinear = identity gather
+    # stride-1 trilinear ~ identity gather: (C*0.05f)/0.05f is C up to one f32 ulp (4.9e-4 above
+    # 4096), so the own-voxel weight is >= 0.999 rather than exactly 1
     w = z.weights[(1, 1, 1)]
     assert torch.allclose(w.sum(1), torch.ones_like(w[:, 0]), atol=1e-5)
+    assert w[:, 0].min() > 0.999
+    assert (z0.F - feats).abs().max() < 2e-3 * feats.abs().max()
     back = point_to_voxel(x0, z0)
-    assert torch.allclose(back.F, x0.F, rtol=1e-6, atol=1e-6)
+    assert (back.F - x0.F).abs().max() < 2e-3 * x0.F.abs().max()
 
 
 def test_edge_cases_empty_single_and_range_limit():

@@ -14,7 +14,7 @@
 //                     trip: every A element is used by exactly one wave), one offset ahead of use;
 //                  3. B-fragments are ds_read_b128 from the staged weights and feed both row
 //                     groups: v_mfma_f32_16x16x32_bf16 or v_mfma_f32_16x16x4_f32 (exact f32);
-//                     a row group with no rule at this offset skips its MFMAs;
+//                     a wave whose 32 rows have no rule at this offset skips its MFMAs;
 //   epilogue       accumulators -> wave-private LDS tile -> whole output rows, 16-byte stores.
 //
 // No atomics and no LDS accumulation: each output row is produced by one wave in a fixed offset
@@ -263,7 +263,13 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     }
     // ---- MFMAs: every B fragment read from LDS feeds the G row groups (skipped when a group has
     //      no rule for this offset); accumulators stay in registers for all K offsets
-    if (!(LIDAL_ABLATE & 4)) {
+    // a wave skips the phase when none of its 32 rows has a rule for this offset; otherwise the
+    // MFMA block is branch-free (per-group skipping cost more in scalar branches than it saved:
+    // profiles/README.md)
+    bool any_present = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) any_present |= pres_cur[g] != 0ull;
+    if (any_present && !(LIDAL_ABLATE & 4)) {
       const T* wbase = wbuf + row16 * WSTRIDE + gsel * VEC;
 #pragma unroll
       for (int cc = 0; cc < MAXCC; ++cc) {
@@ -272,8 +278,7 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
           for (int nb = 0; nb < NB; ++nb) {
             frag b = *reinterpret_cast<const frag*>(wbase + nb * 16 * WSTRIDE + cc * CH);
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-              if (pres_cur[g] != 0ull) mma(acc[g][nb], a_cur[g][cc], b);
+            for (int g = 0; g < G; ++g) mma(acc[g][nb], a_cur[g][cc], b);
           }
         }
       }

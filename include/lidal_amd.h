@@ -84,11 +84,12 @@ int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr
 
 /* Row order for lidal_conv_apply: rows of nbr [k, n_rows] sorted by their occupancy pattern (bit j set
  * iff nbr[j][row] >= 0; stable, so ties keep row order).  perm i32 [n_rows] (sorted position ->
- * row), nbr_perm i32 [k, n_rows] = nbr[:, perm].  With it a 16-row MFMA group / 128-row tile only
- * touches the offsets of its own pattern. */
+ * row), nbr_perm i32 [k, n_rows] = nbr[:, perm], tile_masks u32 [ceil(n_rows/128)] = OR of the row
+ * patterns of each 128-row tile (may be NULL).  With them a tile only touches the offsets of its
+ * own patterns. */
 int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows);
 int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32_t* perm, int32_t* nbr_perm,
-                     void* ws, int64_t ws_bytes, void* stream);
+                     uint32_t* tile_masks, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- point <-> voxel ------------------------------------------------------------------------- */
 /* replaces backend.count_cuda (F.spcount: network/utils.py:20,49). out i32 [m] (zeroed here). */
@@ -131,11 +132,12 @@ int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int wt_dtype, i
  * Output-stationary fused gather-GEMM with register accumulators:
  *     out[row(j), :] = sum_k  in[ nbr[kk][j], : ] * Wk[k]^T,   kk = kflip ? K-1-k : k
  * with Wk laid out [k][co][ci] (reduction dim contiguous), nbr i32 [k, n_out] (-1 = no rule) and
- * row(j) = perm ? perm[j] : j  (pass lidal_kmap_order's perm together with its permuted table).
- * No atomics: each output row is written exactly once => bitwise reproducible. */
+ * row(j) = perm ? perm[j] : j  (pass lidal_kmap_order's perm together with its permuted table and,
+ * optionally, its tile_masks, which spare the kernel the mask derivation and the index slices of
+ * absent offsets).  No atomics: each output row is written exactly once => bitwise reproducible. */
 int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const int32_t* perm,
-                     void* out, int64_t n_out, int ci, int co, int k, int kflip, int dtype,
-                     void* stream);
+                     const uint32_t* tile_masks, void* out, int64_t n_out, int ci, int co, int k,
+                     int kflip, int dtype, void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
  * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  Split-K: offset k with nk rules is cut into

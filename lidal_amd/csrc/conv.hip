@@ -118,8 +118,8 @@ constexpr int BM = NWAVES * G * 16;   // output rows per workgroup
 template <typename T, int NB, int ROW_BYTES, bool GUARD>
 __global__ void __launch_bounds__(NTHREADS)
 conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
-                  const int* __restrict__ perm, T* __restrict__ out, int64_t n_out, int ci, int co,
-                  int K, int kflip) {
+                  const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
+                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip) {
   constexpr int BN = 16 * NB;
   constexpr int VEC = DT<T>::VEC;
   constexpr int CH = DT<T>::CH;
@@ -149,33 +149,42 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   int* nidx = nidx_all + wave * K * RW;                      // [K][RW], wave-private
   __shared__ unsigned tile_mask;
   __shared__ int act_k[MAXK];
-  if (tid == 0) tile_mask = 0u;
-
-  // ---- 0. this wave's slice of the neighbour table -> LDS (K*RW independent coalesced loads)
-  for (int i = lane; i < K * RW; i += 64) {
-    const int k = i / RW, r = i - k * RW;
-    const int kk = kflip ? (K - 1 - k) : k;
-    nidx[i] = (r0 + r < n_out) ? nbr[(int64_t)kk * n_out + r0 + r] : -1;
-  }
-  __syncthreads();
-  // offsets that have at least one rule in this 128-row tile (rows are pre-sorted by occupancy
-  // pattern, so most tiles use only a few of the K offsets): only those are staged and multiplied
-  {
+  unsigned tmask;
+  if (tmasks != nullptr) {
+    // ---- 0a. occupancy mask of this 128-row tile, precomputed with the row order (one load);
+    //          only the offsets it names are fetched, staged and multiplied
+    unsigned m = tmasks[blockIdx.x];
+    if (kflip) m = __brev(m) >> (32 - K);
+    tmask = m;
+    if (tid < K && (m >> tid) & 1u) act_k[__popc(m & ((1u << tid) - 1u))] = tid;
+    __syncthreads();
+    const int n_act0 = __popc(m);
+    for (int i = lane; i < n_act0 * RW; i += 64) {
+      const int q = i / RW, r = i - q * RW;
+      const int k = act_k[q];
+      const int kk = kflip ? (K - 1 - k) : k;
+      nidx[k * RW + r] = (r0 + r < n_out) ? nbr[(int64_t)kk * n_out + r0 + r] : -1;
+    }
+  } else {
+    // ---- 0b. no precomputed mask: fetch every offset's slice and derive the mask here
+    if (tid == 0) tile_mask = 0u;
+    for (int i = lane; i < K * RW; i += 64) {
+      const int k = i / RW, r = i - k * RW;
+      const int kk = kflip ? (K - 1 - k) : k;
+      nidx[i] = (r0 + r < n_out) ? nbr[(int64_t)kk * n_out + r0 + r] : -1;
+    }
+    __syncthreads();
     unsigned wmask = 0u;
     for (int k = 0; k < K; ++k) {
       const int v = (lane < RW) ? nidx[k * RW + lane] : -1;
       if (__ballot(v >= 0) != 0ull) wmask |= 1u << k;
     }
     if (lane == 0 && wmask) atomicOr(&tile_mask, wmask);
+    __syncthreads();
+    tmask = tile_mask;
+    if (tid < K && (tmask >> tid) & 1u) act_k[__popc(tmask & ((1u << tid) - 1u))] = tid;
   }
-  __syncthreads();
-  const unsigned tmask = tile_mask;
   const int n_act = __popc(tmask);
-  if (tid == 0) {
-    int j = 0;
-    for (int k = 0; k < K; ++k)
-      if (tmask & (1u << k)) act_k[j++] = k;
-  }
   const int nphase = n_act * npass;
 
   // weight slab of phase p -> registers (issue early) -> LDS buffer (write late)
@@ -325,8 +334,9 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
 }
 
 template <typename T, int NB, int ROW_BYTES, bool GUARD>
-int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
-                      int64_t n_out, int ci, int co, int K, int kflip, hipStream_t s) {
+int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm,
+                      const unsigned* tmasks, void* out, int64_t n_out, int ci, int co, int K,
+                      int kflip, hipStream_t s) {
   constexpr int BN = 16 * NB;
   constexpr int KC = ROW_BYTES / (int)sizeof(T);
   constexpr int WSTRIDE = KC + DT<T>::VEC;
@@ -342,40 +352,42 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
     attr_set = lds;
   }
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
-  kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, perm, (T*)out, n_out, ci, co,
-                                   K, kflip);
+  kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, perm, tmasks, (T*)out, n_out,
+                                   ci, co, K, kflip);
   LIDAL_CHECK_LAUNCH("lidal_conv_apply");
   return 0;
 }
 
 template <typename T, int ROW_BYTES, bool GUARD>
-int dispatch_conv_cols(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
-                       int64_t n_out, int ci, int co, int K, int kflip, hipStream_t s) {
+int dispatch_conv_cols(const void* in, const void* wk, const int* nbr, const int* perm,
+                       const unsigned* tmasks, void* out, int64_t n_out, int ci, int co, int K,
+                       int kflip, hipStream_t s) {
   // BN = 16*NB output channels per workgroup; grid.y covers the rest.
   if (co <= 32)
-    return launch_conv_apply<T, 2, ROW_BYTES, GUARD>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 2, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
   if (co <= 64)
-    return launch_conv_apply<T, 4, ROW_BYTES, GUARD>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 4, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
   if (co % 128 != 0 && (co % 96 == 0 || co < 128))
-    return launch_conv_apply<T, 6, ROW_BYTES, GUARD>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
-  return launch_conv_apply<T, 8, ROW_BYTES, GUARD>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 6, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
+  return launch_conv_apply<T, 8, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
 }
 
 template <typename T>
-int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm, void* out,
-                        int64_t n_out, int ci, int co, int K, int kflip, hipStream_t s) {
+int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm,
+                        const unsigned* tmasks, void* out, int64_t n_out, int ci, int co, int K,
+                        int kflip, hipStream_t s) {
   // staged reduction bytes per pass: 128 (more workgroups per CU beat longer passes: measured in
   // profiles/README.md), except rows that are a multiple of 192 but not of 128 bytes (ci = 96
   // bf16 -> one pass of 96 instead of 64 + 32).
   const int row_bytes = ci * (int)sizeof(T);
   if (ci % DT<T>::VEC != 0)       // irregular channel count (4-channel bf16 stem): guarded loads
-    return dispatch_conv_cols<T, 128, true>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+    return dispatch_conv_cols<T, 128, true>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
 #ifdef LIDAL_ROWB_OVERRIDE
-  return dispatch_conv_cols<T, LIDAL_ROWB_OVERRIDE, false>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_cols<T, LIDAL_ROWB_OVERRIDE, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
 #endif
   if (row_bytes % 192 == 0 && row_bytes % 128 != 0)
-    return dispatch_conv_cols<T, 192, false>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
-  return dispatch_conv_cols<T, 128, false>(in, wk, nbr, perm, out, n_out, ci, co, K, kflip, s);
+    return dispatch_conv_cols<T, 192, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_cols<T, 128, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -766,19 +778,21 @@ extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int 
 }
 
 extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr,
-                                const int32_t* perm, void* out, int64_t n_out, int ci, int co, int k,
-                                int kflip, int dtype, void* stream) {
+                                const int32_t* perm, const uint32_t* tile_masks, void* out,
+                                int64_t n_out, int ci, int co, int k, int kflip, int dtype,
+                                void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out == 0 || co == 0) return 0;
+  static_assert(BM == 128, "tile masks from lidal_kmap_order are per 128 rows");
   LIDAL_REQUIRE(ci > 0 && k > 0 && k <= MAXK, "conv_apply: bad shape ci=%d k=%d", ci, k);
   if (dtype == LIDAL_F32) {
     LIDAL_REQUIRE(ci % 4 == 0 && co % 4 == 0, "conv_apply f32: channels must be multiples of 4");
-    return dispatch_conv_apply<float>(in, wk, nbr, perm, out, n_out, ci, co, k, kflip, s);
+    return dispatch_conv_apply<float>(in, wk, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, s);
   }
   if (dtype == LIDAL_BF16) {
     LIDAL_REQUIRE((ci % 8 == 0 || ci < 8) && co % 4 == 0,
                   "conv_apply bf16: ci must be a multiple of 8 (or < 8), co a multiple of 4");
-    return dispatch_conv_apply<__bf16>(in, wk, nbr, perm, out, n_out, ci, co, k, kflip, s);
+    return dispatch_conv_apply<__bf16>(in, wk, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, s);
   }
   set_error("conv_apply: bad dtype %d", dtype);
   return 2;

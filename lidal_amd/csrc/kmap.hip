@@ -298,6 +298,23 @@ __global__ void __launch_bounds__(256) permute_table_kernel(const int* __restric
   nbr_perm[(int64_t)k * n + r] = nbr[(int64_t)k * n + perm[r]];
 }
 
+// OR of the sorted row masks over each tile of 128 consecutive sorted rows (one wave per tile)
+__global__ void __launch_bounds__(256) tile_or_kernel(const unsigned* __restrict__ skeys, int64_t n,
+                                                      unsigned* __restrict__ tmask, int64_t tiles) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= tiles) return;
+  unsigned m = 0u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int64_t r = t * 128 + h * 64 + lane;
+    if (r < n) m |= skeys[r];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, 64);
+  if (lane == 0) tmask[t] = m;
+}
+
 size_t mask_sort_tmp_bytes(int64_t n) {
   size_t tmp = 0;
   (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr,
@@ -400,7 +417,8 @@ extern "C" int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows) {
 }
 
 extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32_t* perm,
-                                int32_t* nbr_perm, void* ws, int64_t ws_bytes, void* stream) {
+                                int32_t* nbr_perm, uint32_t* tile_masks, void* ws,
+                                int64_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   LIDAL_REQUIRE(k > 0 && k <= 32, "kmap_order: kernel volume %d must be <= 32", k);
   if (n_rows == 0) return 0;
@@ -417,5 +435,10 @@ extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32
   permute_table_kernel<<<dim3((unsigned)cdiv(q, 256), (unsigned)k), 256, 0, s>>>(nbr, q, perm,
                                                                                  nbr_perm);
   LIDAL_CHECK_LAUNCH("permute_table");
+  if (tile_masks != nullptr) {
+    int64_t tiles = cdiv(q, 128);
+    tile_or_kernel<<<(unsigned)cdiv(tiles, 4), 256, 0, s>>>(skeys, q, tile_masks, tiles);
+    LIDAL_CHECK_LAUNCH("tile_or");
+  }
   return 0;
 }

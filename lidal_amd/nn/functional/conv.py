@@ -36,10 +36,12 @@ class RowOrder:
         self.n_rows = n
         self.perm = torch.empty(max(n, 1), dtype=torch.int, device=dev)
         self.table = torch.empty((k, n), dtype=torch.int, device=dev)
+        self.tile_masks = torch.empty(max(1, -(-n // 128)), dtype=torch.int32, device=dev)
         ws_bytes = B.lib().lidal_kmap_order_workspace_bytes(n)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         B.check(B.lib().lidal_kmap_order(B.ptr(nbr), n, k, B.ptr(self.perm), B.ptr(self.table),
-                                         B.ptr(ws), ws_bytes, B.stream()), 'kmap_order')
+                                         B.ptr(self.tile_masks), B.ptr(ws), ws_bytes, B.stream()),
+                'kmap_order')
 
 
 class KernelMap:
@@ -137,7 +139,7 @@ def _apply(feats, wk, order, kflip):
     n_out = order.n_rows
     out = torch.empty((n_out, co), dtype=feats.dtype, device=feats.device)
     B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
-                                     B.ptr(out), n_out, ci, co, k, int(kflip),
+                                     B.ptr(order.tile_masks), B.ptr(out), n_out, ci, co, k, int(kflip),
                                      B.dtype_code(feats.dtype), B.stream()), 'conv_apply')
     return out
 

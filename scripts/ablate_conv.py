@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'scripts', '_abl')
-VARIANTS = {'base': []}
+VARIANTS = {'base': [], 'skeleton': ['-DLIDAL_ABLATE=7']}
 # (level stride, ci, co): the heavy layer families of the U-Net
 SHAPES = [(1, 32, 32), (1, 96, 96), (2, 32, 32), (4, 128, 128), (4, 64, 64), (8, 256, 256),
           (8, 384, 256), (16, 256, 256)]
@@ -59,12 +59,13 @@ def run():
         times = []
         order = kmap.order_out
         for name, fn in [(n_ + m_, f_) for n_, f_ in libs.items() for m_ in ('+sort',)]:
-            tab, prm = (order.table, order.perm) if name.endswith('+sort') else (kmap.nbr_out, None)
+            tab, prm, tmk = ((order.table, order.perm, order.tile_masks) if name.endswith('+sort')
+                             else (kmap.nbr_out, None, None))
             def launch():
-                rc = fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(out), n, ci, co, 27, 0,
+                rc = fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n, ci, co, 27, 0,
                         B.dtype_code(dtype), B.stream())
                 assert rc == 0
-            if fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(out), n, ci, co, 27, 0,
+            if fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n, ci, co, 27, 0,
                   B.dtype_code(dtype), B.stream()) != 0:
                 times.append(float('nan'))
                 continue

@@ -13,7 +13,7 @@ using namespace lidal;
 namespace {
 
 constexpr int NT = 256;
-constexpr int ROWS_PER_WG = 1024;      // rows a workgroup reduces per partial
+constexpr int ROWS_PER_WG = 512;       // rows per workgroup (one statistics partial each)
 
 template <typename T> struct IO;
 template <> struct IO<float> {
@@ -87,7 +87,21 @@ __global__ void __launch_bounds__(NT) bn_stats_partial_kernel(const T* __restric
   for (int i = 0; i < VEC; ++i) { shift[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
   if (rl < rpi) {
     IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r_beg * c + cg * VEC), shift);
-    for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
+    int64_t r = r_beg + rl;
+    for (; r + 3 * rpi < r_end; r += 4 * rpi) {        // 4 independent 16-byte loads in flight
+      typename IO<T>::vec v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[VEC];
+        IO<T>::unpack(v[u], f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { float d = f[i] - shift[i]; s1[i] += d; s2[i] += d * d; }
+      }
+    }
+    for (; r < r_end; r += rpi) {
       float f[VEC];
       IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), f);
 #pragma unroll
@@ -180,16 +194,27 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
     sc[i] = is * (gamma ? gamma[ch] : 1.f);
     sh[i] = beta ? beta[ch] : 0.f;
   }
-  for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
+  auto one = [&](const typename IO<T>::vec& v, int64_t r) {
     float f[VEC];
-    IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), f);
+    IO<T>::unpack(v, f);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
       if (relu) f[i] = fmaxf(f[i], 0.f);
     }
     *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
+  };
+  int64_t r = r_beg + rl;
+  for (; r + 3 * rpi < r_end; r += 4 * rpi) {
+    typename IO<T>::vec v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v[u], r + u * rpi);
   }
+  for (; r < r_end; r += rpi)
+    one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), r);
 }
 
 // backward partials: per workgroup and channel  sum(dy), sum(dy * xhat)
@@ -217,17 +242,31 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
       if (gamma) ga[i] = gamma[cg * VEC + i];
       if (beta) be[i] = beta[cg * VEC + i];
     }
-    for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
+    auto one = [&](const typename IO<T>::vec& vx, const typename IO<T>::vec& vd) {
       float fx[VEC], fd[VEC];
-      IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), fx);
-      IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), fd);
+      IO<T>::unpack(vx, fx);
+      IO<T>::unpack(vd, fd);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float xhat = (fx[i] - mu[i]) * is[i];
         if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;      // fused ReLU: dy where y > 0
         a[i] += fd[i]; b[i] += fd[i] * xhat;
       }
+    };
+    int64_t r = r_beg + rl;
+    for (; r + 3 * rpi < r_end; r += 4 * rpi) {
+      typename IO<T>::vec vx[4], vd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+        vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * c + cg * VEC);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(vx[u], vd[u]);
     }
+    for (; r < r_end; r += rpi)
+      one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
+          *reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC));
   }
   float* sa = sh; float* sb = sh + NT * VEC;
 #pragma unroll
@@ -294,10 +333,10 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
     ga[i] = gamma ? gamma[ch] : 1.f; be[i] = beta ? beta[ch] : 0.f;
     k1[i] = sum_dy[ch] * inv_n; k2[i] = sum_dy_xhat[ch] * inv_n;
   }
-  for (int64_t r = r_beg + rl; r < r_end; r += rpi) {
+  auto one = [&](const typename IO<T>::vec& vx, const typename IO<T>::vec& vd, int64_t r) {
     float fx[VEC], fd[VEC];
-    IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), fx);
-    IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), fd);
+    IO<T>::unpack(vx, fx);
+    IO<T>::unpack(vd, fd);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float xhat = (fx[i] - mu[i]) * is[i];
@@ -305,7 +344,21 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
       fd[i] = ga[i] * is[i] * (fd[i] - k1[i] - xhat * k2[i]);
     }
     *reinterpret_cast<typename IO<T>::vec*>(dx + r * c + cg * VEC) = IO<T>::pack(fd);
+  };
+  int64_t r = r_beg + rl;
+  for (; r + 3 * rpi < r_end; r += 4 * rpi) {
+    typename IO<T>::vec vx[4], vd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+      vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * c + cg * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(vx[u], vd[u], r + u * rpi);
   }
+  for (; r < r_end; r += rpi)
+    one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
+        *reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), r);
 }
 
 static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, ROWS_PER_WG); }

@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 constexpr int BPB = 64;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
-template <int MI, int NI>
+template <int MI, int NI, bool GUARD>
 __global__ void __launch_bounds__(WTHREADS)
 conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
                        const int2* __restrict__ pairs, const int64_t* __restrict__ koff, int a_col,
@@ -599,15 +599,17 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
 #pragma unroll
     for (int t = 0; t < PT_A; ++t) {
       const int row = (tid + t * WTHREADS) / SEG_A;
-      int2 pr = make_int2(-1, -1);
-      if (p0 + row < p_end) pr = pairs ? pairs[p0 + row] : make_int2((int)(p0 + row), (int)(p0 + row));
+      const int64_t pi = p0 + row, pc = pi < p_end ? pi : p_end - 1;     // clamped: no branch
+      int2 pr = pairs ? pairs[pc] : make_int2((int)pc, (int)pc);
+      if (pi >= p_end) pr = make_int2(-1, -1);
       ia[t] = a_col ? pr.y : pr.x;
     }
 #pragma unroll
     for (int t = 0; t < PT_B; ++t) {
       const int row = (tid + t * WTHREADS) / SEG_B;
-      int2 pr = make_int2(-1, -1);
-      if (p0 + row < p_end) pr = pairs ? pairs[p0 + row] : make_int2((int)(p0 + row), (int)(p0 + row));
+      const int64_t pi = p0 + row, pc = pi < p_end ? pi : p_end - 1;
+      int2 pr = pairs ? pairs[pc] : make_int2((int)pc, (int)pc);
+      if (pi >= p_end) pr = make_int2(-1, -1);
       ib[t] = a_col ? pr.x : pr.y;
     }
   };
@@ -615,16 +617,28 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
 #pragma unroll
     for (int t = 0; t < PT_A; ++t) {
       const int sg = tid + t * WTHREADS, c = (sg % SEG_A) * 8;
-      ra[t] = DT<__bf16>::zero();
-      if (ia[t] >= 0 && ca0 + c < ca)
-        ra[t] = load_frag_guarded<__bf16>(a + (int64_t)ia[t] * ca + ca0 + c, ca - ca0 - c);
+      const bool ok = ia[t] >= 0 && ca0 + c < ca;
+      if constexpr (GUARD) {
+        ra[t] = DT<__bf16>::zero();
+        if (ok) ra[t] = load_frag_guarded<__bf16>(a + (int64_t)ia[t] * ca + ca0 + c, ca - ca0 - c);
+      } else {      // channels are multiples of 8: whole-vector loads, misses read the zero page
+        const __bf16* p = ok ? a + (int64_t)ia[t] * ca + ca0 + c
+                             : reinterpret_cast<const __bf16*>(g_zero_page);
+        ra[t] = *reinterpret_cast<const bf16x8*>(p);
+      }
     }
 #pragma unroll
     for (int t = 0; t < PT_B; ++t) {
       const int sg = tid + t * WTHREADS, c = (sg % SEG_B) * 8;
-      rb[t] = DT<__bf16>::zero();
-      if (ib[t] >= 0 && cb0 + c < cb)
-        rb[t] = load_frag_guarded<__bf16>(b + (int64_t)ib[t] * cb + cb0 + c, cb - cb0 - c);
+      const bool ok = ib[t] >= 0 && cb0 + c < cb;
+      if constexpr (GUARD) {
+        rb[t] = DT<__bf16>::zero();
+        if (ok) rb[t] = load_frag_guarded<__bf16>(b + (int64_t)ib[t] * cb + cb0 + c, cb - cb0 - c);
+      } else {
+        const __bf16* p = ok ? b + (int64_t)ib[t] * cb + cb0 + c
+                             : reinterpret_cast<const __bf16*>(g_zero_page);
+        rb[t] = *reinterpret_cast<const bf16x8*>(p);
+      }
     }
   };
   auto store_rows = [&](int buf) {
@@ -712,12 +726,17 @@ int launch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* 
   dim3 grid((unsigned)splits, (unsigned)K, (unsigned)(tiles_a * tiles_b));
   if constexpr (sizeof(T) == 2) {
     const size_t lds = 2 * BPB * ((TA + 8) + (TB + 8)) * sizeof(__bf16);
-    auto kern = conv_wgrad_bf16_kernel<MI, NI>;
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
+#ifdef LIDAL_WGRAD_FORCE_GUARD
+    const bool guard = true;
+#else
+    const bool guard = (ca % 8 != 0) || (cb % 8 != 0);
+#endif
+    auto kern = guard ? conv_wgrad_bf16_kernel<MI, NI, true> : conv_wgrad_bf16_kernel<MI, NI, false>;
+    static size_t attr_set[2] = {0, 0};
+    if (attr_set[guard] < lds) {
       LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = lds;
+      attr_set[guard] = lds;
     }
     kern<<<grid, WTHREADS, lds, s>>>((const __bf16*)a, (const __bf16*)b, (const int2*)pairs, koff,
                                      a_col, partial, K, ca, cb, tiles_b, target_chunk);

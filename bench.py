@@ -163,8 +163,16 @@ def roofline_conv(args, coords, dev, reps=20):
     algo_bytes = b * (n * ci + n * co) + b * 27 * ci * co + 8 * m
     flops = 2.0 * m * ci * co
     gbs = algo_bytes / sec / 1e9
+    traffic = None          # PMC-derived bytes per launch, measured offline on this exact workload
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_conv_apply.json')))
+        wl = rec['workload']
+        if (wl['rows'], wl['rules'], wl['dtype']) == (n, m, args.dtype):
+            traffic = rec['traffic_bytes']
+    except (OSError, KeyError, ValueError):
+        pass
     return {'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': None,
+            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
             'kernel': 'conv_apply_kernel (k3 s1 96->96, %s)' % args.dtype,
             'launch_us': round(sec * 1e6, 2), 'rows': n, 'rules': m,
             'algorithmic_bytes_per_launch': int(algo_bytes),

@@ -144,12 +144,19 @@ def _apply(feats, wk, order, kflip):
     return out
 
 
-WGRAD_CHUNK = 4096      # rules per split-K slab (lidal_conv_wgrad target_chunk)
+WGRAD_CHUNK = 4096      # rules per split-K slab at the fine levels (lidal_conv_wgrad target_chunk)
 
 
-def _wgrad_splits(n_rows):
+def _wgrad_chunk(n_rows):
+    """Smaller slabs on the coarse levels keep enough workgroups in flight (measured with
+    scripts/ablate_wgrad.py: 2048 wins below ~2e5 rows, 4096 above)."""
+    return WGRAD_CHUNK if n_rows >= 200000 else 2048
+
+
+def _wgrad_splits(n_rows, chunk=None):
     """Upper bound of slabs per offset: no offset has more rules than the table has rows."""
-    return int(max(1, min(256, -(-n_rows // WGRAD_CHUNK))))
+    chunk = chunk or _wgrad_chunk(n_rows)
+    return int(max(1, min(256, -(-n_rows // chunk))))
 
 
 class ConvolutionFunction(Function):
@@ -188,12 +195,13 @@ class ConvolutionFunction(Function):
                 grad_in = _apply(g, wk, kmap.order_out, 0)
         if ctx.needs_input_grad[1]:
             k, ci, co = weight.shape
-            splits = _wgrad_splits(max(n_in, n_out))
+            chunk = _wgrad_chunk(max(n_in, n_out))
+            splits = _wgrad_splits(max(n_in, n_out), chunk)
             gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
             partial = torch.empty((splits, k, ci, co), dtype=torch.float32, device=x.device)
             B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), B.ptr(kmap._nbmaps_cap),
                                              B.ptr(kmap.koff), 1 if transposed else 0, B.ptr(gw),
-                                             B.ptr(partial), splits, WGRAD_CHUNK, k, ci, co,
+                                             B.ptr(partial), splits, chunk, k, ci, co,
                                              B.dtype_code(x.dtype), B.stream()), 'conv_wgrad')
             grad_w = gw.to(weight.dtype)
         return grad_in, grad_w, None, None

@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from ... import backend as B
-from .conv import WGRAD_CHUNK, _wgrad_splits
+from .conv import _wgrad_chunk, _wgrad_splits
 
 __all__ = ['rows_matmul', 'rows_linear']
 
@@ -31,11 +31,12 @@ def _wgrad_dense(a, b):
     """a [N, Ca], b [N, Cb] (same dtype, f32 or bf16) -> a^T @ b as f32 [Ca, Cb]."""
     n, ca = a.shape
     cb = b.shape[1]
-    splits = _wgrad_splits(n)
+    chunk = _wgrad_chunk(n)
+    splits = _wgrad_splits(n, chunk)
     gw = torch.empty((1, ca, cb), dtype=torch.float32, device=a.device)
     partial = torch.empty((splits, 1, ca, cb), dtype=torch.float32, device=a.device)
     B.check(B.lib().lidal_conv_wgrad(B.ptr(a), B.ptr(b), None, B.ptr(_koff(n, a.device)), 0,
-                                     B.ptr(gw), B.ptr(partial), splits, WGRAD_CHUNK, 1, ca, cb,
+                                     B.ptr(gw), B.ptr(partial), splits, chunk, 1, ca, cb,
                                      B.dtype_code(a.dtype), B.stream()), 'conv_wgrad(dense)')
     return gw[0]
 

@@ -7,7 +7,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'scripts', '_abl')
-VARIANTS = {'base': [], 'guard': ['-DLIDAL_WGRAD_FORCE_GUARD']}
+VARIANTS = {'base': []}
+CHUNKS = [512, 1024, 2048, 4096, 8192]
 SHAPES = [(1, 32, 32), (1, 96, 96), (1, 128, 96), (4, 128, 128), (8, 256, 256), (8, 384, 256), (16, 256, 256)]
 
 
@@ -40,21 +41,23 @@ def run():
         lib = ctypes.CDLL(os.path.join(OUT, 'wgrad_%s.so' % name))
         lib.lidal_conv_wgrad.restype, lib.lidal_conv_wgrad.argtypes = sig
         fns[name] = lib.lidal_conv_wgrad
-    print('%-26s' % 'shape' + ''.join('%10s' % n for n in VARIANTS))
+    print('%-26s' % 'shape' + ''.join('%10s' % ('chunk%d' % c) for c in CHUNKS))
     for stride, ci, co in SHAPES:
         c = levels[stride]
         kmap, _ = F.build_kernel_map(c, (stride,) * 3, (3, 3, 3), (1, 1, 1))
         n = c.shape[0]
         x = torch.randn(n, ci, device='cuda').bfloat16()
         g = torch.randn(n, co, device='cuda').bfloat16()
-        splits = _wgrad_splits(n)
         gw = torch.empty((27, ci, co), device='cuda')
-        part = torch.empty((splits, 27, ci, co), device='cuda')
         ts = []
-        for name, fn in fns.items():
+        fn = fns['base']
+        for chunk in CHUNKS:
+            splits = max(1, min(256, -(-n // chunk)))
+            part = torch.empty((splits, 27, ci, co), device='cuda')
+
             def launch():
                 assert fn(B.ptr(x), B.ptr(g), B.ptr(kmap._nbmaps_cap), B.ptr(kmap.koff), 0, B.ptr(gw),
-                          B.ptr(part), splits, WGRAD_CHUNK, 27, ci, co, 1, B.stream()) == 0
+                          B.ptr(part), splits, chunk, 27, ci, co, 1, B.stream()) == 0
             for _ in range(2):
                 launch()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

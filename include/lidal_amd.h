@@ -64,6 +64,23 @@ int64_t lidal_downsample_workspace_bytes(int64_t n);
 int lidal_downsample(const int32_t* coords, int64_t n, int sx, int sy, int sz, int32_t* out,
                      int64_t* n_out_dev, void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- input voxelisation ("next" row 8f-1) ---------------------------------------------------- */
+/* replaces dataset/sk_dataset.py:143-171 for one scan: affine augmentation p*M (f64), feats =
+ * (transformed metres, intensity), x`scale`, random translation into [0, full_scale)^3 from the
+ * global min/max and the host's six uniform draws rnd[6] (:156), astype(int), and
+ * np.unique(axis=0, return_index=True, return_inverse=True).
+ *   points f32 [p,3], intensity f32 [p], m_dev f64 [9] (row-major trans_m), rnd_dev f64 [6]
+ *   feats_p f32 [p,4] (per point; caller gathers rows unique_idx), coords_v i32 [p,3] capacity
+ *   (unique voxels, lexicographic x,y,z), unique_idx i64 [p] capacity (first occurrence),
+ *   inverse i64 [p], n_out_dev i64 [1], n_invalid_dev i32 [1] (points outside the grid: the
+ *   reference asserts there are none, :161). */
+int64_t lidal_voxelize_points_workspace_bytes(int64_t p);
+int lidal_voxelize_points(const float* points, const float* intensity, int64_t p,
+                          const double* m_dev, const double* rnd_dev, double scale, int full_scale,
+                          float* feats_p, int32_t* coords_v, int64_t* unique_idx, int64_t* inverse,
+                          int64_t* n_out_dev, int32_t* n_invalid_dev, void* ws, int64_t ws_bytes,
+                          void* stream);
+
 /* ---- kernel map (rule) building -------------------------------------------------------------- */
 /* replaces the cache-miss branch of F.conv3d (torchsparse/nn/functional/conv.py): kernel_hash +
  * hash_query + nonzero.  `table` was built from sphash(in_coords).

@@ -323,6 +323,157 @@ size_t mask_sort_tmp_bytes(int64_t n) {
   return tmp;
 }
 
+
+// ---------------- input voxelisation (dataset/sk_dataset.py:143-171 on the GPU) ------------------
+// 1. affine: p' = p(f32 -> f64) * M (f64, row vector times matrix, k = 0,1,2 in order, no FMA);
+//    feats = (f32)p', intensity;  scaled = p' * scale;  per-block min/max of `scaled`
+// 2. offset from the global min/max and the host's random draws; voxel = (int)(scaled + offset)
+//    (C truncation, as ndarray.astype(int)); key = x << 26 | y << 13 | z  (coords < 8192)
+// 3. np.unique(axis=0, return_index, return_inverse): stable radix sort of (key, point id), run
+//    heads -> unique rows in lexicographic (x,y,z) order, first-occurrence index, inverse map.
+__global__ void __launch_bounds__(256) affine_kernel(const float* __restrict__ pts,
+                                                     const float* __restrict__ inten, int64_t p,
+                                                     const double* __restrict__ M, double scale,
+                                                     float* __restrict__ feats,
+                                                     double* __restrict__ scaled,
+                                                     double* __restrict__ part /*[blocks][6]*/) {
+  __shared__ double red[6][256];
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (i < p) {
+    double x = (double)pts[i * 3 + 0], y = (double)pts[i * 3 + 1], z = (double)pts[i * 3 + 2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double v = __dadd_rn(__dadd_rn(__dmul_rn(x, M[0 * 3 + j]), __dmul_rn(y, M[1 * 3 + j])),
+                           __dmul_rn(z, M[2 * 3 + j]));
+      feats[i * 4 + j] = (float)v;
+      double sv = __dmul_rn(v, scale);
+      scaled[i * 3 + j] = sv;
+      lo[j] = sv; hi[j] = sv;
+    }
+    feats[i * 4 + 3] = inten[i];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { red[j][threadIdx.x] = lo[j]; red[3 + j][threadIdx.x] = hi[j]; }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        red[j][threadIdx.x] = fmin(red[j][threadIdx.x], red[j][threadIdx.x + w]);
+        red[3 + j][threadIdx.x] = fmax(red[3 + j][threadIdx.x], red[3 + j][threadIdx.x + w]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) part[(int64_t)blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// single block: global min/max -> offset[3] (sk_dataset.py:154-157)
+__global__ void __launch_bounds__(256) voxel_offset_kernel(const double* __restrict__ part,
+                                                           int64_t nblocks,
+                                                           const double* __restrict__ rnd /*[6]*/,
+                                                           double full, double* __restrict__ offset) {
+  __shared__ double red[6][256];
+  double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int64_t b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      v[j] = fmin(v[j], part[b * 6 + j]);
+      v[3 + j] = fmax(v[3 + j], part[b * 6 + 3 + j]);
+    }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) red[j][threadIdx.x] = v[j];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        red[j][threadIdx.x] = fmin(red[j][threadIdx.x], red[j][threadIdx.x + w]);
+        red[3 + j][threadIdx.x] = fmax(red[3 + j][threadIdx.x], red[3 + j][threadIdx.x + w]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) {
+    const int j = threadIdx.x;
+    const double cmin = red[j][0], cmax = red[3 + j][0];
+    // offset = -cmin + clip(full - cmax + cmin - 0.001, 0, None) * r1 + clip(full - cmax + cmin + 0.001, None, 0) * r2
+    double a = __dadd_rn(__dadd_rn(__dadd_rn(full, -cmax), cmin), -0.001);
+    double b = __dadd_rn(__dadd_rn(__dadd_rn(full, -cmax), cmin), 0.001);
+    a = a < 0.0 ? 0.0 : a;
+    b = b > 0.0 ? 0.0 : b;
+    offset[j] = __dadd_rn(__dadd_rn(-cmin, __dmul_rn(a, rnd[j])), __dmul_rn(b, rnd[3 + j]));
+  }
+}
+
+__global__ void __launch_bounds__(256) voxel_keys_kernel(const double* __restrict__ scaled,
+                                                         int64_t p,
+                                                         const double* __restrict__ offset,
+                                                         int full, uint64_t* __restrict__ keys,
+                                                         int* __restrict__ vals,
+                                                         int* __restrict__ n_invalid) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p) return;
+  uint64_t key = 0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    double c = __dadd_rn(scaled[i * 3 + j], offset[j]);
+    bad |= !(c >= 0.0) || !(c < (double)full);          // sk_dataset.py:160-161 validity assert
+    int64_t v = (int64_t)c;                              // astype(int): truncation
+    key = (key << 13) | (uint64_t)(v & 0x1FFF);
+  }
+  keys[i] = key;
+  vals[i] = (int)i;
+  if (bad) atomicAdd(n_invalid, 1);
+}
+
+// after the stable sort: run heads -> unique rows.  uniq_idx[run] = first occurrence (smallest
+// original index of the run), inverse[orig] = run, coords_v[run] = unpacked key.
+__global__ void __launch_bounds__(kBlock) rows_compact_kernel(const uint64_t* __restrict__ skeys,
+                                                              const int* __restrict__ sidx,
+                                                              int64_t n,
+                                                              const int64_t* __restrict__ offsets,
+                                                              int64_t nblocks,
+                                                              int* __restrict__ coords_v,
+                                                              int64_t* __restrict__ uniq_idx,
+                                                              int64_t* __restrict__ inverse,
+                                                              int64_t* __restrict__ n_out) {
+  __shared__ int wave_cnt[kBlock / 64];
+  int64_t base = (int64_t)blockIdx.x * kTile;
+  int64_t pos = offsets[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    int64_t i = base + it * kBlock + threadIdx.x;
+    uint64_t v = (i < n) ? skeys[i] : 0;
+    bool head = (i < n) && (i == 0 || v != skeys[i - 1]);
+    int tot;
+    int r = block_rank(head, wave_cnt, &tot);
+    if (i < n) {
+      int64_t run = pos + r - (head ? 0 : 1);
+      int orig = sidx[i];
+      inverse[orig] = run;
+      if (head) {
+        uniq_idx[run] = orig;
+        coords_v[run * 3 + 0] = (int)((v >> 26) & 0x1FFF);
+        coords_v[run * 3 + 1] = (int)((v >> 13) & 0x1FFF);
+        coords_v[run * 3 + 2] = (int)(v & 0x1FFF);
+      }
+    }
+    pos += tot;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = offsets[nblocks];
+}
+
+size_t voxel_sort_tmp_bytes(int64_t n) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                  (const int*)nullptr, (int*)nullptr, (size_t)(n > 0 ? n : 1), 0,
+                                  39, (hipStream_t)0);
+  return tmp;
+}
+
 }  // namespace
 
 extern "C" int64_t lidal_unique_workspace_bytes(int64_t n) {
@@ -440,5 +591,62 @@ extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32
     tile_or_kernel<<<(unsigned)cdiv(tiles, 4), 256, 0, s>>>(skeys, q, tile_masks, tiles);
     LIDAL_CHECK_LAUNCH("tile_or");
   }
+  return 0;
+}
+
+// ---- input voxelisation -------------------------------------------------------------------------
+extern "C" int64_t lidal_voxelize_points_workspace_bytes(int64_t p) {
+  int64_t q = p > 0 ? p : 1;
+  int64_t blocks = cdiv(q, 256), nb = cdiv(q, kTile);
+  return align_up(24 * q, 256)              /* scaled f64 [p,3] */
+         + align_up(48 * blocks, 256)       /* min/max partials */
+         + 256                              /* offset[3], n_invalid */
+         + 2 * align_up(8 * q, 256)         /* keys, sorted keys */
+         + 2 * align_up(4 * q, 256)         /* ids, sorted ids */
+         + align_up(4 * nb, 256) + align_up(8 * (nb + 1), 256)
+         + align_up((int64_t)voxel_sort_tmp_bytes(q), 256) + 256;
+}
+
+extern "C" int lidal_voxelize_points(const float* points, const float* intensity, int64_t p,
+                                     const double* m_dev, const double* rnd_dev, double scale,
+                                     int full_scale, float* feats_p, int32_t* coords_v,
+                                     int64_t* unique_idx, int64_t* inverse, int64_t* n_out_dev,
+                                     int32_t* n_invalid_dev, void* ws, int64_t ws_bytes,
+                                     void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(full_scale > 0 && full_scale <= 8192, "voxelize_points: full_scale must be <= 8192");
+  LIDAL_HIP(hipMemsetAsync(n_invalid_dev, 0, 4, s));
+  if (p == 0) {
+    LIDAL_HIP(hipMemsetAsync(n_out_dev, 0, 8, s));
+    return 0;
+  }
+  LIDAL_REQUIRE(ws_bytes >= lidal_voxelize_points_workspace_bytes(p), "voxelize_points ws too small");
+  int64_t blocks = cdiv(p, 256), nb = cdiv(p, kTile);
+  char* w = (char*)ws;
+  double* scaled = (double*)w;      w += align_up(24 * p, 256);
+  double* part = (double*)w;        w += align_up(48 * blocks, 256);
+  double* offset = (double*)w;      w += 256;
+  uint64_t* keys = (uint64_t*)w;    w += align_up(8 * p, 256);
+  uint64_t* skeys = (uint64_t*)w;   w += align_up(8 * p, 256);
+  int* ids = (int*)w;               w += align_up(4 * p, 256);
+  int* sids = (int*)w;              w += align_up(4 * p, 256);
+  int* counts = (int*)w;            w += align_up(4 * nb, 256);
+  int64_t* offs = (int64_t*)w;      w += align_up(8 * (nb + 1), 256);
+  void* tmp = (void*)w;
+  size_t tmp_bytes = voxel_sort_tmp_bytes(p);
+  affine_kernel<<<(unsigned)blocks, 256, 0, s>>>(points, intensity, p, m_dev, scale, feats_p, scaled, part);
+  LIDAL_CHECK_LAUNCH("affine");
+  voxel_offset_kernel<<<1, 256, 0, s>>>(part, blocks, rnd_dev, (double)full_scale, offset);
+  LIDAL_CHECK_LAUNCH("voxel_offset");
+  voxel_keys_kernel<<<(unsigned)blocks, 256, 0, s>>>(scaled, p, offset, full_scale, keys, ids, n_invalid_dev);
+  LIDAL_CHECK_LAUNCH("voxel_keys");
+  LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, ids, sids, (size_t)p, 0, 39, s));
+  head_count_kernel<<<(unsigned)nb, kBlock, 0, s>>>(skeys, p, counts);
+  LIDAL_CHECK_LAUNCH("head_count");
+  scan_counts_kernel<<<1, 1024, 0, s>>>(counts, nb, offs);
+  LIDAL_CHECK_LAUNCH("scan_counts");
+  rows_compact_kernel<<<(unsigned)nb, kBlock, 0, s>>>(skeys, sids, p, offs, nb, coords_v, unique_idx,
+                                                      inverse, n_out_dev);
+  LIDAL_CHECK_LAUNCH("rows_compact");
   return 0;
 }

@@ -257,12 +257,61 @@ def make_selection():
           int((sel == 2).sum()), 'pseudo-labelled of', sel.size)
 
 
+def make_voxelize():
+    """Reference dataset/sk_dataset.py (SK_Dataset.__getitem__ + collate_fn, unchanged) on synthetic
+    velodyne .bin files; pins oracle/voxelize_ref.py and gives the GPU voxeliser its fixture."""
+    from lidal_amd import data as ldata
+    from lidal_amd import synth
+    from oracle import voxelize_ref
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    os.makedirs(os.path.join(tmp, 'Processing_files', 'SK'))
+    os.makedirs(os.path.join(tmp, 'seq', '00', 'velodyne'))
+    rng = np.random.default_rng(4)
+    world = synth.make_world(9)
+    files, scans = [], []
+    for i in range(2):
+        pts, inten = synth.raycast_scan(world, (20.0 + 3 * i, 0.0), rng, n_beams=32, n_az=256)
+        f = os.path.join(tmp, 'seq', '00', 'velodyne', '%06d.bin' % i)
+        np.concatenate([pts, inten[:, None]], 1).astype(np.float32).tofile(f)
+        files.append(f), scans.append((pts, inten))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    os.chdir(tmp)
+    try:
+        from dataset.sk_dataset import SK_Dataset       # the reference file, unchanged
+        ds = SK_Dataset(mode='score', lidar_files=files)
+        out = {}
+        samples = []
+        for i, (pts, inten) in enumerate(scans):
+            np.random.seed(100 + i)
+            ref = ds[i]
+            np.random.seed(100 + i)
+            trans_m, rnd = ldata.draw_augmentation(np.random)
+            cv, fv, ui, inv = voxelize_ref.voxelize_scan(pts, inten, trans_m, rnd)
+            assert np.array_equal(cv, ref['coords_v']) and np.array_equal(inv, ref['inverse_idxs'])
+            assert np.array_equal(fv, ref['feats_v']), 'oracle voxelize != reference __getitem__'
+            out.update({'points%d' % i: pts, 'intensity%d' % i: inten, 'trans_m%d' % i: trans_m,
+                        'rnd%d' % i: rnd, 'coords_v%d' % i: ref['coords_v'],
+                        'feats_v%d' % i: ref['feats_v'], 'inverse%d' % i: ref['inverse_idxs']})
+            samples.append(ref)
+        col = ds.collate_fn(samples)
+        out.update(coords_v_b=col['coords_v_b'].numpy(), feats_v_b=col['feats_v_b'].numpy(),
+                   inverse_indices_b=col['inverse_indices_b'].numpy())
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'voxelize_small.npz'), **out)
+    print('voxelize: oracle == reference SK_Dataset on 2 scans;', out['coords_v_b'].shape)
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'make_golden.py needs /root/reference (build container only)'
-    which = sys.argv[1:] or ['model', 'scoring', 'selection']
+    which = sys.argv[1:] or ['model', 'scoring', 'selection', 'voxelize']
     if 'model' in which:
         make_model()
     if 'scoring' in which:
         make_scoring()
     if 'selection' in which:
         make_selection()
+    if 'voxelize' in which:
+        make_voxelize()

@@ -1,0 +1,67 @@
+"""GPU input voxelisation + collate against the fixture produced by the
+REFERENCE's own SK_Dataset.__getitem__ / collate_fn (tests/golden/voxelize_small.npz) and against
+the CPU oracle at full size.  Integer outputs bit-exact; features to 1 f32 ulp (numpy's matmul may
+fuse multiply-adds where the kernel rounds each product)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _ulp_close(a, b):
+    return np.all(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= np.spacing(np.abs(b).astype(np.float32)).astype(np.float64))
+
+
+def test_voxelize_matches_reference_dataset(golden_dir):
+    from lidal_amd import data
+    g = np.load(os.path.join(golden_dir, 'voxelize_small.npz'))
+    samples = []
+    for i in range(2):
+        cv, fv, ui, inv = data.voxelize_scan(torch.from_numpy(g['points%d' % i]).to(DEV),
+                                             torch.from_numpy(g['intensity%d' % i]).to(DEV),
+                                             g['trans_m%d' % i], g['rnd%d' % i])
+        assert cv.dtype == torch.int32 and inv.dtype == torch.int64
+        assert np.array_equal(cv.cpu().numpy(), g['coords_v%d' % i])
+        assert np.array_equal(inv.cpu().numpy(), g['inverse%d' % i])
+        assert _ulp_close(fv.cpu().numpy(), g['feats_v%d' % i])
+        # first-occurrence index: coords of the indexed points are the unique rows
+        samples.append({'coords_v': cv, 'feats_v': fv, 'inverse_idxs': inv})
+    col = data.collate(samples)
+    assert np.array_equal(col['coords_v_b'].cpu().numpy(), g['coords_v_b'])
+    assert np.array_equal(col['inverse_indices_b'].cpu().numpy(), g['inverse_indices_b'])
+    assert _ulp_close(col['feats_v_b'].cpu().numpy(), g['feats_v_b'])
+
+
+def test_voxelize_full_size_matches_oracle_and_feeds_the_model():
+    import lidal_amd
+    from lidal_amd import data, synth
+    from lidal_amd.nn import functional as F
+    from oracle import voxelize_ref
+    rng = np.random.default_rng(0)
+    pts, inten = synth.raycast_scan(synth.make_world(3), (30.0, 0.0), rng)
+    assert pts.shape[0] > 100000
+    rs = np.random.RandomState(7)
+    trans_m, rnd = data.draw_augmentation(rs)
+    cv_r, fv_r, ui_r, inv_r = voxelize_ref.voxelize_scan(pts, inten, trans_m, rnd)
+    cv, fv, ui, inv = data.voxelize_scan(torch.from_numpy(pts).to(DEV), torch.from_numpy(inten).to(DEV),
+                                         trans_m, rnd)
+    assert np.array_equal(cv.cpu().numpy(), cv_r) and np.array_equal(inv.cpu().numpy(), inv_r)
+    assert np.array_equal(ui.cpu().numpy(), ui_r)
+    assert _ulp_close(fv.cpu().numpy(), fv_r)
+    # properties: rows strictly increasing lexicographically, inverse consistent
+    k = cv[:, 0].long() * 2 ** 26 + cv[:, 1].long() * 2 ** 13 + cv[:, 2].long()
+    assert (k[1:] > k[:-1]).all() and int(inv.max()) == cv.shape[0] - 1
+    col = data.collate([{'coords_v': cv, 'feats_v': fv, 'inverse_idxs': inv}])
+    kmap, _ = F.build_kernel_map(col['coords_v_b'], (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    assert kmap.total > cv.shape[0]
+
+
+def test_voxelize_rejects_points_outside_the_grid():
+    from lidal_amd import data
+    pts = torch.tensor([[0.0, 0, 0], [500.0, 0, 0]], device=DEV)      # 500 m * 20 > 8192 voxels
+    with pytest.raises(AssertionError, match='not valid'):
+        data.voxelize_scan(pts, torch.zeros(2, device=DEV), np.eye(3), np.full(6, 0.5))

@@ -143,3 +143,14 @@ def test_models_ref_reproduces_reference_model_files(golden_dir):
             lo, fe = m(tsref.SparseTensor(torch.from_numpy(g['feats']), torch.from_numpy(g['coords'])))
         assert np.array_equal(lo.numpy(), g[name + '_logits'])
         assert np.array_equal(fe.numpy(), g[name + '_feat'])
+
+
+def test_voxelize_oracle_reproduces_reference_dataset(golden_dir):
+    """oracle/voxelize_ref.py vs the fixture of the reference's SK_Dataset.__getitem__."""
+    from oracle import voxelize_ref
+    g = np.load(os.path.join(golden_dir, 'voxelize_small.npz'))
+    for i in range(2):
+        cv, fv, ui, inv = voxelize_ref.voxelize_scan(g['points%d' % i], g['intensity%d' % i],
+                                                     g['trans_m%d' % i], g['rnd%d' % i])
+        assert np.array_equal(cv, g['coords_v%d' % i]) and np.array_equal(inv, g['inverse%d' % i])
+        assert np.array_equal(fv, g['feats_v%d' % i])

@@ -201,6 +201,11 @@ int lidal_view_mean_softmax(const float* logits, const int64_t* inverse, int rep
                             int c, float* prob, int64_t* pred, void* stream);
 
 /* ---- inter-frame divergence / entropy scoring ---------------------------------------------- */
+/* replaces dataset/prepare_kdtree_sk.py:76-80 ("next" row 8f-2): sensor-frame points f32 [p,3] ->
+ * world-frame f64 [p,3] = (hcoords * pose^T)[:, :3] with pose f64 [16] row-major 4x4 (device),
+ * same operation order as the reference's broadcast-multiply + sum. */
+int lidal_register_points(const float* points, int64_t p, const double* pose_dev, double* world,
+                          void* stream);
 /* Uniform-grid nearest-neighbour structure over one frame's world-frame points (replaces the
  * pickled sklearn KDTree of dataset/prepare_kdtree_sk.py:83 as used by
  * score/sv_level/LiDAL.py:52-66).  cell = match radius.

@@ -15,6 +15,8 @@ OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'liblidal_amd.so')
 SOURCES = ['error.cpp', 'hash.hip', 'kmap.hip', 'voxel.hip', 'conv.hip', 'bn.hip', 'score.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
+# units that restate numpy arithmetic (separately rounded products and sums): no fma contraction
+NO_CONTRACT = {'score.hip', 'kmap.hip'}
 
 
 def _stale(target, deps):
@@ -27,9 +29,10 @@ def _stale(target, deps):
 def _compile(src):
     obj = os.path.join(OBJ, src + '.o')
     deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'common.h'),
-            os.path.join(HERE, '..', 'include', 'lidal_amd.h')]
+            os.path.join(HERE, '..', 'include', 'lidal_amd.h'), os.path.abspath(__file__)]
     if _stale(obj, deps):
-        cmd = ['hipcc'] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + \
+        cmd = ['hipcc'] + FLAGS + (['-ffp-contract=off'] if src in NO_CONTRACT else []) + \
+              (['-x', 'hip'] if src.endswith('.cpp') else []) + \
               ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -12,6 +12,10 @@
 
 #include "common.h"
 
+// The reference computes these quantities with numpy (separately rounded products and sums); hipcc
+// contracts a*b+c into fma even through __dmul_rn/__dadd_rn, so this unit is built with
+// -ffp-contract=off (lidal_amd/build.py).
+
 using namespace lidal;
 
 namespace {

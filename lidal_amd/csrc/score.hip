@@ -10,6 +10,10 @@
 
 #include "common.h"
 
+// The reference computes these quantities with numpy (separately rounded products and sums); hipcc
+// contracts a*b+c into fma even through __dmul_rn/__dadd_rn, so this unit is built with
+// -ffp-contract=off (lidal_amd/build.py).
+
 using namespace lidal;
 
 namespace {
@@ -73,6 +77,23 @@ __global__ void __launch_bounds__(256) view_mean_softmax_kernel(const float* __r
       if (m > best) { best = m; arg = j; }
     }
   pred[i] = arg;
+}
+
+// ---------------- world-frame registration (dataset/prepare_kdtree_sk.py:76-80) ----------------
+// world[p][j] = ((h0*P[j][0] + h1*P[j][1]) + h2*P[j][2]) + 1*P[j][3] with h = (f64)point: the
+// reference's np.sum(expand_dims(hcoords, 2) * pose.T, axis=1), products rounded individually.
+__global__ void __launch_bounds__(256) register_kernel(const float* __restrict__ pts, int64_t p,
+                                                       const double* __restrict__ pose,
+                                                       double* __restrict__ world) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  const double h0 = (double)pts[i * 3 + 0], h1 = (double)pts[i * 3 + 1], h2 = (double)pts[i * 3 + 2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    double v = __dadd_rn(__dmul_rn(h0, pose[j * 4 + 0]), __dmul_rn(h1, pose[j * 4 + 1]));
+    v = __dadd_rn(v, __dmul_rn(h2, pose[j * 4 + 2]));
+    world[i * 3 + j] = __dadd_rn(v, pose[j * 4 + 3]);
+  }
 }
 
 // ---------------- uniform grid for radius-limited nearest neighbour ----------------
@@ -370,5 +391,13 @@ extern "C" int lidal_supervoxel_reduce(const double* interd, const float* intere
   supervoxel_reduce_kernel<<<(unsigned)s, 256, 0, (hipStream_t)stream>>>(
       interd, intere, pts, sv_ptr, sv_idx, sv_interd, sv_intere, sv_center);
   LIDAL_CHECK_LAUNCH("lidal_supervoxel_reduce");
+  return 0;
+}
+
+extern "C" int lidal_register_points(const float* points, int64_t p, const double* pose_dev,
+                                     double* world, void* stream) {
+  if (p == 0) return 0;
+  register_kernel<<<(unsigned)cdiv(p, 256), 256, 0, (hipStream_t)stream>>>(points, p, pose_dev, world);
+  LIDAL_CHECK_LAUNCH("lidal_register_points");
   return 0;
 }

@@ -14,7 +14,8 @@ import torch
 
 from . import backend as B
 
-__all__ = ['draw_augmentation', 'voxelize_scan', 'collate']
+__all__ = ['draw_augmentation', 'voxelize_scan', 'collate', 'parse_calibration', 'parse_poses',
+           'register_scan']
 
 SCALE = 20                # sk_dataset.py:56
 FULL_SCALE = 8192
@@ -81,3 +82,49 @@ def collate(samples):
     return {'coords_v_b': torch.cat(coords, 0), 'feats_v_b': torch.cat(feats, 0),
             'labels_v_b': torch.cat(labels, 0) if labels else None,
             'inverse_indices_b': torch.cat(inverse, 0) if inverse else None}
+
+
+# ---- world-frame registration (dataset/prepare_kdtree_sk.py) ---------------------
+def _mat_from_values(values):
+    pose = np.zeros((4, 4))
+    pose[0, 0:4] = values[0:4]
+    pose[1, 0:4] = values[4:8]
+    pose[2, 0:4] = values[8:12]
+    pose[3, 3] = 1.0
+    return pose
+
+
+def parse_calibration(filename):
+    """prepare_kdtree_sk.py:39-62: `key: 12 floats` lines -> dict of 4x4 matrices."""
+    calib = {}
+    with open(filename) as f:
+        for line in f:
+            key, content = line.strip().split(':')
+            calib[key] = _mat_from_values([float(v) for v in content.strip().split()])
+    return calib
+
+
+def parse_poses(filename, calibration):
+    """prepare_kdtree_sk.py:10-36: per-scan camera poses -> LiDAR poses Tr^-1 * pose * Tr."""
+    tr = calibration['Tr']
+    tr_inv = np.linalg.inv(tr)
+    poses = []
+    with open(filename) as f:
+        for line in f:
+            pose = _mat_from_values([float(v) for v in line.strip().split()])
+            poses.append(np.matmul(tr_inv, np.matmul(pose, tr)))
+    return poses
+
+
+def register_scan(points, pose):
+    """prepare_kdtree_sk.py:76-80: sensor-frame points f32 [P,3] (GPU) + 4x4 pose (host f64) ->
+    world-frame f64 [P,3], the data the reference hands to sklearn's KDTree (:83); here it goes to
+    lidal_amd.score.FrameBank.add, which builds the uniform NN grid."""
+    B.require_gpu(points)
+    points = points.contiguous().float()
+    p = points.shape[0]
+    pose_dev = torch.from_numpy(np.ascontiguousarray(pose, dtype=np.float64).reshape(16)).to(points.device)
+    world = torch.empty((p, 3), dtype=torch.float64, device=points.device)
+    B.check(B.lib().lidal_register_points(B.ptr(points), p, B.ptr(pose_dev), B.ptr(world), B.stream()),
+            'register_points')
+    return world

@@ -304,9 +304,49 @@ def make_voxelize():
     print('voxelize: oracle == reference SK_Dataset on 2 scans;', out['coords_v_b'].shape)
 
 
+def make_register():
+    """Reference dataset/prepare_kdtree_sk.py (parse_calibration, parse_poses, process_frame,
+    unchanged) on a synthetic calib/poses/velodyne triple: world coordinates held by the pickled
+    KDTree are the fixture for lidal_amd.data.register_scan."""
+    from lidal_amd import synth
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    os.makedirs(os.path.join(tmp, 'Processing_files', 'SK', 'kdtree', '00'))
+    os.makedirs(os.path.join(tmp, 'sequences', '00', 'velodyne'))
+    rng = np.random.default_rng(8)
+    pts, inten = synth.raycast_scan(synth.make_world(2), (15.0, 0.0), rng, n_beams=16, n_az=128)
+    fbin = os.path.join(tmp, 'sequences', '00', 'velodyne', '000003.bin')
+    np.concatenate([pts, inten[:, None]], 1).astype(np.float32).tofile(fbin)
+    calib_txt = 'P0: ' + ' '.join(['1'] * 12) + '\nTr: 4.27e-04 -9.99e-01 -8.08e-03 -1.19e-02 -7.21e-03 8.08e-03 -9.99e-01 -5.40e-02 9.99e-01 4.85e-04 -7.20e-03 -2.92e-01\n'
+    open(os.path.join(tmp, 'calib.txt'), 'w').write(calib_txt)
+    th = 0.31
+    pose_vals = [np.cos(th), 0.02, np.sin(th), 12.5, -0.01, 1.0, 0.03, -0.7, -np.sin(th), 0.01, np.cos(th), 101.25]
+    open(os.path.join(tmp, 'poses.txt'), 'w').write(' '.join('%.9e' % v for v in pose_vals) + '\n')
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    os.chdir(tmp)
+    try:
+        import dataset.prepare_kdtree_sk as K            # the reference file, unchanged
+        calib = K.parse_calibration(os.path.join(tmp, 'calib.txt'))
+        poses = K.parse_poses(os.path.join(tmp, 'poses.txt'), calib)
+        K.process_frame(0, [fbin], poses)
+        with open(os.path.join(tmp, 'Processing_files/SK/kdtree/00/000003.pickle'), 'rb') as fh:
+            tree = pickle.load(fh)
+    finally:
+        os.chdir(cwd)
+    from lidal_amd import data as ldata
+    c2 = ldata.parse_calibration(os.path.join(tmp, 'calib.txt'))
+    p2 = ldata.parse_poses(os.path.join(tmp, 'poses.txt'), c2)
+    assert np.array_equal(p2[0], poses[0]) and np.array_equal(c2['Tr'], calib['Tr'])
+    np.savez_compressed(os.path.join(HERE, 'register_small.npz'), points=pts, pose=poses[0],
+                        world=np.asarray(tree.data), calib_txt=calib_txt,
+                        poses_txt=open(os.path.join(tmp, 'poses.txt')).read())
+    print('register: fixture from reference process_frame,', np.asarray(tree.data).shape)
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'make_golden.py needs /root/reference (build container only)'
-    which = sys.argv[1:] or ['model', 'scoring', 'selection', 'voxelize']
+    which = sys.argv[1:] or ['model', 'scoring', 'selection', 'voxelize', 'register']
     if 'model' in which:
         make_model()
     if 'scoring' in which:
@@ -315,3 +355,5 @@ if __name__ == '__main__':
         make_selection()
     if 'voxelize' in which:
         make_voxelize()
+    if 'register' in which:
+        make_register()

@@ -65,3 +65,23 @@ def test_voxelize_rejects_points_outside_the_grid():
     pts = torch.tensor([[0.0, 0, 0], [500.0, 0, 0]], device=DEV)      # 500 m * 20 > 8192 voxels
     with pytest.raises(AssertionError, match='not valid'):
         data.voxelize_scan(pts, torch.zeros(2, device=DEV), np.eye(3), np.full(6, 0.5))
+
+
+def test_register_scan_matches_reference_kdtree_data(golden_dir, tmp_path):
+    """World-frame coordinates bit-exact against the data of the KDTree the reference's
+    prepare_kdtree_sk.process_frame pickled; pose parsing against the same text files."""
+    from lidal_amd import data
+    g = np.load(os.path.join(golden_dir, 'register_small.npz'))
+    (tmp_path / 'calib.txt').write_text(str(g['calib_txt']))
+    (tmp_path / 'poses.txt').write_text(str(g['poses_txt']))
+    calib = data.parse_calibration(str(tmp_path / 'calib.txt'))
+    poses = data.parse_poses(str(tmp_path / 'poses.txt'), calib)
+    assert np.array_equal(poses[0], g['pose'])
+    world = data.register_scan(torch.from_numpy(g['points']).to(DEV), poses[0])
+    assert world.dtype == torch.float64
+    assert np.array_equal(world.cpu().numpy(), g['world'])
+    # and it feeds the scorer's frame bank
+    from lidal_amd.score import FrameBank
+    bank = FrameBank(0.1)
+    bank.add(world, torch.full((world.shape[0], 19), 1 / 19, device=DEV))
+    assert bank.grid(0).numel() > 0

@@ -200,6 +200,12 @@ int lidal_colsum(const void* x, int dtype, int64_t n, int c, float* out, void* w
 int lidal_view_mean_softmax(const float* logits, const int64_t* inverse, int reps, int64_t p,
                             int c, float* prob, int64_t* pred, void* stream);
 
+/* replaces evaluate.py:100-109 + utils/iou_sk.py:14-19 ("next" row 8f-4): conf i32 [c*c] +=
+ * bincount(argmax(logits[inverse]) * c + labels) over labelled points (label < 100); conf is
+ * accumulated across calls (the caller zeroes it once and all-reduces it across ranks). */
+int lidal_confusion_accumulate(const float* logits, const int64_t* inverse, const int64_t* labels,
+                               int64_t p, int c, int32_t* conf, void* stream);
+
 /* ---- inter-frame divergence / entropy scoring ---------------------------------------------- */
 /* replaces dataset/prepare_kdtree_sk.py:76-80 ("next" row 8f-2): sensor-frame points f32 [p,3] ->
  * world-frame f64 [p,3] = (hcoords * pose^T)[:, :3] with pose f64 [16] row-major 4x4 (device),

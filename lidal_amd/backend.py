@@ -62,6 +62,7 @@ SIGNATURES = {
                             _i64, _vp]),
     'lidal_colsum': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp]),
     'lidal_view_mean_softmax': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    'lidal_confusion_accumulate': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'lidal_register_points': (_i32, [_vp, _i64, _vp, _vp, _vp]),
     'lidal_nn_grid_bytes': (_i64, [_i64]),
     'lidal_nn_grid_workspace_bytes': (_i64, [_i64]),

@@ -79,6 +79,36 @@ __global__ void __launch_bounds__(256) view_mean_softmax_kernel(const float* __r
   pred[i] = arg;
 }
 
+// ---------------- confusion matrix of evaluate.py:100-109 + utils/iou_sk.py:14-19 ----------------
+// per point: voxel row through the inverse index, argmax over the c logits (first maximum, as
+// torch.max / np.argmax), and conf[pred * c + gt] += 1 for labelled points (gt < 100).  Integer
+// counts: per-workgroup LDS histogram, then global integer atomics (order independent, exact).
+__global__ void __launch_bounds__(256) confusion_kernel(const float* __restrict__ logits,
+                                                        const int64_t* __restrict__ inverse,
+                                                        const int64_t* __restrict__ labels,
+                                                        int64_t p, int c, int* __restrict__ conf) {
+  __shared__ int hist[MAXC * MAXC];
+  for (int i = threadIdx.x; i < c * c; i += 256) hist[i] = 0;
+  __syncthreads();
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < p) {
+    const int64_t gt = labels[i];
+    if (gt >= 0 && gt < 100 && gt < c) {
+      const float* row = logits + inverse[i] * c;
+      float best = row[0];
+      int arg = 0;
+      for (int j = 1; j < c; ++j) {
+        float v = row[j];
+        if (v > best) { best = v; arg = j; }
+      }
+      atomicAdd(&hist[arg * c + (int)gt], 1);
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < c * c; j += 256)
+    if (hist[j]) atomicAdd(&conf[j], hist[j]);
+}
+
 // ---------------- world-frame registration (dataset/prepare_kdtree_sk.py:76-80) ----------------
 // world[p][j] = ((h0*P[j][0] + h1*P[j][1]) + h2*P[j][2]) + 1*P[j][3] with h = (f64)point: the
 // reference's np.sum(expand_dims(hcoords, 2) * pose.T, axis=1), products rounded individually.
@@ -399,5 +429,16 @@ extern "C" int lidal_register_points(const float* points, int64_t p, const doubl
   if (p == 0) return 0;
   register_kernel<<<(unsigned)cdiv(p, 256), 256, 0, (hipStream_t)stream>>>(points, p, pose_dev, world);
   LIDAL_CHECK_LAUNCH("lidal_register_points");
+  return 0;
+}
+
+extern "C" int lidal_confusion_accumulate(const float* logits, const int64_t* inverse,
+                                          const int64_t* labels, int64_t p, int c, int32_t* conf,
+                                          void* stream) {
+  LIDAL_REQUIRE(c > 0 && c <= MAXC, "confusion: classes must be in 1..%d", MAXC);
+  if (p == 0) return 0;
+  confusion_kernel<<<(unsigned)cdiv(p, 256), 256, 0, (hipStream_t)stream>>>(logits, inverse, labels,
+                                                                            p, c, conf);
+  LIDAL_CHECK_LAUNCH("lidal_confusion_accumulate");
   return 0;
 }

@@ -129,3 +129,53 @@ def test_synthetic_inputs_follow_reference_contract():
     seq = synth.make_sequence(3, n_points=500, seed=2, n_beams=8, n_az=128)
     assert seq[1]['world'].dtype == np.float64 and len(seq[1]['sv2point']) == 20
     assert sorted(np.concatenate(seq[1]['sv2point']).tolist()) == list(range(500))
+
+
+def test_on_disk_formats_round_trip_and_match_reference_layout(tmp_path, golden_dir):
+    """files written by lidal_amd.io have the reference's dtypes/shapes/pickle layout,
+    and a reference-format checkpoint (DDP 'module.' prefix included) loads strict=True."""
+    import pickle
+    from lidal_amd import io as lio
+    from lidal_amd.network import MinkUNet
+    prob = torch.rand(50, 19)
+    pred = prob.argmax(1)
+    lio.save_prob_pred(str(tmp_path / 'prob/000001.npy'), str(tmp_path / 'pred/000001.npy'), prob, pred)
+    p = np.load(tmp_path / 'prob/000001.npy')
+    assert p.dtype == np.float32 and p.shape == (50, 19)
+    assert np.load(tmp_path / 'pred/000001.npy').dtype == np.int64
+    assert torch.equal(lio.load_prob(str(tmp_path / 'prob/000001.npy')), prob)
+    sv_id = np.arange(40, 60, dtype=np.int64)
+    sv2point = [np.arange(i, 50, 20, dtype=np.int64) for i in range(20)]
+    lio.save_supervoxels(str(tmp_path / 'sv/000001.pickle'), sv_id, sv2point)
+    with open(tmp_path / 'sv/000001.pickle', 'rb') as f:          # as LiDAL.py:84-85 reads it
+        a, b = pickle.load(f)
+    assert np.array_equal(a, sv_id) and all(np.array_equal(x, y) for x, y in zip(b, sv2point))
+    sid, s2p = lio.load_supervoxels(str(tmp_path / 'sv/000001.pickle'))
+    assert np.array_equal(sid, sv_id) and len(s2p) == 20
+    lio.save_sv_flag(str(tmp_path / 'flag/000001.npy'), np.array([0, 1, 2] * 6 + [0, 0]))
+    assert set(lio.load_sv_flag(str(tmp_path / 'flag/000001.npy')).tolist()) == {0, 1, 2}
+    model = MinkUNet(19)
+    lio.save_checkpoint(str(tmp_path / 'ckpt'), model, 500, 3)
+    raw = torch.load(tmp_path / 'ckpt/current.pt')
+    assert set(raw) == {'model_state_dict', 'iteration', 'ep_id'}
+    ref_keys = [k for k, _, _ in json.load(open(os.path.join(golden_dir, 'state_dict_minkunet.json')))]
+    assert list(raw['model_state_dict']) == ref_keys
+    torch.save({'model_state_dict': {'module.' + k: v for k, v in raw['model_state_dict'].items()},
+                'iteration': 7, 'ep_id': 1}, tmp_path / 'ddp.pt')
+    assert lio.load_checkpoint(str(tmp_path / 'ddp.pt'), MinkUNet(19)) == (7, 1)
+
+
+def test_iou_from_confusion_matches_reference_formula():
+    from lidal_amd.evaluate import iou_from_confusion
+    rng = np.random.default_rng(0)
+    conf = rng.integers(0, 1000, (19, 19)).astype(np.int32)
+    conf[:, 5] = 0
+    conf[5, :] = 0                                    # a class never seen: IoU is nan as in iou_sk
+    ious, miou = iou_from_confusion(conf)
+    for i in range(19):
+        tp = conf[i, i]; fp = conf[i].sum() - tp; fn = conf[:, i].sum() - tp
+        if tp + fp + fn == 0:
+            assert np.isnan(ious[i])
+        else:
+            assert ious[i] == tp / (tp + fp + fn)
+    assert np.isnan(miou)

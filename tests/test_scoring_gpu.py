@@ -115,3 +115,24 @@ def test_prob_inference_end_to_end_vs_oracle():
     assert prob.shape == prob_ref.shape
     assert np.abs(prob.cpu().numpy() - prob_ref).max() <= 1e-4 * np.abs(prob_ref).max() + 1e-6
     assert (pred.cpu().numpy() == pred_ref).mean() > 0.995
+
+
+def test_confusion_matrix_matches_reference_bincount():
+    """evaluate.py:100-109 + utils/iou_sk.py:14-19 restated in numpy vs the device kernel."""
+    from lidal_amd.evaluate import confusion_accumulate, iou_from_confusion
+    g = torch.Generator().manual_seed(4)
+    nv, p, c = 5000, 40000, 19
+    logits = torch.randn(nv, c, generator=g)
+    inverse = torch.randint(0, nv, (p,), generator=g)
+    labels = torch.randint(0, c, (p,), generator=g)
+    labels[torch.rand(p, generator=g) < 0.1] = 255
+    pred = logits[inverse].max(1)[1].numpy()
+    gt = labels.numpy()
+    idx = gt < 100
+    ref = np.bincount(pred[idx] * 19 + gt[idx], minlength=361).reshape(19, 19).astype(np.int32)
+    conf = torch.zeros((c, c), dtype=torch.int32, device=DEV)
+    confusion_accumulate(conf, logits.to(DEV), inverse.to(DEV), labels.to(DEV))
+    confusion_accumulate(conf, logits.to(DEV), inverse.to(DEV), labels.to(DEV))       # accumulates
+    assert np.array_equal(conf.cpu().numpy(), 2 * ref)
+    ious, miou = iou_from_confusion(ref)
+    assert 0.0 < miou < 0.2

@@ -57,6 +57,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--roofline-only', action='store_true',
+                    help='only the dominant-kernel measurement (for rocprofv3: every launch of the '
+                         'kernel in the trace is then the roofline layer)')
     return ap.parse_args()
 
 
@@ -266,6 +269,12 @@ def main():
     world, rank, dev = dist_setup(args)
     from lidal_amd import backend
     backend.lib()                           # fail loudly if the HIP library is missing
+    if args.roofline_only:
+        from lidal_amd import synth
+        batch = synth.make_train_batch(n_frames=args.frames, n_points=args.points, seed=7122 + rank)
+        coords = torch.from_numpy(batch['coords_v_b']).to(dev)
+        print(json.dumps({'roofline': roofline_conv(args, coords, dev)}), flush=True)
+        return
     res = bench_train(args, world, rank, dev)
     log('train timed: %.3f s for %d steps' % (res['seconds'], args.steps))
     ms = res['seconds'] / args.steps * 1e3

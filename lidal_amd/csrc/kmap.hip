@@ -231,6 +231,54 @@ __global__ void __launch_bounds__(kBlock) kmap_probe_kernel(TableView t,
   for (int k = threadIdx.x; k < K; k += kBlock) counts[(int64_t)k * nblocks + blockIdx.x] = cnt[k];
 }
 
+// pass 1 (symmetric form): when the output coordinates ARE the input coordinates and the kernel is
+// odd and centred (every k3 stride-1 conv), rule (i, j, k) implies rule (j, i, K-1-k) and the centre
+// offset is the identity.  Only the first K/2 offsets are probed; each hit also fills its mirror
+// entry (a unique (offset, row) slot, so no write conflicts).  Halves the hash probes.
+__global__ void __launch_bounds__(kBlock) kmap_probe_sym_kernel(TableView t,
+                                                                const int4* __restrict__ coords,
+                                                                int64_t n,
+                                                                const int* __restrict__ offsets,
+                                                                int K, int* __restrict__ nbr_out) {
+  int64_t base = (int64_t)blockIdx.x * kTile;
+  const int half = K / 2;
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    int64_t j = base + it * kBlock + threadIdx.x;
+    if (j >= n) continue;
+    int4 c = coords[j];
+    nbr_out[(int64_t)half * n + j] = (int)j;
+    for (int k = 0; k < half; ++k) {
+      int r = table_lookup(t, (uint64_t)fnv60(c.x + offsets[k * 3 + 0], c.y + offsets[k * 3 + 1],
+                                              c.z + offsets[k * 3 + 2], c.w));
+      nbr_out[(int64_t)k * n + j] = r;
+      if (r >= 0) nbr_out[(int64_t)(K - 1 - k) * n + r] = (int)j;
+    }
+  }
+}
+
+// per-(offset, block) counts of an already filled table (feeds the same scan + compaction)
+__global__ void __launch_bounds__(kBlock) kmap_count_kernel(const int* __restrict__ nbr_out,
+                                                            int64_t n_out, int K,
+                                                            int* __restrict__ counts,
+                                                            int64_t nblocks) {
+  __shared__ int cnt;
+  const int k = blockIdx.y;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int64_t base = (int64_t)blockIdx.x * kTile;
+  int found = 0;
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    int64_t j = base + it * kBlock + threadIdx.x;
+    int r = (j < n_out) ? nbr_out[(int64_t)k * n_out + j] : -1;
+    found += __popcll(__ballot(r >= 0));
+  }
+  if (lane_id() == 0) atomicAdd(&cnt, found);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[(int64_t)k * nblocks + blockIdx.x] = cnt;
+}
+
 // pass 3: ordered compaction of (in_idx, out_idx) pairs, block (b, k).
 __global__ void __launch_bounds__(kBlock) kmap_compact_kernel(const int* __restrict__ nbr_out,
                                                               int64_t n_out,
@@ -527,9 +575,9 @@ extern "C" int64_t lidal_kmap_workspace_bytes(int64_t n_out, int k) {
 }
 
 extern "C" int lidal_kmap_build(const void* table, int64_t table_bytes, const int32_t* out_coords,
-                                int64_t n_out, const int32_t* offsets, int k, int32_t* nbr_out,
-                                int32_t* nbmaps, int32_t* nbsizes, int64_t* koff, void* ws,
-                                int64_t ws_bytes, void* stream) {
+                                int64_t n_out, const int32_t* offsets, int k, int symmetric,
+                                int32_t* nbr_out, int32_t* nbmaps, int32_t* nbsizes, int64_t* koff,
+                                void* ws, int64_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   LIDAL_REQUIRE(k > 0 && k <= 1023, "kmap: bad kernel volume %d", k);
   if (n_out == 0) {
@@ -542,9 +590,20 @@ extern "C" int lidal_kmap_build(const void* table, int64_t table_bytes, const in
   int* counts = (int*)ws;
   int64_t* offs = (int64_t*)((char*)ws + align_up(4 * nblocks * k, 256));
   TableView t = table_view(table, table_bytes);
-  kmap_probe_kernel<<<(int)nblocks, kBlock, k * sizeof(int), s>>>(
-      t, (const int4*)out_coords, n_out, offsets, k, nbr_out, counts, nblocks);
-  LIDAL_CHECK_LAUNCH("kmap_probe");
+  if (symmetric && (k & 1)) {
+    // mirrored entries that receive no hit must read -1
+    LIDAL_HIP(hipMemsetAsync(nbr_out + (int64_t)(k / 2 + 1) * n_out, 0xFF, 4 * n_out * (k / 2), s));
+    kmap_probe_sym_kernel<<<(int)nblocks, kBlock, 0, s>>>(t, (const int4*)out_coords, n_out, offsets,
+                                                          k, nbr_out);
+    LIDAL_CHECK_LAUNCH("kmap_probe_sym");
+    kmap_count_kernel<<<dim3((unsigned)nblocks, (unsigned)k), kBlock, 0, s>>>(nbr_out, n_out, k,
+                                                                              counts, nblocks);
+    LIDAL_CHECK_LAUNCH("kmap_count");
+  } else {
+    kmap_probe_kernel<<<(int)nblocks, kBlock, k * sizeof(int), s>>>(
+        t, (const int4*)out_coords, n_out, offsets, k, nbr_out, counts, nblocks);
+    LIDAL_CHECK_LAUNCH("kmap_probe");
+  }
   scan_counts_kernel<<<1, 1024, 0, s>>>(counts, nblocks * k, offs);
   LIDAL_CHECK_LAUNCH("kmap_scan");
   kmap_compact_kernel<<<dim3((unsigned)nblocks, (unsigned)k), kBlock, 0, s>>>(

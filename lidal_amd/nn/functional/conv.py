@@ -114,11 +114,12 @@ def build_kernel_map(coords, in_stride, kernel_size, stride):
     koff = torch.empty(volume + 1, dtype=torch.int64, device=dev)
     ws_bytes = B.lib().lidal_kmap_workspace_bytes(n_out, volume)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    symmetric = (volume % 2 == 1) and all(s == 1 for s in stride)
     B.check(B.lib().lidal_kmap_build(B.ptr(table.buf), table.nbytes, B.ptr(out_coords), n_out,
-                                     B.ptr(offsets), volume, B.ptr(nbr_out), B.ptr(nbmaps),
+                                     B.ptr(offsets), volume, int(symmetric), B.ptr(nbr_out),
+                                     B.ptr(nbmaps),
                                      B.ptr(nbsizes), B.ptr(koff), B.ptr(ws), ws_bytes,
                                      B.stream()), 'kmap_build')
-    symmetric = (volume % 2 == 1) and all(s == 1 for s in stride)
     return KernelMap(nbmaps, nbsizes, koff, nbr_out, (n_in, n_out), volume, symmetric), out_coords
 
 

@@ -168,7 +168,6 @@ class ConvolutionFunction(Function):
         if cdtype not in (torch.float32, torch.bfloat16):
             cdtype = torch.float32
         x = feats.contiguous().to(cdtype)
-        n_in, n_out = kmap.sizes
         order = kmap.order_in if transposed else kmap.order_out
         out = _apply(x, _pack_weight(weight, cdtype), order, 0)
         ctx.kmap = kmap
@@ -186,7 +185,9 @@ class ConvolutionFunction(Function):
         if ctx.needs_input_grad[0]:
             # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci, reduction over co, and
             # weight [K, ci, co] already has the reduction dim contiguous.
-            wk = weight.detach().contiguous().to(x.dtype)
+            wk = weight.detach().contiguous()
+            if wk.dtype != x.dtype:
+                wk = wk.to(x.dtype)
             if not transposed:
                 if kmap.symmetric:
                     grad_in = _apply(g, wk, kmap.order_out, 1)
@@ -204,7 +205,7 @@ class ConvolutionFunction(Function):
                                              B.ptr(kmap.koff), 1 if transposed else 0, B.ptr(gw),
                                              B.ptr(partial), splits, chunk, k, ci, co,
                                              B.dtype_code(x.dtype), B.stream()), 'conv_wgrad')
-            grad_w = gw.to(weight.dtype)
+            grad_w = gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
         return grad_in, grad_w, None, None
 
 

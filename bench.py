@@ -67,9 +67,15 @@ def dist_setup(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('BENCH_SINGLE_DEVICE'):       # test plumbing: N ranks on one GPU (gloo)
+        local = 0
     torch.cuda.set_device(local)
     if world > 1 or os.environ.get('BENCH_FORCE_DDP'):
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, 'launch with --nproc-per-node == --gpus (got %d vs %d)' % (world, args.gpus)
     return world, rank, torch.device('cuda', local)
 

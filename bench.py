@@ -224,7 +224,7 @@ def bench_scoring(args, model, world, rank, dev):
     """prob_inference (8 augmented views per frame) + inter-frame scoring, frames sharded over
     ranks in the reference's contiguous blocks, probabilities/coords exchanged by one all-gather."""
     from lidal_amd import synth
-    from lidal_amd.score import FrameBank, gather_frames, infer_frame, interframe
+    from lidal_amd.score import interframe, score_sequence
     per = args.score_frames
     total = per * world
     frames = synth.make_sequence(per, n_points=args.points, seed=7122, start=rank * per, total=total)
@@ -239,23 +239,11 @@ def bench_scoring(args, model, world, rank, dev):
                            'world': torch.from_numpy(f['world']).to(dev), 'sv_ptr': ptr, 'sv_idx': idx})
     model.eval()
     autocast = args.dtype == 'bf16'
+    log('scoring inputs resident')
 
     def run():
-        probs = {}
-        for s, d in enumerate(dev_frames):
-            prob, _ = infer_frame(model, d['coords'], d['feats'], d['inverse'], 8, autocast=autocast)
-            probs[rank * per + s] = prob
-        worlds = {rank * per + s: d['world'] for s, d in enumerate(dev_frames)}
-        all_prob = gather_frames(probs, total)
-        all_world = gather_frames(worlds, total)
-        bank = FrameBank(0.1)
-        for w, p in zip(all_world, all_prob):
-            bank.add(w, p)
-        out = []
-        for s, d in enumerate(dev_frames):
-            out.append(interframe.score_frame(bank, rank * per + s, d['sv_ptr'], d['sv_idx'], args.nei))
-        return out
-    log('scoring inputs resident')
+        return score_sequence(model, dev_frames, rank * per, total, nei_num=args.nei, dis_thresh=0.1,
+                              inf_reps=8, autocast=autocast)
     run()                                   # warm-up
     log('scoring warm-up done')
     barrier_sync(world)

@@ -196,6 +196,23 @@ int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n, int c, con
 int lidal_colsum(const void* x, int dtype, int64_t n, int c, float* out, void* ws,
                  int64_t ws_bytes, void* stream);
 
+/* ---- small fused row-wise ops of the training step --------------------------------------------- */
+/* relu(a + b) of the residual blocks (network/utils.py:171), forward and backward
+ * (gin = g where y > 0; both summands receive it).  numel a multiple of 4 (f32) / 8 (bf16). */
+int lidal_add_relu_fwd(const void* a, const void* b, void* y, int64_t numel, int dtype,
+                       void* stream);
+int lidal_add_relu_bwd(const void* y, const void* g, void* gin, int64_t numel, int dtype,
+                       void* stream);
+/* replaces torch.nn.functional.cross_entropy(logits, labels, ignore_index, reduction='mean')
+ * (train.py:136): out2 f32 [2] = {mean loss over non-ignored rows, number of such rows};
+ * backward: dlogits = (softmax - onehot) * grad_scale[0] / out2[1], zero on ignored rows. */
+int64_t lidal_ce_workspace_bytes(int64_t n);
+int lidal_ce_fwd(const void* logits, int dtype, const int64_t* labels, int64_t n, int c,
+                 int64_t ignore_index, float* out2, void* ws, int64_t ws_bytes, void* stream);
+int lidal_ce_bwd(const void* logits, int dtype, const int64_t* labels, int64_t n, int c,
+                 int64_t ignore_index, const float* fwd_out2, const float* grad_scale,
+                 void* dlogits, void* stream);
+
 /* ---- probability inference post-processing ------------------------------------------------- */
 /* replaces score/prob_inference.py:100-113: logits f32 [nv, c] of `reps` collated views,
  * inverse i64 [reps*p] (voxel row of every point in every view) -> prob f32 [p,c] = mean over

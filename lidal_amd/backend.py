@@ -61,6 +61,11 @@ SIGNATURES = {
     'lidal_bn_bwd': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                             _i64, _vp]),
     'lidal_colsum': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp]),
+    'lidal_add_relu_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    'lidal_add_relu_bwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    'lidal_ce_workspace_bytes': (_i64, [_i64]),
+    'lidal_ce_fwd': (_i32, [_vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp]),
+    'lidal_ce_bwd': (_i32, [_vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     'lidal_view_mean_softmax': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'lidal_confusion_accumulate': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'lidal_register_points': (_i32, [_vp, _i64, _vp, _vp, _vp]),

@@ -6,7 +6,9 @@ match the reference's so its checkpoints load with strict=True (train.py:66, pro
 """
 from torch import nn
 
+from .. import SparseTensor
 from .. import nn as spnn
+from ..nn.functional.fused import add_relu
 
 
 def _conv_bn(inc, outc, ks, stride=1, transposed=False):
@@ -59,4 +61,7 @@ class ResidualBlock(nn.Module):
         self.relu = spnn.ReLU(True)
 
     def forward(self, x):
-        return self.relu(self.net(x) + self.downsample(x))
+        a, b = self.net(x), self.downsample(x)
+        out = SparseTensor(add_relu(a.F, b.F), a.C, a.s)       # == self.relu(a + b), one pass
+        out.cmaps, out.kmaps = a.cmaps, a.kmaps
+        return out

@@ -4,10 +4,12 @@ from .conv import KernelMap, build_kernel_map, conv3d
 from .count import spcount
 from .devoxelize import calc_ti_weights, spdevoxelize, ti_weights_and_index
 from .downsample import spdownsample, unique_sorted
+from .fused import add_relu, cross_entropy
 from .hash import sphash
 from .query import HashTable, sphashquery
 from .voxelize import spvoxelize
 
 __all__ = ['sphash', 'sphashquery', 'HashTable', 'spcount', 'spvoxelize', 'spdevoxelize',
            'calc_ti_weights', 'ti_weights_and_index', 'spdownsample', 'unique_sorted', 'conv3d',
+           'add_relu', 'cross_entropy',
            'KernelMap', 'build_kernel_map']

@@ -4,6 +4,7 @@ zero_grad -> model(SparseTensor) -> cross_entropy(ignore_index=255, mean) -> bac
 import torch
 
 from . import SparseTensor
+from .nn.functional.fused import cross_entropy
 
 __all__ = ['train_step', 'forward_backward']
 
@@ -11,8 +12,7 @@ __all__ = ['train_step', 'forward_backward']
 def forward_backward(model, feats_v_b, coords_v_b, labels_v_b, autocast=False):
     with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
         logits, _ = model(SparseTensor(feats_v_b, coords_v_b))
-    loss = torch.nn.functional.cross_entropy(logits.float(), labels_v_b, ignore_index=255,
-                                             reduction='mean')
+    loss = cross_entropy(logits, labels_v_b, ignore_index=255)
     loss.backward()
     return loss, logits
 

@@ -414,3 +414,39 @@ def test_dense_rows_matmul_and_linear(dtype):
     assert _relerr(lin.weight.grad.cpu(), ref.weight.grad) < 1e-4
     assert _relerr(lin.bias.grad.cpu(), ref.bias.grad) < 1e-4
     assert _relerr(xl.grad.cpu(), xl_r.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_add_relu_and_cross_entropy_match_torch(dtype):
+    from lidal_amd.nn.functional.fused import add_relu, cross_entropy
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(30001, 96, generator=g).to(dtype)
+    b = torch.randn(30001, 96, generator=g).to(dtype)
+    go = torch.randn(30001, 96, generator=g).to(dtype)
+    ar, br = a.float().clone().requires_grad_(True), b.float().clone().requires_grad_(True)
+    yr = torch.relu(ar + br)
+    yr.backward(go.float())
+    ag, bg = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yg = add_relu(ag, bg)
+    yg.backward(go.to(DEV))
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert _relerr(yg.float().cpu(), yr.detach()) < tol
+    assert torch.equal(ag.grad, bg.grad)
+    if dtype == torch.float32:
+        assert torch.equal(ag.grad.cpu(), ar.grad)
+    else:       # the bf16 sum can round a tiny positive to exactly representable values only
+        assert ((ag.grad.float().cpu() != 0) == (ar.grad != 0)).float().mean() > 0.999
+    # cross-entropy, ignore_index 255, mean over the labelled rows
+    n, c = 50000, 19
+    logits = (torch.randn(n, c, generator=g) * 3).to(dtype)
+    labels = torch.randint(0, c, (n,), generator=g)
+    labels[torch.rand(n, generator=g) < 0.1] = 255
+    lr = logits.double().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, labels, ignore_index=255, reduction='mean')
+    (ref * 1.7).backward()
+    lg = logits.to(DEV).requires_grad_(True)
+    loss = cross_entropy(lg, labels.to(DEV), 255)
+    (loss * 1.7).backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item()) + (0 if dtype == torch.float32 else 1e-6)
+    assert _relerr(lg.grad.float().cpu(), lr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert (lg.grad[labels.to(DEV) == 255] == 0).all()

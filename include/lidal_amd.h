@@ -118,12 +118,12 @@ int lidal_count(const int32_t* idx, int64_t n, int32_t* out, int64_t m, void* st
  * network/utils.py:22,25,56).  out[idx[i]] += feat[i] / counts[idx[i]]; f32 only. */
 int lidal_voxelize_fwd(const float* feat, const int32_t* idx, const int32_t* counts, float* out,
                        int64_t n, int64_t m, int c, void* stream);
-int lidal_voxelize_bwd(const float* gout, const int32_t* idx, const int32_t* counts, float* gin,
-                       int64_t n, int64_t m, int c, void* stream);
+int lidal_voxelize_bwd(const void* gout, const int32_t* idx, const int32_t* counts, void* gin,
+                       int64_t n, int64_t m, int c, int dtype, void* stream);
 /* replaces backend.devoxelize_forward_cuda / devoxelize_backward_cuda (F.spdevoxelize:
  * network/utils.py:83,95).  idx i32 [n,8], w f32 [n,8]; out[i] = sum_k w[i,k] feat[idx[i,k]]. */
-int lidal_devoxelize_fwd(const float* feat, const int32_t* idx, const float* w, float* out,
-                         int64_t n, int64_t m, int c, void* stream);
+int lidal_devoxelize_fwd(const void* feat, const int32_t* idx, const float* w, void* out,
+                         int64_t n, int64_t m, int c, int dtype, void* stream);
 int lidal_devoxelize_bwd(const float* gout, const int32_t* idx, const float* w, float* gin,
                          int64_t n, int64_t m, int c, void* stream);
 /* Atomic-free, bitwise reproducible forms of the two scatter sums above.  A point->voxel index
@@ -133,10 +133,12 @@ int lidal_devoxelize_bwd(const float* gout, const int32_t* idx, const float* w, 
 int64_t lidal_invlist_workspace_bytes(int64_t n_entries);
 int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n_entries, int64_t m,
                         int32_t* order, int64_t* seg_ptr, void* ws, int64_t ws_bytes, void* stream);
-int lidal_voxelize_fwd_sorted(const float* feat, const int32_t* order, const int64_t* seg_ptr,
-                              const int32_t* counts, float* out, int64_t m, int c, void* stream);
-int lidal_devoxelize_bwd_sorted(const float* gout, const int32_t* order, const int64_t* seg_ptr,
-                                const float* w, float* gin, int64_t m, int c, void* stream);
+int lidal_voxelize_fwd_sorted(const void* feat, const int32_t* order, const int64_t* seg_ptr,
+                              const int32_t* counts, void* out, int64_t m, int c, int dtype,
+                              void* stream);
+int lidal_devoxelize_bwd_sorted(const void* gout, const int32_t* order, const int64_t* seg_ptr,
+                                const float* w, void* gin, int64_t m, int c, int dtype,
+                                void* stream);
 /* replaces F.calc_ti_weights (torchsparse/nn/functional/devoxelize.py; network/utils.py:77):
  * coords f32 [n, cstride>=3], idx i64 [8,n] -> w f32 [n,8] and idx32 i32 [n,8] (both already
  * transposed as network/utils.py:78-79 does). */

@@ -13,6 +13,21 @@ using namespace lidal;
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+// 4 consecutive row elements as f32 (16-byte access for f32 rows, 8-byte for bf16 rows)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {
+  bf16x4_t o;
+  o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+  *reinterpret_cast<bf16x4_t*>(p) = o;
+}
+
 __global__ void __launch_bounds__(256) count_kernel(const int* __restrict__ idx, int64_t n,
                                                     int* __restrict__ out, int64_t m) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,11 +65,11 @@ __global__ void __launch_bounds__(256) voxelize_fwd_kernel(const float* __restri
 }
 
 // gin[i] = gout[idx[i]] / counts[idx[i]]
-template <int VEC>
-__global__ void __launch_bounds__(256) voxelize_bwd_kernel(const float* __restrict__ gout,
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) voxelize_bwd_kernel(const T* __restrict__ gout,
                                                            const int* __restrict__ idx,
                                                            const int* __restrict__ counts,
-                                                           float* __restrict__ gin, int64_t n,
+                                                           T* __restrict__ gin, int64_t n,
                                                            int64_t m, int c) {
   const int cv = c / VEC;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,24 +77,25 @@ __global__ void __launch_bounds__(256) voxelize_bwd_kernel(const float* __restri
   int64_t i = t / cv;
   int j = (int)(t - i * cv) * VEC;
   int pos = idx[i];
-  float* dst = gin + i * c + j;
-  if (pos < 0 || pos >= m || counts[pos] == 0) {
+  T* dst = gin + i * c + j;
+  const bool dead = pos < 0 || pos >= m || counts[pos] == 0;
+  const float div = dead ? 1.f : (float)counts[pos];
+  const T* src = gout + (int64_t)(dead ? 0 : pos) * c + j;
+  if constexpr (VEC == 4) {
+    float4 x = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(src);
+    st4(dst, make_float4(x.x / div, x.y / div, x.z / div, x.w / div));
+  } else {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) dst[v] = 0.f;
-    return;
+    for (int v = 0; v < VEC; ++v) dst[v] = dead ? (T)0.f : (T)((float)src[v] / div);
   }
-  float div = (float)counts[pos];
-  const float* src = gout + (int64_t)pos * c + j;
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) dst[v] = src[v] / div;
 }
 
 // out[i] = sum_k w[i,k] * feat[idx[i,k]]
-template <int VEC>
-__global__ void __launch_bounds__(256) devoxelize_fwd_kernel(const float* __restrict__ feat,
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) devoxelize_fwd_kernel(const T* __restrict__ feat,
                                                              const int* __restrict__ idx,
                                                              const float* __restrict__ w,
-                                                             float* __restrict__ out, int64_t n,
+                                                             T* __restrict__ out, int64_t n,
                                                              int64_t m, int c) {
   const int cv = c / VEC;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,13 +111,22 @@ __global__ void __launch_bounds__(256) devoxelize_fwd_kernel(const float* __rest
     if (pos < 0 || pos >= m) continue;
     float wk = w[i * 8 + k];
     if (wk == 0.f) continue;        // exact zeros: points on a cell face/corner (all of stride 1)
-    const float* src = feat + (int64_t)pos * c + j;
+    const T* src = feat + (int64_t)pos * c + j;
+    if constexpr (VEC == 4) {
+      float4 x = ld4(src);
+      acc[0] += wk * x.x; acc[1] += wk * x.y; acc[2] += wk * x.z; acc[3] += wk * x.w;
+    } else {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] += wk * src[v];
+      for (int v = 0; v < VEC; ++v) acc[v] += wk * (float)src[v];
+    }
   }
-  float* dst = out + i * c + j;
+  T* dst = out + i * c + j;
+  if constexpr (VEC == 4) {
+    st4(dst, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  } else {
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) dst[v] = acc[v];
+    for (int v = 0; v < VEC; ++v) dst[v] = (T)acc[v];
+  }
 }
 
 // gin[idx[i,k]] += w[i,k] * gout[i]    (gin pre-zeroed)
@@ -214,13 +239,13 @@ __global__ void __launch_bounds__(256) inv_segptr_kernel(const unsigned* __restr
 //   devox bwd:  row = e >> 3, scale = w[e]
 // One wave per voxel; LPR lanes cover a row with float4 each, the 64/LPR lane groups take list
 // elements round-robin (4 independent row loads in flight per lane), fixed xor-tree at the end.
-template <int LPR, bool DEVOX>
-__global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restrict__ src,
+template <typename T, int LPR, bool DEVOX>
+__global__ void __launch_bounds__(256) segment_sum_kernel(const T* __restrict__ src,
                                                           const int* __restrict__ order,
                                                           const int64_t* __restrict__ seg_ptr,
                                                           const float* __restrict__ w,
                                                           const int* __restrict__ counts,
-                                                          float* __restrict__ out, int64_t m,
+                                                          T* __restrict__ out, int64_t m,
                                                           int c) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
@@ -241,7 +266,7 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restric
     for (int u = 0; u < 4; ++u) {
       const int64_t row = DEVOX ? (e[u] >> 3) : e[u];
       sc[u] = DEVOX ? w[e[u]] : 1.f;
-      x[u] = act ? *reinterpret_cast<const float4*>(src + row * c + 4 * l) : make_float4(0, 0, 0, 0);
+      x[u] = act ? ld4(src + row * c + 4 * l) : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -253,7 +278,7 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restric
     const int e = order[j];
     const int64_t row = DEVOX ? (e >> 3) : e;
     const float sc = DEVOX ? w[e] : 1.f;
-    float4 x = act ? *reinterpret_cast<const float4*>(src + row * c + 4 * l) : make_float4(0, 0, 0, 0);
+    float4 x = act ? ld4(src + row * c + 4 * l) : make_float4(0, 0, 0, 0);
     if (DEVOX) { acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w; }
     else { acc.x += x.x / inv; acc.y += x.y / inv; acc.z += x.z / inv; acc.w += x.w / inv; }
   }
@@ -262,7 +287,7 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restric
     acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
     acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
   }
-  if (grp == 0 && act) *reinterpret_cast<float4*>(out + v * c + 4 * l) = acc;
+  if (grp == 0 && act) st4(out + v * c + 4 * l, acc);
 }
 
 size_t inv_sort_tmp_bytes(int64_t n) {
@@ -273,18 +298,18 @@ size_t inv_sort_tmp_bytes(int64_t n) {
   return tmp;
 }
 
-template <bool DEVOX>
-int launch_segment_sum(const float* src, const int* order, const int64_t* seg_ptr, const float* w,
-                       const int* counts, float* out, int64_t m, int c, hipStream_t s) {
+template <typename T, bool DEVOX>
+int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, const float* w,
+                       const int* counts, T* out, int64_t m, int c, hipStream_t s) {
   unsigned grid = (unsigned)cdiv(m, 4);
   if (c <= 32)
-    segment_sum_kernel<8, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    segment_sum_kernel<T, 8, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
   else if (c <= 64)
-    segment_sum_kernel<16, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    segment_sum_kernel<T, 16, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
   else if (c <= 128)
-    segment_sum_kernel<32, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    segment_sum_kernel<T, 32, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
   else
-    segment_sum_kernel<64, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    segment_sum_kernel<T, 64, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
   LIDAL_CHECK_LAUNCH("segment_sum");
   return 0;
 }
@@ -299,6 +324,17 @@ int launch_segment_sum(const float* src, const int* order, const int64_t* seg_pt
     } else {                                                                                 \
       int64_t t__ = (total_rows) * (c);                                                      \
       kernel<1><<<(unsigned)cdiv(t__, 256), 256, 0, s>>>(__VA_ARGS__);                       \
+    }                                                                                        \
+  } while (0)
+
+#define DISPATCH_TVEC(kernel, T, c, total_rows, ...)                                         \
+  do {                                                                                       \
+    if ((c) % 4 == 0) {                                                                      \
+      int64_t t__ = (total_rows) * ((c) / 4);                                                \
+      kernel<T, 4><<<(unsigned)cdiv(t__, 256), 256, 0, s>>>(__VA_ARGS__);                    \
+    } else {                                                                                 \
+      int64_t t__ = (total_rows) * (c);                                                      \
+      kernel<T, 1><<<(unsigned)cdiv(t__, 256), 256, 0, s>>>(__VA_ARGS__);                    \
     }                                                                                        \
   } while (0)
 
@@ -321,20 +357,29 @@ extern "C" int lidal_voxelize_fwd(const float* feat, const int32_t* idx, const i
   return 0;
 }
 
-extern "C" int lidal_voxelize_bwd(const float* gout, const int32_t* idx, const int32_t* counts,
-                                  float* gin, int64_t n, int64_t m, int c, void* stream) {
+extern "C" int lidal_voxelize_bwd(const void* gout, const int32_t* idx, const int32_t* counts,
+                                  void* gin, int64_t n, int64_t m, int c, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n == 0 || c == 0) return 0;
-  DISPATCH_VEC(voxelize_bwd_kernel, c, n, gout, idx, counts, gin, n, m, c);
+  if (dtype == LIDAL_F32)
+    DISPATCH_TVEC(voxelize_bwd_kernel, float, c, n, (const float*)gout, idx, counts, (float*)gin, n, m, c);
+  else if (dtype == LIDAL_BF16)
+    DISPATCH_TVEC(voxelize_bwd_kernel, __bf16, c, n, (const __bf16*)gout, idx, counts, (__bf16*)gin, n, m, c);
+  else { set_error("voxelize_bwd: bad dtype %d", dtype); return 2; }
   LIDAL_CHECK_LAUNCH("lidal_voxelize_bwd");
   return 0;
 }
 
-extern "C" int lidal_devoxelize_fwd(const float* feat, const int32_t* idx, const float* w,
-                                    float* out, int64_t n, int64_t m, int c, void* stream) {
+extern "C" int lidal_devoxelize_fwd(const void* feat, const int32_t* idx, const float* w,
+                                    void* out, int64_t n, int64_t m, int c, int dtype,
+                                    void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n == 0 || c == 0) return 0;
-  DISPATCH_VEC(devoxelize_fwd_kernel, c, n, feat, idx, w, out, n, m, c);
+  if (dtype == LIDAL_F32)
+    DISPATCH_TVEC(devoxelize_fwd_kernel, float, c, n, (const float*)feat, idx, w, (float*)out, n, m, c);
+  else if (dtype == LIDAL_BF16)
+    DISPATCH_TVEC(devoxelize_fwd_kernel, __bf16, c, n, (const __bf16*)feat, idx, w, (__bf16*)out, n, m, c);
+  else { set_error("devoxelize_fwd: bad dtype %d", dtype); return 2; }
   LIDAL_CHECK_LAUNCH("lidal_devoxelize_fwd");
   return 0;
 }
@@ -390,19 +435,32 @@ extern "C" int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n
   return 0;
 }
 
-extern "C" int lidal_voxelize_fwd_sorted(const float* feat, const int32_t* order,
-                                         const int64_t* seg_ptr, const int32_t* counts, float* out,
-                                         int64_t m, int c, void* stream) {
+extern "C" int lidal_voxelize_fwd_sorted(const void* feat, const int32_t* order,
+                                         const int64_t* seg_ptr, const int32_t* counts, void* out,
+                                         int64_t m, int c, int dtype, void* stream) {
   if (m == 0 || c == 0) return 0;
   LIDAL_REQUIRE(c % 4 == 0, "voxelize_fwd_sorted: channels must be a multiple of 4");
-  return launch_segment_sum<false>(feat, order, seg_ptr, nullptr, counts, out, m, c,
-                                   (hipStream_t)stream);
+  if (dtype == LIDAL_F32)
+    return launch_segment_sum<float, false>((const float*)feat, order, seg_ptr, nullptr, counts,
+                                            (float*)out, m, c, (hipStream_t)stream);
+  if (dtype == LIDAL_BF16)
+    return launch_segment_sum<__bf16, false>((const __bf16*)feat, order, seg_ptr, nullptr, counts,
+                                             (__bf16*)out, m, c, (hipStream_t)stream);
+  set_error("voxelize_fwd_sorted: bad dtype %d", dtype);
+  return 2;
 }
 
-extern "C" int lidal_devoxelize_bwd_sorted(const float* gout, const int32_t* order,
-                                           const int64_t* seg_ptr, const float* w, float* gin,
-                                           int64_t m, int c, void* stream) {
+extern "C" int lidal_devoxelize_bwd_sorted(const void* gout, const int32_t* order,
+                                           const int64_t* seg_ptr, const float* w, void* gin,
+                                           int64_t m, int c, int dtype, void* stream) {
   if (m == 0 || c == 0) return 0;
   LIDAL_REQUIRE(c % 4 == 0, "devoxelize_bwd_sorted: channels must be a multiple of 4");
-  return launch_segment_sum<true>(gout, order, seg_ptr, w, nullptr, gin, m, c, (hipStream_t)stream);
+  if (dtype == LIDAL_F32)
+    return launch_segment_sum<float, true>((const float*)gout, order, seg_ptr, w, nullptr,
+                                           (float*)gin, m, c, (hipStream_t)stream);
+  if (dtype == LIDAL_BF16)
+    return launch_segment_sum<__bf16, true>((const __bf16*)gout, order, seg_ptr, w, nullptr,
+                                            (__bf16*)gin, m, c, (hipStream_t)stream);
+  set_error("devoxelize_bwd_sorted: bad dtype %d", dtype);
+  return 2;
 }

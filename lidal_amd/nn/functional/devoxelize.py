@@ -37,30 +37,36 @@ class DevoxelizeFunction(Function):
     def forward(ctx, feats, coords, weights):
         B.require_gpu(feats, coords, weights)
         in_dtype = feats.dtype
-        feats = feats.contiguous().float()
+        # bf16 rows travel as bf16 (f32 accumulation inside the kernel); others on an f32 copy
+        native = in_dtype == torch.bfloat16
+        feats = feats.contiguous() if native else feats.contiguous().float()
         if coords.dtype != torch.int or not coords.is_contiguous():
             coords = coords.contiguous().int()
         if weights.dtype != torch.float32 or not weights.is_contiguous():
             weights = weights.contiguous().float()
         m, c = feats.shape
         n = coords.shape[0]
-        out = torch.empty((n, c), dtype=torch.float32, device=feats.device)
+        out = torch.empty((n, c), dtype=feats.dtype, device=feats.device)
         B.check(B.lib().lidal_devoxelize_fwd(B.ptr(feats), B.ptr(coords), B.ptr(weights),
-                                             B.ptr(out), n, m, c, B.stream()), 'devoxelize_fwd')
+                                             B.ptr(out), n, m, c, B.dtype_code(feats.dtype),
+                                             B.stream()), 'devoxelize_fwd')
         ctx.for_backwards = (coords, weights, m, in_dtype)
         return out.to(in_dtype)
 
     @staticmethod
     def backward(ctx, grad_output):
         coords, weights, m, in_dtype = ctx.for_backwards
-        g = grad_output.contiguous().float()
+        native = (in_dtype == torch.bfloat16 and grad_output.dtype == torch.bfloat16
+                  and grad_output.shape[1] % 4 == 0)
+        g = grad_output.contiguous() if native else grad_output.contiguous().float()
         n, c = g.shape
-        gin = torch.empty((m, c), dtype=torch.float32, device=g.device)
+        gin = torch.empty((m, c), dtype=g.dtype, device=g.device)
         if c % 4 == 0:      # ordered per-voxel gather: no atomics, reproducible
             order, seg_ptr = inverse_lists(coords, m, weights)
             B.check(B.lib().lidal_devoxelize_bwd_sorted(B.ptr(g), B.ptr(order), B.ptr(seg_ptr),
                                                         B.ptr(weights), B.ptr(gin), m, c,
-                                                        B.stream()), 'devoxelize_bwd_sorted')
+                                                        B.dtype_code(g.dtype), B.stream()),
+                    'devoxelize_bwd_sorted')
         else:
             B.check(B.lib().lidal_devoxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(weights),
                                                  B.ptr(gin), n, m, c, B.stream()), 'devoxelize_bwd')

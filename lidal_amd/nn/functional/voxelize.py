@@ -14,7 +14,10 @@ class VoxelizeFunction(Function):
     def forward(ctx, feats, coords, counts):
         B.require_gpu(feats, coords, counts)
         in_dtype = feats.dtype
-        feats = feats.contiguous().float()
+        # bf16 rows are read and written as bf16 (f32 accumulation inside the kernel) when the
+        # ordered path applies; everything else computes on an f32 copy
+        native = in_dtype == torch.bfloat16 and feats.shape[1] % 4 == 0
+        feats = feats.contiguous() if native else feats.contiguous().float()
         idx32 = getattr(coords, '_lidal_i32', None)        # int32 view cached on the index tensor
         if idx32 is None:
             idx32 = coords.contiguous().int()
@@ -22,11 +25,12 @@ class VoxelizeFunction(Function):
         counts = counts.contiguous().int()
         n, c = feats.shape
         m = counts.shape[0]
-        out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
+        out = torch.empty((m, c), dtype=feats.dtype, device=feats.device)
         if c % 4 == 0:      # ordered per-voxel gather: no atomics, reproducible
             order, seg_ptr = inverse_lists(idx32, m)
             B.check(B.lib().lidal_voxelize_fwd_sorted(B.ptr(feats), B.ptr(order), B.ptr(seg_ptr),
-                                                      B.ptr(counts), B.ptr(out), m, c, B.stream()),
+                                                      B.ptr(counts), B.ptr(out), m, c,
+                                                      B.dtype_code(feats.dtype), B.stream()),
                     'voxelize_fwd_sorted')
         else:
             B.check(B.lib().lidal_voxelize_fwd(B.ptr(feats), B.ptr(idx32), B.ptr(counts),
@@ -38,11 +42,13 @@ class VoxelizeFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         coords, counts, n, in_dtype = ctx.for_backwards
-        g = grad_output.contiguous().float()
+        native = in_dtype == torch.bfloat16 and grad_output.dtype == torch.bfloat16
+        g = grad_output.contiguous() if native else grad_output.contiguous().float()
         m, c = g.shape
-        gin = torch.empty((n, c), dtype=torch.float32, device=g.device)
+        gin = torch.empty((n, c), dtype=g.dtype, device=g.device)
         B.check(B.lib().lidal_voxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(counts), B.ptr(gin),
-                                           n, m, c, B.stream()), 'voxelize_bwd')
+                                           n, m, c, B.dtype_code(g.dtype), B.stream()),
+                'voxelize_bwd')
         return gin.to(in_dtype), None, None
 
 

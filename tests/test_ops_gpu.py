@@ -450,3 +450,37 @@ def test_add_relu_and_cross_entropy_match_torch(dtype):
     assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item()) + (0 if dtype == torch.float32 else 1e-6)
     assert _relerr(lg.grad.float().cpu(), lr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
     assert (lg.grad[labels.to(DEV) == 255] == 0).all()
+
+
+def test_voxel_exchange_bf16_rows_equal_f32_compute_rounded():
+    """bf16 feature rows go through the point<->voxel kernels as bf16 with f32 accumulation: the
+    results must equal the f32 kernels run on the widened rows, rounded once at the end."""
+    F = _F()
+    g = torch.Generator().manual_seed(8)
+    n, m, c = 40000, 9000, 32
+    idx = torch.randint(0, m, (n,), generator=g)
+    counts = F.spcount(idx.int().to(DEV), m)
+    x = torch.randn(n, c, generator=g).bfloat16().to(DEV)
+    gv = torch.randn(m, c, generator=g).bfloat16().to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = F.spvoxelize(xa, idx.to(DEV), counts)
+    ya.backward(gv)
+    xb = x.float().requires_grad_(True)
+    yb = F.spvoxelize(xb, idx.to(DEV), counts)
+    yb.backward(gv.float())
+    assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb.bfloat16())
+    assert torch.equal(xa.grad, xb.grad.bfloat16())
+    # devoxelize
+    idx8 = torch.randint(-1, m, (n, 8), generator=g).int().to(DEV)
+    w8 = torch.rand(n, 8, generator=g).to(DEV)
+    w8[idx8 < 0] = 0
+    f = torch.randn(m, c, generator=g).bfloat16().to(DEV)
+    gp = torch.randn(n, c, generator=g).bfloat16().to(DEV)
+    fa = f.clone().requires_grad_(True)
+    pa = F.spdevoxelize(fa, idx8, w8)
+    pa.backward(gp)
+    fb = f.float().requires_grad_(True)
+    pb = F.spdevoxelize(fb, idx8, w8)
+    pb.backward(gp.float())
+    assert pa.dtype == torch.bfloat16 and torch.equal(pa, pb.bfloat16())
+    assert torch.equal(fa.grad, fb.grad.bfloat16())

@@ -146,9 +146,11 @@ int lidal_ti_weights(const float* coords, int cstride, const int64_t* idx, int64
                      float* w, int32_t* idx32, void* stream);
 
 /* ---- sparse convolution ---------------------------------------------------------------------- */
-/* Weight re-layout (+ optional cast): W [k][ci][co] -> Wt [k][co][ci]. */
-int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int wt_dtype, int k, int ci,
-                           int co, void* stream);
+/* Weight re-layout (+ optional cast): W [k][ci][co] -> Wt [k][co][ci] in wt_dtype; when wc is
+ * not NULL it also receives W cast to wt_dtype in the ORIGINAL layout (the data-gradient operand
+ * of lidal_conv_apply), from the same read. */
+int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void* wc, int wt_dtype, int k,
+                           int ci, int co, void* stream);
 /* replaces backend.convolution_forward_cuda and the data-gradient half of
  * convolution_backward_cuda (every spnn.Conv3d.forward/backward, 49 per model pass).
  * Output-stationary fused gather-GEMM with register accumulators:

@@ -48,7 +48,7 @@ SIGNATURES = {
     'lidal_voxelize_fwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'lidal_devoxelize_bwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'lidal_ti_weights': (_i32, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp]),
-    'lidal_conv_weight_pack': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'lidal_conv_weight_pack': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'lidal_kmap_order_workspace_bytes': (_i64, [_i64]),
     'lidal_kmap_order': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -126,3 +126,16 @@ def dtype_code(dt):
     if dt == torch.bfloat16:
         return BF16
     raise TypeError('lidal_amd: unsupported feature dtype %s (float32 / bfloat16 only)' % dt)
+
+
+def wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class NoGradCtx:
+    """Stand-in for an autograd ctx: lets a Function's forward body run directly (no autograd node,
+    nothing kept alive) when no input wants a gradient, i.e. at inference."""
+    needs_input_grad = (False,) * 16
+
+    def save_for_backward(self, *tensors):
+        pass

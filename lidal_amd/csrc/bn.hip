@@ -13,7 +13,8 @@ using namespace lidal;
 namespace {
 
 constexpr int NT = 256;
-constexpr int ROWS_PER_WG = 512;       // rows per workgroup (one statistics partial each)
+constexpr int MAX_ROWS_PER_WG = 512;   // rows per workgroup (one statistics partial each) ...
+constexpr int MIN_ROWS_PER_WG = 32;    // ... shrunk on short matrices so a launch still fills the chip
 
 template <typename T> struct IO;
 template <> struct IO<float> {
@@ -51,7 +52,7 @@ __device__ __forceinline__ void chan_merge(float& na, float& ma, float& m2a, flo
 
 // Thread layout shared by every kernel below: thread t of a 256-thread workgroup owns channel
 // group cg = t % CG (VEC consecutive channels = one 16-byte access) and row lane rl = t / CG; the
-// workgroup owns rows [blockIdx.x * ROWS_PER_WG, ...) and row lane rl walks rows rl, rl+RPI, ...
+// workgroup owns rows [blockIdx.x * rpw, ...) and row lane rl walks rows rl, rl+RPI, ...
 // (RPI = 256 / CG rows per sweep).  Consecutive threads touch consecutive 16-byte pieces of a row,
 // then the next row: fully coalesced, and no per-element div/mod.
 
@@ -75,13 +76,13 @@ __device__ __forceinline__ void tree_sum_rows(float* v, int tid, int cg_n, int r
 // plain sums of (x-K) and (x-K)^2 can be added; only slabs are merged with Chan's formula.
 template <typename T>
 __global__ void __launch_bounds__(NT) bn_stats_partial_kernel(const T* __restrict__ x, int64_t n,
-                                                              int c, float* __restrict__ part) {
+                                                              int c, float* __restrict__ part, int rpw) {
   constexpr int VEC = IO<T>::VEC;
   extern __shared__ float sh[];                 // [2][NT][VEC]
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
-  const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
-  const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
   float shift[VEC], s1[VEC], s2[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { shift[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
@@ -178,13 +179,13 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
                                                       const float* __restrict__ istd_or_var,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
-                                                      int relu, T* __restrict__ y) {
+                                                      int relu, T* __restrict__ y, int rpw) {
   constexpr int VEC = IO<T>::VEC;
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
   if (rl >= rpi) return;
-  const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
-  const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
   float mu[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
@@ -225,13 +226,13 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
-                                                            int relu, float* __restrict__ part) {
+                                                            int relu, float* __restrict__ part, int rpw) {
   constexpr int VEC = IO<T>::VEC;
   extern __shared__ float sh[];                 // [2][NT][VEC]
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
-  const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
-  const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
   float a[VEC], b[VEC], mu[VEC], is[VEC], ga[VEC], be[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; ga[i] = 1.f; be[i] = 0.f; }
@@ -317,13 +318,13 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
                                                        const float* __restrict__ beta, int relu,
                                                        const float* __restrict__ sum_dy,
                                                        const float* __restrict__ sum_dy_xhat,
-                                                       T* __restrict__ dx) {
+                                                       T* __restrict__ dx, int rpw) {
   constexpr int VEC = IO<T>::VEC;
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
   if (rl >= rpi) return;
-  const int64_t r_beg = (int64_t)blockIdx.x * ROWS_PER_WG;
-  const int64_t r_end = (r_beg + ROWS_PER_WG < n) ? r_beg + ROWS_PER_WG : n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
   const float inv_n = 1.f / (float)n;
   float mu[VEC], is[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
 #pragma unroll
@@ -361,20 +362,35 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
         *reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), r);
 }
 
-static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, ROWS_PER_WG); }
+static inline int rows_per_wg(int64_t n) {
+  // reducing kernels pay a fixed LDS tree per workgroup: aim for >= 256 slabs (measured on the
+  // SPVCNN step: 256 beats both 1 slab size for all levels and >= 1024)
+  int rpw = MIN_ROWS_PER_WG;
+  while (rpw < MAX_ROWS_PER_WG && (int64_t)rpw * 256 < n) rpw <<= 1;
+  return rpw;
+}
+// the purely elementwise kernels (apply, dx) carry no per-workgroup reduction: finer slabs
+static inline int rows_per_wg_ew(int64_t n) {
+  int rpw = MIN_ROWS_PER_WG;
+  while (rpw < MAX_ROWS_PER_WG && (int64_t)rpw * 1024 < n) rpw <<= 1;
+  return rpw;
+}
+static inline int nslabs_ew(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg_ew(n)); }
+static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg(n)); }
 template <typename T>
 int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
                  float momentum, float* rm, float* rv, int relu, void* y, float* mean,
                  float* invstd, float* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
-  bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>((const T*)x, n, c, part);
+  bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>((const T*)x, n, c, part,
+                                                                           rows_per_wg(n));
   LIDAL_CHECK_LAUNCH("bn_stats_partial");
   bn_stats_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
                                                              invstd, rm, rv);
   LIDAL_CHECK_LAUNCH("bn_stats_final");
-  bn_apply_kernel<T, false><<<np, NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma, beta, eps,
-                                               relu, (T*)y);
+  bn_apply_kernel<T, false><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma,
+                                                        beta, eps, relu, (T*)y, rows_per_wg_ew(n));
   LIDAL_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -386,13 +402,14 @@ int bn_bwd(const void* x, const void* dy, int64_t n, int c, const float* gamma, 
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
   bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>(
-      (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part);
+      (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, rows_per_wg(n));
   LIDAL_CHECK_LAUNCH("bn_bwd_partial");
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gbeta, ggamma);
   LIDAL_CHECK_LAUNCH("bn_bwd_final");
   if (dx != nullptr) {
-    bn_bwd_dx_kernel<T><<<np, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd, gamma,
-                                           beta, relu, gbeta, ggamma, (T*)dx);
+    bn_bwd_dx_kernel<T><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd,
+                                                    gamma, beta, relu, gbeta, ggamma, (T*)dx,
+                                                    rows_per_wg_ew(n));
     LIDAL_CHECK_LAUNCH("bn_bwd_dx");
   }
   return 0;
@@ -437,11 +454,13 @@ extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, con
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
-    bn_apply_kernel<float, true><<<nparts_for(n), NT, 0, s>>>(
-        (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, (float*)y);
+    bn_apply_kernel<float, true><<<nslabs_ew(n), NT, 0, s>>>(
+        (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, (float*)y,
+        rows_per_wg_ew(n));
   else
-    bn_apply_kernel<__bf16, true><<<nparts_for(n), NT, 0, s>>>(
-        (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, (__bf16*)y);
+    bn_apply_kernel<__bf16, true><<<nslabs_ew(n), NT, 0, s>>>(
+        (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, (__bf16*)y,
+        rows_per_wg_ew(n));
   LIDAL_CHECK_LAUNCH("lidal_bn_eval_fwd");
   return 0;
 }
@@ -479,10 +498,12 @@ extern "C" int lidal_colsum(const void* x, int dtype, int64_t n, int c, float* o
   // mean = 0, invstd = (any finite): only the first sum is used
   if (dtype == LIDAL_F32)
     bn_bwd_partial_kernel<float><<<np, NT, 2 * NT * 4 * sizeof(float), s>>>(
-        (const float*)x, (const float*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part);
+        (const float*)x, (const float*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part,
+        rows_per_wg(n));
   else
     bn_bwd_partial_kernel<__bf16><<<np, NT, 2 * NT * 8 * sizeof(float), s>>>(
-        (const __bf16*)x, (const __bf16*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part);
+        (const __bf16*)x, (const __bf16*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part,
+        rows_per_wg(n));
   LIDAL_CHECK_LAUNCH("colsum_partial");
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, out, scratch);
   LIDAL_CHECK_LAUNCH("colsum_final");

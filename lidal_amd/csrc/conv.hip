@@ -391,12 +391,13 @@ int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, const in
 }
 
 // ------------------------------------------------------------------------------------------
-// weight pack: W[k][ci][co] -> Wt[k][co][ci] (+cast)
+// weight pack: W[k][ci][co] -> Wt[k][co][ci] (+cast); optionally also Wc[k][ci][co] = cast(W),
+// the operand of the data gradient, from the same read
 // ------------------------------------------------------------------------------------------
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) weight_pack_kernel(const TI* __restrict__ w,
-                                                          TO* __restrict__ wt, int K, int ci,
-                                                          int co) {
+                                                          TO* __restrict__ wt, TO* __restrict__ wc,
+                                                          int K, int ci, int co) {
   __shared__ float tile[32][33];
   const int k = blockIdx.z;
   const int i0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
@@ -405,7 +406,10 @@ __global__ void __launch_bounds__(256) weight_pack_kernel(const TI* __restrict__
   TO* dst = wt + (int64_t)k * ci * co;
   for (int r = ty; r < 32; r += 8) {
     int i = i0 + r, o = o0 + tx;
-    tile[r][tx] = (i < ci && o < co) ? DT<TI>::to_f32(src[(int64_t)i * co + o]) : 0.f;
+    const bool ok = i < ci && o < co;
+    const float v = ok ? DT<TI>::to_f32(src[(int64_t)i * co + o]) : 0.f;
+    tile[r][tx] = v;
+    if (wc != nullptr && ok) wc[(int64_t)k * ci * co + (int64_t)i * co + o] = DT<TO>::from_f32(v);
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
@@ -775,19 +779,19 @@ int dispatch_wgrad(const void* a, const void* b, const int* pairs, const int64_t
 
 }  // namespace
 
-extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, int wt_dtype, int k,
-                                      int ci, int co, void* stream) {
+extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void* wc, int wt_dtype,
+                                      int k, int ci, int co, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (k == 0 || ci == 0 || co == 0) return 0;
   dim3 grid((unsigned)cdiv(co, 32), (unsigned)cdiv(ci, 32), (unsigned)k);
   if (w_dtype == LIDAL_F32 && wt_dtype == LIDAL_F32)
-    weight_pack_kernel<float, float><<<grid, 256, 0, s>>>((const float*)w, (float*)wt, k, ci, co);
+    weight_pack_kernel<float, float><<<grid, 256, 0, s>>>((const float*)w, (float*)wt, (float*)wc, k, ci, co);
   else if (w_dtype == LIDAL_F32 && wt_dtype == LIDAL_BF16)
-    weight_pack_kernel<float, __bf16><<<grid, 256, 0, s>>>((const float*)w, (__bf16*)wt, k, ci, co);
+    weight_pack_kernel<float, __bf16><<<grid, 256, 0, s>>>((const float*)w, (__bf16*)wt, (__bf16*)wc, k, ci, co);
   else if (w_dtype == LIDAL_BF16 && wt_dtype == LIDAL_BF16)
-    weight_pack_kernel<__bf16, __bf16><<<grid, 256, 0, s>>>((const __bf16*)w, (__bf16*)wt, k, ci, co);
+    weight_pack_kernel<__bf16, __bf16><<<grid, 256, 0, s>>>((const __bf16*)w, (__bf16*)wt, (__bf16*)wc, k, ci, co);
   else if (w_dtype == LIDAL_BF16 && wt_dtype == LIDAL_F32)
-    weight_pack_kernel<__bf16, float><<<grid, 256, 0, s>>>((const __bf16*)w, (float*)wt, k, ci, co);
+    weight_pack_kernel<__bf16, float><<<grid, 256, 0, s>>>((const __bf16*)w, (float*)wt, (float*)wc, k, ci, co);
   else {
     set_error("weight_pack: bad dtypes %d %d", w_dtype, wt_dtype);
     return 2;

@@ -12,6 +12,7 @@ from .. import PointTensor, cat
 from .. import nn as spnn
 from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock,
                      conv_bn_relu)
+from ..nn.functional.conv import prefetch_kernel_maps
 from .glue import initial_voxelize, point_to_voxel, voxel_to_point
 
 __all__ = ['SPVCNN', 'MinkUNet']
@@ -21,6 +22,10 @@ CHANNELS = (32, 32, 64, 128, 256, 256, 128, 96, 96)
 
 class _SparseUNet(nn.Module):
     """stem, stage1-4, up1-4, classifier -- shared by both backbones."""
+
+    # (kernel_size, stride) of the encoder's convs in data-flow order: stem 3x3x3, then per stage
+    # a 2x2x2 stride-2 conv and 3x3x3 residual blocks.  Used to build every kernel map up front.
+    MAP_PLAN = ((3, 1),) + ((2, 2), (3, 1)) * 4
 
     def __init__(self, class_num, cr=1.0):
         super().__init__()
@@ -58,6 +63,7 @@ class MinkUNet(_SparseUNet):
         self.weight_initialization()
 
     def forward(self, x):
+        prefetch_kernel_maps(x, self.MAP_PLAN)
         x0 = self.stem(x)
         x1 = self.stage1(x0)
         x2 = self.stage2(x1)
@@ -86,7 +92,7 @@ class SPVCNN(_SparseUNet):
 
     def forward(self, x):
         z = PointTensor(x.F, x.C.float())
-        x0 = self.stem(initial_voxelize(z, self.pres, self.vres))
+        x0 = self.stem(prefetch_kernel_maps(initial_voxelize(z, self.pres, self.vres), self.MAP_PLAN))
         z0 = voxel_to_point(x0, z, nearest=False)
 
         x1 = self.stage1(point_to_voxel(x0, z0))

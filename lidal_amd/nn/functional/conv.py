@@ -23,7 +23,7 @@ from .downsample import spdownsample
 from .hash import sphash
 from .query import HashTable
 
-__all__ = ['conv3d', 'KernelMap', 'RowOrder', 'build_kernel_map']
+__all__ = ['conv3d', 'KernelMap', 'RowOrder', 'build_kernel_map', 'prefetch_kernel_maps']
 
 
 class RowOrder:
@@ -123,15 +123,52 @@ def build_kernel_map(coords, in_stride, kernel_size, stride):
     return KernelMap(nbmaps, nbsizes, koff, nbr_out, (n_in, n_out), volume, symmetric), out_coords
 
 
-def _pack_weight(weight, dtype):
-    """[K, ci, co] (any float dtype) -> [K, co, ci] in `dtype` (reduction dim contiguous)."""
+def prefetch_kernel_maps(x, plan, transposed=True):
+    """Build, ahead of the feature kernels, every coordinate set and kernel map a network will ask
+    for: `plan` is the sequence of (kernel_size, stride) of its non-transposed convs along the
+    encoder, starting at x's stride.  Each entry lands in x.cmaps / x.kmaps under exactly the key
+    conv3d looks up, so nothing changes downstream -- except that the host waits for the
+    data-dependent output sizes (one per strided conv) happen here, while the GPU queue is still
+    short, instead of draining the queue in the middle of the network.  `transposed` also
+    prepares the transposed tables the decoder uses."""
+    coords, cur = x.coords, tuple(x.stride)
+    x.cmaps.setdefault(cur, coords)
+    for kernel_size, stride in plan:
+        kernel_size = make_ntuple(kernel_size, ndim=3)
+        stride = make_ntuple(stride, ndim=3)
+        if kernel_size == (1, 1, 1) and stride == (1, 1, 1):
+            continue
+        key = (cur, kernel_size, stride, (1, 1, 1))
+        out_stride = tuple(cur[k] * stride[k] for k in range(3))
+        kmap = x.kmaps.get(key)
+        if kmap is None:
+            kmap, out_coords = build_kernel_map(coords, cur, kernel_size, stride)
+            x.kmaps[key] = kmap
+            if any(s > 1 for s in stride):
+                x.cmaps.setdefault(out_stride, out_coords)
+        kmap.order_out
+        if any(s > 1 for s in stride):
+            if transposed:
+                kmap.order_in
+            coords, cur = x.cmaps[out_stride], out_stride
+    return x
+
+
+def _pack_weight(weight, dtype, with_cast=False):
+    """[K, ci, co] (any float dtype) -> [K, co, ci] in `dtype` (reduction dim contiguous).  With
+    `with_cast` also returns the weight in `dtype` in its own layout (the data-gradient operand),
+    written by the same kernel; (packed, None) otherwise."""
     k, ci, co = weight.shape
     w = weight.detach().contiguous()
     wt = torch.empty((k, co, ci), dtype=dtype, device=w.device)
+    wc = None
+    if with_cast:
+        wc = w if w.dtype == dtype else torch.empty((k, ci, co), dtype=dtype, device=w.device)
     B.check(B.lib().lidal_conv_weight_pack(B.ptr(w), B.dtype_code(w.dtype), B.ptr(wt),
+                                           B.ptr(wc) if wc is not None and wc is not w else None,
                                            B.dtype_code(dtype), k, ci, co, B.stream()),
             'conv_weight_pack')
-    return wt
+    return wt, wc
 
 
 def _apply(feats, wk, order, kflip):
@@ -160,16 +197,28 @@ def _wgrad_splits(n_rows, chunk=None):
     return int(max(1, min(256, -(-n_rows // chunk))))
 
 
+def _forward(feats, weight, kmap, transposed, with_cast):
+    B.require_gpu(feats, weight)
+    cdtype = torch.bfloat16 if torch.is_autocast_enabled() else feats.dtype
+    if cdtype not in (torch.float32, torch.bfloat16):
+        cdtype = torch.float32
+    x = feats.contiguous().to(cdtype)
+    order = kmap.order_in if transposed else kmap.order_out
+    wt, wc = _pack_weight(weight, cdtype, with_cast)
+    return x, wc, _apply(x, wt, order, 0)
+
+
+def _conv(feats, weight, kmap, transposed):
+    if B.wants_grad(feats, weight):
+        return ConvolutionFunction.apply(feats, weight, kmap, transposed)
+    return _forward(feats, weight, kmap, transposed, False)[2]      # inference: no autograd node
+
+
 class ConvolutionFunction(Function):
     @staticmethod
     def forward(ctx, feats, weight, kmap, transposed):
-        B.require_gpu(feats, weight)
-        cdtype = torch.bfloat16 if torch.is_autocast_enabled() else feats.dtype
-        if cdtype not in (torch.float32, torch.bfloat16):
-            cdtype = torch.float32
-        x = feats.contiguous().to(cdtype)
-        order = kmap.order_in if transposed else kmap.order_out
-        out = _apply(x, _pack_weight(weight, cdtype), order, 0)
+        x, wc, out = _forward(feats, weight, kmap, transposed, ctx.needs_input_grad[0])
+        ctx.wc = wc                      # weight in the compute dtype, for the data gradient
         ctx.kmap = kmap
         ctx.transposed = transposed
         ctx.save_for_backward(x, weight)
@@ -185,9 +234,7 @@ class ConvolutionFunction(Function):
         if ctx.needs_input_grad[0]:
             # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci, reduction over co, and
             # weight [K, ci, co] already has the reduction dim contiguous.
-            wk = weight.detach().contiguous()
-            if wk.dtype != x.dtype:
-                wk = wk.to(x.dtype)
+            wk = ctx.wc
             if not transposed:
                 if kmap.symmetric:
                     grad_in = _apply(g, wk, kmap.order_out, 1)
@@ -232,14 +279,14 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
             if any(s > 1 for s in stride):
                 input.cmaps.setdefault(out_stride, out_coords)
         out_coords = coords if all(s == 1 for s in stride) else input.cmaps[out_stride]
-        feats = ConvolutionFunction.apply(feats, weight, kmap, False)
+        feats = _conv(feats, weight, kmap, False)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(feats, out_coords, out_stride)
     else:
         tensor_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         kmap = input.kmaps[(tensor_stride, kernel_size, stride, dilation)]
-        feats = ConvolutionFunction.apply(feats, weight, kmap, True)
+        feats = _conv(feats, weight, kmap, True)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(feats, input.cmaps[tensor_stride], tensor_stride)

@@ -51,61 +51,83 @@ def _vec(dtype):
     return 8 if dtype == torch.bfloat16 else 4
 
 
+def _operand(w, linear, cdtype, pad):
+    """The GEMM operand [Cin, Cout+pad] in the compute dtype for `w` ([Cin, Cout], or nn.Linear's
+    [Cout, Cin] when `linear`)."""
+    wc = w.detach().to(cdtype)
+    if linear:
+        wc = wc.t()
+    if pad:
+        wc = torch.nn.functional.pad(wc, (0, pad))
+    return wc
+
+
+def _forward(x, w, bias, linear):
+    cdtype = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
+    xc = x.contiguous().to(cdtype)
+    co = w.shape[0] if linear else w.shape[1]
+    pad = (-co) % _vec(cdtype) if xc.is_cuda else 0
+    wc = _operand(w, linear, cdtype, pad)
+    y = xc @ wc
+    if bias is not None:
+        b = bias.detach().to(cdtype)
+        y = y + (torch.nn.functional.pad(b, (0, pad)) if pad else b)
+    return xc, wc, pad, (y[:, :co] if pad else y)
+
+
 class RowsMatmul(Function):
-    """y = x @ w  (+ bias), w [Cin, Cout].  A Cout that is not a multiple of the 16-byte vector
-    width (the 19-class classifier) is zero-padded internally so that forward, weight gradient and
-    bias gradient all stay on the vectorised kernels; the caller sees exactly [N, Cout]."""
+    """y = x @ w  (+ bias), w [Cin, Cout] (or nn.Linear's [Cout, Cin] with linear=True).  A Cout
+    that is not a multiple of the 16-byte vector width (the 19-class classifier) is zero-padded
+    internally so that forward, weight gradient and bias gradient all stay on the vectorised
+    kernels; the caller sees exactly [N, Cout]."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
-        cdtype = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
-        xc = x.contiguous().to(cdtype)
-        wc = w.detach().to(cdtype)
-        co = wc.shape[1]
-        pad = (-co) % _vec(cdtype) if xc.is_cuda else 0
-        if pad:
-            wc = torch.nn.functional.pad(wc, (0, pad))
-        y = xc @ wc
-        if bias is not None:
-            b = bias.detach().to(cdtype)
-            y = y + (torch.nn.functional.pad(b, (0, pad)) if pad else b)
+    def forward(ctx, x, w, bias, linear):
+        xc, wc, pad, y = _forward(x, w, bias, linear)
         ctx.save_for_backward(xc, w)
+        ctx.wc = wc                      # operand in the compute dtype, re-used by the data gradient
         ctx.has_bias = bias is not None
         ctx.pad = pad
-        return y[:, :co] if pad else y
+        ctx.linear = linear
+        return y
 
     @staticmethod
     def backward(ctx, g):
         xc, w = ctx.saved_tensors
+        linear = ctx.linear
         g = g.to(xc.dtype)
-        co = w.shape[1]
+        co = w.shape[0] if linear else w.shape[1]
         if ctx.pad:
             g = torch.nn.functional.pad(g, (0, ctx.pad))
         g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wc = w.detach().to(xc.dtype)
-            if ctx.pad:
-                wc = torch.nn.functional.pad(wc, (0, ctx.pad))
-            gx = g @ wc.t()
+            gx = g @ ctx.wc.t()
         if ctx.needs_input_grad[1]:
             if _ok(xc, xc.shape[1], g.shape[1]):
-                gw = _wgrad_dense(xc, g)[:, :co].to(w.dtype)
+                gw = _wgrad_dense(xc, g)[:, :co]
             else:
-                gw = (xc.float().t() @ g.float())[:, :co].to(w.dtype)
+                gw = (xc.float().t() @ g.float())[:, :co]
+            gw = (gw.t().contiguous() if linear else gw).to(w.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             from .norm import column_sum
             if g.is_cuda and g.shape[1] % _vec(g.dtype) == 0 and g.shape[1] // _vec(g.dtype) <= 256:
                 gb = column_sum(g)[:co]
             else:
                 gb = g.float().sum(0)[:co]
-        return gx, gw, gb
+        return gx, gw, gb, None
+
+
+def _rows(x, w, bias, linear):
+    if B.wants_grad(x, w, bias):
+        return RowsMatmul.apply(x, w, bias, linear)
+    return _forward(x, w, bias, linear)[3]          # inference: no autograd node
 
 
 def rows_matmul(x, w, bias=None):
-    return RowsMatmul.apply(x, w, bias)
+    return _rows(x, w, bias, False)
 
 
 def rows_linear(x, weight, bias=None):
     """nn.Linear semantics: weight [Cout, Cin]."""
-    return RowsMatmul.apply(x, weight.t(), bias)
+    return _rows(x, weight, bias, True)

@@ -74,4 +74,6 @@ class DevoxelizeFunction(Function):
 
 
 def spdevoxelize(feats, coords, weights):
-    return DevoxelizeFunction.apply(feats, coords, weights)
+    if B.wants_grad(feats):
+        return DevoxelizeFunction.apply(feats, coords, weights)
+    return DevoxelizeFunction.forward(B.NoGradCtx(), feats, coords, weights)        # inference: no autograd node

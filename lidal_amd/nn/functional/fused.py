@@ -12,13 +12,18 @@ def _vec(dt):
     return 8 if dt == torch.bfloat16 else 4
 
 
+def _add_relu_fwd(a, b):
+    a, b = a.contiguous(), b.contiguous().to(a.dtype)
+    y = torch.empty_like(a)
+    B.check(B.lib().lidal_add_relu_fwd(B.ptr(a), B.ptr(b), B.ptr(y), a.numel(),
+                                       B.dtype_code(a.dtype), B.stream()), 'add_relu_fwd')
+    return y
+
+
 class AddReLU(Function):
     @staticmethod
     def forward(ctx, a, b):
-        a, b = a.contiguous(), b.contiguous().to(a.dtype)
-        y = torch.empty_like(a)
-        B.check(B.lib().lidal_add_relu_fwd(B.ptr(a), B.ptr(b), B.ptr(y), a.numel(),
-                                           B.dtype_code(a.dtype), B.stream()), 'add_relu_fwd')
+        y = _add_relu_fwd(a, b)
         ctx.save_for_backward(y)
         return y
 
@@ -36,7 +41,7 @@ def add_relu(a, b):
     """relu(a + b) for two [N, C] feature matrices of the same shape."""
     if (a.is_cuda and a.shape == b.shape and a.dtype in (torch.float32, torch.bfloat16)
             and a.numel() % _vec(a.dtype) == 0 and a.numel() > 0):
-        return AddReLU.apply(a, b)
+        return AddReLU.apply(a, b) if B.wants_grad(a, b) else _add_relu_fwd(a, b)
     return torch.relu(a + b)
 
 

@@ -82,6 +82,14 @@ class BatchNormRows(Function):
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps,
                     relu=False):
+    if not training and not B.wants_grad(x, weight, bias):      # inference: one kernel, no node
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        B.check(B.lib().lidal_bn_eval_fwd(B.ptr(x), B.dtype_code(x.dtype), x.shape[0], x.shape[1],
+                                          B.ptr(weight), B.ptr(bias), B.ptr(running_mean),
+                                          B.ptr(running_var), float(eps), int(relu), B.ptr(y),
+                                          B.stream()), 'bn_eval_fwd')
+        return y
     return BatchNormRows.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
                                relu)
 

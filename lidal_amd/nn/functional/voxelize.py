@@ -53,4 +53,6 @@ class VoxelizeFunction(Function):
 
 
 def spvoxelize(feats, coords, counts):
-    return VoxelizeFunction.apply(feats, coords, counts)
+    if B.wants_grad(feats):
+        return VoxelizeFunction.apply(feats, coords, counts)
+    return VoxelizeFunction.forward(B.NoGradCtx(), feats, coords, counts)        # inference: no autograd node

@@ -128,3 +128,48 @@ def test_reference_style_import_alias():
     from torchsparse import PointTensor, SparseTensor  # noqa: F401
     from torchsparse.nn.utils import get_kernel_offsets  # noqa: F401
     assert torchsparse is lidal_amd and hasattr(spnn, 'Conv3d') and hasattr(F, 'sphashquery')
+
+
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_inference_fast_path_is_bitwise_the_autograd_path(name, golden_dir):
+    """Under no_grad the operators skip their autograd nodes (and eval BatchNorm runs as one
+    kernel); with gradients enabled the same eval forward goes through the Function classes.
+    Both must give the same bits, in f32 and under bf16 autocast."""
+    import lidal_amd
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    model = fill_state_dict(_models()[name](19)).to(DEV).eval()
+    feats, coords = torch.from_numpy(g['feats']).to(DEV), torch.from_numpy(g['coords']).to(DEV)
+    for autocast in (False, True):
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            with torch.no_grad():
+                a, fa = model(lidal_amd.SparseTensor(feats, coords))
+            b, fb = model(lidal_amd.SparseTensor(feats, coords))
+        assert b.requires_grad and not a.requires_grad
+        assert torch.equal(a, b.detach()) and torch.equal(fa, fb.detach())
+
+
+def test_prefetched_kernel_maps_are_the_ones_conv3d_builds(golden_dir):
+    """prefetch_kernel_maps fills x.cmaps / x.kmaps with exactly what the convs would build one by
+    one (same keys, same tables), so running the network after it changes nothing."""
+    import lidal_amd
+    from lidal_amd import nn as spnn
+    from lidal_amd.nn.functional.conv import prefetch_kernel_maps
+    g = _load(golden_dir)
+    coords = torch.from_numpy(g['coords']).to(DEV)
+    feats = torch.from_numpy(g['feats']).to(DEV)
+    plan = ((3, 1), (2, 2), (3, 1), (2, 2), (3, 1))
+    xa = prefetch_kernel_maps(lidal_amd.SparseTensor(feats, coords), plan)
+    xb = lidal_amd.SparseTensor(feats, coords)
+    torch.manual_seed(0)
+    convs = [spnn.Conv3d(4, 4, k, stride=s).to(DEV) for k, s in plan]
+    y = xb
+    with torch.no_grad():
+        for c in convs:
+            y = c(y)
+    assert set(xa.kmaps) == set(xb.kmaps) and set(xa.cmaps) == set(xb.cmaps)
+    for key in xb.kmaps:
+        assert torch.equal(xa.kmaps[key].nbr_out, xb.kmaps[key].nbr_out)
+        assert torch.equal(xa.kmaps[key].nbmaps, xb.kmaps[key].nbmaps)
+    for key in xb.cmaps:
+        assert torch.equal(xa.cmaps[key], xb.cmaps[key])

@@ -126,6 +126,8 @@ int lidal_devoxelize_fwd(const void* feat, const int32_t* idx, const float* w, v
                          int64_t n, int64_t m, int c, int dtype, void* stream);
 int lidal_devoxelize_bwd(const float* gout, const int32_t* idx, const float* w, float* gin,
                          int64_t n, int64_t m, int c, void* stream);
+/* (n_entries = length of `order`; lists averaging >= 32 contributors per voxel are split over
+ * several waves / workgroups per voxel, ws from lidal_segment_workspace_bytes, may be NULL if 0) */
 /* Atomic-free, bitwise reproducible forms of the two scatter sums above.  A point->voxel index
  * idx i32 [n_entries] (n_entries = n for voxelize, 8n for devoxelize: entry = point*8 + corner) is
  * transposed once into per-voxel contributor lists: order i32 [n_entries] (entries sorted by voxel,
@@ -133,12 +135,13 @@ int lidal_devoxelize_bwd(const float* gout, const int32_t* idx, const float* w, 
 int64_t lidal_invlist_workspace_bytes(int64_t n_entries);
 int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n_entries, int64_t m,
                         int32_t* order, int64_t* seg_ptr, void* ws, int64_t ws_bytes, void* stream);
+int64_t lidal_segment_workspace_bytes(int64_t n_entries, int64_t m, int c);
 int lidal_voxelize_fwd_sorted(const void* feat, const int32_t* order, const int64_t* seg_ptr,
                               const int32_t* counts, void* out, int64_t m, int c, int dtype,
-                              void* stream);
+                              int64_t n_entries, void* ws, int64_t ws_bytes, void* stream);
 int lidal_devoxelize_bwd_sorted(const void* gout, const int32_t* order, const int64_t* seg_ptr,
                                 const float* w, void* gin, int64_t m, int c, int dtype,
-                                void* stream);
+                                int64_t n_entries, void* ws, int64_t ws_bytes, void* stream);
 /* replaces F.calc_ti_weights (torchsparse/nn/functional/devoxelize.py; network/utils.py:77):
  * coords f32 [n, cstride>=3], idx i64 [8,n] -> w f32 [n,8] and idx32 i32 [n,8] (both already
  * transposed as network/utils.py:78-79 does). */

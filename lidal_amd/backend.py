@@ -45,8 +45,9 @@ SIGNATURES = {
     'lidal_devoxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     'lidal_invlist_workspace_bytes': (_i64, [_i64]),
     'lidal_invlist_build': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
-    'lidal_voxelize_fwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    'lidal_devoxelize_bwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    'lidal_segment_workspace_bytes': (_i64, [_i64, _i64, _i32]),
+    'lidal_voxelize_fwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
+    'lidal_devoxelize_bwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
     'lidal_ti_weights': (_i32, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp]),
     'lidal_conv_weight_pack': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'lidal_kmap_order_workspace_bytes': (_i64, [_i64]),

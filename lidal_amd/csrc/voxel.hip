@@ -239,23 +239,16 @@ __global__ void __launch_bounds__(256) inv_segptr_kernel(const unsigned* __restr
 //   devox bwd:  row = e >> 3, scale = w[e]
 // One wave per voxel; LPR lanes cover a row with float4 each, the 64/LPR lane groups take list
 // elements round-robin (4 independent row loads in flight per lane), fixed xor-tree at the end.
+// Wave-level body: lanes 0..LPR-1 return sum_{j in [beg, end)} scale(j) * src[row(j)][4l .. 4l+3]
+// (every lane group takes list elements round-robin, fixed xor-tree at the end).
 template <typename T, int LPR, bool DEVOX>
-__global__ void __launch_bounds__(256) segment_sum_kernel(const T* __restrict__ src,
-                                                          const int* __restrict__ order,
-                                                          const int64_t* __restrict__ seg_ptr,
-                                                          const float* __restrict__ w,
-                                                          const int* __restrict__ counts,
-                                                          T* __restrict__ out, int64_t m,
-                                                          int c) {
+__device__ __forceinline__ float4 segment_wave_sum(const T* __restrict__ src,
+                                                   const int* __restrict__ order,
+                                                   const float* __restrict__ w, int64_t beg,
+                                                   int64_t end, float inv, int c, int lane) {
   constexpr int RPW = 64 / LPR;
-  const int lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= m) return;
   const int l = lane % LPR, grp = lane / LPR;
   const bool act = 4 * l < c;
-  const int64_t beg = seg_ptr[v], end = seg_ptr[v + 1];
-  float inv = 1.f;
-  if (!DEVOX) { int cv = counts[v]; inv = cv > 0 ? (float)cv : 1.f; }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t j = beg + grp;
   for (; j + 3 * RPW < end; j += 4 * RPW) {
@@ -287,7 +280,99 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(const T* __restrict__ 
     acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
     acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
   }
-  if (grp == 0 && act) st4(out + v * c + 4 * l, acc);
+  return acc;
+}
+
+// out[v][:] = sum_{j in list(v)} scale(j) * src[row(j)][:]
+//   voxelize:   row = e,      scale = 1 / counts[v]
+//   devox bwd:  row = e >> 3, scale = w[e]
+// One wave per voxel (the fine levels: a handful of contributors per voxel); LPR lanes cover a
+// row with 4 channels each, 4 independent row loads in flight per lane.
+template <typename T, int LPR, bool DEVOX>
+__global__ void __launch_bounds__(256) segment_sum_kernel(const T* __restrict__ src,
+                                                          const int* __restrict__ order,
+                                                          const int64_t* __restrict__ seg_ptr,
+                                                          const float* __restrict__ w,
+                                                          const int* __restrict__ counts,
+                                                          T* __restrict__ out, int64_t m,
+                                                          int c) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= m) return;
+  const int l = lane % LPR, grp = lane / LPR;
+  float inv = 1.f;
+  if (!DEVOX) { int cv = counts[v]; inv = cv > 0 ? (float)cv : 1.f; }
+  float4 acc = segment_wave_sum<T, LPR, DEVOX>(src, order, w, seg_ptr[v], seg_ptr[v + 1], inv, c, lane);
+  if (grp == 0 && 4 * l < c) st4(out + v * c + 4 * l, acc);
+}
+
+// The coarse levels (hundreds of contributors per voxel, few voxels): `parts` workgroups per
+// voxel, each wave sums a contiguous 1/(4*parts) of the list, the 4 waves are folded through LDS
+// in wave order; with parts == 1 the result is final, otherwise it lands in an f32 partial row
+// (v * parts + part) that segment_fold_kernel adds up in part order.  No atomics anywhere.
+template <typename T, int LPR, bool DEVOX>
+__global__ void __launch_bounds__(256) segment_sum_wg_kernel(const T* __restrict__ src,
+                                                             const int* __restrict__ order,
+                                                             const int64_t* __restrict__ seg_ptr,
+                                                             const float* __restrict__ w,
+                                                             const int* __restrict__ counts,
+                                                             T* __restrict__ out,
+                                                             float* __restrict__ partial,
+                                                             int64_t m, int c, int parts) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t v = blockIdx.x / parts;
+  const int part = (int)(blockIdx.x - v * parts);
+  const int l = lane % LPR, grp = lane / LPR;
+  const int64_t beg = seg_ptr[v], end = seg_ptr[v + 1];
+  const int64_t chunk = (end - beg + 4 * parts - 1) / (4 * parts);
+  int64_t b0 = beg + (int64_t)(part * 4 + wave) * chunk;
+  int64_t b1 = b0 + chunk;
+  if (b0 > end) b0 = end;
+  if (b1 > end) b1 = end;
+  float inv = 1.f;
+  if (!DEVOX) { int cv = counts[v]; inv = cv > 0 ? (float)cv : 1.f; }
+  float4 acc = segment_wave_sum<T, LPR, DEVOX>(src, order, w, b0, b1, inv, c, lane);
+  if (grp == 0) red[wave][l] = acc;
+  __syncthreads();
+  if (wave == 0 && grp == 0 && 4 * l < c) {
+    float4 a = red[0][l];
+#pragma unroll
+    for (int u = 1; u < 4; ++u) {
+      float4 b = red[u][l];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (parts == 1) st4(out + v * c + 4 * l, a);
+    else st4(partial + ((int64_t)v * parts + part) * c + 4 * l, a);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) segment_fold_kernel(const float* __restrict__ partial,
+                                                           T* __restrict__ out, int64_t m, int c,
+                                                           int parts) {
+  const int cv = c / 4;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= m * cv) return;
+  int64_t v = t / cv;
+  int j = (int)(t - v * cv) * 4;
+  float4 a = ld4(partial + (v * parts) * c + j);
+  for (int p = 1; p < parts; ++p) {
+    float4 b = ld4(partial + (v * parts + p) * c + j);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  st4(out + v * c + j, a);
+}
+
+// lists this long per voxel (on average) go to the workgroup kernel
+constexpr int64_t SEG_LONG = 32;
+
+static inline int segment_parts(int64_t n_entries, int64_t m) {
+  if (m <= 0 || n_entries < SEG_LONG * m) return 0;          // wave-per-voxel kernel
+  int64_t avg = n_entries / m;
+  int parts = 1;
+  while (parts < 8 && (int64_t)parts * 256 <= avg) parts <<= 1;   // >= 64 entries per wave
+  return parts;
 }
 
 size_t inv_sort_tmp_bytes(int64_t n) {
@@ -300,17 +385,40 @@ size_t inv_sort_tmp_bytes(int64_t n) {
 
 template <typename T, bool DEVOX>
 int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, const float* w,
-                       const int* counts, T* out, int64_t m, int c, hipStream_t s) {
-  unsigned grid = (unsigned)cdiv(m, 4);
+                       const int* counts, T* out, int64_t m, int c, int64_t n_entries, void* ws,
+                       int64_t ws_bytes, hipStream_t s) {
+  const int parts = segment_parts(n_entries, m);
+  if (parts == 0) {
+    unsigned grid = (unsigned)cdiv(m, 4);
+    if (c <= 32)
+      segment_sum_kernel<T, 8, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    else if (c <= 64)
+      segment_sum_kernel<T, 16, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    else if (c <= 128)
+      segment_sum_kernel<T, 32, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    else
+      segment_sum_kernel<T, 64, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    LIDAL_CHECK_LAUNCH("segment_sum");
+    return 0;
+  }
+  LIDAL_REQUIRE(c <= 256, "segment_sum: at most 256 channels");
+  float* partial = (float*)ws;
+  if (parts > 1)
+    LIDAL_REQUIRE(ws != nullptr && ws_bytes >= (int64_t)m * parts * c * 4, "segment_sum workspace too small");
+  unsigned grid = (unsigned)(m * parts);
   if (c <= 32)
-    segment_sum_kernel<T, 8, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    segment_sum_wg_kernel<T, 8, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, partial, m, c, parts);
   else if (c <= 64)
-    segment_sum_kernel<T, 16, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    segment_sum_wg_kernel<T, 16, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, partial, m, c, parts);
   else if (c <= 128)
-    segment_sum_kernel<T, 32, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
+    segment_sum_wg_kernel<T, 32, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, partial, m, c, parts);
   else
-    segment_sum_kernel<T, 64, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
-  LIDAL_CHECK_LAUNCH("segment_sum");
+    segment_sum_wg_kernel<T, 64, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, partial, m, c, parts);
+  LIDAL_CHECK_LAUNCH("segment_sum_wg");
+  if (parts > 1) {
+    segment_fold_kernel<T><<<(unsigned)cdiv(m * (c / 4), 256), 256, 0, s>>>(partial, out, m, c, parts);
+    LIDAL_CHECK_LAUNCH("segment_fold");
+  }
   return 0;
 }
 
@@ -435,32 +543,43 @@ extern "C" int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n
   return 0;
 }
 
+extern "C" int64_t lidal_segment_workspace_bytes(int64_t n_entries, int64_t m, int c) {
+  int parts = segment_parts(n_entries, m);
+  return parts > 1 ? (int64_t)m * parts * c * 4 : 0;
+}
+
 extern "C" int lidal_voxelize_fwd_sorted(const void* feat, const int32_t* order,
                                          const int64_t* seg_ptr, const int32_t* counts, void* out,
-                                         int64_t m, int c, int dtype, void* stream) {
+                                         int64_t m, int c, int dtype, int64_t n_entries, void* ws,
+                                         int64_t ws_bytes, void* stream) {
   if (m == 0 || c == 0) return 0;
   LIDAL_REQUIRE(c % 4 == 0, "voxelize_fwd_sorted: channels must be a multiple of 4");
   if (dtype == LIDAL_F32)
     return launch_segment_sum<float, false>((const float*)feat, order, seg_ptr, nullptr, counts,
-                                            (float*)out, m, c, (hipStream_t)stream);
+                                            (float*)out, m, c, n_entries, ws, ws_bytes,
+                                            (hipStream_t)stream);
   if (dtype == LIDAL_BF16)
     return launch_segment_sum<__bf16, false>((const __bf16*)feat, order, seg_ptr, nullptr, counts,
-                                             (__bf16*)out, m, c, (hipStream_t)stream);
+                                             (__bf16*)out, m, c, n_entries, ws, ws_bytes,
+                                             (hipStream_t)stream);
   set_error("voxelize_fwd_sorted: bad dtype %d", dtype);
   return 2;
 }
 
 extern "C" int lidal_devoxelize_bwd_sorted(const void* gout, const int32_t* order,
                                            const int64_t* seg_ptr, const float* w, void* gin,
-                                           int64_t m, int c, int dtype, void* stream) {
+                                           int64_t m, int c, int dtype, int64_t n_entries, void* ws,
+                                           int64_t ws_bytes, void* stream) {
   if (m == 0 || c == 0) return 0;
   LIDAL_REQUIRE(c % 4 == 0, "devoxelize_bwd_sorted: channels must be a multiple of 4");
   if (dtype == LIDAL_F32)
     return launch_segment_sum<float, true>((const float*)gout, order, seg_ptr, w, nullptr,
-                                           (float*)gin, m, c, (hipStream_t)stream);
+                                           (float*)gin, m, c, n_entries, ws, ws_bytes,
+                                           (hipStream_t)stream);
   if (dtype == LIDAL_BF16)
     return launch_segment_sum<__bf16, true>((const __bf16*)gout, order, seg_ptr, w, nullptr,
-                                            (__bf16*)gin, m, c, (hipStream_t)stream);
+                                            (__bf16*)gin, m, c, n_entries, ws, ws_bytes,
+                                            (hipStream_t)stream);
   set_error("devoxelize_bwd_sorted: bad dtype %d", dtype);
   return 2;
 }

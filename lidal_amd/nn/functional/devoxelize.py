@@ -4,7 +4,7 @@ import torch
 from torch.autograd import Function
 
 from ... import backend as B
-from .invlist import inverse_lists
+from .invlist import inverse_lists, segment_workspace
 
 __all__ = ['spdevoxelize', 'calc_ti_weights', 'ti_weights_and_index']
 
@@ -63,9 +63,11 @@ class DevoxelizeFunction(Function):
         gin = torch.empty((m, c), dtype=g.dtype, device=g.device)
         if c % 4 == 0:      # ordered per-voxel gather: no atomics, reproducible
             order, seg_ptr = inverse_lists(coords, m, weights)
+            ws, nbytes = segment_workspace(8 * n, m, c, g.device)
             B.check(B.lib().lidal_devoxelize_bwd_sorted(B.ptr(g), B.ptr(order), B.ptr(seg_ptr),
                                                         B.ptr(weights), B.ptr(gin), m, c,
-                                                        B.dtype_code(g.dtype), B.stream()),
+                                                        B.dtype_code(g.dtype), 8 * n, B.ptr(ws),
+                                                        nbytes, B.stream()),
                     'devoxelize_bwd_sorted')
         else:
             B.check(B.lib().lidal_devoxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(weights),

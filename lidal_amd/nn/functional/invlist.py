@@ -5,7 +5,7 @@ import torch
 
 from ... import backend as B
 
-__all__ = ['inverse_lists']
+__all__ = ['inverse_lists', 'segment_workspace']
 
 
 def inverse_lists(idx, m, weights=None):
@@ -27,3 +27,11 @@ def inverse_lists(idx, m, weights=None):
                                         B.ptr(ws), ws_bytes, B.stream()), 'invlist_build')
     idx._lidal_invlist = (m, order, seg_ptr)
     return order, seg_ptr
+
+
+def segment_workspace(n_entries, m, c, device):
+    """(buffer or None, bytes) for the split-list form of the ordered segment sums."""
+    nbytes = B.lib().lidal_segment_workspace_bytes(n_entries, m, c)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes

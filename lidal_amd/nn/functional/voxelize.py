@@ -4,7 +4,7 @@ import torch
 from torch.autograd import Function
 
 from ... import backend as B
-from .invlist import inverse_lists
+from .invlist import inverse_lists, segment_workspace
 
 __all__ = ['spvoxelize']
 
@@ -28,9 +28,11 @@ class VoxelizeFunction(Function):
         out = torch.empty((m, c), dtype=feats.dtype, device=feats.device)
         if c % 4 == 0:      # ordered per-voxel gather: no atomics, reproducible
             order, seg_ptr = inverse_lists(idx32, m)
+            ws, nbytes = segment_workspace(n, m, c, feats.device)
             B.check(B.lib().lidal_voxelize_fwd_sorted(B.ptr(feats), B.ptr(order), B.ptr(seg_ptr),
                                                       B.ptr(counts), B.ptr(out), m, c,
-                                                      B.dtype_code(feats.dtype), B.stream()),
+                                                      B.dtype_code(feats.dtype), n, B.ptr(ws),
+                                                      nbytes, B.stream()),
                     'voxelize_fwd_sorted')
         else:
             B.check(B.lib().lidal_voxelize_fwd(B.ptr(feats), B.ptr(idx32), B.ptr(counts),

@@ -484,3 +484,37 @@ def test_voxel_exchange_bf16_rows_equal_f32_compute_rounded():
     pb.backward(gp.float())
     assert pa.dtype == torch.bfloat16 and torch.equal(pa, pb.bfloat16())
     assert torch.equal(fa.grad, fb.grad.bfloat16())
+
+
+@pytest.mark.parametrize('m,c', [(50, 256), (700, 96), (3000, 32)])
+def test_voxel_exchange_long_contributor_lists(m, c):
+    """Coarse levels: hundreds of points per voxel.  The ordered sums are then split over several
+    waves / workgroups per voxel; results must match an f64 scatter-add and be reproducible."""
+    F = _F()
+    g = torch.Generator().manual_seed(m)
+    n = 60000
+    idx = torch.randint(0, m, (n,), generator=g)
+    counts = F.spcount(idx.int().to(DEV), m)
+    x = torch.randn(n, c, generator=g)
+    xg = x.to(DEV).requires_grad_(True)
+    y = F.spvoxelize(xg, idx.to(DEV), counts)
+    ref = torch.zeros(m, c, dtype=torch.float64).index_add_(0, idx, x.double())
+    ref /= torch.bincount(idx, minlength=m).clamp(min=1).double()[:, None]
+    assert _relerr(y.detach().cpu(), ref) < 1e-5
+    assert torch.equal(y, F.spvoxelize(xg, idx.to(DEV), counts))
+    idx8 = torch.randint(-1, m, (n, 8), generator=g).int()
+    w8 = torch.rand(n, 8, generator=g)
+    w8[idx8 < 0] = 0
+    f = torch.randn(m, c, generator=g).to(DEV).requires_grad_(True)
+    gp = torch.randn(n, c, generator=g)
+    p = F.spdevoxelize(f, idx8.to(DEV), w8.to(DEV))
+    p.backward(gp.to(DEV))
+    ref_g = torch.zeros(m, c, dtype=torch.float64)
+    for k in range(8):
+        ok = idx8[:, k] >= 0
+        ref_g.index_add_(0, idx8[ok, k].long(), gp[ok].double() * w8[ok, k, None].double())
+    assert _relerr(f.grad.cpu(), ref_g) < 1e-5
+    g1 = f.grad.clone()
+    f.grad = None
+    F.spdevoxelize(f, idx8.to(DEV), w8.to(DEV)).backward(gp.to(DEV))
+    assert torch.equal(g1, f.grad)

@@ -415,6 +415,20 @@ int bn_bwd(const void* x, const void* dy, int64_t n, int c, const float* gamma, 
   return 0;
 }
 
+// eval-mode BatchNorm as a per-channel affine map: y = x * scale + shift
+__global__ void __launch_bounds__(256) bn_fold_kernel(const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ var, float eps,
+                                                      int c, float* __restrict__ scale,
+                                                      float* __restrict__ shift) {
+  int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  float sc = (1.f / sqrtf(var[ch] + eps)) * (gamma ? gamma[ch] : 1.f);
+  scale[ch] = sc;
+  shift[ch] = (beta ? beta[ch] : 0.f) - mean[ch] * sc;
+}
+
 }  // namespace
 
 static int bn_check(int64_t n, int c, int dtype) {
@@ -479,6 +493,16 @@ extern "C" int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n,
                          grad_beta, (float*)ws, s);
   return bn_bwd<__bf16>(x, dy, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
                         grad_beta, (float*)ws, s);
+}
+
+extern "C" int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, float eps, int c, float* scale,
+                             float* shift, void* stream) {
+  if (c <= 0) return 0;
+  bn_fold_kernel<<<(unsigned)cdiv(c, 256), 256, 0, (hipStream_t)stream>>>(
+      gamma, beta, running_mean, running_var, eps, c, scale, shift);
+  LIDAL_CHECK_LAUNCH("lidal_bn_fold");
+  return 0;
 }
 
 // Column sums of a [n, c] matrix (bias gradients of the dense layers): the backward partial/final

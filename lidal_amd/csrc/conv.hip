@@ -119,7 +119,9 @@ template <typename T, int NB, int ROW_BYTES, bool GUARD>
 __global__ void __launch_bounds__(NTHREADS)
 conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
                   const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
-                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip) {
+                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
+                  const float* __restrict__ ep_scale, const float* __restrict__ ep_shift,
+                  int ep_relu) {
   constexpr int BN = 16 * NB;
   constexpr int VEC = DT<T>::VEC;
   constexpr int CH = DT<T>::CH;
@@ -308,6 +310,20 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   //      LDS tile in T -> whole rows to HBM with 16-byte stores
   if (LIDAL_ABLATE & 16) return;
   T* et = wl + wave * RW * ESTRIDE;
+  if (ep_scale != nullptr) {       // inference: y = act(acc * scale[col] + shift[col]) (folded BN)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = n0 + nb * 16 + row16;
+      const float es = col < co ? ep_scale[col] : 1.f, eh = col < co ? ep_shift[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[g][nb][r] * es + eh;
+          acc[g][nb][r] = (ep_relu && v < 0.f) ? 0.f : v;
+        }
+    }
+  }
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -333,10 +349,12 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   }
 }
 
+struct Epi { const float* scale; const float* shift; int relu; };
+
 template <typename T, int NB, int ROW_BYTES, bool GUARD>
 int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm,
                       const unsigned* tmasks, void* out, int64_t n_out, int ci, int co, int K,
-                      int kflip, hipStream_t s) {
+                      int kflip, Epi ep, hipStream_t s) {
   constexpr int BN = 16 * NB;
   constexpr int KC = ROW_BYTES / (int)sizeof(T);
   constexpr int WSTRIDE = KC + DT<T>::VEC;
@@ -353,7 +371,7 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
   }
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
   kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, perm, tmasks, (T*)out, n_out,
-                                   ci, co, K, kflip);
+                                   ci, co, K, kflip, ep.scale, ep.shift, ep.relu);
   LIDAL_CHECK_LAUNCH("lidal_conv_apply");
   return 0;
 }
@@ -361,33 +379,33 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
 template <typename T, int ROW_BYTES, bool GUARD>
 int dispatch_conv_cols(const void* in, const void* wk, const int* nbr, const int* perm,
                        const unsigned* tmasks, void* out, int64_t n_out, int ci, int co, int K,
-                       int kflip, hipStream_t s) {
+                       int kflip, Epi ep, hipStream_t s) {
   // BN = 16*NB output channels per workgroup; grid.y covers the rest.
   if (co <= 32)
-    return launch_conv_apply<T, 2, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 2, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
   if (co <= 64)
-    return launch_conv_apply<T, 4, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 4, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
   if (co % 128 != 0 && (co % 96 == 0 || co < 128))
-    return launch_conv_apply<T, 6, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
-  return launch_conv_apply<T, 8, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
+    return launch_conv_apply<T, 6, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
+  return launch_conv_apply<T, 8, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
 }
 
 template <typename T>
 int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm,
                         const unsigned* tmasks, void* out, int64_t n_out, int ci, int co, int K,
-                        int kflip, hipStream_t s) {
+                        int kflip, Epi ep, hipStream_t s) {
   // staged reduction bytes per pass: 128 (more workgroups per CU beat longer passes: measured in
   // profiles/README.md), except rows that are a multiple of 192 but not of 128 bytes (ci = 96
   // bf16 -> one pass of 96 instead of 64 + 32).
   const int row_bytes = ci * (int)sizeof(T);
   if (ci % DT<T>::VEC != 0)       // irregular channel count (4-channel bf16 stem): guarded loads
-    return dispatch_conv_cols<T, 128, true>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
+    return dispatch_conv_cols<T, 128, true>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
 #ifdef LIDAL_ROWB_OVERRIDE
-  return dispatch_conv_cols<T, LIDAL_ROWB_OVERRIDE, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
+  return dispatch_conv_cols<T, LIDAL_ROWB_OVERRIDE, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
 #endif
   if (row_bytes % 192 == 0 && row_bytes % 128 != 0)
-    return dispatch_conv_cols<T, 192, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
-  return dispatch_conv_cols<T, 128, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, s);
+    return dispatch_conv_cols<T, 192, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
+  return dispatch_conv_cols<T, 128, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -803,19 +821,22 @@ extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void
 extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr,
                                 const int32_t* perm, const uint32_t* tile_masks, void* out,
                                 int64_t n_out, int ci, int co, int k, int kflip, int dtype,
+                                const float* ep_scale, const float* ep_shift, int ep_relu,
                                 void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out == 0 || co == 0) return 0;
+  LIDAL_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv_apply: scale and shift go together");
+  Epi ep{ep_scale, ep_shift, ep_relu};
   static_assert(BM == 128, "tile masks from lidal_kmap_order are per 128 rows");
   LIDAL_REQUIRE(ci > 0 && k > 0 && k <= MAXK, "conv_apply: bad shape ci=%d k=%d", ci, k);
   if (dtype == LIDAL_F32) {
     LIDAL_REQUIRE(ci % 4 == 0 && co % 4 == 0, "conv_apply f32: channels must be multiples of 4");
-    return dispatch_conv_apply<float>(in, wk, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, s);
+    return dispatch_conv_apply<float>(in, wk, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
   }
   if (dtype == LIDAL_BF16) {
     LIDAL_REQUIRE((ci % 8 == 0 || ci < 8) && co % 4 == 0,
                   "conv_apply bf16: ci must be a multiple of 8 (or < 8), co a multiple of 4");
-    return dispatch_conv_apply<__bf16>(in, wk, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, s);
+    return dispatch_conv_apply<__bf16>(in, wk, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
   }
   set_error("conv_apply: bad dtype %d", dtype);
   return 2;

@@ -4,11 +4,53 @@ Attribute names (`net`, `downsample`, `relu`) and Sequential positions are the c
 surface: state_dict keys such as `stage2.1.net.3.kernel` or `up1.1.0.downsample.1.weight` must
 match the reference's so its checkpoints load with strict=True (train.py:66, prob_inference.py:68).
 """
+import torch
 from torch import nn
 
 from .. import SparseTensor
+from .. import backend as B
 from .. import nn as spnn
+from ..nn.functional.conv import conv3d
 from ..nn.functional.fused import add_relu
+
+
+class ConvNormSequential(nn.Sequential):
+    """nn.Sequential (same child names, same state_dict keys) that, at inference (eval mode, no
+    gradient wanted), runs each Conv3d -> BatchNorm pair as ONE kernel: the eval-mode BatchNorm is a
+    per-channel affine map, applied (with the fused ReLU) in the convolution's epilogue instead of
+    a separate pass over the feature matrix.  Anything else runs child by child."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, spnn.Conv3d) and isinstance(nxt, spnn.BatchNorm) and _fusable(m, nxt, x):
+                x = _conv_norm(m, nxt, x)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+def _fusable(conv, bn, x):
+    return (not bn.training and bn.track_running_stats and conv.bias is None
+            and conv.kernel_size != (1, 1, 1) and x.F.is_cuda
+            and not B.wants_grad(x.F, conv.kernel, bn.weight, bn.bias)
+            and bn.weight is not None and bn.weight.dtype == torch.float32)
+
+
+def _conv_norm(conv, bn, x):
+    c = bn.num_features
+    fold = torch.empty((2, c), dtype=torch.float32, device=x.F.device)
+    B.check(B.lib().lidal_bn_fold(B.ptr(bn.weight), B.ptr(bn.bias), B.ptr(bn.running_mean),
+                                  B.ptr(bn.running_var), float(bn.eps), c, B.ptr(fold[0]),
+                                  B.ptr(fold[1]), B.stream()), 'bn_fold')
+    return conv3d(x, conv.kernel, kernel_size=conv.kernel_size, bias=None, stride=conv.stride,
+                  dilation=conv.dilation, transposed=conv.transposed,
+                  epilogue=(fold[0], fold[1], bn.fused_relu))
 
 
 def _conv_bn(inc, outc, ks, stride=1, transposed=False):
@@ -31,7 +73,7 @@ class BasicConvolutionBlock(nn.Module):
 
     def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
         super().__init__()
-        self.net = nn.Sequential(*conv_bn_relu(inc, outc, ks, stride))
+        self.net = ConvNormSequential(*conv_bn_relu(inc, outc, ks, stride))
 
     def forward(self, x):
         return self.net(x)
@@ -42,7 +84,7 @@ class BasicDeconvolutionBlock(nn.Module):
 
     def __init__(self, inc, outc, ks=3, stride=1):
         super().__init__()
-        self.net = nn.Sequential(*conv_bn_relu(inc, outc, ks, stride, transposed=True))
+        self.net = ConvNormSequential(*conv_bn_relu(inc, outc, ks, stride, transposed=True))
 
     def forward(self, x):
         return self.net(x)
@@ -53,11 +95,11 @@ class ResidualBlock(nn.Module):
 
     def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
         super().__init__()
-        self.net = nn.Sequential(*conv_bn_relu(inc, outc, ks, stride), *_conv_bn(outc, outc, ks, 1))
+        self.net = ConvNormSequential(*conv_bn_relu(inc, outc, ks, stride), *_conv_bn(outc, outc, ks, 1))
         if inc == outc and stride == 1:
             self.downsample = nn.Identity()
         else:
-            self.downsample = nn.Sequential(*_conv_bn(inc, outc, 1, stride))
+            self.downsample = ConvNormSequential(*_conv_bn(inc, outc, 1, stride))
         self.relu = spnn.ReLU(True)
 
     def forward(self, x):

@@ -10,8 +10,8 @@ from torch import nn
 
 from .. import PointTensor, cat
 from .. import nn as spnn
-from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock,
-                     conv_bn_relu)
+from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, ConvNormSequential,
+                     ResidualBlock, conv_bn_relu)
 from ..nn.functional.conv import prefetch_kernel_maps
 from .glue import initial_voxelize, point_to_voxel, voxel_to_point
 
@@ -31,7 +31,7 @@ class _SparseUNet(nn.Module):
         super().__init__()
         cs = [int(cr * c) for c in CHANNELS]
         self.cs = cs
-        self.stem = nn.Sequential(*conv_bn_relu(4, cs[0], 3), *conv_bn_relu(cs[0], cs[0], 3))
+        self.stem = ConvNormSequential(*conv_bn_relu(4, cs[0], 3), *conv_bn_relu(cs[0], cs[0], 3))
         for i in range(1, 5):          # encoder: stride-2 conv then two residual blocks
             setattr(self, 'stage%d' % i, nn.Sequential(
                 BasicConvolutionBlock(cs[i - 1], cs[i - 1], ks=2, stride=2, dilation=1),

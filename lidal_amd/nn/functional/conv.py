@@ -171,14 +171,17 @@ def _pack_weight(weight, dtype, with_cast=False):
     return wt, wc
 
 
-def _apply(feats, wk, order, kflip):
-    """out[j] = sum_k feats[nbr[kk][j]] @ wk[k]^T with wk [K, co, ci]; `order` = RowOrder(nbr)."""
+def _apply(feats, wk, order, kflip, epilogue=None):
+    """out[j] = sum_k feats[nbr[kk][j]] @ wk[k]^T with wk [K, co, ci]; `order` = RowOrder(nbr).
+    epilogue = (scale f32 [co], shift f32 [co], relu): out = act(out * scale + shift) in-kernel."""
     k, co, ci = wk.shape
     n_out = order.n_rows
     out = torch.empty((n_out, co), dtype=feats.dtype, device=feats.device)
+    scale, shift, relu = epilogue if epilogue is not None else (None, None, False)
     B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
                                      B.ptr(order.tile_masks), B.ptr(out), n_out, ci, co, k, int(kflip),
-                                     B.dtype_code(feats.dtype), B.stream()), 'conv_apply')
+                                     B.dtype_code(feats.dtype), B.ptr(scale), B.ptr(shift),
+                                     int(bool(relu)), B.stream()), 'conv_apply')
     return out
 
 
@@ -197,7 +200,7 @@ def _wgrad_splits(n_rows, chunk=None):
     return int(max(1, min(256, -(-n_rows // chunk))))
 
 
-def _forward(feats, weight, kmap, transposed, with_cast):
+def _forward(feats, weight, kmap, transposed, with_cast, epilogue=None):
     B.require_gpu(feats, weight)
     cdtype = torch.bfloat16 if torch.is_autocast_enabled() else feats.dtype
     if cdtype not in (torch.float32, torch.bfloat16):
@@ -205,13 +208,14 @@ def _forward(feats, weight, kmap, transposed, with_cast):
     x = feats.contiguous().to(cdtype)
     order = kmap.order_in if transposed else kmap.order_out
     wt, wc = _pack_weight(weight, cdtype, with_cast)
-    return x, wc, _apply(x, wt, order, 0)
+    return x, wc, _apply(x, wt, order, 0, epilogue)
 
 
-def _conv(feats, weight, kmap, transposed):
+def _conv(feats, weight, kmap, transposed, epilogue=None):
     if B.wants_grad(feats, weight):
+        assert epilogue is None, 'the fused BatchNorm epilogue is inference-only'
         return ConvolutionFunction.apply(feats, weight, kmap, transposed)
-    return _forward(feats, weight, kmap, transposed, False)[2]      # inference: no autograd node
+    return _forward(feats, weight, kmap, transposed, False, epilogue)[2]   # no autograd node
 
 
 class ConvolutionFunction(Function):
@@ -256,13 +260,18 @@ class ConvolutionFunction(Function):
         return grad_in, grad_w, None, None
 
 
-def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False):
+def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False,
+           epilogue=None):
+    """torchsparse F.conv3d.  `epilogue` (inference only, not for 1x1x1 kernels) = (scale, shift,
+    relu) applies the per-channel affine map of a following eval-mode BatchNorm (+ ReLU) inside
+    the convolution kernel."""
     feats, coords = input.feats, input.coords
     kernel_size = make_ntuple(kernel_size, ndim=3)
     stride = make_ntuple(stride, ndim=3)
     dilation = make_ntuple(dilation, ndim=3)
 
     if kernel_size == (1, 1, 1) and stride == (1, 1, 1) and dilation == (1, 1, 1):
+        assert epilogue is None
         B.require_gpu(feats)
         from .dense import rows_matmul
         feats = rows_matmul(feats, weight, bias)
@@ -279,14 +288,14 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
             if any(s > 1 for s in stride):
                 input.cmaps.setdefault(out_stride, out_coords)
         out_coords = coords if all(s == 1 for s in stride) else input.cmaps[out_stride]
-        feats = _conv(feats, weight, kmap, False)
+        feats = _conv(feats, weight, kmap, False, epilogue)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(feats, out_coords, out_stride)
     else:
         tensor_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         kmap = input.kmaps[(tensor_stride, kernel_size, stride, dilation)]
-        feats = _conv(feats, weight, kmap, True)
+        feats = _conv(feats, weight, kmap, True, epilogue)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(feats, input.cmaps[tensor_stride], tensor_stride)

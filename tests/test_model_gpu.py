@@ -131,10 +131,11 @@ def test_reference_style_import_alias():
 
 
 @pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
-def test_inference_fast_path_is_bitwise_the_autograd_path(name, golden_dir):
-    """Under no_grad the operators skip their autograd nodes (and eval BatchNorm runs as one
-    kernel); with gradients enabled the same eval forward goes through the Function classes.
-    Both must give the same bits, in f32 and under bf16 autocast."""
+def test_inference_fast_path_matches_the_autograd_path(name, golden_dir):
+    """Under no_grad the operators skip their autograd nodes and every Conv3d -> BatchNorm(-> ReLU)
+    runs as one kernel (affine epilogue); with gradients enabled the same eval forward goes through
+    the Function classes and separate BatchNorm kernels.  Same numbers up to the rounding of the
+    re-associated affine map (f32), resp. of one bf16 rounding less per layer (autocast)."""
     import lidal_amd
     from weights import fill_state_dict
     g = _load(golden_dir)
@@ -146,7 +147,11 @@ def test_inference_fast_path_is_bitwise_the_autograd_path(name, golden_dir):
                 a, fa = model(lidal_amd.SparseTensor(feats, coords))
             b, fb = model(lidal_amd.SparseTensor(feats, coords))
         assert b.requires_grad and not a.requires_grad
-        assert torch.equal(a, b.detach()) and torch.equal(fa, fb.detach())
+        tol = 0.05 if autocast else 2e-5
+        assert _rel(a.float().cpu().numpy(), b.detach().float().cpu().numpy()) < tol
+        assert _rel(fa.float().cpu().numpy(), fb.detach().float().cpu().numpy()) < tol
+        if not autocast:
+            assert (a.argmax(1) == b.argmax(1)).float().mean() > 0.999
 
 
 def test_prefetched_kernel_maps_are_the_ones_conv3d_builds(golden_dir):

@@ -518,3 +518,30 @@ def test_voxel_exchange_long_contributor_lists(m, c):
     f.grad = None
     F.spdevoxelize(f, idx8.to(DEV), w8.to(DEV)).backward(gp.to(DEV))
     assert torch.equal(g1, f.grad)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_affine_relu_epilogue(dtype):
+    """lidal_conv_apply's inference epilogue == conv followed by the affine map and ReLU."""
+    F = _F()
+    from lidal_amd import SparseTensor
+    from lidal_amd.nn.functional.conv import conv3d
+    coords = _surface_coords(60, 2, seed=3).to(DEV)
+    n, ci, co = coords.shape[0], 32, 96
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, ci, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(27, ci, co, generator=g) * 0.1).to(DEV)
+    scale = (torch.rand(co, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(co, generator=g).to(DEV)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        plain = conv3d(SparseTensor(x, coords), w, 3).F.float()
+        for relu in (False, True):
+            fused = conv3d(SparseTensor(x, coords), w, 3, epilogue=(scale, shift, relu)).F.float()
+            ref = plain * scale + shift
+            if relu:
+                ref = torch.relu(ref)
+            # `plain` was rounded to the storage dtype before the affine map, `fused` was not
+            tol = 1e-6 if dtype == torch.float32 else 2e-2
+            assert _relerr(fused.cpu(), ref.cpu()) < tol
+            if relu:
+                assert (fused >= 0).all()

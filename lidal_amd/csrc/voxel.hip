@@ -364,14 +364,18 @@ __global__ void __launch_bounds__(256) segment_fold_kernel(const float* __restri
   st4(out + v * c + j, a);
 }
 
-// lists this long per voxel (on average) go to the workgroup kernel
-constexpr int64_t SEG_LONG = 32;
-
-static inline int segment_parts(int64_t n_entries, int64_t m) {
-  if (m <= 0 || n_entries < SEG_LONG * m) return 0;          // wave-per-voxel kernel
-  int64_t avg = n_entries / m;
+// A wave sums RPW = 64 / LPR rows per step, 4 steps in flight: lists that would keep one wave
+// busy for ~5 such rounds or more (on average; measured crossover on the SPVCNN levels: 15 rows
+// per lane group still favours one wave per voxel, 23 the workgroup kernel) go to the workgroup
+// kernel, with enough workgroups per voxel that a wave sees ~4 rounds.  0 = wave-per-voxel kernel.
+static inline int segment_parts(int64_t n_entries, int64_t m, int c) {
+  if (m <= 0) return 0;
+  const int lpr = c <= 32 ? 8 : c <= 64 ? 16 : c <= 128 ? 32 : 64;
+  const int64_t rpw = 64 / lpr, avg = n_entries / m;
+  if (avg < 20 * rpw) return 0;
+  const int64_t waves = (avg + 16 * rpw - 1) / (16 * rpw);
   int parts = 1;
-  while (parts < 8 && (int64_t)parts * 256 <= avg) parts <<= 1;   // >= 64 entries per wave
+  while (parts < 4 && (int64_t)parts * 4 < waves) parts <<= 1;
   return parts;
 }
 
@@ -387,7 +391,7 @@ template <typename T, bool DEVOX>
 int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, const float* w,
                        const int* counts, T* out, int64_t m, int c, int64_t n_entries, void* ws,
                        int64_t ws_bytes, hipStream_t s) {
-  const int parts = segment_parts(n_entries, m);
+  const int parts = segment_parts(n_entries, m, c);
   if (parts == 0) {
     unsigned grid = (unsigned)cdiv(m, 4);
     if (c <= 32)
@@ -544,7 +548,7 @@ extern "C" int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n
 }
 
 extern "C" int64_t lidal_segment_workspace_bytes(int64_t n_entries, int64_t m, int c) {
-  int parts = segment_parts(n_entries, m);
+  int parts = segment_parts(n_entries, m, c);
   return parts > 1 ? (int64_t)m * parts * c * 4 : 0;
 }
 

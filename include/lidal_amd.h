@@ -161,14 +161,16 @@ int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void* wc, int w
  * with Wk laid out [k][co][ci] (reduction dim contiguous), nbr i32 [k, n_out] (-1 = no rule) and
  * row(j) = perm ? perm[j] : j  (pass lidal_kmap_order's perm together with its permuted table and,
  * optionally, its tile_masks, which spare the kernel the mask derivation and the index slices of
- * absent offsets).  No atomics: each output row is written exactly once => bitwise reproducible.
+ * absent offsets).  n_in = rows of `in` (every nbr entry is < n_in; in and Wk are addressed with
+ * 32-bit byte offsets, so each must stay below 2 GiB).  No atomics: each output row is written
+ * exactly once => bitwise reproducible.
  * Optional epilogue (inference: the eval-mode spnn.BatchNorm and ReLU that follow the conv in
  * network/utils.py:110-114,147-155): ep_scale / ep_shift f32 [co] (both or neither; see
  * lidal_bn_fold) give out = act(acc * scale + shift), act = ReLU iff ep_relu. */
 int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const int32_t* perm,
-                     const uint32_t* tile_masks, void* out, int64_t n_out, int ci, int co, int k,
-                     int kflip, int dtype, const float* ep_scale, const float* ep_shift,
-                     int ep_relu, void* stream);
+                     const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out, int ci,
+                     int co, int k, int kflip, int dtype, const float* ep_scale,
+                     const float* ep_shift, int ep_relu, void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
  * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  Split-K: offset k with nk rules is cut into

@@ -44,6 +44,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 constexpr int NWAVES = LIDAL_NWAVES;     // waves per conv_apply workgroup
 constexpr int NTHREADS = 64 * NWAVES;
 
+// 16 raw bytes of a lane's operand fragment: the A fragments travel through the software pipeline
+// in this type (as <8 x bf16> hipcc splits them into halves at every loop-carried value, which
+// also drags the wait for the gather to the top of the phase)
+typedef int raw4 __attribute__((ext_vector_type(4)));
+
 template <typename T> struct DT;
 template <> struct DT<float> {
   static constexpr int VEC = 4;    // elements per 16-byte lane load
@@ -92,6 +97,19 @@ __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b
 // result is first touched by the MFMA (no exec-masked control flow, no early vmcnt waits).
 __device__ __attribute__((aligned(16))) unsigned char g_zero_page[512];
 
+// Diagnostic build only (-DLIDAL_STAMP, scripts/ablate_conv.py): cycle stamps around the four
+// segments of a phase, summed per wave and added into g_stamp at the end of the kernel.  The
+// fences a stamp needs forbid overlaps the real kernel has: read the SHARES, not the run time.
+#ifdef LIDAL_STAMP
+__device__ unsigned long long g_stamp[8];
+#define LIDAL_STAMP_AT(t)                                                          \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");      \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // conv_apply
 // ------------------------------------------------------------------------------------------
@@ -101,6 +119,10 @@ constexpr int MAXK = 32;         // kernel volume limit (27 and 8 on this path)
 #endif
 constexpr int G = LIDAL_G;       // 16-row groups per wave  => BM = 4 waves * G * 16 rows
 constexpr int BM = NWAVES * G * 16;   // output rows per workgroup
+
+#ifndef LIDAL_MINWAVES
+#define LIDAL_MINWAVES(nb) 2      /* 3 for nb <= 6 measured no better (scripts/ablate_conv.py) */
+#endif
 
 // Timing-only ablation builds (scripts/ablate_conv.py): -DLIDAL_ABLATE=<mask> removes one cost at a
 // time; results are wrong by construction.  1: no A gather  2: no weight staging  4: no MFMA
@@ -116,12 +138,12 @@ constexpr int BM = NWAVES * G * 16;   // output rows per workgroup
 // wholly inside the row or wholly masked, which keeps the gathers branch-free and un-serialised
 // (the guarded form made hipcc wait vmcnt(0) after every load).
 template <typename T, int NB, int ROW_BYTES, bool GUARD>
-__global__ void __launch_bounds__(NTHREADS)
+__global__ void __launch_bounds__(NTHREADS, LIDAL_MINWAVES(NB))
 conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
                   const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
                   T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
                   const float* __restrict__ ep_scale, const float* __restrict__ ep_shift,
-                  int ep_relu) {
+                  int ep_relu, unsigned in_bytes, unsigned wk_bytes) {
   constexpr int BN = 16 * NB;
   constexpr int VEC = DT<T>::VEC;
   constexpr int CH = DT<T>::CH;
@@ -186,27 +208,79 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     tmask = tile_mask;
     if (tid < K && (tmask >> tid) & 1u) act_k[__popc(tmask & ((1u << tid) - 1u))] = tid;
   }
+  tmask = __builtin_amdgcn_readfirstlane(tmask);      // wave-uniform: the walk below is scalar
   const int n_act = __popc(tmask);
   const int nphase = n_act * npass;
 
-  // weight slab of phase p -> registers (issue early) -> LDS buffer (write late)
+  // The phases walk the tile's active offsets in ascending k (the set bits of tmask), each offset
+  // in `npass` reduction slices.  The walk lives in scalar registers -- an LDS look-up of the
+  // offset list followed by a dependent LDS read of the neighbour indices would put two LDS round
+  // trips in front of every phase's loads.
+  struct Walk { unsigned rem; int k; int pass; };
+  auto walk_begin = [&]() {
+    Walk w;
+    w.k = tmask ? __builtin_ctz(tmask) : 0;
+    w.rem = tmask & (tmask - 1u);
+    w.pass = 0;
+    return w;
+  };
+  auto walk_next = [&](Walk& w) {
+    if (++w.pass == npass) {
+      w.pass = 0;
+      w.k = w.rem ? __builtin_ctz(w.rem) : 0;      // past the end: any valid slot (result unused)
+      w.rem &= w.rem - 1u;
+    }
+  };
+
+  // Both operand streams are addressed through buffer descriptors: a 32-bit byte offset per lane
+  // (a handful of VALU ops per load instead of 64-bit pointer arithmetic -- address generation was
+  // the longest segment of a phase, profiles/README.md) and a hardware range check that returns
+  // zeros for any offset >= the buffer size, which is how absent rules (offset OOB_OFF) and
+  // channels past the row end are served without branches or loads.
+  constexpr unsigned OOB_OFF = 0x80000000u;      // >= any buffer size accepted by the launcher
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wk =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wk), 0, (int)wk_bytes, 0x00020000);
+
+  // weight slab of offset k, slice c0 -> registers (issue early) -> LDS buffer (write late)
+  // (`live` false: the same loads, all out of range -- see the phase loop)
   frag wreg[WPT];
-  auto stage_load = [&](int p) {
-    const int q = p / npass, c0 = (p - q * npass) * KC;
-    const int k = act_k[q];
+  unsigned woff[WPT];           // per-thread byte offset of its segments inside a slab (or OOB_OFF)
+  int wx[WPT];                  // first reduction element of the segment
+#pragma unroll
+  for (int t = 0; t < WPT; ++t) {
+    const int sidx = tid + t * NTHREADS;
+    const int col = sidx / SEGS, x = (sidx - col * SEGS) * VEC;
+    wx[t] = x;
+    woff[t] = (sidx < BN * SEGS && n0 + col < co && !(LIDAL_ABLATE & 2))
+                  ? (unsigned)((col * ci + x) * (int)sizeof(T)) : OOB_OFF;
+  }
+  // `live` false turns every load of a phase into an out-of-range one by OR-ing the top offset bit;
+  // the value is laundered through an empty asm so that hipcc cannot turn the uniform flag back
+  // into a branch around the loads (which is what makes its wait counts pessimistic, see below)
+  auto kill_bit = [&](bool live) {
+    unsigned kb = live ? 0u : OOB_OFF;
+    asm volatile("" : "+s"(kb));
+    return kb;
+  };
+  auto stage_load = [&](int k, int c0, bool live) {
     const int kc = min(KC, ci - c0);
-    const T* wsrc = wk + ((int64_t)k * co + n0) * ci + c0;
+    const unsigned kill = kill_bit(live);
+    // uniform part of the address: slab k, first column n0, slice c0
+    const unsigned sbase = (unsigned)(((k * co + n0) * ci + c0) * (int)sizeof(T));
 #pragma unroll
     for (int t = 0; t < WPT; ++t) {
-      const int sidx = tid + t * NTHREADS;
-      const int col = sidx / SEGS, x = (sidx - col * SEGS) * VEC;
-      const bool ok = sidx < BN * SEGS && n0 + col < co && x < kc && !(LIDAL_ABLATE & 2);
       if constexpr (GUARD) {
+        const int sidx = tid + t * NTHREADS;
+        const int col = sidx / SEGS;
+        const bool ok = live && woff[t] != OOB_OFF && wx[t] < kc;
+        const T* wsrc = wk + ((int64_t)k * co + n0) * ci + c0;
         wreg[t] = DT<T>::zero();
-        if (ok) wreg[t] = load_frag_guarded<T>(wsrc + (int64_t)col * ci + x, kc - x);
+        if (ok) wreg[t] = load_frag_guarded<T>(wsrc + (int64_t)col * ci + wx[t], kc - wx[t]);
       } else {
-        const T* p = ok ? wsrc + (int64_t)col * ci + x : reinterpret_cast<const T*>(g_zero_page);
-        wreg[t] = *reinterpret_cast<const frag*>(p);
+        const unsigned off = ((wx[t] < kc) ? woff[t] : OOB_OFF) | kill;
+        wreg[t] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs_wk, off, sbase, 0));
       }
     }
   };
@@ -219,26 +293,42 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
       if (sidx < BN * SEGS) *reinterpret_cast<frag*>(dstw + col * WSTRIDE + x) = wreg[t];
     }
   };
-  // A fragments of phase p: for each row group 16 gathered input rows x kc channels, straight to
+  // neighbour indices of this lane's row in each row group for offset k (wave-private LDS slice)
+  auto read_idx = [&](int (&src)[G], int k) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) src[g] = nidx[k * RW + g * 16 + row16];
+  };
+  // A fragments of one phase: for each row group 16 gathered input rows x kc channels, straight to
   // VGPRs (16 B per lane, 64 B contiguous per row); `present` = ballot of rows that have a rule
-  auto load_a = [&](frag (&a)[G][MAXCC], unsigned long long (&present)[G], int p) {
-    const int q = p / npass, c0 = (p - q * npass) * KC;
-    const int k = act_k[q];
+  auto load_a = [&](raw4 (&a)[G][MAXCC], unsigned long long (&present)[G], const int (&idx)[G],
+                    int c0, bool live) {
     const int kc = min(KC, ci - c0);
+    const unsigned row_bytes = (unsigned)(ci * (int)sizeof(T));
+    const unsigned lane_off = (unsigned)((c0 + gsel * VEC) * (int)sizeof(T));
+    const unsigned kill = kill_bit(live);
+    const unsigned long long live_mask = kill ? 0ull : ~0ull;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int src = nidx[k * RW + g * 16 + row16];
-      present[g] = __ballot(src >= 0);
+      const int src = GUARD ? (live ? idx[g] : -1) : idx[g];
+      present[g] = __ballot(src >= 0) & live_mask;
+      if constexpr (GUARD) {
 #pragma unroll
-      for (int cc = 0; cc < MAXCC; ++cc) {
-        const int x = cc * CH + gsel * VEC;
-        const bool ok = src >= 0 && x < kc && !(LIDAL_ABLATE & 1);
-        if constexpr (GUARD) {
-          a[g][cc] = DT<T>::zero();
-          if (ok) a[g][cc] = load_frag_guarded<T>(in + (int64_t)src * ci + c0 + x, kc - x);
-        } else {
-          const T* p = ok ? in + (int64_t)src * ci + c0 + x : reinterpret_cast<const T*>(g_zero_page);
-          a[g][cc] = *reinterpret_cast<const frag*>(p);
+        for (int cc = 0; cc < MAXCC; ++cc) {
+          const int x = cc * CH + gsel * VEC;
+          const bool ok = src >= 0 && x < kc && !(LIDAL_ABLATE & 1);
+          frag f = DT<T>::zero();
+          if (ok) f = load_frag_guarded<T>(in + (int64_t)src * ci + c0 + x, kc - x);
+          a[g][cc] = __builtin_bit_cast(raw4, f);
+        }
+      } else {
+        const unsigned base = ((src >= 0 && !(LIDAL_ABLATE & 1)) ? (unsigned)src * row_bytes + lane_off
+                                                                  : OOB_OFF) | kill;
+#pragma unroll
+        for (int cc = 0; cc < MAXCC; ++cc) {
+          // a chunk past the row end (ci not a multiple of the pass width) is sent out of range
+          const unsigned off = (cc * CH + gsel * VEC < kc) ? base + (unsigned)(cc * CH * (int)sizeof(T))
+                                                           : OOB_OFF;       // (base | kill) + 128 stays OOB
+          a[g][cc] = __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
         }
       }
     }
@@ -251,32 +341,57 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   __syncthreads();            // act_k visible
-  frag a_cur[G][MAXCC], a_nxt[G][MAXCC];
-  unsigned long long pres_cur[G], pres_nxt[G];
+  // Two register sets of A fragments used alternately (no copies): the gathers of phase p+1 are
+  // issued before the MFMAs of phase p and are first waited for by the MFMAs of phase p+1, i.e. a
+  // full phase later, with the weight-slab store and the barrier in between (a register copy at
+  // the end of the phase would make the wave wait for its gathers right there).
+  raw4 a0[G][MAXCC], a1[G][MAXCC];
+  unsigned long long pres0[G], pres1[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) pres_cur[g] = 0ull;
+  for (int g = 0; g < G; ++g) pres0[g] = pres1[g] = 0ull;
+  Walk w1 = walk_begin();       // the phase whose loads are issued next
+  int idx_nxt[G];               // its neighbour indices, read from LDS one phase ahead
+#pragma unroll
+  for (int g = 0; g < G; ++g) idx_nxt[g] = -1;
   if (nphase > 0) {
-    stage_load(0);
+    stage_load(w1.k, 0, true);
     stage_store(0);
-    load_a(a_cur, pres_cur, 0);
+    read_idx(idx_nxt, w1.k);
+    load_a(a0, pres0, idx_nxt, 0, true);
+    walk_next(w1);
+    read_idx(idx_nxt, w1.k);
   }
   __syncthreads();            // slab 0 visible
 
-  for (int p = 0; p < nphase; ++p) {
+#ifdef LIDAL_STAMP
+  unsigned long long st_sum[4] = {0ull, 0ull, 0ull, 0ull};
+#endif
+  auto phase = [&](int p, raw4 (&a_cur)[G][MAXCC], unsigned long long (&pres_cur)[G],
+                   raw4 (&a_nxt)[G][MAXCC], unsigned long long (&pres_nxt)[G]) {
+#ifdef LIDAL_STAMP
+    unsigned long long st0, st1, st2, st3, st4;
+    LIDAL_STAMP_AT(st0);
+#endif
     const int c0 = (p % npass) * KC;
     const int kc = min(KC, ci - c0);
     const T* wbuf = wl + (p & 1) * BN * WSTRIDE;
     const bool more = p + 1 < nphase;
-    // ---- next phase's weight slab and A fragments go in flight before this phase's MFMAs
-    if (more) {
-      stage_load(p + 1);
-      load_a(a_nxt, pres_nxt, p + 1);
-    }
-    // ---- MFMAs: every B fragment read from LDS feeds the G row groups (skipped when a group has
-    //      no rule for this offset); accumulators stay in registers for all K offsets
-    // a wave skips the phase when none of its 32 rows has a rule for this offset; otherwise the
-    // MFMA block is branch-free (per-group skipping cost more in scalar branches than it saved:
-    // profiles/README.md)
+    // ---- next phase's weight slab (first) and A fragments go in flight before this phase's MFMAs.
+    // The last phase issues the same number of loads, aimed at the zero page: with the loads under
+    // `if (more)` hipcc must pick ONE vmcnt for the MFMAs' wait that is safe on the path without
+    // loads, and on the path with loads that count also waits for the 11 loads just issued --
+    // every phase then sat out its own prefetch (profiles/README.md).
+    stage_load(w1.k, w1.pass * KC, more);
+    load_a(a_nxt, pres_nxt, idx_nxt, w1.pass * KC, more);
+    walk_next(w1);
+    read_idx(idx_nxt, w1.k);               // for the phase after next; first used a phase from now
+#ifdef LIDAL_STAMP
+    LIDAL_STAMP_AT(st1);
+#endif
+    // ---- MFMAs: every B fragment read from LDS feeds the G row groups; accumulators stay in
+    //      registers for all K offsets.  A wave skips the phase when none of its 32 rows has a rule
+    //      for this offset; otherwise the MFMA block is branch-free (per-group skipping cost more
+    //      in scalar branches than it saved: profiles/README.md)
     bool any_present = false;
 #pragma unroll
     for (int g = 0; g < G; ++g) any_present |= pres_cur[g] != 0ull;
@@ -289,22 +404,35 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
           for (int nb = 0; nb < NB; ++nb) {
             frag b = *reinterpret_cast<const frag*>(wbase + nb * 16 * WSTRIDE + cc * CH);
 #pragma unroll
-            for (int g = 0; g < G; ++g) mma(acc[g][nb], a_cur[g][cc], b);
+            for (int g = 0; g < G; ++g) mma(acc[g][nb], __builtin_bit_cast(frag, a_cur[g][cc]), b);
           }
         }
       }
     }
-    if (more) {
-      stage_store((p + 1) & 1);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        pres_cur[g] = pres_nxt[g];
-#pragma unroll
-        for (int cc = 0; cc < MAXCC; ++cc) a_cur[g][cc] = a_nxt[g][cc];
-      }
-    }
+#ifdef LIDAL_STAMP
+    LIDAL_STAMP_AT(st2);
+#endif
+    if (more) stage_store((p + 1) & 1);     // waits for the slab loads only: they were issued first
+#ifdef LIDAL_STAMP
+    LIDAL_STAMP_AT(st3);
+#endif
     __syncthreads();
+#ifdef LIDAL_STAMP
+    LIDAL_STAMP_AT(st4);
+    st_sum[0] += st1 - st0; st_sum[1] += st2 - st1; st_sum[2] += st3 - st2; st_sum[3] += st4 - st3;
+#endif
+  };
+  for (int p = 0; p < nphase; p += 2) {
+    phase(p, a0, pres0, a1, pres1);
+    if (p + 1 < nphase) phase(p + 1, a1, pres1, a0, pres0);
   }
+#ifdef LIDAL_STAMP
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_stamp[i], st_sum[i]);
+    atomicAdd(&g_stamp[4], (unsigned long long)nphase);
+  }
+#endif
 
   // ---- epilogue: accumulators (D layout: col = lane&15, row = 4*(lane>>4) + r) -> wave-private
   //      LDS tile in T -> whole rows to HBM with 16-byte stores
@@ -349,7 +477,7 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   }
 }
 
-struct Epi { const float* scale; const float* shift; int relu; };
+struct Epi { const float* scale; const float* shift; int relu; unsigned in_bytes, wk_bytes; };
 
 template <typename T, int NB, int ROW_BYTES, bool GUARD>
 int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm,
@@ -371,7 +499,8 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
   }
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
   kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, perm, tmasks, (T*)out, n_out,
-                                   ci, co, K, kflip, ep.scale, ep.shift, ep.relu);
+                                   ci, co, K, kflip, ep.scale, ep.shift, ep.relu, ep.in_bytes,
+                                   ep.wk_bytes);
   LIDAL_CHECK_LAUNCH("lidal_conv_apply");
   return 0;
 }
@@ -797,6 +926,18 @@ int dispatch_wgrad(const void* a, const void* b, const int* pairs, const int64_t
 
 }  // namespace
 
+#ifdef LIDAL_STAMP
+extern "C" int lidal_debug_stamps(unsigned long long* out8, int reset) {
+  LIDAL_HIP(hipDeviceSynchronize());
+  LIDAL_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    LIDAL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)));
+  }
+  return 0;
+}
+#endif
+
 extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void* wc, int wt_dtype,
                                       int k, int ci, int co, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -820,13 +961,17 @@ extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void
 
 extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr,
                                 const int32_t* perm, const uint32_t* tile_masks, void* out,
-                                int64_t n_out, int ci, int co, int k, int kflip, int dtype,
-                                const float* ep_scale, const float* ep_shift, int ep_relu,
-                                void* stream) {
+                                int64_t n_in, int64_t n_out, int ci, int co, int k, int kflip,
+                                int dtype, const float* ep_scale, const float* ep_shift,
+                                int ep_relu, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out == 0 || co == 0) return 0;
   LIDAL_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv_apply: scale and shift go together");
-  Epi ep{ep_scale, ep_shift, ep_relu};
+  const int64_t esz = dtype == LIDAL_BF16 ? 2 : 4;
+  LIDAL_REQUIRE(n_in >= 0 && n_in * ci * esz < 0x7FFFFFF0ll && (int64_t)k * ci * co * esz < 0x7FFFFFF0ll,
+                "conv_apply: the input matrix (%lld rows x %d) and the weights must each stay below "
+                "2 GiB (32-bit buffer addressing)", (long long)n_in, ci);
+  Epi ep{ep_scale, ep_shift, ep_relu, (unsigned)(n_in * ci * esz), (unsigned)((int64_t)k * ci * co * esz)};
   static_assert(BM == 128, "tile masks from lidal_kmap_order are per 128 rows");
   LIDAL_REQUIRE(ci > 0 && k > 0 && k <= MAXK, "conv_apply: bad shape ci=%d k=%d", ci, k);
   if (dtype == LIDAL_F32) {

@@ -179,7 +179,8 @@ def _apply(feats, wk, order, kflip, epilogue=None):
     out = torch.empty((n_out, co), dtype=feats.dtype, device=feats.device)
     scale, shift, relu = epilogue if epilogue is not None else (None, None, False)
     B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
-                                     B.ptr(order.tile_masks), B.ptr(out), n_out, ci, co, k, int(kflip),
+                                     B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci, co, k,
+                                     int(kflip),
                                      B.dtype_code(feats.dtype), B.ptr(scale), B.ptr(shift),
                                      int(bool(relu)), B.stream()), 'conv_apply')
     return out

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'scripts', '_abl')
-VARIANTS = {'base': [], 'skeleton': ['-DLIDAL_ABLATE=7']}
+VARIANTS = {'base': [], 'mw2': ['-DLIDAL_MINWAVES(nb)=2'], 'skeleton': ['-DLIDAL_ABLATE=7']}
 # (level stride, ci, co): the heavy layer families of the U-Net
 SHAPES = [(1, 32, 32), (1, 96, 96), (2, 32, 32), (4, 128, 128), (4, 64, 64), (8, 256, 256),
           (8, 384, 256), (16, 256, 256)]
@@ -57,15 +57,16 @@ def run():
         out = torch.empty((n, co), dtype=dtype, device='cuda')
         row = 's%d %d->%d (%dk,%dk)' % (stride, ci, co, n // 1000, kmap.total // 1000)
         times = []
+        stamps = ''
         order = kmap.order_out
         for name, fn in [(n_ + m_, f_) for n_, f_ in libs.items() for m_ in ('+sort',)]:
             tab, prm, tmk = ((order.table, order.perm, order.tile_masks) if name.endswith('+sort')
                              else (kmap.nbr_out, None, None))
             def launch():
-                rc = fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n, ci, co, 27, 0,
+                rc = fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n, n, ci, co, 27, 0,
                         B.dtype_code(dtype), None, None, 0, B.stream())
                 assert rc == 0
-            if fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n, ci, co, 27, 0,
+            if fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n, n, ci, co, 27, 0,
                   B.dtype_code(dtype), None, None, 0, B.stream()) != 0:
                 times.append(float('nan'))
                 continue
@@ -79,7 +80,15 @@ def run():
             e1.record()
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) * 200)
-        print('%-22s' % row + ''.join('%11.1f' % t for t in times))
+            if name.startswith('stamp'):
+                lib = ctypes.CDLL(os.path.join(OUT, 'conv_stamp.so'))
+                buf = (ctypes.c_ulonglong * 8)()
+                lib.lidal_debug_stamps(buf, 1)
+                tot = sum(buf[:4]) or 1
+                stamps = '   [wave-phase cycles: issue %.0f  mfma %.0f  store %.0f  barrier %.0f | shares %s]' % (
+                    buf[0] / max(buf[4], 1), buf[1] / max(buf[4], 1), buf[2] / max(buf[4], 1),
+                    buf[3] / max(buf[4], 1), ' '.join('%.0f%%' % (100 * b / tot) for b in buf[:4]))
+        print('%-22s' % row + ''.join('%11.1f' % t for t in times) + (stamps if 'stamp' in VARIANTS else ''))
 
 
 if __name__ == '__main__':

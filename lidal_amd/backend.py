@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblidal_amd.so')
+LIB_PATH = os.environ.get('LIDAL_AMD_LIB') or os.path.join(_HERE, 'liblidal_amd.so')    # override: A/B builds
 
 F32, BF16 = 0, 1
 _lib = None

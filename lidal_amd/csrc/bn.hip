@@ -13,8 +13,11 @@ using namespace lidal;
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAX_ROWS_PER_WG = 512;   // rows per workgroup (one statistics partial each) ...
-constexpr int MIN_ROWS_PER_WG = 32;    // ... shrunk on short matrices so a launch still fills the chip
+#ifndef LIDAL_BN_UNR
+#define LIDAL_BN_UNR 4
+#endif
+constexpr int UNR = LIDAL_BN_UNR;      // row loads in flight per thread (per operand)
+constexpr int MIN_ROWS_PER_WG = 32;    // rows per workgroup (one statistics partial each), at least
 
 template <typename T> struct IO;
 template <> struct IO<float> {
@@ -89,13 +92,13 @@ __global__ void __launch_bounds__(NT) bn_stats_partial_kernel(const T* __restric
   if (rl < rpi) {
     IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r_beg * c + cg * VEC), shift);
     int64_t r = r_beg + rl;
-    for (; r + 3 * rpi < r_end; r += 4 * rpi) {        // 4 independent 16-byte loads in flight
-      typename IO<T>::vec v[4];
+    for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {        // UNR independent 16-byte loads in flight
+      typename IO<T>::vec v[UNR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < UNR; ++u)
         v[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         float f[VEC];
         IO<T>::unpack(v[u], f);
 #pragma unroll
@@ -206,13 +209,13 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
     *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
   };
   int64_t r = r_beg + rl;
-  for (; r + 3 * rpi < r_end; r += 4 * rpi) {
-    typename IO<T>::vec v[4];
+  for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
+    typename IO<T>::vec v[UNR];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < UNR; ++u)
       v[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) one(v[u], r + u * rpi);
+    for (int u = 0; u < UNR; ++u) one(v[u], r + u * rpi);
   }
   for (; r < r_end; r += rpi)
     one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), r);
@@ -255,15 +258,15 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
       }
     };
     int64_t r = r_beg + rl;
-    for (; r + 3 * rpi < r_end; r += 4 * rpi) {
-      typename IO<T>::vec vx[4], vd[4];
+    for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
+      typename IO<T>::vec vx[UNR], vd[UNR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
         vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * c + cg * VEC);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) one(vx[u], vd[u]);
+      for (int u = 0; u < UNR; ++u) one(vx[u], vd[u]);
     }
     for (; r < r_end; r += rpi)
       one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
@@ -347,34 +350,32 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
     *reinterpret_cast<typename IO<T>::vec*>(dx + r * c + cg * VEC) = IO<T>::pack(fd);
   };
   int64_t r = r_beg + rl;
-  for (; r + 3 * rpi < r_end; r += 4 * rpi) {
-    typename IO<T>::vec vx[4], vd[4];
+  for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
+    typename IO<T>::vec vx[UNR], vd[UNR];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
       vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * c + cg * VEC);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) one(vx[u], vd[u], r + u * rpi);
+    for (int u = 0; u < UNR; ++u) one(vx[u], vd[u], r + u * rpi);
   }
   for (; r < r_end; r += rpi)
     one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
         *reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), r);
 }
 
-static inline int rows_per_wg(int64_t n) {
-  // reducing kernels pay a fixed LDS tree per workgroup: aim for >= 256 slabs (measured on the
-  // SPVCNN step: 256 beats both 1 slab size for all levels and >= 1024)
-  int rpw = MIN_ROWS_PER_WG;
-  while (rpw < MAX_ROWS_PER_WG && (int64_t)rpw * 256 < n) rpw <<= 1;
-  return rpw;
+// Slab size = rows / 256: one workgroup per CU on every level.  Each workgroup pays a fixed set-up
+// (per-channel parameters, and an LDS tree in the reducing kernels), so fewer and larger slabs win
+// as long as every CU has one; and an equal share per CU matters: with 512-row slabs the 396k-row
+// level ran as 775 workgroups, 3.03 per CU (measured sweep: profiles/README.md).
+static inline int slab_rows(int64_t n) {
+  int64_t rpw = (n + 255) / 256;
+  if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
+  return (int)rpw;
 }
-// the purely elementwise kernels (apply, dx) carry no per-workgroup reduction: finer slabs
-static inline int rows_per_wg_ew(int64_t n) {
-  int rpw = MIN_ROWS_PER_WG;
-  while (rpw < MAX_ROWS_PER_WG && (int64_t)rpw * 1024 < n) rpw <<= 1;
-  return rpw;
-}
+static inline int rows_per_wg(int64_t n) { return slab_rows(n); }
+static inline int rows_per_wg_ew(int64_t n) { return slab_rows(n); }
 static inline int nslabs_ew(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg_ew(n)); }
 static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg(n)); }
 template <typename T>

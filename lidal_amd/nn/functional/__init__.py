@@ -6,10 +6,10 @@ from .devoxelize import calc_ti_weights, spdevoxelize, ti_weights_and_index
 from .downsample import spdownsample, unique_sorted
 from .fused import add_relu, cross_entropy
 from .hash import sphash
-from .query import HashTable, sphashquery
+from .query import HashTable, coords_table, sphashquery
 from .voxelize import spvoxelize
 
-__all__ = ['sphash', 'sphashquery', 'HashTable', 'spcount', 'spvoxelize', 'spdevoxelize',
+__all__ = ['sphash', 'sphashquery', 'HashTable', 'coords_table', 'spcount', 'spvoxelize', 'spdevoxelize',
            'calc_ti_weights', 'ti_weights_and_index', 'spdownsample', 'unique_sorted', 'conv3d',
            'add_relu', 'cross_entropy',
            'KernelMap', 'build_kernel_map']

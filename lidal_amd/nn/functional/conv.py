@@ -21,7 +21,7 @@ from ...utils import make_ntuple
 from ..utils import get_kernel_offsets
 from .downsample import spdownsample
 from .hash import sphash
-from .query import HashTable
+from .query import coords_table
 
 __all__ = ['conv3d', 'KernelMap', 'RowOrder', 'build_kernel_map', 'prefetch_kernel_maps']
 
@@ -103,7 +103,7 @@ def build_kernel_map(coords, in_stride, kernel_size, stride):
     dev = coords.device
     offsets = get_kernel_offsets(kernel_size, stride=in_stride, device=dev)
     volume = offsets.shape[0]
-    table = HashTable(sphash(coords))
+    table = coords_table(coords)
     out_coords = coords
     if any(s > 1 for s in stride):
         out_coords = spdownsample(coords, stride, kernel_size, in_stride)

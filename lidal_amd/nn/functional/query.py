@@ -5,7 +5,7 @@ import torch
 
 from ... import backend as B
 
-__all__ = ['sphashquery', 'HashTable']
+__all__ = ['sphashquery', 'HashTable', 'coords_table']
 
 
 class HashTable:
@@ -34,3 +34,18 @@ class HashTable:
 
 def sphashquery(queries, references):
     return HashTable(references).query(queries)
+
+
+def coords_table(coords):
+    """HashTable over sphash(coords) for an int32 [N, 4] coordinate tensor, built once per tensor
+    and cached ON it (keyed by its version counter): the kernel-map builds and the point<->voxel
+    look-ups of one level all probe the same table, and the level's coordinate tensor is one shared
+    object (SparseTensor.cmaps)."""
+    from .hash import sphash
+    key = (coords._version, coords.data_ptr(), coords.shape[0])
+    cached = getattr(coords, '_lidal_table', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    table = HashTable(sphash(coords))
+    coords._lidal_table = (key, table)
+    return table

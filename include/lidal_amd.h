@@ -192,10 +192,12 @@ int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs, const i
 int64_t lidal_bn_workspace_bytes(int64_t n, int c);
 /* `relu` != 0 fuses the ReLU that follows the normalisation in the model (forward: max(y, 0);
  * backward: dy is taken where y > 0, y recomputed from x). */
+/* num_batches_tracked (nn.BatchNorm1d's i64 scalar buffer, may be NULL) is incremented by one. */
 int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean,
-                       float* running_var, int relu, void* y, float* save_mean, float* save_invstd,
-                       void* ws, int64_t ws_bytes, void* stream);
+                       float* running_var, int64_t* num_batches_tracked, int relu, void* y,
+                       float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
+                       void* stream);
 int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                       const float* beta, const float* running_mean, const float* running_var,
                       float eps, int relu, void* y, void* stream);

@@ -139,8 +139,10 @@ __global__ void __launch_bounds__(NT) bn_stats_final_kernel(const float* __restr
                                                             float* __restrict__ mean,
                                                             float* __restrict__ invstd,
                                                             float* __restrict__ running_mean,
-                                                            float* __restrict__ running_var) {
+                                                            float* __restrict__ running_var,
+                                                            long long* __restrict__ num_batches) {
   __shared__ float sn[NT], sm[NT], sq[NT];
+  if (num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches += 1;
   const int tid = threadIdx.x, cl = tid & 7, pl = tid >> 3;      // 8 channels x 32 lanes
   const int ch = blockIdx.x * 8 + cl;
   float na = 0.f, ma = 0.f, qa = 0.f;
@@ -380,15 +382,15 @@ static inline int nslabs_ew(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_pe
 static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg(n)); }
 template <typename T>
 int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-                 float momentum, float* rm, float* rv, int relu, void* y, float* mean,
-                 float* invstd, float* part, hipStream_t s) {
+                 float momentum, float* rm, float* rv, long long* nbt, int relu, void* y,
+                 float* mean, float* invstd, float* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
   bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>((const T*)x, n, c, part,
                                                                            rows_per_wg(n));
   LIDAL_CHECK_LAUNCH("bn_stats_partial");
   bn_stats_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
-                                                             invstd, rm, rv);
+                                                             invstd, rm, rv, nbt);
   LIDAL_CHECK_LAUNCH("bn_stats_final");
   bn_apply_kernel<T, false><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma,
                                                         beta, eps, relu, (T*)y, rows_per_wg_ew(n));
@@ -447,7 +449,8 @@ extern "C" int64_t lidal_bn_workspace_bytes(int64_t n, int c) {
 
 extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                                   const float* beta, float eps, float momentum,
-                                  float* running_mean, float* running_var, int relu, void* y,
+                                  float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, int relu, void* y,
                                   float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
                                   void* stream) {
   if (int rc = bn_check(n, c, dtype)) return rc;
@@ -456,9 +459,11 @@ extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, co
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
     return bn_train_fwd<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var,
-                               relu, y, save_mean, save_invstd, (float*)ws, s);
-  return bn_train_fwd<__bf16>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, relu,
-                              y, save_mean, save_invstd, (float*)ws, s);
+                               (long long*)num_batches_tracked, relu, y, save_mean, save_invstd,
+                               (float*)ws, s);
+  return bn_train_fwd<__bf16>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var,
+                              (long long*)num_batches_tracked, relu, y, save_mean, save_invstd,
+                              (float*)ws, s);
 }
 
 extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,

@@ -87,11 +87,9 @@ class BatchNorm1d(nn.BatchNorm1d):
                 or self.momentum is None):
             out = super().forward(feats)
             return torch.relu(out) if self.fused_relu else out
-        if self.training:
-            self.num_batches_tracked.add_(1)
         return norm.batch_norm_rows(feats, self.weight, self.bias, self.running_mean,
                                     self.running_var, self.training, self.momentum, self.eps,
-                                    self.fused_relu)
+                                    self.fused_relu, self.num_batches_tracked)
 
 
 class BatchNorm(BatchNorm1d):

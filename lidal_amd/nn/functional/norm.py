@@ -29,7 +29,8 @@ def _ws(n, c, dev):
 
 class BatchNormRows(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu,
+                num_batches_tracked=None):
         x = x.contiguous()
         n, c = x.shape
         dev = x.device
@@ -42,7 +43,8 @@ class BatchNormRows(Function):
             ws, nbytes = _ws(n, c, dev)
             B.check(B.lib().lidal_bn_train_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
                                                float(momentum), B.ptr(running_mean),
-                                               B.ptr(running_var), int(relu), B.ptr(y), B.ptr(mean),
+                                               B.ptr(running_var), B.ptr(num_batches_tracked), int(relu),
+                                               B.ptr(y), B.ptr(mean),
                                                B.ptr(invstd), B.ptr(ws), nbytes, B.stream()),
                     'bn_train_fwd')
         else:
@@ -67,7 +69,7 @@ class BatchNormRows(Function):
             if ctx.relu:
                 gf = gf * ((xhat * w + b) > 0)
             return ((gf * (w * invstd)).to(x.dtype), (gf * xhat).sum(0), gf.sum(0), None, None,
-                    None, None, None, None)
+                    None, None, None, None, None)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         gg = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -77,11 +79,12 @@ class BatchNormRows(Function):
                                      B.ptr(b), int(ctx.relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),
                                      B.ptr(gg), B.ptr(gb),
                                      B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
-        return dx, gg, gb, None, None, None, None, None, None
+        return dx, gg, gb, None, None, None, None, None, None, None
 
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                    relu=False):
+                    relu=False, num_batches_tracked=None):
+    """`num_batches_tracked` (i64 scalar buffer, training only) is incremented inside the kernel."""
     if not training and not B.wants_grad(x, weight, bias):      # inference: one kernel, no node
         x = x.contiguous()
         y = torch.empty_like(x)
@@ -91,7 +94,7 @@ def batch_norm_rows(x, weight, bias, running_mean, running_var, training, moment
                                           B.stream()), 'bn_eval_fwd')
         return y
     return BatchNormRows.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                               relu)
+                               relu, num_batches_tracked if training else None)
 
 
 def column_sum(x):

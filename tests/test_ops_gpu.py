@@ -545,3 +545,20 @@ def test_conv_affine_relu_epilogue(dtype):
             assert _relerr(fused.cpu(), ref.cpu()) < tol
             if relu:
                 assert (fused >= 0).all()
+
+
+def test_batchnorm_module_counts_batches_in_kernel():
+    """spnn.BatchNorm1d.num_batches_tracked is incremented by the statistics kernel (no separate
+    launch) in training mode only, exactly as nn.BatchNorm1d counts."""
+    from lidal_amd import nn as spnn
+    bn = spnn.BatchNorm1d(32).to(DEV)
+    x = torch.randn(1000, 32, device=DEV)
+    bn.train()
+    for _ in range(3):
+        bn(x)
+    assert int(bn.num_batches_tracked.item()) == 3
+    bn.eval()
+    bn(x)
+    with torch.no_grad():
+        bn(x)
+    assert int(bn.num_batches_tracked.item()) == 3

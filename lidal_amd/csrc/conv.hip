@@ -38,11 +38,24 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-#ifndef LIDAL_NWAVES
-#define LIDAL_NWAVES 4
+// conv_apply workgroup shape, chosen per output-column width NB (16-column blocks per workgroup):
+// NW waves x G 16-row groups per wave = 128 output rows either way.  8 waves x 1 group (half the
+// accumulators and A fragments per wave, twice the waves to hide the gathers) wins for the 64- and
+// 96-column kernels, 4 waves x 2 groups (each weight fragment read from LDS feeds two MFMAs)
+// elsewhere in bf16 (scripts/ablate_conv.py: 96->96 137.9 -> 127.3 us, 64->64 35.7 -> 34.5, but 32->32
+// 45.7 -> 47.4 and 256->256 at stride 16 106 -> 112); the f32 kernels (MFMA-bound, 4x the MFMA
+// issue slots per fragment) gain 6-19 % from 8 x 1 at every width.  -DLIDAL_G / -DLIDAL_NWAVES force
+// one shape.
+#if defined(LIDAL_G) && defined(LIDAL_NWAVES)
+constexpr int conv_groups(int, bool) { return LIDAL_G; }
+constexpr int conv_waves(int, bool) { return LIDAL_NWAVES; }
+#elif defined(LIDAL_G)
+constexpr int conv_groups(int, bool) { return LIDAL_G; }
+constexpr int conv_waves(int, bool) { return 4; }
+#else
+constexpr int conv_groups(int nb, bool f32) { return (f32 || nb == 4 || nb == 6) ? 1 : 2; }
+constexpr int conv_waves(int nb, bool f32) { return (f32 || nb == 4 || nb == 6) ? 8 : 4; }
 #endif
-constexpr int NWAVES = LIDAL_NWAVES;     // waves per conv_apply workgroup
-constexpr int NTHREADS = 64 * NWAVES;
 
 // 16 raw bytes of a lane's operand fragment: the A fragments travel through the software pipeline
 // in this type (as <8 x bf16> hipcc splits them into halves at every loop-carried value, which
@@ -114,11 +127,6 @@ __device__ unsigned long long g_stamp[8];
 // conv_apply
 // ------------------------------------------------------------------------------------------
 constexpr int MAXK = 32;         // kernel volume limit (27 and 8 on this path)
-#ifndef LIDAL_G
-#define LIDAL_G 2
-#endif
-constexpr int G = LIDAL_G;       // 16-row groups per wave  => BM = 4 waves * G * 16 rows
-constexpr int BM = NWAVES * G * 16;   // output rows per workgroup
 
 #ifndef LIDAL_MINWAVES
 #define LIDAL_MINWAVES(nb) 2      /* 3 for nb <= 6 measured no better (scripts/ablate_conv.py) */
@@ -137,13 +145,15 @@ constexpr int BM = NWAVES * G * 16;   // output rows per workgroup
 // loads then fall back to element-wise guarded code.  Everywhere else every lane load is either
 // wholly inside the row or wholly masked, which keeps the gathers branch-free and un-serialised
 // (the guarded form made hipcc wait vmcnt(0) after every load).
-template <typename T, int NB, int ROW_BYTES, bool GUARD>
-__global__ void __launch_bounds__(NTHREADS, LIDAL_MINWAVES(NB))
+template <typename T, int NB, int ROW_BYTES, bool GUARD, int G, int NWAVES>
+__global__ void __launch_bounds__(64 * NWAVES, LIDAL_MINWAVES(NB))
 conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
                   const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
                   T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
                   const float* __restrict__ ep_scale, const float* __restrict__ ep_shift,
                   int ep_relu, unsigned in_bytes, unsigned wk_bytes) {
+  constexpr int NTHREADS = 64 * NWAVES;
+  constexpr int BM = NWAVES * G * 16;                   // output rows per workgroup
   constexpr int BN = 16 * NB;
   constexpr int VEC = DT<T>::VEC;
   constexpr int CH = DT<T>::CH;
@@ -177,7 +187,7 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   if (tmasks != nullptr) {
     // ---- 0a. occupancy mask of this 128-row tile, precomputed with the row order (one load);
     //          only the offsets it names are fetched, staged and multiplied
-    unsigned m = tmasks[blockIdx.x];
+    unsigned m = tmasks[((int64_t)blockIdx.x * BM) >> 7];     // masks are per 128 sorted rows
     if (kflip) m = __brev(m) >> (32 - K);
     tmask = m;
     if (tid < K && (m >> tid) & 1u) act_k[__popc(m & ((1u << tid) - 1u))] = tid;
@@ -483,6 +493,10 @@ template <typename T, int NB, int ROW_BYTES, bool GUARD>
 int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm,
                       const unsigned* tmasks, void* out, int64_t n_out, int ci, int co, int K,
                       int kflip, Epi ep, hipStream_t s) {
+  constexpr bool F32 = sizeof(T) == 4;
+  constexpr int G = conv_groups(NB, F32), NWAVES = conv_waves(NB, F32);
+  constexpr int NTHREADS = 64 * NWAVES, BM = NWAVES * G * 16;
+  static_assert(BM == 128 || BM == 64, "tile masks from lidal_kmap_order are per 128 rows");
   constexpr int BN = 16 * NB;
   constexpr int KC = ROW_BYTES / (int)sizeof(T);
   constexpr int WSTRIDE = KC + DT<T>::VEC;
@@ -490,7 +504,7 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
   constexpr int WREGION = (2 * BN * WSTRIDE > NWAVES * G * 16 * ESTRIDE) ? 2 * BN * WSTRIDE
                                                                            : NWAVES * G * 16 * ESTRIDE;
   const size_t lds = sizeof(T) * WREGION + (size_t)NWAVES * K * G * 16 * sizeof(int);
-  auto kern = conv_apply_kernel<T, NB, ROW_BYTES, GUARD>;
+  auto kern = conv_apply_kernel<T, NB, ROW_BYTES, GUARD, G, NWAVES>;
   static size_t attr_set = 0;
   if (attr_set < lds) {
     LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -972,7 +986,6 @@ extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* n
                 "conv_apply: the input matrix (%lld rows x %d) and the weights must each stay below "
                 "2 GiB (32-bit buffer addressing)", (long long)n_in, ci);
   Epi ep{ep_scale, ep_shift, ep_relu, (unsigned)(n_in * ci * esz), (unsigned)((int64_t)k * ci * co * esz)};
-  static_assert(BM == 128, "tile masks from lidal_kmap_order are per 128 rows");
   LIDAL_REQUIRE(ci > 0 && k > 0 && k <= MAXK, "conv_apply: bad shape ci=%d k=%d", ci, k);
   if (dtype == LIDAL_F32) {
     LIDAL_REQUIRE(ci % 4 == 0 && co % 4 == 0, "conv_apply f32: channels must be multiples of 4");

@@ -75,8 +75,9 @@ SIGNATURES = {
     'lidal_nn_grid_bytes': (_i64, [_i64]),
     'lidal_nn_grid_workspace_bytes': (_i64, [_i64]),
     'lidal_nn_grid_build': (_i32, [_vp, _i64, _f64, _vp, _i64, _vp, _i64, _vp]),
+    'lidal_interframe_workspace_bytes': (_i64, [_i64, _i32]),
     'lidal_interframe_score': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp,
-                                      _vp, _vp, _vp]),
+                                      _vp, _vp, _vp, _i64, _vp]),
     'lidal_supervoxel_reduce': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
 }
 

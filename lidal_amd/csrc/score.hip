@@ -225,13 +225,44 @@ struct NeiArgs {
   int n;
 };
 
+__device__ __forceinline__ GridView nei_grid(const NeiArgs& nei, int n, double cell) {
+  GridView g;
+  char* base = (char*)nei.grid[n] + 64;
+  g.t.keys = (unsigned long long*)base;
+  g.t.vals = (int*)(base + nei.cap[n] * 8);
+  g.t.mask = (uint64_t)nei.cap[n] - 1;
+  g.keys = (const uint64_t*)(base + nei.cap[n] * 12);
+  g.idx = (const int*)(base + nei.cap[n] * 12 + ((8 * nei.p[n] + 255) / 256) * 256);
+  g.p = nei.p[n];
+  g.cell = cell;
+  return g;
+}
+
+// Stage 1: one thread per (neighbour frame, query point): the nearest point of that frame within
+// the match radius, or -1.  The 24 (or 10) look-ups of a query point are independent, so they run
+// as p * n_nei threads instead of one serial chain of 27 * n_nei hash probes per point.
 __global__ void __launch_bounds__(256)
-interframe_kernel(const double* __restrict__ q_pts, const float* __restrict__ q_prob, int64_t p,
-                  int c, NeiArgs nei, double dis_thresh, double* __restrict__ interd,
+interframe_match_kernel(const double* __restrict__ q_pts, int64_t p, NeiArgs nei, double dis_thresh,
+                        int* __restrict__ match /*[n_nei][p]*/) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (i >= p) return;
+  const double qx = q_pts[i * 3 + 0], qy = q_pts[i * 3 + 1], qz = q_pts[i * 3 + 2];
+  const GridView g = nei_grid(nei, n, dis_thresh);
+  double d2;
+  int j = grid_nearest(g, nei.pts[n], qx, qy, qz, &d2);
+  if (j >= 0 && !(sqrt(d2) <= dis_thresh)) j = -1;
+  match[(int64_t)n * p + i] = j;
+}
+
+// Stage 2: one thread per query point walks its matches in the reference's neighbour order and
+// accumulates with numpy's widths and summation orders.
+__global__ void __launch_bounds__(256)
+interframe_kernel(const float* __restrict__ q_prob, int64_t p, int c, NeiArgs nei,
+                  const int* __restrict__ match, double* __restrict__ interd,
                   float* __restrict__ intere, int* __restrict__ map_count) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p) return;
-  const double qx = q_pts[i * 3 + 0], qy = q_pts[i * 3 + 1], qz = q_pts[i * 3 + 2];
   float q[MAXC], sum[MAXC];
 #pragma unroll
   for (int j = 0; j < MAXC; ++j) {
@@ -242,20 +273,8 @@ interframe_kernel(const double* __restrict__ q_pts, const float* __restrict__ q_
   double div = 0.0;
   int cnt = 0;
   for (int n = 0; n < nei.n; ++n) {
-    GridView g;
-    {
-      char* base = (char*)nei.grid[n] + 64;
-      g.t.keys = (unsigned long long*)base;
-      g.t.vals = (int*)(base + nei.cap[n] * 8);
-      g.t.mask = (uint64_t)nei.cap[n] - 1;
-      g.keys = (const uint64_t*)(base + nei.cap[n] * 12);
-      g.idx = (const int*)(base + nei.cap[n] * 12 + ((8 * nei.p[n] + 255) / 256) * 256);
-      g.p = nei.p[n];
-      g.cell = dis_thresh;
-    }
-    double d2;
-    int j = grid_nearest(g, nei.pts[n], qx, qy, qz, &d2);
-    if (j < 0 || !(sqrt(d2) <= dis_thresh)) continue;
+    const int j = match[(int64_t)n * p + i];
+    if (j < 0) continue;
     const float* np = nei.prob[n] + (int64_t)j * c;
     float term[MAXC];
 #pragma unroll
@@ -388,15 +407,22 @@ extern "C" int lidal_nn_grid_build(const double* pts, int64_t p, double cell, vo
   return 0;
 }
 
+extern "C" int64_t lidal_interframe_workspace_bytes(int64_t p, int n_nei) {
+  return (int64_t)(n_nei > 0 ? n_nei : 1) * (p > 0 ? p : 1) * 4 + 256;
+}
+
 extern "C" int lidal_interframe_score(const double* q_pts, const float* q_prob, int64_t p, int c,
                                       const void* const* nei_grids_host,
                                       const double* const* nei_pts_host,
                                       const float* const* nei_prob_host, const int64_t* nei_p_host,
                                       int n_nei, double dis_thresh, double* interd, float* intere,
-                                      int32_t* map_count, void* stream) {
+                                      int32_t* map_count, void* ws, int64_t ws_bytes,
+                                      void* stream) {
   LIDAL_REQUIRE(c > 0 && c <= MAXC, "interframe_score: classes must be in 1..%d", MAXC);
   LIDAL_REQUIRE(n_nei >= 0 && n_nei <= MAXNEI, "interframe_score: at most %d neighbours", MAXNEI);
   if (p == 0) return 0;
+  LIDAL_REQUIRE(ws_bytes >= lidal_interframe_workspace_bytes(p, n_nei), "interframe workspace too small");
+  int* match = (int*)ws;
   NeiArgs a;
   memset(&a, 0, sizeof(a));
   a.n = n_nei;
@@ -407,8 +433,14 @@ extern "C" int lidal_interframe_score(const double* q_pts, const float* q_prob, 
     a.p[n] = nei_p_host[n];
     a.cap[n] = grid_cap(nei_p_host[n] > 0 ? nei_p_host[n] : 1);
   }
-  interframe_kernel<<<(unsigned)cdiv(p, 256), 256, 0, (hipStream_t)stream>>>(
-      q_pts, q_prob, p, c, a, dis_thresh, interd, intere, map_count);
+  hipStream_t s = (hipStream_t)stream;
+  if (n_nei > 0) {
+    interframe_match_kernel<<<dim3((unsigned)cdiv(p, 256), (unsigned)n_nei), 256, 0, s>>>(
+        q_pts, p, a, dis_thresh, match);
+    LIDAL_CHECK_LAUNCH("interframe_match");
+  }
+  interframe_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(q_prob, p, c, a, match, interd, intere,
+                                                           map_count);
   LIDAL_CHECK_LAUNCH("lidal_interframe_score");
   return 0;
 }

@@ -83,9 +83,12 @@ def score_points(bank, i, nei_num=24):
     n_arr = (ctypes.c_int64 * len(nei))(*[bank.world[n].shape[0] for n in nei])
     for n in nei:
         assert bank.prob[n].shape[1] == c
+    ws_bytes = B.lib().lidal_interframe_workspace_bytes(p, len(nei))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     B.check(B.lib().lidal_interframe_score(B.ptr(q_pts), B.ptr(q_prob), p, c, g_arr, p_arr, f_arr,
                                            n_arr, len(nei), bank.dis_thresh, B.ptr(interd),
-                                           B.ptr(intere), B.ptr(count), B.stream()),
+                                           B.ptr(intere), B.ptr(count), B.ptr(ws), ws_bytes,
+                                           B.stream()),
             'interframe_score')
     return interd, intere, count
 

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'scripts', '_abl')
-VARIANTS = {'base': [], 'g2w4': ['-DLIDAL_G=2', '-DLIDAL_NWAVES=4'], 'g1w8': ['-DLIDAL_G=1', '-DLIDAL_NWAVES=8']}
+VARIANTS = {'base': [], 'rowb256': ['-DLIDAL_ROWB_OVERRIDE=256'], 'base2': []}
 # (level stride, ci, co): the heavy layer families of the U-Net
 SHAPES = [(1, 32, 32), (1, 96, 96), (2, 32, 32), (4, 128, 128), (4, 64, 64), (8, 256, 256),
           (8, 384, 256), (16, 256, 256)]

@@ -191,8 +191,36 @@ __global__ void __launch_bounds__(256) unpack_coords_kernel(const int64_t* __res
 }
 
 // ---------------- kernel map ----------------
-// pass 1: probe.  One thread owns kItems output rows and walks all K offsets, so a coordinate
-// row is read once; nbr_out[k][j] stores are coalesced along j.
+// kItems table look-ups of one thread with their first probes all in flight before any is
+// resolved (a look-up is a dependent chain key -> value; one at a time leaves the memory system idle).
+__device__ __forceinline__ void lookup_batch(const TableView& t, const uint64_t (&key)[kItems],
+                                             const bool (&ok)[kItems], int (&r)[kItems]) {
+  uint64_t slot[kItems];
+  unsigned long long first[kItems];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    slot[it] = slot_of(key[it], t.mask);
+    first[it] = ok[it] ? t.keys[slot[it]] : kEmptyKey;
+  }
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    r[it] = -1;
+    if (!ok[it] || first[it] == kEmptyKey) continue;
+    if (first[it] == key[it]) { r[it] = t.vals[slot[it]]; continue; }
+    uint64_t sl = (slot[it] + 1) & t.mask;                 // collision: walk on
+    while (true) {
+      unsigned long long k = t.keys[sl];
+      if (k == key[it]) { r[it] = t.vals[sl]; break; }
+      if (k == kEmptyKey) break;
+      sl = (sl + 1) & t.mask;
+    }
+  }
+}
+
+// pass 1: probe.  Workgroup (b, k) looks up offset k for the kTile output rows of block b (one
+// thread per (row, offset) pair x kItems rows: the K look-ups of a row are independent, so they run
+// as separate threads rather than one serial chain per row); nbr_out[k][j] stores are coalesced
+// along j; counts[k][b] = hits of the block.
 __global__ void __launch_bounds__(kBlock) kmap_probe_kernel(TableView t,
                                                             const int4* __restrict__ coords,
                                                             int64_t n_out,
@@ -200,60 +228,66 @@ __global__ void __launch_bounds__(kBlock) kmap_probe_kernel(TableView t,
                                                             int* __restrict__ nbr_out,
                                                             int* __restrict__ counts,
                                                             int64_t nblocks) {
-  extern __shared__ int cnt[];   // [K]
-  for (int k = threadIdx.x; k < K; k += kBlock) cnt[k] = 0;
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  int64_t base = (int64_t)blockIdx.x * kTile;
-  int4 c[kItems];
+  const int k = blockIdx.y;
+  const int ox = offsets[k * 3 + 0], oy = offsets[k * 3 + 1], oz = offsets[k * 3 + 2];
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  uint64_t key[kItems];
   bool ok[kItems];
+  int r[kItems];
 #pragma unroll
   for (int it = 0; it < kItems; ++it) {
-    int64_t j = base + it * kBlock + threadIdx.x;
+    const int64_t j = base + it * kBlock + threadIdx.x;
     ok[it] = j < n_out;
-    c[it] = ok[it] ? coords[j] : make_int4(0, 0, 0, 0);
+    const int4 c = ok[it] ? coords[j] : make_int4(0, 0, 0, 0);
+    key[it] = (uint64_t)fnv60(c.x + ox, c.y + oy, c.z + oz, c.w);
   }
-  for (int k = 0; k < K; ++k) {
-    int ox = offsets[k * 3 + 0], oy = offsets[k * 3 + 1], oz = offsets[k * 3 + 2];
-    int found = 0;
+  lookup_batch(t, key, ok, r);
+  int found = 0;
 #pragma unroll
-    for (int it = 0; it < kItems; ++it) {
-      int64_t j = base + it * kBlock + threadIdx.x;
-      int r = -1;
-      if (ok[it]) {
-        r = table_lookup(t, (uint64_t)fnv60(c[it].x + ox, c[it].y + oy, c[it].z + oz, c[it].w));
-        nbr_out[(int64_t)k * n_out + j] = r;
-      }
-      found += __popcll(__ballot(r >= 0));
-    }
-    if (lane_id() == 0) atomicAdd(&cnt[k], found);
+  for (int it = 0; it < kItems; ++it) {
+    const int64_t j = base + it * kBlock + threadIdx.x;
+    if (ok[it]) nbr_out[(int64_t)k * n_out + j] = r[it];
+    found += __popcll(__ballot(r[it] >= 0));
   }
+  if (lane_id() == 0) atomicAdd(&cnt, found);
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += kBlock) counts[(int64_t)k * nblocks + blockIdx.x] = cnt[k];
+  if (threadIdx.x == 0) counts[(int64_t)k * nblocks + blockIdx.x] = cnt;
 }
 
 // pass 1 (symmetric form): when the output coordinates ARE the input coordinates and the kernel is
 // odd and centred (every k3 stride-1 conv), rule (i, j, k) implies rule (j, i, K-1-k) and the centre
-// offset is the identity.  Only the first K/2 offsets are probed; each hit also fills its mirror
-// entry (a unique (offset, row) slot, so no write conflicts).  Halves the hash probes.
+// offset is the identity.  Only the first K/2 offsets are probed (grid.y = K/2); each hit also
+// fills its mirror entry (a unique (offset, row) slot, so no write conflicts).  Halves the probes.
 __global__ void __launch_bounds__(kBlock) kmap_probe_sym_kernel(TableView t,
                                                                 const int4* __restrict__ coords,
                                                                 int64_t n,
                                                                 const int* __restrict__ offsets,
                                                                 int K, int* __restrict__ nbr_out) {
-  int64_t base = (int64_t)blockIdx.x * kTile;
+  const int64_t base = (int64_t)blockIdx.x * kTile;
   const int half = K / 2;
+  const int k = blockIdx.y;
+  const int ox = offsets[k * 3 + 0], oy = offsets[k * 3 + 1], oz = offsets[k * 3 + 2];
+  uint64_t key[kItems];
+  bool ok[kItems];
+  int r[kItems];
 #pragma unroll
   for (int it = 0; it < kItems; ++it) {
-    int64_t j = base + it * kBlock + threadIdx.x;
-    if (j >= n) continue;
-    int4 c = coords[j];
-    nbr_out[(int64_t)half * n + j] = (int)j;
-    for (int k = 0; k < half; ++k) {
-      int r = table_lookup(t, (uint64_t)fnv60(c.x + offsets[k * 3 + 0], c.y + offsets[k * 3 + 1],
-                                              c.z + offsets[k * 3 + 2], c.w));
-      nbr_out[(int64_t)k * n + j] = r;
-      if (r >= 0) nbr_out[(int64_t)(K - 1 - k) * n + r] = (int)j;
-    }
+    const int64_t j = base + it * kBlock + threadIdx.x;
+    ok[it] = j < n;
+    const int4 c = ok[it] ? coords[j] : make_int4(0, 0, 0, 0);
+    key[it] = (uint64_t)fnv60(c.x + ox, c.y + oy, c.z + oz, c.w);
+  }
+  lookup_batch(t, key, ok, r);
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int64_t j = base + it * kBlock + threadIdx.x;
+    if (!ok[it]) continue;
+    if (k == 0) nbr_out[(int64_t)half * n + j] = (int)j;            // centre offset: identity
+    nbr_out[(int64_t)k * n + j] = r[it];
+    if (r[it] >= 0) nbr_out[(int64_t)(K - 1 - k) * n + r[it]] = (int)j;
   }
 }
 
@@ -590,17 +624,17 @@ extern "C" int lidal_kmap_build(const void* table, int64_t table_bytes, const in
   int* counts = (int*)ws;
   int64_t* offs = (int64_t*)((char*)ws + align_up(4 * nblocks * k, 256));
   TableView t = table_view(table, table_bytes);
-  if (symmetric && (k & 1)) {
+  if (symmetric && (k & 1) && k >= 3) {
     // mirrored entries that receive no hit must read -1
     LIDAL_HIP(hipMemsetAsync(nbr_out + (int64_t)(k / 2 + 1) * n_out, 0xFF, 4 * n_out * (k / 2), s));
-    kmap_probe_sym_kernel<<<(int)nblocks, kBlock, 0, s>>>(t, (const int4*)out_coords, n_out, offsets,
-                                                          k, nbr_out);
+    kmap_probe_sym_kernel<<<dim3((unsigned)nblocks, (unsigned)(k / 2)), kBlock, 0, s>>>(
+        t, (const int4*)out_coords, n_out, offsets, k, nbr_out);
     LIDAL_CHECK_LAUNCH("kmap_probe_sym");
     kmap_count_kernel<<<dim3((unsigned)nblocks, (unsigned)k), kBlock, 0, s>>>(nbr_out, n_out, k,
                                                                               counts, nblocks);
     LIDAL_CHECK_LAUNCH("kmap_count");
   } else {
-    kmap_probe_kernel<<<(int)nblocks, kBlock, k * sizeof(int), s>>>(
+    kmap_probe_kernel<<<dim3((unsigned)nblocks, (unsigned)k), kBlock, 0, s>>>(
         t, (const int4*)out_coords, n_out, offsets, k, nbr_out, counts, nblocks);
     LIDAL_CHECK_LAUNCH("kmap_probe");
   }

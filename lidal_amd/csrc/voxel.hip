@@ -90,6 +90,11 @@ __global__ void __launch_bounds__(256) voxelize_bwd_kernel(const T* __restrict__
   }
 }
 
+// 64 bytes of zeros: corners without a voxel or with an exactly zero weight read from here, so the
+// eight corner loads of a point are unconditional and all in flight together (a `continue` around
+// each load had serialised them)
+__device__ __attribute__((aligned(16))) unsigned char g_zero_row[64];
+
 // out[i] = sum_k w[i,k] * feat[idx[i,k]]
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) devoxelize_fwd_kernel(const T* __restrict__ feat,
@@ -105,25 +110,39 @@ __global__ void __launch_bounds__(256) devoxelize_fwd_kernel(const T* __restrict
   float acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  if constexpr (VEC == 4) {
+    // the point's 8 indices and weights as four 16-byte loads, then 8 row loads in flight
+    const int4 p0 = *reinterpret_cast<const int4*>(idx + i * 8), p1 = *reinterpret_cast<const int4*>(idx + i * 8 + 4);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + i * 8), w1 = *reinterpret_cast<const float4*>(w + i * 8 + 4);
+    const int pos[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float4 x[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    int pos = idx[i * 8 + k];
-    if (pos < 0 || pos >= m) continue;
-    float wk = w[i * 8 + k];
-    if (wk == 0.f) continue;        // exact zeros: points on a cell face/corner (all of stride 1)
-    const T* src = feat + (int64_t)pos * c + j;
-    if constexpr (VEC == 4) {
-      float4 x = ld4(src);
-      acc[0] += wk * x.x; acc[1] += wk * x.y; acc[2] += wk * x.z; acc[3] += wk * x.w;
-    } else {
+    for (int k = 0; k < 8; ++k) {
+      // exact zeros: points on a cell face/corner (all of stride 1) -- skipped as upstream's sum
+      // would add 0 * row (finite rows; the reference never holds inf/nan features here)
+      const bool live = pos[k] >= 0 && pos[k] < m && wk[k] != 0.f;
+      const T* src = live ? feat + (int64_t)pos[k] * c + j : reinterpret_cast<const T*>(g_zero_row);
+      x[k] = ld4(src);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool live = pos[k] >= 0 && pos[k] < m && wk[k] != 0.f;
+      if (live) { acc[0] += wk[k] * x[k].x; acc[1] += wk[k] * x[k].y; acc[2] += wk[k] * x[k].z; acc[3] += wk[k] * x[k].w; }
+    }
+    st4(out + i * c + j, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int pos = idx[i * 8 + k];
+      if (pos < 0 || pos >= m) continue;
+      float wk = w[i * 8 + k];
+      if (wk == 0.f) continue;
+      const T* src = feat + (int64_t)pos * c + j;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] += wk * (float)src[v];
     }
-  }
-  T* dst = out + i * c + j;
-  if constexpr (VEC == 4) {
-    st4(dst, make_float4(acc[0], acc[1], acc[2], acc[3]));
-  } else {
+    T* dst = out + i * c + j;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) dst[v] = (T)acc[v];
   }

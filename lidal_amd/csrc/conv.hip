@@ -694,18 +694,40 @@ conv_wgrad_kernel(const T* __restrict__ a, const T* __restrict__ b, const int2* 
       }
 }
 
+// gw[i] = sum over the slabs of i's offset, in slab order (fixed => reproducible).  V = 4: one
+// float4 per thread and four slab loads in flight; V = 1 for element counts not divisible by 4.
+template <int V>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int64_t* __restrict__ koff,
                                                            float* __restrict__ gw, int K,
                                                            int64_t per_k, int splits,
                                                            int target_chunk) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)K * per_k) return;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  const int64_t total = (int64_t)K * per_k;
+  if (i >= total) return;
   const int k = (int)(i / per_k);
   const int used = splits_for(koff[k + 1] - koff[k], splits, target_chunk);
-  float s = 0.f;
-  for (int sp = 0; sp < used; ++sp) s += partial[(int64_t)sp * K * per_k + i];   // fixed order
-  gw[i] = s;
+  if constexpr (V == 4) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sp = 0;
+    for (; sp + 3 < used; sp += 4) {
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        x[u] = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + u) * total + i);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s.x += x[u].x; s.y += x[u].y; s.z += x[u].z; s.w += x[u].w; }
+    }
+    for (; sp < used; ++sp) {
+      const float4 x = *reinterpret_cast<const float4*>(partial + (int64_t)sp * total + i);
+      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+    }
+    *reinterpret_cast<float4*>(gw + i) = s;
+  } else {
+    float s = 0.f;
+    for (int sp = 0; sp < used; ++sp) s += partial[(int64_t)sp * total + i];
+    gw[i] = s;
+  }
 }
 
 // ---- bf16 wgrad: v_mfma_f32_16x16x32_bf16 with both operands read TRANSPOSED from LDS ----------
@@ -1018,9 +1040,14 @@ extern "C" int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pai
   }
   if (rc) return rc;
   int64_t n = (int64_t)k * ca * cb;
-  wgrad_reduce_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>(partial, koff, gw, k,
-                                                             (int64_t)ca * cb, splits,
-                                                             target_chunk);
+  if (((int64_t)ca * cb) % 4 == 0)
+    wgrad_reduce_kernel<4><<<(unsigned)cdiv(n / 4, 256), 256, 0, s>>>(partial, koff, gw, k,
+                                                                      (int64_t)ca * cb, splits,
+                                                                      target_chunk);
+  else
+    wgrad_reduce_kernel<1><<<(unsigned)cdiv(n, 256), 256, 0, s>>>(partial, koff, gw, k,
+                                                                  (int64_t)ca * cb, splits,
+                                                                  target_chunk);
   LIDAL_CHECK_LAUNCH("wgrad_reduce");
   return 0;
 }

@@ -526,7 +526,10 @@ int dispatch_conv_cols(const void* in, const void* wk, const int* nbr, const int
   // BN = 16*NB output channels per workgroup; grid.y covers the rest.
   if (co <= 32)
     return launch_conv_apply<T, 2, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
-  if (co <= 64)
+  // 64-column blocks also for wide layers on the smallest levels: with fewer 128-column workgroups
+  // than ~1.5 per CU the chip is under-filled and each workgroup is one long serial chain of phases
+  // (256->256 on 17k rows: 106 -> 95 us; on 43k rows the extra gather passes lose, 142 -> 178)
+  if (co <= 64 || (co % 64 == 0 && cdiv(n_out, 128) * cdiv(co, 128) <= 384))
     return launch_conv_apply<T, 4, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
   if (co % 128 != 0 && (co % 96 == 0 || co < 128))
     return launch_conv_apply<T, 6, ROW_BYTES, GUARD>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);

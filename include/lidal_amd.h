@@ -91,12 +91,15 @@ int lidal_voxelize_points(const float* points, const float* intensity, int64_t p
  *   nbsizes  i32 [k],  koff i64 [k+1] exclusive prefix of nbsizes (koff[k] = total rules).
  * symmetric != 0 declares that out_coords are the coordinates the table was built from and that
  * offsets[k-1-j] == -offsets[j] (odd centred kernel at stride 1): half of the probes are then
- * replaced by mirroring (rule (i,j,k) <=> rule (j,i,k-1-j)); the result is identical. */
+ * replaced by mirroring (rule (i,j,k) <=> rule (j,i,k-1-j)); the result is identical.
+ * mode 0 builds everything; mode 1 only nbr_out (all the forward / inference path reads; nbmaps,
+ * nbsizes, koff may be NULL); mode 2 derives nbmaps / nbsizes / koff from an nbr_out built earlier
+ * (the weight gradient reads them; table / out_coords / offsets are then ignored). */
 int64_t lidal_kmap_workspace_bytes(int64_t n_out, int k);
 int lidal_kmap_build(const void* table, int64_t table_bytes, const int32_t* out_coords,
                      int64_t n_out, const int32_t* offsets, int k, int symmetric, int32_t* nbr_out,
-                     int32_t* nbmaps, int32_t* nbsizes, int64_t* koff, void* ws, int64_t ws_bytes,
-                     void* stream);
+                     int32_t* nbmaps, int32_t* nbsizes, int64_t* koff, int mode, void* ws,
+                     int64_t ws_bytes, void* stream);
 /* nbr_in i32 [k, n_in]: output row fed by input row i through offset k, or -1 (inverse table, used
  * by data-gradient and transposed convolution). */
 int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr_in, int64_t n_in,

@@ -611,32 +611,43 @@ extern "C" int64_t lidal_kmap_workspace_bytes(int64_t n_out, int k) {
 extern "C" int lidal_kmap_build(const void* table, int64_t table_bytes, const int32_t* out_coords,
                                 int64_t n_out, const int32_t* offsets, int k, int symmetric,
                                 int32_t* nbr_out, int32_t* nbmaps, int32_t* nbsizes, int64_t* koff,
-                                void* ws, int64_t ws_bytes, void* stream) {
+                                int mode, void* ws, int64_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   LIDAL_REQUIRE(k > 0 && k <= 1023, "kmap: bad kernel volume %d", k);
+  LIDAL_REQUIRE(mode >= 0 && mode <= 2, "kmap: mode must be 0 (table + rules), 1 (table) or 2 (rules)");
+  const bool want_table = mode != 2, want_rules = mode != 1;
   if (n_out == 0) {
-    LIDAL_HIP(hipMemsetAsync(nbsizes, 0, 4 * k, s));
-    LIDAL_HIP(hipMemsetAsync(koff, 0, 8 * (k + 1), s));
+    if (want_rules) {
+      LIDAL_HIP(hipMemsetAsync(nbsizes, 0, 4 * k, s));
+      LIDAL_HIP(hipMemsetAsync(koff, 0, 8 * (k + 1), s));
+    }
     return 0;
   }
   LIDAL_REQUIRE(ws_bytes >= lidal_kmap_workspace_bytes(n_out, k), "kmap workspace too small");
   int64_t nblocks = cdiv(n_out, kTile);
   int* counts = (int*)ws;
   int64_t* offs = (int64_t*)((char*)ws + align_up(4 * nblocks * k, 256));
-  TableView t = table_view(table, table_bytes);
-  if (symmetric && (k & 1) && k >= 3) {
-    // mirrored entries that receive no hit must read -1
-    LIDAL_HIP(hipMemsetAsync(nbr_out + (int64_t)(k / 2 + 1) * n_out, 0xFF, 4 * n_out * (k / 2), s));
-    kmap_probe_sym_kernel<<<dim3((unsigned)nblocks, (unsigned)(k / 2)), kBlock, 0, s>>>(
-        t, (const int4*)out_coords, n_out, offsets, k, nbr_out);
-    LIDAL_CHECK_LAUNCH("kmap_probe_sym");
+  bool counted = false;
+  if (want_table) {
+    TableView t = table_view(table, table_bytes);
+    if (symmetric && (k & 1) && k >= 3) {
+      // mirrored entries that receive no hit must read -1
+      LIDAL_HIP(hipMemsetAsync(nbr_out + (int64_t)(k / 2 + 1) * n_out, 0xFF, 4 * n_out * (k / 2), s));
+      kmap_probe_sym_kernel<<<dim3((unsigned)nblocks, (unsigned)(k / 2)), kBlock, 0, s>>>(
+          t, (const int4*)out_coords, n_out, offsets, k, nbr_out);
+      LIDAL_CHECK_LAUNCH("kmap_probe_sym");
+    } else {
+      kmap_probe_kernel<<<dim3((unsigned)nblocks, (unsigned)k), kBlock, 0, s>>>(
+          t, (const int4*)out_coords, n_out, offsets, k, nbr_out, counts, nblocks);
+      LIDAL_CHECK_LAUNCH("kmap_probe");
+      counted = true;
+    }
+  }
+  if (!want_rules) return 0;
+  if (!counted) {
     kmap_count_kernel<<<dim3((unsigned)nblocks, (unsigned)k), kBlock, 0, s>>>(nbr_out, n_out, k,
                                                                               counts, nblocks);
     LIDAL_CHECK_LAUNCH("kmap_count");
-  } else {
-    kmap_probe_kernel<<<dim3((unsigned)nblocks, (unsigned)k), kBlock, 0, s>>>(
-        t, (const int4*)out_coords, n_out, offsets, k, nbr_out, counts, nblocks);
-    LIDAL_CHECK_LAUNCH("kmap_probe");
   }
   scan_counts_kernel<<<1, 1024, 0, s>>>(counts, nblocks * k, offs);
   LIDAL_CHECK_LAUNCH("kmap_scan");

@@ -45,18 +45,48 @@ class RowOrder:
 
 
 class KernelMap:
-    def __init__(self, nbmaps_cap, nbsizes, koff, nbr_out, sizes, volume, symmetric):
-        self._nbmaps_cap = nbmaps_cap        # i32 [K*n_out, 2] capacity buffer
-        self.nbsizes = nbsizes               # i32 [K] (device)
-        self.koff = koff                     # i64 [K+1] (device), koff[K] = total rules
+    """nbr_out is built eagerly; the torchsparse-order rule lists (nbmaps / nbsizes / koff), which
+    only the weight gradient and the torchsparse list view read, are derived from it on first use
+    (so inference never builds or allocates them: K * n_out * 8 bytes at the fine levels)."""
+
+    def __init__(self, nbr_out, sizes, volume, symmetric):
         self.nbr_out = nbr_out               # i32 [K, n_out]
         self.sizes = sizes                   # (n_in, n_out)
         self.volume = volume
         self.symmetric = symmetric           # odd kernel, stride 1: nbr_in[k] == nbr_out[K-1-k]
+        self._rules = None                   # (nbmaps_cap i32 [K*n_out, 2], nbsizes i32 [K], koff i64 [K+1])
         self._nbr_in = None
         self._total = None
         self._order_out = None
         self._order_in = None
+
+    def _build_rules(self):
+        if self._rules is None:
+            k, n_out = self.nbr_out.shape
+            dev = self.nbr_out.device
+            nbmaps = torch.empty((k * n_out, 2), dtype=torch.int, device=dev)
+            nbsizes = torch.empty(k, dtype=torch.int, device=dev)
+            koff = torch.empty(k + 1, dtype=torch.int64, device=dev)
+            ws_bytes = B.lib().lidal_kmap_workspace_bytes(n_out, k)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            B.check(B.lib().lidal_kmap_build(None, 0, None, n_out, None, k, int(self.symmetric),
+                                             B.ptr(self.nbr_out), B.ptr(nbmaps), B.ptr(nbsizes),
+                                             B.ptr(koff), 2, B.ptr(ws), ws_bytes, B.stream()),
+                    'kmap_build(rules)')
+            self._rules = (nbmaps, nbsizes, koff)
+        return self._rules
+
+    @property
+    def _nbmaps_cap(self):
+        return self._build_rules()[0]
+
+    @property
+    def nbsizes(self):
+        return self._build_rules()[1]
+
+    @property
+    def koff(self):
+        return self._build_rules()[2]
 
     @property
     def total(self):
@@ -109,18 +139,26 @@ def build_kernel_map(coords, in_stride, kernel_size, stride):
         out_coords = spdownsample(coords, stride, kernel_size, in_stride)
     n_in, n_out = coords.shape[0], out_coords.shape[0]
     nbr_out = torch.empty((volume, n_out), dtype=torch.int, device=dev)
-    nbmaps = torch.empty((volume * n_out, 2), dtype=torch.int, device=dev)
-    nbsizes = torch.empty(volume, dtype=torch.int, device=dev)
-    koff = torch.empty(volume + 1, dtype=torch.int64, device=dev)
     ws_bytes = B.lib().lidal_kmap_workspace_bytes(n_out, volume)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     symmetric = (volume % 2 == 1) and all(s == 1 for s in stride)
+    # training will ask for the rule lists (weight gradient): build them in the same call;
+    # under no_grad only the neighbour table is built (KernelMap derives the rest if ever asked)
+    rules = None
+    if torch.is_grad_enabled():
+        rules = (torch.empty((volume * n_out, 2), dtype=torch.int, device=dev),
+                 torch.empty(volume, dtype=torch.int, device=dev),
+                 torch.empty(volume + 1, dtype=torch.int64, device=dev))
     B.check(B.lib().lidal_kmap_build(B.ptr(table.buf), table.nbytes, B.ptr(out_coords), n_out,
                                      B.ptr(offsets), volume, int(symmetric), B.ptr(nbr_out),
-                                     B.ptr(nbmaps),
-                                     B.ptr(nbsizes), B.ptr(koff), B.ptr(ws), ws_bytes,
-                                     B.stream()), 'kmap_build')
-    return KernelMap(nbmaps, nbsizes, koff, nbr_out, (n_in, n_out), volume, symmetric), out_coords
+                                     B.ptr(rules[0]) if rules else None,
+                                     B.ptr(rules[1]) if rules else None,
+                                     B.ptr(rules[2]) if rules else None,
+                                     0 if rules else 1, B.ptr(ws), ws_bytes, B.stream()),
+            'kmap_build')
+    kmap = KernelMap(nbr_out, (n_in, n_out), volume, symmetric)
+    kmap._rules = rules
+    return kmap, out_coords
 
 
 def prefetch_kernel_maps(x, plan, transposed=True):

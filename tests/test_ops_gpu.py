@@ -562,3 +562,19 @@ def test_batchnorm_module_counts_batches_in_kernel():
     with torch.no_grad():
         bn(x)
     assert int(bn.num_batches_tracked.item()) == 3
+
+
+def test_kernel_map_rules_built_lazily_match_eager():
+    """Under no_grad only the neighbour table is built; the torchsparse-order rule lists derived
+    from it later (mode 2) must equal the ones built in the same call with gradients enabled."""
+    F = _F()
+    for ks, st in ((3, 1), (2, 2)):
+        c = _surface_coords(50, 2, seed=ks).to(DEV)
+        eager, oc_e = F.build_kernel_map(c, (1, 1, 1), (ks,) * 3, (st,) * 3)
+        assert eager._rules is not None
+        with torch.no_grad():
+            lazy, oc_l = F.build_kernel_map(c, (1, 1, 1), (ks,) * 3, (st,) * 3)
+        assert lazy._rules is None
+        assert torch.equal(oc_e, oc_l) and torch.equal(eager.nbr_out, lazy.nbr_out)
+        assert torch.equal(eager.nbsizes, lazy.nbsizes) and torch.equal(eager.koff, lazy.koff)
+        assert torch.equal(eager.nbmaps, lazy.nbmaps)

@@ -393,6 +393,8 @@ __global__ void __launch_bounds__(256) row_mask_kernel(const int* __restrict__ n
   unsigned m = 0u;
   for (int k = 0; k < K; ++k)
     if (nbr[(int64_t)k * n + j] >= 0) m |= 1u << rank.to_key[k];
+  // sorted by Gray rank, not binary value: consecutive keys then differ in few bits (7.0 -> 6.8)
+  m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
   keys[j] = m;
   vals[j] = (int)j;
 }
@@ -417,7 +419,7 @@ __global__ void __launch_bounds__(256) tile_or_kernel(const unsigned* __restrict
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     int64_t r = t * 128 + h * 64 + lane;
-    if (r < n) m |= skeys[r];
+    if (r < n) { const unsigned g = skeys[r]; m |= g ^ (g >> 1); }     // Gray rank -> key bits
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, 64);

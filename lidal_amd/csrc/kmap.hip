@@ -431,12 +431,21 @@ __global__ void __launch_bounds__(256) tile_or_kernel(const unsigned* __restrict
   }
 }
 
+// rocprim sorts anything up to 1M items by merge sort, whatever the key width; for the 8-bit masks
+// of the 2x2x2 maps one Onesweep pass is 3x faster from ~100k rows up (scripts/sort_bench.hip:
+// 400k pairs 114 us vs 36 us), so those go through a config whose merge-sort limit is 64k.
+using NarrowKeySort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                 rocprim::default_config, 65536>;
 size_t mask_sort_tmp_bytes(int64_t n) {
-  size_t tmp = 0;
+  size_t tmp = 0, tmp2 = 0;
   (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr,
                                   (const int*)nullptr, (int*)nullptr, (size_t)(n > 0 ? n : 1), 0,
                                   32, (hipStream_t)0);
-  return tmp;
+  (void)rocprim::radix_sort_pairs<NarrowKeySort>((void*)nullptr, tmp2, (const unsigned*)nullptr,
+                                                 (unsigned*)nullptr, (const int*)nullptr,
+                                                 (int*)nullptr, (size_t)(n > 0 ? n : 1), 0, 8,
+                                                 (hipStream_t)0);
+  return tmp > tmp2 ? tmp : tmp2;
 }
 
 
@@ -721,7 +730,11 @@ extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32
   const BitRank rank = bit_rank(k);
   row_mask_kernel<<<(unsigned)cdiv(q, 256), 256, 0, s>>>(nbr, q, k, rank, keys, vals);
   LIDAL_CHECK_LAUNCH("row_mask");
-  LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, perm, (size_t)q, 0, k, s));
+  if (k <= 8)
+    LIDAL_HIP(rocprim::radix_sort_pairs<NarrowKeySort>(tmp, tmp_bytes, keys, skeys, vals, perm,
+                                                       (size_t)q, 0, k, s));
+  else
+    LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, perm, (size_t)q, 0, k, s));
   permute_table_kernel<<<dim3((unsigned)cdiv(q, 256), (unsigned)k), 256, 0, s>>>(nbr, q, perm,
                                                                                  nbr_perm);
   LIDAL_CHECK_LAUNCH("permute_table");

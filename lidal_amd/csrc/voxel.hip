@@ -398,12 +398,21 @@ static inline int segment_parts(int64_t n_entries, int64_t m, int c) {
   return parts;
 }
 
+// rocprim merge-sorts up to 1M items whatever the key width; voxel indices of the coarse levels
+// need 15-17 bits, i.e. two Onesweep passes (scripts/sort_bench.hip: 400k pairs, 17 bits: 95 us
+// against 117 us), so lists of >= 64k entries with <= 16-bit keys take the radix path.
+using NarrowKeySort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                 rocprim::default_config, 65536>;
 size_t inv_sort_tmp_bytes(int64_t n) {
-  size_t tmp = 0;
+  size_t tmp = 0, tmp2 = 0;
   (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr,
                                   (const int*)nullptr, (int*)nullptr, (size_t)(n > 0 ? n : 1), 0,
                                   32, (hipStream_t)0);
-  return tmp;
+  (void)rocprim::radix_sort_pairs<NarrowKeySort>((void*)nullptr, tmp2, (const unsigned*)nullptr,
+                                                 (unsigned*)nullptr, (const int*)nullptr,
+                                                 (int*)nullptr, (size_t)(n > 0 ? n : 1), 0, 16,
+                                                 (hipStream_t)0);
+  return tmp > tmp2 ? tmp : tmp2;
 }
 
 template <typename T, bool DEVOX>
@@ -560,7 +569,11 @@ extern "C" int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n
   LIDAL_CHECK_LAUNCH("inv_keys");
   int bits = 1;
   while ((1ll << bits) <= m) ++bits;
-  LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, order, (size_t)q, 0, bits, s));
+  if (bits <= 16)
+    LIDAL_HIP(rocprim::radix_sort_pairs<NarrowKeySort>(tmp, tmp_bytes, keys, skeys, vals, order,
+                                                       (size_t)q, 0, bits, s));
+  else
+    LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, order, (size_t)q, 0, bits, s));
   inv_segptr_kernel<<<(unsigned)cdiv(m + 1, 256), 256, 0, s>>>(skeys, q, m, seg_ptr);
   LIDAL_CHECK_LAUNCH("inv_segptr");
   return 0;

@@ -224,13 +224,33 @@ def _apply(feats, wk, order, kflip, epilogue=None):
     return out
 
 
-WGRAD_CHUNK = 4096      # rules per split-K slab at the fine levels (lidal_conv_wgrad target_chunk)
+WGRAD_SLOTS = 512        # workgroups the chip holds at once (256 CUs x 2 resident wgrad workgroups)
 
 
-def _wgrad_chunk(n_rows):
-    """Smaller slabs on the coarse levels keep enough workgroups in flight (measured with
-    scripts/ablate_wgrad.py: 2048 wins below ~2e5 rows, 4096 above)."""
-    return WGRAD_CHUNK if n_rows >= 200000 else 2048
+def _wgrad_tile(c):
+    """Channels per weight-gradient tile side (conv.hip: pick_blocks * 32)."""
+    if c <= 32:
+        return 32
+    if c <= 64:
+        return 64
+    if c % 128 == 0:
+        return 128
+    return 96 if (c % 96 == 0 or c < 128) else 128
+
+
+def _wgrad_chunk(n_rows, ca=None, cb=None, rules_per_row=6):
+    """Rules per split-K slab (lidal_conv_wgrad target_chunk): sized so that the launch is about
+    ONE round of resident workgroups -- slabs = rules / chunk, workgroups = slabs x channel tiles.
+    The rule count is only known on the device, so it is estimated from the rows (~6 rules per row
+    for a 3x3x3 map on LiDAR surfaces, exactly 1 for the 2x2x2 maps and the dense layers).
+    scripts/ablate_wgrad.py: 4096 is best for 96->96 on 397k rows, 1024 for 128->128 on 105k rows
+    (99.8 vs 124 us at 2048), and a fixed 4096 left the dense layers with 97 workgroups; the step
+    went from 25.2 to 24.3 ms against the old rule (4096 from 200k rows up, else 2048)."""
+    tiles = 1
+    if ca is not None and cb is not None:
+        tiles = -(-ca // _wgrad_tile(ca)) * -(-cb // _wgrad_tile(cb))
+    chunk = rules_per_row * n_rows * tiles / WGRAD_SLOTS
+    return int(min(4096, max(512, -(-int(chunk) // 64) * 64)))
 
 
 def _wgrad_splits(n_rows, chunk=None):
@@ -287,7 +307,7 @@ class ConvolutionFunction(Function):
                 grad_in = _apply(g, wk, kmap.order_out, 0)
         if ctx.needs_input_grad[1]:
             k, ci, co = weight.shape
-            chunk = _wgrad_chunk(max(n_in, n_out))
+            chunk = _wgrad_chunk(max(n_in, n_out), ci, co, 6 if k > 8 else 1)
             splits = _wgrad_splits(max(n_in, n_out), chunk)
             gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
             partial = torch.empty((splits, k, ci, co), dtype=torch.float32, device=x.device)

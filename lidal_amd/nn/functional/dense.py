@@ -31,7 +31,7 @@ def _wgrad_dense(a, b):
     """a [N, Ca], b [N, Cb] (same dtype, f32 or bf16) -> a^T @ b as f32 [Ca, Cb]."""
     n, ca = a.shape
     cb = b.shape[1]
-    chunk = _wgrad_chunk(n)
+    chunk = _wgrad_chunk(n, ca, cb, 1)
     splits = _wgrad_splits(n, chunk)
     gw = torch.empty((1, ca, cb), dtype=torch.float32, device=a.device)
     partial = torch.empty((splits, 1, ca, cb), dtype=torch.float32, device=a.device)

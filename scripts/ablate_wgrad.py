@@ -27,7 +27,7 @@ def run():
     import torch
     from lidal_amd import backend as B, synth
     from lidal_amd.nn import functional as F
-    from lidal_amd.nn.functional.conv import WGRAD_CHUNK, _wgrad_splits
+    from lidal_amd.nn.functional.conv import _wgrad_splits  # noqa: F401
     batch = synth.make_train_batch(n_frames=5, n_points=120000, seed=7122)
     coords = torch.from_numpy(batch['coords_v_b']).cuda()
     levels = {1: coords}

@@ -51,6 +51,50 @@ def _vec(dtype):
     return 8 if dtype == torch.bfloat16 else 4
 
 
+_ident_cache = {}
+
+
+def _identity_table(n, device):
+    """(nbr i32 [1, n] = arange, tile masks u32 [tiles] = 1): the dense product as a one-offset
+    convolution whose rule list is the identity."""
+    key = (n, str(device))
+    t = _ident_cache.get(key)
+    if t is None:
+        if len(_ident_cache) > 64:
+            _ident_cache.clear()
+        t = (torch.arange(n, dtype=torch.int, device=device).view(1, n),
+             torch.ones(max(1, -(-n // 128)), dtype=torch.int, device=device))
+        _ident_cache[key] = t
+    return t
+
+
+def _gemm_ok(x, ci, co):
+    if not x.is_cuda or x.shape[0] == 0 or x.shape[0] * ci * x.element_size() >= 0x7FFFFFF0:
+        return False
+    # bf16 only: the f32 mode is the parity mode and keeps the library GEMM, whose summation order
+    # the end-to-end gradient goldens were pinned with (the two differ by ~1e-4 at the stem after
+    # 49 layers, which is the goldens' own floor)
+    return x.dtype == torch.bfloat16 and ci % 8 == 0 and co % 8 == 0
+
+
+def _rows_gemm(x, wk, shift=None):
+    """x [n, ci] @ wk[0]^T with wk [1, co, ci] (reduction dim contiguous), + shift f32 [co]: the
+    sparse-convolution kernel with the identity rule list.  A library GEMM runs these tall-skinny
+    products (4e5 x 128 @ 128 x 96) at ~1.7 TB/s of operand traffic; this kernel streams the rows
+    once and keeps the small weight in LDS."""
+    n, ci = x.shape
+    co = wk.shape[1]
+    nbr, masks = _identity_table(n, x.device)
+    out = torch.empty((n, co), dtype=x.dtype, device=x.device)
+    scale = None
+    if shift is not None:
+        scale = torch.ones(co, dtype=torch.float32, device=x.device)
+    B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(nbr), None, B.ptr(masks), B.ptr(out),
+                                     n, n, ci, co, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
+                                     B.ptr(shift), 0, B.stream()), 'conv_apply(dense)')
+    return out
+
+
 def _operand(w, linear, cdtype, pad):
     """The GEMM operand [Cin, Cout+pad] in the compute dtype for `w` ([Cin, Cout], or nn.Linear's
     [Cout, Cin] when `linear`)."""
@@ -68,10 +112,18 @@ def _forward(x, w, bias, linear):
     co = w.shape[0] if linear else w.shape[1]
     pad = (-co) % _vec(cdtype) if xc.is_cuda else 0
     wc = _operand(w, linear, cdtype, pad)
-    y = xc @ wc
-    if bias is not None:
-        b = bias.detach().to(cdtype)
-        y = y + (torch.nn.functional.pad(b, (0, pad)) if pad else b)
+    if _gemm_ok(xc, xc.shape[1], co + pad):
+        shift = None
+        if bias is not None:
+            shift = bias.detach().float()
+            if pad:
+                shift = torch.nn.functional.pad(shift, (0, pad))
+        y = _rows_gemm(xc, wc.t().contiguous().unsqueeze(0), shift)
+    else:
+        y = xc @ wc
+        if bias is not None:
+            b = bias.detach().to(cdtype)
+            y = y + (torch.nn.functional.pad(b, (0, pad)) if pad else b)
     return xc, wc, pad, (y[:, :co] if pad else y)
 
 
@@ -102,7 +154,10 @@ class RowsMatmul(Function):
         g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = g @ ctx.wc.t()
+            if _gemm_ok(g, g.shape[1], xc.shape[1]):
+                gx = _rows_gemm(g, ctx.wc.contiguous().unsqueeze(0))     # [1, ci, co]: reduction over co
+            else:
+                gx = g @ ctx.wc.t()
         if ctx.needs_input_grad[1]:
             if _ok(xc, xc.shape[1], g.shape[1]):
                 gw = _wgrad_dense(xc, g)[:, :co]

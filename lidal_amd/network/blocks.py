@@ -11,14 +11,16 @@ from .. import SparseTensor
 from .. import backend as B
 from .. import nn as spnn
 from ..nn.functional.conv import conv3d
+from ..nn.functional.dense import rows_linear
 from ..nn.functional.fused import add_relu
 
 
 class ConvNormSequential(nn.Sequential):
     """nn.Sequential (same child names, same state_dict keys) that, at inference (eval mode, no
-    gradient wanted), runs each Conv3d -> BatchNorm pair as ONE kernel: the eval-mode BatchNorm is a
-    per-channel affine map, applied (with the fused ReLU) in the convolution's epilogue instead of
-    a separate pass over the feature matrix.  Anything else runs child by child."""
+    gradient wanted), runs each Conv3d -> BatchNorm (or Linear -> BatchNorm1d on a plain [N, C]
+    tensor) pair as ONE kernel: the eval-mode BatchNorm is a per-channel affine map, applied (with
+    the fused ReLU) in the convolution's epilogue instead of a separate pass over the feature
+    matrix.  Anything else runs child by child."""
 
     def forward(self, x):
         mods = list(self)
@@ -29,28 +31,42 @@ class ConvNormSequential(nn.Sequential):
             if isinstance(m, spnn.Conv3d) and isinstance(nxt, spnn.BatchNorm) and _fusable(m, nxt, x):
                 x = _conv_norm(m, nxt, x)
                 i += 2
+            elif (isinstance(m, spnn.Linear) and isinstance(nxt, spnn.BatchNorm1d)
+                  and torch.is_tensor(x) and _fusable_rows(nxt, x, m.weight, m.bias)):
+                scale, shift = _fold(nxt, x.device)
+                x = rows_linear(x, m.weight, m.bias, epilogue=(scale, shift, nxt.fused_relu))
+                i += 2
             else:
                 x = m(x)
                 i += 1
         return x
 
 
-def _fusable(conv, bn, x):
-    return (not bn.training and bn.track_running_stats and conv.bias is None
-            and conv.kernel_size != (1, 1, 1) and x.F.is_cuda
-            and not B.wants_grad(x.F, conv.kernel, bn.weight, bn.bias)
+def _fusable_rows(bn, feats, *params):
+    return (not bn.training and bn.track_running_stats and feats.is_cuda
+            and not B.wants_grad(feats, bn.weight, bn.bias, *params)
             and bn.weight is not None and bn.weight.dtype == torch.float32)
 
 
-def _conv_norm(conv, bn, x):
+def _fusable(conv, bn, x):
+    return conv.bias is None and _fusable_rows(bn, x.F, conv.kernel)
+
+
+def _fold(bn, device):
+    """Eval-mode BatchNorm as (scale, shift) f32 [C]: y = x * scale + shift."""
     c = bn.num_features
-    fold = torch.empty((2, c), dtype=torch.float32, device=x.F.device)
+    fold = torch.empty((2, c), dtype=torch.float32, device=device)
     B.check(B.lib().lidal_bn_fold(B.ptr(bn.weight), B.ptr(bn.bias), B.ptr(bn.running_mean),
                                   B.ptr(bn.running_var), float(bn.eps), c, B.ptr(fold[0]),
                                   B.ptr(fold[1]), B.stream()), 'bn_fold')
+    return fold[0], fold[1]
+
+
+def _conv_norm(conv, bn, x):
+    scale, shift = _fold(bn, x.F.device)
     return conv3d(x, conv.kernel, kernel_size=conv.kernel_size, bias=None, stride=conv.stride,
                   dilation=conv.dilation, transposed=conv.transposed,
-                  epilogue=(fold[0], fold[1], bn.fused_relu))
+                  epilogue=(scale, shift, bn.fused_relu))
 
 
 def _conv_bn(inc, outc, ks, stride=1, transposed=False):

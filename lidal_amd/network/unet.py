@@ -83,7 +83,7 @@ class SPVCNN(_SparseUNet):
         self.pres = 0.05
         self.vres = 0.05
         self.point_transforms = nn.ModuleList([
-            nn.Sequential(spnn.Linear(a, b), spnn.BatchNorm1d(b), nn.Identity())   # ReLU fused in BN
+            ConvNormSequential(spnn.Linear(a, b), spnn.BatchNorm1d(b), nn.Identity())   # ReLU fused in BN
             for a, b in ((cs[0], cs[4]), (cs[4], cs[6]), (cs[6], cs[8]))])
         for seq in self.point_transforms:
             seq[1].fused_relu = True

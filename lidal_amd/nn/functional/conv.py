@@ -330,10 +330,9 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
     dilation = make_ntuple(dilation, ndim=3)
 
     if kernel_size == (1, 1, 1) and stride == (1, 1, 1) and dilation == (1, 1, 1):
-        assert epilogue is None
         B.require_gpu(feats)
         from .dense import rows_matmul
-        feats = rows_matmul(feats, weight, bias)
+        feats = rows_matmul(feats, weight, bias, epilogue)
         output = SparseTensor(feats, coords, input.stride)
     elif not transposed:
         if dilation != (1, 1, 1):

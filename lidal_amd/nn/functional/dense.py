@@ -77,7 +77,7 @@ def _gemm_ok(x, ci, co):
     return x.dtype == torch.bfloat16 and ci % 8 == 0 and co % 8 == 0
 
 
-def _rows_gemm(x, wk, shift=None):
+def _rows_gemm(x, wk, shift=None, scale=None, relu=False):
     """x [n, ci] @ wk[0]^T with wk [1, co, ci] (reduction dim contiguous), + shift f32 [co]: the
     sparse-convolution kernel with the identity rule list.  A library GEMM runs these tall-skinny
     products (4e5 x 128 @ 128 x 96) at ~1.7 TB/s of operand traffic; this kernel streams the rows
@@ -86,12 +86,11 @@ def _rows_gemm(x, wk, shift=None):
     co = wk.shape[1]
     nbr, masks = _identity_table(n, x.device)
     out = torch.empty((n, co), dtype=x.dtype, device=x.device)
-    scale = None
-    if shift is not None:
+    if shift is not None and scale is None:
         scale = torch.ones(co, dtype=torch.float32, device=x.device)
     B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(nbr), None, B.ptr(masks), B.ptr(out),
                                      n, n, ci, co, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
-                                     B.ptr(shift), 0, B.stream()), 'conv_apply(dense)')
+                                     B.ptr(shift), int(bool(relu)), B.stream()), 'conv_apply(dense)')
     return out
 
 
@@ -106,24 +105,36 @@ def _operand(w, linear, cdtype, pad):
     return wc
 
 
-def _forward(x, w, bias, linear):
+def _forward(x, w, bias, linear, epilogue=None):
+    """epilogue (inference only) = (scale f32 [Cout], shift f32 [Cout], relu): the eval-mode
+    BatchNorm (+ ReLU) that follows the layer, y = act((x @ w + bias) * scale + shift)."""
     cdtype = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
     xc = x.contiguous().to(cdtype)
     co = w.shape[0] if linear else w.shape[1]
     pad = (-co) % _vec(cdtype) if xc.is_cuda else 0
     wc = _operand(w, linear, cdtype, pad)
-    if _gemm_ok(xc, xc.shape[1], co + pad):
-        shift = None
+    scale = shift = None
+    relu = False
+    if epilogue is not None:
+        scale, shift, relu = epilogue
         if bias is not None:
-            shift = bias.detach().float()
-            if pad:
-                shift = torch.nn.functional.pad(shift, (0, pad))
-        y = _rows_gemm(xc, wc.t().contiguous().unsqueeze(0), shift)
+            shift = shift + bias.detach().float() * scale
+    elif bias is not None:
+        shift = bias.detach().float()
+    if _gemm_ok(xc, xc.shape[1], co + pad):
+        if pad:
+            shift = None if shift is None else torch.nn.functional.pad(shift, (0, pad))
+            scale = None if scale is None else torch.nn.functional.pad(scale, (0, pad), value=1.0)
+        y = _rows_gemm(xc, wc.t().contiguous().unsqueeze(0), shift, scale, relu)
     else:
         y = xc @ wc
-        if bias is not None:
+        if epilogue is not None:
+            y = y.float() * scale + shift
+            y = (torch.relu(y) if relu else y).to(cdtype)
+        elif bias is not None:
             b = bias.detach().to(cdtype)
             y = y + (torch.nn.functional.pad(b, (0, pad)) if pad else b)
+        return xc, wc, pad, (y[:, :co] if pad and epilogue is None else y)
     return xc, wc, pad, (y[:, :co] if pad else y)
 
 
@@ -173,16 +184,17 @@ class RowsMatmul(Function):
         return gx, gw, gb, None
 
 
-def _rows(x, w, bias, linear):
+def _rows(x, w, bias, linear, epilogue=None):
     if B.wants_grad(x, w, bias):
+        assert epilogue is None, 'the fused BatchNorm epilogue is inference-only'
         return RowsMatmul.apply(x, w, bias, linear)
-    return _forward(x, w, bias, linear)[3]          # inference: no autograd node
+    return _forward(x, w, bias, linear, epilogue)[3]          # inference: no autograd node
 
 
-def rows_matmul(x, w, bias=None):
-    return _rows(x, w, bias, False)
+def rows_matmul(x, w, bias=None, epilogue=None):
+    return _rows(x, w, bias, False, epilogue)
 
 
-def rows_linear(x, weight, bias=None):
+def rows_linear(x, weight, bias=None, epilogue=None):
     """nn.Linear semantics: weight [Cout, Cin]."""
-    return _rows(x, weight, bias, True)
+    return _rows(x, weight, bias, True, epilogue)

@@ -160,7 +160,7 @@ def roofline_conv(args, coords, dev, reps=20):
     def launch():
         B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
                                          B.ptr(order.tile_masks), B.ptr(out), n, n, ci, co, 27, 0,
-                                         B.dtype_code(dtype), None, None, 0, B.stream()), 'conv')
+                                         B.dtype_code(dtype), None, None, 0, None, B.stream()), 'conv')
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -53,7 +53,7 @@ SIGNATURES = {
     'lidal_kmap_order_workspace_bytes': (_i64, [_i64]),
     'lidal_kmap_order': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
-                                _vp, _i32, _vp]),
+                                _vp, _i32, _vp, _vp]),
     'lidal_conv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                 _vp]),
     'lidal_bn_workspace_bytes': (_i64, [_i64, _i32]),

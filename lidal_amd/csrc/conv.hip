@@ -151,7 +151,7 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
                   const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
                   T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
                   const float* __restrict__ ep_scale, const float* __restrict__ ep_shift,
-                  int ep_relu, unsigned in_bytes, unsigned wk_bytes) {
+                  int ep_relu, const T* __restrict__ ep_res, unsigned in_bytes, unsigned wk_bytes) {
   constexpr int NTHREADS = 64 * NWAVES;
   constexpr int BM = NWAVES * G * 16;                   // output rows per workgroup
   constexpr int BN = 16 * NB;
@@ -478,16 +478,26 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     T* dst = out + row * co + n0 + cseg;
     const T* srcp = et + r * ESTRIDE + cseg;
     if (n0 + cseg + VEC <= co) {
-      *reinterpret_cast<frag*>(dst) = *reinterpret_cast<const frag*>(srcp);
+      frag v = *reinterpret_cast<const frag*>(srcp);
+      if (ep_res != nullptr) {       // + residual row (same row, same columns), summed in f32
+        const frag rr = *reinterpret_cast<const frag*>(ep_res + row * co + n0 + cseg);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = DT<T>::from_f32(DT<T>::to_f32(v[e]) + DT<T>::to_f32(rr[e]));
+      }
+      *reinterpret_cast<frag*>(dst) = v;
     } else {
 #pragma unroll
       for (int e = 0; e < VEC; ++e)
-        if (n0 + cseg + e < co) dst[e] = srcp[e];
+        if (n0 + cseg + e < co) {
+          float v = DT<T>::to_f32(srcp[e]);
+          if (ep_res != nullptr) v += DT<T>::to_f32(ep_res[row * co + n0 + cseg + e]);
+          dst[e] = DT<T>::from_f32(v);
+        }
     }
   }
 }
 
-struct Epi { const float* scale; const float* shift; int relu; unsigned in_bytes, wk_bytes; };
+struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, wk_bytes; };
 
 template <typename T, int NB, int ROW_BYTES, bool GUARD>
 int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int* perm,
@@ -513,8 +523,8 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
   }
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
   kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, perm, tmasks, (T*)out, n_out,
-                                   ci, co, K, kflip, ep.scale, ep.shift, ep.relu, ep.in_bytes,
-                                   ep.wk_bytes);
+                                   ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
+                                   ep.in_bytes, ep.wk_bytes);
   LIDAL_CHECK_LAUNCH("lidal_conv_apply");
   return 0;
 }
@@ -1002,7 +1012,7 @@ extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* n
                                 const int32_t* perm, const uint32_t* tile_masks, void* out,
                                 int64_t n_in, int64_t n_out, int ci, int co, int k, int kflip,
                                 int dtype, const float* ep_scale, const float* ep_shift,
-                                int ep_relu, void* stream) {
+                                int ep_relu, const void* ep_residual, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out == 0 || co == 0) return 0;
   LIDAL_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv_apply: scale and shift go together");
@@ -1010,7 +1020,8 @@ extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* n
   LIDAL_REQUIRE(n_in >= 0 && n_in * ci * esz < 0x7FFFFFF0ll && (int64_t)k * ci * co * esz < 0x7FFFFFF0ll,
                 "conv_apply: the input matrix (%lld rows x %d) and the weights must each stay below "
                 "2 GiB (32-bit buffer addressing)", (long long)n_in, ci);
-  Epi ep{ep_scale, ep_shift, ep_relu, (unsigned)(n_in * ci * esz), (unsigned)((int64_t)k * ci * co * esz)};
+  Epi ep{ep_scale, ep_shift, ep_relu, ep_residual, (unsigned)(n_in * ci * esz),
+         (unsigned)((int64_t)k * ci * co * esz)};
   LIDAL_REQUIRE(ci > 0 && k > 0 && k <= MAXK, "conv_apply: bad shape ci=%d k=%d", ci, k);
   if (dtype == LIDAL_F32) {
     LIDAL_REQUIRE(ci % 4 == 0 && co % 4 == 0, "conv_apply f32: channels must be multiples of 4");

@@ -22,8 +22,12 @@ class ConvNormSequential(nn.Sequential):
     the fused ReLU) in the convolution's epilogue instead of a separate pass over the feature
     matrix.  Anything else runs child by child."""
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """`residual` ([N, C] tensor, plain-tensor pipelines only): returns residual + self(x); on
+        the fused inference path the sum happens in the last layer's epilogue."""
         mods = list(self)
+        while mods and isinstance(mods[-1], nn.Identity):
+            mods.pop()
         i = 0
         while i < len(mods):
             m = mods[i]
@@ -34,12 +38,16 @@ class ConvNormSequential(nn.Sequential):
             elif (isinstance(m, spnn.Linear) and isinstance(nxt, spnn.BatchNorm1d)
                   and torch.is_tensor(x) and _fusable_rows(nxt, x, m.weight, m.bias)):
                 scale, shift = _fold(nxt, x.device)
-                x = rows_linear(x, m.weight, m.bias, epilogue=(scale, shift, nxt.fused_relu))
+                last = i + 2 == len(mods)
+                x = rows_linear(x, m.weight, m.bias,
+                                epilogue=(scale, shift, nxt.fused_relu, residual if last else None))
+                if last:
+                    residual = None
                 i += 2
             else:
                 x = m(x)
                 i += 1
-        return x
+        return x if residual is None else residual + x
 
 
 def _fusable_rows(bn, feats, *params):

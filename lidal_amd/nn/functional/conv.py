@@ -220,7 +220,7 @@ def _apply(feats, wk, order, kflip, epilogue=None):
                                      B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci, co, k,
                                      int(kflip),
                                      B.dtype_code(feats.dtype), B.ptr(scale), B.ptr(shift),
-                                     int(bool(relu)), B.stream()), 'conv_apply')
+                                     int(bool(relu)), None, B.stream()), 'conv_apply')
     return out
 
 

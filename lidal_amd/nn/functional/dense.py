@@ -77,7 +77,7 @@ def _gemm_ok(x, ci, co):
     return x.dtype == torch.bfloat16 and ci % 8 == 0 and co % 8 == 0
 
 
-def _rows_gemm(x, wk, shift=None, scale=None, relu=False):
+def _rows_gemm(x, wk, shift=None, scale=None, relu=False, residual=None):
     """x [n, ci] @ wk[0]^T with wk [1, co, ci] (reduction dim contiguous), + shift f32 [co]: the
     sparse-convolution kernel with the identity rule list.  A library GEMM runs these tall-skinny
     products (4e5 x 128 @ 128 x 96) at ~1.7 TB/s of operand traffic; this kernel streams the rows
@@ -86,11 +86,15 @@ def _rows_gemm(x, wk, shift=None, scale=None, relu=False):
     co = wk.shape[1]
     nbr, masks = _identity_table(n, x.device)
     out = torch.empty((n, co), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == out.shape and residual.dtype == out.dtype
     if shift is not None and scale is None:
         scale = torch.ones(co, dtype=torch.float32, device=x.device)
     B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(nbr), None, B.ptr(masks), B.ptr(out),
                                      n, n, ci, co, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
-                                     B.ptr(shift), int(bool(relu)), B.stream()), 'conv_apply(dense)')
+                                     B.ptr(shift), int(bool(relu)), B.ptr(residual), B.stream()),
+            'conv_apply(dense)')
     return out
 
 
@@ -106,17 +110,19 @@ def _operand(w, linear, cdtype, pad):
 
 
 def _forward(x, w, bias, linear, epilogue=None):
-    """epilogue (inference only) = (scale f32 [Cout], shift f32 [Cout], relu): the eval-mode
-    BatchNorm (+ ReLU) that follows the layer, y = act((x @ w + bias) * scale + shift)."""
+    """epilogue (inference only) = (scale f32 [Cout], shift f32 [Cout], relu[, residual [N, Cout]]):
+    the eval-mode BatchNorm (+ ReLU) that follows the layer and an optional row-wise sum,
+    y = act((x @ w + bias) * scale + shift) + residual."""
     cdtype = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
     xc = x.contiguous().to(cdtype)
     co = w.shape[0] if linear else w.shape[1]
     pad = (-co) % _vec(cdtype) if xc.is_cuda else 0
     wc = _operand(w, linear, cdtype, pad)
-    scale = shift = None
+    scale = shift = residual = None
     relu = False
     if epilogue is not None:
-        scale, shift, relu = epilogue
+        scale, shift, relu = epilogue[:3]
+        residual = epilogue[3] if len(epilogue) > 3 else None
         if bias is not None:
             shift = shift + bias.detach().float() * scale
     elif bias is not None:
@@ -125,17 +131,25 @@ def _forward(x, w, bias, linear, epilogue=None):
         if pad:
             shift = None if shift is None else torch.nn.functional.pad(shift, (0, pad))
             scale = None if scale is None else torch.nn.functional.pad(scale, (0, pad), value=1.0)
-        y = _rows_gemm(xc, wc.t().contiguous().unsqueeze(0), shift, scale, relu)
-    else:
-        y = xc @ wc
-        if epilogue is not None:
-            y = y.float() * scale + shift
-            y = (torch.relu(y) if relu else y).to(cdtype)
-        elif bias is not None:
-            b = bias.detach().to(cdtype)
-            y = y + (torch.nn.functional.pad(b, (0, pad)) if pad else b)
-        return xc, wc, pad, (y[:, :co] if pad and epilogue is None else y)
-    return xc, wc, pad, (y[:, :co] if pad else y)
+        fused_res = residual if (residual is not None and not pad) else None
+        if fused_res is not None:
+            fused_res = fused_res.to(cdtype)
+        y = _rows_gemm(xc, wc.t().contiguous().unsqueeze(0), shift, scale, relu, fused_res)
+        y = y[:, :co] if pad else y
+        if residual is not None and fused_res is None:
+            y = y + residual.to(cdtype)
+        return xc, wc, pad, y
+    y = xc @ wc
+    y = y[:, :co] if pad else y
+    if epilogue is not None:
+        y = y.float() * scale + shift
+        y = torch.relu(y) if relu else y
+        if residual is not None:
+            y = y + residual.float()
+        y = y.to(cdtype)
+    elif bias is not None:
+        y = y + bias.detach().to(cdtype)
+    return xc, wc, pad, y
 
 
 class RowsMatmul(Function):

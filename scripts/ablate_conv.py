@@ -64,10 +64,10 @@ def run():
                              else (kmap.nbr_out, None, None))
             def launch():
                 rc = fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n, n, ci, co, 27, 0,
-                        B.dtype_code(dtype), None, None, 0, B.stream())
+                        B.dtype_code(dtype), None, None, 0, None, B.stream())
                 assert rc == 0
             if fn(B.ptr(x), B.ptr(wk), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n, n, ci, co, 27, 0,
-                  B.dtype_code(dtype), None, None, 0, B.stream()) != 0:
+                  B.dtype_code(dtype), None, None, 0, None, B.stream()) != 0:
                 times.append(float('nan'))
                 continue
             for _ in range(2):

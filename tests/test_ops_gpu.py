@@ -578,3 +578,24 @@ def test_kernel_map_rules_built_lazily_match_eager():
         assert torch.equal(oc_e, oc_l) and torch.equal(eager.nbr_out, lazy.nbr_out)
         assert torch.equal(eager.nbsizes, lazy.nbsizes) and torch.equal(eager.koff, lazy.koff)
         assert torch.equal(eager.nbmaps, lazy.nbmaps)
+
+
+def test_dense_epilogue_affine_relu_residual():
+    """Inference epilogue of the dense path: act((x @ W^T + b) * scale + shift) + residual in one
+    kernel (bf16 under autocast), and the unfused f32 fallback computing the same expression."""
+    from lidal_amd.nn.functional.dense import rows_linear
+    g = torch.Generator().manual_seed(21)
+    n, ci, co = 5003, 64, 96
+    x = torch.randn(n, ci, generator=g).to(DEV)
+    w = (torch.randn(co, ci, generator=g) * 0.1).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    scale = (torch.rand(co, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(co, generator=g).to(DEV)
+    res = torch.randn(n, co, generator=g).to(DEV)
+    ref = torch.relu((x.double() @ w.double().t() + b.double()) * scale.double() + shift.double()) + res.double()
+    with torch.no_grad():
+        y32 = rows_linear(x, w, b, epilogue=(scale, shift, True, res))
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y16 = rows_linear(x, w, b, epilogue=(scale, shift, True, res.bfloat16()))
+    assert y32.dtype == torch.float32 and _relerr(y32.cpu(), ref.cpu()) < 1e-5
+    assert y16.dtype == torch.bfloat16 and _relerr(y16.float().cpu(), ref.cpu()) < 2e-2

@@ -458,7 +458,7 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[g][nb][r] * es + eh;
-          acc[g][nb][r] = (ep_relu && v < 0.f) ? 0.f : v;
+          acc[g][nb][r] = ((ep_relu & 1) && v < 0.f) ? 0.f : v;
         }
     }
   }
@@ -482,7 +482,11 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
       if (ep_res != nullptr) {       // + residual row (same row, same columns), summed in f32
         const frag rr = *reinterpret_cast<const frag*>(ep_res + row * co + n0 + cseg);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = DT<T>::from_f32(DT<T>::to_f32(v[e]) + DT<T>::to_f32(rr[e]));
+        for (int e = 0; e < VEC; ++e) {
+          float f = DT<T>::to_f32(v[e]) + DT<T>::to_f32(rr[e]);
+          if ((ep_relu & 2) && f < 0.f) f = 0.f;          // ReLU of the residual block's sum
+          v[e] = DT<T>::from_f32(f);
+        }
       }
       *reinterpret_cast<frag*>(dst) = v;
     } else {
@@ -490,7 +494,10 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
       for (int e = 0; e < VEC; ++e)
         if (n0 + cseg + e < co) {
           float v = DT<T>::to_f32(srcp[e]);
-          if (ep_res != nullptr) v += DT<T>::to_f32(ep_res[row * co + n0 + cseg + e]);
+          if (ep_res != nullptr) {
+            v += DT<T>::to_f32(ep_res[row * co + n0 + cseg + e]);
+            if ((ep_relu & 2) && v < 0.f) v = 0.f;
+          }
           dst[e] = DT<T>::from_f32(v);
         }
     }

@@ -22,9 +22,9 @@ class ConvNormSequential(nn.Sequential):
     the fused ReLU) in the convolution's epilogue instead of a separate pass over the feature
     matrix.  Anything else runs child by child."""
 
-    def forward(self, x, residual=None):
-        """`residual` ([N, C] tensor, plain-tensor pipelines only): returns residual + self(x); on
-        the fused inference path the sum happens in the last layer's epilogue."""
+    def forward(self, x, residual=None, relu_after=False):
+        """`residual` ([N, C] features): returns self(x) + residual (ReLU'd if `relu_after`); on the
+        fused inference path the sum happens in the last layer's epilogue."""
         mods = list(self)
         while mods and isinstance(mods[-1], nn.Identity):
             mods.pop()
@@ -33,21 +33,31 @@ class ConvNormSequential(nn.Sequential):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if isinstance(m, spnn.Conv3d) and isinstance(nxt, spnn.BatchNorm) and _fusable(m, nxt, x):
-                x = _conv_norm(m, nxt, x)
+                last = i + 2 == len(mods) and residual is not None
+                x = _conv_norm(m, nxt, x, residual if last else None, relu_after)
+                if last:
+                    residual = None
                 i += 2
             elif (isinstance(m, spnn.Linear) and isinstance(nxt, spnn.BatchNorm1d)
                   and torch.is_tensor(x) and _fusable_rows(nxt, x, m.weight, m.bias)):
                 scale, shift = _fold(nxt, x.device)
                 last = i + 2 == len(mods)
+                relu = int(nxt.fused_relu) | (2 if (last and relu_after and residual is not None) else 0)
                 x = rows_linear(x, m.weight, m.bias,
-                                epilogue=(scale, shift, nxt.fused_relu, residual if last else None))
+                                epilogue=(scale, shift, relu, residual if last else None))
                 if last:
                     residual = None
                 i += 2
             else:
                 x = m(x)
                 i += 1
-        return x if residual is None else residual + x
+        if residual is None:
+            return x
+        if torch.is_tensor(x):
+            return add_relu(x, residual) if relu_after else residual + x
+        out = SparseTensor(add_relu(x.F, residual) if relu_after else x.F + residual, x.C, x.s)
+        out.cmaps, out.kmaps = x.cmaps, x.kmaps
+        return out
 
 
 def _fusable_rows(bn, feats, *params):
@@ -70,11 +80,12 @@ def _fold(bn, device):
     return fold[0], fold[1]
 
 
-def _conv_norm(conv, bn, x):
+def _conv_norm(conv, bn, x, residual=None, relu_after=False):
     scale, shift = _fold(bn, x.F.device)
+    relu = int(bn.fused_relu) | (2 if (relu_after and residual is not None) else 0)
     return conv3d(x, conv.kernel, kernel_size=conv.kernel_size, bias=None, stride=conv.stride,
                   dilation=conv.dilation, transposed=conv.transposed,
-                  epilogue=(scale, shift, bn.fused_relu))
+                  epilogue=(scale, shift, relu, residual))
 
 
 def _conv_bn(inc, outc, ks, stride=1, transposed=False):
@@ -127,7 +138,7 @@ class ResidualBlock(nn.Module):
         self.relu = spnn.ReLU(True)
 
     def forward(self, x):
-        a, b = self.net(x), self.downsample(x)
-        out = SparseTensor(add_relu(a.F, b.F), a.C, a.s)       # == self.relu(a + b), one pass
-        out.cmaps, out.kmaps = a.cmaps, a.kmaps
-        return out
+        b = self.downsample(x)
+        # == self.relu(self.net(x) + b): one add+ReLU pass in training, none at inference (the sum
+        # and the ReLU run in the epilogue of net's last convolution)
+        return self.net(x, residual=b.F, relu_after=True)

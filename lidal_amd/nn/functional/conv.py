@@ -211,16 +211,21 @@ def _pack_weight(weight, dtype, with_cast=False):
 
 def _apply(feats, wk, order, kflip, epilogue=None):
     """out[j] = sum_k feats[nbr[kk][j]] @ wk[k]^T with wk [K, co, ci]; `order` = RowOrder(nbr).
-    epilogue = (scale f32 [co], shift f32 [co], relu): out = act(out * scale + shift) in-kernel."""
+    epilogue = (scale f32 [co], shift f32 [co], relu[, residual [n_out, co]]): in-kernel
+    out = act(out * scale + shift) + residual; relu 1 = ReLU before the sum, 2 = after it."""
     k, co, ci = wk.shape
     n_out = order.n_rows
     out = torch.empty((n_out, co), dtype=feats.dtype, device=feats.device)
-    scale, shift, relu = epilogue if epilogue is not None else (None, None, False)
+    scale, shift, relu = epilogue[:3] if epilogue is not None else (None, None, 0)
+    residual = epilogue[3] if epilogue is not None and len(epilogue) > 3 else None
+    if residual is not None:
+        residual = residual.contiguous().to(feats.dtype)
+        assert residual.shape == (n_out, co)
     B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
                                      B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci, co, k,
                                      int(kflip),
                                      B.dtype_code(feats.dtype), B.ptr(scale), B.ptr(shift),
-                                     int(bool(relu)), None, B.stream()), 'conv_apply')
+                                     int(relu), B.ptr(residual), B.stream()), 'conv_apply')
     return out
 
 

@@ -93,7 +93,7 @@ def _rows_gemm(x, wk, shift=None, scale=None, relu=False, residual=None):
         scale = torch.ones(co, dtype=torch.float32, device=x.device)
     B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(nbr), None, B.ptr(masks), B.ptr(out),
                                      n, n, ci, co, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
-                                     B.ptr(shift), int(bool(relu)), B.ptr(residual), B.stream()),
+                                     B.ptr(shift), int(relu), B.ptr(residual), B.stream()),
             'conv_apply(dense)')
     return out
 
@@ -134,18 +134,22 @@ def _forward(x, w, bias, linear, epilogue=None):
         fused_res = residual if (residual is not None and not pad) else None
         if fused_res is not None:
             fused_res = fused_res.to(cdtype)
-        y = _rows_gemm(xc, wc.t().contiguous().unsqueeze(0), shift, scale, relu, fused_res)
+        late = residual is not None and fused_res is None       # sum (and its ReLU) outside the kernel
+        y = _rows_gemm(xc, wc.t().contiguous().unsqueeze(0), shift, scale,
+                       int(relu) & 1 if late else int(relu), fused_res)
         y = y[:, :co] if pad else y
-        if residual is not None and fused_res is None:
+        if late:
             y = y + residual.to(cdtype)
+            y = torch.relu(y) if int(relu) & 2 else y
         return xc, wc, pad, y
     y = xc @ wc
     y = y[:, :co] if pad else y
     if epilogue is not None:
         y = y.float() * scale + shift
-        y = torch.relu(y) if relu else y
+        y = torch.relu(y) if int(relu) & 1 else y
         if residual is not None:
             y = y + residual.float()
+            y = torch.relu(y) if int(relu) & 2 else y
         y = y.to(cdtype)
     elif bias is not None:
         y = y + bias.detach().to(cdtype)

@@ -545,6 +545,14 @@ def test_conv_affine_relu_epilogue(dtype):
             assert _relerr(fused.cpu(), ref.cpu()) < tol
             if relu:
                 assert (fused >= 0).all()
+        # residual operand: relu & 1 acts before the sum, relu & 2 after it (residual block)
+        res = torch.randn(n, co, generator=g).to(dtype).to(DEV)
+        a = conv3d(SparseTensor(x, coords), w, 3, epilogue=(scale, shift, 1, res)).F.float()
+        b = conv3d(SparseTensor(x, coords), w, 3, epilogue=(scale, shift, 2, res)).F.float()
+        base = plain * scale + shift
+        tol = 1e-6 if dtype == torch.float32 else 2e-2
+        assert _relerr(a.cpu(), (torch.relu(base) + res.float()).cpu()) < tol
+        assert _relerr(b.cpu(), torch.relu(base + res.float()).cpu()) < tol
 
 
 def test_batchnorm_module_counts_batches_in_kernel():

@@ -179,3 +179,21 @@ def test_iou_from_confusion_matches_reference_formula():
         else:
             assert ious[i] == tp / (tp + fp + fn)
     assert np.isnan(miou)
+
+
+def test_wgrad_slab_policy_is_bounded_and_occupancy_sized():
+    """Host policy of the split-K weight gradient: slab = rules x tiles / 512 resident workgroups,
+    a multiple of 64 rules within [512, 4096]; the slab count never exceeds the 256 the partial
+    buffer is allocated for."""
+    from lidal_amd.nn.functional.conv import _wgrad_chunk, _wgrad_splits, _wgrad_tile
+    assert [_wgrad_tile(c) for c in (19, 32, 64, 96, 128, 192, 256, 384)] == [32, 32, 64, 96, 128, 96, 128, 128]
+    for n in (1, 500, 17000, 105000, 397000, 3000000):
+        for ca, cb in ((32, 32), (96, 96), (128, 96), (256, 256), (384, 256)):
+            for rpr in (1, 6):
+                c = _wgrad_chunk(n, ca, cb, rpr)
+                assert 512 <= c <= 4096 and c % 64 == 0
+                assert 1 <= _wgrad_splits(n, c) <= 256
+    # one round of workgroups: 96->96 on the bench batch keeps the large slab, the small level shrinks
+    assert _wgrad_chunk(397000, 96, 96, 6) == 4096
+    assert _wgrad_chunk(105000, 128, 128, 6) < 2048
+    assert _wgrad_chunk(397000, 128, 96, 1) < 1024          # dense layer: many more than 97 workgroups

@@ -143,3 +143,12 @@ class NoGradCtx:
 
     def save_for_backward(self, *tensors):
         pass
+
+
+def compute_dtype(x):
+    """Operand dtype of the MFMA kernels for input `x`: bf16 under bf16 autocast, the input's own
+    dtype if it is f32 / bf16, f32 otherwise (fp16 autocast is not a mode of this backend: it
+    computes in f32 rather than silently in another 16-bit format)."""
+    if torch.is_autocast_enabled():
+        return torch.bfloat16 if torch.get_autocast_dtype('cuda') == torch.bfloat16 else torch.float32
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32

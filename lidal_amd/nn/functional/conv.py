@@ -266,9 +266,7 @@ def _wgrad_splits(n_rows, chunk=None):
 
 def _forward(feats, weight, kmap, transposed, with_cast, epilogue=None):
     B.require_gpu(feats, weight)
-    cdtype = torch.bfloat16 if torch.is_autocast_enabled() else feats.dtype
-    if cdtype not in (torch.float32, torch.bfloat16):
-        cdtype = torch.float32
+    cdtype = B.compute_dtype(feats)
     x = feats.contiguous().to(cdtype)
     order = kmap.order_in if transposed else kmap.order_out
     wt, wc = _pack_weight(weight, cdtype, with_cast)

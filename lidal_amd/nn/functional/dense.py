@@ -113,7 +113,7 @@ def _forward(x, w, bias, linear, epilogue=None):
     """epilogue (inference only) = (scale f32 [Cout], shift f32 [Cout], relu[, residual [N, Cout]]):
     the eval-mode BatchNorm (+ ReLU) that follows the layer and an optional row-wise sum,
     y = act((x @ w + bias) * scale + shift) + residual."""
-    cdtype = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
+    cdtype = B.compute_dtype(x)
     xc = x.contiguous().to(cdtype)
     co = w.shape[0] if linear else w.shape[1]
     pad = (-co) % _vec(cdtype) if xc.is_cuda else 0

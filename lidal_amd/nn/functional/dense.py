@@ -60,7 +60,7 @@ def _identity_table(n, device):
     key = (n, str(device))
     t = _ident_cache.get(key)
     if t is None:
-        if len(_ident_cache) > 64:
+        if len(_ident_cache) >= 8:          # a few row counts recur (the levels of one batch); bound the memory
             _ident_cache.clear()
         t = (torch.arange(n, dtype=torch.int, device=device).view(1, n),
              torch.ones(max(1, -(-n // 128)), dtype=torch.int, device=device))

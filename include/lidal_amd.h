@@ -172,8 +172,9 @@ int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void* wc, int w
  * lidal_bn_fold) give out = act(acc * scale + shift), act = ReLU iff (ep_relu & 1); ep_residual
  * (NULL or a [n_out, co] matrix of the output's dtype) is added to that, row for row (the
  * point-branch sum network/spvcnn.py:136,143,151; the shortcut of a residual block,
- * network/utils.py:171, whose ReLU comes AFTER the sum: ep_relu & 2).  With k = 1 and the identity table the same kernel is the dense
- * per-row product of the 1x1x1 convolutions and nn.Linear layers. */
+ * network/utils.py:171, whose ReLU comes AFTER the sum: ep_relu & 2).  With k = 1 and nbr = NULL
+ * (the identity rule list) the same kernel is the dense per-row product of the 1x1x1 convolutions
+ * and nn.Linear layers. */
 int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const int32_t* perm,
                      const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out, int ci,
                      int co, int k, int kflip, int dtype, const float* ep_scale,

@@ -184,7 +184,12 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   __shared__ unsigned tile_mask;
   __shared__ int act_k[MAXK];
   unsigned tmask;
-  if (tmasks != nullptr) {
+  if (nbr == nullptr) {
+    // ---- 0. no table at all: the identity rule list of a dense per-row product (K == 1)
+    tmask = 1u;
+    if (tid == 0) act_k[0] = 0;
+    for (int r = lane; r < RW; r += 64) nidx[r] = (r0 + r < n_out) ? (int)(r0 + r) : -1;
+  } else if (tmasks != nullptr) {
     // ---- 0a. occupancy mask of this 128-row tile, precomputed with the row order (one load);
     //          only the offsets it names are fetched, staged and multiplied
     unsigned m = tmasks[((int64_t)blockIdx.x * BM) >> 7];     // masks are per 128 sorted rows
@@ -1030,6 +1035,7 @@ extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* n
   Epi ep{ep_scale, ep_shift, ep_relu, ep_residual, (unsigned)(n_in * ci * esz),
          (unsigned)((int64_t)k * ci * co * esz)};
   LIDAL_REQUIRE(ci > 0 && k > 0 && k <= MAXK, "conv_apply: bad shape ci=%d k=%d", ci, k);
+  LIDAL_REQUIRE(nbr != nullptr || (k == 1 && n_in == n_out), "conv_apply: a NULL table means the identity (k = 1)");
   if (dtype == LIDAL_F32) {
     LIDAL_REQUIRE(ci % 4 == 0 && co % 4 == 0, "conv_apply f32: channels must be multiples of 4");
     return dispatch_conv_apply<float>(in, wk, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);

@@ -51,23 +51,6 @@ def _vec(dtype):
     return 8 if dtype == torch.bfloat16 else 4
 
 
-_ident_cache = {}
-
-
-def _identity_table(n, device):
-    """(nbr i32 [1, n] = arange, tile masks u32 [tiles] = 1): the dense product as a one-offset
-    convolution whose rule list is the identity."""
-    key = (n, str(device))
-    t = _ident_cache.get(key)
-    if t is None:
-        if len(_ident_cache) >= 8:          # a few row counts recur (the levels of one batch); bound the memory
-            _ident_cache.clear()
-        t = (torch.arange(n, dtype=torch.int, device=device).view(1, n),
-             torch.ones(max(1, -(-n // 128)), dtype=torch.int, device=device))
-        _ident_cache[key] = t
-    return t
-
-
 def _gemm_ok(x, ci, co):
     if not x.is_cuda or x.shape[0] == 0 or x.shape[0] * ci * x.element_size() >= 0x7FFFFFF0:
         return False
@@ -79,19 +62,18 @@ def _gemm_ok(x, ci, co):
 
 def _rows_gemm(x, wk, shift=None, scale=None, relu=False, residual=None):
     """x [n, ci] @ wk[0]^T with wk [1, co, ci] (reduction dim contiguous), + shift f32 [co]: the
-    sparse-convolution kernel with the identity rule list.  A library GEMM runs these tall-skinny
+    sparse-convolution kernel with the identity rule list (a NULL table).  A library GEMM runs these tall-skinny
     products (4e5 x 128 @ 128 x 96) at ~1.7 TB/s of operand traffic; this kernel streams the rows
     once and keeps the small weight in LDS."""
     n, ci = x.shape
     co = wk.shape[1]
-    nbr, masks = _identity_table(n, x.device)
     out = torch.empty((n, co), dtype=x.dtype, device=x.device)
     if residual is not None:
         residual = residual.contiguous()
         assert residual.shape == out.shape and residual.dtype == out.dtype
     if shift is not None and scale is None:
         scale = torch.ones(co, dtype=torch.float32, device=x.device)
-    B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(nbr), None, B.ptr(masks), B.ptr(out),
+    B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), None, None, None, B.ptr(out),
                                      n, n, ci, co, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
                                      B.ptr(shift), int(relu), B.ptr(residual), B.stream()),
             'conv_apply(dense)')

@@ -133,3 +133,36 @@ def test_edge_cases_empty_single_and_range_limit():
     nb, ns, sizes, ocr, res = RF.build_kmap(c, (1, 1, 1), (2, 2, 2), (2, 2, 2))
     km, oc = F.build_kernel_map(c.to(DEV), (1, 1, 1), (2, 2, 2), (2, 2, 2))
     assert torch.equal(oc.cpu(), ocr) and torch.equal(km.nbmaps.cpu().long(), nb)
+
+
+def test_edge_cases_of_the_fused_ops():
+    """Empty / single-row / all-ignored inputs through the fused row-wise ops, the dense path and
+    the inference epilogues."""
+    import lidal_amd
+    from lidal_amd.nn import functional as F
+    from lidal_amd.nn.functional.dense import rows_linear
+    z = torch.zeros((0, 32), device=DEV)
+    assert F.add_relu(z, z).shape == (0, 32)
+    lab = torch.full((64,), 255, dtype=torch.int64, device=DEV)
+    logits = torch.randn(64, 19, device=DEV, requires_grad=True)
+    loss = F.cross_entropy(logits, lab, 255)            # nothing to average over: nan, as torch
+    assert torch.isnan(loss)
+    lab[3] = 7
+    loss = F.cross_entropy(logits, lab, 255)
+    loss.backward()
+    ref = torch.nn.functional.cross_entropy(logits.detach(), lab, ignore_index=255)
+    assert abs(loss.item() - ref.item()) < 1e-5 and (logits.grad[lab == 255] == 0).all()
+    w = torch.randn(24, 32, device=DEV)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        assert rows_linear(z, w).shape == (0, 24)
+        one = rows_linear(torch.ones(1, 32, device=DEV), w)             # one row through the MFMA tile
+    assert torch.allclose(one.float()[0], w.sum(1), atol=0.15)
+    # inference epilogue on a single voxel at the coordinate range limit
+    c1 = torch.tensor([[8191, 0, 8191, 3]], dtype=torch.int, device=DEV)
+    wk = torch.randn(27, 8, 32, device=DEV)
+    scale, shift = torch.full((32,), 2.0, device=DEV), torch.full((32,), -1.0, device=DEV)
+    res = torch.ones(1, 32, device=DEV)
+    with torch.no_grad():
+        y = F.conv3d(lidal_amd.SparseTensor(torch.ones(1, 8, device=DEV), c1, 1), wk, 3,
+                     epilogue=(scale, shift, 2, res)).F
+    assert torch.allclose(y[0], torch.relu(wk[13].sum(0) * 2 - 1 + 1), atol=1e-4)

@@ -8,6 +8,8 @@ vice versa.
   super_voxel/.../<frame>.pickle (sv_id i64 [S], sv2point list of i64 arrays)
                                               dataset/prepare_supervoxel_kmeans_sk.py:62-74
   sv_flag/.../<frame>.npy      i64 [S] in {0,1,2}   LiDAL.py:328-330
+  super_voxel/KMeans/sv_pnums.npy, sv_centers.npy   i64 [sum S]; f32 [sum S, 3] with the
+                               +1000 * sequence-index offset      LiDAL.py:173-177,220-222
   <dir>/current.pt             {'model_state_dict', 'iteration', 'ep_id'}   train.py:151-155
 """
 import os
@@ -17,7 +19,7 @@ import numpy as np
 import torch
 
 __all__ = ['save_prob_pred', 'load_prob', 'load_supervoxels', 'save_supervoxels', 'load_sv_flag',
-           'save_sv_flag', 'save_checkpoint', 'load_checkpoint']
+           'save_sv_flag', 'load_sv_stats', 'save_sv_stats', 'save_checkpoint', 'load_checkpoint']
 
 
 def _mkdir_for(path):
@@ -62,6 +64,21 @@ def load_sv_flag(path):
 def save_sv_flag(path, flags):
     _mkdir_for(path)
     np.save(path, np.asarray(flags))
+
+
+def load_sv_stats(pnums_path, centers_path):
+    """The cached per-supervoxel statistics of LiDAL.py:173-177: (sv_pnums i64 [N], sv_centers f32
+    [N,3]) -- feed them to score.ScoreBoard(n, sv_pnums, sv_centers) (the reference's `sv_pre`)."""
+    pn, ce = np.load(pnums_path), np.load(centers_path)
+    assert pn.ndim == 1 and ce.shape == (pn.shape[0], 3), (pn.shape, ce.shape)
+    return pn, ce
+
+
+def save_sv_stats(pnums_path, centers_path, sv_pnums, sv_centers):
+    """LiDAL.py:220-222 (written once, by the first scoring round)."""
+    _mkdir_for(pnums_path), _mkdir_for(centers_path)
+    np.save(pnums_path, np.asarray(sv_pnums))
+    np.save(centers_path, np.asarray(sv_centers))
 
 
 def save_checkpoint(directory, model, iteration, ep_id):

@@ -2,10 +2,10 @@
 view-mean probabilities) and score/sv_level/LiDAL.py (inter-frame divergence / entropy per
 supervoxel + greedy selection), with frames sharded over the GPUs of a node."""
 from .interframe import FrameBank, neighbour_ids, score_frame
-from .pipeline import score_sequence
+from .pipeline import ScoreBoard, collect_sequence, score_sequence
 from .prob_inference import infer_frame
 from .selection import select
 from .sharding import frame_range, gather_frames
 
-__all__ = ['infer_frame', 'FrameBank', 'neighbour_ids', 'score_frame', 'score_sequence', 'select',
+__all__ = ['infer_frame', 'FrameBank', 'neighbour_ids', 'score_frame', 'score_sequence', 'collect_sequence', 'ScoreBoard', 'select',
            'frame_range', 'gather_frames']

@@ -1,37 +1,106 @@
 """One scoring pass over a sequence, frame-sharded: the GPU counterpart of running
 /root/reference/score/prob_inference.py (per-frame 8-view inference, :91-133) followed by
-score/sv_level/LiDAL.py:185-218 (per-frame inter-frame divergence / entropy per supervoxel).
+score/sv_level/LiDAL.py:185-218 (per-frame inter-frame divergence / entropy per supervoxel) and
+the hand-off to the single-process selection (:208-222 scatter into the global arrays, :225-330).
 
 Each rank owns a contiguous block of frames (dataset/sk_dataloader.py:196-198); probabilities and
-world coordinates are exchanged by one all-gather (replacing the .npy / KD-tree pickle hand-off),
-after which every rank scores its own frames against full +-nei windows.
+world coordinates are exchanged by one all-gather each (replacing the .npy / KD-tree pickle
+hand-off), after which every rank scores its own frames against full +-nei windows.  The
+per-supervoxel results (20 x 7 numbers per frame) then travel to rank 0 in one more collective;
+selection is host Python on rank 0 (replicas only).
 """
+import numpy as np
 import torch
+import torch.distributed as dist
 
 from .interframe import FrameBank, score_frame
 from .prob_inference import infer_frame
-from .sharding import gather_frames
+from .selection import select
+from .sharding import gather_frames, is_sharded
 
-__all__ = ['score_sequence']
+__all__ = ['score_sequence', 'collect_sequence', 'ScoreBoard']
 
 
 def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_thresh=0.1,
-                   inf_reps=8, autocast=False):
+                   inf_reps=8, autocast=False, group=None):
     """local_frames: list of dicts for frames first_frame, first_frame+1, ... owned by this rank,
     each with device tensors coords (i32 [N,4]), feats (f32 [N,4]), inverse (i64 [reps*P]),
     world (f64 [P,3]), sv_ptr / sv_idx (CSR of the supervoxels).
     Returns a list (one entry per local frame) of (sv_interds f32 [S], sv_interes f32 [S],
     sv_centers f32 [S,3]) device tensors."""
     probs, worlds = {}, {}
+    n_class = None
     for s, d in enumerate(local_frames):
         prob, _ = infer_frame(model, d['coords'], d['feats'], d['inverse'], inf_reps,
                               autocast=autocast)
         probs[first_frame + s] = prob
         worlds[first_frame + s] = d['world']
-    all_prob = gather_frames(probs, n_total)
-    all_world = gather_frames(worlds, n_total)
+        n_class = prob.shape[1]
+    if n_class is None:                       # a rank without frames still joins the collectives
+        n_class = model.num_classes if hasattr(model, 'num_classes') else 19
+    dev = local_frames[0]['world'].device if local_frames else None
+    all_prob = gather_frames(probs, n_total, (n_class,), torch.float32, group=group, device=dev)
+    all_world = gather_frames(worlds, n_total, (3,), torch.float64, group=group, device=dev)
     bank = FrameBank(dis_thresh)
     for w, p in zip(all_world, all_prob):
         bank.add(w, p)
     return [score_frame(bank, first_frame + s, d['sv_ptr'], d['sv_idx'], nei_num)
             for s, d in enumerate(local_frames)]
+
+
+def collect_sequence(local_scores, local_sv_ids, local_sv_ptrs, first_frame, n_total, group=None):
+    """The return leg of a sequence (LiDAL.py:206-207, `re_values = pool.map(worker_func, ids)`):
+    local_scores = score_sequence()'s list for this rank's frames, local_sv_ids = per frame the
+    global supervoxel ids (i64 [S], the pickle's `sv_id`), local_sv_ptrs = per frame the CSR
+    pointer (pnums = its differences, LiDAL.py:94).  On rank 0 returns, for every frame of the
+    sequence in order, worker_func's tuple (sv_id i64 [S], sv_interds f32 [S], sv_interes f32 [S],
+    sv_pnums i64 [S], sv_centers f32 [S,3]) as numpy arrays; None on the other ranks.
+    Everything rides in ONE f64 [S,7] block per frame (f32 values, ids and counts are exact in f64)."""
+    packed = {}
+    for s, (sc, ids, ptr) in enumerate(zip(local_scores, local_sv_ids, local_sv_ptrs)):
+        sv_d, sv_e, sv_c = sc
+        ids = torch.as_tensor(np.asarray(ids), dtype=torch.float64, device=sv_d.device)
+        pn = (ptr[1:] - ptr[:-1]).to(device=sv_d.device, dtype=torch.float64)
+        packed[first_frame + s] = torch.cat(
+            [ids[:, None], sv_d.double()[:, None], sv_e.double()[:, None], pn[:, None],
+             sv_c.double()], dim=1).contiguous()
+    if is_sharded(group):
+        dev = local_scores[0][0].device if local_scores else None
+        got = gather_frames(packed, n_total, (7,), torch.float64, group=group, device=dev)
+        if dist.get_rank(group) != 0:
+            return None
+    else:
+        got = [packed[f] for f in range(n_total)]
+    out = []
+    for g in got:
+        g = g.cpu().numpy()
+        out.append((g[:, 0].astype(np.int64), g[:, 1].astype(np.float32), g[:, 2].astype(np.float32),
+                    g[:, 3].astype(np.int64), g[:, 4:7].astype(np.float32)))
+    return out
+
+
+class ScoreBoard:
+    """Rank 0's global per-supervoxel arrays (LiDAL.py:167-182) + the scatter of each sequence's
+    results into them (:208-218) + the selection call (:225-325)."""
+
+    def __init__(self, n_sv, sv_pnums=None, sv_centers=None):
+        self.sv_interds = np.zeros(n_sv, dtype=np.float32)
+        self.sv_interes = np.zeros(n_sv, dtype=np.float32)
+        self.sv_pre = sv_pnums is not None          # cached stats from an earlier round (:173-177)
+        self.sv_pnums = np.asarray(sv_pnums) if self.sv_pre else np.zeros(n_sv, dtype=int)
+        self.sv_centers = (np.asarray(sv_centers) if self.sv_pre
+                           else np.zeros((n_sv, 3), dtype=np.float32))
+
+    def add_sequence(self, seq_index, frames):
+        """frames: collect_sequence()'s list for sequence number `seq_index` of the split."""
+        for sv_id, d, e, n, c in frames:
+            self.sv_interds[sv_id] = d
+            self.sv_interes[sv_id] = e
+            if not self.sv_pre:
+                self.sv_pnums[sv_id] = n
+                # offset that keeps supervoxels of different sequences > 5 m apart (:218)
+                self.sv_centers[sv_id] = c + seq_index * 1000.0
+
+    def select(self, sv_flags, train_point_num, sv_dis_thresh=5.0):
+        return select(sv_flags, self.sv_interds, self.sv_interes, self.sv_pnums, self.sv_centers,
+                      train_point_num, sv_dis_thresh)

@@ -15,6 +15,8 @@ What each fixture pins
   selection_small.npz reference score/sv_level/LiDAL.py __main__ run unchanged in a temp
                       Processing_files tree (10 sequences); asserts oracle.scoring_ref.select
                       reproduces the written sv_flag files.
+  io_small.npz        raw bytes of files of that tree (written by the reference's __main__, or
+                      consumed by it) + the arrays they decode to: fixture of lidal_amd.io.
 """
 import json
 import os
@@ -235,13 +237,13 @@ def make_selection():
     sv_pnums = np.load(os.path.join(base, 'super_voxel/KMeans/sv_pnums.npy'))
     sv_centers = np.load(os.path.join(base, 'super_voxel/KMeans/sv_centers.npy'))
     # oracle: score every frame, then select
-    d_all, e_all = [], []
+    d_all, e_all, c_all = [], [], []
     for s_i in range(len(seqs)):
         lo = s_i * n_frames
         pr, wo = all_probs[lo:lo + n_frames], all_worlds[lo:lo + n_frames]
         for i in range(n_frames):
             d, e, n, c = scoring_ref.score_frame(i, pr, wo, all_sv[lo + i], 24, 0.1)
-            d_all.append(d), e_all.append(e)
+            d_all.append(d), e_all.append(e), c_all.append(c)
             assert np.array_equal(n, sv_pnums[(lo + i) * n_sv:(lo + i + 1) * n_sv])
             assert np.array_equal(c + np.float32(s_i * 1000.0),
                                   sv_centers[(lo + i) * n_sv:(lo + i + 1) * n_sv])
@@ -252,7 +254,28 @@ def make_selection():
     np.savez_compressed(os.path.join(HERE, 'selection_small.npz'), flags_in=flags_in,
                         sv_interds=np.concatenate(d_all), sv_interes=np.concatenate(e_all),
                         sv_pnums=sv_pnums, sv_centers=sv_centers,
+                        sv_centers_local=np.concatenate(c_all),      # per frame, before the +1000*seq offset
+                        n_frames=n_frames, n_sv=n_sv,
                         flags_out=np.concatenate(new_flags), train_point_num=2349559532)
+    # io_small.npz: the BYTES of files of that tree -- the ones the reference's __main__ wrote
+    # (sv_flag of round 1, sv_pnums.npy, sv_centers.npy: LiDAL.py:220-222,328-330) and the inputs it
+    # consumed in the formats of Appendix B (prob .npy, supervoxel pickle, round-0 sv_flag) -- with
+    # the arrays they must decode to.  Data, not source.
+    def raw(*parts):
+        return np.frombuffer(open(os.path.join(base, *parts), 'rb').read(), dtype=np.uint8)
+    np.savez_compressed(
+        os.path.join(HERE, 'io_small.npz'),
+        file_sv_flag_1r=raw('sv_flag/KMeans/SPVCNN/LiDAL/1r', seqs[2], '000004.npy'),
+        sv_flag_1r=new_flags[2 * n_frames + 4],
+        file_sv_flag_0r=raw('sv_flag/KMeans/0r', seqs[2], '000004.npy'),
+        sv_flag_0r=all_flags[2 * n_frames + 4],
+        file_sv_pnums=raw('super_voxel/KMeans/sv_pnums.npy'), sv_pnums=sv_pnums,
+        file_sv_centers=raw('super_voxel/KMeans/sv_centers.npy'), sv_centers=sv_centers,
+        file_prob=raw('prob_map/SPVCNN/fr/0r', seqs[2], '000004.npy'),
+        prob=all_probs[2 * n_frames + 4],
+        file_supervoxel=raw('super_voxel/KMeans', seqs[2], '000004.pickle'),
+        sv_id=np.arange((2 * n_frames + 4) * n_sv, (2 * n_frames + 5) * n_sv, dtype=np.int64),
+        sv2point=np.stack(all_sv[2 * n_frames + 4]))
     print('selection: oracle == reference __main__;', int((sel == 1).sum()), 'labelled,',
           int((sel == 2).sum()), 'pseudo-labelled of', sel.size)
 

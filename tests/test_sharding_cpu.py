@@ -1,6 +1,8 @@
 """Multi-rank path on CPU: world_size-2 gloo processes shard frames as
 dataset/sk_dataloader.py:196-198 does and exchange per-frame arrays with ONE all-gather; the
-gathered bank must equal the single-process one."""
+gathered bank must equal the single-process one.  The return leg -- per-supervoxel results to
+rank 0, scatter into the global arrays (LiDAL.py:208-218), selection (:225-330) -- is checked
+against the flags the reference's own __main__ wrote (tests/golden/selection_small.npz)."""
 import os
 import socket
 
@@ -8,6 +10,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 def _free_port():
@@ -23,16 +27,20 @@ def _frames(n_frames):
     return [torch.from_numpy(rng.random((50 + 7 * f, 19)).astype(np.float32)) for f in range(n_frames)]
 
 
-def _worker(rank, world, port, n_frames, out_dir):
+def _init(rank, world, port):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    _init(rank, world, port)
     from lidal_amd.score import frame_range, gather_frames
     frames = _frames(n_frames)
     mine = {f: frames[f] for f in frame_range(n_frames, world, rank)}
-    got = gather_frames(mine, n_frames)
+    got = gather_frames(mine, n_frames, (19,), torch.float32)
     ok = len(got) == n_frames and all(torch.equal(a, b) for a, b in zip(got, frames))
-    worlds = gather_frames({f: frames[f][:, :3].double() for f in mine}, n_frames)
+    worlds = gather_frames({f: frames[f][:, :3].double() for f in mine}, n_frames, (3,), torch.float64)
     ok = ok and all(torch.equal(a, b[:, :3].double()) for a, b in zip(worlds, frames))
     torch.save(ok, os.path.join(out_dir, 'ok_%d.pt' % rank))
     dist.destroy_process_group()
@@ -48,7 +56,9 @@ def test_frame_range_is_the_reference_contiguous_split():
 
 
 def test_gather_frames_world_size_2_gloo(tmp_path):
-    for n_frames in (7, 2):
+    # 7 and 2 frames: uneven / even blocks; 1 frame: rank 1 owns NOTHING and still has to join the
+    # collectives with tensors of the agreed shape, dtype and device (9 frames on 8 GPUs in config 4)
+    for n_frames in (7, 2, 1):
         port = _free_port()
         mp.spawn(_worker, args=(2, port, n_frames, str(tmp_path)), nprocs=2, join=True)
         assert all(torch.load(os.path.join(str(tmp_path), 'ok_%d.pt' % r)) for r in range(2))
@@ -57,5 +67,68 @@ def test_gather_frames_world_size_2_gloo(tmp_path):
 def test_gather_frames_single_process_is_identity():
     from lidal_amd.score import gather_frames
     frames = _frames(4)
-    got = gather_frames({f: frames[f] for f in range(4)}, 4)
+    got = gather_frames({f: frames[f] for f in range(4)}, 4, (19,), torch.float32)
     assert all(a is b for a, b in zip(got, frames))
+
+
+def _select_worker(rank, world, port, out_dir):
+    """Each rank holds the per-frame results of ITS frame block of every sequence (as
+    score_sequence returns them); rank 0 must end up with the reference's flags."""
+    _init(rank, world, port)
+    from lidal_amd.score import ScoreBoard, collect_sequence, frame_range
+    g = np.load(os.path.join(GOLDEN, 'selection_small.npz'))
+    n_frames, n_sv = int(g['n_frames']), int(g['n_sv'])
+    n_seq = g['flags_in'].size // (n_frames * n_sv)
+    board = ScoreBoard(g['flags_in'].size) if rank == 0 else None
+    for s_i in range(n_seq):
+        mine = list(frame_range(n_frames, world, rank))
+        scores, ids, ptrs = [], [], []
+        for f in mine:
+            lo = (s_i * n_frames + f) * n_sv
+            sl = slice(lo, lo + n_sv)
+            scores.append((torch.from_numpy(g['sv_interds'][sl]), torch.from_numpy(g['sv_interes'][sl]),
+                           torch.from_numpy(g['sv_centers_local'][sl])))
+            ids.append(np.arange(lo, lo + n_sv, dtype=np.int64))
+            ptrs.append(torch.from_numpy(np.concatenate([[0], np.cumsum(g['sv_pnums'][sl])])))
+        frames = collect_sequence(scores, ids, ptrs, mine[0] if mine else 0, n_frames)
+        assert (frames is None) == (rank != 0)
+        if rank == 0:
+            board.add_sequence(s_i, frames)
+    ok = True
+    if rank == 0:
+        ok = (np.array_equal(board.sv_interds, g['sv_interds'])
+              and np.array_equal(board.sv_interes, g['sv_interes'])
+              and np.array_equal(board.sv_pnums, g['sv_pnums'])
+              and np.array_equal(board.sv_centers, g['sv_centers']))      # incl. the +1000*seq offset
+        flags = board.select(g['flags_in'], int(g['train_point_num']))
+        ok = ok and np.array_equal(flags, g['flags_out'])
+    torch.save(bool(ok), os.path.join(out_dir, 'sel_%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_rank0_collection_and_selection_match_reference_flags_gloo(tmp_path):
+    """sv results of all ranks -> rank 0 -> global arrays -> select() equals the
+    sv_flag files /root/reference/score/sv_level/LiDAL.py's __main__ wrote (10 sequences x 25
+    frames x 20 supervoxels), with the frames of every sequence split over 2 ranks."""
+    port = _free_port()
+    mp.spawn(_select_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(torch.load(os.path.join(str(tmp_path), 'sel_%d.pt' % r)) for r in range(2))
+
+
+def test_collection_single_process_matches_reference_flags():
+    from lidal_amd.score import ScoreBoard, collect_sequence
+    g = np.load(os.path.join(GOLDEN, 'selection_small.npz'))
+    n_frames, n_sv = int(g['n_frames']), int(g['n_sv'])
+    board = ScoreBoard(g['flags_in'].size)
+    for s_i in range(g['flags_in'].size // (n_frames * n_sv)):
+        scores, ids, ptrs = [], [], []
+        for f in range(n_frames):
+            lo = (s_i * n_frames + f) * n_sv
+            sl = slice(lo, lo + n_sv)
+            scores.append((torch.from_numpy(g['sv_interds'][sl]), torch.from_numpy(g['sv_interes'][sl]),
+                           torch.from_numpy(g['sv_centers_local'][sl])))
+            ids.append(np.arange(lo, lo + n_sv, dtype=np.int64))
+            ptrs.append(torch.from_numpy(np.concatenate([[0], np.cumsum(g['sv_pnums'][sl])])))
+        board.add_sequence(s_i, collect_sequence(scores, ids, ptrs, 0, n_frames))
+    assert np.array_equal(board.sv_centers, g['sv_centers'])
+    assert np.array_equal(board.select(g['flags_in'], int(g['train_point_num'])), g['flags_out'])

@@ -14,6 +14,14 @@ LIB_PATH = os.environ.get('LIDAL_AMD_LIB') or os.path.join(_HERE, 'liblidal_amd.
 
 F32, BF16 = 0, 1
 _lib = None
+# calls that reached the HIP library, per entry point family (tests assert the product modules took
+# the HIP path: spnn.Linear / BatchNorm1d can fall through to torch for configurations the kernels
+# do not cover, and a silent dispatch regression would otherwise still pass the numerics tests)
+HITS = {}
+
+
+def hit(name):
+    HITS[name] = HITS.get(name, 0) + 1
 
 _vp, _i32, _i64, _f32, _f64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                ctypes.c_double)
@@ -100,17 +108,31 @@ def lib():
 
 
 def check(rc, what):
+    HITS[what] = HITS.get(what, 0) + 1
     if rc != 0:
         raise RuntimeError('lidal_amd.%s failed (%d): %s' %
                            (what, rc, lib().lidal_last_error().decode()))
 
 
 def require_gpu(*tensors):
+    """Every operand must be a GPU tensor ON THE CURRENT DEVICE: kernels are launched on the current
+    device's stream (stream() below), so a tensor of another GPU would be a foreign pointer there
+    (a memory fault, not a Python error).  One process per GPU is the deployment; inside one
+    process use `with torch.cuda.device(t.device):` around calls on a non-current device."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 'lidal_amd operators run on the GPU only (got a %s tensor); the CPU restatement '
                 'is oracle/ and is test infrastructure, not a fallback' % t.device)
+        if cur is None:
+            cur = torch._C._cuda_getDevice()
+        if t.device.index != cur:
+            raise RuntimeError('lidal_amd: tensor on %s but the current device is cuda:%d -- kernels '
+                               'launch on the current device (torch.cuda.set_device / '
+                               'torch.cuda.device(...))' % (t.device, cur))
 
 
 def ptr(t):

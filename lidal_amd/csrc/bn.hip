@@ -43,11 +43,11 @@ template <> struct IO<__bf16> {
 };
 
 // merge (nb, mb, M2b) into (na, ma, M2a)  -- Chan et al.
-__device__ __forceinline__ void chan_merge(float& na, float& ma, float& m2a, float nb, float mb,
-                                           float m2b) {
-  if (nb == 0.f) return;
-  float n = na + nb;
-  float d = mb - ma;
+__device__ __forceinline__ void chan_merge(double& na, double& ma, double& m2a, double nb, double mb,
+                                           double m2b) {
+  if (nb == 0.) return;
+  double n = na + nb;
+  double d = mb - ma;
   ma = ma + d * (nb / n);
   m2a = m2a + m2b + d * d * (na * nb / n);
   na = n;
@@ -60,8 +60,8 @@ __device__ __forceinline__ void chan_merge(float& na, float& ma, float& m2a, flo
 // then the next row: fully coalesced, and no per-element div/mod.
 
 // LDS tree sum over the row lanes of each channel group: v[tid*VEC+i] += ... ; result in rl == 0
-template <int VEC>
-__device__ __forceinline__ void tree_sum_rows(float* v, int tid, int cg_n, int rpi, int rl) {
+template <int VEC, typename A>
+__device__ __forceinline__ void tree_sum_rows(A* v, int tid, int cg_n, int rpi, int rl) {
   int span = 1;
   while (span < rpi) span <<= 1;
   for (int s = span >> 1; s >= 1; s >>= 1) {
@@ -77,18 +77,24 @@ __device__ __forceinline__ void tree_sum_rows(float* v, int tid, int cg_n, int r
 // ---- statistics: per-workgroup partial (count, mean, M2) per channel ----
 // All threads of the workgroup shift by the SAME value (the slab's first row), so inside the slab
 // plain sums of (x-K) and (x-K)^2 can be added; only slabs are merged with Chan's formula.
+// Every sum of this file is ACCUMULATED IN F64 (per thread, in the LDS tree, across slabs): the
+// kernels are HBM-bound, the f64 adds are free, and the reductions then carry no summation error
+// at all -- what is left is the f32 rounding of each term.  (With f32 accumulation the gradient of
+// one BatchNorm gamma of the 49-layer golden model was off by 1.2e-3 against the f64 reference,
+// 4x the error of the f32 CPU oracle: an ill-conditioned sum(dy * xhat), see tests/test_ops_gpu.py.)
 template <typename T>
 __global__ void __launch_bounds__(NT) bn_stats_partial_kernel(const T* __restrict__ x, int64_t n,
-                                                              int c, float* __restrict__ part, int rpw) {
+                                                              int c, double* __restrict__ part, int rpw) {
   constexpr int VEC = IO<T>::VEC;
-  extern __shared__ float sh[];                 // [2][NT][VEC]
+  extern __shared__ double sh[];                // [2][NT][VEC]
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
   const int64_t r_beg = (int64_t)blockIdx.x * rpw;
   const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
-  float shift[VEC], s1[VEC], s2[VEC];
+  float shift[VEC];
+  double s1[VEC], s2[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { shift[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+  for (int i = 0; i < VEC; ++i) { shift[i] = 0.f; s1[i] = 0.; s2[i] = 0.; }
   if (rl < rpi) {
     IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r_beg * c + cg * VEC), shift);
     int64_t r = r_beg + rl;
@@ -102,29 +108,29 @@ __global__ void __launch_bounds__(NT) bn_stats_partial_kernel(const T* __restric
         float f[VEC];
         IO<T>::unpack(v[u], f);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { float d = f[i] - shift[i]; s1[i] += d; s2[i] += d * d; }
+        for (int i = 0; i < VEC; ++i) { float d = f[i] - shift[i]; s1[i] += (double)d; s2[i] += (double)d * (double)d; }
       }
     }
     for (; r < r_end; r += rpi) {
       float f[VEC];
       IO<T>::unpack(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), f);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { float d = f[i] - shift[i]; s1[i] += d; s2[i] += d * d; }
+      for (int i = 0; i < VEC; ++i) { float d = f[i] - shift[i]; s1[i] += (double)d; s2[i] += (double)d * (double)d; }
     }
   }
-  float* a1 = sh; float* a2 = sh + NT * VEC;
+  double* a1 = sh; double* a2 = sh + NT * VEC;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { a1[tid * VEC + i] = s1[i]; a2[tid * VEC + i] = s2[i]; }
-  tree_sum_rows<VEC>(a1, tid, cg_n, rpi, rl);
-  tree_sum_rows<VEC>(a2, tid, cg_n, rpi, rl);
+  tree_sum_rows<VEC, double>(a1, tid, cg_n, rpi, rl);
+  tree_sum_rows<VEC, double>(a2, tid, cg_n, rpi, rl);
   if (rl == 0) {
-    const float cnt = (float)(r_end - r_beg);
+    const double cnt = (double)(r_end - r_beg);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float t1 = a1[tid * VEC + i], t2 = a2[tid * VEC + i];
-      float d = t1 / cnt, m2 = t2 - t1 * d;
-      float* dst = part + ((int64_t)blockIdx.x * c + cg * VEC + i) * 3;
-      dst[0] = cnt; dst[1] = shift[i] + d; dst[2] = m2 < 0.f ? 0.f : m2;
+      double t1 = a1[tid * VEC + i], t2 = a2[tid * VEC + i];
+      double d = t1 / cnt, m2 = t2 - t1 * d;
+      double* dst = part + ((int64_t)blockIdx.x * c + cg * VEC + i) * 3;
+      dst[0] = cnt; dst[1] = (double)shift[i] + d; dst[2] = m2 < 0. ? 0. : m2;
     }
   }
 }
@@ -133,7 +139,7 @@ __global__ void __launch_bounds__(NT) bn_stats_partial_kernel(const T* __restric
 // subset in order, then a fixed LDS tree merges the 32 lanes.  Writes mean / invstd and updates the
 // running statistics exactly as torch.nn.BatchNorm1d (biased var to normalise, unbiased for
 // running_var).
-__global__ void __launch_bounds__(NT) bn_stats_final_kernel(const float* __restrict__ part,
+__global__ void __launch_bounds__(NT) bn_stats_final_kernel(const double* __restrict__ part,
                                                             int nparts, int c, float eps,
                                                             float momentum,
                                                             float* __restrict__ mean,
@@ -141,24 +147,24 @@ __global__ void __launch_bounds__(NT) bn_stats_final_kernel(const float* __restr
                                                             float* __restrict__ running_mean,
                                                             float* __restrict__ running_var,
                                                             long long* __restrict__ num_batches) {
-  __shared__ float sn[NT], sm[NT], sq[NT];
+  __shared__ double sn[NT], sm[NT], sq[NT];
   if (num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches += 1;
   const int tid = threadIdx.x, cl = tid & 7, pl = tid >> 3;      // 8 channels x 32 lanes
   const int ch = blockIdx.x * 8 + cl;
-  float na = 0.f, ma = 0.f, qa = 0.f;
+  double na = 0., ma = 0., qa = 0.;
   if (ch < c)
     for (int p = pl; p < nparts; p += 32) {
-      const float* s = part + ((int64_t)p * c + ch) * 3;
-      if (na == 0.f) { na = s[0]; ma = s[1]; qa = s[2]; }
+      const double* s = part + ((int64_t)p * c + ch) * 3;
+      if (na == 0.) { na = s[0]; ma = s[1]; qa = s[2]; }
       else chan_merge(na, ma, qa, s[0], s[1], s[2]);
     }
   sn[tid] = na; sm[tid] = ma; sq[tid] = qa;
   for (int s = 16; s >= 1; s >>= 1) {
     __syncthreads();
     if (pl < s) {
-      float nb = sn[tid + s * 8], mb = sm[tid + s * 8], qb = sq[tid + s * 8];
-      float n0 = sn[tid], m0 = sm[tid], q0 = sq[tid];
-      if (n0 == 0.f) { n0 = nb; m0 = mb; q0 = qb; }
+      double nb = sn[tid + s * 8], mb = sm[tid + s * 8], qb = sq[tid + s * 8];
+      double n0 = sn[tid], m0 = sm[tid], q0 = sq[tid];
+      if (n0 == 0.) { n0 = nb; m0 = mb; q0 = qb; }
       else chan_merge(n0, m0, q0, nb, mb, qb);
       sn[tid] = n0; sm[tid] = m0; sq[tid] = q0;
     }
@@ -166,12 +172,12 @@ __global__ void __launch_bounds__(NT) bn_stats_final_kernel(const float* __restr
   __syncthreads();
   if (pl == 0 && ch < c) {
     na = sn[tid]; ma = sm[tid]; qa = sq[tid];
-    float var = na > 0.f ? qa / na : 0.f;
-    mean[ch] = ma;
-    invstd[ch] = 1.f / sqrtf(var + eps);
+    const double var = na > 0. ? qa / na : 0.;
+    mean[ch] = (float)ma;
+    invstd[ch] = (float)(1. / sqrt(var + (double)eps));
     if (running_mean != nullptr) {
-      float unbiased = na > 1.f ? qa / (na - 1.f) : var;
-      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * ma;
+      const float unbiased = (float)(na > 1. ? qa / (na - 1.) : var);
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)ma;
       running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
     }
   }
@@ -231,16 +237,17 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
-                                                            int relu, float* __restrict__ part, int rpw) {
+                                                            int relu, double* __restrict__ part, int rpw) {
   constexpr int VEC = IO<T>::VEC;
-  extern __shared__ float sh[];                 // [2][NT][VEC]
+  extern __shared__ double sh[];                // [2][NT][VEC]
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
   const int64_t r_beg = (int64_t)blockIdx.x * rpw;
   const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
-  float a[VEC], b[VEC], mu[VEC], is[VEC], ga[VEC], be[VEC];
+  double a[VEC], b[VEC];
+  float mu[VEC], is[VEC], ga[VEC], be[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; ga[i] = 1.f; be[i] = 0.f; }
+  for (int i = 0; i < VEC; ++i) { a[i] = 0.; b[i] = 0.; mu[i] = 0.f; is[i] = 0.f; ga[i] = 1.f; be[i] = 0.f; }
   if (rl < rpi) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -256,7 +263,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
       for (int i = 0; i < VEC; ++i) {
         const float xhat = (fx[i] - mu[i]) * is[i];
         if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;      // fused ReLU: dy where y > 0
-        a[i] += fd[i]; b[i] += fd[i] * xhat;
+        a[i] += (double)fd[i]; b[i] += (double)fd[i] * (double)xhat;
       }
     };
     int64_t r = r_beg + rl;
@@ -274,28 +281,28 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
       one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
           *reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC));
   }
-  float* sa = sh; float* sb = sh + NT * VEC;
+  double* sa = sh; double* sb = sh + NT * VEC;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { sa[tid * VEC + i] = a[i]; sb[tid * VEC + i] = b[i]; }
-  tree_sum_rows<VEC>(sa, tid, cg_n, rpi, rl);
-  tree_sum_rows<VEC>(sb, tid, cg_n, rpi, rl);
+  tree_sum_rows<VEC, double>(sa, tid, cg_n, rpi, rl);
+  tree_sum_rows<VEC, double>(sb, tid, cg_n, rpi, rl);
   if (rl == 0) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float* dst = part + ((int64_t)blockIdx.x * c + cg * VEC + i) * 2;
+      double* dst = part + ((int64_t)blockIdx.x * c + cg * VEC + i) * 2;
       dst[0] = sa[tid * VEC + i]; dst[1] = sb[tid * VEC + i];
     }
   }
 }
 
-__global__ void __launch_bounds__(NT) bn_bwd_final_kernel(const float* __restrict__ part,
+__global__ void __launch_bounds__(NT) bn_bwd_final_kernel(const double* __restrict__ part,
                                                           int nparts, int c,
                                                           float* __restrict__ sum_dy,
                                                           float* __restrict__ sum_dy_xhat) {
-  __shared__ float sa[NT], sb[NT];
+  __shared__ double sa[NT], sb[NT];
   const int tid = threadIdx.x, cl = tid & 7, pl = tid >> 3;
   const int ch = blockIdx.x * 8 + cl;
-  float a = 0.f, b = 0.f;
+  double a = 0., b = 0.;
   if (ch < c)
     for (int p = pl; p < nparts; p += 32) {
       a += part[((int64_t)p * c + ch) * 2];
@@ -308,8 +315,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_final_kernel(const float* __restric
   }
   __syncthreads();
   if (pl == 0 && ch < c) {
-    sum_dy[ch] = sa[tid];            // = grad_beta
-    sum_dy_xhat[ch] = sb[tid];       // = grad_gamma
+    sum_dy[ch] = (float)sa[tid];            // = grad_beta
+    sum_dy_xhat[ch] = (float)sb[tid];       // = grad_gamma
   }
 }
 
@@ -383,10 +390,10 @@ static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_p
 template <typename T>
 int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
                  float momentum, float* rm, float* rv, long long* nbt, int relu, void* y,
-                 float* mean, float* invstd, float* part, hipStream_t s) {
+                 float* mean, float* invstd, double* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
-  bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>((const T*)x, n, c, part,
+  bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>((const T*)x, n, c, part,
                                                                            rows_per_wg(n));
   LIDAL_CHECK_LAUNCH("bn_stats_partial");
   bn_stats_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
@@ -401,10 +408,10 @@ int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const floa
 template <typename T>
 int bn_bwd(const void* x, const void* dy, int64_t n, int c, const float* gamma, const float* beta,
            int relu, const float* mean, const float* invstd, void* dx, float* ggamma, float* gbeta,
-           float* part, hipStream_t s) {
+           double* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
-  bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(float), s>>>(
+  bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>(
       (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, rows_per_wg(n));
   LIDAL_CHECK_LAUNCH("bn_bwd_partial");
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gbeta, ggamma);
@@ -444,7 +451,7 @@ static int bn_check(int64_t n, int c, int dtype) {
 }
 
 extern "C" int64_t lidal_bn_workspace_bytes(int64_t n, int c) {
-  return (int64_t)nparts_for(n) * c * 3 * sizeof(float) + 256;
+  return (int64_t)nparts_for(n) * c * 3 * sizeof(double) + 256;
 }
 
 extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
@@ -460,10 +467,10 @@ extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, co
   if (dtype == LIDAL_F32)
     return bn_train_fwd<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var,
                                (long long*)num_batches_tracked, relu, y, save_mean, save_invstd,
-                               (float*)ws, s);
+                               (double*)ws, s);
   return bn_train_fwd<__bf16>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var,
                               (long long*)num_batches_tracked, relu, y, save_mean, save_invstd,
-                              (float*)ws, s);
+                              (double*)ws, s);
 }
 
 extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
@@ -496,9 +503,9 @@ extern "C" int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n,
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
     return bn_bwd<float>(x, dy, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
-                         grad_beta, (float*)ws, s);
+                         grad_beta, (double*)ws, s);
   return bn_bwd<__bf16>(x, dy, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
-                        grad_beta, (float*)ws, s);
+                        grad_beta, (double*)ws, s);
 }
 
 extern "C" int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,
@@ -519,19 +526,19 @@ extern "C" int lidal_colsum(const void* x, int dtype, int64_t n, int c, float* o
   LIDAL_REQUIRE(n > 0, "colsum: needs at least one row");
   LIDAL_REQUIRE(ws_bytes >= lidal_bn_workspace_bytes(n, c) + 3 * (int64_t)c * 4, "colsum ws too small");
   hipStream_t s = (hipStream_t)stream;
-  float* part = (float*)ws;
-  float* zeros = (float*)((char*)ws + (lidal_bn_workspace_bytes(n, c) / 4) * 4);
+  double* part = (double*)ws;
+  float* zeros = (float*)((char*)ws + (lidal_bn_workspace_bytes(n, c) / 8) * 8);
   float* ones = zeros + c;
   float* scratch = ones + c;
   LIDAL_HIP(hipMemsetAsync(zeros, 0, 4 * c, s));
   int np = nparts_for(n);
   // mean = 0, invstd = (any finite): only the first sum is used
   if (dtype == LIDAL_F32)
-    bn_bwd_partial_kernel<float><<<np, NT, 2 * NT * 4 * sizeof(float), s>>>(
+    bn_bwd_partial_kernel<float><<<np, NT, 2 * NT * 4 * sizeof(double), s>>>(
         (const float*)x, (const float*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part,
         rows_per_wg(n));
   else
-    bn_bwd_partial_kernel<__bf16><<<np, NT, 2 * NT * 8 * sizeof(float), s>>>(
+    bn_bwd_partial_kernel<__bf16><<<np, NT, 2 * NT * 8 * sizeof(double), s>>>(
         (const __bf16*)x, (const __bf16*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part,
         rows_per_wg(n));
   LIDAL_CHECK_LAUNCH("colsum_partial");

@@ -127,6 +127,12 @@ __device__ unsigned long long g_stamp[8];
 // conv_apply
 // ------------------------------------------------------------------------------------------
 constexpr int MAXK = 32;         // kernel volume limit (27 and 8 on this path)
+constexpr int MAX_DEVICES = 16;
+static inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+  return d;
+}
 
 #ifndef LIDAL_MINWAVES
 #define LIDAL_MINWAVES(nb) 2      /* 3 for nb <= 6 measured no better (scripts/ablate_conv.py) */
@@ -527,11 +533,13 @@ int launch_conv_apply(const void* in, const void* wk, const int* nbr, const int*
                                                                            : NWAVES * G * 16 * ESTRIDE;
   const size_t lds = sizeof(T) * WREGION + (size_t)NWAVES * K * G * 16 * sizeof(int);
   auto kern = conv_apply_kernel<T, NB, ROW_BYTES, GUARD, G, NWAVES>;
-  static size_t attr_set = 0;
-  if (attr_set < lds) {
+  // the attribute is per device: cache what was set per device id (one process may drive several)
+  static size_t attr_set[MAX_DEVICES] = {};
+  const int dev = current_device();
+  if (attr_set[dev] < lds) {
     LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = lds;
+    attr_set[dev] = lds;
   }
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
   kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wk, nbr, perm, tmasks, (T*)out, n_out,
@@ -944,11 +952,12 @@ int launch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* 
     const bool guard = (ca % 8 != 0) || (cb % 8 != 0);
 #endif
     auto kern = guard ? conv_wgrad_bf16_kernel<MI, NI, true> : conv_wgrad_bf16_kernel<MI, NI, false>;
-    static size_t attr_set[2] = {0, 0};
-    if (attr_set[guard] < lds) {
+    static size_t attr_set[2][MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (attr_set[guard][dev] < lds) {
       LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set[guard] = lds;
+      attr_set[guard][dev] = lds;
     }
     kern<<<grid, WTHREADS, lds, s>>>((const __bf16*)a, (const __bf16*)b, (const int2*)pairs, koff,
                                      a_col, partial, K, ca, cb, tiles_b, target_chunk);

@@ -66,9 +66,9 @@ def voxelize_scan(points, intensity, trans_m, rnd, scale=SCALE, full_scale=FULL_
 
 def collate(samples):
     """sk_dataset.py:188-242 on device tensors.  samples: dicts with coords_v [N,3], feats_v and
-    optionally labels_v / inverse_idxs.  The batch index becomes the 4th coordinate column and the
+    optionally labels_v / labels_p / inverse_idxs.  The batch index becomes the 4th coordinate column and the
     inverse indices are offset by the voxels of the preceding samples."""
-    coords, feats, labels, inverse = [], [], [], []
+    coords, feats, labels, inverse, labels_p = [], [], [], [], []
     off = 0
     for b, s in enumerate(samples):
         c = s['coords_v'].int()
@@ -76,11 +76,14 @@ def collate(samples):
         feats.append(s['feats_v'].float())
         if 'labels_v' in s:
             labels.append(s['labels_v'].long())
+        if 'labels_p' in s:          # val / score modes: per-POINT labels (sk_dataset.py:236-238)
+            labels_p.append(s['labels_p'].long())
         if 'inverse_idxs' in s:
             inverse.append(s['inverse_idxs'].long() + off)
             off += c.shape[0]        # == max(inverse) + 1: every voxel is hit by some point
     return {'coords_v_b': torch.cat(coords, 0), 'feats_v_b': torch.cat(feats, 0),
             'labels_v_b': torch.cat(labels, 0) if labels else None,
+            'labels_p_b': torch.cat(labels_p, 0) if labels_p else None,
             'inverse_indices_b': torch.cat(inverse, 0) if inverse else None}
 
 

@@ -52,7 +52,7 @@ def point_to_voxel(x, z):
         cache_i[x.s], cache_c[x.s] = cache_i[1], cache_c[1]
     if cache_i.get(x.s) is None:
         pc_hash = F.sphash(_floor_to_stride(z, x.s[0]))
-        idx_query = F.coords_table(x.C).query(pc_hash)     # == F.sphashquery(pc_hash, F.sphash(x.C))
+        idx_query = F.coords_table(x.C, x.cmaps).query(pc_hash)     # == F.sphashquery(pc_hash, F.sphash(x.C))
         cache_i[x.s] = idx_query
         cache_c[x.s] = F.spcount(idx_query.int(), x.C.shape[0])
     new_tensor = SparseTensor(F.spvoxelize(z.F, cache_i[x.s], cache_c[x.s]), x.C, x.s)
@@ -66,7 +66,7 @@ def voxel_to_point(x, z, nearest=False):
     if z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
         off = get_kernel_offsets(2, x.s, 1, device=z.F.device)
         old_hash = F.sphash(_floor_to_stride(z, x.s[0]), off)          # [8, N]
-        idx_query = F.coords_table(x.C).query(old_hash)    # == F.sphashquery(old_hash, F.sphash(x.C))
+        idx_query = F.coords_table(x.C, x.cmaps).query(old_hash)    # == F.sphashquery(old_hash, F.sphash(x.C))
         weights, idx_query = F.ti_weights_and_index(z.C, idx_query, scale=x.s[0])   # [N,8] both
         if nearest:
             weights[:, 1:] = 0.

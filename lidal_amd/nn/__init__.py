@@ -7,6 +7,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from .. import backend as B
 from ..tensor import SparseTensor
 from ..utils import make_ntuple
 from . import functional, utils
@@ -68,6 +69,7 @@ class Linear(nn.Linear):
 
     def forward(self, x):
         if not x.is_cuda or x.dim() != 2:
+            B.hit('torch_fallback:Linear')
             return super().forward(x)
         from .functional.dense import rows_linear
         return rows_linear(x, self.weight, self.bias)
@@ -85,6 +87,7 @@ class BatchNorm1d(nn.BatchNorm1d):
         from .functional import norm
         if (not norm.supported(feats, self.weight, self.bias) or not self.track_running_stats
                 or self.momentum is None):
+            B.hit('torch_fallback:BatchNorm1d')
             out = super().forward(feats)
             return torch.relu(out) if self.fused_relu else out
         return norm.batch_norm_rows(feats, self.weight, self.bias, self.running_mean,

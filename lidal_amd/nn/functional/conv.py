@@ -125,15 +125,16 @@ class KernelMap:
         return (self.nbmaps, self.nbsizes, self.sizes)[i]
 
 
-def build_kernel_map(coords, in_stride, kernel_size, stride):
-    """Cache-miss branch of upstream conv3d.  Returns (KernelMap, out_coords)."""
+def build_kernel_map(coords, in_stride, kernel_size, stride, scope=None):
+    """Cache-miss branch of upstream conv3d.  Returns (KernelMap, out_coords).  `scope` = the
+    owning SparseTensor's cmaps dict (scopes the level's hash table, query.coords_table)."""
     B.require_gpu(coords)
     assert coords.dtype == torch.int
     coords = coords.contiguous()
     dev = coords.device
     offsets = get_kernel_offsets(kernel_size, stride=in_stride, device=dev)
     volume = offsets.shape[0]
-    table = coords_table(coords)
+    table = coords_table(coords, scope)
     out_coords = coords
     if any(s > 1 for s in stride):
         out_coords = spdownsample(coords, stride, kernel_size, in_stride)
@@ -180,7 +181,7 @@ def prefetch_kernel_maps(x, plan, transposed=True):
         out_stride = tuple(cur[k] * stride[k] for k in range(3))
         kmap = x.kmaps.get(key)
         if kmap is None:
-            kmap, out_coords = build_kernel_map(coords, cur, kernel_size, stride)
+            kmap, out_coords = build_kernel_map(coords, cur, kernel_size, stride, x.cmaps)
             x.kmaps[key] = kmap
             if any(s > 1 for s in stride):
                 x.cmaps.setdefault(out_stride, out_coords)
@@ -358,7 +359,7 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
         kmap = input.kmaps.get(key)
         out_stride = tuple(input.stride[k] * stride[k] for k in range(3))
         if kmap is None:
-            kmap, out_coords = build_kernel_map(coords, input.stride, kernel_size, stride)
+            kmap, out_coords = build_kernel_map(coords, input.stride, kernel_size, stride, input.cmaps)
             input.kmaps[key] = kmap
             if any(s > 1 for s in stride):
                 input.cmaps.setdefault(out_stride, out_coords)

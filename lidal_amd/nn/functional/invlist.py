@@ -11,8 +11,12 @@ __all__ = ['inverse_lists', 'segment_workspace']
 def inverse_lists(idx, m, weights=None):
     """idx: i32 tensor [N] or [N,8]; returns (order i32 [idx.numel()], seg_ptr i64 [m+1]).
     Cached as attributes of `idx` (the glue code re-uses one index tensor per stride)."""
+    # the list depends on the index CONTENTS and, for devoxelize backward, on which weights are zero:
+    # key on version counter + storage of both (an in-place edit or a re-used tensor rebuilds it)
+    key = (m, idx._version, idx.data_ptr(), idx.numel()) + \
+          (() if weights is None else (weights._version, weights.data_ptr()))
     cached = getattr(idx, '_lidal_invlist', None)
-    if cached is not None and cached[0] == m:
+    if cached is not None and cached[0] == key:
         return cached[1], cached[2]
     B.require_gpu(idx)
     flat = idx.contiguous().view(-1)
@@ -25,7 +29,7 @@ def inverse_lists(idx, m, weights=None):
     w = None if weights is None else weights.contiguous().view(-1)
     B.check(B.lib().lidal_invlist_build(B.ptr(flat), B.ptr(w), n, m, B.ptr(order), B.ptr(seg_ptr),
                                         B.ptr(ws), ws_bytes, B.stream()), 'invlist_build')
-    idx._lidal_invlist = (m, order, seg_ptr)
+    idx._lidal_invlist = (key, order, seg_ptr)
     return order, seg_ptr
 
 

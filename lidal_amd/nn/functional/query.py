@@ -36,16 +36,27 @@ def sphashquery(queries, references):
     return HashTable(references).query(queries)
 
 
-def coords_table(coords):
-    """HashTable over sphash(coords) for an int32 [N, 4] coordinate tensor, built once per tensor
-    and cached ON it (keyed by its version counter): the kernel-map builds and the point<->voxel
-    look-ups of one level all probe the same table, and the level's coordinate tensor is one shared
-    object (SparseTensor.cmaps)."""
+def coords_table(coords, scope=None):
+    """HashTable over sphash(coords) for an int32 [N, 4] coordinate tensor, built once per level of
+    one input: the kernel-map builds and the point<->voxel look-ups of a level all probe the same
+    table.  The table is cached ON the coordinate tensor, keyed by its version counter / storage AND
+    by `scope` -- the `cmaps` dict (tensor.MapCache) of the SparseTensor family it was built for --
+    so a caller that keeps one coordinate tensor resident over many forward passes (bench.py) gets a
+    fresh table per pass, exactly the work the reference does per iteration.  scope=None: no
+    cross-call caching."""
+    import weakref
     from .hash import sphash
     key = (coords._version, coords.data_ptr(), coords.shape[0])
     cached = getattr(coords, '_lidal_table', None)
-    if cached is not None and cached[0] == key:
+    if (cached is not None and cached[0] == key and scope is not None and cached[2] is not None
+            and cached[2]() is scope):
         return cached[1]
     table = HashTable(sphash(coords))
-    coords._lidal_table = (key, table)
+    ref = None
+    if scope is not None:
+        try:
+            ref = weakref.ref(scope)
+        except TypeError:           # a plain dict assigned by foreign code: cannot be scoped
+            ref = None
+    coords._lidal_table = (key, table, ref)
     return table

@@ -18,10 +18,14 @@ class VoxelizeFunction(Function):
         # ordered path applies; everything else computes on an f32 copy
         native = in_dtype == torch.bfloat16 and feats.shape[1] % 4 == 0
         feats = feats.contiguous() if native else feats.contiguous().float()
-        idx32 = getattr(coords, '_lidal_i32', None)        # int32 view cached on the index tensor
-        if idx32 is None:
+        # int32 copy cached on the index tensor, keyed on its version counter and storage
+        key = (coords._version, coords.data_ptr(), coords.numel())
+        cached = getattr(coords, '_lidal_i32', None)
+        if cached is not None and cached[0] == key:
+            idx32 = cached[1]
+        else:
             idx32 = coords.contiguous().int()
-            coords._lidal_i32 = idx32
+            coords._lidal_i32 = (key, idx32)
         counts = counts.contiguous().int()
         n, c = feats.shape
         m = counts.shape[0]

@@ -8,7 +8,15 @@ input so a kernel map is built once per resolution level.
 """
 from .utils import make_ntuple
 
-__all__ = ['SparseTensor', 'PointTensor']
+__all__ = ['SparseTensor', 'PointTensor', 'MapCache']
+
+
+class MapCache(dict):
+    """The per-input dict behind `cmaps` / `kmaps`: a plain dict that can be weakly referenced, so
+    caches derived from a level's coordinates (the hash table, nn/functional/query.py) can be
+    scoped to the input they were built for -- a NEW SparseTensor over the same coordinate tensor
+    rebuilds everything, as the reference does every iteration."""
+    __slots__ = ('__weakref__',)
 
 
 class SparseTensor:
@@ -16,8 +24,8 @@ class SparseTensor:
         self.feats = feats
         self.coords = coords
         self.stride = make_ntuple(stride, ndim=3)
-        self.cmaps = {}
-        self.kmaps = {}
+        self.cmaps = MapCache()
+        self.kmaps = MapCache()
 
     F = property(lambda self: self.feats, lambda self, v: setattr(self, 'feats', v))
     C = property(lambda self: self.coords, lambda self, v: setattr(self, 'coords', v))

@@ -9,6 +9,7 @@ What each fixture pins
   model_small.npz     reference network/spvcnn.py + network/minkunet.py (unchanged files) run on
                       oracle.tsref: logits/feat for a seeded ~3 k-point scan (eval), one train
                       step (loss + gradient norms), every kernel map the forward builds.
+  model_10k.npz       the same SPVCNN file on a seeded 10 k-point scan (BASELINE.json configs[0]).
   state_dict_*.json   the checkpoint compatibility surface (keys, shapes, dtypes).
   scoring_small.npz   reference score/sv_level/LiDAL.py::worker_func run unchanged on synthetic
                       frames; also asserts oracle.scoring_ref reproduces it (the oracle PIN).
@@ -107,11 +108,38 @@ def make_model():
             out[name + '_grad_norms' + tag] = np.array(
                 [named[k].grad.norm().item() for k in gkeys], dtype=np.float64)
             out[name + '_grad_stem' + tag] = named['stem.0.kernel'].grad.numpy().astype(np.float32)
+            if tag == '':
+                # whole gradient tensors of the sampled parameters (kernels wider than 64 channels
+                # cut to their leading 32 x 32 block): the bf16 test needs directions, not norms
+                for i, k in enumerate(gkeys + (['point_transforms.1.0.weight'] if name == 'spvcnn' else [])):
+                    gr = named[k].grad.numpy()
+                    if gr.ndim == 3 and max(gr.shape[1:]) > 64:
+                        gr = gr[:, :32, :32]
+                    out['%s_gradfull_%d' % (name, i)] = gr.astype(np.float32).copy()
+                    out['%s_gradfull_key_%d' % (name, i)] = np.array(k)
             out[name + '_grad_up1dc' + tag] = (named['up1.0.net.0.kernel'].grad.numpy()[:, :8, :8]
                                                .astype(np.float32).copy())
         out[name + '_train_logits'] = logits.detach().numpy().astype(np.float32)
         print(name, 'loss', loss.item(), 'logits', tuple(logits.shape))
     np.savez_compressed(os.path.join(HERE, 'model_small.npz'), **out)
+
+
+def make_model_10k():
+    """BASELINE.json configs[0] as written: a synthetic 10 k-point scan, 0.05 m voxels, SPVCNN
+    forward on the CPU path -- the reference's network/spvcnn.py (unchanged) on the oracle."""
+    ts, SPVCNN, _ = _import_reference_models()
+    from lidal_amd import synth
+    torch.set_num_threads(8)
+    batch = synth.make_train_batch(n_frames=1, n_points=10000, seed=7122)
+    coords = torch.from_numpy(batch['coords_v_b'])
+    feats = torch.from_numpy(batch['feats_v_b'])
+    model = fill_state_dict(SPVCNN(19)).eval()
+    with torch.no_grad():
+        logits, feat = model(ts.SparseTensor(feats.clone(), coords.clone()))
+    np.savez_compressed(os.path.join(HERE, 'model_10k.npz'), coords=batch['coords_v_b'],
+                        feats=batch['feats_v_b'], spvcnn_logits=logits.numpy(),
+                        spvcnn_feat_sample=feat.numpy()[::16].copy())
+    print('model_10k:', tuple(coords.shape), 'voxels; logits', tuple(logits.shape))
 
 
 def _stub_nuscenes(tmp):
@@ -369,9 +397,11 @@ def make_register():
 
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'make_golden.py needs /root/reference (build container only)'
-    which = sys.argv[1:] or ['model', 'scoring', 'selection', 'voxelize', 'register']
+    which = sys.argv[1:] or ['model', 'model_10k', 'scoring', 'selection', 'voxelize', 'register']
     if 'model' in which:
         make_model()
+    if 'model_10k' in which:
+        make_model_10k()
     if 'scoring' in which:
         make_scoring()
     if 'selection' in which:

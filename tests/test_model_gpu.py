@@ -72,7 +72,7 @@ def test_train_step_matches_reference_golden(name, golden_dir):
     49 conv + train-mode BN layers in f32 and are ill-conditioned for MinkUNet on this input: the
     f32 CPU oracle itself misses its own f64 run by up to 2.5e-4 on the norms and 1.8e-3
     elementwise (stored in the fixture as *_f32).  So the gradient checks allow a small multiple of
-    the f32 oracle's own worst deviation (floors 5e-4 on norms, 1e-4 elementwise); per-operator gradients are held to 1e-4 in
+    the f32 oracle's own worst deviation (2x; floors 3e-4 on norms, 1e-4 elementwise); per-operator gradients are held to 1e-4 in
     test_ops_gpu.py."""
     from lidal_amd.train_step import forward_backward
     from weights import fill_state_dict
@@ -90,14 +90,16 @@ def test_train_step_matches_reference_golden(name, golden_dir):
     dev_gpu = np.abs(norms / g[name + '_grad_norms'] - 1)
     dev_f32 = np.abs(g[name + '_grad_norms_f32'] / g[name + '_grad_norms'] - 1)
     # Which parameter an f32 run misses most is implementation luck (MinkUNet: CPU f32 2.5e-4 on a
-    # conv kernel, torch's GPU BatchNorm 2.8e-4 and ours 1.2e-3 on one BN gamma), so the bar is a
-    # small multiple of the f32 oracle's WORST deviation over the sampled parameters.
-    assert dev_gpu.max() <= max(5e-4, 8 * dev_f32.max()), (dev_gpu, dev_f32)
+    # conv kernel, torch's GPU BatchNorm 2.8e-4 on one BN gamma), so the bar is TWICE the f32
+    # oracle's worst deviation over the sampled parameters (round 1 needed 8x: its BatchNorm
+    # reductions accumulated in f32 and missed that gamma by 1.2e-3; they accumulate in f64 now,
+    # bn.hip, and test_ops_gpu.py::test_batch_norm_backward_reductions_full_size pins them).
+    assert dev_gpu.max() <= max(3e-4, 2 * dev_f32.max()), (dev_gpu, dev_f32)
     worst = max(_rel(g[name + t + '_f32'], g[name + t]) for t in ('_grad_stem', '_grad_up1dc'))
     for key, tag in (('stem.0.kernel', '_grad_stem'), ('up1.0.net.0.kernel', '_grad_up1dc')):
         got = named[key].grad.cpu().numpy()
         got = got if tag == '_grad_stem' else got[:, :8, :8]
-        bar = max(1e-4, 4 * worst)
+        bar = max(1e-4, 2 * worst)
         assert _rel(got, g[name + tag]) < bar, (key, _rel(got, g[name + tag]), bar)
 
 
@@ -196,3 +198,72 @@ def test_training_drives_the_loss_down(autocast):
     opt = torch.optim.Adam(model.parameters())
     losses = [train_step(model, opt, f, c, lab, autocast=autocast)[0].item() for _ in range(30)]
     assert all(np.isfinite(losses)) and losses[-1] < 0.4 * losses[0], losses[::5]
+
+
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_bf16_train_step_gradients_point_the_same_way(name, golden_dir):
+    """The BENCHMARKED configuration (bf16 conv operands under autocast, f32 accumulation / BN /
+    loss) end to end: one train step on the golden input, every sampled parameter's gradient
+    against the f64 run of the reference model files -- cosine >= 0.999 and norm within 2 % (whole
+    tensors; kernels wider than 64 channels by their leading 32 x 32 block).  A wrong-but-plausible
+    bf16 weight gradient in one layer family cannot pass this."""
+    from lidal_amd import backend as B
+    from lidal_amd.train_step import forward_backward
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    model = fill_state_dict(_models()[name](19)).to(DEV).train()
+    if hasattr(model, 'dropout'):
+        model.dropout.p = 0.0
+    B.HITS.clear()
+    loss, logits = forward_backward(model, torch.from_numpy(g['feats']).to(DEV),
+                                    torch.from_numpy(g['coords']).to(DEV),
+                                    torch.from_numpy(g['labels']).to(DEV), autocast=True)
+    # the product modules took the HIP path: 49 BatchNorms (+3 in the point branch), every dense
+    # layer on the conv kernel, nothing fell through to torch
+    n_bn = 49 + (3 if name == 'spvcnn' else 0)
+    assert B.HITS.get('bn_train_fwd', 0) == n_bn and B.HITS.get('bn_bwd', 0) == n_bn, B.HITS
+    assert B.HITS.get('conv_apply(dense)', 0) >= 7 and B.HITS.get('conv_wgrad(dense)', 0) >= 7, B.HITS
+    assert not any(k.startswith(('torch_fallback', 'library_gemm')) for k in B.HITS), B.HITS
+    assert abs(loss.item() - float(g[name + '_train_loss'])) < 2e-2 * abs(float(g[name + '_train_loss']))
+    named = dict(model.named_parameters())
+    i = 0
+    while '%s_gradfull_key_%d' % (name, i) in g.files:
+        key, want = str(g['%s_gradfull_key_%d' % (name, i)]), g['%s_gradfull_%d' % (name, i)].astype(np.float64)
+        got = named[key].grad.double().cpu().numpy()
+        if got.shape != want.shape:
+            got = got[:, :32, :32]
+        cos = (got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want))
+        ratio = np.linalg.norm(got) / np.linalg.norm(want)
+        assert cos >= 0.999 and abs(ratio - 1) <= 0.02, (key, cos, ratio)
+        i += 1
+    assert i >= 7
+
+
+def test_f32_mode_hits_the_hip_kernels(golden_dir):
+    """The f32 parity mode: BatchNorm / Linear modules on the HIP kernels; the only library calls are
+    the f32 dense products (by design, nn/functional/dense.py)."""
+    import lidal_amd
+    from lidal_amd import backend as B
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    model = fill_state_dict(_models()['spvcnn'](19)).to(DEV).eval()
+    B.HITS.clear()
+    with torch.no_grad():
+        model(lidal_amd.SparseTensor(torch.from_numpy(g['feats']).to(DEV), torch.from_numpy(g['coords']).to(DEV)))
+    assert not any(k.startswith('torch_fallback') for k in B.HITS), B.HITS
+    assert B.HITS.get('conv_apply', 0) >= 42 and B.HITS.get('kmap_build', 0) == 9, B.HITS
+
+
+def test_config1_10k_point_scan_forward(golden_dir):
+    """BASELINE.json configs[0] as written: synthetic 10 k-point scan, 0.05 m voxels, SPVCNN forward;
+    golden = the reference's network/spvcnn.py on the CPU oracle (tests/golden/model_10k.npz)."""
+    import lidal_amd
+    from weights import fill_state_dict
+    g = np.load(os.path.join(golden_dir, 'model_10k.npz'))
+    model = fill_state_dict(_models()['spvcnn'](19)).to(DEV).eval()
+    with torch.no_grad():
+        logits, feat = model(lidal_amd.SparseTensor(torch.from_numpy(g['feats']).to(DEV),
+                                                    torch.from_numpy(g['coords']).to(DEV)))
+    assert _rel(logits.cpu().numpy(), g['spvcnn_logits']) < 1e-4
+    assert _rel(feat.cpu().numpy()[::16], g['spvcnn_feat_sample']) < 1e-4
+    assert np.array_equal(logits.argmax(1).cpu().numpy(), g['spvcnn_logits'].argmax(1))

@@ -382,6 +382,49 @@ def test_batch_norm_rows_matches_torch(dtype, c, n):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batch_norm_backward_reductions_full_size(dtype):
+    """dgamma / dbeta / saved statistics of ONE BatchNorm at the bench size (4e5 rows x 96 channels)
+    against an f64 reference, PER CHANNEL at 1e-4 -- including channels whose sum(dy * xhat) is
+    ill-conditioned (dy nearly uncorrelated with x: the sum is ~1e-3 of the sum of magnitudes) and
+    a channel with |mean| >> std.  The kernels accumulate every reduction in f64 (bn.hip), so the
+    error left is the f32 rounding of each term: |err| <= 2e-7 * sum|terms| as well."""
+    from lidal_amd.nn.functional.norm import batch_norm_rows
+    n, c = 400003, 96
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, generator=g) * 1.5 + 0.3
+    x[:, 1] = x[:, 1] * 0.02 + 25.0
+    go = torch.randn(n, c, generator=g)                      # uncorrelated with x: cancelling sums
+    go[:, 2] += 0.5 * x[:, 2]                                # one well-conditioned channel
+    xq, gq = x.to(dtype), go.to(dtype)
+    w = (torch.rand(c, generator=g) + 0.5)
+    b = torch.randn(c, generator=g) * 0.1
+    xd, gd = xq.double(), gq.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    xhat = (xd - mean) * torch.rsqrt(var + 1e-5)
+    ref_gamma, ref_beta = (gd * xhat).sum(0), gd.sum(0)
+    mag_gamma, mag_beta = (gd * xhat).abs().sum(0), gd.abs().sum(0)
+    assert (ref_gamma.abs() / mag_gamma).median() < 5e-3     # the fixture IS ill-conditioned
+    xg = xq.to(DEV).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    y = batch_norm_rows(xg, wg, bg, rm, rv, True, 0.1, 1e-5)
+    y.backward(gq.to(DEV))
+    got_gamma, got_beta = wg.grad.double().cpu(), bg.grad.double().cpu()
+    # f32 statistics feed xhat: an error dm of the saved mean moves dgamma by dm * invstd * sum(dy),
+    # which is part of the budget (dm <= 1 ulp of the mean)
+    slack = 1.2e-7 * mean.abs() * torch.rsqrt(var + 1e-5) * ref_beta.abs()
+    err_g, err_b = (got_gamma - ref_gamma).abs(), (got_beta - ref_beta).abs()
+    assert (err_g <= 2e-7 * mag_gamma + 2 * slack + 1e-4 * ref_gamma.abs()).all(), \
+        (err_g / mag_gamma).max()
+    assert (err_b <= 2e-7 * mag_beta).all(), (err_b / mag_beta).max()
+    ok = ref_gamma.abs() > 1e-3 * mag_gamma                  # 1e-4 relative wherever it is meaningful
+    assert ((err_g / ref_gamma.abs())[ok] < 1e-4).all() and ok.sum() >= 1
+    assert (err_b / ref_beta.abs().clamp_min(1e-3 * mag_beta) < 1e-4).all()
+    assert _relerr(rm.cpu(), 0.1 * mean) < 1e-6
+    assert _relerr(rv.cpu(), 0.9 + 0.1 * xd.var(0, unbiased=True)) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_dense_rows_matmul_and_linear(dtype):
     """1x1x1 conv / point-branch Linear: forward, dx and the split-K weight gradient vs f64."""
     import lidal_amd.nn as spnn

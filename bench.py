@@ -14,8 +14,16 @@ f32 accumulation (BASELINE.json configs[1]).  value = input voxels of all ranks 
 One JSON line is printed by rank 0.  Besides the contract fields it carries
   roofline      the dominant kernel (fused sparse conv, the level-0 96->96 k3 layer) timed live
                 with HIP events on the launch stream: algorithmic bytes / duration
+  families      one more (untimed) step with every library call bracketed by events: GPU time,
+                algorithmic bytes / FLOPs and roofline fraction per kernel family
+                (sparse conv fwd+dgrad, weight gradient, BatchNorm, kernel maps, point<->voxel,
+                fused elementwise), and of the whole step
+  variants      the same step on ONE scan (BASELINE.json's literal "@120k pts"), in the f32 parity
+                mode, and with the second backbone (MinkUNet, configs[2])
+  secondary     frames/s of prob_inference (8 views) + LiDAL inter-frame scoring (configs[3..4]),
+                frame-sharded, 32 frames per rank, neighbour windows 10 and 24, with its own CPU
+                baseline (oracle worker_func restatement under a process pool, LiDAL.py:204-206)
   cpu_baseline  the oracle (CPU restatement of the torchsparse path) on a bounded sample
-  secondary     frames/s of prob_inference (8 views) + LiDAL inter-frame scoring, frame-sharded
 """
 import argparse
 import json
@@ -52,11 +60,15 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--frames', type=int, default=5, help='scans per step (sk_dataloader.py:21)')
     ap.add_argument('--points', type=int, default=120000)
-    ap.add_argument('--score-frames', type=int, default=12, help='frames per rank for `secondary`')
-    ap.add_argument('--nei', type=int, default=10, help='neighbour window (BASELINE config 5)')
+    ap.add_argument('--score-frames', type=int, default=32,
+                    help='frames per rank for `secondary` (config 4: 256 frames / 8 GPUs)')
+    ap.add_argument('--nei', type=int, nargs='+', default=[10, 24],
+                    help='neighbour windows of `secondary` (BASELINE config 5: 10; LiDAL.py:120: 24)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-families', action='store_true')
+    ap.add_argument('--no-variants', action='store_true')
     ap.add_argument('--roofline-only', action='store_true',
                     help='only the dominant-kernel measurement (for rocprofv3: every launch of the '
                          'kernel in the trace is then the roofline layer)')
@@ -80,6 +92,11 @@ def dist_setup(args):
     return world, rank, torch.device('cuda', local)
 
 
+def collective_tensor(x, dev):
+    cdev = dev if dist.get_backend() == 'nccl' else torch.device('cpu')
+    return torch.tensor([x], dtype=torch.float64, device=cdev)
+
+
 def barrier_sync(world):
     torch.cuda.synchronize()
     if world > 1:
@@ -90,7 +107,7 @@ def barrier_sync(world):
 def max_over_ranks(x, world, dev):
     if world == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    t = collective_tensor(x, dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
 
@@ -98,49 +115,65 @@ def max_over_ranks(x, world, dev):
 def sum_over_ranks(x, world, dev):
     if world == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    t = collective_tensor(x, dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.item()
 
 
-def bench_train(args, world, rank, dev):
+# ---------------------------------------------------------------------------------------------
+# the train step
+# ---------------------------------------------------------------------------------------------
+def make_batch(frames, points, seed, dev):
     from lidal_amd import synth
+    batch = synth.make_train_batch(n_frames=frames, n_points=points, seed=seed)
+    return (torch.from_numpy(batch['coords_v_b']).to(dev), torch.from_numpy(batch['feats_v_b']).to(dev),
+            torch.from_numpy(batch['labels_v_b']).to(dev))
+
+
+def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=True):
+    """Times `steps` iterations of train.py:127-140 on the resident `batch` (coords, feats, labels)."""
     from lidal_amd.network import SPVCNN, MinkUNet
     from lidal_amd.train_step import train_step
-    batch = synth.make_train_batch(n_frames=args.frames, n_points=args.points, seed=7122 + rank)
-    log('batch built', batch['coords_v_b'].shape)
-    coords = torch.from_numpy(batch['coords_v_b']).to(dev)
-    feats = torch.from_numpy(batch['feats_v_b']).to(dev)
-    labels = torch.from_numpy(batch['labels_v_b']).to(dev)
+    coords, feats, labels = batch
     torch.manual_seed(7122)
-    model = (SPVCNN if args.model == 'spvcnn' else MinkUNet)(19).to(dev).train()
+    model = (SPVCNN if model_name == 'spvcnn' else MinkUNet)(19).to(dev).train()
     net = model
-    if world > 1 or os.environ.get('BENCH_FORCE_DDP'):
+    if ddp and (world > 1 or os.environ.get('BENCH_FORCE_DDP')):
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
     # Adam with the reference's defaults (train.py:56); `fused` only selects torch's single-kernel
     # implementation of the same update (the default path calls .item() once per parameter on the host)
     opt = torch.optim.Adam(net.parameters(), fused=True)
-    autocast = args.dtype == 'bf16'
+    autocast = dtype == 'bf16'
 
     def step():
         return train_step(net, opt, feats, coords, labels, autocast=autocast)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step()
         torch.cuda.synchronize()
-        log('warmup step', i)
-    barrier_sync(world)
+    barrier_sync(world if ddp else 1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss, _ = step()
-    barrier_sync(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    barrier_sync(world if ddp else 1)
+    dt = time.perf_counter() - t0
+    if ddp:
+        dt = max_over_ranks(dt, world, dev)
     assert np.isfinite(loss.item()), 'training diverged'
-    voxels = sum_over_ranks(float(coords.shape[0]), world, dev)
-    return {'model': model, 'coords': coords, 'seconds': dt, 'voxels_per_step': voxels,
-            'loss': float(loss.item()), 'batch': batch}
+    return {'model': model, 'step': step, 'seconds': dt, 'steps': steps, 'voxels': int(coords.shape[0]),
+            'loss': float(loss.item())}
 
 
+def variant_line(res):
+    ms = res['seconds'] / res['steps'] * 1e3
+    return {'ms_per_step': round(ms, 3), 'voxels_per_step': res['voxels'],
+            'voxels_per_s': round(res['voxels'] / ms * 1e3, 1), 'steps': res['steps'],
+            'loss': round(res['loss'], 4)}
+
+
+# ---------------------------------------------------------------------------------------------
+# roofline of the dominant kernel
+# ---------------------------------------------------------------------------------------------
 def roofline_conv(args, coords, dev, reps=20):
     """Dominant kernel: the fused sparse conv (lidal_conv_apply) on the heaviest layer family --
     the 96->96 k3 convolutions at stride 1 (network/spvcnn.py:75-81).  Timed with HIP events on the
@@ -174,16 +207,21 @@ def roofline_conv(args, coords, dev, reps=20):
     algo_bytes = b * (n * ci + n * co) + b * 27 * ci * co + 8 * m
     flops = 2.0 * m * ci * co
     gbs = algo_bytes / sec / 1e9
-    traffic = None          # PMC-derived bytes per launch, measured offline on this exact workload
-    try:
-        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_conv_apply.json')))
-        wl = rec['workload']
-        if (wl['rows'], wl['rules'], wl['dtype']) == (n, m, args.dtype):
-            traffic = rec['traffic_bytes']
-    except (OSError, KeyError, ValueError):
-        pass
+    # PMC-derived bytes per launch: measured OFFLINE (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on
+    # `bench.py --roofline-only`, corrected as MI355X_MICROARCH.md prescribes) and kept under
+    # profiles/; reported only if that record is of this exact workload
+    traffic, traffic_src = None, None
+    for name in ('r02_pmc_conv_apply.json', 'r01_pmc_conv_apply.json'):
+        try:
+            rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            wl = rec['workload']
+            if (wl['rows'], wl['rules'], wl['dtype']) == (n, m, args.dtype):
+                traffic, traffic_src = rec['traffic_bytes'], 'offline PMC passes: profiles/' + name
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     return {'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
+            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
             'kernel': 'conv_apply_kernel (k3 s1 96->96, %s)' % args.dtype,
             'launch_us': round(sec * 1e6, 2), 'rows': n, 'rules': m,
             'algorithmic_bytes_per_launch': int(algo_bytes),
@@ -192,11 +230,159 @@ def roofline_conv(args, coords, dev, reps=20):
                      'frac': round(flops / sec / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5)}}
 
 
-def cpu_baseline(args, rank_seed=7122, sample_points=None, max_threads=32):
+# ---------------------------------------------------------------------------------------------
+# per-family roofline of one whole step
+# ---------------------------------------------------------------------------------------------
+FAMILY_OF = {
+    'lidal_conv_apply': 'conv_apply', 'lidal_conv_wgrad': 'conv_wgrad', 'lidal_conv_weight_pack': 'weight_pack',
+    'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
+    'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
+    'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
+    'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
+    'lidal_downsample': 'kernel_maps', 'lidal_kmap_build': 'kernel_maps', 'lidal_kmap_invert': 'kernel_maps',
+    'lidal_kmap_order': 'kernel_maps',
+    'lidal_count': 'point_voxel', 'lidal_voxelize_fwd': 'point_voxel', 'lidal_voxelize_bwd': 'point_voxel',
+    'lidal_devoxelize_fwd': 'point_voxel', 'lidal_devoxelize_bwd': 'point_voxel',
+    'lidal_invlist_build': 'point_voxel', 'lidal_voxelize_fwd_sorted': 'point_voxel',
+    'lidal_devoxelize_bwd_sorted': 'point_voxel', 'lidal_ti_weights': 'point_voxel',
+    'lidal_add_relu_fwd': 'fused_elementwise', 'lidal_add_relu_bwd': 'fused_elementwise',
+    'lidal_ce_fwd': 'fused_elementwise', 'lidal_ce_bwd': 'fused_elementwise',
+}
+
+
+def _val(a):
+    v = getattr(a, 'value', a)
+    try:
+        return 0 if v is None else int(v)
+    except (TypeError, ValueError):
+        return 0
+
+
+def family_table(step, coords, dtype_name, step_ms):
+    """Runs `step` once with every library call bracketed by events and prices each call with the
+    algorithmic bytes / FLOPs of SURVEY.md 8(d):
+      conv fwd / dgrad   b(N_in Ci + N_out Co) + b K Ci Co + 8 M     2 M Ci Co
+      weight gradient    b(N_in Ci + N_out Co) + 4 K Ci Co + 8 M     2 M Ci Co
+      BatchNorm          fwd 3 N C b, bwd 5 N C b;   relu(a+b) 3 N C b;   CE N (C b + 8)
+      kernel map         16 N_in + 16 N_out + 8 M per map (hash, unique, probe, compaction, row order)
+      point<->voxel      one row in + one row out per gathered row (b C each)
+    M (rules) of a 27-offset map is measured on this batch's levels; 8-offset (stride 2) maps have
+    M = N_fine, dense layers M = N.  Everything between library calls (Adam, cat, dropout, casts,
+    host gaps) is `other` = step time - sum of the bracketed intervals."""
+    from lidal_amd import SparseTensor
+    from lidal_amd import backend as B
+    from lidal_amd.nn.functional.conv import prefetch_kernel_maps
+    from lidal_amd.network.unet import _SparseUNet
+    b_el = 2 if dtype_name == 'bf16' else 4
+    # rules per level of this batch (same voxel sets whichever row order the model uses)
+    with torch.no_grad():
+        x = prefetch_kernel_maps(SparseTensor(None, coords), _SparseUNet.MAP_PLAN)
+        rules = {}
+        for key, km in x.kmaps.items():
+            if km.volume == 27:
+                rules[km.sizes[1]] = km.total
+    torch.cuda.synchronize()
+    calls = []
+    B.set_call_timer(lambda name, a, e0, e1: calls.append((name, [_val(v) for v in a], e0, e1)))
+    try:
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        prof_ms = (time.perf_counter() - t0) * 1e3
+    finally:
+        B.set_call_timer(None)
+    fam = {}
+    fwd_shape = {}                      # input pointer of a forward conv -> (n_in, n_out)
+
+    def rules_of(k, n_in, n_out):
+        if k == 1:
+            return n_out
+        if k == 8:
+            return max(n_in, n_out)
+        return rules.get(n_out, rules.get(n_in, 6 * n_out))
+
+    for name, a, e0, e1 in calls:
+        f = FAMILY_OF.get(name, 'other_lib')
+        ms = e0.elapsed_time(e1)
+        by = fl = 0.0
+        if name == 'lidal_conv_apply':
+            n_in, n_out, ci, co, k, dt = a[6], a[7], a[8], a[9], a[10], a[12]
+            b = 2 if dt == 1 else 4
+            m = rules_of(k, n_in, n_out)
+            by = b * (n_in * ci + n_out * co) + b * k * ci * co + 8 * m
+            fl = 2.0 * m * ci * co
+            fwd_shape[a[0]] = (n_in, n_out)
+        elif name == 'lidal_conv_wgrad':
+            k, ca, cb, dt = a[9], a[10], a[11], a[12]
+            b = 2 if dt == 1 else 4
+            # a = the saved input x [n_in, ca] of the forward conv, b = grad_out [n_out, cb]
+            n_in, n_out = fwd_shape.get(a[0], (coords.shape[0], coords.shape[0]))
+            m = rules_of(k, n_in, n_out)
+            by = b * (n_in * ca + n_out * cb) + 4 * k * ca * cb + 8 * m
+            fl = 2.0 * m * ca * cb
+        elif name == 'lidal_conv_weight_pack':
+            by = (4 + b_el) * a[5] * a[6] * a[7]
+        elif name in ('lidal_bn_train_fwd', 'lidal_bn_eval_fwd'):
+            by = (3 if name == 'lidal_bn_train_fwd' else 2) * a[2] * a[3] * (2 if a[1] == 1 else 4)
+        elif name == 'lidal_bn_bwd':
+            by = 5 * a[3] * a[4] * (2 if a[2] == 1 else 4)
+        elif name == 'lidal_colsum':
+            by = a[2] * a[3] * (2 if a[1] == 1 else 4)
+        elif name in ('lidal_add_relu_fwd', 'lidal_add_relu_bwd'):
+            by = 3 * a[3] * (2 if a[4] == 1 else 4)
+        elif name in ('lidal_ce_fwd', 'lidal_ce_bwd'):
+            by = a[3] * (a[4] * (2 if a[1] == 1 else 4) + 8) * (1 if name == 'lidal_ce_fwd' else 2)
+        elif name == 'lidal_kmap_build':
+            n_out, k = a[3], a[5]
+            n_in = a[1] // 24 if a[1] else n_out                # table: 12 B per slot, 2 slots per key
+            by = 16 * n_in + 16 * n_out + 8 * rules_of(k, n_in, n_out)
+        elif name in ('lidal_voxelize_fwd_sorted', 'lidal_devoxelize_bwd_sorted'):
+            m_rows, c, dt, n_ent = a[5], a[6], a[7], a[8]
+            by = (n_ent + m_rows) * c * (2 if dt == 1 else 4)
+        elif name == 'lidal_voxelize_bwd':
+            by = (a[4] + a[5]) * a[6] * (2 if a[7] == 1 else 4)
+        elif name == 'lidal_devoxelize_fwd':
+            by = (8 * a[4] + a[4]) * a[6] * (2 if a[7] == 1 else 4)
+        d = fam.setdefault(f, {'ms': 0.0, 'launches': 0, 'bytes': 0.0, 'flops': 0.0})
+        d['ms'] += ms
+        d['launches'] += 1
+        d['bytes'] += by
+        d['flops'] += fl
+    out = {}
+    tot_ms = tot_by = tot_fl = 0.0
+    peak_tf = MFMA_PEAK_TFLOPS[dtype_name]
+    for f, d in sorted(fam.items(), key=lambda kv: -kv[1]['ms']):
+        tot_ms += d['ms']
+        tot_by += d['bytes']
+        tot_fl += d['flops']
+        row = {'ms': round(d['ms'], 3), 'calls': d['launches'],
+               'algorithmic_GB': round(d['bytes'] / 1e9, 3),
+               'hbm_frac': round(d['bytes'] / (d['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if d['ms'] > 0 else None}
+        if d['flops']:
+            row['GFLOP'] = round(d['flops'] / 1e9, 1)
+            row['mfma_frac'] = round(d['flops'] / (d['ms'] * 1e-3) / 1e12 / peak_tf, 4)
+        out[f] = row
+    out['other'] = {'ms': round(max(step_ms - tot_ms, 0.0), 3),
+                    'what': 'torch ops between library calls (Adam, cat, dropout, casts) + gaps'}
+    out['whole_step'] = {
+        'ms': round(step_ms, 3), 'profiled_step_ms': round(prof_ms, 3), 'algorithmic_GB': round(tot_by / 1e9, 3),
+        'GFLOP': round(tot_fl / 1e9, 1),
+        'hbm_frac': round(tot_by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        'mfma_frac': round(tot_fl / (step_ms * 1e-3) / 1e12 / peak_tf, 4),
+        'ms_at_hbm_roof': round(tot_by / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
+        'ms_at_mfma_roof': round(tot_fl / (peak_tf * 1e12) * 1e3, 3)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baselines
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(args, rank_seed=7122, sample_points=None, max_threads=32, runs=3):
     """Oracle (CPU restatement of the torchsparse path) on a BOUNDED sample of the same workload:
     one synthetic scan of `sample_points` points (same generator and input pipeline as the bench
-    batch), forward + CE + backward once (upstream torchsparse has no CPU backward; autograd through
-    the restatement supplies it).  Threads = min(host cores, max_threads)."""
+    batch), forward + CE + backward (upstream torchsparse has no CPU backward; autograd through the
+    restatement supplies it): one warm-up, then the median of `runs`.  Threads = min(host cores,
+    max_threads)."""
     from lidal_amd import synth
     from oracle import tsref
     from oracle.models_ref import MinkUNetRef, SPVCNNRef
@@ -209,95 +395,225 @@ def cpu_baseline(args, rank_seed=7122, sample_points=None, max_threads=32):
     labels = torch.from_numpy(batch['labels_v_b'])
     torch.manual_seed(7122)
     model = (SPVCNNRef if args.model == 'spvcnn' else MinkUNetRef)(19).train()
-    t0 = time.perf_counter()
-    logits, _ = model(tsref.SparseTensor(feats, coords))
-    loss = torch.nn.functional.cross_entropy(logits, labels, ignore_index=255, reduction='mean')
-    t1 = time.perf_counter()
-    loss.backward()
-    t2 = time.perf_counter()
+    times = []
+    for _ in range(runs + 1):
+        model.zero_grad()
+        t0 = time.perf_counter()
+        logits, _ = model(tsref.SparseTensor(feats, coords))
+        loss = torch.nn.functional.cross_entropy(logits, labels, ignore_index=255, reduction='mean')
+        t1 = time.perf_counter()
+        loss.backward()
+        t2 = time.perf_counter()
+        times.append((t2 - t0, t1 - t0, t2 - t1))
+    times = sorted(times[1:])
+    tot, fwd, bwd = times[len(times) // 2]
     n = coords.shape[0]
-    return {'value': round(n / (t2 - t0), 1), 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 synthetic scan of %d points (%d voxels), %s f32 fwd+CE+bwd once on the '
-                      'CPU oracle (fwd %.1f s, bwd %.1f s)' % (sample_points, n, args.model,
-                                                               t1 - t0, t2 - t1)}
+    return {'value': round(n / tot, 1), 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 synthetic scan of %d points (%d voxels), %s f32 fwd+CE+bwd on the CPU oracle: '
+                      'median of %d runs after 1 warm-up (fwd %.1f s, bwd %.1f s)'
+                      % (sample_points, n, args.model, runs, fwd, bwd)}
 
 
-def bench_scoring(args, model, world, rank, dev):
-    """prob_inference (8 augmented views per frame) + inter-frame scoring, frames sharded over
-    ranks in the reference's contiguous blocks, probabilities/coords exchanged by one all-gather."""
+def _score_worker(job):
+    i, nei, dis = job
+    from oracle import scoring_ref
+    g = _score_worker.shared
+    t0 = time.perf_counter()
+    scoring_ref.score_frame(i, g['probs'], g['worlds'], g['sv2point'][i], nei, dis)
+    return time.perf_counter() - t0
+
+
+def _score_worker_init(probs, worlds, sv2point):
+    _score_worker.shared = {'probs': probs, 'worlds': worlds, 'sv2point': sv2point}
+
+
+def scoring_cpu_baseline(frames, nei, cores_cap=24):
+    """CPU baseline of the inter-frame scoring: oracle.scoring_ref.score_frame (the restatement of
+    worker_func, LiDAL.py:27-103, pinned bit for bit to the reference) under a process pool of
+    min(24, cores) workers as LiDAL.py:204-206 runs it, on a BOUNDED number of frames of the same
+    synthetic sequence (random but normalised probabilities: the CPU path's cost does not depend on
+    the values).  The 8-view model inference that precedes it has no CPU form in the reference."""
+    import multiprocessing as mp
+    cores = min(cores_cap, os.cpu_count() or 1)
+    rng = np.random.default_rng(3)
+    probs = []
+    for f in frames:
+        p = rng.random((f['world'].shape[0], 19), dtype=np.float32) + 0.05
+        probs.append(p / p.sum(1, keepdims=True))
+    worlds = [f['world'] for f in frames]
+    sv = [f['sv2point'] for f in frames]
+    n_jobs = min(len(frames), cores)
+    ctx = mp.get_context('spawn')                       # never fork a process that has initialised the GPU
+    with ctx.Pool(cores, initializer=_score_worker_init, initargs=(probs, worlds, sv)) as pool:
+        pool.map(_score_worker, [(0, nei, 0.1)])        # warm-up: imports, page-in
+        t0 = time.perf_counter()
+        per = pool.map(_score_worker, [(i, nei, 0.1) for i in range(n_jobs)], chunksize=1)
+        dt = time.perf_counter() - t0
+    return {'value': round(n_jobs / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d frames of %d points, nei_num %d, oracle.scoring_ref.score_frame (worker_func '
+                      'restatement, KD-tree queries) under Pool(%d): %.1f s wall, %.1f s per frame per worker; '
+                      'scoring only (the reference has no CPU inference path)'
+                      % (n_jobs, frames[0]['world'].shape[0], nei, cores, dt, float(np.mean(per)))}
+
+
+# ---------------------------------------------------------------------------------------------
+# secondary metric: prob_inference + LiDAL scoring
+# ---------------------------------------------------------------------------------------------
+def _gen_frame_block(job):
+    n, points, seed, start, total = job
     from lidal_amd import synth
-    from lidal_amd.score import interframe, score_sequence
+    return synth.make_sequence(n, n_points=points, seed=seed, start=start, total=total)
+
+
+def _gen_score_batch(job):
+    pts, inten, seed = job
+    from lidal_amd import synth
+    return synth.make_score_batch(pts, inten, np.random.default_rng(seed), inf_reps=8)
+
+
+def make_scoring_inputs(args, world, rank):
+    """Synthetic frames of this rank's block + their 8 augmented views, generated by a small spawn
+    pool (32 frames x 8 views of 120 k points is ~50 s of single-core numpy otherwise)."""
+    import multiprocessing as mp
     per = args.score_frames
     total = per * world
-    frames = synth.make_sequence(per, n_points=args.points, seed=7122, start=rank * per, total=total)
-    rng = np.random.default_rng([7122, 99, rank])
+    workers = max(1, min(8, (os.cpu_count() or 1) // max(world, 1), per))
+    if workers == 1 or per < 4:
+        frames = _gen_frame_block((per, args.points, 7122, rank * per, total))
+        batches = [_gen_score_batch((f['points'], f['intensity'], [7122, 99, rank, i]))
+                   for i, f in enumerate(frames)]
+        return frames, batches
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(workers) as pool:
+        bounds = np.linspace(0, per, workers + 1).astype(int)
+        jobs = [(int(bounds[i + 1] - bounds[i]), args.points, 7122, rank * per + int(bounds[i]), total)
+                for i in range(workers) if bounds[i + 1] > bounds[i]]
+        frames = [f for blk in pool.map(_gen_frame_block, jobs) for f in blk]
+        batches = pool.map(_gen_score_batch, [(f['points'], f['intensity'], [7122, 99, rank, i])
+                                              for i, f in enumerate(frames)], chunksize=1)
+    return frames, batches
+
+
+def bench_scoring(args, model, world, rank, dev, frames, batches):
+    """prob_inference (8 augmented views per frame) + inter-frame scoring + the return leg to rank
+    0, frames sharded over ranks in the reference's contiguous blocks; probabilities / world
+    coordinates exchanged by one all_gather_into_tensor each."""
+    from lidal_amd.score import collect_sequence, interframe, score_sequence
+    per = args.score_frames
+    total = per * world
     dev_frames = []
-    for f in frames:
-        sb = synth.make_score_batch(f['points'], f['intensity'], rng, inf_reps=8)
+    for f, sb in zip(frames, batches):
         ptr, idx, _ = interframe.sv_csr(f['sv2point'], dev)
         dev_frames.append({'coords': torch.from_numpy(sb['coords_v_b']).to(dev),
                            'feats': torch.from_numpy(sb['feats_v_b']).to(dev),
                            'inverse': torch.from_numpy(sb['inverse_indices_b']).to(dev),
                            'world': torch.from_numpy(f['world']).to(dev), 'sv_ptr': ptr, 'sv_idx': idx})
+    sv_ids = [f['sv_id'] for f in frames]
     model.eval()
     autocast = args.dtype == 'bf16'
     log('scoring inputs resident')
+    out = {'metric': 'frames/sec prob_inference(8 views)+LiDAL scoring', 'unit': 'frames/s',
+           'frames': total, 'frames_per_rank': per, 'points_per_frame': args.points,
+           'voxels_per_frame': int(np.mean([d['coords'].shape[0] for d in dev_frames])),
+           'exchange': ('all_gather_into_tensor(prob f32 [P,19]) + (world f64 [P,3]) + sv results to rank 0'
+                        if world > 1 else 'none (1 rank)'), 'by_nei': {}}
 
-    def run():
-        return score_sequence(model, dev_frames, rank * per, total, nei_num=args.nei, dis_thresh=0.1,
-                              inf_reps=8, autocast=autocast)
-    run()                                   # warm-up
-    log('scoring warm-up done')
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    out = run()
-    barrier_sync(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
-    assert all(torch.isfinite(o[0]).all() for o in out)
+    def run(nei):
+        scores = score_sequence(model, dev_frames, rank * per, total, nei_num=nei, dis_thresh=0.1,
+                                inf_reps=8, autocast=autocast)
+        return scores, collect_sequence(scores, sv_ids, [d['sv_ptr'] for d in dev_frames], rank * per, total)
+    for nei in args.nei:
+        if total < nei + 3:
+            continue
+        run(nei)                                # warm-up
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        scores, got = run(nei)
+        barrier_sync(world)
+        dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+        assert all(torch.isfinite(o[0]).all() for o in scores)
+        assert (got is not None) == (rank == 0)
+        out['by_nei'][str(nei)] = {'value': round(total / dt, 3), 'ms_per_frame_per_gpu': round(dt / per * 1e3, 3)}
+    first = str(args.nei[0]) if str(args.nei[0]) in out['by_nei'] else next(iter(out['by_nei']), None)
+    if first is not None:
+        out['value'] = out['by_nei'][first]['value']
+        out['nei_num'] = int(first)
     model.train()
-    return {'metric': 'frames/sec prob_inference(8 views)+LiDAL scoring', 'value': round(total / dt, 3),
-            'unit': 'frames/s', 'frames': total, 'nei_num': args.nei, 'points_per_frame': args.points,
-            'exchange': 'all_gather(prob f32 [P,19], world f64 [P,3])' if world > 1 else 'none (1 rank)'}
+    return out
 
 
 def main():
     args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    solo = rank == 0 and world == 1         # the extras describe one GPU; N>1 runs report the contract line
+    # ---- host-only work first: process pools (input generation, the CPU baselines) start their
+    #      workers BEFORE this process touches the GPU (a GPU-initialised process must not exec)
+    frames = batches = None
+    cpu_lines = {}
+    if not args.no_secondary and not args.roofline_only:
+        frames, batches = make_scoring_inputs(args, world, rank)
+        log('scoring inputs generated')
+        if solo and not args.no_cpu_baseline:
+            cpu_lines['secondary'] = scoring_cpu_baseline(frames, args.nei[0])
+            log('scoring cpu baseline', cpu_lines['secondary'])
+    if solo and not args.no_cpu_baseline and not args.roofline_only:
+        cpu_lines['train'] = cpu_baseline(args)
+        log('train cpu baseline', cpu_lines['train'])
+    # ---- GPU
     world, rank, dev = dist_setup(args)
     from lidal_amd import backend
     backend.lib()                           # fail loudly if the HIP library is missing
+    batch = make_batch(args.frames, args.points, 7122 + rank, dev)
+    log('batch built', tuple(batch[0].shape))
     if args.roofline_only:
-        from lidal_amd import synth
-        batch = synth.make_train_batch(n_frames=args.frames, n_points=args.points, seed=7122 + rank)
-        coords = torch.from_numpy(batch['coords_v_b']).to(dev)
-        print(json.dumps({'roofline': roofline_conv(args, coords, dev)}), flush=True)
+        print(json.dumps({'roofline': roofline_conv(args, batch[0], dev)}), flush=True)
         return
-    res = bench_train(args, world, rank, dev)
+    res = bench_train(world, rank, dev, args.model, args.dtype, batch, args.steps, args.warmup)
     log('train timed: %.3f s for %d steps' % (res['seconds'], args.steps))
     ms = res['seconds'] / args.steps * 1e3
+    voxels = sum_over_ranks(float(res['voxels']), world, dev)
     line = {
         'metric': 'voxels/sec SPVCNN fwd+bwd @120k pts' if args.model == 'spvcnn'
                   else 'voxels/sec MinkUNet fwd+bwd @120k pts',
-        'value': round(res['voxels_per_step'] * args.steps / res['seconds'], 1),
+        'value': round(voxels * args.steps / res['seconds'], 1),
         'unit': 'voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': '%s train step (train.py:127-140: fwd + CE + bwd + Adam), %d scans x ~%dk pts '
                                'per GPU, 0.05 m voxels, kernel maps rebuilt every step'
                                % (args.model, args.frames, args.points // 1000),
-                   'voxels_per_step_per_gpu': int(res['voxels_per_step'] / world),
+                   'voxels_per_step_per_gpu': int(voxels / world),
                    'parallelism': 'dp%d' % world, 'loss': round(res['loss'], 4)},
     }
     if rank == 0 and not args.no_roofline:
-        line['roofline'] = roofline_conv(args, res['coords'], dev)
+        line['roofline'] = roofline_conv(args, batch[0], dev)
         log('roofline', line['roofline'])
-    if not args.no_secondary:
-        sec = bench_scoring(args, res['model'], world, rank, dev)
+    if solo and not args.no_families:
+        line['families'] = family_table(res['step'], batch[0], args.dtype, ms)
+        log('families', line['families'])
+    if solo and not args.no_variants:
+        var = {}
+        one = make_batch(1, args.points, 7122, dev)
+        var['single_scan'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, one,
+                                                      max(args.steps, 10), 3, ddp=False))
+        other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
+        var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
+                                                    max(3, args.steps // 2), 2, ddp=False))
+        other_model = 'minkunet' if args.model == 'spvcnn' else 'spvcnn'
+        var[other_model] = variant_line(bench_train(1, 0, dev, other_model, args.dtype, batch,
+                                                    args.steps, 3, ddp=False))
+        line['variants'] = var
+        log('variants', var)
+    if frames is not None:
+        sec = bench_scoring(args, res['model'], world, rank, dev, frames, batches)
         log('secondary', sec)
         if rank == 0:
             line['secondary'] = sec
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        log('cpu baseline ...')
-        line['cpu_baseline'] = cpu_baseline(args)
+            if 'secondary' in cpu_lines:
+                line['secondary']['cpu_baseline'] = cpu_lines['secondary']
+    if 'train' in cpu_lines:
+        line['cpu_baseline'] = cpu_lines['train']
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist.is_initialized():

@@ -179,6 +179,28 @@ int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const i
                      const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out, int ci,
                      int co, int k, int kflip, int dtype, const float* ep_scale,
                      const float* ep_shift, int ep_relu, const void* ep_residual, void* stream);
+/* Second-generation form of lidal_conv_apply (csrc/conv_img.hip): the same contraction with the
+ * weights supplied as LDS IMAGES -- every slab (offset, column block, reduction slice) laid out in
+ * global memory exactly as the MFMA B-fragment reads want it in LDS, so the kernel stages a slab by
+ * LDS-DMA (no vector registers, no ds_write) and reads it bank-conflict free.
+ *   lidal_conv_weight_image_bytes  size of the image of a [k][n_red][n_col] weight for a
+ *                                  convolution producing n_out rows (the tiling depends on it)
+ *   lidal_conv_weight_image        role 0: w is [k][n_red][n_col] (forward: n_red = ci, n_col = co)
+ *                                  role 1: w is [k][n_col][n_red] (data gradient of the same
+ *                                  parameter: n_red = co, n_col = ci); casts to `dtype`
+ *   lidal_conv_apply_image         arguments as lidal_conv_apply, wimg = the image built for the
+ *                                  SAME (ci = n_red, co = n_col, k, dtype, n_out); tile_masks are
+ *                                  required with a table (nbr == NULL: identity rule list, k = 1);
+ *                                  ci must be a multiple of 4 (f32) / 8 (bf16).
+ * Results are bitwise those of lidal_conv_apply (same offset and reduction order). */
+int64_t lidal_conv_weight_image_bytes(int k, int ci, int co, int dtype, int64_t n_out);
+int lidal_conv_weight_image(const void* w, int w_dtype, int role, void* img, int dtype, int k,
+                            int n_red, int n_col, int64_t n_out, void* stream);
+int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr, const int32_t* perm,
+                           const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out,
+                           int ci, int co, int k, int kflip, int dtype, const float* ep_scale,
+                           const float* ep_shift, int ep_relu, const void* ep_residual,
+                           void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
  * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  Split-K: offset k with nk rules is cut into

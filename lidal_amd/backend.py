@@ -62,6 +62,10 @@ SIGNATURES = {
     'lidal_kmap_order': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
                                 _vp, _i32, _vp, _vp]),
+    'lidal_conv_weight_image_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
+    'lidal_conv_weight_image': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
+    'lidal_conv_apply_image': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
+                                      _vp, _i32, _vp, _vp]),
     'lidal_conv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                 _vp]),
     'lidal_bn_workspace_bytes': (_i64, [_i64, _i32]),
@@ -90,7 +94,40 @@ SIGNATURES = {
 }
 
 
-def lib():
+class _TimedLib:
+    """Measurement hook (bench.py): every library call bracketed by events on the launch stream and
+    reported to `sink(name, args, e0, e1)`.  Off unless set_call_timer() installs a sink."""
+
+    def __init__(self, handle, sink):
+        self._handle, self._sink = handle, sink
+
+    def __getattr__(self, name):
+        fn = getattr(self._handle, name)
+        if fn.restype is not _i32 or name.endswith('_bytes') or name == 'lidal_version':
+            return fn                               # size queries: no kernel behind them
+        sink = self._sink
+
+        def timed(*args):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            sink(name, args, e0, e1)
+            return rc
+        return timed
+
+
+_timer = None
+
+
+def set_call_timer(sink):
+    """sink(name, args, start_event, end_event) per library call, or None to switch timing off."""
+    global _timer
+    _timer = None if sink is None else _TimedLib(lib_handle(), sink)
+
+
+def lib_handle():
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
@@ -105,6 +142,10 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def lib():
+    return _timer if _timer is not None else lib_handle()
 
 
 def check(rc, what):

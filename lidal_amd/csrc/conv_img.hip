@@ -1,0 +1,513 @@
+// Sparse 3D convolution for gfx950, second generation of lidal_conv_apply (conv.hip): same dataflow
+// (output-stationary, register accumulators, A fragments gathered straight into registers one phase
+// ahead, weights of the current offset shared by the workgroup through LDS) with the weight stream
+// moved off the vector registers:
+//
+//   * weights arrive as LDS IMAGES: lidal_conv_weight_image lays every slab (offset k, column block,
+//     reduction slice) out in global memory exactly as the MFMA B-fragment reads want it in LDS,
+//         image[cc][gsel][nb][row16] x 16 bytes  =  Wt[n0 + 16 nb + row16][c0 + CH cc + VEC gsel ...]
+//     so that (a) a slab is staged by LDS-DMA (`buffer_load_dwordx4 ... lds`: 1 KiB per wave
+//     instruction, no VGPRs, no ds_write) as a linear copy and (b) every ds_read_b128 of a
+//     fragment is bank-conflict free without padding (the 16-byte slot of an access is row16,
+//     and each of ds_read_b128's four 16-lane groups covers all sixteen row16 values once);
+//   * the vector registers and LDS that frees (12 VGPRs of staging, the 16-byte row pad, the
+//     index slices of absent offsets) buy a third resident workgroup per CU on the 96-column
+//     kernels; the phase loop has no weight-store segment any more.
+//
+// Everything else -- row order by occupancy pattern, per-tile offset masks, buffer addressing with
+// the hardware range check serving absent rules, scalar offset walk, copy-free two-set software
+// pipeline, epilogues -- is as described in conv.hip / DESIGN.md.
+#include <type_traits>
+
+#include "common.h"
+
+using namespace lidal;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef int raw4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int VEC = 4;
+  static constexpr int CH = 16;
+  typedef f32x4 frag;
+  __device__ static float to_f32(float v) { return v; }
+  __device__ static float from_f32(float v) { return v; }
+};
+template <> struct DT<__bf16> {
+  static constexpr int VEC = 8;
+  static constexpr int CH = 32;
+  typedef bf16x8 frag;
+  __device__ static float to_f32(__bf16 v) { return (float)v; }
+  __device__ static __bf16 from_f32(float v) { return (__bf16)v; }
+};
+
+__device__ __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+
+constexpr int MAXK = 32;
+constexpr int MAX_DEVICES = 16;
+static inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+  return d;
+}
+
+// ---- tiling policy, shared by the image packer and the launcher ------------------------------
+struct Tiling { int nb; int row_bytes; };       // 16-column blocks per workgroup, staged bytes per pass
+
+__host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int esz) {
+  Tiling t;
+  const int row_bytes = ci * esz;
+  t.row_bytes = (row_bytes % 192 == 0 && row_bytes % 128 != 0) ? 192 : 128;
+  if (co <= 32) t.nb = 2;
+  else if (co <= 64 || (co % 64 == 0 && ((n_out + 127) / 128) * ((co + 127) / 128) <= 384)) t.nb = 4;
+  else if (co % 128 != 0 && (co % 96 == 0 || co < 128)) t.nb = 6;
+  else t.nb = 8;
+  return t;
+}
+__host__ __device__ inline int64_t image_bytes(int k, int ci, int co, Tiling t, int esz) {
+  const int bn = 16 * t.nb, kc = t.row_bytes / esz;
+  const int nblk = (co + bn - 1) / bn, npass = (ci + kc - 1) / kc;
+  return (int64_t)k * nblk * npass * bn * t.row_bytes;
+}
+
+// image[k][nblk][pass][cc][gsel][nb][row16][VEC]; one thread per 16-byte segment.
+// role 0: W[k][red][col] (forward: red = ci, col = co);  role 1: W[k][col][red] (data gradient)
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+weight_image_kernel(const TI* __restrict__ w, TO* __restrict__ img, int K, int n_red, int n_col,
+                    int role, int nb, int kc, int64_t segs) {
+  constexpr int VEC = DT<TO>::VEC, CH = DT<TO>::CH;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= segs) return;
+  const int bn = 16 * nb, ncc = kc / CH;
+  const int nblk = (n_col + bn - 1) / bn, npass = (n_red + kc - 1) / kc;
+  int64_t r = s;
+  const int row16 = (int)(r % 16); r /= 16;
+  const int b = (int)(r % nb); r /= nb;
+  const int gsel = (int)(r % 4); r /= 4;
+  const int cc = (int)(r % ncc); r /= ncc;
+  const int pass = (int)(r % npass); r /= npass;
+  const int blk = (int)(r % nblk); r /= nblk;
+  const int k = (int)r;
+  const int col = blk * bn + b * 16 + row16;
+  const int red0 = pass * kc + cc * CH + gsel * VEC;
+  TO v[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int red = red0 + e;
+    float f = 0.f;
+    if (col < n_col && red < n_red) {
+      const int64_t base = (int64_t)k * n_red * n_col;
+      f = DT<TI>::to_f32(role == 0 ? w[base + (int64_t)red * n_col + col] : w[base + (int64_t)col * n_red + red]);
+    }
+    v[e] = DT<TO>::from_f32(f);
+  }
+  typedef typename DT<TO>::frag frag;
+  *reinterpret_cast<frag*>(img + s * VEC) = *reinterpret_cast<frag*>(v);
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
+#ifndef LIDAL_IMG_MINWAVES
+#define LIDAL_IMG_MINWAVES 2
+#endif
+
+// LDS (dynamic): weight slabs [2][SLAB] (re-used as the epilogue tile) | dump 1 KiB.  The neighbour
+// indices never touch LDS: each lane loads the index of ITS row for the phase after next straight
+// from the permuted table (64 contiguous bytes per 16-row group) two phases ahead of use.
+template <typename T, int NB, int ROW_BYTES, int G, int NWAVES, int MINW, bool DENSE>
+__global__ void __launch_bounds__(64 * NWAVES, MINW)
+conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
+                      const int* __restrict__ nbr, const int* __restrict__ perm,
+                      const unsigned* __restrict__ tmasks, T* __restrict__ out, int64_t n_out,
+                      int ci, int co, int K, int kflip, const float* __restrict__ ep_scale,
+                      const float* __restrict__ ep_shift, int ep_relu, const T* __restrict__ ep_res,
+                      unsigned in_bytes, unsigned img_bytes, unsigned nbr_bytes) {
+  constexpr int NTHREADS = 64 * NWAVES;
+  constexpr int BM = NWAVES * G * 16;
+  constexpr int BN = 16 * NB;
+  constexpr int VEC = DT<T>::VEC;
+  constexpr int CH = DT<T>::CH;
+  constexpr int KC = ROW_BYTES / (int)sizeof(T);
+  constexpr int MAXCC = KC / CH;
+  constexpr int SLAB = BN * ROW_BYTES;                   // bytes of one staged slab
+  constexpr int PIECES = SLAB / 1024;                    // 1 KiB LDS-DMA pieces per slab
+  constexpr int PPW = (PIECES + NWAVES - 1) / NWAVES;    // pieces per wave (the surplus hits the dump)
+  constexpr int RW = G * 16;
+  constexpr int ESTRIDE = BN + VEC;
+  constexpr int EPI = NWAVES * RW * ESTRIDE * (int)sizeof(T);
+  constexpr int WREGION = (2 * SLAB > EPI) ? 2 * SLAB : EPI;
+  constexpr int GA = G * MAXCC;                          // A gathers per lane and phase
+  static_assert(SLAB % 1024 == 0, "slab must be whole LDS-DMA pieces");
+  typedef typename DT<T>::frag frag;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;
+  unsigned char* dump = smem + WREGION;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row16 = lane & 15;
+  const int gsel = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * RW;
+  const int n0 = blockIdx.y * BN;
+  const int npass = (ci + KC - 1) / KC;
+
+  // ---- tile mask: the OR of the 128-row masks this tile covers (scalar loads)
+  unsigned tmask;
+  if constexpr (DENSE) {          // no table at all: the identity rule list of a per-row product (K == 1)
+    tmask = 1u;
+  } else {
+    unsigned m = 0u;
+    const int64_t t0 = ((int64_t)blockIdx.x * BM) >> 7;
+#pragma unroll
+    for (int h = 0; h < BM / 128; ++h)
+      if ((t0 + h) * 128 < n_out) m |= tmasks[t0 + h];
+    if (kflip) m = __brev(m) >> (32 - K);
+    tmask = m;
+  }
+  tmask = __builtin_amdgcn_readfirstlane(tmask);
+  const int n_act = __popc(tmask);
+  const int nphase = n_act * npass;
+
+  struct Walk { unsigned rem; int k; int pass; };
+  auto walk_begin = [&]() {
+    Walk w;
+    w.k = tmask ? __builtin_ctz(tmask) : 0;
+    w.rem = tmask & (tmask - 1u);
+    w.pass = 0;
+    return w;
+  };
+  auto walk_next = [&](Walk& w) {
+    if (++w.pass == npass) {
+      w.pass = 0;
+      w.k = w.rem ? __builtin_ctz(w.rem) : 0;      // past the end: any valid offset (result unused)
+      w.rem &= w.rem - 1u;
+    }
+  };
+
+  constexpr unsigned OOB_OFF = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wimg), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nbr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, (int)nbr_bytes, 0x00020000);
+  const int nblk = gridDim.y;
+
+  // slab (k, this column block, pass) -> LDS buffer `buf` by LDS-DMA: wave w moves pieces
+  // w, w + NWAVES, ...; every wave issues exactly PPW instructions (a surplus piece, or a dead
+  // phase, reads out of range -- zeros, no memory traffic -- into the dump)
+  auto stage_dma = [&](int k, int pass, int buf, bool live) {
+    const unsigned slab_off = (unsigned)((((int64_t)k * nblk + blockIdx.y) * npass + pass) * SLAB);
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+      const int piece = wave + t * NWAVES;
+      const bool ok = live && piece < PIECES;
+      unsigned char* dst = ok ? wl + buf * SLAB + piece * 1024 : dump;
+      const unsigned soff = ok ? slab_off + (unsigned)piece * 1024u : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)dst, 16,
+                                               (unsigned)lane * 16u, soff, 0, 0);
+    }
+  };
+  // neighbour index of this lane's row in each row group for offset k: one 4-byte load per group
+  // (the four lanes of a row share the address).  The raw loaded value is carried to its use a
+  // phase later; rows past the end of the table are masked THERE (row_ok), so nothing touches
+  // the value -- and nothing waits for the load -- in the phase that issues it.
+  const unsigned row_off = (unsigned)((r0 + row16) * 4);
+  bool row_ok[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) row_ok[g] = r0 + g * 16 + row16 < n_out;
+  auto load_idx = [&](int (&dst)[G], int k) {
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) dst[g] = (int)(r0 + g * 16 + row16);
+    } else {
+      const int kk = kflip ? (K - 1 - k) : k;
+      const unsigned koff = (unsigned)kk * (unsigned)n_out * 4u;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        dst[g] = __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, row_off + (unsigned)(g * 64), koff, 0);
+    }
+  };
+  auto kill_bit = [&](bool live) {
+    unsigned kb = live ? 0u : OOB_OFF;
+    asm volatile("" : "+s"(kb));
+    return kb;
+  };
+  auto load_a = [&](raw4 (&a)[G][MAXCC], unsigned long long (&present)[G], const int (&idx)[G],
+                    int c0, bool live) {
+    const int kc = min(KC, ci - c0);
+    const unsigned row_bytes = (unsigned)(ci * (int)sizeof(T));
+    const unsigned lane_off = (unsigned)((c0 + gsel * VEC) * (int)sizeof(T));
+    const unsigned kill = kill_bit(live);
+    const unsigned long long live_mask = kill ? 0ull : ~0ull;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int src = row_ok[g] ? idx[g] : -1;
+      present[g] = __ballot(src >= 0) & live_mask;
+      const unsigned base = ((src >= 0) ? (unsigned)src * row_bytes + lane_off : OOB_OFF) | kill;
+#pragma unroll
+      for (int cc = 0; cc < MAXCC; ++cc) {
+        const unsigned off = (cc * CH + gsel * VEC < kc) ? base + (unsigned)(cc * CH * (int)sizeof(T)) : OOB_OFF;
+        a[g][cc] = __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+      }
+    }
+  };
+
+  f32x4 acc[G][NB];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Software pipeline (vector-memory operations retire in order, so the ORDER of issue inside a
+  // phase is what makes every wait cheap).  Phase p issues, in this order: slab(p+1) by DMA,
+  // index(p+2), A(p+1); then runs the MFMAs of phase p on A(p) / slab(p).
+  //   * A(p+1) needs index(p+1): issued in phase p-1 BEFORE A(p), so waiting for it leaves A(p)
+  //     and this phase's DMA in flight;
+  //   * the MFMAs need A(p): everything issued in this phase may stay in flight;
+  //   * the barrier that ends the phase needs slab(p+1): issued FIRST in the phase, so only the
+  //     index and A loads behind it (G + GA) stay in flight -- the explicit s_waitcnt below
+  //     (hipcc does not order a ds_read behind an LDS-DMA write on its own).
+  raw4 a0[G][MAXCC], a1[G][MAXCC];
+  unsigned long long pres0[G], pres1[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) pres0[g] = pres1[g] = 0ull;
+  Walk w1 = walk_begin();       // the phase whose A / slab are issued next
+  Walk w2 = walk_begin();       // the phase whose indices are issued next (one further ahead)
+  int idx_a[G], idx_b[G];       // indices of two consecutive OFFSETS' phases, used alternately
+  constexpr int TAIL = (DENSE ? 0 : G) + GA;      // the dense form issues no index loads
+  if (nphase > 0) {
+    stage_dma(w1.k, 0, 0, true);
+    load_idx(idx_a, w2.k);
+    walk_next(w2);
+    load_idx(idx_b, w2.k);
+    walk_next(w2);
+    load_a(a0, pres0, idx_a, 0, true);
+    walk_next(w1);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (GA & 15) | ((GA >> 4) << 14));     // slab 0 landed
+  }
+  __syncthreads();
+
+  auto phase = [&](int p, raw4 (&a_cur)[G][MAXCC], unsigned long long (&pres_cur)[G],
+                   raw4 (&a_nxt)[G][MAXCC], unsigned long long (&pres_nxt)[G], int (&idx_nxt)[G],
+                   int (&idx_free)[G]) {
+    const int c0 = (p % npass) * KC;
+    const int kc = min(KC, ci - c0);
+    const unsigned char* wbuf = wl + (p & 1) * SLAB;
+    const bool more = p + 1 < nphase;
+    stage_dma(w1.k, w1.pass, (p + 1) & 1, more);
+    load_idx(idx_free, w2.k);          // phase p+2 (idx_free held phase p's indices: dead now)
+    walk_next(w2);
+    load_a(a_nxt, pres_nxt, idx_nxt, w1.pass * KC, more);      // idx_nxt: issued a phase ago, before A(p)
+    walk_next(w1);
+    bool any_present = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) any_present |= pres_cur[g] != 0ull;
+    if (any_present) {
+      const unsigned char* wbase = wbuf + (gsel * NB) * 256 + row16 * 16;
+#pragma unroll
+      for (int cc = 0; cc < MAXCC; ++cc) {
+        if (cc * CH < kc) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            frag b = *reinterpret_cast<const frag*>(wbase + (cc * 4 * NB + nb) * 256);
+#pragma unroll
+            for (int g = 0; g < G; ++g) mma(acc[g][nb], __builtin_bit_cast(frag, a_cur[g][cc]), b);
+          }
+        }
+      }
+    }
+    // slab(p+1) landed: only the loads issued behind its DMA may stay in flight
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));
+    __syncthreads();
+  };
+  // with npass > 1 the index registers of an offset serve npass consecutive phases: the walk w2
+  // then advances per PHASE like w1, re-loading the same slice (cheap, and it keeps the two-set
+  // alternation independent of npass)
+  for (int p = 0; p < nphase; p += 2) {
+    phase(p, a0, pres0, a1, pres1, idx_b, idx_a);
+    if (p + 1 < nphase) phase(p + 1, a1, pres1, a0, pres0, idx_a, idx_b);
+  }
+
+  // ---- epilogue (as conv.hip): accumulators -> wave-private LDS tile -> whole rows, 16-byte stores
+  T* et = reinterpret_cast<T*>(wl) + wave * RW * ESTRIDE;
+  if (ep_scale != nullptr) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = n0 + nb * 16 + row16;
+      const float es = col < co ? ep_scale[col] : 1.f, eh = col < co ? ep_shift[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[g][nb][r] * es + eh;
+          acc[g][nb][r] = ((ep_relu & 1) && v < 0.f) ? 0.f : v;
+        }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        et[(g * 16 + gsel * 4 + r) * ESTRIDE + nb * 16 + row16] = DT<T>::from_f32(acc[g][nb][r]);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  constexpr int RSEGS = BN / VEC;
+  for (int i = lane; i < RW * RSEGS; i += 64) {
+    const int r = i / RSEGS, cseg = (i - r * RSEGS) * VEC;
+    if (r0 + r >= n_out) continue;
+    const int64_t row = perm ? (int64_t)perm[r0 + r] : r0 + r;
+    T* dst = out + row * co + n0 + cseg;
+    const T* srcp = et + r * ESTRIDE + cseg;
+    if (n0 + cseg + VEC <= co) {
+      frag v = *reinterpret_cast<const frag*>(srcp);
+      if (ep_res != nullptr) {
+        const frag rr = *reinterpret_cast<const frag*>(ep_res + row * co + n0 + cseg);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float f = DT<T>::to_f32(v[e]) + DT<T>::to_f32(rr[e]);
+          if ((ep_relu & 2) && f < 0.f) f = 0.f;
+          v[e] = DT<T>::from_f32(f);
+        }
+      }
+      *reinterpret_cast<frag*>(dst) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (n0 + cseg + e < co) {
+          float v = DT<T>::to_f32(srcp[e]);
+          if (ep_res != nullptr) {
+            v += DT<T>::to_f32(ep_res[row * co + n0 + cseg + e]);
+            if ((ep_relu & 2) && v < 0.f) v = 0.f;
+          }
+          dst[e] = DT<T>::from_f32(v);
+        }
+    }
+  }
+}
+
+struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; };
+
+#ifndef LIDAL_IMG_G
+#define LIDAL_IMG_G 1
+#endif
+#ifndef LIDAL_IMG_NWAVES
+#define LIDAL_IMG_NWAVES 8
+#endif
+
+template <typename T, int NB, int ROW_BYTES>
+int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm, const unsigned* tmasks,
+               void* out, int64_t n_out, int ci, int co, int K, int kflip, Epi ep, hipStream_t s) {
+  constexpr int G = LIDAL_IMG_G, NWAVES = LIDAL_IMG_NWAVES;
+  constexpr int NTHREADS = 64 * NWAVES, BM = NWAVES * G * 16, BN = 16 * NB;
+  constexpr int SLAB = BN * ROW_BYTES;
+  constexpr int EPI = NWAVES * G * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
+  constexpr int WREGION = (2 * SLAB > EPI) ? 2 * SLAB : EPI;
+  static_assert(BM % 128 == 0, "tile masks are per 128 rows");
+  const size_t lds = WREGION + 1024;
+  auto kern = nbr ? conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, false>
+                  : conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, true>;
+  static size_t attr_set[2][MAX_DEVICES] = {};
+  const int dev = current_device();
+  if (attr_set[nbr ? 0 : 1][dev] < lds) {
+    LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[nbr ? 0 : 1][dev] = lds;
+  }
+  dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
+  kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out, ci,
+                                   co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
+                                   ep.in_bytes, ep.img_bytes, ep.nbr_bytes);
+  LIDAL_CHECK_LAUNCH("lidal_conv_apply_image");
+  return 0;
+}
+
+template <typename T>
+int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, const int* perm,
+                 const unsigned* tmasks, void* out, int64_t n_out, int ci, int co, int K, int kflip,
+                 Epi ep, hipStream_t s) {
+#define IMG_CASE(NBV, RB) \
+  if (t.nb == NBV && t.row_bytes == RB) \
+    return launch_img<T, NBV, RB>(in, wimg, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
+  IMG_CASE(2, 128) IMG_CASE(4, 128) IMG_CASE(6, 128) IMG_CASE(8, 128)
+  IMG_CASE(2, 192) IMG_CASE(4, 192) IMG_CASE(6, 192) IMG_CASE(8, 192)
+#undef IMG_CASE
+  set_error("conv_apply_image: no kernel for tiling nb=%d row_bytes=%d", t.nb, t.row_bytes);
+  return 2;
+}
+
+}  // namespace
+
+extern "C" int64_t lidal_conv_weight_image_bytes(int k, int ci, int co, int dtype, int64_t n_out) {
+  const int esz = dtype == LIDAL_BF16 ? 2 : 4;
+  return image_bytes(k, ci, co, pick_tiling(ci, co, n_out, esz), esz);
+}
+
+extern "C" int lidal_conv_weight_image(const void* w, int w_dtype, int role, void* img, int dtype,
+                                       int k, int n_red, int n_col, int64_t n_out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (k == 0 || n_red == 0 || n_col == 0) return 0;
+  LIDAL_REQUIRE(role == 0 || role == 1, "weight_image: role must be 0 (forward) or 1 (data gradient)");
+  const int esz = dtype == LIDAL_BF16 ? 2 : 4;
+  const Tiling t = pick_tiling(n_red, n_col, n_out, esz);
+  const int kc = t.row_bytes / esz;
+  const int64_t segs = image_bytes(k, n_red, n_col, t, esz) / 16;
+  const unsigned grid = (unsigned)cdiv(segs, 256);
+  if (w_dtype == LIDAL_F32 && dtype == LIDAL_F32)
+    weight_image_kernel<float, float><<<grid, 256, 0, s>>>((const float*)w, (float*)img, k, n_red, n_col, role, t.nb, kc, segs);
+  else if (w_dtype == LIDAL_F32 && dtype == LIDAL_BF16)
+    weight_image_kernel<float, __bf16><<<grid, 256, 0, s>>>((const float*)w, (__bf16*)img, k, n_red, n_col, role, t.nb, kc, segs);
+  else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_BF16)
+    weight_image_kernel<__bf16, __bf16><<<grid, 256, 0, s>>>((const __bf16*)w, (__bf16*)img, k, n_red, n_col, role, t.nb, kc, segs);
+  else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_F32)
+    weight_image_kernel<__bf16, float><<<grid, 256, 0, s>>>((const __bf16*)w, (float*)img, k, n_red, n_col, role, t.nb, kc, segs);
+  else {
+    set_error("weight_image: bad dtypes %d %d", w_dtype, dtype);
+    return 2;
+  }
+  LIDAL_CHECK_LAUNCH("lidal_conv_weight_image");
+  return 0;
+}
+
+extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
+                                      const int32_t* perm, const uint32_t* tile_masks, void* out,
+                                      int64_t n_in, int64_t n_out, int ci, int co, int k, int kflip,
+                                      int dtype, const float* ep_scale, const float* ep_shift,
+                                      int ep_relu, const void* ep_residual, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out == 0 || co == 0) return 0;
+  LIDAL_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv_apply_image: scale and shift go together");
+  LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16, "conv_apply_image: bad dtype %d", dtype);
+  const int esz = dtype == LIDAL_BF16 ? 2 : 4;
+  const int vec = 16 / esz;
+  LIDAL_REQUIRE(ci > 0 && ci % vec == 0 && co % 4 == 0 && k > 0 && k <= MAXK,
+                "conv_apply_image: ci must be a multiple of %d, co of 4, k <= %d (got ci=%d co=%d k=%d)",
+                vec, MAXK, ci, co, k);
+  LIDAL_REQUIRE(nbr == nullptr ? (k == 1 && n_in == n_out) : (tile_masks != nullptr),
+                "conv_apply_image: needs lidal_kmap_order's tile masks (or NULL table = identity, k = 1)");
+  const Tiling t = pick_tiling(ci, co, n_out, esz);
+  const int64_t ib = image_bytes(k, ci, co, t, esz);
+  LIDAL_REQUIRE(n_in >= 0 && n_in * ci * esz < 0x7FFFFFF0ll && ib < 0x7FFFFFF0ll,
+                "conv_apply_image: the input matrix and the weight image must each stay below 2 GiB");
+  LIDAL_REQUIRE((int64_t)k * n_out * 4 < 0x7FFFFFF0ll, "conv_apply_image: neighbour table above 2 GiB");
+  Epi ep{ep_scale, ep_shift, ep_relu, ep_residual, (unsigned)(n_in * ci * esz), (unsigned)ib,
+         (unsigned)((int64_t)k * n_out * 4)};
+  if (dtype == LIDAL_F32)
+    return dispatch_img<float>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
+  return dispatch_img<__bf16>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
+}

@@ -122,6 +122,12 @@ weight_image_kernel(const TI* __restrict__ w, TO* __restrict__ img, int K, int n
 #ifndef LIDAL_IMG_MINWAVES
 #define LIDAL_IMG_MINWAVES 2
 #endif
+// Timing-only ablation builds (scripts/exp_img.py with an A/B library): results are wrong by
+// construction.  1: A gathers folded into the first 2048 rows (L2-resident: what perfect gather
+// locality would buy)  2: no weight DMA  4: no MFMA / fragment reads  8: no A gathers  16: no epilogue
+#ifndef LIDAL_IMG_ABL
+#define LIDAL_IMG_ABL 0
+#endif
 
 // LDS (dynamic): weight slabs [2][SLAB] (re-used as the epilogue tile) | dump 1 KiB.  The neighbour
 // indices never touch LDS: each lane loads the index of ITS row for the phase after next straight
@@ -217,7 +223,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
       const int piece = wave + t * NWAVES;
       const bool ok = live && piece < PIECES;
       unsigned char* dst = ok ? wl + buf * SLAB + piece * 1024 : dump;
-      const unsigned soff = ok ? slab_off + (unsigned)piece * 1024u : OOB_OFF;
+      const unsigned soff = (ok && !(LIDAL_IMG_ABL & 2)) ? slab_off + (unsigned)piece * 1024u : OOB_OFF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)dst, 16,
                                                (unsigned)lane * 16u, soff, 0, 0);
     }
@@ -256,8 +262,10 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
     const unsigned long long live_mask = kill ? 0ull : ~0ull;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int src = row_ok[g] ? idx[g] : -1;
-      present[g] = __ballot(src >= 0) & live_mask;
+      int src = row_ok[g] ? idx[g] : -1;
+      if ((LIDAL_IMG_ABL & 1) && src >= 0) src &= 2047;
+      if (LIDAL_IMG_ABL & 8) src = (src >= 0) ? -2 : -1;
+      present[g] = __ballot(src != -1) & live_mask;
       const unsigned base = ((src >= 0) ? (unsigned)src * row_bytes + lane_off : OOB_OFF) | kill;
 #pragma unroll
       for (int cc = 0; cc < MAXCC; ++cc) {
@@ -317,7 +325,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
     bool any_present = false;
 #pragma unroll
     for (int g = 0; g < G; ++g) any_present |= pres_cur[g] != 0ull;
-    if (any_present) {
+    if (any_present && !(LIDAL_IMG_ABL & 4)) {
       const unsigned char* wbase = wbuf + (gsel * NB) * 256 + row16 * 16;
 #pragma unroll
       for (int cc = 0; cc < MAXCC; ++cc) {
@@ -330,6 +338,12 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
           }
         }
       }
+    }
+    if (LIDAL_IMG_ABL & 4) {        // keep the gathers alive without their consumer
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int cc = 0; cc < MAXCC; ++cc) asm volatile("" ::"v"(a_cur[g][cc]));
     }
     // slab(p+1) landed: only the loads issued behind its DMA may stay in flight
     __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));
@@ -344,6 +358,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
   }
 
   // ---- epilogue (as conv.hip): accumulators -> wave-private LDS tile -> whole rows, 16-byte stores
+  if (LIDAL_IMG_ABL & 16) return;
   T* et = reinterpret_cast<T*>(wl) + wave * RW * ESTRIDE;
   if (ep_scale != nullptr) {
 #pragma unroll

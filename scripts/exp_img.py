@@ -82,7 +82,10 @@ def main():
         s *= 2
     print('lib', B.LIB_PATH, 'dtype', dtype)
     print('%-30s %10s %10s  %s' % ('shape (rows, rules)', 'v1 us', 'image us', 'bit-equal'))
+    only = os.environ.get('EXP_SHAPES')
     for stride, ci, co in SHAPES:
+        if only and '%d:%d:%d' % (stride, ci, co) not in only.split(','):
+            continue
         c = levels[stride]
         kmap, _ = F.build_kernel_map(c, (stride,) * 3, (3, 3, 3), (1, 1, 1))
         n = c.shape[0]

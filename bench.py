@@ -186,14 +186,15 @@ def roofline_conv(args, coords, dev, reps=20):
     kmap, _ = F.build_kernel_map(coords, (1, 1, 1), (3, 3, 3), (1, 1, 1))
     n, m = coords.shape[0], kmap.total
     order = kmap.order_out
+    from lidal_amd.nn.functional.conv import _weight_image
     x = torch.randn(n, ci, device=dev).to(dtype)
-    wk = (torch.randn(27, co, ci, device=dev) * 0.02).to(dtype)
+    img = _weight_image(torch.randn(27, ci, co, device=dev) * 0.02, dtype, n, 0)
     out = torch.empty((n, co), dtype=dtype, device=dev)
 
     def launch():
-        B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
-                                         B.ptr(order.tile_masks), B.ptr(out), n, n, ci, co, 27, 0,
-                                         B.dtype_code(dtype), None, None, 0, None, B.stream()), 'conv')
+        B.check(B.lib().lidal_conv_apply_image(B.ptr(x), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
+                                               B.ptr(order.tile_masks), B.ptr(out), n, n, ci, co, 27, 0,
+                                               B.dtype_code(dtype), None, None, 0, None, B.stream()), 'conv')
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -211,7 +212,7 @@ def roofline_conv(args, coords, dev, reps=20):
     # `bench.py --roofline-only`, corrected as MI355X_MICROARCH.md prescribes) and kept under
     # profiles/; reported only if that record is of this exact workload
     traffic, traffic_src = None, None
-    for name in ('r02_pmc_conv_apply.json', 'r01_pmc_conv_apply.json'):
+    for name in ('r02_pmc_conv_apply.json',):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             wl = rec['workload']
@@ -222,7 +223,7 @@ def roofline_conv(args, coords, dev, reps=20):
             pass
     return {'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
-            'kernel': 'conv_apply_kernel (k3 s1 96->96, %s)' % args.dtype,
+            'kernel': 'conv_apply_img_kernel (k3 s1 96->96, %s)' % args.dtype,
             'launch_us': round(sec * 1e6, 2), 'rows': n, 'rules': m,
             'algorithmic_bytes_per_launch': int(algo_bytes),
             'mfma': {'achieved': round(flops / sec / 1e12, 3), 'peak': MFMA_PEAK_TFLOPS[args.dtype],
@@ -234,7 +235,8 @@ def roofline_conv(args, coords, dev, reps=20):
 # per-family roofline of one whole step
 # ---------------------------------------------------------------------------------------------
 FAMILY_OF = {
-    'lidal_conv_apply': 'conv_apply', 'lidal_conv_wgrad': 'conv_wgrad', 'lidal_conv_weight_pack': 'weight_pack',
+    'lidal_conv_apply': 'conv_apply', 'lidal_conv_apply_image': 'conv_apply', 'lidal_conv_wgrad': 'conv_wgrad',
+    'lidal_conv_weight_pack': 'weight_pack', 'lidal_conv_weight_image': 'weight_pack',
     'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
@@ -305,7 +307,7 @@ def family_table(step, coords, dtype_name, step_ms):
         f = FAMILY_OF.get(name, 'other_lib')
         ms = e0.elapsed_time(e1)
         by = fl = 0.0
-        if name == 'lidal_conv_apply':
+        if name in ('lidal_conv_apply', 'lidal_conv_apply_image'):
             n_in, n_out, ci, co, k, dt = a[6], a[7], a[8], a[9], a[10], a[12]
             b = 2 if dt == 1 else 4
             m = rules_of(k, n_in, n_out)
@@ -321,6 +323,8 @@ def family_table(step, coords, dtype_name, step_ms):
             by = b * (n_in * ca + n_out * cb) + 4 * k * ca * cb + 8 * m
             fl = 2.0 * m * ca * cb
         elif name == 'lidal_conv_weight_pack':
+            by = (4 + b_el) * a[5] * a[6] * a[7]
+        elif name == 'lidal_conv_weight_image':
             by = (4 + b_el) * a[5] * a[6] * a[7]
         elif name in ('lidal_bn_train_fwd', 'lidal_bn_eval_fwd'):
             by = (3 if name == 'lidal_bn_train_fwd' else 2) * a[2] * a[3] * (2 if a[1] == 1 else 4)

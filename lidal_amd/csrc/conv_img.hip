@@ -67,7 +67,10 @@ struct Tiling { int nb; int row_bytes; };       // 16-column blocks per workgrou
 __host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int esz) {
   Tiling t;
   const int row_bytes = ci * esz;
-  t.row_bytes = (row_bytes % 192 == 0 && row_bytes % 128 != 0) ? 192 : 128;
+  // staged bytes of the reduction dim per pass: 192 for rows that are whole 192-byte but not 128-byte
+  // multiples (96 bf16 channels), 64 for the other rows that 128 does not divide (32 bf16 channels)
+  t.row_bytes = (row_bytes % 192 == 0 && row_bytes % 128 != 0) ? 192
+                : (row_bytes % 128 != 0 && row_bytes % 64 == 0) ? 64 : 128;
   if (co <= 32) t.nb = 2;
   else if (co <= 64 || (co % 64 == 0 && ((n_out + 127) / 128) * ((co + 127) / 128) <= 384)) t.nb = 4;
   else if (co % 128 != 0 && (co % 96 == 0 || co < 128)) t.nb = 6;
@@ -116,23 +119,114 @@ weight_image_kernel(const TI* __restrict__ w, TO* __restrict__ img, int K, int n
   *reinterpret_cast<frag*>(img + s * VEC) = *reinterpret_cast<frag*>(v);
 }
 
+// Timing-only ablation builds (scripts/exp_img.py with an A/B library): results are wrong by
+// construction.  1: A gathers folded into the first 2048 rows (L2-resident: what perfect gather
+// locality would buy)  2: no weight DMA  4: no MFMA / fragment reads  8: no A gathers  16: no epilogue
+#ifndef LIDAL_LEAN_BBATCH
+#define LIDAL_LEAN_BBATCH(nb) (nb)
+#endif
+#ifndef LIDAL_LEAN_WAVES
+#define LIDAL_LEAN_WAVES(nb, row_bytes) 8
+#endif
+#ifndef LIDAL_LEAN_NOSKIP
+#define LIDAL_LEAN_NOSKIP 0
+#endif
+#ifndef LIDAL_LEAN_MINWAVES
+#define LIDAL_LEAN_MINWAVES 4      /* waves per SIMD the register budget must allow: 2 workgroups per CU */
+#endif
+#ifndef LIDAL_IMG_ABL
+#define LIDAL_IMG_ABL 0
+#endif
+
+// ---- epilogue shared by the kernels of this file (as conv.hip): accumulators (D layout: col =
+// lane&15, row = 4*(lane>>4) + r) -> wave-private LDS tile in T -> whole rows to HBM, 16-byte stores,
+// with the optional affine map / ReLU / residual of the inference paths
+template <typename T, int NB, int G, int NWAVES>
+__device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* wl, int wave, int lane,
+                                           int64_t r0, int n0, int64_t n_out, int co,
+                                           const int* __restrict__ perm, T* __restrict__ out,
+                                           const float* __restrict__ ep_scale,
+                                           const float* __restrict__ ep_shift, int ep_relu,
+                                           const T* __restrict__ ep_res, bool perm_in_reg = false,
+                                           int perm_v = 0) {
+  // perm_in_reg: lane l (< 16) of the wave holds perm[r0 + l] in perm_v, loaded when the tile began
+  // (the lean kernel: no dependent load in front of the stores)
+  constexpr int VEC = DT<T>::VEC;
+  constexpr int BN = 16 * NB;
+  constexpr int RW = G * 16;
+  constexpr int ESTRIDE = BN + VEC;
+  typedef typename DT<T>::frag frag;
+  const int row16 = lane & 15, gsel = lane >> 4;
+  if (LIDAL_IMG_ABL & 16) return;
+  T* et = reinterpret_cast<T*>(wl) + wave * RW * ESTRIDE;
+  if (ep_scale != nullptr) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = n0 + nb * 16 + row16;
+      const float es = col < co ? ep_scale[col] : 1.f, eh = col < co ? ep_shift[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[g][nb][r] * es + eh;
+          acc[g][nb][r] = ((ep_relu & 1) && v < 0.f) ? 0.f : v;
+        }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        et[(g * 16 + gsel * 4 + r) * ESTRIDE + nb * 16 + row16] = DT<T>::from_f32(acc[g][nb][r]);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  constexpr int RSEGS = BN / VEC;
+  for (int i = lane; i < RW * RSEGS; i += 64) {
+    const int r = i / RSEGS, cseg = (i - r * RSEGS) * VEC;
+    const int prow = perm_in_reg ? __shfl(perm_v, r & 15, 64) : 0;      // all lanes take part
+    if (r0 + r >= n_out) continue;
+    const int64_t row = perm ? (perm_in_reg ? (int64_t)prow : (int64_t)perm[r0 + r]) : r0 + r;
+    T* dst = out + row * co + n0 + cseg;
+    const T* srcp = et + r * ESTRIDE + cseg;
+    if (n0 + cseg + VEC <= co) {
+      frag v = *reinterpret_cast<const frag*>(srcp);
+      if (ep_res != nullptr) {
+        const frag rr = *reinterpret_cast<const frag*>(ep_res + row * co + n0 + cseg);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float f = DT<T>::to_f32(v[e]) + DT<T>::to_f32(rr[e]);
+          if ((ep_relu & 2) && f < 0.f) f = 0.f;
+          v[e] = DT<T>::from_f32(f);
+        }
+      }
+      *reinterpret_cast<frag*>(dst) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (n0 + cseg + e < co) {
+          float v = DT<T>::to_f32(srcp[e]);
+          if (ep_res != nullptr) {
+            v += DT<T>::to_f32(ep_res[row * co + n0 + cseg + e]);
+            if ((ep_relu & 2) && v < 0.f) v = 0.f;
+          }
+          dst[e] = DT<T>::from_f32(v);
+        }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
 #ifndef LIDAL_IMG_MINWAVES
 #define LIDAL_IMG_MINWAVES 2
 #endif
-// Timing-only ablation builds (scripts/exp_img.py with an A/B library): results are wrong by
-// construction.  1: A gathers folded into the first 2048 rows (L2-resident: what perfect gather
-// locality would buy)  2: no weight DMA  4: no MFMA / fragment reads  8: no A gathers  16: no epilogue
-#ifndef LIDAL_IMG_ABL
-#define LIDAL_IMG_ABL 0
-#endif
 
-// LDS (dynamic): weight slabs [2][SLAB] (re-used as the epilogue tile) | dump 1 KiB.  The neighbour
-// indices never touch LDS: each lane loads the index of ITS row for the phase after next straight
-// from the permuted table (64 contiguous bytes per 16-row group) two phases ahead of use.
-template <typename T, int NB, int ROW_BYTES, int G, int NWAVES, int MINW, bool DENSE>
+// LDS (dynamic): ring of D+1 weight slabs (re-used as the epilogue tile) | dump 1 KiB.  The
+// neighbour indices never touch LDS: each lane loads the index of ITS row straight from the permuted
+// table (64 contiguous bytes per 16-row group) D phases ahead of the gather that uses it.
+template <typename T, int NB, int ROW_BYTES, int G, int NWAVES, int MINW, bool DENSE, int D>
 __global__ void __launch_bounds__(64 * NWAVES, MINW)
 conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
                       const int* __restrict__ nbr, const int* __restrict__ perm,
@@ -153,8 +247,10 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
   constexpr int RW = G * 16;
   constexpr int ESTRIDE = BN + VEC;
   constexpr int EPI = NWAVES * RW * ESTRIDE * (int)sizeof(T);
-  constexpr int WREGION = (2 * SLAB > EPI) ? 2 * SLAB : EPI;
+  constexpr int R = D + 1;                               // ring slots: slabs, A register sets, indices
+  constexpr int WREGION = (R * SLAB > EPI) ? R * SLAB : EPI;
   constexpr int GA = G * MAXCC;                          // A gathers per lane and phase
+  static_assert(D >= 1 && D <= 3, "pipeline depth 1..3");
   static_assert(SLAB % 1024 == 0, "slab must be whole LDS-DMA pieces");
   typedef typename DT<T>::frag frag;
 
@@ -216,13 +312,13 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
   // slab (k, this column block, pass) -> LDS buffer `buf` by LDS-DMA: wave w moves pieces
   // w, w + NWAVES, ...; every wave issues exactly PPW instructions (a surplus piece, or a dead
   // phase, reads out of range -- zeros, no memory traffic -- into the dump)
-  auto stage_dma = [&](int k, int pass, int buf, bool live) {
+  auto stage_dma = [&](int k, int pass, int slot, bool live) {
     const unsigned slab_off = (unsigned)((((int64_t)k * nblk + blockIdx.y) * npass + pass) * SLAB);
 #pragma unroll
     for (int t = 0; t < PPW; ++t) {
       const int piece = wave + t * NWAVES;
       const bool ok = live && piece < PIECES;
-      unsigned char* dst = ok ? wl + buf * SLAB + piece * 1024 : dump;
+      unsigned char* dst = ok ? wl + slot * SLAB + piece * 1024 : dump;
       const unsigned soff = (ok && !(LIDAL_IMG_ABL & 2)) ? slab_off + (unsigned)piece * 1024u : OOB_OFF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)dst, 16,
                                                (unsigned)lane * 16u, soff, 0, 0);
@@ -281,50 +377,67 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Software pipeline (vector-memory operations retire in order, so the ORDER of issue inside a
-  // phase is what makes every wait cheap).  Phase p issues, in this order: slab(p+1) by DMA,
-  // index(p+2), A(p+1); then runs the MFMAs of phase p on A(p) / slab(p).
-  //   * A(p+1) needs index(p+1): issued in phase p-1 BEFORE A(p), so waiting for it leaves A(p)
-  //     and this phase's DMA in flight;
-  //   * the MFMAs need A(p): everything issued in this phase may stay in flight;
-  //   * the barrier that ends the phase needs slab(p+1): issued FIRST in the phase, so only the
-  //     index and A loads behind it (G + GA) stay in flight -- the explicit s_waitcnt below
-  //     (hipcc does not order a ds_read behind an LDS-DMA write on its own).
-  raw4 a0[G][MAXCC], a1[G][MAXCC];
-  unsigned long long pres0[G], pres1[G];
+  // Software pipeline of depth D over rings of R = D + 1 slots (weight slabs in LDS, A-fragment
+  // register sets, index registers).  Vector-memory operations retire IN ORDER, so a wait for the
+  // weight slab of the next phase also waits for every load issued before that slab's DMA: to keep
+  // D phases of gathers in flight the slab DMA runs D phases ahead as well, and the order of issue
+  // inside a phase is what keeps every wait cheap.  Phase p (slot s = p mod R) issues
+  //     index(p + 2D)  ->  slab(p + D) by DMA  ->  A(p + D)
+  // then runs the MFMAs of phase p on A(p) / slab(p), then waits for slab(p + 1) and joins the
+  // barrier.
+  //   * A(p+D) is addressed from index(p+D), issued D phases ago FIRST in its phase: waiting for it
+  //     leaves D phases of slabs and gathers in flight;
+  //   * the MFMAs need A(p), issued D phases ago: everything younger stays in flight (hipcc counts
+  //     this wait itself);
+  //   * slab(p+1) was issued D-1 phases ago: the explicit s_waitcnt leaves A(p+1) and the D-1 whole
+  //     phases of loads behind it in flight (hipcc does not order a ds_read behind an LDS-DMA
+  //     write on its own);
+  //   * the barrier that ends phase p frees slot s for slab(p + R), which phase p + 1 issues.
+  // A phase lasts about (memory latency) / D instead of one memory latency (measured on the depth-1
+  // form: the loop ran at one dependent HBM round trip per phase with nothing else on its critical
+  // path, profiles/README.md).
+  raw4 a[R][G][MAXCC];
+  unsigned long long pres[R][G];
+  int idx[R][G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) pres0[g] = pres1[g] = 0ull;
-  Walk w1 = walk_begin();       // the phase whose A / slab are issued next
-  Walk w2 = walk_begin();       // the phase whose indices are issued next (one further ahead)
-  int idx_a[G], idx_b[G];       // indices of two consecutive OFFSETS' phases, used alternately
-  constexpr int TAIL = (DENSE ? 0 : G) + GA;      // the dense form issues no index loads
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int g = 0; g < G; ++g) { pres[r][g] = 0ull; idx[r][g] = -1; }
+  Walk wa = walk_begin();       // the phase whose slab / A are issued next
+  Walk wi = walk_begin();       // the phase whose indices are issued next
+  constexpr int IL = DENSE ? 0 : G;                       // index loads per phase
+  // loads that may stay in flight while slab(p+1) is awaited (steady state and prologue alike)
+  constexpr int TAIL = GA + (D - 1) * (IL + PPW + GA);
   if (nphase > 0) {
-    stage_dma(w1.k, 0, 0, true);
-    load_idx(idx_a, w2.k);
-    walk_next(w2);
-    load_idx(idx_b, w2.k);
-    walk_next(w2);
-    load_a(a0, pres0, idx_a, 0, true);
-    walk_next(w1);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (GA & 15) | ((GA >> 4) << 14));     // slab 0 landed
+#pragma unroll
+    for (int q = 0; q < R; ++q) { load_idx(idx[q], wi.k); walk_next(wi); }        // index(0..D)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      stage_dma(wa.k, wa.pass, j, j < nphase);
+      load_a(a[j], pres[j], idx[j], wa.pass * KC, j < nphase);
+      walk_next(wa);
+      if (j < D - 1) { load_idx(idx[j], wi.k); walk_next(wi); }                   // index(D+1 .. 2D-1)
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));       // slab 0 landed
   }
   __syncthreads();
 
-  auto phase = [&](int p, raw4 (&a_cur)[G][MAXCC], unsigned long long (&pres_cur)[G],
-                   raw4 (&a_nxt)[G][MAXCC], unsigned long long (&pres_nxt)[G], int (&idx_nxt)[G],
-                   int (&idx_free)[G]) {
+  auto phase = [&](auto slot_c, int p) {
+    constexpr int s = decltype(slot_c)::value;
+    constexpr int sa = (s + D) % R;              // slot of phase p + D (== the slot of phase p - 1)
+    constexpr int si = (s + D - 1 + R) % R;      // slot of index(p + 2D)
     const int c0 = (p % npass) * KC;
     const int kc = min(KC, ci - c0);
-    const unsigned char* wbuf = wl + (p & 1) * SLAB;
-    const bool more = p + 1 < nphase;
-    stage_dma(w1.k, w1.pass, (p + 1) & 1, more);
-    load_idx(idx_free, w2.k);          // phase p+2 (idx_free held phase p's indices: dead now)
-    walk_next(w2);
-    load_a(a_nxt, pres_nxt, idx_nxt, w1.pass * KC, more);      // idx_nxt: issued a phase ago, before A(p)
-    walk_next(w1);
+    const unsigned char* wbuf = wl + s * SLAB;
+    const bool more = p + D < nphase;
+    load_idx(idx[si], wi.k);
+    walk_next(wi);
+    stage_dma(wa.k, wa.pass, sa, more);
+    load_a(a[sa], pres[sa], idx[sa], wa.pass * KC, more);
+    walk_next(wa);
     bool any_present = false;
 #pragma unroll
-    for (int g = 0; g < G; ++g) any_present |= pres_cur[g] != 0ull;
+    for (int g = 0; g < G; ++g) any_present |= pres[s][g] != 0ull;
     if (any_present && !(LIDAL_IMG_ABL & 4)) {
       const unsigned char* wbase = wbuf + (gsel * NB) * 256 + row16 * 16;
 #pragma unroll
@@ -334,7 +447,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
           for (int nb = 0; nb < NB; ++nb) {
             frag b = *reinterpret_cast<const frag*>(wbase + (cc * 4 * NB + nb) * 256);
 #pragma unroll
-            for (int g = 0; g < G; ++g) mma(acc[g][nb], __builtin_bit_cast(frag, a_cur[g][cc]), b);
+            for (int g = 0; g < G; ++g) mma(acc[g][nb], __builtin_bit_cast(frag, a[s][g][cc]), b);
           }
         }
       }
@@ -343,77 +456,235 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int cc = 0; cc < MAXCC; ++cc) asm volatile("" ::"v"(a_cur[g][cc]));
+        for (int cc = 0; cc < MAXCC; ++cc) asm volatile("" ::"v"(a[s][g][cc]));
     }
-    // slab(p+1) landed: only the loads issued behind its DMA may stay in flight
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));       // slab(p+1) landed
     __syncthreads();
   };
-  // with npass > 1 the index registers of an offset serve npass consecutive phases: the walk w2
-  // then advances per PHASE like w1, re-loading the same slice (cheap, and it keeps the two-set
-  // alternation independent of npass)
-  for (int p = 0; p < nphase; p += 2) {
-    phase(p, a0, pres0, a1, pres1, idx_b, idx_a);
-    if (p + 1 < nphase) phase(p + 1, a1, pres1, a0, pres0, idx_a, idx_b);
+  for (int p = 0; p < nphase; p += R) {
+    phase(std::integral_constant<int, 0>{}, p);
+    if (p + 1 < nphase) phase(std::integral_constant<int, 1>{}, p + 1);
+    if constexpr (R > 2) { if (p + 2 < nphase) phase(std::integral_constant<int, 2 % R>{}, p + 2); }
+    if constexpr (R > 3) { if (p + 3 < nphase) phase(std::integral_constant<int, 3 % R>{}, p + 3); }
   }
 
-  // ---- epilogue (as conv.hip): accumulators -> wave-private LDS tile -> whole rows, 16-byte stores
-  if (LIDAL_IMG_ABL & 16) return;
-  T* et = reinterpret_cast<T*>(wl) + wave * RW * ESTRIDE;
-  if (ep_scale != nullptr) {
+  store_tile<T, NB, G, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
+                               ep_res);
+}
+
+// ------------------------------------------------------------------------------------------
+// the lean kernel: same dataflow, a quarter of the scalar instructions
+// ------------------------------------------------------------------------------------------
+// PMC and ablations on the generic kernel above (profiles/README.md): its waves issue ~130 scalar
+// instructions and 22 s_waitcnt per phase around 18 MFMAs, and with 16-24 waves resident the ONE
+// scalar unit of a CU saturates -- a build with no gathers, no weight traffic and no MFMAs still
+// took 45 % of the full run time.  This form serves the common case (whole reduction slices: ci a
+// multiple of the slice; one 16-row group per wave; fewer than 2^24 input rows) with everything
+// that does not change inside a tile hoisted out of the phase loop:
+//   * no live/dead flags: the loop body always prefetches a phase that exists, the last phase is
+//     peeled; no "channels left in this slice" tests (whole slices);
+//   * a wave moves CONSECUTIVE 1-KiB pieces of a slab, so one M0 write and immediate offsets serve
+//     its whole share of the DMA; waves without a share skip the DMA and the wait for it;
+//   * gather addresses: one 24-bit multiply per row, the steps of a slice by immediate offsets;
+//   * one walk state (offset, slice) advanced once per phase.
+// NWAVES = 8 (128-row tiles) or 16 (256-row tiles: half the weight traffic per row at the same
+// number of resident waves, for layers whose slab is large against their gathers).
+// Tried on this kernel and dropped (each measured, profiles/README.md): gathers two phases ahead
+// (three register sets / weight slots: 98 vs 94 us on the roofline layer -- the gathers run at the
+// ~5.5 TB/s this access pattern gets from the Infinity Cache whatever the depth), persistent
+// workgroups with the pipeline running through tile boundaries (117 us: the write-out of a tile
+// then sits on every wave's critical path instead of overlapping another workgroup's phases).
+template <typename T, int NB, int ROW_BYTES, int NWAVES, bool DENSE>
+__global__ void __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? LIDAL_LEAN_MINWAVES : 4))
+conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int* __restrict__ nbr,
+                 const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
+                 T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
+                 const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int ep_relu,
+                 const T* __restrict__ ep_res, unsigned in_bytes, unsigned img_bytes,
+                 unsigned nbr_bytes) {
+  constexpr int BM = NWAVES * 16;
+  constexpr int BN = 16 * NB;
+  constexpr int CH = DT<T>::CH;
+  constexpr int KC = ROW_BYTES / (int)sizeof(T);
+  constexpr int MAXCC = KC / CH;                         // MFMA reduction steps (64 bytes) per slice
+  constexpr int SLAB = BN * ROW_BYTES;
+  constexpr int PIECES = SLAB / 1024;
+  constexpr int PPW = (PIECES + NWAVES - 1) / NWAVES;    // consecutive pieces per DMA wave
+  constexpr int DMA_WAVES = PIECES / PPW;                // waves that move a share
+  static_assert(PIECES % PPW == 0 && DMA_WAVES <= NWAVES, "a DMA wave moves a whole share");
+  static_assert(ROW_BYTES % 64 == 0 && SLAB % 1024 == 0, "slices are whole MFMA steps / DMA pieces");
+  static_assert(BM % 128 == 0, "tile masks are per 128 rows");
+  typedef typename DT<T>::frag frag;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;                              // [2][SLAB], re-used as the epilogue tile
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row16 = lane & 15;
+  const int gsel = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * 16;
+  const int n0 = blockIdx.y * BN;
+  const int npass = ci / KC;
+
+  unsigned tmask = 1u;
+  if constexpr (!DENSE) {
+    unsigned m = 0u;
+    const int64_t t0 = ((int64_t)blockIdx.x * BM) >> 7;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int col = n0 + nb * 16 + row16;
-      const float es = col < co ? ep_scale[col] : 1.f, eh = col < co ? ep_shift[col] : 0.f;
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[g][nb][r] * es + eh;
-          acc[g][nb][r] = ((ep_relu & 1) && v < 0.f) ? 0.f : v;
-        }
-    }
+    for (int h = 0; h < BM / 128; ++h)
+      if ((t0 + h) * 128 < n_out) m |= tmasks[t0 + h];
+    if (kflip) m = __brev(m) >> (32 - K);
+    tmask = __builtin_amdgcn_readfirstlane(m);
   }
+  const int nphase = __popc(tmask) * npass;
+
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wimg), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nbr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, (int)nbr_bytes, 0x00020000);
+
+  // ---- invariants of the tile
+  constexpr unsigned OOB_OFF = 0x80000000u;
+  const unsigned row_bytes = (unsigned)ci * (unsigned)sizeof(T);
+  const unsigned lane_off = (unsigned)gsel * 16u;               // this lane's 16 bytes of a 64-byte step
+  const unsigned idx_voff = (unsigned)((r0 + row16) * 4);       // this row inside one offset's table row
+  const bool row_in = r0 + row16 < n_out;
+  const unsigned k_stride = (unsigned)n_out * 4u;               // bytes of one offset's table row
+  const unsigned slab_k = (unsigned)gridDim.y * (unsigned)npass * (unsigned)SLAB;      // slabs of one offset
+  const unsigned slab_base = (unsigned)blockIdx.y * (unsigned)npass * (unsigned)SLAB
+                             + (unsigned)(wave * PPW) * 1024u;                          // + this wave's share
+  const unsigned dma_voff = (unsigned)lane * 16u;
+  const bool dma_wave = wave < DMA_WAVES;
+  unsigned char* const dma_dst = wl + (wave * PPW) * 1024;
+  const unsigned char* const wbase = wl + (gsel * NB) * 256 + row16 * 16;
+
+  // this lane's entry of the row permutation, requested now and used by the write-out at the end
+  // (unconditional: without a permutation, and past the last row, the range check returns zeros)
+  const __amdgpu_buffer_rsrc_t rs_perm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int*>(perm), 0, perm != nullptr ? (int)k_stride : 0, 0x00020000);
+  const int perm_v = __builtin_amdgcn_raw_buffer_load_b32(rs_perm, idx_voff, 0, 0);
+
+  // the walk over (active offset, slice): one scalar state, advanced once per phase
+  unsigned rem = tmask;
+  int wk = 0, wpass = npass - 1;
+  auto advance = [&]() {
+    if (++wpass == npass) {
+      wpass = 0;
+      wk = rem ? __builtin_ctz(rem) : 0;            // past the end: offset 0 (a harmless index load)
+      rem &= rem - 1u;
+    }
+  };
+  auto issue_idx = [&](int k) -> int {
+    if constexpr (DENSE) {
+      return (int)(r0 + row16);
+    } else {
+      const unsigned kk = (unsigned)(kflip ? (K - 1 - k) : k);
+      return __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, idx_voff, kk * k_stride, 0);
+    }
+  };
+  auto issue_dma = [&](int k, int pass, auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
+    if (dma_wave && !(LIDAL_IMG_ABL & 2)) {
+      const unsigned soff = (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base;
+      auto* dst = (__attribute__((address_space(3))) void*)(dma_dst + slot * SLAB);
+      static_assert(PPW <= 3, "immediate offsets of the DMA share");
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 0, 0);
+      if constexpr (PPW >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 1024, 0);
+      if constexpr (PPW >= 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 2048, 0);
+    }
+  };
+  // A fragments of (neighbour rows idx, slice pass); returns the ballot of rows that have a rule.
+  // Lanes of rows without one aim out of range: zeros, no memory access.
+  auto issue_a = [&](raw4 (&a)[MAXCC], int idx, int pass) __attribute__((always_inline)) -> unsigned long long {
+    const bool has = idx >= 0 && row_in;
+    if (LIDAL_IMG_ABL & 1) idx &= 2047;
+    unsigned off = __umul24((unsigned)idx, row_bytes) + lane_off;
+    off = (has && !(LIDAL_IMG_ABL & 8)) ? off : OOB_OFF;
+    const unsigned soff = (unsigned)pass * (unsigned)ROW_BYTES;
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+    for (int cc = 0; cc < MAXCC; ++cc)
+      a[cc] = __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + (unsigned)(cc * 64), soff, 0));
+    return __ballot(has);
+  };
+
+  f32x4 acc[1][NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+  for (int nb = 0; nb < NB; ++nb) acc[0][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const raw4 (&a)[MAXCC], unsigned long long have, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+    if (have != 0ull && !(LIDAL_IMG_ABL & 4)) {       // a wave none of whose 16 rows has a rule skips
+      constexpr int BB = LIDAL_LEAN_BBATCH(NB);       // fragment reads issued as one batch
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        et[(g * 16 + gsel * 4 + r) * ESTRIDE + nb * 16 + row16] = DT<T>::from_f32(acc[g][nb][r]);
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  constexpr int RSEGS = BN / VEC;
-  for (int i = lane; i < RW * RSEGS; i += 64) {
-    const int r = i / RSEGS, cseg = (i - r * RSEGS) * VEC;
-    if (r0 + r >= n_out) continue;
-    const int64_t row = perm ? (int64_t)perm[r0 + r] : r0 + r;
-    T* dst = out + row * co + n0 + cseg;
-    const T* srcp = et + r * ESTRIDE + cseg;
-    if (n0 + cseg + VEC <= co) {
-      frag v = *reinterpret_cast<const frag*>(srcp);
-      if (ep_res != nullptr) {
-        const frag rr = *reinterpret_cast<const frag*>(ep_res + row * co + n0 + cseg);
+      for (int cc = 0; cc < MAXCC; ++cc) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float f = DT<T>::to_f32(v[e]) + DT<T>::to_f32(rr[e]);
-          if ((ep_relu & 2) && f < 0.f) f = 0.f;
-          v[e] = DT<T>::from_f32(f);
+        for (int nb0 = 0; nb0 < NB; nb0 += BB) {
+          frag b[BB];
+#pragma unroll
+          for (int j = 0; j < BB; ++j)
+            b[j] = *reinterpret_cast<const frag*>(wbase + slot * SLAB + (cc * 4 * NB + nb0 + j) * 256);
+#pragma unroll
+          for (int j = 0; j < BB; ++j) mma(acc[0][nb0 + j], __builtin_bit_cast(frag, a[cc]), b[j]);
         }
       }
-      *reinterpret_cast<frag*>(dst) = v;
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        if (n0 + cseg + e < co) {
-          float v = DT<T>::to_f32(srcp[e]);
-          if (ep_res != nullptr) {
-            v += DT<T>::to_f32(ep_res[row * co + n0 + cseg + e]);
-            if ((ep_relu & 2) && v < 0.f) v = 0.f;
-          }
-          dst[e] = DT<T>::from_f32(v);
-        }
     }
+    if (LIDAL_IMG_ABL & 4) {
+#pragma unroll
+      for (int cc = 0; cc < MAXCC; ++cc) asm volatile("" ::"v"(a[cc]));
+    }
+  };
+  // the next slab has landed: of this wave's loads only the MAXCC gathers issued behind its DMA may
+  // still be in flight (waves without a DMA share have nothing to wait for)
+  auto slab_wait = [&]() {
+    if (dma_wave) __builtin_amdgcn_s_waitcnt(0x0F70 | (MAXCC & 15) | ((MAXCC >> 4) << 14));
+    __syncthreads();
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  // Pipeline: phase p issues index(p+2), slab(p+1) by DMA, A(p+1) -- in this order: vector-memory
+  // operations retire in order, so the gather's wait for index(p+1) (issued a phase ago, FIRST)
+  // leaves last phase's slab and gathers in flight, and slab_wait leaves this phase's gathers.
+  raw4 a0[MAXCC], a1[MAXCC];
+  unsigned long long h0 = 0ull, h1 = 0ull;
+  if (nphase > 0) {
+    advance();
+    const int k0 = wk, p0 = wpass;
+    int i0 = issue_idx(k0);
+    advance();
+    int i1 = issue_idx(wk);
+    int kn = wk, pn = wpass;                        // (offset, slice) of the phase issued next
+    issue_dma(k0, p0, S0{});
+    h0 = issue_a(a0, i0, p0);
+    slab_wait();
+    int p = 0;
+    while (true) {
+      if (p + 1 >= nphase) { compute(a0, h0, S0{}); break; }
+      advance();
+      i0 = issue_idx(wk);
+      issue_dma(kn, pn, S1{});
+      h1 = issue_a(a1, i1, pn);
+      kn = wk; pn = wpass;
+      compute(a0, h0, S0{});
+      slab_wait();
+      ++p;
+      if (p + 1 >= nphase) { compute(a1, h1, S1{}); break; }
+      advance();
+      i1 = issue_idx(wk);
+      issue_dma(kn, pn, S0{});
+      h0 = issue_a(a0, i0, pn);
+      kn = wk; pn = wpass;
+      compute(a1, h1, S1{});
+      slab_wait();
+      ++p;
+    }
+    __syncthreads();                                // every wave is done with the last slab
   }
+  store_tile<T, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
+                               ep_res, true, perm_v);
 }
 
 struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; };
@@ -424,6 +695,9 @@ struct Epi { const float* scale; const float* shift; int relu; const void* res; 
 #ifndef LIDAL_IMG_NWAVES
 #define LIDAL_IMG_NWAVES 8
 #endif
+#ifndef LIDAL_IMG_DEPTH
+#define LIDAL_IMG_DEPTH 1
+#endif
 
 template <typename T, int NB, int ROW_BYTES>
 int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm, const unsigned* tmasks,
@@ -432,11 +706,38 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
   constexpr int NTHREADS = 64 * NWAVES, BM = NWAVES * G * 16, BN = 16 * NB;
   constexpr int SLAB = BN * ROW_BYTES;
   constexpr int EPI = NWAVES * G * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
-  constexpr int WREGION = (2 * SLAB > EPI) ? 2 * SLAB : EPI;
+  constexpr int D = LIDAL_IMG_DEPTH;
+  constexpr int WREGION = ((D + 1) * SLAB > EPI) ? (D + 1) * SLAB : EPI;
   static_assert(BM % 128 == 0, "tile masks are per 128 rows");
+#ifndef LIDAL_IMG_NOLEAN
+  if constexpr (G == 1 && NWAVES == 8) {
+    if (ci % (ROW_BYTES / (int)sizeof(T)) == 0 && ep.in_bytes / ((unsigned)ci * sizeof(T)) < (1u << 24)) {
+      // 256-row tiles (16 waves) where the weight slab outweighs the gathers of a 128-row tile
+      constexpr int LW = LIDAL_LEAN_WAVES(NB, ROW_BYTES);
+      constexpr int LBM = LW * 16;
+      constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
+      constexpr int LEAN_LDS = (2 * SLAB > LEPI) ? 2 * SLAB : LEPI;
+      auto lk = nbr ? conv_lean_kernel<T, NB, ROW_BYTES, LW, false>
+                    : conv_lean_kernel<T, NB, ROW_BYTES, LW, true>;
+      static size_t lean_attr[2][MAX_DEVICES] = {};
+      const int ldev = current_device();
+      if (lean_attr[nbr ? 0 : 1][ldev] < (size_t)LEAN_LDS) {
+        LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_LDS));
+        lean_attr[nbr ? 0 : 1][ldev] = LEAN_LDS;
+      }
+      dim3 lgrid((unsigned)cdiv(n_out, LBM), (unsigned)cdiv(co, BN));
+      lk<<<lgrid, 64 * LW, LEAN_LDS, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
+                                          ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
+                                          ep.in_bytes, ep.img_bytes, ep.nbr_bytes);
+      LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(lean)");
+      return 0;
+    }
+  }
+#endif
   const size_t lds = WREGION + 1024;
-  auto kern = nbr ? conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, false>
-                  : conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, true>;
+  auto kern = nbr ? conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, false, D>
+                  : conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, true, D>;
   static size_t attr_set[2][MAX_DEVICES] = {};
   const int dev = current_device();
   if (attr_set[nbr ? 0 : 1][dev] < lds) {
@@ -459,6 +760,7 @@ int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, con
 #define IMG_CASE(NBV, RB) \
   if (t.nb == NBV && t.row_bytes == RB) \
     return launch_img<T, NBV, RB>(in, wimg, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
+  IMG_CASE(2, 64) IMG_CASE(4, 64) IMG_CASE(6, 64) IMG_CASE(8, 64)
   IMG_CASE(2, 128) IMG_CASE(4, 128) IMG_CASE(6, 128) IMG_CASE(8, 128)
   IMG_CASE(2, 192) IMG_CASE(4, 192) IMG_CASE(6, 192) IMG_CASE(8, 192)
 #undef IMG_CASE

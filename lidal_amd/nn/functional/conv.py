@@ -193,28 +193,27 @@ def prefetch_kernel_maps(x, plan, transposed=True):
     return x
 
 
-def _pack_weight(weight, dtype, with_cast=False):
-    """[K, ci, co] (any float dtype) -> [K, co, ci] in `dtype` (reduction dim contiguous).  With
-    `with_cast` also returns the weight in `dtype` in its own layout (the data-gradient operand),
-    written by the same kernel; (packed, None) otherwise."""
+def _weight_image(weight, dtype, n_out, role):
+    """LDS image (csrc/conv_img.hip) of a [K, ci, co] weight in `dtype` for a convolution that
+    produces n_out rows.  role 0: forward operand (reduction over ci, columns co); role 1: the
+    data-gradient operand of the same parameter (reduction over co, columns ci)."""
     k, ci, co = weight.shape
     w = weight.detach().contiguous()
-    wt = torch.empty((k, co, ci), dtype=dtype, device=w.device)
-    wc = None
-    if with_cast:
-        wc = w if w.dtype == dtype else torch.empty((k, ci, co), dtype=dtype, device=w.device)
-    B.check(B.lib().lidal_conv_weight_pack(B.ptr(w), B.dtype_code(w.dtype), B.ptr(wt),
-                                           B.ptr(wc) if wc is not None and wc is not w else None,
-                                           B.dtype_code(dtype), k, ci, co, B.stream()),
-            'conv_weight_pack')
-    return wt, wc
+    n_red, n_col = (ci, co) if role == 0 else (co, ci)
+    code = B.dtype_code(dtype)
+    nbytes = B.lib().lidal_conv_weight_image_bytes(k, n_red, n_col, code, n_out)
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    B.check(B.lib().lidal_conv_weight_image(B.ptr(w), B.dtype_code(w.dtype), role, B.ptr(img), code,
+                                            k, n_red, n_col, n_out, B.stream()), 'conv_weight_image')
+    return img
 
 
-def _apply(feats, wk, order, kflip, epilogue=None):
-    """out[j] = sum_k feats[nbr[kk][j]] @ wk[k]^T with wk [K, co, ci]; `order` = RowOrder(nbr).
+def _apply(feats, img, k, co, order, kflip, epilogue=None):
+    """out[j] = sum_k feats[nbr[kk][j]] @ W_k with the weights as the LDS image `img` (built for
+    (ci = feats.shape[1], co, k, feats.dtype, n_out = order.n_rows)); `order` = RowOrder(nbr).
     epilogue = (scale f32 [co], shift f32 [co], relu[, residual [n_out, co]]): in-kernel
     out = act(out * scale + shift) + residual; relu 1 = ReLU before the sum, 2 = after it."""
-    k, co, ci = wk.shape
+    ci = feats.shape[1]
     n_out = order.n_rows
     out = torch.empty((n_out, co), dtype=feats.dtype, device=feats.device)
     scale, shift, relu = epilogue[:3] if epilogue is not None else (None, None, 0)
@@ -222,11 +221,11 @@ def _apply(feats, wk, order, kflip, epilogue=None):
     if residual is not None:
         residual = residual.contiguous().to(feats.dtype)
         assert residual.shape == (n_out, co)
-    B.check(B.lib().lidal_conv_apply(B.ptr(feats), B.ptr(wk), B.ptr(order.table), B.ptr(order.perm),
-                                     B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci, co, k,
-                                     int(kflip),
-                                     B.dtype_code(feats.dtype), B.ptr(scale), B.ptr(shift),
-                                     int(relu), B.ptr(residual), B.stream()), 'conv_apply')
+    B.check(B.lib().lidal_conv_apply_image(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
+                                           B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
+                                           co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(scale),
+                                           B.ptr(shift), int(relu), B.ptr(residual), B.stream()),
+            'conv_apply')
     return out
 
 
@@ -272,7 +271,7 @@ def _pad_channels(ci, dtype):
     return (-ci) % vec
 
 
-def _forward(feats, weight, kmap, transposed, with_cast, epilogue=None):
+def _forward(feats, weight, kmap, transposed, epilogue=None):
     B.require_gpu(feats, weight)
     cdtype = B.compute_dtype(feats)
     x = feats.contiguous().to(cdtype)
@@ -281,22 +280,22 @@ def _forward(feats, weight, kmap, transposed, with_cast, epilogue=None):
         x = torch.nn.functional.pad(x, (0, pad))
         weight = torch.nn.functional.pad(weight.detach(), (0, 0, 0, pad))
     order = kmap.order_in if transposed else kmap.order_out
-    wt, wc = _pack_weight(weight, cdtype, with_cast)
-    return x, wc, _apply(x, wt, order, 0, epilogue)
+    k, _, co = weight.shape
+    img = _weight_image(weight, cdtype, order.n_rows, 0)
+    return x, _apply(x, img, k, co, order, 0, epilogue)
 
 
 def _conv(feats, weight, kmap, transposed, epilogue=None):
     if B.wants_grad(feats, weight):
         assert epilogue is None, 'the fused BatchNorm epilogue is inference-only'
         return ConvolutionFunction.apply(feats, weight, kmap, transposed)
-    return _forward(feats, weight, kmap, transposed, False, epilogue)[2]   # no autograd node
+    return _forward(feats, weight, kmap, transposed, epilogue)[1]   # no autograd node
 
 
 class ConvolutionFunction(Function):
     @staticmethod
     def forward(ctx, feats, weight, kmap, transposed):
-        x, wc, out = _forward(feats, weight, kmap, transposed, ctx.needs_input_grad[0])
-        ctx.wc = wc                      # weight in the compute dtype, for the data gradient
+        x, out = _forward(feats, weight, kmap, transposed)
         ctx.kmap = kmap
         ctx.transposed = transposed
         ctx.save_for_backward(x, weight)
@@ -310,17 +309,18 @@ class ConvolutionFunction(Function):
         n_in, n_out = kmap.sizes
         grad_in = grad_w = None
         if ctx.needs_input_grad[0]:
-            # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci, reduction over co, and
-            # weight [K, ci, co] already has the reduction dim contiguous.
-            wk = ctx.wc
+            # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci, reduction over co
+            k, ci_w, co = weight.shape
+            w = weight
+            if x.shape[1] != ci_w:                 # the input was channel-padded (bf16 stem)
+                w = torch.nn.functional.pad(weight.detach(), (0, 0, 0, x.shape[1] - ci_w))
             if not transposed:
-                if kmap.symmetric:
-                    grad_in = _apply(g, wk, kmap.order_out, 1)
-                else:
-                    grad_in = _apply(g, wk, kmap.order_in, 0)
+                order, kflip = (kmap.order_out, 1) if kmap.symmetric else (kmap.order_in, 0)
             else:
-                grad_in = _apply(g, wk, kmap.order_out, 0)
-            grad_in = grad_in[:, :weight.shape[1]]          # drop the padding channels, if any
+                order, kflip = kmap.order_out, 0
+            img = _weight_image(w, x.dtype, order.n_rows, 1)
+            grad_in = _apply(g, img, k, w.shape[1], order, kflip)
+            grad_in = grad_in[:, :ci_w]                     # drop the padding channels, if any
         if ctx.needs_input_grad[1]:
             k, ci_w, co = weight.shape
             ci = x.shape[1]                          # >= ci_w when the input was channel-padded

@@ -60,22 +60,26 @@ def _gemm_ok(x, ci, co):
     return x.dtype == torch.bfloat16 and ci % 8 == 0 and co % 8 == 0
 
 
-def _rows_gemm(x, wk, shift=None, scale=None, relu=False, residual=None):
-    """x [n, ci] @ wk[0]^T with wk [1, co, ci] (reduction dim contiguous), + shift f32 [co]: the
-    sparse-convolution kernel with the identity rule list (a NULL table).  A library GEMM runs these tall-skinny
-    products (4e5 x 128 @ 128 x 96) at ~1.7 TB/s of operand traffic; this kernel streams the rows
-    once and keeps the small weight in LDS."""
-    n, ci = x.shape
-    co = wk.shape[1]
-    out = torch.empty((n, co), dtype=x.dtype, device=x.device)
+def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None):
+    """x [n, n_red] times the [Cin, Cout] operand `w` (compute dtype): role 0 = x @ w (reduction over
+    Cin), role 1 = x @ w^T (reduction over Cout: the data gradient), + shift f32: the sparse
+    convolution kernel with the identity rule list (a NULL table) and the weight as an LDS image.
+    A library GEMM runs these tall-skinny products (4e5 x 128 @ 128 x 96) at ~1.7 TB/s of operand
+    traffic; this kernel streams the rows once and keeps the small weight in LDS."""
+    from .conv import _weight_image
+    n, n_red = x.shape
+    n_col = w.shape[1] if role == 0 else w.shape[0]
+    assert n_red == (w.shape[0] if role == 0 else w.shape[1])
+    img = _weight_image(w.contiguous().unsqueeze(0), x.dtype, n, role)
+    out = torch.empty((n, n_col), dtype=x.dtype, device=x.device)
     if residual is not None:
         residual = residual.contiguous()
         assert residual.shape == out.shape and residual.dtype == out.dtype
     if shift is not None and scale is None:
-        scale = torch.ones(co, dtype=torch.float32, device=x.device)
-    B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wk), None, None, None, B.ptr(out),
-                                     n, n, ci, co, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
-                                     B.ptr(shift), int(relu), B.ptr(residual), B.stream()),
+        scale = torch.ones(n_col, dtype=torch.float32, device=x.device)
+    B.check(B.lib().lidal_conv_apply_image(B.ptr(x), B.ptr(img), None, None, None, B.ptr(out),
+                                           n, n, n_red, n_col, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
+                                           B.ptr(shift), int(relu), B.ptr(residual), B.stream()),
             'conv_apply(dense)')
     return out
 
@@ -117,7 +121,7 @@ def _forward(x, w, bias, linear, epilogue=None):
         if fused_res is not None:
             fused_res = fused_res.to(cdtype)
         late = residual is not None and fused_res is None       # sum (and its ReLU) outside the kernel
-        y = _rows_gemm(xc, wc.t().contiguous().unsqueeze(0), shift, scale,
+        y = _rows_gemm(xc, wc, 0, shift, scale,
                        int(relu) & 1 if late else int(relu), fused_res)
         y = y[:, :co] if pad else y
         if late:
@@ -167,7 +171,7 @@ class RowsMatmul(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if _gemm_ok(g, g.shape[1], xc.shape[1]):
-                gx = _rows_gemm(g, ctx.wc.contiguous().unsqueeze(0))     # [1, ci, co]: reduction over co
+                gx = _rows_gemm(g, ctx.wc, 1)             # reduction over co
             else:
                 gx = g @ ctx.wc.t()
         if ctx.needs_input_grad[1]:

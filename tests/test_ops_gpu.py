@@ -650,3 +650,60 @@ def test_dense_epilogue_affine_relu_residual():
             y16 = rows_linear(x, w, b, epilogue=(scale, shift, True, res.bfloat16()))
     assert y32.dtype == torch.float32 and _relerr(y32.cpu(), ref.cpu()) < 1e-5
     assert y16.dtype == torch.bfloat16 and _relerr(y16.float().cpu(), ref.cpu()) < 2e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_apply_image_is_bitwise_conv_apply(dtype):
+    """The two generations of the conv kernel through the C-ABI: lidal_conv_apply (weights [k][co][ci]
+    staged through registers, conv.hip) and lidal_conv_apply_image (weights as LDS images moved by
+    LDS-DMA, conv_img.hip) run the same offset and reduction order, so every output bit agrees --
+    forward and flipped (data-gradient) walk, epilogue + residual, channel counts off the tile sizes
+    (ragged last column block, partial reduction slice), the dense identity form, n_out not a multiple
+    of the tile, and a one-row input."""
+    from lidal_amd import backend as B
+    F = _F()
+    L = B.lib()
+    code = B.dtype_code(dtype)
+    g = torch.Generator().manual_seed(17)
+
+    def both(x, w_kio, order, k, kflip, ep=None):
+        n_in, ci = x.shape
+        co = w_kio.shape[2]
+        n_out = order.n_rows if order is not None else n_in
+        wt = w_kio.permute(0, 2, 1).contiguous().to(dtype)
+        nb = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out)
+        img = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        B.check(L.lidal_conv_weight_image(B.ptr(w_kio), B.dtype_code(w_kio.dtype), 0, B.ptr(img), code, k, ci,
+                                          co, n_out, B.stream()), 'image')
+        outs = []
+        for fn, wop in ((L.lidal_conv_apply, wt), (L.lidal_conv_apply_image, img)):
+            out = torch.full((n_out, co), float('nan'), dtype=dtype, device=DEV)
+            sc, sh, relu, res = ep if ep else (None, None, 0, None)
+            tab, prm, tmk = (order.table, order.perm, order.tile_masks) if order is not None else (None,) * 3
+            B.check(fn(B.ptr(x), B.ptr(wop), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n_in, n_out, ci,
+                       co, k, kflip, code, B.ptr(sc), B.ptr(sh), relu, B.ptr(res), B.stream()), 'conv')
+            outs.append(out)
+        assert not torch.isnan(outs[1].float()).any()
+        assert torch.equal(outs[0], outs[1])
+        return outs[1]
+
+    coords = _surface_coords(61, 2, seed=5).to(DEV)                  # 7442 rows: ragged last tile
+    kmap, _ = F.build_kernel_map(coords, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    n = coords.shape[0]
+    vec = 4 if dtype == torch.float32 else 8
+    for ci, co in ((32, 32), (96, 96), (8 * vec // 4, 64), (128, 96), (256, 128), (192, 20), (40, 200)):
+        x = torch.randn(n, ci, generator=g).to(dtype).to(DEV)
+        w = (torch.randn(27, ci, co, generator=g) * 0.1).to(DEV)
+        for kflip in (0, 1):
+            both(x, w, kmap.order_out, 27, kflip)
+    x = torch.randn(n, 64, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(27, 64, 96, generator=g) * 0.1).to(DEV)
+    ep = ((torch.rand(96, generator=g) + 0.5).to(DEV), torch.randn(96, generator=g).to(DEV), 3,
+          torch.randn(n, 96, generator=g).to(dtype).to(DEV))
+    both(x, w, kmap.order_out, 27, 0, ep)
+    km2, _ = F.build_kernel_map(coords, (1, 1, 1), (2, 2, 2), (2, 2, 2))      # strided + its transpose
+    both(x, (torch.randn(8, 64, 32, generator=g) * 0.1).to(DEV), km2.order_out, 8, 0)
+    xc = torch.randn(km2.sizes[1], 32, generator=g).to(dtype).to(DEV)
+    both(xc, (torch.randn(8, 32, 64, generator=g) * 0.1).to(DEV), km2.order_in, 8, 0)
+    both(x, (torch.randn(1, 64, 20, generator=g) * 0.1).to(DEV), None, 1, 0)                  # dense form
+    both(x[:1].contiguous(), (torch.randn(1, 64, 96, generator=g) * 0.1).to(DEV), None, 1, 0)  # one row

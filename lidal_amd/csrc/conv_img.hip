@@ -61,6 +61,9 @@ static inline int current_device() {
   return d;
 }
 
+#ifndef LIDAL_NB4_LIMIT
+#define LIDAL_NB4_LIMIT 384
+#endif
 // ---- tiling policy, shared by the image packer and the launcher ------------------------------
 struct Tiling { int nb; int row_bytes; };       // 16-column blocks per workgroup, staged bytes per pass
 
@@ -72,7 +75,7 @@ __host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int
   t.row_bytes = (row_bytes % 192 == 0 && row_bytes % 128 != 0) ? 192
                 : (row_bytes % 128 != 0 && row_bytes % 64 == 0) ? 64 : 128;
   if (co <= 32) t.nb = 2;
-  else if (co <= 64 || (co % 64 == 0 && ((n_out + 127) / 128) * ((co + 127) / 128) <= 384)) t.nb = 4;
+  else if (co <= 64 || (co % 64 == 0 && ((n_out + 127) / 128) * ((co + 127) / 128) <= LIDAL_NB4_LIMIT)) t.nb = 4;
   else if (co % 128 != 0 && (co % 96 == 0 || co < 128)) t.nb = 6;
   else t.nb = 8;
   return t;

@@ -378,8 +378,11 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
 // (per-channel parameters, and an LDS tree in the reducing kernels), so fewer and larger slabs win
 // as long as every CU has one; and an equal share per CU matters: with 512-row slabs the 396k-row
 // level ran as 775 workgroups, 3.03 per CU (measured sweep: profiles/README.md).
+#ifndef LIDAL_BN_WGS
+#define LIDAL_BN_WGS 256
+#endif
 static inline int slab_rows(int64_t n) {
-  int64_t rpw = (n + 255) / 256;
+  int64_t rpw = (n + LIDAL_BN_WGS - 1) / LIDAL_BN_WGS;
   if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
   return (int)rpw;
 }

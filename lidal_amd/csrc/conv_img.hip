@@ -496,7 +496,10 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
 // (three register sets / weight slots: 98 vs 94 us on the roofline layer -- the gathers run at the
 // ~5.5 TB/s this access pattern gets from the Infinity Cache whatever the depth), persistent
 // workgroups with the pipeline running through tile boundaries (117 us: the write-out of a tile
-// then sits on every wave's critical path instead of overlapping another workgroup's phases).
+// then sits on every wave's critical path instead of overlapping another workgroup's phases),
+// gathers with the four lanes of a quad on the 64 contiguous bytes of a row step and a ds_bpermute
+// into the MFMA lane layout (the addresser merges a quad into one request: the loads alone got
+// 8-18 % cheaper in a timing probe, but the twelve bpermutes per phase cost more: 99 vs 94 us).
 template <typename T, int NB, int ROW_BYTES, int NWAVES, bool DENSE>
 __global__ void __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? LIDAL_LEAN_MINWAVES : 4))
 conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int* __restrict__ nbr,

@@ -194,7 +194,7 @@ def roofline_conv(args, coords, dev, reps=20):
     def launch():
         B.check(B.lib().lidal_conv_apply_image(B.ptr(x), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
                                                B.ptr(order.tile_masks), B.ptr(out), n, n, ci, co, 27, 0,
-                                               B.dtype_code(dtype), None, None, 0, None, B.stream()), 'conv')
+                                               B.dtype_code(dtype), None, None, 0, None, None, B.stream()), 'conv')
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -237,7 +237,8 @@ def roofline_conv(args, coords, dev, reps=20):
 FAMILY_OF = {
     'lidal_conv_apply': 'conv_apply', 'lidal_conv_apply_image': 'conv_apply', 'lidal_conv_wgrad': 'conv_wgrad',
     'lidal_conv_weight_pack': 'weight_pack', 'lidal_conv_weight_image': 'weight_pack',
-    'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
+    'lidal_conv_weight_image_pair': 'weight_pack',
+    'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
@@ -326,8 +327,11 @@ def family_table(step, coords, dtype_name, step_ms):
             by = (4 + b_el) * a[5] * a[6] * a[7]
         elif name == 'lidal_conv_weight_image':
             by = (4 + b_el) * a[5] * a[6] * a[7]
-        elif name in ('lidal_bn_train_fwd', 'lidal_bn_eval_fwd'):
-            by = (3 if name == 'lidal_bn_train_fwd' else 2) * a[2] * a[3] * (2 if a[1] == 1 else 4)
+        elif name == 'lidal_conv_weight_image_pair':
+            by = (4 + 2 * b_el) * a[7] * a[8] * a[9]
+        elif name in ('lidal_bn_train_fwd', 'lidal_bn_eval_fwd', 'lidal_bn_train_fwd_tiles'):
+            # the statistics pass that `_tiles` no longer makes stays in the algorithmic count (3 N C b)
+            by = (2 if name == 'lidal_bn_eval_fwd' else 3) * a[2] * a[3] * (2 if a[1] == 1 else 4)
         elif name == 'lidal_bn_bwd':
             by = 5 * a[3] * a[4] * (2 if a[2] == 1 else 4)
         elif name == 'lidal_colsum':

@@ -192,15 +192,24 @@ int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const i
  *                                  SAME (ci = n_red, co = n_col, k, dtype, n_out); tile_masks are
  *                                  required with a table (nbr == NULL: identity rule list, k = 1);
  *                                  ci must be a multiple of 4 (f32) / 8 (bf16).
- * Results are bitwise those of lidal_conv_apply (same offset and reduction order). */
+ * Results are bitwise those of lidal_conv_apply (same offset and reduction order).
+ * tile_stats (NULL or f32 [ceil(n_out / 128)][co][3]): per 128-row tile of the kernel's row order and
+ * output column, (count, mean, M2) of the values as stored -- the batch statistics of a train-mode
+ * BatchNorm that follows (network/utils.py:115), taken in the epilogue instead of by a pass over the
+ * stored matrix; merged by lidal_bn_train_fwd_tiles. */
 int64_t lidal_conv_weight_image_bytes(int k, int ci, int co, int dtype, int64_t n_out);
 int lidal_conv_weight_image(const void* w, int w_dtype, int role, void* img, int dtype, int k,
                             int n_red, int n_col, int64_t n_out, void* stream);
+/* both images of one [k][ci][co] parameter in ONE launch: img_fwd (role 0, for a convolution
+ * producing n_out_fwd rows) and img_bwd (role 1, for its data gradient producing n_out_bwd rows) */
+int lidal_conv_weight_image_pair(const void* w, int w_dtype, void* img_fwd, int64_t n_out_fwd,
+                                 void* img_bwd, int64_t n_out_bwd, int dtype, int k, int ci, int co,
+                                 void* stream);
 int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr, const int32_t* perm,
                            const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out,
                            int ci, int co, int k, int kflip, int dtype, const float* ep_scale,
                            const float* ep_shift, int ep_relu, const void* ep_residual,
-                           void* stream);
+                           float* tile_stats, void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
  * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  Split-K: offset k with nk rules is cut into
@@ -228,6 +237,13 @@ int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* 
                        float* running_var, int64_t* num_batches_tracked, int relu, void* y,
                        float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
                        void* stream);
+/* lidal_bn_train_fwd with the statistics pass replaced by the per-tile (count, mean, M2) triples
+ * lidal_conv_apply_image wrote (tile_stats f32 [n_tiles][c][3]). */
+int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int c, const float* gamma,
+                             const float* beta, float eps, float momentum, float* running_mean,
+                             float* running_var, int64_t* num_batches_tracked, int relu, void* y,
+                             float* save_mean, float* save_invstd, const float* tile_stats,
+                             int64_t n_tiles, void* stream);
 int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                       const float* beta, const float* running_mean, const float* running_var,
                       float eps, int relu, void* y, void* stream);

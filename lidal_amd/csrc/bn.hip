@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(NT) bn_stats_partial_kernel(const T* __restric
 // subset in order, then a fixed LDS tree merges the 32 lanes.  Writes mean / invstd and updates the
 // running statistics exactly as torch.nn.BatchNorm1d (biased var to normalise, unbiased for
 // running_var).
-__global__ void __launch_bounds__(NT) bn_stats_final_kernel(const double* __restrict__ part,
+template <typename P>
+__global__ void __launch_bounds__(NT) bn_stats_final_kernel(const P* __restrict__ part,
                                                             int nparts, int c, float eps,
                                                             float momentum,
                                                             float* __restrict__ mean,
@@ -154,9 +155,9 @@ __global__ void __launch_bounds__(NT) bn_stats_final_kernel(const double* __rest
   double na = 0., ma = 0., qa = 0.;
   if (ch < c)
     for (int p = pl; p < nparts; p += 32) {
-      const double* s = part + ((int64_t)p * c + ch) * 3;
-      if (na == 0.) { na = s[0]; ma = s[1]; qa = s[2]; }
-      else chan_merge(na, ma, qa, s[0], s[1], s[2]);
+      const P* s = part + ((int64_t)p * c + ch) * 3;
+      if (na == 0.) { na = (double)s[0]; ma = (double)s[1]; qa = (double)s[2]; }
+      else chan_merge(na, ma, qa, (double)s[0], (double)s[1], (double)s[2]);
     }
   sn[tid] = na; sm[tid] = ma; sq[tid] = qa;
   for (int s = 16; s >= 1; s >>= 1) {
@@ -399,7 +400,7 @@ int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const floa
   bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>((const T*)x, n, c, part,
                                                                            rows_per_wg(n));
   LIDAL_CHECK_LAUNCH("bn_stats_partial");
-  bn_stats_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
+  bn_stats_final_kernel<double><<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
                                                              invstd, rm, rv, nbt);
   LIDAL_CHECK_LAUNCH("bn_stats_final");
   bn_apply_kernel<T, false><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma,
@@ -474,6 +475,73 @@ extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, co
   return bn_train_fwd<__bf16>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var,
                               (long long*)num_batches_tracked, relu, y, save_mean, save_invstd,
                               (double*)ws, s);
+}
+
+// Merge of the per-tile (count, mean, M2) f32 triples a convolution left (thousands of tiles): one
+// workgroup per channel, plain f64 sums N, S1 = sum n m, S2 = sum (M2 + n m^2) -- in f64 the
+// cancellation of S2/N - mean^2 is harmless, and no per-element division (Chan's formula) is needed.
+__global__ void __launch_bounds__(NT) bn_tiles_final_kernel(const float* __restrict__ part, int nparts,
+                                                            int c, float eps, float momentum,
+                                                            float* __restrict__ mean,
+                                                            float* __restrict__ invstd,
+                                                            float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var,
+                                                            long long* __restrict__ num_batches) {
+  __shared__ double sn[NT], s1[NT], s2[NT];
+  const int tid = threadIdx.x, ch = blockIdx.x;
+  if (num_batches != nullptr && ch == 0 && tid == 0) *num_batches += 1;
+  double n = 0., a = 0., b = 0.;
+  for (int p = tid; p < nparts; p += NT) {
+    const float* s = part + ((int64_t)p * c + ch) * 3;
+    const double pn = (double)s[0], pm = (double)s[1];
+    n += pn; a += pn * pm; b += (double)s[2] + pn * pm * pm;
+  }
+  sn[tid] = n; s1[tid] = a; s2[tid] = b;
+  for (int st = NT / 2; st >= 1; st >>= 1) {
+    __syncthreads();
+    if (tid < st) { sn[tid] += sn[tid + st]; s1[tid] += s1[tid + st]; s2[tid] += s2[tid + st]; }
+  }
+  if (tid == 0) {
+    n = sn[0];
+    const double m = n > 0. ? s1[0] / n : 0.;
+    double m2 = s2[0] - n * m * m;
+    if (m2 < 0.) m2 = 0.;
+    const double var = n > 0. ? m2 / n : 0.;
+    mean[ch] = (float)m;
+    invstd[ch] = (float)(1. / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+      const float unbiased = (float)(n > 1. ? m2 / (n - 1.) : var);
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+    }
+  }
+}
+
+// statistics already reduced per 128-row tile by the producing convolution (conv_img.hip,
+// store_tile): merge the tiles, then normalise -- no statistics pass over x
+extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int c, const float* gamma,
+                                        const float* beta, float eps, float momentum,
+                                        float* running_mean, float* running_var,
+                                        int64_t* num_batches_tracked, int relu, void* y,
+                                        float* save_mean, float* save_invstd, const float* tile_stats,
+                                        int64_t n_tiles, void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  LIDAL_REQUIRE(n > 0 && n_tiles > 0 && tile_stats != nullptr, "bn_train_fwd_tiles: needs rows and tile statistics");
+  hipStream_t s = (hipStream_t)stream;
+  bn_tiles_final_kernel<<<(unsigned)c, NT, 0, s>>>(tile_stats, (int)n_tiles, c, eps, momentum, save_mean,
+                                                   save_invstd, running_mean, running_var,
+                                                   (long long*)num_batches_tracked);
+  LIDAL_CHECK_LAUNCH("bn_stats_final(tiles)");
+  if (dtype == LIDAL_F32)
+    bn_apply_kernel<float, false><<<nslabs_ew(n), NT, 0, s>>>((const float*)x, n, c, save_mean, save_invstd,
+                                                              gamma, beta, eps, relu, (float*)y,
+                                                              rows_per_wg_ew(n));
+  else
+    bn_apply_kernel<__bf16, false><<<nslabs_ew(n), NT, 0, s>>>((const __bf16*)x, n, c, save_mean,
+                                                               save_invstd, gamma, beta, eps, relu,
+                                                               (__bf16*)y, rows_per_wg_ew(n));
+  LIDAL_CHECK_LAUNCH("bn_apply");
+  return 0;
 }
 
 extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,

@@ -89,12 +89,9 @@ __host__ __device__ inline int64_t image_bytes(int k, int ci, int co, Tiling t, 
 // image[k][nblk][pass][cc][gsel][nb][row16][VEC]; one thread per 16-byte segment.
 // role 0: W[k][red][col] (forward: red = ci, col = co);  role 1: W[k][col][red] (data gradient)
 template <typename TI, typename TO>
-__global__ void __launch_bounds__(256)
-weight_image_kernel(const TI* __restrict__ w, TO* __restrict__ img, int K, int n_red, int n_col,
-                    int role, int nb, int kc, int64_t segs) {
+__device__ __forceinline__ void image_segment(const TI* __restrict__ w, TO* __restrict__ img, int n_red,
+                                              int n_col, int role, int nb, int kc, int64_t s) {
   constexpr int VEC = DT<TO>::VEC, CH = DT<TO>::CH;
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= segs) return;
   const int bn = 16 * nb, ncc = kc / CH;
   const int nblk = (n_col + bn - 1) / bn, npass = (n_red + kc - 1) / kc;
   int64_t r = s;
@@ -120,6 +117,18 @@ weight_image_kernel(const TI* __restrict__ w, TO* __restrict__ img, int K, int n
   }
   typedef typename DT<TO>::frag frag;
   *reinterpret_cast<frag*>(img + s * VEC) = *reinterpret_cast<frag*>(v);
+}
+
+// one launch builds up to two images of the same parameter: segments [0, segs_a) of image A (role_a,
+// n_red_a x n_col_a), then segs_b segments of image B with the roles of the two channel dims swapped
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+weight_image_kernel(const TI* __restrict__ w, TO* __restrict__ img_a, int n_red, int n_col, int role,
+                    int nb_a, int kc_a, int64_t segs_a, TO* __restrict__ img_b, int nb_b, int kc_b,
+                    int64_t segs_b) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < segs_a) image_segment<TI, TO>(w, img_a, n_red, n_col, role, nb_a, kc_a, s);
+  else if (s < segs_a + segs_b) image_segment<TI, TO>(w, img_b, n_col, n_red, role ^ 1, nb_b, kc_b, s - segs_a);
 }
 
 // Timing-only ablation builds (scripts/exp_img.py with an A/B library): results are wrong by
@@ -151,7 +160,7 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
                                            const float* __restrict__ ep_scale,
                                            const float* __restrict__ ep_shift, int ep_relu,
                                            const T* __restrict__ ep_res, bool perm_in_reg = false,
-                                           int perm_v = 0) {
+                                           int perm_v = 0, float* __restrict__ tile_stats = nullptr) {
   // perm_in_reg: lane l (< 16) of the wave holds perm[r0 + l] in perm_v, loaded when the tile began
   // (the lean kernel: no dependent load in front of the stores)
   constexpr int VEC = DT<T>::VEC;
@@ -217,6 +226,64 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
         }
     }
   }
+  // ---- BatchNorm batch statistics of the tile (training: the layer that follows is a train-mode
+  // BatchNorm): per column (count, mean, M2) of the values AS STORED, over the tile's valid rows.
+  // Per wave in registers (two-pass: mean, then squared deviations), waves merged through LDS with
+  // Chan's formula; lidal_bn_train_fwd_tiles merges the tiles (in f64).  Replaces the statistics
+  // pass over the stored matrix.
+  if (tile_stats != nullptr) {
+    constexpr int EPI_BYTES = NWAVES * RW * ESTRIDE * (int)sizeof(T);
+    float* st = reinterpret_cast<float*>(wl + EPI_BYTES);          // [NWAVES][BN][2]
+    const int64_t left = n_out - r0;
+    const int nvalid = left <= 0 ? 0 : (left < RW ? (int)left : RW);
+    const float inv_n = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float v[G][4];
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[g][r] = DT<T>::to_f32(DT<T>::from_f32(acc[g][nb][r]));
+          if (g * 16 + gsel * 4 + r < nvalid) sum += v[g][r];
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * inv_n;
+      float m2 = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (g * 16 + gsel * 4 + r < nvalid) { const float d = v[g][r] - mean; m2 += d * d; }
+      m2 += __shfl_xor(m2, 16, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      if (gsel == 0) {
+        st[(wave * BN + nb * 16 + row16) * 2] = mean;
+        st[(wave * BN + nb * 16 + row16) * 2 + 1] = m2;
+      }
+    }
+    __syncthreads();
+    const int c = wave * 64 + lane;
+    if (c < BN && n0 + c < co) {
+      const int64_t rb = r0 - (int64_t)wave * RW;                  // first row of the workgroup's tile
+      float na = 0.f, ma = 0.f, qa = 0.f;
+      for (int w = 0; w < NWAVES; ++w) {
+        const int64_t lw = n_out - (rb + (int64_t)w * RW);
+        const float nw = lw <= 0 ? 0.f : (lw < RW ? (float)lw : (float)RW);
+        if (nw > 0.f) {
+          const float mw = st[(w * BN + c) * 2], qw = st[(w * BN + c) * 2 + 1];
+          const float n = na + nw, d = mw - ma;
+          ma += d * (nw / n);
+          qa += qw + d * d * (na * nw / n);
+          na = n;
+        }
+      }
+      float* dst = tile_stats + ((int64_t)blockIdx.x * co + n0 + c) * 3;
+      dst[0] = na; dst[1] = ma; dst[2] = qa;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -236,7 +303,8 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
                       const unsigned* __restrict__ tmasks, T* __restrict__ out, int64_t n_out,
                       int ci, int co, int K, int kflip, const float* __restrict__ ep_scale,
                       const float* __restrict__ ep_shift, int ep_relu, const T* __restrict__ ep_res,
-                      unsigned in_bytes, unsigned img_bytes, unsigned nbr_bytes) {
+                      unsigned in_bytes, unsigned img_bytes, unsigned nbr_bytes,
+                      float* __restrict__ tile_stats) {
   constexpr int NTHREADS = 64 * NWAVES;
   constexpr int BM = NWAVES * G * 16;
   constexpr int BN = 16 * NB;
@@ -472,7 +540,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
   }
 
   store_tile<T, NB, G, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
-                               ep_res);
+                               ep_res, false, 0, tile_stats);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -507,7 +575,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
                  const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int ep_relu,
                  const T* __restrict__ ep_res, unsigned in_bytes, unsigned img_bytes,
-                 unsigned nbr_bytes) {
+                 unsigned nbr_bytes, float* __restrict__ tile_stats) {
   constexpr int BM = NWAVES * 16;
   constexpr int BN = 16 * NB;
   constexpr int CH = DT<T>::CH;
@@ -690,10 +758,10 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
     __syncthreads();                                // every wave is done with the last slab
   }
   store_tile<T, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
-                               ep_res, true, perm_v);
+                               ep_res, true, perm_v, tile_stats);
 }
 
-struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; };
+struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; };
 
 #ifndef LIDAL_IMG_G
 #define LIDAL_IMG_G 1
@@ -722,7 +790,8 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       constexpr int LW = LIDAL_LEAN_WAVES(NB, ROW_BYTES);
       constexpr int LBM = LW * 16;
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
-      constexpr int LEAN_LDS = (2 * SLAB > LEPI) ? 2 * SLAB : LEPI;
+      constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
+      constexpr int LEAN_LDS = (2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS;
       auto lk = nbr ? conv_lean_kernel<T, NB, ROW_BYTES, LW, false>
                     : conv_lean_kernel<T, NB, ROW_BYTES, LW, true>;
       static size_t lean_attr[2][MAX_DEVICES] = {};
@@ -735,13 +804,13 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       dim3 lgrid((unsigned)cdiv(n_out, LBM), (unsigned)cdiv(co, BN));
       lk<<<lgrid, 64 * LW, LEAN_LDS, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
                                           ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
-                                          ep.in_bytes, ep.img_bytes, ep.nbr_bytes);
+                                          ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats);
       LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(lean)");
       return 0;
     }
   }
 #endif
-  const size_t lds = WREGION + 1024;
+  const size_t lds = WREGION + 1024 + NWAVES * BN * 2 * sizeof(float);
   auto kern = nbr ? conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, false, D>
                   : conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, true, D>;
   static size_t attr_set[2][MAX_DEVICES] = {};
@@ -754,7 +823,7 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
   kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out, ci,
                                    co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
-                                   ep.in_bytes, ep.img_bytes, ep.nbr_bytes);
+                                   ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats);
   LIDAL_CHECK_LAUNCH("lidal_conv_apply_image");
   return 0;
 }
@@ -781,37 +850,55 @@ extern "C" int64_t lidal_conv_weight_image_bytes(int k, int ci, int co, int dtyp
   return image_bytes(k, ci, co, pick_tiling(ci, co, n_out, esz), esz);
 }
 
-extern "C" int lidal_conv_weight_image(const void* w, int w_dtype, int role, void* img, int dtype,
-                                       int k, int n_red, int n_col, int64_t n_out, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int weight_images(const void* w, int w_dtype, int role, void* img_a, int64_t n_out_a, void* img_b,
+                         int64_t n_out_b, int dtype, int k, int n_red, int n_col, hipStream_t s) {
   if (k == 0 || n_red == 0 || n_col == 0) return 0;
   LIDAL_REQUIRE(role == 0 || role == 1, "weight_image: role must be 0 (forward) or 1 (data gradient)");
   const int esz = dtype == LIDAL_BF16 ? 2 : 4;
-  const Tiling t = pick_tiling(n_red, n_col, n_out, esz);
-  const int kc = t.row_bytes / esz;
-  const int64_t segs = image_bytes(k, n_red, n_col, t, esz) / 16;
-  const unsigned grid = (unsigned)cdiv(segs, 256);
-  if (w_dtype == LIDAL_F32 && dtype == LIDAL_F32)
-    weight_image_kernel<float, float><<<grid, 256, 0, s>>>((const float*)w, (float*)img, k, n_red, n_col, role, t.nb, kc, segs);
-  else if (w_dtype == LIDAL_F32 && dtype == LIDAL_BF16)
-    weight_image_kernel<float, __bf16><<<grid, 256, 0, s>>>((const float*)w, (__bf16*)img, k, n_red, n_col, role, t.nb, kc, segs);
-  else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_BF16)
-    weight_image_kernel<__bf16, __bf16><<<grid, 256, 0, s>>>((const __bf16*)w, (__bf16*)img, k, n_red, n_col, role, t.nb, kc, segs);
-  else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_F32)
-    weight_image_kernel<__bf16, float><<<grid, 256, 0, s>>>((const __bf16*)w, (float*)img, k, n_red, n_col, role, t.nb, kc, segs);
+  const Tiling ta = pick_tiling(n_red, n_col, n_out_a, esz);
+  const int64_t segs_a = image_bytes(k, n_red, n_col, ta, esz) / 16;
+  Tiling tb = ta;
+  int64_t segs_b = 0;
+  if (img_b != nullptr) {
+    tb = pick_tiling(n_col, n_red, n_out_b, esz);
+    segs_b = image_bytes(k, n_col, n_red, tb, esz) / 16;
+  }
+  const unsigned grid = (unsigned)cdiv(segs_a + segs_b, 256);
+#define IMG_LAUNCH(TI, TO) \
+  weight_image_kernel<TI, TO><<<grid, 256, 0, s>>>((const TI*)w, (TO*)img_a, n_red, n_col, role, ta.nb, \
+                                                   ta.row_bytes / esz, segs_a, (TO*)img_b, tb.nb,       \
+                                                   tb.row_bytes / esz, segs_b)
+  if (w_dtype == LIDAL_F32 && dtype == LIDAL_F32) IMG_LAUNCH(float, float);
+  else if (w_dtype == LIDAL_F32 && dtype == LIDAL_BF16) IMG_LAUNCH(float, __bf16);
+  else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_BF16) IMG_LAUNCH(__bf16, __bf16);
+  else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_F32) IMG_LAUNCH(__bf16, float);
   else {
     set_error("weight_image: bad dtypes %d %d", w_dtype, dtype);
     return 2;
   }
+#undef IMG_LAUNCH
   LIDAL_CHECK_LAUNCH("lidal_conv_weight_image");
   return 0;
+}
+
+extern "C" int lidal_conv_weight_image(const void* w, int w_dtype, int role, void* img, int dtype,
+                                       int k, int n_red, int n_col, int64_t n_out, void* stream) {
+  return weight_images(w, w_dtype, role, img, n_out, nullptr, 0, dtype, k, n_red, n_col, (hipStream_t)stream);
+}
+
+extern "C" int lidal_conv_weight_image_pair(const void* w, int w_dtype, void* img_fwd, int64_t n_out_fwd,
+                                            void* img_bwd, int64_t n_out_bwd, int dtype, int k, int ci,
+                                            int co, void* stream) {
+  return weight_images(w, w_dtype, 0, img_fwd, n_out_fwd, img_bwd, n_out_bwd, dtype, k, ci, co,
+                       (hipStream_t)stream);
 }
 
 extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
                                       const int32_t* perm, const uint32_t* tile_masks, void* out,
                                       int64_t n_in, int64_t n_out, int ci, int co, int k, int kflip,
                                       int dtype, const float* ep_scale, const float* ep_shift,
-                                      int ep_relu, const void* ep_residual, void* stream) {
+                                      int ep_relu, const void* ep_residual, float* tile_stats,
+                                      void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_out == 0 || co == 0) return 0;
   LIDAL_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv_apply_image: scale and shift go together");
@@ -829,7 +916,7 @@ extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const in
                 "conv_apply_image: the input matrix and the weight image must each stay below 2 GiB");
   LIDAL_REQUIRE((int64_t)k * n_out * 4 < 0x7FFFFFF0ll, "conv_apply_image: neighbour table above 2 GiB");
   Epi ep{ep_scale, ep_shift, ep_relu, ep_residual, (unsigned)(n_in * ci * esz), (unsigned)ib,
-         (unsigned)((int64_t)k * n_out * 4)};
+         (unsigned)((int64_t)k * n_out * 4), tile_stats};
   if (dtype == LIDAL_F32)
     return dispatch_img<float>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
   return dispatch_img<__bf16>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);

@@ -89,9 +89,9 @@ def _conv_norm(conv, bn, x, residual=None, relu_after=False):
 
 
 def _conv_bn(inc, outc, ks, stride=1, transposed=False):
-    return [spnn.Conv3d(inc, outc, kernel_size=ks, stride=stride, dilation=1,
-                        transposed=transposed),
-            spnn.BatchNorm(outc)]
+    conv = spnn.Conv3d(inc, outc, kernel_size=ks, stride=stride, dilation=1, transposed=transposed)
+    conv.bn_follows = True      # training: the conv kernel leaves the BatchNorm's batch statistics on its output
+    return [conv, spnn.BatchNorm(outc)]
 
 
 def conv_bn_relu(inc, outc, ks, stride=1, transposed=False):

@@ -86,6 +86,7 @@ class SPVCNN(_SparseUNet):
             ConvNormSequential(spnn.Linear(a, b), spnn.BatchNorm1d(b), nn.Identity())   # ReLU fused in BN
             for a, b in ((cs[0], cs[4]), (cs[4], cs[6]), (cs[6], cs[8]))])
         for seq in self.point_transforms:
+            seq[0].bn_follows = True        # the Linear kernel leaves the BatchNorm's batch statistics
             seq[1].fused_relu = True
         self.weight_initialization()
         self.dropout = nn.Dropout(0.3, True)

@@ -58,21 +58,27 @@ class Conv3d(nn.Module):
         if self.bias is not None:
             self.bias.data.uniform_(-std, std)
 
+    bn_follows = False      # set by lidal_amd.network where a BatchNorm directly consumes the output
+
     def forward(self, input):
         return conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
-                      stride=self.stride, dilation=self.dilation, transposed=self.transposed)
+                      stride=self.stride, dilation=self.dilation, transposed=self.transposed,
+                      want_stats=self.bn_follows and self.training and torch.is_grad_enabled())
 
 
 class Linear(nn.Linear):
     """nn.Linear on a [N, C] tensor whose weight gradient runs on the split-K MFMA kernel (see
     functional/dense.py); parameters are nn.Linear's, so state_dict keys are unchanged."""
 
+    bn_follows = False
+
     def forward(self, x):
         if not x.is_cuda or x.dim() != 2:
             B.hit('torch_fallback:Linear')
             return super().forward(x)
         from .functional.dense import rows_linear
-        return rows_linear(x, self.weight, self.bias)
+        return rows_linear(x, self.weight, self.bias,
+                           want_stats=self.bn_follows and self.training and torch.is_grad_enabled())
 
 
 class BatchNorm1d(nn.BatchNorm1d):
@@ -92,7 +98,8 @@ class BatchNorm1d(nn.BatchNorm1d):
             return torch.relu(out) if self.fused_relu else out
         return norm.batch_norm_rows(feats, self.weight, self.bias, self.running_mean,
                                     self.running_var, self.training, self.momentum, self.eps,
-                                    self.fused_relu, self.num_batches_tracked)
+                                    self.fused_relu, self.num_batches_tracked,
+                                    getattr(feats, '_lidal_bn_stats', None))
 
 
 class BatchNorm(BatchNorm1d):

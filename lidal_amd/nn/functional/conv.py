@@ -208,7 +208,23 @@ def _weight_image(weight, dtype, n_out, role):
     return img
 
 
-def _apply(feats, img, k, co, order, kflip, epilogue=None):
+def _weight_image_pair(weight, dtype, n_out_fwd, n_out_bwd):
+    """(forward image, data-gradient image) of a [K, ci, co] weight from ONE launch."""
+    k, ci, co = weight.shape
+    w = weight.detach().contiguous()
+    code = B.dtype_code(dtype)
+    L = B.lib()
+    nf = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out_fwd)
+    nb = L.lidal_conv_weight_image_bytes(k, co, ci, code, n_out_bwd)
+    buf = torch.empty(nf + nb, dtype=torch.uint8, device=w.device)
+    img_f, img_b = buf[:nf], buf[nf:]
+    B.check(L.lidal_conv_weight_image_pair(B.ptr(w), B.dtype_code(w.dtype), B.ptr(img_f), n_out_fwd,
+                                           B.ptr(img_b), n_out_bwd, code, k, ci, co, B.stream()),
+            'conv_weight_image')
+    return img_f, img_b
+
+
+def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False):
     """out[j] = sum_k feats[nbr[kk][j]] @ W_k with the weights as the LDS image `img` (built for
     (ci = feats.shape[1], co, k, feats.dtype, n_out = order.n_rows)); `order` = RowOrder(nbr).
     epilogue = (scale f32 [co], shift f32 [co], relu[, residual [n_out, co]]): in-kernel
@@ -221,11 +237,20 @@ def _apply(feats, img, k, co, order, kflip, epilogue=None):
     if residual is not None:
         residual = residual.contiguous().to(feats.dtype)
         assert residual.shape == (n_out, co)
+    stats = None
+    # bf16 only: the tile triples are f32, and in the f32 parity mode the BatchNorm statistics keep
+    # their own f64-accumulated pass (an ill-conditioned gamma gradient of the golden model notices)
+    want_stats = want_stats and feats.dtype == torch.bfloat16
+    if want_stats:              # (count, mean, M2) per 128-row tile and column, for the BatchNorm that follows
+        stats = torch.empty((-(-n_out // 128), co, 3), dtype=torch.float32, device=feats.device)
     B.check(B.lib().lidal_conv_apply_image(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
                                            B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
                                            co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(scale),
-                                           B.ptr(shift), int(relu), B.ptr(residual), B.stream()),
+                                           B.ptr(shift), int(relu), B.ptr(residual), B.ptr(stats),
+                                           B.stream()),
             'conv_apply')
+    if want_stats:
+        out._lidal_bn_stats = stats     # picked up by spnn.BatchNorm (nn/functional/norm.py)
     return out
 
 
@@ -271,7 +296,15 @@ def _pad_channels(ci, dtype):
     return (-ci) % vec
 
 
-def _forward(feats, weight, kmap, transposed, epilogue=None):
+def _bwd_order(kmap, transposed):
+    """(RowOrder, kflip) of the data gradient of a convolution over `kmap`."""
+    if transposed:
+        return kmap.order_out, 0
+    return (kmap.order_out, 1) if kmap.symmetric else (kmap.order_in, 0)
+
+
+def _forward(feats, weight, kmap, transposed, epilogue=None, with_bwd_image=False, want_stats=False):
+    """-> (x in the compute dtype, out, image of the data gradient or None)."""
     B.require_gpu(feats, weight)
     cdtype = B.compute_dtype(feats)
     x = feats.contiguous().to(cdtype)
@@ -281,21 +314,33 @@ def _forward(feats, weight, kmap, transposed, epilogue=None):
         weight = torch.nn.functional.pad(weight.detach(), (0, 0, 0, pad))
     order = kmap.order_in if transposed else kmap.order_out
     k, _, co = weight.shape
-    img = _weight_image(weight, cdtype, order.n_rows, 0)
-    return x, _apply(x, img, k, co, order, 0, epilogue)
+    img_b = None
+    if with_bwd_image:          # both operands of this parameter from one launch
+        img, img_b = _weight_image_pair(weight, cdtype, order.n_rows, _bwd_order(kmap, transposed)[0].n_rows)
+    else:
+        img = _weight_image(weight, cdtype, order.n_rows, 0)
+    return x, _apply(x, img, k, co, order, 0, epilogue, want_stats), img_b
 
 
-def _conv(feats, weight, kmap, transposed, epilogue=None):
+def _conv(feats, weight, kmap, transposed, epilogue=None, want_stats=False):
     if B.wants_grad(feats, weight):
         assert epilogue is None, 'the fused BatchNorm epilogue is inference-only'
-        return ConvolutionFunction.apply(feats, weight, kmap, transposed)
-    return _forward(feats, weight, kmap, transposed, epilogue)[1]   # no autograd node
+        out = ConvolutionFunction.apply(feats, weight, kmap, transposed, want_stats)
+        if ConvolutionFunction.last_stats is not None:      # from the Function's own output to autograd's
+            out._lidal_bn_stats = ConvolutionFunction.last_stats
+            ConvolutionFunction.last_stats = None
+        return out
+    return _forward(feats, weight, kmap, transposed, epilogue, False, want_stats)[1]   # no autograd node
 
 
 class ConvolutionFunction(Function):
+    last_stats = None           # tile statistics of the latest forward (a non-differentiable side output)
+
     @staticmethod
-    def forward(ctx, feats, weight, kmap, transposed):
-        x, out = _forward(feats, weight, kmap, transposed)
+    def forward(ctx, feats, weight, kmap, transposed, want_stats=False):
+        x, out, ctx.img_bwd = _forward(feats, weight, kmap, transposed, None, ctx.needs_input_grad[0],
+                                       want_stats)
+        ConvolutionFunction.last_stats = getattr(out, '_lidal_bn_stats', None) if want_stats else None
         ctx.kmap = kmap
         ctx.transposed = transposed
         ctx.save_for_backward(x, weight)
@@ -309,17 +354,11 @@ class ConvolutionFunction(Function):
         n_in, n_out = kmap.sizes
         grad_in = grad_w = None
         if ctx.needs_input_grad[0]:
-            # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci, reduction over co
+            # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci (of the padded input), reduction
+            # over co; the operand image was built together with the forward one
             k, ci_w, co = weight.shape
-            w = weight
-            if x.shape[1] != ci_w:                 # the input was channel-padded (bf16 stem)
-                w = torch.nn.functional.pad(weight.detach(), (0, 0, 0, x.shape[1] - ci_w))
-            if not transposed:
-                order, kflip = (kmap.order_out, 1) if kmap.symmetric else (kmap.order_in, 0)
-            else:
-                order, kflip = kmap.order_out, 0
-            img = _weight_image(w, x.dtype, order.n_rows, 1)
-            grad_in = _apply(g, img, k, w.shape[1], order, kflip)
+            order, kflip = _bwd_order(kmap, transposed)
+            grad_in = _apply(g, ctx.img_bwd, k, x.shape[1], order, kflip)
             grad_in = grad_in[:, :ci_w]                     # drop the padding channels, if any
         if ctx.needs_input_grad[1]:
             k, ci_w, co = weight.shape
@@ -334,14 +373,15 @@ class ConvolutionFunction(Function):
                                              B.dtype_code(x.dtype), B.stream()), 'conv_wgrad')
             gw = gw[:, :ci_w].contiguous() if ci != ci_w else gw
             grad_w = gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
-        return grad_in, grad_w, None, None
+        return grad_in, grad_w, None, None, None
 
 
 def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False,
-           epilogue=None):
+           epilogue=None, want_stats=False):
     """torchsparse F.conv3d.  `epilogue` (inference only, not for 1x1x1 kernels) = (scale, shift,
     relu) applies the per-channel affine map of a following eval-mode BatchNorm (+ ReLU) inside
-    the convolution kernel."""
+    the convolution kernel.  `want_stats` (training: a train-mode BatchNorm follows) makes the kernel
+    leave that BatchNorm's batch statistics, reduced per 128-row tile, on the output features."""
     feats, coords = input.feats, input.coords
     kernel_size = make_ntuple(kernel_size, ndim=3)
     stride = make_ntuple(stride, ndim=3)
@@ -350,7 +390,7 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
     if kernel_size == (1, 1, 1) and stride == (1, 1, 1) and dilation == (1, 1, 1):
         B.require_gpu(feats)
         from .dense import rows_matmul
-        feats = rows_matmul(feats, weight, bias, epilogue)
+        feats = rows_matmul(feats, weight, bias, epilogue, want_stats)
         output = SparseTensor(feats, coords, input.stride)
     elif not transposed:
         if dilation != (1, 1, 1):
@@ -364,14 +404,14 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
             if any(s > 1 for s in stride):
                 input.cmaps.setdefault(out_stride, out_coords)
         out_coords = coords if all(s == 1 for s in stride) else input.cmaps[out_stride]
-        feats = _conv(feats, weight, kmap, False, epilogue)
+        feats = _conv(feats, weight, kmap, False, epilogue, want_stats and bias is None)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(feats, out_coords, out_stride)
     else:
         tensor_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         kmap = input.kmaps[(tensor_stride, kernel_size, stride, dilation)]
-        feats = _conv(feats, weight, kmap, True, epilogue)
+        feats = _conv(feats, weight, kmap, True, epilogue, want_stats and bias is None)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(feats, input.cmaps[tensor_stride], tensor_stride)

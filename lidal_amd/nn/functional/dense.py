@@ -60,7 +60,7 @@ def _gemm_ok(x, ci, co):
     return x.dtype == torch.bfloat16 and ci % 8 == 0 and co % 8 == 0
 
 
-def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None):
+def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None, img=None, want_stats=False):
     """x [n, n_red] times the [Cin, Cout] operand `w` (compute dtype): role 0 = x @ w (reduction over
     Cin), role 1 = x @ w^T (reduction over Cout: the data gradient), + shift f32: the sparse
     convolution kernel with the identity rule list (a NULL table) and the weight as an LDS image.
@@ -70,17 +70,24 @@ def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None):
     n, n_red = x.shape
     n_col = w.shape[1] if role == 0 else w.shape[0]
     assert n_red == (w.shape[0] if role == 0 else w.shape[1])
-    img = _weight_image(w.contiguous().unsqueeze(0), x.dtype, n, role)
+    if img is None:
+        img = _weight_image(w.contiguous().unsqueeze(0), x.dtype, n, role)
     out = torch.empty((n, n_col), dtype=x.dtype, device=x.device)
     if residual is not None:
         residual = residual.contiguous()
         assert residual.shape == out.shape and residual.dtype == out.dtype
     if shift is not None and scale is None:
         scale = torch.ones(n_col, dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty((-(-n // 128), n_col, 3), dtype=torch.float32, device=x.device)
     B.check(B.lib().lidal_conv_apply_image(B.ptr(x), B.ptr(img), None, None, None, B.ptr(out),
                                            n, n, n_red, n_col, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
-                                           B.ptr(shift), int(relu), B.ptr(residual), B.stream()),
+                                           B.ptr(shift), int(relu), B.ptr(residual), B.ptr(stats),
+                                           B.stream()),
             'conv_apply(dense)')
+    if want_stats:
+        out._lidal_bn_stats = stats
     return out
 
 
@@ -95,10 +102,11 @@ def _operand(w, linear, cdtype, pad):
     return wc
 
 
-def _forward(x, w, bias, linear, epilogue=None):
+def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats=False):
     """epilogue (inference only) = (scale f32 [Cout], shift f32 [Cout], relu[, residual [N, Cout]]):
     the eval-mode BatchNorm (+ ReLU) that follows the layer and an optional row-wise sum,
     y = act((x @ w + bias) * scale + shift) + residual."""
+    img_b = None
     cdtype = B.compute_dtype(x)
     xc = x.contiguous().to(cdtype)
     co = w.shape[0] if linear else w.shape[1]
@@ -121,13 +129,18 @@ def _forward(x, w, bias, linear, epilogue=None):
         if fused_res is not None:
             fused_res = fused_res.to(cdtype)
         late = residual is not None and fused_res is None       # sum (and its ReLU) outside the kernel
+        img_f = None
+        if with_bwd_image:      # forward and data-gradient operands of this parameter from one launch
+            from .conv import _weight_image_pair
+            img_f, img_b = _weight_image_pair(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], xc.shape[0])
+        want_stats = want_stats and not pad and not late and cdtype == torch.bfloat16
         y = _rows_gemm(xc, wc, 0, shift, scale,
-                       int(relu) & 1 if late else int(relu), fused_res)
+                       int(relu) & 1 if late else int(relu), fused_res, img_f, want_stats)
         y = y[:, :co] if pad else y
         if late:
             y = y + residual.to(cdtype)
             y = torch.relu(y) if int(relu) & 2 else y
-        return xc, wc, pad, y
+        return xc, wc, pad, y, img_b
     B.hit('library_gemm:rows')        # f32 parity mode (by design) or a shape the kernel does not take
     y = xc @ wc
     y = y[:, :co] if pad else y
@@ -140,7 +153,7 @@ def _forward(x, w, bias, linear, epilogue=None):
         y = y.to(cdtype)
     elif bias is not None:
         y = y + bias.detach().to(cdtype)
-    return xc, wc, pad, y
+    return xc, wc, pad, y, img_b
 
 
 class RowsMatmul(Function):
@@ -148,10 +161,12 @@ class RowsMatmul(Function):
     that is not a multiple of the 16-byte vector width (the 19-class classifier) is zero-padded
     internally so that forward, weight gradient and bias gradient all stay on the vectorised
     kernels; the caller sees exactly [N, Cout]."""
+    last_stats = None
 
     @staticmethod
-    def forward(ctx, x, w, bias, linear):
-        xc, wc, pad, y = _forward(x, w, bias, linear)
+    def forward(ctx, x, w, bias, linear, want_stats=False):
+        xc, wc, pad, y, ctx.img_bwd = _forward(x, w, bias, linear, None, ctx.needs_input_grad[0], want_stats)
+        RowsMatmul.last_stats = getattr(y, '_lidal_bn_stats', None)
         ctx.save_for_backward(xc, w)
         ctx.wc = wc                      # operand in the compute dtype, re-used by the data gradient
         ctx.has_bias = bias is not None
@@ -171,7 +186,7 @@ class RowsMatmul(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if _gemm_ok(g, g.shape[1], xc.shape[1]):
-                gx = _rows_gemm(g, ctx.wc, 1)             # reduction over co
+                gx = _rows_gemm(g, ctx.wc, 1, img=ctx.img_bwd)             # reduction over co
             else:
                 gx = g @ ctx.wc.t()
         if ctx.needs_input_grad[1]:
@@ -186,20 +201,25 @@ class RowsMatmul(Function):
                 gb = column_sum(g)[:co]
             else:
                 gb = g.float().sum(0)[:co]
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
-def _rows(x, w, bias, linear, epilogue=None):
+def _rows(x, w, bias, linear, epilogue=None, want_stats=False):
     if B.wants_grad(x, w, bias):
         assert epilogue is None, 'the fused BatchNorm epilogue is inference-only'
-        return RowsMatmul.apply(x, w, bias, linear)
-    return _forward(x, w, bias, linear, epilogue)[3]          # inference: no autograd node
+        y = RowsMatmul.apply(x, w, bias, linear, want_stats)
+        if want_stats and RowsMatmul.last_stats is not None:
+            y._lidal_bn_stats = RowsMatmul.last_stats
+        RowsMatmul.last_stats = None
+        return y
+    return _forward(x, w, bias, linear, epilogue, False, want_stats)[3]          # inference: no autograd node
 
 
-def rows_matmul(x, w, bias=None, epilogue=None):
-    return _rows(x, w, bias, False, epilogue)
+def rows_matmul(x, w, bias=None, epilogue=None, want_stats=False):
+    return _rows(x, w, bias, False, epilogue, want_stats)
 
 
-def rows_linear(x, weight, bias=None, epilogue=None):
-    """nn.Linear semantics: weight [Cout, Cin]."""
-    return _rows(x, weight, bias, True, epilogue)
+def rows_linear(x, weight, bias=None, epilogue=None, want_stats=False):
+    """nn.Linear semantics: weight [Cout, Cin].  `want_stats`: leave the batch statistics of a
+    train-mode BatchNorm that follows on the output (see conv.conv3d)."""
+    return _rows(x, weight, bias, True, epilogue, want_stats)

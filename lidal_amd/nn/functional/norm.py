@@ -30,7 +30,7 @@ def _ws(n, c, dev):
 class BatchNormRows(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu,
-                num_batches_tracked=None):
+                num_batches_tracked=None, tile_stats=None):
         x = x.contiguous()
         n, c = x.shape
         dev = x.device
@@ -40,13 +40,21 @@ class BatchNormRows(Function):
         if training:
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             invstd = torch.empty(c, dtype=torch.float32, device=dev)
-            ws, nbytes = _ws(n, c, dev)
-            B.check(B.lib().lidal_bn_train_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
-                                               float(momentum), B.ptr(running_mean),
-                                               B.ptr(running_var), B.ptr(num_batches_tracked), int(relu),
-                                               B.ptr(y), B.ptr(mean),
-                                               B.ptr(invstd), B.ptr(ws), nbytes, B.stream()),
-                    'bn_train_fwd')
+            if tile_stats is not None:      # statistics came with x from the producing convolution
+                B.check(B.lib().lidal_bn_train_fwd_tiles(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
+                                                         float(momentum), B.ptr(running_mean),
+                                                         B.ptr(running_var), B.ptr(num_batches_tracked),
+                                                         int(relu), B.ptr(y), B.ptr(mean), B.ptr(invstd),
+                                                         B.ptr(tile_stats), tile_stats.shape[0], B.stream()),
+                        'bn_train_fwd')
+            else:
+                ws, nbytes = _ws(n, c, dev)
+                B.check(B.lib().lidal_bn_train_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
+                                                   float(momentum), B.ptr(running_mean),
+                                                   B.ptr(running_var), B.ptr(num_batches_tracked), int(relu),
+                                                   B.ptr(y), B.ptr(mean),
+                                                   B.ptr(invstd), B.ptr(ws), nbytes, B.stream()),
+                        'bn_train_fwd')
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
@@ -79,12 +87,16 @@ class BatchNormRows(Function):
                                      B.ptr(b), int(ctx.relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),
                                      B.ptr(gg), B.ptr(gb),
                                      B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
-        return dx, gg, gb, None, None, None, None, None, None, None
+        return dx, gg, gb, None, None, None, None, None, None, None, None
 
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                    relu=False, num_batches_tracked=None):
-    """`num_batches_tracked` (i64 scalar buffer, training only) is incremented inside the kernel."""
+                    relu=False, num_batches_tracked=None, tile_stats=None):
+    """`num_batches_tracked` (i64 scalar buffer, training only) is incremented inside the kernel.
+    `tile_stats` (training only): f32 [ceil(N/128), C, 3] (count, mean, M2) per 128-row tile, written
+    by the convolution that produced x (conv3d(..., want_stats=True)): no statistics pass over x."""
+    if tile_stats is not None and not (training and tile_stats.shape == (-(-x.shape[0] // 128), x.shape[1], 3)):
+        tile_stats = None
     if not training and not B.wants_grad(x, weight, bias):      # inference: one kernel, no node
         x = x.contiguous()
         y = torch.empty_like(x)
@@ -94,7 +106,7 @@ def batch_norm_rows(x, weight, bias, running_mean, running_var, training, moment
                                           B.stream()), 'bn_eval_fwd')
         return y
     return BatchNormRows.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                               relu, num_batches_tracked if training else None)
+                               relu, num_batches_tracked if training else None, tile_stats)
 
 
 def column_sum(x):

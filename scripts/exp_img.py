@@ -62,7 +62,7 @@ def run_pair(x, w_kio, tab, prm, tmk, n, dtype, k=27):
     def v2():
         B.check(B.lib().lidal_conv_apply_image(B.ptr(x), B.ptr(img), B.ptr(tab), B.ptr(prm), B.ptr(tmk),
                                                B.ptr(o2), n, n, ci, co, k, 0, B.dtype_code(dtype), None, None,
-                                               0, None, B.stream()), 'v2')
+                                               0, None, None, B.stream()), 'v2')
     v1(), v2()
     torch.cuda.synchronize()
     same = torch.equal(o1, o2)

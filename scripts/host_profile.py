@@ -8,7 +8,7 @@ from lidal_amd.train_step import train_step
 b = synth.make_train_batch(n_frames=1, n_points=120000, seed=7122)
 dev = 'cuda'
 coords = torch.from_numpy(b['coords_v_b']).to(dev); feats = torch.from_numpy(b['feats_v_b']).to(dev); labels = torch.from_numpy(b['labels_v_b']).to(dev)
-model = SPVCNN(19).to(dev).train(); opt = torch.optim.Adam(model.parameters())
+model = SPVCNN(19).to(dev).train(); opt = torch.optim.Adam(model.parameters(), fused=True)
 for _ in range(3): train_step(model, opt, feats, coords, labels, autocast=True)
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()

@@ -680,8 +680,9 @@ def test_conv_apply_image_is_bitwise_conv_apply(dtype):
             out = torch.full((n_out, co), float('nan'), dtype=dtype, device=DEV)
             sc, sh, relu, res = ep if ep else (None, None, 0, None)
             tab, prm, tmk = (order.table, order.perm, order.tile_masks) if order is not None else (None,) * 3
+            extra = (None,) if fn is L.lidal_conv_apply_image else ()          # tile_stats
             B.check(fn(B.ptr(x), B.ptr(wop), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(out), n_in, n_out, ci,
-                       co, k, kflip, code, B.ptr(sc), B.ptr(sh), relu, B.ptr(res), B.stream()), 'conv')
+                       co, k, kflip, code, B.ptr(sc), B.ptr(sh), relu, B.ptr(res), *extra, B.stream()), 'conv')
             outs.append(out)
         assert not torch.isnan(outs[1].float()).any()
         assert torch.equal(outs[0], outs[1])
@@ -707,3 +708,58 @@ def test_conv_apply_image_is_bitwise_conv_apply(dtype):
     both(xc, (torch.randn(8, 32, 64, generator=g) * 0.1).to(DEV), km2.order_in, 8, 0)
     both(x, (torch.randn(1, 64, 20, generator=g) * 0.1).to(DEV), None, 1, 0)                  # dense form
     both(x[:1].contiguous(), (torch.randn(1, 64, 96, generator=g) * 0.1).to(DEV), None, 1, 0)  # one row
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_epilogue_batch_statistics(dtype):
+    """conv3d(..., want_stats=True): the kernel leaves (count, mean, M2) per 128-row tile and column
+    of the values it stored; merged, they are the batch statistics a pass over the output gives, and
+    spnn.BatchNorm fed with them produces what it produces from its own statistics pass (output,
+    running statistics, gradients).  Sparse k3 layer with a ragged last tile, a column count off the
+    tile width, and the dense (Linear) form."""
+    import lidal_amd
+    import lidal_amd.nn as spnn
+    from lidal_amd.nn.functional.conv import conv3d
+    from lidal_amd.nn.functional.dense import rows_linear
+    g = torch.Generator().manual_seed(23)
+    coords = _surface_coords(61, 2, seed=7).to(DEV)
+    n = coords.shape[0]
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        for ci, co in ((32, 96), (64, 40)):
+            x = (torch.randn(n, ci, generator=g) + 0.3).to(DEV)
+            w = (torch.randn(27, ci, co, generator=g) * 0.1).to(DEV).requires_grad_(True)
+            out = conv3d(lidal_amd.SparseTensor(x, coords), w, 3, want_stats=True).F
+            if dtype == torch.float32:             # parity mode: BatchNorm keeps its own f64 statistics pass
+                assert not hasattr(out, '_lidal_bn_stats')
+                continue
+            st = out._lidal_bn_stats.double().cpu()
+            assert st.shape == (-(-n // 128), co, 3)
+            o = out.detach().double().cpu()
+            cnt = st[:, :, 0].sum(0)
+            mean = (st[:, :, 0] * st[:, :, 1]).sum(0) / cnt
+            m2 = (st[:, :, 2] + st[:, :, 0] * (st[:, :, 1] - mean) ** 2).sum(0)
+            assert torch.equal(cnt, torch.full((co,), float(n), dtype=torch.float64))
+            assert _relerr(mean, o.mean(0)) < 1e-5 and _relerr(m2 / n, o.var(0, unbiased=False)) < 1e-5
+            bn_a, bn_b = spnn.BatchNorm1d(co).to(DEV), spnn.BatchNorm1d(co).to(DEV)
+            bn_a.fused_relu = bn_b.fused_relu = True
+            xa = out.detach().clone().requires_grad_(True)
+            xa._lidal_bn_stats = out._lidal_bn_stats
+            xb = out.detach().clone().requires_grad_(True)
+            from lidal_amd import backend as B
+            B.HITS.clear()
+            ya, yb = bn_a(xa), bn_b(xb)
+            go = torch.randn(n, co, generator=g).to(DEV).to(ya.dtype)
+            ya.backward(go), yb.backward(go)
+            tol = 1e-5 if dtype == torch.float32 else 1e-2
+            assert _relerr(ya.float().cpu(), yb.detach().float().cpu()) < tol
+            assert _relerr(bn_a.running_var.cpu(), bn_b.running_var.cpu()) < 1e-5
+            assert _relerr(bn_a.running_mean.cpu(), bn_b.running_mean.cpu()) < 1e-5
+            assert _relerr(xa.grad.float().cpu(), xb.grad.float().cpu()) < tol
+            assert _relerr(bn_a.weight.grad.cpu(), bn_b.weight.grad.cpu()) < 1e-3
+        x = torch.randn(5003, 64, generator=g).to(DEV).requires_grad_(True)
+        lin = torch.nn.Linear(64, 96).to(DEV)
+        y = rows_linear(x, lin.weight, lin.bias, want_stats=True)
+        if dtype == torch.bfloat16:
+            st = y._lidal_bn_stats.double().cpu()
+            mean = (st[:, :, 0] * st[:, :, 1]).sum(0) / st[:, :, 0].sum(0)
+            assert _relerr(mean, y.detach().double().cpu().mean(0)) < 1e-5

@@ -198,6 +198,9 @@ int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const i
  * BatchNorm that follows (network/utils.py:115), taken in the epilogue instead of by a pass over the
  * stored matrix; merged by lidal_bn_train_fwd_tiles. */
 int64_t lidal_conv_weight_image_bytes(int k, int ci, int co, int dtype, int64_t n_out);
+/* identifies the tiling an image is built for (two n_out with the same value share images: a
+ * host-side cache key for weights that do not change between calls, i.e. inference) */
+int lidal_conv_weight_image_tiling(int ci, int co, int dtype, int64_t n_out);
 int lidal_conv_weight_image(const void* w, int w_dtype, int role, void* img, int dtype, int k,
                             int n_red, int n_col, int64_t n_out, void* stream);
 /* both images of one [k][ci][co] parameter in ONE launch: img_fwd (role 0, for a convolution

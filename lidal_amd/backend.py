@@ -63,6 +63,7 @@ SIGNATURES = {
     'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
                                 _vp, _i32, _vp, _vp]),
     'lidal_conv_weight_image_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
+    'lidal_conv_weight_image_tiling': (_i32, [_i32, _i32, _i32, _i64]),
     'lidal_conv_weight_image': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     'lidal_conv_weight_image_pair': (_i32, [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'lidal_conv_apply_image': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
@@ -106,7 +107,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._handle, name)
-        if fn.restype is not _i32 or name.endswith('_bytes') or name == 'lidal_version':
+        if fn.restype is not _i32 or name.endswith(('_bytes', '_tiling')) or name == 'lidal_version':
             return fn                               # size queries: no kernel behind them
         sink = self._sink
 

@@ -845,6 +845,11 @@ int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, con
 
 }  // namespace
 
+extern "C" int lidal_conv_weight_image_tiling(int ci, int co, int dtype, int64_t n_out) {
+  const Tiling t = pick_tiling(ci, co, n_out, dtype == LIDAL_BF16 ? 2 : 4);
+  return t.nb * 1000 + t.row_bytes;
+}
+
 extern "C" int64_t lidal_conv_weight_image_bytes(int k, int ci, int co, int dtype, int64_t n_out) {
   const int esz = dtype == LIDAL_BF16 ? 2 : 4;
   return image_bytes(k, ci, co, pick_tiling(ci, co, n_out, esz), esz);

@@ -71,12 +71,20 @@ def _fusable(conv, bn, x):
 
 
 def _fold(bn, device):
-    """Eval-mode BatchNorm as (scale, shift) f32 [C]: y = x * scale + shift."""
+    """Eval-mode BatchNorm as (scale, shift) f32 [C]: y = x * scale + shift.  Cached on the module,
+    keyed by the version counters of its parameters and running statistics (they do not change
+    between inference calls)."""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_mean.data_ptr(), str(device))
+    cached = getattr(bn, '_lidal_fold', None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
     c = bn.num_features
     fold = torch.empty((2, c), dtype=torch.float32, device=device)
     B.check(B.lib().lidal_bn_fold(B.ptr(bn.weight), B.ptr(bn.bias), B.ptr(bn.running_mean),
                                   B.ptr(bn.running_var), float(bn.eps), c, B.ptr(fold[0]),
                                   B.ptr(fold[1]), B.stream()), 'bn_fold')
+    object.__setattr__(bn, '_lidal_fold', (key, fold[0], fold[1]))
     return fold[0], fold[1]
 
 

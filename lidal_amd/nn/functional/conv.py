@@ -196,15 +196,29 @@ def prefetch_kernel_maps(x, plan, transposed=True):
 def _weight_image(weight, dtype, n_out, role):
     """LDS image (csrc/conv_img.hip) of a [K, ci, co] weight in `dtype` for a convolution that
     produces n_out rows.  role 0: forward operand (reduction over ci, columns co); role 1: the
-    data-gradient operand of the same parameter (reduction over co, columns ci)."""
+    data-gradient operand of the same parameter (reduction over co, columns ci).
+    Outside autograd (inference: the weights do not change between calls) the image is cached on the
+    weight tensor, keyed by its version counter, storage, role, dtype and the tiling n_out selects."""
     k, ci, co = weight.shape
-    w = weight.detach().contiguous()
     n_red, n_col = (ci, co) if role == 0 else (co, ci)
     code = B.dtype_code(dtype)
-    nbytes = B.lib().lidal_conv_weight_image_bytes(k, n_red, n_col, code, n_out)
+    L = B.lib()
+    key = cache = None
+    if not torch.is_grad_enabled():
+        key = (weight._version, weight.data_ptr(), role, code, L.lidal_conv_weight_image_tiling(n_red, n_col, code, n_out))
+        cache = getattr(weight, '_lidal_images', None)
+        if cache is not None and key in cache:
+            return cache[key]
+    w = weight.detach().contiguous()
+    nbytes = L.lidal_conv_weight_image_bytes(k, n_red, n_col, code, n_out)
     img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    B.check(B.lib().lidal_conv_weight_image(B.ptr(w), B.dtype_code(w.dtype), role, B.ptr(img), code,
-                                            k, n_red, n_col, n_out, B.stream()), 'conv_weight_image')
+    B.check(L.lidal_conv_weight_image(B.ptr(w), B.dtype_code(w.dtype), role, B.ptr(img), code,
+                                      k, n_red, n_col, n_out, B.stream()), 'conv_weight_image')
+    if key is not None:
+        if cache is None or next(iter(cache))[0] != weight._version:      # drop images of older versions
+            cache = {}
+            weight._lidal_images = cache
+        cache[key] = img
     return img
 
 

@@ -130,6 +130,22 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
             fused_res = fused_res.to(cdtype)
         late = residual is not None and fused_res is None       # sum (and its ReLU) outside the kernel
         img_f = None
+        img_key = None
+        if not torch.is_grad_enabled():     # inference: the image of an unchanged parameter is re-used
+            code = B.dtype_code(cdtype)
+            img_key = (w._version, w.data_ptr(), linear, code, pad,
+                       B.lib().lidal_conv_weight_image_tiling(xc.shape[1], co + pad, code, xc.shape[0]))
+            cache = getattr(w, '_lidal_images', None)
+            if cache is not None and img_key in cache:
+                img_f = cache[img_key]
+            else:
+                from .conv import _weight_image
+                with torch.enable_grad():       # (bypass the per-tensor cache of the temporary operand)
+                    img_f = _weight_image(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], 0)
+                if cache is None or next(iter(cache))[0] != w._version:
+                    cache = {}
+                    w._lidal_images = cache
+                cache[img_key] = img_f
         if with_bwd_image:      # forward and data-gradient operands of this parameter from one launch
             from .conv import _weight_image_pair
             img_f, img_b = _weight_image_pair(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], xc.shape[0])

@@ -85,3 +85,38 @@ def test_register_scan_matches_reference_kdtree_data(golden_dir, tmp_path):
     bank = FrameBank(0.1)
     bank.add(world, torch.full((world.shape[0], 19), 1 / 19, device=DEV))
     assert bank.grid(0).numel() > 0
+
+
+def test_collate_feeds_the_validation_path():
+    """The val collate of the reference returns labels_p_b next to inverse_indices_b
+    (sk_dataset.py:227-238) and evaluate.py:95-124 consumes exactly that: voxelize two scans on the
+    device, collate them WITH per-point labels, run evaluate_batches, and compare the confusion
+    matrix with the reference formula (utils/iou_sk.py:14-19) on the model's own logits."""
+    from lidal_amd import SparseTensor, data as ldata, synth
+    from lidal_amd.evaluate import evaluate_batches
+    from lidal_amd.network import MinkUNet
+    rng = np.random.default_rng(12)
+    world = synth.make_world(5)
+    samples, labels = [], []
+    for i in range(2):
+        pts, inten = synth.raycast_scan(world, (18.0 + 2 * i, 0.0), rng, n_beams=16, n_az=256)
+        trans_m, rnd = ldata.draw_augmentation(np.random.RandomState(40 + i))
+        cv, fv, _, inv = ldata.voxelize_scan(torch.from_numpy(pts).to(DEV), torch.from_numpy(inten).to(DEV),
+                                             trans_m, rnd)
+        lab = torch.from_numpy(rng.integers(0, 19, pts.shape[0])).to(DEV)
+        lab[::7] = 255                                           # ignored by the metric (>= 100)
+        samples.append({'coords_v': cv, 'feats_v': fv, 'inverse_idxs': inv, 'labels_p': lab})
+        labels.append(lab)
+    batch = ldata.collate(samples)
+    assert batch['labels_p_b'].shape == batch['inverse_indices_b'].shape
+    assert torch.equal(batch['labels_p_b'], torch.cat(labels))
+    torch.manual_seed(3)
+    model = MinkUNet(19).to(DEV)
+    conf, ious, miou = evaluate_batches(model, [batch])
+    with torch.no_grad():
+        logits, _ = model.eval()(SparseTensor(batch['feats_v_b'], batch['coords_v_b']))
+    pred = logits[batch['inverse_indices_b']].argmax(1).cpu().numpy()
+    gt = batch['labels_p_b'].cpu().numpy()
+    keep = gt < 100
+    ref = np.bincount(pred[keep] * 19 + gt[keep], minlength=361).reshape(19, 19)
+    assert np.array_equal(conf, ref) and conf.sum() == keep.sum()

@@ -316,7 +316,7 @@ def family_table(step, coords, dtype_name, step_ms):
             fl = 2.0 * m * ci * co
             fwd_shape[a[0]] = (n_in, n_out)
         elif name == 'lidal_conv_wgrad':
-            k, ca, cb, dt = a[9], a[10], a[11], a[12]
+            k, ca, cb, dt = a[11], a[12], a[13], a[14]
             b = 2 if dt == 1 else 4
             # a = the saved input x [n_in, ca] of the forward conv, b = grad_out [n_out, cb]
             n_in, n_out = fwd_shape.get(a[0], (coords.shape[0], coords.shape[0]))

@@ -215,15 +215,19 @@ int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
                            float* tile_stats, void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
- * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device).  Split-K: offset k with nk rules is cut into
- * min(splits, ceil(nk / target_chunk)) slabs; `partial` f32 [splits][k][ca][cb] scratch holds the
- * slabs, which are reduced in a fixed order => bitwise reproducible.
+ * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device); n_a, n_b = rows of a and b.
  * pairs == NULL means the identity rule list (row p with row p): the weight gradient of a dense
  * [n, ca]^T x [n, cb] product (1x1x1 convolutions and the point-branch Linear layers), where a
- * library GEMM would run its whole n-long reduction in a handful of workgroups. */
-int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs, const int64_t* koff,
-                     int a_col, float* gw, float* partial, int splits, int target_chunk, int k,
-                     int ca, int cb, int dtype, void* stream);
+ * library GEMM would run its whole n-long reduction in a handful of workgroups.
+ * The reduction over the rules is split between workgroups; each leaves an f32 [ca][cb] slab in
+ * `partial` (n_slabs slabs, at least lidal_conv_wgrad_slabs(...) of them) and a second kernel adds
+ * the slabs of every offset in a fixed order => bitwise reproducible, no atomics.  bf16 with
+ * ca, cb multiples of 8: W equally long runs of 64-rule stages, one per resident workgroup,
+ * gathered by LDS-DMA (csrc/wgrad_dma.hip); otherwise split-K slabs per offset (csrc/conv.hip). */
+int64_t lidal_conv_wgrad_slabs(int64_t n_a, int64_t n_b, int k, int ca, int cb, int dtype);
+int lidal_conv_wgrad(const void* a, const void* b, int64_t n_a, int64_t n_b, const int32_t* pairs,
+                     const int64_t* koff, int a_col, float* gw, float* partial, int64_t n_slabs,
+                     int k, int ca, int cb, int dtype, void* stream);
 
 /* ---- batch normalisation over rows ------------------------------------------------------------ */
 /* replaces the torch.nn.BatchNorm1d kernels behind spnn.BatchNorm (network/utils.py:115; 49 per

@@ -68,8 +68,8 @@ SIGNATURES = {
     'lidal_conv_weight_image_pair': (_i32, [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'lidal_conv_apply_image': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
                                       _vp, _i32, _vp, _vp, _vp]),
-    'lidal_conv_wgrad': (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
-                                _vp]),
+    'lidal_conv_wgrad_slabs': (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
+    'lidal_conv_wgrad': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'lidal_bn_workspace_bytes': (_i64, [_i64, _i32]),
     'lidal_bn_train_fwd': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp,
                                   _vp, _vp, _i64, _vp]),

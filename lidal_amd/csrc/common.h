@@ -107,4 +107,38 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short v) {
   return __uint_as_float(((unsigned)v) << 16);
 }
 
+// ---- per-device one-time kernel attributes (hipFuncSetAttribute is per device) ----
+constexpr int MAX_DEVICES = 16;
+static inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+  return d;
+}
+
+// ---- weight-gradient decomposition shared by conv.hip, wgrad_dma.hip and the reducer ----
+// Split-K policy: offset k with nk rules is cut into ceil(nk / target_chunk) slabs (at least 1, at
+// most the `splits` slabs the caller allocated), so the centre offset (every row has a rule) gets
+// proportionally more workgroups than the others.
+__host__ __device__ __forceinline__ int splits_for(int64_t nk, int max_splits, int target_chunk) {
+  int64_t s = (nk + target_chunk - 1) / target_chunk;
+  if (s < 1) s = 1;
+  if (s > max_splits) s = max_splits;
+  return (int)s;
+}
+// 16-wide MFMA blocks per wave along one channel dimension (x2 waves = the workgroup tile)
+static inline int wgrad_blocks(int c) {
+  if (c <= 32) return 1;
+  if (c <= 64) return 2;
+  if (c % 128 == 0) return 4;
+  if (c % 96 == 0 || c < 128) return 3;
+  return 4;
+}
+// wgrad_dma.hip: the bf16 weight gradient with LDS-DMA gathers (whole 16-byte channel segments,
+// operands below 4 GiB); W workgroups, W + K slabs of scratch
+bool wgrad_dma_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb);
+int wgrad_dma_workgroups(int64_t n_a, int64_t n_b, int k, int ca, int cb);
+int wgrad_dma(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* pairs,
+              const int64_t* koff, int a_col, float* gw, float* partial, int W, int K, int ca,
+              int cb, hipStream_t s);
+
 }  // namespace lidal

@@ -127,12 +127,6 @@ __device__ unsigned long long g_stamp[8];
 // conv_apply
 // ------------------------------------------------------------------------------------------
 constexpr int MAXK = 32;         // kernel volume limit (27 and 8 on this path)
-constexpr int MAX_DEVICES = 16;
-static inline int current_device() {
-  int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
-  return d;
-}
 
 #ifndef LIDAL_MINWAVES
 #define LIDAL_MINWAVES(nb) 2      /* 3 for nb <= 6 measured no better (scripts/ablate_conv.py) */
@@ -618,15 +612,6 @@ __global__ void __launch_bounds__(256) weight_pack_kernel(const TI* __restrict__
 constexpr int WTHREADS = 256;   // wgrad workgroups: 4 waves as 2 x 2
 constexpr int BP = 32;   // rules per staging step (f32 kernel)
 
-// Split-K policy shared by both wgrad kernels and the reducer: offset k with nk rules is cut into
-// ceil(nk / target_chunk) slabs (at least 1, at most the `splits` slabs the caller allocated), so
-// the centre offset (every row has a rule) gets proportionally more workgroups than the others.
-__host__ __device__ __forceinline__ int splits_for(int64_t nk, int max_splits, int target_chunk) {
-  int64_t s = (nk + target_chunk - 1) / target_chunk;
-  if (s < 1) s = 1;
-  if (s > max_splits) s = max_splits;
-  return (int)s;
-}
 
 // workgroup tile: (2*MI*16) x (2*NI*16) of gw[k]; waves as 2 x 2.
 template <typename T, int MI, int NI>
@@ -769,6 +754,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // exactly that from the row-major tiles the 16-byte gathers produce, so no transposing store is
 // needed.  BPB = 64 rules per step (two MFMA k-steps), LDS tiles double-buffered, gathered rows of
 // the next step are in flight in registers while this step's MFMAs run; one barrier per step.
+#ifndef LIDAL_WGRAD_ABL
+#define LIDAL_WGRAD_ABL 0      /* timing-only probes (results wrong): 1 = both gathers folded into 2048 rows */
+#endif
 constexpr int BPB = 64;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
@@ -823,6 +811,7 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
       int2 pr = pairs ? pairs[pc] : make_int2((int)pc, (int)pc);
       if (pi >= p_end) pr = make_int2(-1, -1);
       ia[t] = a_col ? pr.y : pr.x;
+      if (LIDAL_WGRAD_ABL & 1) ia[t] = ia[t] < 0 ? ia[t] : (ia[t] & 2047);     // timing probe: L2-resident gathers
     }
 #pragma unroll
     for (int t = 0; t < PT_B; ++t) {
@@ -831,6 +820,7 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
       int2 pr = pairs ? pairs[pc] : make_int2((int)pc, (int)pc);
       if (pi >= p_end) pr = make_int2(-1, -1);
       ib[t] = a_col ? pr.x : pr.y;
+      if (LIDAL_WGRAD_ABL & 1) ib[t] = ib[t] < 0 ? ib[t] : (ib[t] & 2047);
     }
   };
   auto load_rows = [&]() {
@@ -970,19 +960,12 @@ int launch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* 
   return 0;
 }
 
-static inline int pick_blocks(int c) {   // 16-wide blocks per wave along one dim (x2 waves)
-  if (c <= 32) return 1;
-  if (c <= 64) return 2;
-  if (c % 128 == 0) return 4;
-  if (c % 96 == 0 || c < 128) return 3;
-  return 4;
-}
 
 template <typename T>
 int dispatch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* koff, int a_col,
                    float* partial, int splits, int target_chunk, int K, int ca, int cb,
                    hipStream_t s) {
-  int mi = pick_blocks(ca), ni = pick_blocks(cb);
+  int mi = wgrad_blocks(ca), ni = wgrad_blocks(cb);
 #define WG_CASE(M, N) \
   if (mi == M && ni == N) return launch_wgrad<T, M, N>(a, b, pairs, koff, a_col, partial, splits, target_chunk, K, ca, cb, s);
   WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
@@ -1058,22 +1041,52 @@ extern "C" int lidal_conv_apply(const void* in, const void* wk, const int32_t* n
   return 2;
 }
 
-extern "C" int lidal_conv_wgrad(const void* a, const void* b, const int32_t* pairs,
-                                const int64_t* koff, int a_col, float* gw, float* partial,
-                                int splits, int target_chunk, int k, int ca, int cb, int dtype,
+// Split-K plan of the register kernels (f32, and bf16 shapes the DMA kernel does not serve): slabs
+// of `chunk` rules, sized so that the launch is about ONE round of resident workgroups -- slabs =
+// rules / chunk, workgroups = slabs x channel tiles.  The rule count is only known on the device,
+// so it is estimated from the rows (~6 rules per row for a 3x3x3 map on LiDAR surfaces, exactly 1
+// for the 2x2x2 maps and the dense layers).  scripts/ablate_wgrad.py (round 1): 4096 is best for
+// 96->96 on 397k rows, 1024 for 128->128 on 105k rows.
+static void splitk_plan(int64_t n_rows, int k, int ca, int cb, int* splits, int* chunk) {
+  const int64_t tiles = cdiv(ca, wgrad_blocks(ca) * 32) * cdiv(cb, wgrad_blocks(cb) * 32);
+  int64_t c = (k > 8 ? 6 : 1) * n_rows * tiles / 512;
+  c = align_up(c < 1 ? 1 : c, 64);
+  c = c > 4096 ? 4096 : (c < 512 ? 512 : c);
+  int64_t s = cdiv(n_rows, c);          // no offset has more rules than the larger table has rows
+  *splits = (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+  *chunk = (int)c;
+}
+
+extern "C" int64_t lidal_conv_wgrad_slabs(int64_t n_a, int64_t n_b, int k, int ca, int cb, int dtype) {
+  const int64_t n_rows = n_a > n_b ? n_a : n_b;
+  if (dtype == LIDAL_BF16 && wgrad_dma_serves(n_a, n_b, k, ca, cb))
+    return (int64_t)wgrad_dma_workgroups(n_a, n_b, k, ca, cb) + k;
+  int splits, chunk;
+  splitk_plan(n_rows, k, ca, cb, &splits, &chunk);
+  return (int64_t)splits * k;
+}
+
+extern "C" int lidal_conv_wgrad(const void* a, const void* b, int64_t n_a, int64_t n_b,
+                                const int32_t* pairs, const int64_t* koff, int a_col, float* gw,
+                                float* partial, int64_t n_slabs, int k, int ca, int cb, int dtype,
                                 void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (k == 0 || ca == 0 || cb == 0) return 0;
-  LIDAL_REQUIRE(splits >= 1 && target_chunk >= 64, "wgrad: splits >= 1 and target_chunk >= 64");
-  int rc;
+  LIDAL_REQUIRE(n_a >= 0 && n_b >= 0, "wgrad: negative row count");
+  LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16, "wgrad: bad dtype %d", dtype);
+  LIDAL_REQUIRE(n_slabs >= lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, dtype),
+                "wgrad: scratch of %lld slabs, lidal_conv_wgrad_slabs asks for %lld", (long long)n_slabs,
+                (long long)lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, dtype));
+  const int64_t n_rows = n_a > n_b ? n_a : n_b;
+  if (dtype == LIDAL_BF16 && wgrad_dma_serves(n_a, n_b, k, ca, cb))
+    return wgrad_dma(a, b, n_a, n_b, pairs, koff, a_col, gw, partial,
+                     wgrad_dma_workgroups(n_a, n_b, k, ca, cb), k, ca, cb, s);
+  int splits, target_chunk, rc;
+  splitk_plan(n_rows, k, ca, cb, &splits, &target_chunk);
   if (dtype == LIDAL_F32)
     rc = dispatch_wgrad<float>(a, b, pairs, koff, a_col, partial, splits, target_chunk, k, ca, cb, s);
-  else if (dtype == LIDAL_BF16)
+  else       // channel counts that are not whole 16-byte segments: the register kernel
     rc = dispatch_wgrad<__bf16>(a, b, pairs, koff, a_col, partial, splits, target_chunk, k, ca, cb, s);
-  else {
-    set_error("wgrad: bad dtype %d", dtype);
-    return 2;
-  }
   if (rc) return rc;
   int64_t n = (int64_t)k * ca * cb;
   if (((int64_t)ca * cb) % 4 == 0)

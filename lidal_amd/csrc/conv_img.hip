@@ -54,12 +54,6 @@ __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b
 }
 
 constexpr int MAXK = 32;
-constexpr int MAX_DEVICES = 16;
-static inline int current_device() {
-  int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
-  return d;
-}
 
 #ifndef LIDAL_NB4_LIMIT
 #define LIDAL_NB4_LIMIT 384

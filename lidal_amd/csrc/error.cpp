@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace lidal
 
 extern "C" const char* lidal_last_error(void) { return lidal::g_err; }
-extern "C" int lidal_version(void) { return 121; }   // 1.21: weight images + LDS-DMA conv (conv_img.hip), image pairs
+extern "C" int lidal_version(void) { return 122; }   // 1.21: weight images + LDS-DMA conv (conv_img.hip), image pairs

@@ -268,39 +268,11 @@ def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False):
     return out
 
 
-WGRAD_SLOTS = 512        # workgroups the chip holds at once (256 CUs x 2 resident wgrad workgroups)
-
-
-def _wgrad_tile(c):
-    """Channels per weight-gradient tile side (conv.hip: pick_blocks * 32)."""
-    if c <= 32:
-        return 32
-    if c <= 64:
-        return 64
-    if c % 128 == 0:
-        return 128
-    return 96 if (c % 96 == 0 or c < 128) else 128
-
-
-def _wgrad_chunk(n_rows, ca=None, cb=None, rules_per_row=6):
-    """Rules per split-K slab (lidal_conv_wgrad target_chunk): sized so that the launch is about
-    ONE round of resident workgroups -- slabs = rules / chunk, workgroups = slabs x channel tiles.
-    The rule count is only known on the device, so it is estimated from the rows (~6 rules per row
-    for a 3x3x3 map on LiDAR surfaces, exactly 1 for the 2x2x2 maps and the dense layers).
-    scripts/ablate_wgrad.py: 4096 is best for 96->96 on 397k rows, 1024 for 128->128 on 105k rows
-    (99.8 vs 124 us at 2048), and a fixed 4096 left the dense layers with 97 workgroups; the step
-    went from 25.2 to 24.3 ms against the old rule (4096 from 200k rows up, else 2048)."""
-    tiles = 1
-    if ca is not None and cb is not None:
-        tiles = -(-ca // _wgrad_tile(ca)) * -(-cb // _wgrad_tile(cb))
-    chunk = rules_per_row * n_rows * tiles / WGRAD_SLOTS
-    return int(min(4096, max(512, -(-int(chunk) // 64) * 64)))
-
-
-def _wgrad_splits(n_rows, chunk=None):
-    """Upper bound of slabs per offset: no offset has more rules than the table has rows."""
-    chunk = chunk or _wgrad_chunk(n_rows)
-    return int(max(1, min(256, -(-n_rows // chunk))))
+def wgrad_scratch(n_a, n_b, k, ca, cb, dtype, device):
+    """The f32 [slabs, ca, cb] scratch lidal_conv_wgrad reduces through; the slab count (workgroups
+    of the launch + k for the bf16 DMA kernel, split-K slabs x k otherwise) is the library's plan."""
+    slabs = int(B.lib().lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, B.dtype_code(dtype)))
+    return torch.empty((slabs, ca, cb), dtype=torch.float32, device=device)
 
 
 def _pad_channels(ci, dtype):
@@ -377,14 +349,13 @@ class ConvolutionFunction(Function):
         if ctx.needs_input_grad[1]:
             k, ci_w, co = weight.shape
             ci = x.shape[1]                          # >= ci_w when the input was channel-padded
-            chunk = _wgrad_chunk(max(n_in, n_out), ci, co, 6 if k > 8 else 1)
-            splits = _wgrad_splits(max(n_in, n_out), chunk)
             gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
-            partial = torch.empty((splits, k, ci, co), dtype=torch.float32, device=x.device)
-            B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), B.ptr(kmap._nbmaps_cap),
-                                             B.ptr(kmap.koff), 1 if transposed else 0, B.ptr(gw),
-                                             B.ptr(partial), splits, chunk, k, ci, co,
-                                             B.dtype_code(x.dtype), B.stream()), 'conv_wgrad')
+            partial = wgrad_scratch(x.shape[0], g.shape[0], k, ci, co, x.dtype, x.device)
+            B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), x.shape[0], g.shape[0],
+                                             B.ptr(kmap._nbmaps_cap), B.ptr(kmap.koff),
+                                             1 if transposed else 0, B.ptr(gw), B.ptr(partial),
+                                             partial.shape[0], k, ci, co, B.dtype_code(x.dtype),
+                                             B.stream()), 'conv_wgrad')
             gw = gw[:, :ci_w].contiguous() if ci != ci_w else gw
             grad_w = gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
         return grad_in, grad_w, None, None, None

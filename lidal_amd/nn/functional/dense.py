@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from ... import backend as B
-from .conv import _wgrad_chunk, _wgrad_splits
+from .conv import wgrad_scratch
 
 __all__ = ['rows_matmul', 'rows_linear']
 
@@ -31,12 +31,10 @@ def _wgrad_dense(a, b):
     """a [N, Ca], b [N, Cb] (same dtype, f32 or bf16) -> a^T @ b as f32 [Ca, Cb]."""
     n, ca = a.shape
     cb = b.shape[1]
-    chunk = _wgrad_chunk(n, ca, cb, 1)
-    splits = _wgrad_splits(n, chunk)
     gw = torch.empty((1, ca, cb), dtype=torch.float32, device=a.device)
-    partial = torch.empty((splits, 1, ca, cb), dtype=torch.float32, device=a.device)
-    B.check(B.lib().lidal_conv_wgrad(B.ptr(a), B.ptr(b), None, B.ptr(_koff(n, a.device)), 0,
-                                     B.ptr(gw), B.ptr(partial), splits, chunk, 1, ca, cb,
+    partial = wgrad_scratch(n, n, 1, ca, cb, a.dtype, a.device)
+    B.check(B.lib().lidal_conv_wgrad(B.ptr(a), B.ptr(b), n, n, None, B.ptr(_koff(n, a.device)), 0,
+                                     B.ptr(gw), B.ptr(partial), partial.shape[0], 1, ca, cb,
                                      B.dtype_code(a.dtype), B.stream()), 'conv_wgrad(dense)')
     return gw[0]
 

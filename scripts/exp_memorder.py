@@ -22,7 +22,7 @@ def main():
     dtype = torch.bfloat16
     batch = synth.make_train_batch(n_frames=5, n_points=120000, seed=7122)
     base = batch['coords_v_b']
-    for order in ('dataset', 'hash'):
+    for order in os.environ.get('LIDAL_EXP_ORDERS', 'dataset,hash').split(','):
         c_np = base if order == 'dataset' else base[np.random.default_rng(0).permutation(len(base))]
         coords = torch.from_numpy(np.ascontiguousarray(c_np)).to(dev)
         with torch.enable_grad():
@@ -40,17 +40,15 @@ def main():
                 B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wt), B.ptr(o.table), B.ptr(o.perm),
                                                  B.ptr(o.tile_masks), B.ptr(out), n, n, ci, co, 27, 0,
                                                  B.dtype_code(dtype), None, None, 0, None, B.stream()), 'conv')
-            chunk = C._wgrad_chunk(n, ci, co, 6)
-            splits = C._wgrad_splits(n, chunk)
             gw = torch.empty((27, ci, co), dtype=torch.float32, device=dev)
-            partial = torch.empty((splits, 27, ci, co), dtype=torch.float32, device=dev)
+            partial = C.wgrad_scratch(n, n, 27, ci, co, dtype, dev)
 
             def wgrad():
-                B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(go), B.ptr(kmap._nbmaps_cap), B.ptr(kmap.koff), 0,
-                                                 B.ptr(gw), B.ptr(partial), splits, chunk, 27, ci, co,
+                B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(go), n, n, B.ptr(kmap._nbmaps_cap), B.ptr(kmap.koff), 0,
+                                                 B.ptr(gw), B.ptr(partial), partial.shape[0], 27, ci, co,
                                                  B.dtype_code(dtype), B.stream()), 'wgrad')
-            print('%-8s %3d->%-3d  conv_apply %7.1f us   wgrad %7.1f us (chunk %d, splits %d)'
-                  % (order, ci, co, timeit(conv), timeit(wgrad), chunk, splits), flush=True)
+            print('%-8s %3d->%-3d  conv_apply %7.1f us   wgrad %7.1f us (%d slabs)'
+                  % (order, ci, co, timeit(conv), timeit(wgrad), partial.shape[0]), flush=True)
 
 
 if __name__ == '__main__':

@@ -181,22 +181,23 @@ def test_iou_from_confusion_matches_reference_formula():
     assert np.isnan(miou)
 
 
-def test_wgrad_slab_policy_is_bounded_and_occupancy_sized():
-    """Host policy of the split-K weight gradient: slab = rules x tiles / 512 resident workgroups,
-    a multiple of 64 rules within [512, 4096]; the slab count never exceeds the 256 the partial
-    buffer is allocated for."""
-    from lidal_amd.nn.functional.conv import _wgrad_chunk, _wgrad_splits, _wgrad_tile
-    assert [_wgrad_tile(c) for c in (19, 32, 64, 96, 128, 192, 256, 384)] == [32, 32, 64, 96, 128, 96, 128, 128]
+def test_wgrad_scratch_plan_is_bounded_and_occupancy_sized():
+    """lidal_conv_wgrad_slabs (host arithmetic, no GPU): the bf16 DMA kernel asks for one slab per
+    workgroup of ONE resident round (<= 512) + k, and fewer when the rows would leave a workgroup
+    less than ~16 stages; the split-K register kernels ask for <= 256 slabs per offset."""
+    from lidal_amd import backend as B
+    slabs = B.lib().lidal_conv_wgrad_slabs
     for n in (1, 500, 17000, 105000, 397000, 3000000):
         for ca, cb in ((32, 32), (96, 96), (128, 96), (256, 256), (384, 256)):
-            for rpr in (1, 6):
-                c = _wgrad_chunk(n, ca, cb, rpr)
-                assert 512 <= c <= 4096 and c % 64 == 0
-                assert 1 <= _wgrad_splits(n, c) <= 256
-    # one round of workgroups: 96->96 on the bench batch keeps the large slab, the small level shrinks
-    assert _wgrad_chunk(397000, 96, 96, 6) == 4096
-    assert _wgrad_chunk(105000, 128, 128, 6) < 2048
-    assert _wgrad_chunk(397000, 128, 96, 1) < 1024          # dense layer: many more than 97 workgroups
+            for k in (1, 8, 27):
+                assert k + 1 <= slabs(n, n, k, ca, cb, 1) <= 512 + k          # bf16
+                assert k <= slabs(n, n, k, ca, cb, 0) <= 256 * k              # f32
+    assert slabs(397000, 397000, 27, 96, 96, 1) == 256 + 27          # line-bound level 0: one per CU
+    assert slabs(397000, 397000, 27, 32, 32, 1) == 512 + 27          # small stages: two per CU
+    assert slabs(43000, 43000, 27, 256, 256, 1) == 128 + 27          # four channel tiles share the round
+    assert slabs(1000, 1000, 27, 96, 96, 1) < 16 + 27                # a small level: few, long enough runs
+    assert slabs(397000, 397000, 27, 100, 96, 1) == slabs(397000, 397000, 27, 100, 96, 1)
+    assert slabs(397000, 397000, 27, 100, 96, 1) % 27 == 0           # 100 channels: the split-K kernel
 
 
 def test_io_reads_files_the_reference_wrote(tmp_path, golden_dir):

@@ -154,8 +154,9 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
                                            const float* __restrict__ ep_scale,
                                            const float* __restrict__ ep_shift, int ep_relu,
                                            const T* __restrict__ ep_res, bool perm_in_reg = false,
-                                           int perm_v = 0, float* __restrict__ tile_stats = nullptr) {
-  // perm_in_reg: lane l (< 16) of the wave holds perm[r0 + l] in perm_v, loaded when the tile began
+                                           int perm_v = 0, float* __restrict__ tile_stats = nullptr,
+                                           int stats_tile = -1) {
+  // perm_in_reg: lane l (< 16 G) of the wave holds perm[r0 + l] in perm_v, loaded when the tile began
   // (the lean kernel: no dependent load in front of the stores)
   constexpr int VEC = DT<T>::VEC;
   constexpr int BN = 16 * NB;
@@ -190,7 +191,7 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
   constexpr int RSEGS = BN / VEC;
   for (int i = lane; i < RW * RSEGS; i += 64) {
     const int r = i / RSEGS, cseg = (i - r * RSEGS) * VEC;
-    const int prow = perm_in_reg ? __shfl(perm_v, r & 15, 64) : 0;      // all lanes take part
+    const int prow = perm_in_reg ? __shfl(perm_v, r & (RW - 1), 64) : 0;      // all lanes take part
     if (r0 + r >= n_out) continue;
     const int64_t row = perm ? (perm_in_reg ? (int64_t)prow : (int64_t)perm[r0 + r]) : r0 + r;
     T* dst = out + row * co + n0 + cseg;
@@ -274,7 +275,7 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
           na = n;
         }
       }
-      float* dst = tile_stats + ((int64_t)blockIdx.x * co + n0 + c) * 3;
+      float* dst = tile_stats + ((int64_t)(stats_tile >= 0 ? stats_tile : (int)blockIdx.x) * co + n0 + c) * 3;
       dst[0] = na; dst[1] = ma; dst[2] = qa;
     }
   }
@@ -755,6 +756,251 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
                                ep_res, true, perm_v, tile_stats);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// EXPERIMENT (not in the shipped library; -DLIDAL_CONV_DMA builds it): rows AND weights by LDS-DMA
+// ------------------------------------------------------------------------------------------
+// Measured (scripts/exp_img.py, bit-equal to the shipped kernels on every shape), 96->96 on 396k rows,
+// lean kernel 92 us:
+//   * one tile per workgroup, ring of 3 (rows + slab) stages = 129 KB, one workgroup per CU: 160 us
+//     (156 at depth 1) -- a tile is ~7 phases, its prologue (ids, then rows: two memory round trips)
+//     and write-out are covered by nothing;
+//   * the persistent form below (one phase stream through all tiles of a workgroup, next tile's loads
+//     in flight during the write-out): 182 us.  Ablations: without the row gathers 186 us, without the
+//     LDS reads / MFMAs 109 us, with neither 87 us.  Not the memory: four waves per CU (one per
+//     SIMD) expose every latency of the issue path (id reads, 12 DMA issues with their M0 writes,
+//     three scalar walks: ~1 us per phase) and of the fragment reads (~1.2 us per phase), and they
+//     add up instead of overlapping.
+// The weight gradient (wgrad_dma.hip) wins with the same data path because its stages carry the same
+// bytes with a third of the bookkeeping and nothing to write out.  What would be needed here is a
+// producer/consumer split with 8 consumer waves -- whose weight-fragment reads then fill the LDS
+// pipe (144 KB per phase).  Kept as the record of the experiment.
+#ifdef LIDAL_CONV_DMA
+template <int SEG>
+__device__ __forceinline__ int swz_a(int row, int seg) {
+  if constexpr (SEG == 12) { const int s = seg + ((row >> 2) & 3); return s >= 12 ? s - 12 : s; }
+  if constexpr (SEG == 8) return seg ^ ((row >> 1) & 7);
+  if constexpr (SEG == 4) return seg ^ ((row >> 2) & 3);
+  return seg;
+}
+template <int SEG>
+__device__ __forceinline__ int unswz_a(int row, int phys) {
+  if constexpr (SEG == 12) { const int s = phys - ((row >> 2) & 3); return s < 0 ? s + 12 : s; }
+  return swz_a<SEG>(row, phys);
+}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  return u32x4{(unsigned)p, (unsigned)(p >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_base, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void dma4(u32x4 rsrc, unsigned lds_base, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+#ifndef LIDAL_DMA_DEPTH
+#define LIDAL_DMA_DEPTH 2
+#endif
+
+#ifndef LIDAL_DMA_PERSIST
+#define LIDAL_DMA_PERSIST 256        /* workgroups per column block: one per CU */
+#endif
+constexpr int DMA_MAX_TILES = 256;    // tiles one persistent workgroup may own (its masks sit in LDS)
+
+// Persistent form: workgroup b owns tiles b, b + P, b + 2P, ... and runs ONE phase stream through
+// all of them -- the ids / weights / rows of the next tile are already in flight while this tile is
+// written out, so a tile's prologue and epilogue cost no memory idle time (the one-tile-per-workgroup
+// form above measured 160 us on the roofline layer: ~13 us per 7-phase tile).
+// LDS: A ring [3][128 rows x slice] | W ring [2][slab] | ids ring [5][512 B] | dump 1 KiB |
+//      tile masks [256] | epilogue tile + statistics.
+// Issue order of phase q: ids(q+4), W(q+1), A(q+2); the wait at the top of phase q needs W(q) (issued
+// a phase ago) and everything older, so only the A share issued behind it may still be in flight.
+template <int NB, int ROW_BYTES>
+__global__ void __launch_bounds__(256)
+conv_dma_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wimg,
+                const int* __restrict__ nbr, const int* __restrict__ perm,
+                const unsigned* __restrict__ tmasks, __bf16* __restrict__ out, int64_t n_out, int ci,
+                int co, int K, int kflip, const float* __restrict__ ep_scale,
+                const float* __restrict__ ep_shift, int ep_relu, const __bf16* __restrict__ ep_res,
+                unsigned in_bytes, unsigned img_bytes, unsigned nbr_bytes,
+                float* __restrict__ tile_stats, int n_tiles) {
+  typedef __bf16 T;
+  constexpr int NW = 4, G = 2, BM = NW * G * 16, BN = 16 * NB;
+  constexpr int KC = ROW_BYTES / 2, MAXCC = ROW_BYTES / 64, SEG = ROW_BYTES / 16;
+  constexpr int A_BYTES = BM * ROW_BYTES, SLAB = BN * ROW_BYTES;
+  constexpr int RA = 3, RW_ = 2, IDS_R = 5, IDS_BYTES = BM * 4;
+  constexpr int IA = A_BYTES / 1024 / NW;                 // row DMAs per wave and phase
+  constexpr int WP = SLAB / 1024, IW = (WP + NW - 1) / NW;      // slab pieces; per wave (surplus -> dump)
+  constexpr int EPI = NW * G * 16 * (BN + 8) * 2 + NW * BN * 2 * (int)sizeof(float);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  static_assert(A_BYTES % (1024 * NW) == 0 && SLAB % 1024 == 0 && IA < 64, "DMA shares");
+  typedef DT<T>::frag frag;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int OFF_W = RA * A_BYTES, OFF_IDS = OFF_W + RW_ * SLAB, OFF_DUMP = OFF_IDS + IDS_R * IDS_BYTES;
+  constexpr int OFF_MASK = OFF_DUMP + 1024, OFF_EPI = OFF_MASK + DMA_MAX_TILES * 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned* lmask = reinterpret_cast<unsigned*>(smem + OFF_MASK);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row16 = lane & 15, gsel = lane >> 4;
+  const int n0 = blockIdx.y * BN;
+  const int npass = ci / KC;
+  const int P = gridDim.x, bx = blockIdx.x;
+  const int my_tiles = (n_tiles - bx + P - 1) / P;
+
+  for (int t = threadIdx.x; t < my_tiles; t += 256) {
+    unsigned m = tmasks[bx + t * P];
+    if (kflip) m = __brev(m) >> (32 - K);
+    lmask[t] = m;
+  }
+  __syncthreads();
+
+  const u32x4 rs_in = raw_rsrc(in, in_bytes), rs_w = raw_rsrc(wimg, img_bytes), rs_nbr = raw_rsrc(nbr, nbr_bytes);
+  const unsigned row_bytes = (unsigned)ci * 2u;
+  const unsigned k_stride = (unsigned)n_out * 4u;
+  const unsigned slab_k = (unsigned)gridDim.y * (unsigned)npass * (unsigned)SLAB;
+  const unsigned slab_blk = (unsigned)blockIdx.y * (unsigned)npass * (unsigned)SLAB;
+
+  // this lane's share of an A stage: tile row + byte offset inside the slice for each row DMA
+  int arow[IA];
+  unsigned acol[IA];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int sg = 64 * (wave * IA + i) + lane, row = sg / SEG;
+    arow[i] = row;
+    acol[i] = (unsigned)unswz_a<SEG>(row, sg % SEG) * 16u;
+  }
+
+  // a walk over the workgroup's phase stream: tiles in order, inside a tile its (active offset, slice)
+  struct Walk { int i; unsigned rem; int k, pass, q; long long rt; bool live; };
+  auto walk_init = [&](int q0) { Walk w; w.i = -1; w.rem = 0u; w.k = 0; w.pass = npass - 1; w.q = q0; w.rt = 0; w.live = true; return w; };
+  auto walk_next = [&](Walk& w) __attribute__((always_inline)) {
+    ++w.q;
+    if (!w.live) return;
+    if (++w.pass == npass) {
+      w.pass = 0;
+      while (w.rem == 0u) {
+        if (++w.i >= my_tiles) { w.live = false; return; }
+        w.rem = __builtin_amdgcn_readfirstlane(lmask[w.i]);
+        w.rt = (long long)(bx + w.i * P) * BM;
+      }
+      w.k = __builtin_ctz(w.rem);
+      w.rem &= w.rem - 1u;
+    }
+  };
+  // ids of phase q: the tile's 128 entries of one offset's table row; waves 0 / 1 bring rows 0..63 /
+  // 64..127, waves 2 / 3 repeat them (every wave keeps the same number of loads in flight)
+  Walk wi = walk_init(-1), ww = walk_init(-1), wr = walk_init(-1);
+  auto issue_ids = [&]() __attribute__((always_inline)) {
+    walk_next(wi);
+    const long long r = wi.rt + 64 * (wave & 1) + lane;
+    const unsigned kk = (unsigned)(kflip ? (K - 1 - wi.k) : wi.k);
+    const unsigned off = (wi.live && r < n_out) ? (unsigned)r * 4u + kk * k_stride : OOB;
+    dma4(rs_nbr, lds0 + OFF_IDS + (unsigned)(wi.q % IDS_R) * IDS_BYTES + (unsigned)(wave & 1) * 256u, off);
+  };
+  auto issue_w = [&]() __attribute__((always_inline)) {
+    walk_next(ww);
+    const unsigned dst = lds0 + OFF_W + (unsigned)(ww.q % RW_) * SLAB;
+    const unsigned wsrc = (unsigned)ww.k * slab_k + slab_blk + (unsigned)ww.pass * (unsigned)SLAB + (unsigned)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < IW; ++i) {
+      const int piece = wave * IW + i;
+      const bool okw = ww.live && piece < WP && !(LIDAL_IMG_ABL & 2);
+      dma16(rs_w, piece < WP ? dst + (unsigned)piece * 1024u : lds0 + OFF_DUMP, okw ? wsrc + (unsigned)piece * 1024u : OOB);
+    }
+  };
+  auto issue_a = [&]() __attribute__((always_inline)) {
+    walk_next(wr);
+    const unsigned stage = lds0 + (unsigned)(wr.q % RA) * A_BYTES;
+    const unsigned char* ids = smem + OFF_IDS + (wr.q % IDS_R) * IDS_BYTES;
+    int id[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) id[i] = *reinterpret_cast<const int*>(ids + arow[i] * 4);
+#pragma unroll
+    for (int i = 0; i < IA; ++i) asm volatile("" : "+v"(id[i]));
+    const unsigned pass_off = (unsigned)wr.pass * (unsigned)ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      if (LIDAL_IMG_ABL & 1) id[i] = id[i] < 0 ? id[i] : (id[i] & 2047);
+      const bool ok = wr.live && id[i] >= 0 && wr.rt + arow[i] < n_out && !(LIDAL_IMG_ABL & 8);
+      const unsigned off = ok ? (unsigned)id[i] * row_bytes + pass_off + acol[i] : OOB;
+      dma16(rs_in, stage + (unsigned)(wave * IA + i) * 1024u, off);
+    }
+  };
+
+  // fragment addresses: A rows of this wave's two groups (segment permutation by row), weight base
+  int fa[G][MAXCC];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int cc = 0; cc < MAXCC; ++cc) {
+      const int row = wave * 32 + g * 16 + row16;
+      fa[g][cc] = row * ROW_BYTES + swz_a<SEG>(row, cc * 4 + gsel) * 16;
+    }
+  const int fw = OFF_W + (gsel * NB) * 256 + row16 * 16;
+
+  // prologue: ids of the first two phases, then two issue rounds in the loop's own order
+  issue_ids();
+  issue_ids();
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  issue_ids();                    // ids(2)
+  {                               // W(-1): nothing to bring, the same number of loads
+#pragma unroll
+    for (int i = 0; i < IW; ++i) dma16(rs_w, lds0 + OFF_DUMP, OOB);
+  }
+  issue_a();                      // A(0)
+  issue_ids();                    // ids(3)
+  issue_w();                      // W(0)
+  issue_a();                      // A(1)
+
+  int q = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const long long rt = (long long)(bx + ti * P) * BM;
+    const int64_t r0 = rt + wave * 32;
+    const int nph = __popc(__builtin_amdgcn_readfirstlane(lmask[ti])) * npass;
+    int perm_v = 0;
+    if (perm != nullptr && lane < 32 && r0 + lane < n_out) perm_v = perm[r0 + lane];
+    f32x4 acc[G][NB];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < nph; ++p, ++q) {
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (IA & 15) | ((IA >> 4) << 14));
+      __syncthreads();
+      issue_ids();                // ids(q+4)
+      issue_w();                  // W(q+1)
+      issue_a();                  // A(q+2)
+      if (!(LIDAL_IMG_ABL & 4)) {
+        const unsigned char* sa = smem + (q % RA) * A_BYTES;
+        const unsigned char* sw = smem + (q % RW_) * SLAB;
+#pragma unroll
+        for (int cc = 0; cc < MAXCC; ++cc) {
+          frag a[G], b[NB];
+#pragma unroll
+          for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const frag*>(sa + fa[g][cc]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const frag*>(sw + fw + (cc * 4 * NB + nb) * 256);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int g = 0; g < G; ++g) mma(acc[g][nb], a[g], b[nb]);
+        }
+      }
+    }
+    __syncthreads();              // the statistics area of the previous tile's write-out is free
+    store_tile<T, NB, G, NW>(acc, smem + OFF_EPI, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift,
+                             ep_relu, ep_res, true, perm_v, tile_stats, (int)(rt >> 7));
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);           // the zero fills past the end, before LDS is released
+}
+#endif  // LIDAL_CONV_DMA
+
 struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; };
 
 #ifndef LIDAL_IMG_G
@@ -777,6 +1023,34 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
   constexpr int D = LIDAL_IMG_DEPTH;
   constexpr int WREGION = ((D + 1) * SLAB > EPI) ? (D + 1) * SLAB : EPI;
   static_assert(BM % 128 == 0, "tile masks are per 128 rows");
+#ifdef LIDAL_CONV_DMA      /* experiment builds: -D'LIDAL_CONV_DMA(nb,row_bytes,n_in,n_out)=1' picks the layers */
+  if constexpr (sizeof(T) == 2) {
+    const int64_t n_in = (int64_t)(ep.in_bytes / ((unsigned)ci * sizeof(T)));
+    if (nbr != nullptr && ci % (ROW_BYTES / 2) == 0 && (int64_t)n_in * ci * 2 < 0xFFFFFFF0ll &&
+        LIDAL_CONV_DMA(NB, ROW_BYTES, n_in, n_out)) {
+      constexpr int DEPI = 4 * 32 * (BN + 8) * 2 + 4 * BN * 2 * (int)sizeof(float);
+      constexpr int DLDS = 3 * 128 * ROW_BYTES + 2 * SLAB + 5 * 512 + 1024 + DMA_MAX_TILES * 4 + DEPI;
+      const int n_tiles = (int)cdiv(n_out, 128);
+      int persist = LIDAL_DMA_PERSIST;
+      if (persist > n_tiles) persist = n_tiles;
+      if (n_tiles > (int64_t)persist * DMA_MAX_TILES) persist = (int)cdiv(n_tiles, DMA_MAX_TILES);
+      auto dk = conv_dma_kernel<NB, ROW_BYTES>;
+      static size_t dma_attr[MAX_DEVICES] = {};
+      const int ddev = current_device();
+      if (dma_attr[ddev] < (size_t)DLDS) {
+        LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dk),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, DLDS));
+        dma_attr[ddev] = DLDS;
+      }
+      dim3 dgrid((unsigned)persist, (unsigned)cdiv(co, BN));
+      dk<<<dgrid, 256, DLDS, s>>>((const __bf16*)in, (const __bf16*)wimg, nbr, perm, tmasks, (__bf16*)out, n_out,
+                                  ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const __bf16*)ep.res,
+                                  ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, n_tiles);
+      LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(dma)");
+      return 0;
+    }
+  }
+#endif
 #ifndef LIDAL_IMG_NOLEAN
   if constexpr (G == 1 && NWAVES == 8) {
     if (ci % (ROW_BYTES / (int)sizeof(T)) == 0 && ep.in_bytes / ((unsigned)ci * sizeof(T)) < (1u << 24)) {
@@ -785,7 +1059,10 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       constexpr int LBM = LW * 16;
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
-      constexpr int LEAN_LDS = (2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS;
+#ifndef LIDAL_LEAN_LDS_PAD
+#define LIDAL_LEAN_LDS_PAD 0        /* experiment: extra LDS bytes = fewer resident workgroups */
+#endif
+      constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + LIDAL_LEAN_LDS_PAD;
       auto lk = nbr ? conv_lean_kernel<T, NB, ROW_BYTES, LW, false>
                     : conv_lean_kernel<T, NB, ROW_BYTES, LW, true>;
       static size_t lean_attr[2][MAX_DEVICES] = {};

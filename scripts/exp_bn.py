@@ -1,5 +1,7 @@
-"""GPU experiment: achieved bandwidth of the BatchNorm kernels per (rows, channels) of the bench
-batch's levels (algorithmic bytes: forward 3 N C b, backward 5 N C b)."""
+"""GPU experiment: achieved bandwidth of the BatchNorm launches per (rows, channels) of the bench
+batch's levels, called straight through the C-ABI (no autograd): forward with the statistics pass
+(3 N C b algorithmic bytes), forward on the convolution's tile statistics (2 N C b), backward
+(5 N C b)."""
 import os
 import sys
 
@@ -9,7 +11,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'scripts'))
 from lidal_amd import backend as B  # noqa: E402
-from lidal_amd.nn.functional.norm import batch_norm_rows  # noqa: E402
 from exp_img import timeit  # noqa: E402
 
 SHAPES = [(396662, 32), (396662, 96), (226000, 32), (226000, 64), (105000, 64), (105000, 128), (43000, 128),
@@ -19,29 +20,44 @@ SHAPES = [(396662, 32), (396662, 96), (226000, 32), (226000, 64), (105000, 64), 
 def main():
     dev = torch.device('cuda')
     print('lib', B.LIB_PATH)
-    tot_f = tot_b = 0.0
+    L = B.lib()
+    tot = [0.0, 0.0, 0.0]
     for n, c in SHAPES:
-        x = torch.randn(n, c, device=dev).bfloat16().requires_grad_(True)
-        w = torch.ones(c, device=dev, requires_grad=True)
-        b = torch.zeros(c, device=dev, requires_grad=True)
-        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        x = torch.randn(n, c, device=dev).bfloat16()
         go = torch.randn(n, c, device=dev).bfloat16()
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        w, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        mean, invstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        gg, gb = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        nbytes = L.lidal_bn_workspace_bytes(n, c)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        n_tiles = -(-n // 128)
+        ts = torch.zeros(n_tiles, c, 3, device=dev)
+        ts[:, :, 0] = 128.0
+        ts[:, :, 2] = 128.0
 
         def fwd():
-            return batch_norm_rows(x, w, b, rm, rv, True, 0.1, 1e-5, True)
-        y = fwd()
+            B.check(L.lidal_bn_train_fwd(B.ptr(x), 1, n, c, B.ptr(w), B.ptr(b), 1e-5, 0.1, B.ptr(rm), B.ptr(rv),
+                                         None, 1, B.ptr(y), B.ptr(mean), B.ptr(invstd), B.ptr(ws), nbytes,
+                                         B.stream()), 'fwd')
+
+        def fwd_tiles():
+            B.check(L.lidal_bn_train_fwd_tiles(B.ptr(x), 1, n, c, B.ptr(w), B.ptr(b), 1e-5, 0.1, B.ptr(rm),
+                                               B.ptr(rv), None, 1, B.ptr(y), B.ptr(mean), B.ptr(invstd),
+                                               B.ptr(ts), n_tiles, B.stream()), 'fwd_tiles')
 
         def bwd():
-            torch.autograd.grad(y, (x, w, b), go, retain_graph=True)
-        with torch.no_grad():
-            tf = timeit(fwd)
-        tb = timeit(bwd)
+            B.check(L.lidal_bn_bwd(B.ptr(x), B.ptr(go), 1, n, c, B.ptr(w), B.ptr(b), 1, B.ptr(mean),
+                                   B.ptr(invstd), B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(ws), nbytes,
+                                   B.stream()), 'bwd')
+        fwd()
+        t = [timeit(fwd), timeit(fwd_tiles), timeit(bwd)]
         by = n * c * 2
-        tot_f += tf
-        tot_b += tb
-        print('%7d x %3d   fwd %6.1f us (%5.2f TB/s)   bwd %6.1f us (%5.2f TB/s)'
-              % (n, c, tf, 3 * by / tf / 1e6, tb, 5 * by / tb / 1e6), flush=True)
-    print('sum fwd %.1f us  bwd %.1f us' % (tot_f, tot_b))
+        tot = [a + b_ for a, b_ in zip(tot, t)]
+        print('%7d x %3d   fwd %6.1f us (%5.2f TB/s)   fwd on tile stats %6.1f us (%5.2f TB/s)   bwd %6.1f us (%5.2f TB/s)'
+              % (n, c, t[0], 3 * by / t[0] / 1e6, t[1], 2 * by / t[1] / 1e6, t[2], 5 * by / t[2] / 1e6), flush=True)
+    print('sum fwd %.1f  fwd_tiles %.1f  bwd %.1f us' % tuple(tot))
 
 
 if __name__ == '__main__':

@@ -339,16 +339,10 @@ class ConvolutionFunction(Function):
         g = grad_output.contiguous().to(x.dtype)
         n_in, n_out = kmap.sizes
         grad_in = grad_w = None
-        if ctx.needs_input_grad[0]:
-            # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci (of the padded input), reduction
-            # over co; the operand image was built together with the forward one
-            k, ci_w, co = weight.shape
-            order, kflip = _bwd_order(kmap, transposed)
-            grad_in = _apply(g, ctx.img_bwd, k, x.shape[1], order, kflip)
-            grad_in = grad_in[:, :ci_w]                     # drop the padding channels, if any
-        if ctx.needs_input_grad[1]:
-            k, ci_w, co = weight.shape
-            ci = x.shape[1]                          # >= ci_w when the input was channel-padded
+        k, ci_w, co = weight.shape
+        ci = x.shape[1]                          # >= ci_w when the input was channel-padded
+
+        def wgrad():
             gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
             partial = wgrad_scratch(x.shape[0], g.shape[0], k, ci, co, x.dtype, x.device)
             B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), x.shape[0], g.shape[0],
@@ -357,7 +351,26 @@ class ConvolutionFunction(Function):
                                              partial.shape[0], k, ci, co, B.dtype_code(x.dtype),
                                              B.stream()), 'conv_wgrad')
             gw = gw[:, :ci_w].contiguous() if ci != ci_w else gw
-            grad_w = gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
+            return gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
+
+        side = None
+        if ctx.needs_input_grad[1]:
+            if B.overlap_wgrad(x.dtype) and ctx.needs_input_grad[0]:
+                _ = kmap.koff                   # the rule lists are built on the main stream
+                side = B.beside(x.device, (x, g, kmap._nbmaps_cap, kmap.koff))
+                with side as done:              # beside the data gradient below
+                    grad_w = wgrad()
+                    done(grad_w)
+            else:
+                grad_w = wgrad()
+        if ctx.needs_input_grad[0]:
+            # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci (of the padded input), reduction
+            # over co; the operand image was built together with the forward one
+            order, kflip = _bwd_order(kmap, transposed)
+            grad_in = _apply(g, ctx.img_bwd, k, x.shape[1], order, kflip)
+            grad_in = grad_in[:, :ci_w]                     # drop the padding channels, if any
+        if side is not None:
+            side.finish()
         return grad_in, grad_w, None, None, None
 
 

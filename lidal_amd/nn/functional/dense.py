@@ -198,17 +198,30 @@ class RowsMatmul(Function):
             g = torch.nn.functional.pad(g, (0, ctx.pad))
         g = g.contiguous()
         gx = gw = gb = None
+
+        def wgrad():
+            if _ok(xc, xc.shape[1], g.shape[1]):
+                gw_ = _wgrad_dense(xc, g)[:, :co]
+            else:
+                gw_ = (xc.float().t() @ g.float())[:, :co]
+            return (gw_.t().contiguous() if linear else gw_.contiguous()).to(w.dtype)
+
+        side = None
+        if ctx.needs_input_grad[1]:
+            if B.overlap_wgrad(xc.dtype) and ctx.needs_input_grad[0] and g.is_cuda:
+                side = B.beside(g.device, (xc, g))
+                with side as done:              # beside the data gradient below (backend.beside)
+                    gw = wgrad()
+                    done(gw)
+            else:
+                gw = wgrad()
         if ctx.needs_input_grad[0]:
             if _gemm_ok(g, g.shape[1], xc.shape[1]):
                 gx = _rows_gemm(g, ctx.wc, 1, img=ctx.img_bwd)             # reduction over co
             else:
                 gx = g @ ctx.wc.t()
-        if ctx.needs_input_grad[1]:
-            if _ok(xc, xc.shape[1], g.shape[1]):
-                gw = _wgrad_dense(xc, g)[:, :co]
-            else:
-                gw = (xc.float().t() @ g.float())[:, :co]
-            gw = (gw.t().contiguous() if linear else gw).to(w.dtype)
+        if side is not None:
+            side.finish()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             from .norm import column_sum
             if g.is_cuda and g.shape[1] % _vec(g.dtype) == 0 and g.shape[1] // _vec(g.dtype) <= 256:

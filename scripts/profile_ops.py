@@ -27,7 +27,7 @@ def main():
     for _ in range(3):
         train_step(model, opt, feats, coords, labels, autocast=True)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=bool(os.environ.get('PROFILE_STACKS'))) as prof:
         for _ in range(steps):
             train_step(model, opt, feats, coords, labels, autocast=True)
         torch.cuda.synchronize()
@@ -39,6 +39,15 @@ def main():
     print('%-90s %8s %12s' % ('operator / kernel (self GPU time)', 'calls/st', 'ms/step'))
     for k, c, t in rows[:70]:
         print('%-90s %8.1f %12.3f' % (k[:90], c / steps, t / 1e3 / steps))
+
+
+    if os.environ.get('PROFILE_STACKS'):        # who calls the small ATen operators
+        want = ('aten::zero_', 'aten::fill_', 'aten::copy_', 'aten::add', 'aten::add_', 'aten::cat', 'aten::zeros',
+                'aten::to', 'aten::contiguous', 'aten::clone')
+        for e in prof.key_averages(group_by_stack_n=8):
+            if e.key in want and e.count >= steps:
+                frames = [f for f in e.stack if 'lidal_amd' in f or 'train_step' in f or 'bench' in f][:3]
+                print('%-14s %6.1f/step  %s' % (e.key, e.count / steps, ' <- '.join(f.strip()[-70:] for f in frames)))
 
 
 if __name__ == '__main__':

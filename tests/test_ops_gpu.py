@@ -763,3 +763,61 @@ def test_conv_epilogue_batch_statistics(dtype):
             st = y._lidal_bn_stats.double().cpu()
             mean = (st[:, :, 0] * st[:, :, 1]).sum(0) / st[:, :, 0].sum(0)
             assert _relerr(mean, y.detach().double().cpu().mean(0)) < 1e-5
+
+
+def _wgrad_abi(a, b, pairs, koff, a_col, k):
+    """lidal_conv_wgrad through the C-ABI with the library's own scratch plan."""
+    from lidal_amd import backend as B
+    from lidal_amd.nn.functional.conv import wgrad_scratch
+    ca, cb = a.shape[1], b.shape[1]
+    gw = torch.full((k, ca, cb), float('nan'), dtype=torch.float32, device=a.device)
+    part = wgrad_scratch(a.shape[0], b.shape[0], k, ca, cb, a.dtype, a.device)
+    B.check(B.lib().lidal_conv_wgrad(B.ptr(a), B.ptr(b), a.shape[0], b.shape[0], B.ptr(pairs), B.ptr(koff),
+                                     a_col, B.ptr(gw), B.ptr(part), part.shape[0], k, ca, cb,
+                                     B.dtype_code(a.dtype), B.stream()), 'conv_wgrad')
+    return gw
+
+
+@pytest.mark.parametrize('ca,cb', [(32, 32), (96, 96), (128, 96), (48, 40), (256, 256), (64, 384)])
+def test_wgrad_dma_exact_products_of_bf16_operands(ca, cb):
+    """The bf16 weight gradient (LDS-DMA gathers, one even run of 64-rule stages per workgroup,
+    slabs added in workgroup order; csrc/wgrad_dma.hip) against the f64 sum of the exact products of
+    the same bf16 operands, rule list of backend.convolution_backward_cuda: 3x3x3 map (offsets with
+    few and with no rules, runs crossing offset boundaries), 2x2x2 strided map in both gather
+    directions (a_col 0 / 1), the identity list of the dense layers, and lists shorter than a stage.
+    f32 accumulation in a different order than the reference: 2e-5 of the largest entry; two launches
+    bitwise equal."""
+    F = _F()
+    g = torch.Generator().manual_seed(ca * 1000 + cb)
+    cases = []
+    c = _surface_coords(34, 2, seed=ca + cb).to(DEV)                      # 2312 voxels
+    km, _ = F.build_kernel_map(c, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    cases.append(('k3', km._nbmaps_cap, km.koff, 27, c.shape[0], c.shape[0], 0))
+    km2, oc = F.build_kernel_map(c, (1, 1, 1), (2, 2, 2), (2, 2, 2))
+    cases.append(('k2s2', km2._nbmaps_cap, km2.koff, 8, c.shape[0], oc.shape[0], 0))
+    cases.append(('k2s2 transposed', km2._nbmaps_cap, km2.koff, 8, oc.shape[0], c.shape[0], 1))
+    tiny = _surface_coords(3, 1, seed=1).to(DEV)                            # 9 voxels: every offset < 64 rules
+    km3, _ = F.build_kernel_map(tiny, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    cases.append(('tiny', km3._nbmaps_cap, km3.koff, 27, 9, 9, 0))
+    n_dense = 1000
+    cases.append(('dense', None, torch.tensor([0, n_dense], dtype=torch.int64, device=DEV), 1, n_dense, n_dense, 0))
+    for name, pairs, koff, k, n_a, n_b, a_col in cases:
+        a = torch.randn(n_a, ca, generator=g).to(DEV).bfloat16()
+        b = torch.randn(n_b, cb, generator=g).to(DEV).bfloat16()
+        got = _wgrad_abi(a, b, pairs, koff, a_col, k)
+        again = _wgrad_abi(a, b, pairs, koff, a_col, k)
+        assert torch.equal(got, again), name
+        ko = koff.cpu().tolist()
+        ref = torch.zeros(k, ca, cb, dtype=torch.float64, device=DEV)
+        for kk in range(k):
+            if ko[kk + 1] == ko[kk]:
+                continue
+            if pairs is None:
+                ia = ib = torch.arange(ko[kk], ko[kk + 1], device=DEV)
+            else:
+                pr = pairs[ko[kk]:ko[kk + 1]].long()
+                ia, ib = (pr[:, 1], pr[:, 0]) if a_col else (pr[:, 0], pr[:, 1])
+            ref[kk] = a[ia].double().t() @ b[ib].double()
+        assert torch.isfinite(got).all(), name
+        err = (got.double() - ref).abs().max().item() / ref.abs().max().clamp_min(1e-30).item()
+        assert err < 2e-5, (name, err)

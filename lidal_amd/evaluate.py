@@ -45,11 +45,10 @@ def evaluate_batches(model, batches, n_classes=19, group=None):
     """batches: iterable of dicts with coords_v_b, feats_v_b, inverse_indices_b, labels_p_b on the
     GPU (the reference's val collate).  Returns (confusion i32 [C,C] numpy, per-class IoU, mIoU)."""
     model.eval()
-    conf = None
+    # on the model's device from the start: a rank without batches still joins the all-reduce
+    conf = torch.zeros((n_classes, n_classes), dtype=torch.int32, device=next(model.parameters()).device)
     for b in batches:
         logits, _ = model(SparseTensor(b['feats_v_b'], b['coords_v_b']))
-        if conf is None:
-            conf = torch.zeros((n_classes, n_classes), dtype=torch.int32, device=logits.device)
         confusion_accumulate(conf, logits, b['inverse_indices_b'], b['labels_p_b'])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(conf, op=dist.ReduceOp.SUM, group=group)          # evaluate.py:117-119

@@ -50,6 +50,15 @@ def main():
             named = dict(model.named_parameters())
             np.savez(os.path.join(out_dir, 'ddp_2rank.npz'), loss=loss.item(),
                      **{k.replace('.', '/'): named[k].grad.float().cpu().numpy() for k in mc.GRAD_KEYS})
+    elif mode in ('eval', 'eval_empty'):
+        # evaluate.py:95-124: every rank accumulates the confusion matrix of ITS batches, one
+        # all-reduce sums them; 'eval_empty' gives rank 1 no batch at all
+        from lidal_amd.evaluate import evaluate_batches
+        model = mc.make_model(dev)
+        batches = mc.make_val_batches()
+        mine = batches[rank::world] if mode == 'eval' else (batches if rank == 0 else [])
+        conf, ious, miou = evaluate_batches(model, [{k: v.to(dev) for k, v in b.items()} for b in mine])
+        np.savez(os.path.join(out_dir, '%s_rank%d.npz' % (mode, rank)), conf=conf, miou=miou)
     dist.barrier()
     dist.destroy_process_group()
 

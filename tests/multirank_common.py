@@ -44,3 +44,21 @@ def make_half_batches():
         out.append({'coords': torch.from_numpy(b['coords_v_b']), 'feats': torch.from_numpy(b['feats_v_b']),
                     'labels': torch.from_numpy(b['labels_v_b'])})
     return out
+
+
+def make_val_batches(n=3):
+    """Validation batches in the reference's val-collate form (per-point labels + inverse map)."""
+    import numpy as np
+    from lidal_amd import synth
+    out = []
+    for i in range(n):
+        rng = np.random.default_rng(950 + i)
+        pts, inten = synth.raycast_scan(synth.make_world(950 + i), (10.0 + 3.0 * i, 0.0), rng, n_points=3000)
+        coords_v, feats_v, _, inverse = synth.voxelize_scan(pts, inten, rng)
+        b = synth.collate([{'coords_v': coords_v, 'feats_v': feats_v, 'inverse_idxs': inverse}])
+        labels_p = rng.integers(0, 19, size=pts.shape[0]).astype(np.int64)
+        labels_p[rng.random(pts.shape[0]) < 0.1] = 255
+        out.append({'coords_v_b': torch.from_numpy(b['coords_v_b']), 'feats_v_b': torch.from_numpy(b['feats_v_b']),
+                    'inverse_indices_b': torch.from_numpy(b['inverse_indices_b']),
+                    'labels_p_b': torch.from_numpy(labels_p)})
+    return out

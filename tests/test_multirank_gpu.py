@@ -89,3 +89,23 @@ def test_two_rank_ddp_gradient_is_the_mean_of_the_rank_gradients(tmp_path):
         want = 0.5 * (grads[0][k] + grads[1][k])
         got = two[k.replace('.', '/')].astype(np.float64)
         assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max() + 1e-12, k
+
+
+def test_two_rank_confusion_matrix_all_reduce(tmp_path):
+    """SURVEY 8f-4's collective leg (evaluate.py:117-119): the 19x19 int32 confusion matrices of the
+    ranks' own validation batches are summed by one all-reduce; every rank ends with the matrix (and
+    mIoU) of the single-process run over all batches -- also when one rank has no batch."""
+    import multirank_common as mc
+    from lidal_amd.evaluate import evaluate_batches
+    dev = torch.device('cuda', 0)
+    model = mc.make_model(dev)
+    one_conf, _, one_miou = evaluate_batches(model, [{k: v.to(dev) for k, v in b.items()}
+                                                     for b in mc.make_val_batches()])
+    assert one_conf.sum() > 0
+    torch.cuda.synchronize()
+    for mode in ('eval', 'eval_empty'):
+        _spawn(mode, tmp_path)
+        for r in range(2):
+            got = np.load(os.path.join(str(tmp_path), '%s_rank%d.npz' % (mode, r)))
+            assert np.array_equal(got['conf'], one_conf), (mode, r)
+            assert (np.isnan(got['miou']) and np.isnan(one_miou)) or got['miou'] == one_miou

@@ -60,10 +60,12 @@ class Conv3d(nn.Module):
 
     bn_follows = False      # set by lidal_amd.network where a BatchNorm directly consumes the output
 
-    def forward(self, input):
+    def forward(self, input, fork=False):
+        """`fork` (k > 1, not transposed): returns (output, alias of `input`) for a second consumer of
+        the input whose gradient then joins this layer's data gradient in-kernel (functional/conv.py)."""
         return conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
                       stride=self.stride, dilation=self.dilation, transposed=self.transposed,
-                      want_stats=self.bn_follows and self.training and torch.is_grad_enabled())
+                      want_stats=self.bn_follows and self.training and torch.is_grad_enabled(), fork=fork)
 
 
 class Linear(nn.Linear):

@@ -308,32 +308,38 @@ def _forward(feats, weight, kmap, transposed, epilogue=None, with_bwd_image=Fals
     return x, _apply(x, img, k, co, order, 0, epilogue, want_stats), img_b
 
 
-def _conv(feats, weight, kmap, transposed, epilogue=None, want_stats=False):
+def _conv(feats, weight, kmap, transposed, epilogue=None, want_stats=False, fork=False):
+    """`fork`: return (out, alias of `feats`) -- the alias is for a second consumer (the shortcut of a
+    residual block); the gradient arriving through it is added to the data gradient inside the
+    data-gradient kernel's epilogue instead of by a separate pass (autograd's accumulation)."""
     if B.wants_grad(feats, weight):
         assert epilogue is None, 'the fused BatchNorm epilogue is inference-only'
-        out = ConvolutionFunction.apply(feats, weight, kmap, transposed, want_stats)
+        fused = fork and feats.requires_grad and feats.shape[1] == weight.shape[1]
+        res = ConvolutionFunction.apply(feats, weight, kmap, transposed, want_stats, fused)
+        out, skip = res if fused else (res, feats)
         if ConvolutionFunction.last_stats is not None:      # from the Function's own output to autograd's
             out._lidal_bn_stats = ConvolutionFunction.last_stats
             ConvolutionFunction.last_stats = None
-        return out
-    return _forward(feats, weight, kmap, transposed, epilogue, False, want_stats)[1]   # no autograd node
+        return (out, skip) if fork else out
+    out = _forward(feats, weight, kmap, transposed, epilogue, False, want_stats)[1]   # no autograd node
+    return (out, feats) if fork else out
 
 
 class ConvolutionFunction(Function):
     last_stats = None           # tile statistics of the latest forward (a non-differentiable side output)
 
     @staticmethod
-    def forward(ctx, feats, weight, kmap, transposed, want_stats=False):
+    def forward(ctx, feats, weight, kmap, transposed, want_stats=False, fork=False):
         x, out, ctx.img_bwd = _forward(feats, weight, kmap, transposed, None, ctx.needs_input_grad[0],
                                        want_stats)
         ConvolutionFunction.last_stats = getattr(out, '_lidal_bn_stats', None) if want_stats else None
         ctx.kmap = kmap
         ctx.transposed = transposed
         ctx.save_for_backward(x, weight)
-        return out
+        return (out, feats) if fork else out          # an input returned as is becomes an alias of it
 
     @staticmethod
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_output, grad_skip=None):
         x, weight = ctx.saved_tensors
         kmap, transposed = ctx.kmap, ctx.transposed
         g = grad_output.contiguous().to(x.dtype)
@@ -367,19 +373,24 @@ class ConvolutionFunction(Function):
             # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci (of the padded input), reduction
             # over co; the operand image was built together with the forward one
             order, kflip = _bwd_order(kmap, transposed)
-            grad_in = _apply(g, ctx.img_bwd, k, x.shape[1], order, kflip)
+            # the gradient of the forked alias joins in the epilogue (out = acc + residual)
+            ep = (None, None, 0, grad_skip) if grad_skip is not None else None
+            grad_in = _apply(g, ctx.img_bwd, k, x.shape[1], order, kflip, ep)
             grad_in = grad_in[:, :ci_w]                     # drop the padding channels, if any
+        elif grad_skip is not None:
+            grad_in = grad_skip
         if side is not None:
             side.finish()
-        return grad_in, grad_w, None, None, None
+        return grad_in, grad_w, None, None, None, None
 
 
 def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transposed=False,
-           epilogue=None, want_stats=False):
+           epilogue=None, want_stats=False, fork=False):
     """torchsparse F.conv3d.  `epilogue` (inference only, not for 1x1x1 kernels) = (scale, shift,
     relu) applies the per-channel affine map of a following eval-mode BatchNorm (+ ReLU) inside
     the convolution kernel.  `want_stats` (training: a train-mode BatchNorm follows) makes the kernel
-    leave that BatchNorm's batch statistics, reduced per 128-row tile, on the output features."""
+    leave that BatchNorm's batch statistics, reduced per 128-row tile, on the output features.
+    `fork` (k > 1, not transposed): returns (output, alias of input) -- see _conv."""
     feats, coords = input.feats, input.coords
     kernel_size = make_ntuple(kernel_size, ndim=3)
     stride = make_ntuple(stride, ndim=3)
@@ -402,7 +413,10 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
             if any(s > 1 for s in stride):
                 input.cmaps.setdefault(out_stride, out_coords)
         out_coords = coords if all(s == 1 for s in stride) else input.cmaps[out_stride]
-        feats = _conv(feats, weight, kmap, False, epilogue, want_stats and bias is None)
+        if fork:
+            feats, skip_feats = _conv(feats, weight, kmap, False, epilogue, want_stats and bias is None, True)
+        else:
+            feats = _conv(feats, weight, kmap, False, epilogue, want_stats and bias is None)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(feats, out_coords, out_stride)
@@ -416,4 +430,9 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
     output.cmaps = input.cmaps
     output.cmaps.setdefault(output.stride, output.coords)
     output.kmaps = input.kmaps
+    if fork:
+        assert kernel_size != (1, 1, 1) and not transposed, 'fork: k > 1, not transposed'
+        skip = SparseTensor(skip_feats, coords, input.stride)
+        skip.cmaps, skip.kmaps = input.cmaps, input.kmaps
+        return output, skip
     return output

@@ -348,7 +348,7 @@ def family_table(step, coords, dtype_name, step_ms):
             m_rows, c, dt, n_ent = a[5], a[6], a[7], a[8]
             by = (n_ent + m_rows) * c * (2 if dt == 1 else 4)
         elif name == 'lidal_voxelize_bwd':
-            by = (a[4] + a[5]) * a[6] * (2 if a[7] == 1 else 4)
+            by = ((2 if a[3] else 1) * a[5] + a[6]) * a[7] * (2 if a[8] == 1 else 4)     # gin (+ residual) + gout rows
         elif name == 'lidal_devoxelize_fwd':
             by = (8 * a[4] + a[4]) * a[6] * (2 if a[7] == 1 else 4)
         d = fam.setdefault(f, {'ms': 0.0, 'launches': 0, 'bytes': 0.0, 'flops': 0.0})

@@ -121,8 +121,11 @@ int lidal_count(const int32_t* idx, int64_t n, int32_t* out, int64_t m, void* st
  * network/utils.py:22,25,56).  out[idx[i]] += feat[i] / counts[idx[i]]; f32 only. */
 int lidal_voxelize_fwd(const float* feat, const int32_t* idx, const int32_t* counts, float* out,
                        int64_t n, int64_t m, int c, void* stream);
-int lidal_voxelize_bwd(const void* gout, const int32_t* idx, const int32_t* counts, void* gin,
-                       int64_t n, int64_t m, int c, int dtype, void* stream);
+/* backward: gin[i] = gout[idx[i]] / counts[idx[i]] (+ residual[i], same dtype [n, c], may be NULL:
+ * the gradient reaching the same point rows through a second consumer of the features). */
+int lidal_voxelize_bwd(const void* gout, const int32_t* idx, const int32_t* counts,
+                       const void* residual, void* gin, int64_t n, int64_t m, int c, int dtype,
+                       void* stream);
 /* replaces backend.devoxelize_forward_cuda / devoxelize_backward_cuda (F.spdevoxelize:
  * network/utils.py:83,95).  idx i32 [n,8], w f32 [n,8]; out[i] = sum_k w[i,k] feat[idx[i,k]]. */
 int lidal_devoxelize_fwd(const void* feat, const int32_t* idx, const float* w, void* out,

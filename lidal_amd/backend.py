@@ -48,7 +48,7 @@ SIGNATURES = {
     'lidal_kmap_invert': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp]),
     'lidal_count': (_i32, [_vp, _i64, _vp, _i64, _vp]),
     'lidal_voxelize_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
-    'lidal_voxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    'lidal_voxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     'lidal_devoxelize_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     'lidal_devoxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     'lidal_invlist_workspace_bytes': (_i64, [_i64]),
@@ -205,6 +205,10 @@ _side_streams = {}
 _pending = []
 _join_queued = [False]
 _OVERLAP = os.environ.get('LIDAL_WGRAD_STREAM', 'auto')
+
+
+# gradient fan-in fused into the producing kernels (residual-block input, point features); 0 = off
+FORK = int(os.environ.get('LIDAL_FORK', '3'))       # bit 0: residual blocks, bit 1: point features
 
 
 def overlap_wgrad(dtype):

@@ -64,11 +64,13 @@ __global__ void __launch_bounds__(256) voxelize_fwd_kernel(const float* __restri
   }
 }
 
-// gin[i] = gout[idx[i]] / counts[idx[i]]
+// gin[i] = gout[idx[i]] / counts[idx[i]]  (+ res[i]: the gradient that reaches the same point rows
+// through a second consumer, added here instead of by a separate accumulation pass)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) voxelize_bwd_kernel(const T* __restrict__ gout,
                                                            const int* __restrict__ idx,
                                                            const int* __restrict__ counts,
+                                                           const T* __restrict__ res,
                                                            T* __restrict__ gin, int64_t n,
                                                            int64_t m, int c) {
   const int cv = c / VEC;
@@ -83,10 +85,19 @@ __global__ void __launch_bounds__(256) voxelize_bwd_kernel(const T* __restrict__
   const T* src = gout + (int64_t)(dead ? 0 : pos) * c + j;
   if constexpr (VEC == 4) {
     float4 x = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(src);
-    st4(dst, make_float4(x.x / div, x.y / div, x.z / div, x.w / div));
+    x = make_float4(x.x / div, x.y / div, x.z / div, x.w / div);
+    if (res != nullptr) {
+      // the quotient is rounded to T first, as the stand-alone result would be, then the sum
+      const float4 r = ld4(res + i * c + j);
+      x = make_float4((float)(T)x.x + r.x, (float)(T)x.y + r.y, (float)(T)x.z + r.z, (float)(T)x.w + r.w);
+    }
+    st4(dst, x);
   } else {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) dst[v] = dead ? (T)0.f : (T)((float)src[v] / div);
+    for (int v = 0; v < VEC; ++v) {
+      T q = dead ? (T)0.f : (T)((float)src[v] / div);
+      dst[v] = res != nullptr ? (T)((float)q + (float)res[i * c + j + v]) : q;
+    }
   }
 }
 
@@ -498,13 +509,16 @@ extern "C" int lidal_voxelize_fwd(const float* feat, const int32_t* idx, const i
 }
 
 extern "C" int lidal_voxelize_bwd(const void* gout, const int32_t* idx, const int32_t* counts,
-                                  void* gin, int64_t n, int64_t m, int c, int dtype, void* stream) {
+                                  const void* residual, void* gin, int64_t n, int64_t m, int c,
+                                  int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n == 0 || c == 0) return 0;
   if (dtype == LIDAL_F32)
-    DISPATCH_TVEC(voxelize_bwd_kernel, float, c, n, (const float*)gout, idx, counts, (float*)gin, n, m, c);
+    DISPATCH_TVEC(voxelize_bwd_kernel, float, c, n, (const float*)gout, idx, counts,
+                  (const float*)residual, (float*)gin, n, m, c);
   else if (dtype == LIDAL_BF16)
-    DISPATCH_TVEC(voxelize_bwd_kernel, __bf16, c, n, (const __bf16*)gout, idx, counts, (__bf16*)gin, n, m, c);
+    DISPATCH_TVEC(voxelize_bwd_kernel, __bf16, c, n, (const __bf16*)gout, idx, counts,
+                  (const __bf16*)residual, (__bf16*)gin, n, m, c);
   else { set_error("voxelize_bwd: bad dtype %d", dtype); return 2; }
   LIDAL_CHECK_LAUNCH("lidal_voxelize_bwd");
   return 0;

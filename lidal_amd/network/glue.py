@@ -6,6 +6,7 @@ the stride-1 tables built after the stem are re-used by the last up-stage.
 import torch
 
 from .. import PointTensor, SparseTensor
+from .. import backend as B
 from ..nn import functional as F
 from ..nn.utils import get_kernel_offsets
 
@@ -55,7 +56,13 @@ def point_to_voxel(x, z):
         idx_query = F.coords_table(x.C, x.cmaps).query(pc_hash)     # == F.sphashquery(pc_hash, F.sphash(x.C))
         cache_i[x.s] = idx_query
         cache_c[x.s] = F.spcount(idx_query.int(), x.C.shape[0])
-    new_tensor = SparseTensor(F.spvoxelize(z.F, cache_i[x.s], cache_c[x.s]), x.C, x.s)
+    # z.F has a second consumer downstream (the point-branch Linear of SPVCNN.forward): it gets an
+    # alias whose gradient joins the voxelize backward in-kernel (F.spvoxelize, fork)
+    if B.FORK & 2:
+        feats, z.F = F.spvoxelize(z.F, cache_i[x.s], cache_c[x.s], fork=True)
+    else:
+        feats = F.spvoxelize(z.F, cache_i[x.s], cache_c[x.s])
+    new_tensor = SparseTensor(feats, x.C, x.s)
     new_tensor.cmaps = x.cmaps
     new_tensor.kmaps = x.kmaps
     return new_tensor

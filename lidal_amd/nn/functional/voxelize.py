@@ -11,8 +11,9 @@ __all__ = ['spvoxelize']
 
 class VoxelizeFunction(Function):
     @staticmethod
-    def forward(ctx, feats, coords, counts):
+    def forward(ctx, feats, coords, counts, fork=False):
         B.require_gpu(feats, coords, counts)
+        feats_in = feats
         in_dtype = feats.dtype
         # bf16 rows are read and written as bf16 (f32 accumulation inside the kernel) when the
         # ordered path applies; everything else computes on an f32 copy
@@ -43,22 +44,31 @@ class VoxelizeFunction(Function):
                                                B.ptr(out), n, m, c, B.stream()), 'voxelize_fwd')
         coords = idx32
         ctx.for_backwards = (coords, counts, n, in_dtype)
-        return out.to(in_dtype)
+        # fork: an alias of the input for its second consumer; the gradient arriving through it is
+        # added inside the backward kernel (no separate accumulation pass over the point rows)
+        return (out.to(in_dtype), feats_in) if fork else out.to(in_dtype)
 
     @staticmethod
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_output, grad_skip=None):
         coords, counts, n, in_dtype = ctx.for_backwards
         native = in_dtype == torch.bfloat16 and grad_output.dtype == torch.bfloat16
         g = grad_output.contiguous() if native else grad_output.contiguous().float()
         m, c = g.shape
+        res = None if grad_skip is None else grad_skip.contiguous().to(g.dtype)
         gin = torch.empty((n, c), dtype=g.dtype, device=g.device)
-        B.check(B.lib().lidal_voxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(counts), B.ptr(gin),
+        B.check(B.lib().lidal_voxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(counts), B.ptr(res), B.ptr(gin),
                                            n, m, c, B.dtype_code(g.dtype), B.stream()),
                 'voxelize_bwd')
-        return gin.to(in_dtype), None, None
+        return gin.to(in_dtype), None, None, None
 
 
-def spvoxelize(feats, coords, counts):
+def spvoxelize(feats, coords, counts, fork=False):
+    """`fork`: returns (voxel rows, alias of `feats`) -- hand the alias to the other consumer of the
+    point features; its gradient then joins this one's inside the backward kernel."""
     if B.wants_grad(feats):
-        return VoxelizeFunction.apply(feats, coords, counts)
-    return VoxelizeFunction.forward(B.NoGradCtx(), feats, coords, counts)        # inference: no autograd node
+        if fork and feats.requires_grad:
+            return VoxelizeFunction.apply(feats, coords, counts, True)
+        out = VoxelizeFunction.apply(feats, coords, counts)
+    else:
+        out = VoxelizeFunction.forward(B.NoGradCtx(), feats, coords, counts)     # inference: no autograd node
+    return (out, feats) if fork else out

@@ -242,18 +242,21 @@ int64_t lidal_bn_workspace_bytes(int64_t n, int c);
 /* `relu` != 0 fuses the ReLU that follows the normalisation in the model (forward: max(y, 0);
  * backward: dy is taken where y > 0, y recomputed from x). */
 /* num_batches_tracked (nn.BatchNorm1d's i64 scalar buffer, may be NULL) is incremented by one. */
+/* residual (same dtype [n, c], may be NULL): y = act(bn(x)) + residual -- the point-branch sum of
+ * network/spvcnn.py:104,111,118 (`z1.F = z1.F + point_transforms(z.F)`) inside the normalising pass;
+ * its gradient is grad_y unchanged. */
 int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean,
-                       float* running_var, int64_t* num_batches_tracked, int relu, void* y,
-                       float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
-                       void* stream);
+                       float* running_var, int64_t* num_batches_tracked, int relu,
+                       const void* residual, void* y, float* save_mean, float* save_invstd, void* ws,
+                       int64_t ws_bytes, void* stream);
 /* lidal_bn_train_fwd with the statistics pass replaced by the per-tile (count, mean, M2) triples
  * lidal_conv_apply_image wrote (tile_stats f32 [n_tiles][c][3]). */
 int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int c, const float* gamma,
                              const float* beta, float eps, float momentum, float* running_mean,
-                             float* running_var, int64_t* num_batches_tracked, int relu, void* y,
-                             float* save_mean, float* save_invstd, const float* tile_stats,
-                             int64_t n_tiles, void* stream);
+                             float* running_var, int64_t* num_batches_tracked, int relu,
+                             const void* residual, void* y, float* save_mean, float* save_invstd,
+                             const float* tile_stats, int64_t n_tiles, void* stream);
 int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                       const float* beta, const float* running_mean, const float* running_var,
                       float eps, int relu, void* y, void* stream);

@@ -71,10 +71,10 @@ SIGNATURES = {
     'lidal_conv_wgrad_slabs': (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     'lidal_conv_wgrad': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'lidal_bn_workspace_bytes': (_i64, [_i64, _i32]),
-    'lidal_bn_train_fwd': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp,
+    'lidal_bn_train_fwd': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                   _vp, _vp, _i64, _vp]),
     'lidal_bn_train_fwd_tiles': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp,
-                                        _vp, _vp, _i64, _vp]),
+                                        _vp, _vp, _vp, _i64, _vp]),
     'lidal_bn_eval_fwd': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp]),
     'lidal_bn_bwd': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                             _i64, _vp]),
@@ -208,7 +208,7 @@ _OVERLAP = os.environ.get('LIDAL_WGRAD_STREAM', 'auto')
 
 
 # gradient fan-in fused into the producing kernels (residual-block input, point features); 0 = off
-FORK = int(os.environ.get('LIDAL_FORK', '3'))       # bit 0: residual blocks, bit 1: point features
+FORK = int(os.environ.get('LIDAL_FORK', '7'))       # bit 0: residual blocks, bit 1: point features, bit 2: point-branch sum in BatchNorm
 
 
 def overlap_wgrad(dtype):

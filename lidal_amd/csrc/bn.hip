@@ -185,13 +185,16 @@ __global__ void __launch_bounds__(NT) bn_stats_final_kernel(const P* __restrict_
 }
 
 // y = (x - mean) * invstd * gamma + beta  ==  x * sc + sh   (per-channel sc, sh held in registers)
+// `res` (may be null): y = act(...) rounded to T, + res -- the sum of the point branch
+// (network/spvcnn.py:104 `z1.F = z1.F + point_transforms(z.F)`) without a pass of its own
 template <typename T, bool VAR_IN>
 __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, int64_t n, int c,
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ istd_or_var,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
-                                                      int relu, T* __restrict__ y, int rpw) {
+                                                      int relu, const T* __restrict__ res,
+                                                      T* __restrict__ y, int rpw) {
   constexpr int VEC = IO<T>::VEC;
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
@@ -207,27 +210,40 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
     sc[i] = is * (gamma ? gamma[ch] : 1.f);
     sh[i] = beta ? beta[ch] : 0.f;
   }
-  auto one = [&](const typename IO<T>::vec& v, int64_t r) {
-    float f[VEC];
+  auto one = [&](const typename IO<T>::vec& v, const typename IO<T>::vec& vr, int64_t r) {
+    float f[VEC], fr[VEC];
     IO<T>::unpack(v, f);
+    IO<T>::unpack(vr, fr);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
       if (relu) f[i] = fmaxf(f[i], 0.f);
+      if (res != nullptr) f[i] = (float)(T)f[i] + fr[i];       // as the stand-alone sum of two T rows
     }
     *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
   };
+  const T* rsrc = res != nullptr ? res : x;        // no residual: the second load re-reads x (cached)
   int64_t r = r_beg + rl;
   for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
-    typename IO<T>::vec v[UNR];
+    typename IO<T>::vec v[UNR], vr[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
       v[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+    if (res != nullptr) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) one(v[u], r + u * rpi);
+      for (int u = 0; u < UNR; ++u)
+        vr[u] = *reinterpret_cast<const typename IO<T>::vec*>(rsrc + (r + u * rpi) * c + cg * VEC);
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) vr[u] = v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) one(v[u], vr[u], r + u * rpi);
   }
-  for (; r < r_end; r += rpi)
-    one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC), r);
+  for (; r < r_end; r += rpi) {
+    const typename IO<T>::vec v = *reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC);
+    one(v, res != nullptr ? *reinterpret_cast<const typename IO<T>::vec*>(res + r * c + cg * VEC) : v, r);
+  }
 }
 
 // backward partials: per workgroup and channel  sum(dy), sum(dy * xhat)
@@ -393,8 +409,8 @@ static inline int nslabs_ew(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_pe
 static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg(n)); }
 template <typename T>
 int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-                 float momentum, float* rm, float* rv, long long* nbt, int relu, void* y,
-                 float* mean, float* invstd, double* part, hipStream_t s) {
+                 float momentum, float* rm, float* rv, long long* nbt, int relu, const void* res,
+                 void* y, float* mean, float* invstd, double* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
   bn_stats_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>((const T*)x, n, c, part,
@@ -404,7 +420,8 @@ int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const floa
                                                              invstd, rm, rv, nbt);
   LIDAL_CHECK_LAUNCH("bn_stats_final");
   bn_apply_kernel<T, false><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma,
-                                                        beta, eps, relu, (T*)y, rows_per_wg_ew(n));
+                                                        beta, eps, relu, (const T*)res, (T*)y,
+                                                        rows_per_wg_ew(n));
   LIDAL_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -461,20 +478,20 @@ extern "C" int64_t lidal_bn_workspace_bytes(int64_t n, int c) {
 extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                                   const float* beta, float eps, float momentum,
                                   float* running_mean, float* running_var,
-                                  int64_t* num_batches_tracked, int relu, void* y,
-                                  float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
-                                  void* stream) {
+                                  int64_t* num_batches_tracked, int relu, const void* residual,
+                                  void* y, float* save_mean, float* save_invstd, void* ws,
+                                  int64_t ws_bytes, void* stream) {
   if (int rc = bn_check(n, c, dtype)) return rc;
   LIDAL_REQUIRE(n > 0, "bn_train_fwd: needs at least one row");
   LIDAL_REQUIRE(ws_bytes >= lidal_bn_workspace_bytes(n, c), "bn workspace too small");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
     return bn_train_fwd<float>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var,
-                               (long long*)num_batches_tracked, relu, y, save_mean, save_invstd,
-                               (double*)ws, s);
+                               (long long*)num_batches_tracked, relu, residual, y, save_mean,
+                               save_invstd, (double*)ws, s);
   return bn_train_fwd<__bf16>(x, n, c, gamma, beta, eps, momentum, running_mean, running_var,
-                              (long long*)num_batches_tracked, relu, y, save_mean, save_invstd,
-                              (double*)ws, s);
+                              (long long*)num_batches_tracked, relu, residual, y, save_mean,
+                              save_invstd, (double*)ws, s);
 }
 
 // Merge of the per-tile (count, mean, M2) f32 triples a convolution left (thousands of tiles): one
@@ -522,9 +539,10 @@ __global__ void __launch_bounds__(NT) bn_tiles_final_kernel(const float* __restr
 extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int c, const float* gamma,
                                         const float* beta, float eps, float momentum,
                                         float* running_mean, float* running_var,
-                                        int64_t* num_batches_tracked, int relu, void* y,
-                                        float* save_mean, float* save_invstd, const float* tile_stats,
-                                        int64_t n_tiles, void* stream) {
+                                        int64_t* num_batches_tracked, int relu,
+                                        const void* residual, void* y, float* save_mean,
+                                        float* save_invstd, const float* tile_stats, int64_t n_tiles,
+                                        void* stream) {
   if (int rc = bn_check(n, c, dtype)) return rc;
   LIDAL_REQUIRE(n > 0 && n_tiles > 0 && tile_stats != nullptr, "bn_train_fwd_tiles: needs rows and tile statistics");
   hipStream_t s = (hipStream_t)stream;
@@ -534,12 +552,14 @@ extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int
   LIDAL_CHECK_LAUNCH("bn_stats_final(tiles)");
   if (dtype == LIDAL_F32)
     bn_apply_kernel<float, false><<<nslabs_ew(n), NT, 0, s>>>((const float*)x, n, c, save_mean, save_invstd,
-                                                              gamma, beta, eps, relu, (float*)y,
+                                                              gamma, beta, eps, relu,
+                                                              (const float*)residual, (float*)y,
                                                               rows_per_wg_ew(n));
   else
     bn_apply_kernel<__bf16, false><<<nslabs_ew(n), NT, 0, s>>>((const __bf16*)x, n, c, save_mean,
                                                                save_invstd, gamma, beta, eps, relu,
-                                                               (__bf16*)y, rows_per_wg_ew(n));
+                                                               (const __bf16*)residual, (__bf16*)y,
+                                                               rows_per_wg_ew(n));
   LIDAL_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -553,11 +573,11 @@ extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, con
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
     bn_apply_kernel<float, true><<<nslabs_ew(n), NT, 0, s>>>(
-        (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, (float*)y,
+        (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, nullptr, (float*)y,
         rows_per_wg_ew(n));
   else
     bn_apply_kernel<__bf16, true><<<nslabs_ew(n), NT, 0, s>>>(
-        (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, (__bf16*)y,
+        (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, nullptr, (__bf16*)y,
         rows_per_wg_ew(n));
   LIDAL_CHECK_LAUNCH("lidal_bn_eval_fwd");
   return 0;

@@ -49,6 +49,12 @@ class ConvNormSequential(nn.Sequential):
                 if last:
                     residual = None
                 i += 2
+            elif (isinstance(m, spnn.BatchNorm1d) and not isinstance(m, spnn.BatchNorm) and torch.is_tensor(x)
+                  and i + 1 == len(mods) and residual is not None and not relu_after and m.training
+                  and (B.FORK & 4)):
+                x = m(x, residual=residual)         # training: the sum rides in the normalising pass
+                residual = None
+                i += 1
             else:
                 x = m(x)
                 i += 1

@@ -91,17 +91,20 @@ class BatchNorm1d(nn.BatchNorm1d):
 
     fused_relu = False      # set by lidal_amd.network where a ReLU directly follows the norm
 
-    def forward(self, feats):
+    def forward(self, feats, residual=None):
+        """`residual` ([N, C]): returns norm(feats) (+ ReLU) + residual; in training the sum happens
+        inside the normalising pass."""
         from .functional import norm
         if (not norm.supported(feats, self.weight, self.bias) or not self.track_running_stats
                 or self.momentum is None):
             B.hit('torch_fallback:BatchNorm1d')
             out = super().forward(feats)
-            return torch.relu(out) if self.fused_relu else out
+            out = torch.relu(out) if self.fused_relu else out
+            return out if residual is None else out + residual
         return norm.batch_norm_rows(feats, self.weight, self.bias, self.running_mean,
                                     self.running_var, self.training, self.momentum, self.eps,
                                     self.fused_relu, self.num_batches_tracked,
-                                    getattr(feats, '_lidal_bn_stats', None))
+                                    getattr(feats, '_lidal_bn_stats', None), residual)
 
 
 class BatchNorm(BatchNorm1d):

@@ -30,8 +30,11 @@ def _ws(n, c, dev):
 class BatchNormRows(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu,
-                num_batches_tracked=None, tile_stats=None):
+                num_batches_tracked=None, tile_stats=None, residual=None):
         x = x.contiguous()
+        if residual is not None:        # y = act(bn(x)) + residual in the normalising pass (training)
+            assert training and residual.shape == x.shape
+            residual = residual.contiguous().to(x.dtype)
         n, c = x.shape
         dev = x.device
         y = torch.empty_like(x)
@@ -44,15 +47,16 @@ class BatchNormRows(Function):
                 B.check(B.lib().lidal_bn_train_fwd_tiles(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
                                                          float(momentum), B.ptr(running_mean),
                                                          B.ptr(running_var), B.ptr(num_batches_tracked),
-                                                         int(relu), B.ptr(y), B.ptr(mean), B.ptr(invstd),
-                                                         B.ptr(tile_stats), tile_stats.shape[0], B.stream()),
+                                                         int(relu), B.ptr(residual), B.ptr(y), B.ptr(mean),
+                                                         B.ptr(invstd), B.ptr(tile_stats),
+                                                         tile_stats.shape[0], B.stream()),
                         'bn_train_fwd')
             else:
                 ws, nbytes = _ws(n, c, dev)
                 B.check(B.lib().lidal_bn_train_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
                                                    float(momentum), B.ptr(running_mean),
                                                    B.ptr(running_var), B.ptr(num_batches_tracked), int(relu),
-                                                   B.ptr(y), B.ptr(mean),
+                                                   B.ptr(residual), B.ptr(y), B.ptr(mean),
                                                    B.ptr(invstd), B.ptr(ws), nbytes, B.stream()),
                         'bn_train_fwd')
         else:
@@ -63,6 +67,7 @@ class BatchNormRows(Function):
                                               int(relu), B.ptr(y), B.stream()), 'bn_eval_fwd')
         ctx.training = training
         ctx.relu = bool(relu)
+        ctx.has_residual = residual is not None
         ctx.save_for_backward(x, w, b, mean, invstd)
         return y
 
@@ -77,7 +82,7 @@ class BatchNormRows(Function):
             if ctx.relu:
                 gf = gf * ((xhat * w + b) > 0)
             return ((gf * (w * invstd)).to(x.dtype), (gf * xhat).sum(0), gf.sum(0), None, None,
-                    None, None, None, None, None)
+                    None, None, None, None, None, None, None)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         gg = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -87,14 +92,17 @@ class BatchNormRows(Function):
                                      B.ptr(b), int(ctx.relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),
                                      B.ptr(gg), B.ptr(gb),
                                      B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
-        return dx, gg, gb, None, None, None, None, None, None, None, None
+        # the residual passes straight through: its gradient is grad_out itself
+        return (dx, gg, gb, None, None, None, None, None, None, None, None,
+                grad_out if ctx.has_residual and ctx.needs_input_grad[11] else None)
 
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                    relu=False, num_batches_tracked=None, tile_stats=None):
+                    relu=False, num_batches_tracked=None, tile_stats=None, residual=None):
     """`num_batches_tracked` (i64 scalar buffer, training only) is incremented inside the kernel.
     `tile_stats` (training only): f32 [ceil(N/128), C, 3] (count, mean, M2) per 128-row tile, written
-    by the convolution that produced x (conv3d(..., want_stats=True)): no statistics pass over x."""
+    by the convolution that produced x (conv3d(..., want_stats=True)): no statistics pass over x.
+    `residual` (training only, [N, C]): returns act(bn(x)) + residual from the same pass."""
     if tile_stats is not None and not (training and tile_stats.shape == (-(-x.shape[0] // 128), x.shape[1], 3)):
         tile_stats = None
     if not training and not B.wants_grad(x, weight, bias):      # inference: one kernel, no node
@@ -105,8 +113,11 @@ def batch_norm_rows(x, weight, bias, running_mean, running_var, training, moment
                                           B.ptr(running_var), float(eps), int(relu), B.ptr(y),
                                           B.stream()), 'bn_eval_fwd')
         return y
+    if residual is not None and not training:
+        return batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps, relu,
+                               num_batches_tracked, tile_stats) + residual
     return BatchNormRows.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                               relu, num_batches_tracked if training else None, tile_stats)
+                               relu, num_batches_tracked if training else None, tile_stats, residual)
 
 
 def column_sum(x):

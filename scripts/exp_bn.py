@@ -39,12 +39,12 @@ def main():
 
         def fwd():
             B.check(L.lidal_bn_train_fwd(B.ptr(x), 1, n, c, B.ptr(w), B.ptr(b), 1e-5, 0.1, B.ptr(rm), B.ptr(rv),
-                                         None, 1, B.ptr(y), B.ptr(mean), B.ptr(invstd), B.ptr(ws), nbytes,
+                                         None, 1, None, B.ptr(y), B.ptr(mean), B.ptr(invstd), B.ptr(ws), nbytes,
                                          B.stream()), 'fwd')
 
         def fwd_tiles():
             B.check(L.lidal_bn_train_fwd_tiles(B.ptr(x), 1, n, c, B.ptr(w), B.ptr(b), 1e-5, 0.1, B.ptr(rm),
-                                               B.ptr(rv), None, 1, B.ptr(y), B.ptr(mean), B.ptr(invstd),
+                                               B.ptr(rv), None, 1, None, B.ptr(y), B.ptr(mean), B.ptr(invstd),
                                                B.ptr(ts), n_tiles, B.stream()), 'fwd_tiles')
 
         def bwd():

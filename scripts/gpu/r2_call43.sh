@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-for f in 0 1 3 0 3; do LIDAL_FORK=$f timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-families --no-roofline --no-variants 2>&1 | tail -1 | python3 -c "
+for f in 3 7 3 7 3 7; do LIDAL_FORK=$f timeout 600 python bench.py --steps 20 --no-cpu-baseline --no-secondary --no-families --no-roofline --no-variants 2>&1 | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('fork=$f', d['ms_per_step'])"; done

@@ -821,3 +821,33 @@ def test_wgrad_dma_exact_products_of_bf16_operands(ca, cb):
         assert torch.isfinite(got).all(), name
         err = (got.double() - ref).abs().max().item() / ref.abs().max().clamp_min(1e-30).item()
         assert err < 2e-5, (name, err)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batch_norm_residual_rides_in_the_normalising_pass(dtype):
+    """y = relu(bn(x)) + residual from ONE pass (the point-branch sum of network/spvcnn.py:104,111,118)
+    is bitwise what the stand-alone sum of the normalised rows and the residual gives, statistics
+    from a pass over x or from a convolution's tile triples alike; the residual's gradient is
+    grad_out itself and the other gradients do not change."""
+    from lidal_amd.nn.functional.norm import batch_norm_rows
+    g = torch.Generator().manual_seed(11)
+    n, c = 5001, 64
+    x = torch.randn(n, c, generator=g).to(DEV).to(dtype)
+    res = torch.randn(n, c, generator=g).to(DEV).to(dtype)
+    go = torch.randn(n, c, generator=g).to(DEV).to(dtype)
+    w = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    b = torch.randn(c, generator=g).to(DEV)
+    outs = []
+    for fused in (False, True):
+        xi, ri = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        if fused:
+            y = batch_norm_rows(xi, wi, bi, rm, rv, True, 0.1, 1e-5, True, None, None, ri)
+        else:
+            y = batch_norm_rows(xi, wi, bi, rm, rv, True, 0.1, 1e-5, True) + ri
+        y.backward(go)
+        outs.append((y.detach(), xi.grad, ri.grad, wi.grad, bi.grad, rm, rv))
+    for a, bb in zip(*outs):
+        assert torch.equal(a, bb)
+    assert torch.equal(outs[1][2], go)

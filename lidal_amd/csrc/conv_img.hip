@@ -125,6 +125,30 @@ weight_image_kernel(const TI* __restrict__ w, TO* __restrict__ img_a, int n_red,
   else if (s < segs_a + segs_b) image_segment<TI, TO>(w, img_b, n_col, n_red, role ^ 1, nb_b, kc_b, s - segs_a);
 }
 
+// every parameter of a model in ONE launch (training: the weights change every step, and 42 launches of
+// 7 us each were 0.3 ms of the step): job j owns segments [first, first + segs_a + segs_b) of the grid
+struct ImageJob {
+  const void* w; void* img_a; void* img_b;
+  long long first, segs_a, segs_b;
+  int n_red, n_col, role, nb_a, kc_a, nb_b, kc_b, pad;
+};
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+weight_image_batch_kernel(const ImageJob* __restrict__ jobs, int n_jobs, int64_t total) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {                       // last job whose first segment is <= s
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first <= s) lo = mid; else hi = mid - 1;
+  }
+  const ImageJob j = jobs[lo];
+  const int64_t l = s - j.first;
+  if (l < j.segs_a) image_segment<TI, TO>((const TI*)j.w, (TO*)j.img_a, j.n_red, j.n_col, j.role, j.nb_a, j.kc_a, l);
+  else if (l < j.segs_a + j.segs_b)
+    image_segment<TI, TO>((const TI*)j.w, (TO*)j.img_b, j.n_col, j.n_red, j.role ^ 1, j.nb_b, j.kc_b, l - j.segs_a);
+}
+
 // Timing-only ablation builds (scripts/exp_img.py with an A/B library): results are wrong by
 // construction.  1: A gathers folded into the first 2048 rows (L2-resident: what perfect gather
 // locality would buy)  2: no weight DMA  4: no MFMA / fragment reads  8: no A gathers  16: no epilogue
@@ -1167,6 +1191,51 @@ extern "C" int lidal_conv_weight_image_pair(const void* w, int w_dtype, void* im
                                             int co, void* stream) {
   return weight_images(w, w_dtype, 0, img_fwd, n_out_fwd, img_bwd, n_out_bwd, dtype, k, ci, co,
                        (hipStream_t)stream);
+}
+
+extern "C" int lidal_conv_weight_image_job_bytes(void) { return (int)sizeof(ImageJob); }
+
+// fills one ImageJob (host memory) for the pair of images lidal_conv_weight_image_pair would build;
+// `first` = segments of the jobs before it; returns this job's segment count (< 0: error)
+extern "C" int64_t lidal_conv_weight_image_job(void* job, const void* w, void* img_fwd, int64_t n_out_fwd,
+                                               void* img_bwd, int64_t n_out_bwd, int dtype, int k, int ci,
+                                               int co, int64_t first) {
+  if (job == nullptr || (dtype != LIDAL_F32 && dtype != LIDAL_BF16)) { set_error("weight_image_job: bad arguments"); return -1; }
+  const int esz = dtype == LIDAL_BF16 ? 2 : 4;
+  const Tiling ta = pick_tiling(ci, co, n_out_fwd, esz);
+  ImageJob j;
+  j.w = w; j.img_a = img_fwd; j.img_b = img_bwd; j.first = first;
+  j.segs_a = image_bytes(k, ci, co, ta, esz) / 16;
+  j.n_red = ci; j.n_col = co; j.role = 0; j.nb_a = ta.nb; j.kc_a = ta.row_bytes / esz;
+  j.segs_b = 0; j.nb_b = ta.nb; j.kc_b = j.kc_a; j.pad = 0;
+  if (img_bwd != nullptr) {
+    const Tiling tb = pick_tiling(co, ci, n_out_bwd, esz);
+    j.segs_b = image_bytes(k, co, ci, tb, esz) / 16;
+    j.nb_b = tb.nb; j.kc_b = tb.row_bytes / esz;
+  }
+  *reinterpret_cast<ImageJob*>(job) = j;
+  return j.segs_a + j.segs_b;
+}
+
+// jobs: DEVICE array of n_jobs ImageJob records (as lidal_conv_weight_image_job filled them, in order)
+extern "C" int lidal_conv_weight_image_batch(const void* jobs, int n_jobs, int64_t total_segments,
+                                             int w_dtype, int dtype, void* stream) {
+  if (n_jobs == 0 || total_segments == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)cdiv(total_segments, 256);
+#define IMG_BATCH(TI, TO) \
+  weight_image_batch_kernel<TI, TO><<<grid, 256, 0, s>>>((const ImageJob*)jobs, n_jobs, total_segments)
+  if (w_dtype == LIDAL_F32 && dtype == LIDAL_F32) IMG_BATCH(float, float);
+  else if (w_dtype == LIDAL_F32 && dtype == LIDAL_BF16) IMG_BATCH(float, __bf16);
+  else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_BF16) IMG_BATCH(__bf16, __bf16);
+  else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_F32) IMG_BATCH(__bf16, float);
+  else {
+    set_error("weight_image_batch: bad dtypes %d %d", w_dtype, dtype);
+    return 2;
+  }
+#undef IMG_BATCH
+  LIDAL_CHECK_LAUNCH("lidal_conv_weight_image_batch");
+  return 0;
 }
 
 extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,

@@ -12,6 +12,8 @@ values) plus what the output-stationary kernel consumes:
   nbr_in  [K, n_in]   output row fed by input row i through offset k (built lazily)
   order_out/order_in  RowOrder: the tables with rows sorted by occupancy pattern (built lazily)
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -222,8 +224,81 @@ def _weight_image(weight, dtype, n_out, role):
     return img
 
 
+class _ImageBank:
+    """Training: the image pairs of every convolution weight, rebuilt by ONE launch per step.
+    A weight registers itself at its first use (its images then live in a persistent buffer, keyed by
+    the tilings the two row counts select); whenever a requested image is older than its weight
+    (`_version` moved: the optimizer stepped), ALL registered weights of that device / dtype whose
+    images are stale are rebuilt together (lidal_conv_weight_image_batch) -- 42 launches of ~7 us
+    become one.  LIDAL_IMAGE_BATCH=0 rebuilds per call as before."""
+
+    def __init__(self):
+        self.entries = {}           # id(weight) -> entry dict
+        self.tables = {}            # (device, code, w_code) -> (signature, device table, n_jobs, total)
+
+    def get(self, weight, dtype, n_out_fwd, n_out_bwd):
+        import weakref
+        k, ci, co = weight.shape
+        code = B.dtype_code(dtype)
+        L = B.lib()
+        key = (weight.data_ptr(), code, weight.dtype, L.lidal_conv_weight_image_tiling(ci, co, code, n_out_fwd),
+               L.lidal_conv_weight_image_tiling(co, ci, code, n_out_bwd))
+        e = self.entries.get(id(weight))
+        if e is None or e['ref']() is not weight or e['key'] != key:
+            nf = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out_fwd)
+            nb = L.lidal_conv_weight_image_bytes(k, co, ci, code, n_out_bwd)
+            buf = torch.empty(nf + nb, dtype=torch.uint8, device=weight.device)
+            wid = id(weight)
+            e = {'ref': weakref.ref(weight, lambda _r, wid=wid: self.entries.pop(wid, None)), 'key': key,
+                 'buf': buf, 'img_f': buf[:nf], 'img_b': buf[nf:], 'version': -1, 'code': code,
+                 'n_out': (n_out_fwd, n_out_bwd), 'group': (str(weight.device), code, B.dtype_code(weight.dtype))}
+            self.entries[wid] = e
+        if e['version'] != weight._version:
+            self._rebuild(e['group'])
+        return e['img_f'], e['img_b']
+
+    def _rebuild(self, group):
+        """All stale images of `group` in one launch."""
+        L = B.lib()
+        stale = []
+        for e in self.entries.values():
+            w = e['ref']()
+            if w is not None and e['group'] == group and e['version'] != w._version:
+                stale.append((e, w))
+        sig = tuple((id(e), e['key']) for e, _ in stale)
+        cached = self.tables.get(group)
+        if cached is None or cached[0] != sig:
+            import ctypes
+            jb = L.lidal_conv_weight_image_job_bytes()
+            host = ctypes.create_string_buffer(jb * len(stale))
+            first = 0
+            for i, (e, w) in enumerate(stale):
+                k, ci, co = w.shape
+                n = L.lidal_conv_weight_image_job(ctypes.c_void_p(ctypes.addressof(host) + i * jb), B.ptr(w),
+                                                  B.ptr(e['img_f']), e['n_out'][0], B.ptr(e['img_b']),
+                                                  e['n_out'][1], e['code'], k, ci, co, first)
+                if n < 0:
+                    B.check(1, 'conv_weight_image_job')
+                first += n
+            table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(stale[0][1].device)
+            cached = (sig, table, len(stale), first)
+            self.tables[group] = cached
+        _, table, n_jobs, total = cached
+        B.check(L.lidal_conv_weight_image_batch(B.ptr(table), n_jobs, total, group[2], group[1], B.stream()),
+                'conv_weight_image')
+        for e, w in stale:
+            e['version'] = w._version
+
+
+_IMAGE_BANK = _ImageBank()
+_IMAGE_BATCH = os.environ.get('LIDAL_IMAGE_BATCH', '1') != '0'
+
+
 def _weight_image_pair(weight, dtype, n_out_fwd, n_out_bwd):
-    """(forward image, data-gradient image) of a [K, ci, co] weight from ONE launch."""
+    """(forward image, data-gradient image) of a [K, ci, co] weight: from the step's one batched
+    launch (_ImageBank) for contiguous parameters, else from ONE launch of their own."""
+    if _IMAGE_BATCH and isinstance(weight, torch.nn.Parameter) and weight.is_contiguous():
+        return _IMAGE_BANK.get(weight, dtype, n_out_fwd, n_out_bwd)
     k, ci, co = weight.shape
     w = weight.detach().contiguous()
     code = B.dtype_code(dtype)

@@ -288,3 +288,34 @@ def test_config1_10k_point_scan_forward(golden_dir):
     assert _rel(logits.cpu().numpy(), g['spvcnn_logits']) < 1e-4
     assert _rel(feat.cpu().numpy()[::16], g['spvcnn_feat_sample']) < 1e-4
     assert np.array_equal(logits.argmax(1).cpu().numpy(), g['spvcnn_logits'].argmax(1))
+
+
+@pytest.mark.parametrize('autocast', [False, True])
+def test_batched_weight_images_equal_per_layer_images(autocast):
+    """Training rebuilds the LDS images of ALL convolution weights with one launch per step
+    (nn/functional/conv.py: _ImageBank, keyed on the weights' version counters); five Adam steps must
+    give bitwise the losses and parameters of per-layer rebuilds -- a stale image (an optimizer step
+    the bank missed) would change them."""
+    from lidal_amd import synth
+    from lidal_amd.nn.functional import conv as C
+    from lidal_amd.train_step import train_step
+    b = synth.make_train_batch(n_frames=1, n_points=6000, seed=5)
+    c = torch.from_numpy(b['coords_v_b']).to(DEV)
+    f = torch.from_numpy(b['feats_v_b']).to(DEV)
+    lab = torch.from_numpy(b['labels_v_b']).to(DEV)
+    runs = []
+    saved = C._IMAGE_BATCH
+    try:
+        for batch in (False, True):
+            C._IMAGE_BATCH = batch
+            torch.manual_seed(0)
+            model = _models()['spvcnn'](19).to(DEV).train()
+            model.dropout.p = 0.0
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+            losses = [train_step(model, opt, f, c, lab, autocast=autocast)[0].item() for _ in range(5)]
+            runs.append((losses, [p.detach().clone() for p in model.parameters()]))
+    finally:
+        C._IMAGE_BATCH = saved
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert all(torch.equal(a, bb) for a, bb in zip(runs[0][1], runs[1][1]))
+    assert runs[0][0][-1] != runs[0][0][0]

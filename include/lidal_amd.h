@@ -213,12 +213,13 @@ int lidal_conv_weight_image_pair(const void* w, int w_dtype, void* img_fwd, int6
                                  void* stream);
 /* the image pairs of MANY parameters in one launch (training: every weight changes every step).
  * lidal_conv_weight_image_job fills one host record of lidal_conv_weight_image_job_bytes() bytes
- * (`first` = segments of the records before it; returns this record's segment count, < 0 on error);
+ * (role 0: w is [k][ci][co], role 1: [k][co][ci] = nn.Linear's layout; `first` = segments of the
+ * records before it; returns this record's segment count, < 0 on error);
  * lidal_conv_weight_image_batch takes the records as a DEVICE array. */
 int lidal_conv_weight_image_job_bytes(void);
-int64_t lidal_conv_weight_image_job(void* job, const void* w, void* img_fwd, int64_t n_out_fwd,
-                                    void* img_bwd, int64_t n_out_bwd, int dtype, int k, int ci, int co,
-                                    int64_t first);
+int64_t lidal_conv_weight_image_job(void* job, const void* w, int role, void* img_fwd,
+                                    int64_t n_out_fwd, void* img_bwd, int64_t n_out_bwd, int dtype,
+                                    int k, int ci, int co, int64_t first);
 int lidal_conv_weight_image_batch(const void* jobs, int n_jobs, int64_t total_segments, int w_dtype,
                                   int dtype, void* stream);
 int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr, const int32_t* perm,

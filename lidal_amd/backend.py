@@ -67,7 +67,7 @@ SIGNATURES = {
     'lidal_conv_weight_image': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     'lidal_conv_weight_image_pair': (_i32, [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'lidal_conv_weight_image_job_bytes': (_i32, []),
-    'lidal_conv_weight_image_job': (_i64, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i64]),
+    'lidal_conv_weight_image_job': (_i64, [_vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i64]),
     'lidal_conv_weight_image_batch': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp]),
     'lidal_conv_apply_image': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
                                       _vp, _i32, _vp, _vp, _vp]),

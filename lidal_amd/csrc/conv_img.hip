@@ -1195,18 +1195,22 @@ extern "C" int lidal_conv_weight_image_pair(const void* w, int w_dtype, void* im
 
 extern "C" int lidal_conv_weight_image_job_bytes(void) { return (int)sizeof(ImageJob); }
 
-// fills one ImageJob (host memory) for the pair of images lidal_conv_weight_image_pair would build;
-// `first` = segments of the jobs before it; returns this job's segment count (< 0: error)
-extern "C" int64_t lidal_conv_weight_image_job(void* job, const void* w, void* img_fwd, int64_t n_out_fwd,
-                                               void* img_bwd, int64_t n_out_bwd, int dtype, int k, int ci,
-                                               int co, int64_t first) {
-  if (job == nullptr || (dtype != LIDAL_F32 && dtype != LIDAL_BF16)) { set_error("weight_image_job: bad arguments"); return -1; }
+// fills one ImageJob (host memory) for the pair of images lidal_conv_weight_image_pair would build
+// (role 0: w is [k][ci][co]; role 1: w is [k][co][ci], nn.Linear's layout -- the forward image still
+// reduces over ci); `first` = segments of the jobs before it; returns this job's segment count (< 0: error)
+extern "C" int64_t lidal_conv_weight_image_job(void* job, const void* w, int role, void* img_fwd,
+                                               int64_t n_out_fwd, void* img_bwd, int64_t n_out_bwd,
+                                               int dtype, int k, int ci, int co, int64_t first) {
+  if (job == nullptr || (dtype != LIDAL_F32 && dtype != LIDAL_BF16) || (role != 0 && role != 1)) {
+    set_error("weight_image_job: bad arguments");
+    return -1;
+  }
   const int esz = dtype == LIDAL_BF16 ? 2 : 4;
   const Tiling ta = pick_tiling(ci, co, n_out_fwd, esz);
   ImageJob j;
   j.w = w; j.img_a = img_fwd; j.img_b = img_bwd; j.first = first;
   j.segs_a = image_bytes(k, ci, co, ta, esz) / 16;
-  j.n_red = ci; j.n_col = co; j.role = 0; j.nb_a = ta.nb; j.kc_a = ta.row_bytes / esz;
+  j.n_red = ci; j.n_col = co; j.role = role; j.nb_a = ta.nb; j.kc_a = ta.row_bytes / esz;
   j.segs_b = 0; j.nb_b = ta.nb; j.kc_b = j.kc_a; j.pad = 0;
   if (img_bwd != nullptr) {
     const Tiling tb = pick_tiling(co, ci, n_out_bwd, esz);

@@ -234,24 +234,30 @@ class _ImageBank:
 
     def __init__(self):
         self.entries = {}           # id(weight) -> entry dict
+        self.serial = 0             # entries are told apart by a serial number (id()s get re-used)
         self.tables = {}            # (device, code, w_code) -> (signature, device table, n_jobs, total)
 
-    def get(self, weight, dtype, n_out_fwd, n_out_bwd):
+    def get(self, weight, dtype, n_out_fwd, n_out_bwd, shape=None, role=0):
+        """`shape` = (k, ci, co) of the operand when `weight` is not [k, ci, co] itself: a [ci, co]
+        1x1x1 kernel (role 0) or nn.Linear's [co, ci] weight (role 1)."""
         import weakref
-        k, ci, co = weight.shape
+        k, ci, co = shape if shape is not None else weight.shape
         code = B.dtype_code(dtype)
         L = B.lib()
         key = (weight.data_ptr(), code, weight.dtype, L.lidal_conv_weight_image_tiling(ci, co, code, n_out_fwd),
-               L.lidal_conv_weight_image_tiling(co, ci, code, n_out_bwd))
+               L.lidal_conv_weight_image_tiling(co, ci, code, n_out_bwd), role)
         e = self.entries.get(id(weight))
         if e is None or e['ref']() is not weight or e['key'] != key:
             nf = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out_fwd)
             nb = L.lidal_conv_weight_image_bytes(k, co, ci, code, n_out_bwd)
             buf = torch.empty(nf + nb, dtype=torch.uint8, device=weight.device)
             wid = id(weight)
+            self.serial += 1
             e = {'ref': weakref.ref(weight, lambda _r, wid=wid: self.entries.pop(wid, None)), 'key': key,
+                 'serial': self.serial,
                  'buf': buf, 'img_f': buf[:nf], 'img_b': buf[nf:], 'version': -1, 'code': code,
-                 'n_out': (n_out_fwd, n_out_bwd), 'group': (str(weight.device), code, B.dtype_code(weight.dtype))}
+                 'n_out': (n_out_fwd, n_out_bwd), 'shape': (k, ci, co), 'role': role,
+                 'group': (str(weight.device), code, B.dtype_code(weight.dtype))}
             self.entries[wid] = e
         if e['version'] != weight._version:
             self._rebuild(e['group'])
@@ -265,7 +271,7 @@ class _ImageBank:
             w = e['ref']()
             if w is not None and e['group'] == group and e['version'] != w._version:
                 stale.append((e, w))
-        sig = tuple((id(e), e['key']) for e, _ in stale)
+        sig = tuple(e['serial'] for e, _ in stale)
         cached = self.tables.get(group)
         if cached is None or cached[0] != sig:
             import ctypes
@@ -273,9 +279,9 @@ class _ImageBank:
             host = ctypes.create_string_buffer(jb * len(stale))
             first = 0
             for i, (e, w) in enumerate(stale):
-                k, ci, co = w.shape
+                k, ci, co = e['shape']
                 n = L.lidal_conv_weight_image_job(ctypes.c_void_p(ctypes.addressof(host) + i * jb), B.ptr(w),
-                                                  B.ptr(e['img_f']), e['n_out'][0], B.ptr(e['img_b']),
+                                                  e['role'], B.ptr(e['img_f']), e['n_out'][0], B.ptr(e['img_b']),
                                                   e['n_out'][1], e['code'], k, ci, co, first)
                 if n < 0:
                     B.check(1, 'conv_weight_image_job')

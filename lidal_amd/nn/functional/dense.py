@@ -109,7 +109,14 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
     xc = x.contiguous().to(cdtype)
     co = w.shape[0] if linear else w.shape[1]
     pad = (-co) % _vec(cdtype) if xc.is_cuda else 0
-    wc = _operand(w, linear, cdtype, pad)
+    from . import conv as C
+    # training, a plain f32 parameter: its images come from the step's one batched launch, built from
+    # the parameter itself -- no cast / transposed copy of the operand is needed (shape only)
+    banked = (with_bwd_image and epilogue is None and C._IMAGE_BATCH and not pad
+              and isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
+              and _gemm_ok(xc, xc.shape[1], co))
+    wc = (torch.empty((xc.shape[1], co), dtype=cdtype, device='meta') if banked
+          else _operand(w, linear, cdtype, pad))
     scale = shift = residual = None
     relu = False
     if epilogue is not None:
@@ -129,7 +136,8 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
         late = residual is not None and fused_res is None       # sum (and its ReLU) outside the kernel
         img_f = None
         img_key = None
-        if not torch.is_grad_enabled():     # inference: the image of an unchanged parameter is re-used
+        # (grad mode is also off inside RowsMatmul.forward: `with_bwd_image` tells training apart)
+        if not with_bwd_image and not torch.is_grad_enabled():     # inference: the image of an unchanged parameter is re-used
             code = B.dtype_code(cdtype)
             img_key = (w._version, w.data_ptr(), linear, code, pad,
                        B.lib().lidal_conv_weight_image_tiling(xc.shape[1], co + pad, code, xc.shape[0]))
@@ -145,8 +153,11 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
                     w._lidal_images = cache
                 cache[img_key] = img_f
         if with_bwd_image:      # forward and data-gradient operands of this parameter from one launch
-            from .conv import _weight_image_pair
-            img_f, img_b = _weight_image_pair(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], xc.shape[0])
+            if banked:          # ... straight from the f32 parameter in its own layout
+                img_f, img_b = C._IMAGE_BANK.get(w, cdtype, xc.shape[0], xc.shape[0],
+                                                 (1, xc.shape[1], co), 1 if linear else 0)
+            else:
+                img_f, img_b = C._weight_image_pair(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], xc.shape[0])
         want_stats = want_stats and not pad and not late and cdtype == torch.bfloat16
         y = _rows_gemm(xc, wc, 0, shift, scale,
                        int(relu) & 1 if late else int(relu), fused_res, img_f, want_stats)

@@ -3,6 +3,6 @@ set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/r2c47; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; tail -6 $O/gpu_tests.log
-for f in 0 1 0 1; do LIDAL_IMAGE_BATCH=$f timeout 600 python bench.py --steps 20 --no-cpu-baseline --no-secondary --no-families --no-roofline --no-variants 2>&1 | tail -1 | python3 -c "
+for f in 1 1 1; do LIDAL_IMAGE_BATCH=$f timeout 600 python bench.py --steps 20 --no-cpu-baseline --no-secondary --no-families --no-roofline --no-variants 2>&1 | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('batch=$f', d['ms_per_step'])"; done

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'liblidal_amd.so')
-SOURCES = ['error.cpp', 'hash.hip', 'kmap.hip', 'voxel.hip', 'conv.hip', 'conv_img.hip', 'wgrad_dma.hip', 'bn.hip', 'elementwise.hip', 'score.hip']
+SOURCES = ['error.cpp', 'hash.hip', 'kmap.hip', 'voxel.hip', 'conv.hip', 'conv_img.hip', 'wgrad_dma.hip', 'sort.hip', 'bn.hip', 'elementwise.hip', 'score.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
 # units that restate numpy arithmetic (separately rounded products and sums): no fma contraction
 NO_CONTRACT = {'score.hip', 'kmap.hip'}

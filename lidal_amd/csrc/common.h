@@ -141,4 +141,10 @@ int wgrad_dma(const void* a, const void* b, int64_t n_a, int64_t n_b, const int*
               const int64_t* koff, int a_col, float* gw, float* partial, int W, int K, int ca,
               int cb, hipStream_t s);
 
+// sort.hip: stable LSD radix sort of (u32 key, i32 value) pairs by the low `bits` key bits, 1 + ceil(bits/8)
+// launches; keys_in / vals_in are not written
+int64_t sort_pairs_ws_bytes(int64_t n);
+int sort_pairs_u32(const unsigned* keys_in, const int* vals_in, unsigned* keys_out, int* vals_out,
+                   int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s);
+
 }  // namespace lidal

@@ -709,9 +709,14 @@ extern "C" int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, i
   return 0;
 }
 
+static int64_t order_sort_tmp_bytes(int64_t q) {
+  const int64_t a = (int64_t)mask_sort_tmp_bytes(q), b = sort_pairs_ws_bytes(q);
+  return a > b ? a : b;
+}
+
 extern "C" int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows) {
   int64_t q = n_rows > 0 ? n_rows : 1;
-  return 3 * align_up(4 * q, 256) + align_up((int64_t)mask_sort_tmp_bytes(q), 256) + 256;
+  return 3 * align_up(4 * q, 256) + align_up(order_sort_tmp_bytes(q), 256) + 256;
 }
 
 extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32_t* perm,
@@ -730,6 +735,14 @@ extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32
   const BitRank rank = bit_rank(k);
   row_mask_kernel<<<(unsigned)cdiv(q, 256), 256, 0, s>>>(nbr, q, k, rank, keys, vals);
   LIDAL_CHECK_LAUNCH("row_mask");
+  // 8-bit masks (2x2x2 maps): the library's own one-pass radix sort (csrc/sort.hip: 19-28 us for
+  // 226k-397k pairs against Onesweep's 36); wider masks stay on rocPRIM's merge sort, which sort.hip
+  // does not beat (4 passes with scattered 4-byte writes: 168 us against 114 for 397k 27-bit pairs)
+#ifndef LIDAL_ROCPRIM_SORT
+  if (k <= 8) {
+    if (int rc = sort_pairs_u32(keys, vals, skeys, perm, q, k, tmp, order_sort_tmp_bytes(q), s)) return rc;
+  } else
+#endif
   if (k <= 8)
     LIDAL_HIP(rocprim::radix_sort_pairs<NarrowKeySort>(tmp, tmp_bytes, keys, skeys, vals, perm,
                                                        (size_t)q, 0, k, s));

@@ -558,9 +558,14 @@ extern "C" int lidal_ti_weights(const float* coords, int cstride, const int64_t*
   return 0;
 }
 
+static int64_t inv_tmp_bytes(int64_t q) {
+  const int64_t a = (int64_t)inv_sort_tmp_bytes(q), b = sort_pairs_ws_bytes(q);
+  return a > b ? a : b;
+}
+
 extern "C" int64_t lidal_invlist_workspace_bytes(int64_t n_entries) {
   int64_t q = n_entries > 0 ? n_entries : 1;
-  return 2 * align_up(4 * q, 256) + align_up(4 * q, 256) + align_up((int64_t)inv_sort_tmp_bytes(q), 256) + 256;
+  return 2 * align_up(4 * q, 256) + align_up(4 * q, 256) + align_up(inv_tmp_bytes(q), 256) + 256;
 }
 
 extern "C" int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n_entries, int64_t m,

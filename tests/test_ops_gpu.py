@@ -851,3 +851,34 @@ def test_batch_norm_residual_rides_in_the_normalising_pass(dtype):
     for a, bb in zip(*outs):
         assert torch.equal(a, bb)
     assert torch.equal(outs[1][2], go)
+
+
+@pytest.mark.parametrize('n,bits', [(1, 8), (63, 3), (255, 8), (256, 8), (257, 9), (1000, 27), (4097, 16), (50001, 27),
+                                    (396662, 27), (396662, 8), (1000003, 19), (3200000, 17), (70000, 32)])
+def test_radix_sort_pairs_is_the_stable_sort(n, bits):
+    """csrc/sort.hip (what lidal_kmap_order sorts the 8-bit masks with): keys and values
+    bit-equal to torch.sort(stable=True) -- a stable sort has one answer -- for lists shorter than
+    a round, of exactly one range, of several ranges, with heavy duplicates (3- and 8-bit keys) and
+    with full 32-bit keys; the inputs are left untouched."""
+    from lidal_amd import backend as B
+    g = torch.Generator().manual_seed(n + bits)
+    hi = 1 << bits
+    keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int64)
+    if n > 1000:        # a run of equal keys that spans ranges, and the extreme values
+        keys[n // 3: n // 3 + n // 5] = keys[0]
+        keys[-1], keys[1] = hi - 1, 0
+    vals = torch.randperm(n, generator=g).int()
+    k_dev = (keys & 0xFFFFFFFF).to(torch.int64).to(DEV)
+    k32 = torch.where(k_dev >= 2 ** 31, k_dev - 2 ** 32, k_dev).int()      # same bits as u32
+    v_dev = vals.to(DEV)
+    k_in, v_in = k32.clone(), v_dev.clone()
+    ko, vo = torch.empty_like(k32), torch.empty_like(v_dev)
+    nbytes = B.lib().lidal_sort_pairs_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    B.check(B.lib().lidal_sort_pairs(B.ptr(k32), B.ptr(v_dev), B.ptr(ko), B.ptr(vo), n, bits, B.ptr(ws), nbytes,
+                                     B.stream()), 'sort_pairs')
+    sk, order = torch.sort(keys.to(DEV), stable=True)
+    got_keys = ko.long() & 0xFFFFFFFF
+    assert torch.equal(got_keys, sk)
+    assert torch.equal(vo, v_dev[order])
+    assert torch.equal(k32, k_in) and torch.equal(v_dev, v_in)

@@ -333,7 +333,7 @@ def family_table(step, coords, dtype_name, step_ms):
             # the statistics pass that `_tiles` no longer makes stays in the algorithmic count (3 N C b)
             by = (2 if name == 'lidal_bn_eval_fwd' else 3) * a[2] * a[3] * (2 if a[1] == 1 else 4)
         elif name == 'lidal_bn_bwd':
-            by = 5 * a[3] * a[4] * (2 if a[2] == 1 else 4)
+            by = 5 * a[4] * a[5] * (2 if a[3] == 1 else 4)
         elif name == 'lidal_colsum':
             by = a[2] * a[3] * (2 if a[1] == 1 else 4)
         elif name in ('lidal_add_relu_fwd', 'lidal_add_relu_bwd'):

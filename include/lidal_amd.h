@@ -277,8 +277,10 @@ int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int c, const f
 int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
                       const float* beta, const float* running_mean, const float* running_var,
                       float eps, int relu, void* y, void* stream);
-/* dx may be NULL (only parameter gradients wanted). */
-int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n, int c, const float* gamma,
+/* dx may be NULL (only parameter gradients wanted).  dy_stride = elements between the rows of dy
+ * (>= c, a multiple of the 16-byte vector): the gradient of a channel slice of a concatenation
+ * (network/utils.py:cat in the up stages) is read in place, without a contiguous copy. */
+int lidal_bn_bwd(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c, const float* gamma,
                  const float* beta, int relu, const float* save_mean, const float* save_invstd,
                  void* dx, float* grad_gamma, float* grad_beta, void* ws, int64_t ws_bytes,
                  void* stream);

@@ -81,7 +81,7 @@ SIGNATURES = {
     'lidal_bn_train_fwd_tiles': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp,
                                         _vp, _vp, _vp, _i64, _vp]),
     'lidal_bn_eval_fwd': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp]),
-    'lidal_bn_bwd': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+    'lidal_bn_bwd': (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                             _i64, _vp]),
     'lidal_bn_fold': (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
     'lidal_colsum': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp]),

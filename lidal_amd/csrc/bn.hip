@@ -254,7 +254,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
-                                                            int relu, double* __restrict__ part, int rpw) {
+                                                            int relu, double* __restrict__ part, int rpw,
+                                                            int64_t ldy) {
   constexpr int VEC = IO<T>::VEC;
   extern __shared__ double sh[];                // [2][NT][VEC]
   const int cg_n = c / VEC, rpi = NT / cg_n;
@@ -289,14 +290,14 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
-        vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * c + cg * VEC);
+        vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * ldy + cg * VEC);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) one(vx[u], vd[u]);
     }
     for (; r < r_end; r += rpi)
       one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
-          *reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC));
+          *reinterpret_cast<const typename IO<T>::vec*>(dy + r * ldy + cg * VEC));
   }
   double* sa = sh; double* sb = sh + NT * VEC;
 #pragma unroll
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
                                                        const float* __restrict__ beta, int relu,
                                                        const float* __restrict__ sum_dy,
                                                        const float* __restrict__ sum_dy_xhat,
-                                                       T* __restrict__ dx, int rpw) {
+                                                       T* __restrict__ dx, int rpw, int64_t ldy) {
   constexpr int VEC = IO<T>::VEC;
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
@@ -381,14 +382,14 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
-      vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * c + cg * VEC);
+      vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * ldy + cg * VEC);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) one(vx[u], vd[u], r + u * rpi);
   }
   for (; r < r_end; r += rpi)
     one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
-        *reinterpret_cast<const typename IO<T>::vec*>(dy + r * c + cg * VEC), r);
+        *reinterpret_cast<const typename IO<T>::vec*>(dy + r * ldy + cg * VEC), r);
 }
 
 // Slab size = rows / 256: one workgroup per CU on every level.  Each workgroup pays a fixed set-up
@@ -427,20 +428,20 @@ int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const floa
 }
 
 template <typename T>
-int bn_bwd(const void* x, const void* dy, int64_t n, int c, const float* gamma, const float* beta,
-           int relu, const float* mean, const float* invstd, void* dx, float* ggamma, float* gbeta,
-           double* part, hipStream_t s) {
+int bn_bwd(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const float* gamma,
+           const float* beta, int relu, const float* mean, const float* invstd, void* dx, float* ggamma,
+           float* gbeta, double* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
   int np = nparts_for(n);
   bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>(
-      (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, rows_per_wg(n));
+      (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, rows_per_wg(n), ldy);
   LIDAL_CHECK_LAUNCH("bn_bwd_partial");
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gbeta, ggamma);
   LIDAL_CHECK_LAUNCH("bn_bwd_final");
   if (dx != nullptr) {
     bn_bwd_dx_kernel<T><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd,
                                                     gamma, beta, relu, gbeta, ggamma, (T*)dx,
-                                                    rows_per_wg_ew(n));
+                                                    rows_per_wg_ew(n), ldy);
     LIDAL_CHECK_LAUNCH("bn_bwd_dx");
   }
   return 0;
@@ -583,7 +584,7 @@ extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, con
   return 0;
 }
 
-extern "C" int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n, int c,
+extern "C" int lidal_bn_bwd(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c,
                             const float* gamma, const float* beta, int relu,
                             const float* save_mean, const float* save_invstd, void* dx,
                             float* grad_gamma, float* grad_beta, void* ws, int64_t ws_bytes,
@@ -591,11 +592,14 @@ extern "C" int lidal_bn_bwd(const void* x, const void* dy, int dtype, int64_t n,
   if (int rc = bn_check(n, c, dtype)) return rc;
   LIDAL_REQUIRE(n > 0, "bn_bwd: needs at least one row");
   LIDAL_REQUIRE(ws_bytes >= lidal_bn_workspace_bytes(n, c), "bn workspace too small");
+  const int vec = dtype == LIDAL_F32 ? 4 : 8;
+  LIDAL_REQUIRE(dy_stride >= c && dy_stride % vec == 0, "bn_bwd: dy row stride %lld (rows of %d, 16-byte steps)",
+                (long long)dy_stride, c);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
-    return bn_bwd<float>(x, dy, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
+    return bn_bwd<float>(x, dy, dy_stride, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
                          grad_beta, (double*)ws, s);
-  return bn_bwd<__bf16>(x, dy, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
+  return bn_bwd<__bf16>(x, dy, dy_stride, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
                         grad_beta, (double*)ws, s);
 }
 
@@ -627,11 +631,11 @@ extern "C" int lidal_colsum(const void* x, int dtype, int64_t n, int c, float* o
   if (dtype == LIDAL_F32)
     bn_bwd_partial_kernel<float><<<np, NT, 2 * NT * 4 * sizeof(double), s>>>(
         (const float*)x, (const float*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part,
-        rows_per_wg(n));
+        rows_per_wg(n), (int64_t)c);
   else
     bn_bwd_partial_kernel<__bf16><<<np, NT, 2 * NT * 8 * sizeof(double), s>>>(
         (const __bf16*)x, (const __bf16*)x, n, c, zeros, zeros, nullptr, nullptr, 0, part,
-        rows_per_wg(n));
+        rows_per_wg(n), (int64_t)c);
   LIDAL_CHECK_LAUNCH("colsum_partial");
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, out, scratch);
   LIDAL_CHECK_LAUNCH("colsum_final");

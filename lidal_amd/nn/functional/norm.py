@@ -75,7 +75,14 @@ class BatchNormRows(Function):
     def backward(ctx, grad_out):
         x, w, b, mean, invstd = ctx.saved_tensors
         n, c = x.shape
-        g = grad_out.contiguous().to(x.dtype)
+        # a channel slice of a concatenation's gradient (up stages) is read in place by the kernels
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        if (grad_out.dim() == 2 and grad_out.dtype == x.dtype and grad_out.stride(1) == 1 and ctx.training
+                and grad_out.stride(0) >= c and grad_out.stride(0) % vec == 0
+                and grad_out.storage_offset() % vec == 0):
+            g = grad_out
+        else:
+            g = grad_out.contiguous().to(x.dtype)
         if not ctx.training:            # eval-mode backward (not on the LiDAL path): plain torch
             xhat = (x.float() - mean) * invstd
             gf = g.float()
@@ -88,7 +95,7 @@ class BatchNormRows(Function):
         gg = torch.empty(c, dtype=torch.float32, device=x.device)
         gb = torch.empty(c, dtype=torch.float32, device=x.device)
         ws, nbytes = _ws(n, c, x.device)
-        B.check(B.lib().lidal_bn_bwd(B.ptr(x), B.ptr(g), B.dtype_code(x.dtype), n, c, B.ptr(w),
+        B.check(B.lib().lidal_bn_bwd(B.ptr(x), B.ptr(g), g.stride(0), B.dtype_code(x.dtype), n, c, B.ptr(w),
                                      B.ptr(b), int(ctx.relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),
                                      B.ptr(gg), B.ptr(gb),
                                      B.ptr(ws), nbytes, B.stream()), 'bn_bwd')

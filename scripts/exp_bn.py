@@ -48,7 +48,7 @@ def main():
                                                B.ptr(ts), n_tiles, B.stream()), 'fwd_tiles')
 
         def bwd():
-            B.check(L.lidal_bn_bwd(B.ptr(x), B.ptr(go), 1, n, c, B.ptr(w), B.ptr(b), 1, B.ptr(mean),
+            B.check(L.lidal_bn_bwd(B.ptr(x), B.ptr(go), c, 1, n, c, B.ptr(w), B.ptr(b), 1, B.ptr(mean),
                                    B.ptr(invstd), B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(ws), nbytes,
                                    B.stream()), 'bwd')
         fwd()

@@ -882,3 +882,27 @@ def test_radix_sort_pairs_is_the_stable_sort(n, bits):
     assert torch.equal(got_keys, sk)
     assert torch.equal(vo, v_dev[order])
     assert torch.equal(k32, k_in) and torch.equal(v_dev, v_in)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batch_norm_backward_reads_a_channel_slice_in_place(dtype):
+    """The up stages concatenate [deconv output | skip]; the BatchNorm behind the deconv receives the
+    left channel slice of the concatenation's gradient -- a strided view.  lidal_bn_bwd reads it in
+    place (dy_stride); results are bitwise those of a contiguous copy."""
+    from lidal_amd.nn.functional.norm import batch_norm_rows
+    g = torch.Generator().manual_seed(3)
+    n, c, extra = 4099, 96, 32
+    x = torch.randn(n, c, generator=g).to(DEV).to(dtype)
+    wide = torch.randn(n, c + extra, generator=g).to(DEV).to(dtype)
+    w = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    b = torch.randn(c, generator=g).to(DEV)
+    outs = []
+    for go in (wide[:, :c], wide[:, :c].contiguous()):
+        xi = x.clone().requires_grad_(True)
+        wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = batch_norm_rows(xi, wi, bi, torch.zeros(c, device=DEV), torch.ones(c, device=DEV), True, 0.1, 1e-5, True)
+        y.backward(go)
+        outs.append((xi.grad, wi.grad, bi.grad))
+    assert not wide[:, :c].is_contiguous()
+    for a, bb in zip(*outs):
+        assert torch.equal(a, bb)

@@ -6,7 +6,10 @@
 //     397k pairs, 27 bits  168 (merge sort: 114-137)               3.2M pairs, 19 bits 364 (175)
 // One pass is competitive; several are not: every pass scatters its items as single 4-byte writes
 // (a 1024-item round holds ~4 items per digit, so runs are 16 bytes), where Onesweep first orders
-// ~8k items per workgroup in LDS and writes runs of 128 bytes.  The library therefore uses this
+// ~8k items per workgroup in LDS and writes runs of 128 bytes.  (Tried here too: 8192-item rounds
+// ordered in LDS before the write-out -- 177 us for the 27-bit case: with coalesced writes the
+// counting of the next digit at the landing place, ~400k contended global atomics per pass, is what
+// remains; counting in a launch of its own instead costs what a pass costs.)  The library therefore uses this
 // sort for the 8-bit occupancy masks of the 2x2x2 maps only; the 27-bit masks, the voxel
 // lists and the 60-bit coordinate keys stay on rocPRIM.  1 + P launches for P = ceil(bits / 8):
 //   * the items are cut into NB <= 256 contiguous ranges, one workgroup each;

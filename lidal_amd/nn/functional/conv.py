@@ -230,7 +230,10 @@ class _ImageBank:
     the tilings the two row counts select); whenever a requested image is older than its weight
     (`_version` moved: the optimizer stepped), ALL registered weights of that device / dtype whose
     images are stale are rebuilt together (lidal_conv_weight_image_batch) -- 42 launches of ~7 us
-    become one.  LIDAL_IMAGE_BATCH=0 rebuilds per call as before."""
+    become one.  LIDAL_IMAGE_BATCH=0 rebuilds per call as before.
+    The version counter is what torch's optimizers, `copy_` and `load_state_dict` move; a write through
+    `param.data` (which carries its own counter) is invisible to it -- as it is to the inference caches --
+    and needs `param._version`-moving code (e.g. `param.add_(0)` under `no_grad`) or LIDAL_IMAGE_BATCH=0."""
 
     def __init__(self):
         self.entries = {}           # id(weight) -> entry dict

@@ -216,8 +216,14 @@ _OVERLAP = os.environ.get('LIDAL_WGRAD_STREAM', 'auto')
 FORK = int(os.environ.get('LIDAL_FORK', '7'))       # bit 0: residual blocks, bit 1: point features, bit 2: point-branch sum in BatchNorm
 
 
-def overlap_wgrad(dtype):
-    return _OVERLAP == '1' or (_OVERLAP == 'auto' and dtype == torch.float32)
+_OVERLAP_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAM_ROWS', '0'))
+
+
+def overlap_wgrad(dtype, n_rows=0):
+    if _OVERLAP == '1' or (_OVERLAP == 'auto' and dtype == torch.float32):
+        return True
+    # experiment: bf16 layers of the coarse levels only (their kernels do not fill the chip)
+    return _OVERLAP == 'auto' and 0 < n_rows <= _OVERLAP_ROWS
 
 
 def side_stream(device):

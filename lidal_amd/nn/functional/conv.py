@@ -445,7 +445,7 @@ class ConvolutionFunction(Function):
 
         side = None
         if ctx.needs_input_grad[1]:
-            if B.overlap_wgrad(x.dtype) and ctx.needs_input_grad[0]:
+            if B.overlap_wgrad(x.dtype, max(n_in, n_out)) and ctx.needs_input_grad[0]:
                 _ = kmap.koff                   # the rule lists are built on the main stream
                 side = B.beside(x.device, (x, g, kmap._nbmaps_cap, kmap.koff))
                 with side as done:              # beside the data gradient below

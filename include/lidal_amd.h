@@ -35,6 +35,9 @@ int lidal_version(void);
  * coords i32 [n,4] = (x,y,z,batch) -> out i64 [n]: FNV-1a-64 over the four 32-bit words folded to
  * 60 bits. */
 int lidal_hash(const int32_t* coords, int64_t n, int64_t* out, void* stream);
+/* network/utils.py:44-47,72-75: float rows (x, y, z, b) [n,4] -> int32 rows (floor(x/s) s, floor(y/s) s,
+ * floor(z/s) s, (int)b), the voxel a point falls into at tensor stride s, in one pass. */
+int lidal_floor_coords(const float* coords, int64_t n, int stride, int32_t* out, void* stream);
 /* replaces backend.kernel_hash_cuda  (F.sphash(coords, offsets): network/utils.py:70-74).
  * offsets i32 [k,3]; out i64 [k,n], hash of (xyz + offset_k, batch). */
 int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t* offsets, int k,

@@ -74,6 +74,27 @@ extern "C" int lidal_hash(const int32_t* coords, int64_t n, int64_t* out, void* 
   return 0;
 }
 
+// out[i] = (floor(x / s) s, floor(y / s) s, floor(z / s) s, (int)b) of a float row (x, y, z, b):
+// network/utils.py:44-47,72-75 (`torch.floor(z.C[:, :3] / s).int() * s` + cat of the batch column) as
+// ONE pass instead of six elementwise launches per point<->voxel exchange.  IEEE division, as torch
+// computes it for the power-of-two strides of the model (where a reciprocal multiply is exact too).
+__global__ void __launch_bounds__(256) floor_coords_kernel(const float4* __restrict__ c, int64_t n, float s,
+                                                           int si, int4* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = c[i];
+  out[i] = make_int4((int)floorf(v.x / s) * si, (int)floorf(v.y / s) * si, (int)floorf(v.z / s) * si, (int)v.w);
+}
+
+extern "C" int lidal_floor_coords(const float* coords, int64_t n, int stride, int32_t* out, void* stream) {
+  if (n == 0) return 0;
+  LIDAL_REQUIRE(stride > 0, "floor_coords: stride %d", stride);
+  floor_coords_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>((const float4*)coords, n, (float)stride,
+                                                                    stride, (int4*)out);
+  LIDAL_CHECK_LAUNCH("lidal_floor_coords");
+  return 0;
+}
+
 extern "C" int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t* offsets, int k,
                                  int64_t* out, void* stream) {
   if (n == 0 || k == 0) return 0;

@@ -15,8 +15,14 @@ __all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point']
 
 def _floor_to_stride(z, s):
     """(floor(xyz / s).int() * s, batch.int()) as one int32 [N,4] tensor (utils.py:44-47,72-75)."""
-    xyz = torch.floor(z.C[:, :3] / s).int() * s
-    return torch.cat([xyz, z.C[:, -1].int().view(-1, 1)], 1)
+    c = z.C
+    if c.is_cuda and c.dtype == torch.float32 and c.dim() == 2 and c.shape[1] == 4 and c.is_contiguous() \
+            and float(s) == int(s):
+        out = torch.empty(c.shape, dtype=torch.int32, device=c.device)      # one pass (csrc/hash.hip)
+        B.check(B.lib().lidal_floor_coords(B.ptr(c), c.shape[0], int(s), B.ptr(out), B.stream()), 'floor_coords')
+        return out
+    xyz = torch.floor(c[:, :3] / s).int() * s
+    return torch.cat([xyz, c[:, -1].int().view(-1, 1)], 1)
 
 
 def initial_voxelize(z, init_res, after_res):

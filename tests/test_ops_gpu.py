@@ -906,3 +906,19 @@ def test_batch_norm_backward_reads_a_channel_slice_in_place(dtype):
     assert not wide[:, :c].is_contiguous()
     for a, bb in zip(*outs):
         assert torch.equal(a, bb)
+
+
+@pytest.mark.parametrize('stride', [1, 2, 4, 8, 16])
+def test_floor_coords_is_the_reference_expression(stride):
+    """network/utils.py:44-47: `torch.floor(z.C[:, :3] / s).int() * s` + the batch column, in one
+    kernel (lidal_floor_coords); bit-equal to the torch expression incl. negative and whole values."""
+    from lidal_amd import PointTensor
+    from lidal_amd.network.glue import _floor_to_stride
+    g = torch.Generator().manual_seed(stride)
+    c = (torch.rand(20001, 4, generator=g) * 4000 - 300)
+    c[:100, :3] = torch.arange(-50, 50).float()[:, None]            # whole numbers, negatives
+    c[:, 3] = torch.randint(0, 5, (20001,), generator=g).float()
+    c = c.to(DEV)
+    want = torch.cat([torch.floor(c[:, :3] / stride).int() * stride, c[:, -1].int().view(-1, 1)], 1)
+    got = _floor_to_stride(PointTensor(torch.zeros(c.shape[0], 1, device=DEV), c), stride)
+    assert got.dtype == torch.int32 and torch.equal(got, want)

@@ -194,9 +194,9 @@ int64_t sort_pairs_ws_bytes(int64_t n) {
   return 2 * align_up(4 * q, 256) + align_up((int64_t)4 * MAX_RANGES * 256 * 4, 256);
 }
 
-// keys_in / vals_in are not written; keys_out / vals_out receive the sorted pairs (bits low key bits
-// significant, the others must be zero or equal).  keys_out may be null when only the permutation is
-// wanted?  No: it is the ping-pong partner; pass a buffer.
+// keys_in / vals_in are not written; keys_out / vals_out receive the sorted pairs (`bits` low key bits
+// significant, the higher ones must be zero).  keys_out is also the ping-pong partner of the
+// scratch buffer, so it cannot be omitted.
 int sort_pairs_u32(const unsigned* keys_in, const int* vals_in, unsigned* keys_out, int* vals_out,
                    int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s) {
   if (n == 0) return 0;

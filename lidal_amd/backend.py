@@ -197,6 +197,37 @@ def stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
+# ---- when may cached weight operands be re-used? -----------------------------------------------
+# LDS images of weights, folded BatchNorm maps etc. are cached per parameter.  A parameter's version
+# counter moves with `copy_` / `load_state_dict` / the foreach optimizers -- but NOT with
+# torch.optim.Adam(fused=True) (measured: five fused steps left `_version` where it was, and a bank keyed
+# on it alone trained on the first step's images), nor with writes through `.data`.  So the key also
+# carries an EPOCH that moves at the end of every backward pass that went through this library's
+# operators: parameters only change between a backward pass and the next forward.
+WEIGHT_EPOCH = [0]
+_epoch_queued = [False]
+
+
+def _bump_epoch():
+    WEIGHT_EPOCH[0] += 1
+    _epoch_queued[0] = False
+
+
+def note_backward():
+    """Called from the operators' backward functions: the epoch moves when this backward pass ends."""
+    if not _epoch_queued[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_bump_epoch)
+            _epoch_queued[0] = True
+        except RuntimeError:            # not inside a backward pass (a backward function called by hand)
+            _bump_epoch()
+
+
+def weights_key(t):
+    """What a cached operand of parameter / buffer `t` is valid for."""
+    return (WEIGHT_EPOCH[0], t._version, t.data_ptr())
+
+
 # ---- second stream for the weight gradients --------------------------------------------------
 # In the backward pass of a convolution the weight gradient and the data gradient both depend only
 # on grad_out; nothing downstream needs the weight gradient before the optimizer (or DDP's bucket

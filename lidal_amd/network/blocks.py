@@ -81,8 +81,9 @@ def _fold(bn, device):
     """Eval-mode BatchNorm as (scale, shift) f32 [C]: y = x * scale + shift.  Cached on the module,
     keyed by the version counters of its parameters and running statistics (they do not change
     between inference calls)."""
-    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr(), bn.running_mean.data_ptr(), str(device))
+    # (running statistics are written by the training kernels in place: the epoch covers them too)
+    key = (B.weights_key(bn.weight), B.weights_key(bn.bias), B.weights_key(bn.running_mean),
+           B.weights_key(bn.running_var), str(device))
     cached = getattr(bn, '_lidal_fold', None)
     if cached is not None and cached[0] == key:
         return cached[1], cached[2]

@@ -207,7 +207,7 @@ def _weight_image(weight, dtype, n_out, role):
     L = B.lib()
     key = cache = None
     if not torch.is_grad_enabled():
-        key = (weight._version, weight.data_ptr(), role, code, L.lidal_conv_weight_image_tiling(n_red, n_col, code, n_out))
+        key = (B.weights_key(weight), role, code, L.lidal_conv_weight_image_tiling(n_red, n_col, code, n_out))
         cache = getattr(weight, '_lidal_images', None)
         if cache is not None and key in cache:
             return cache[key]
@@ -217,7 +217,7 @@ def _weight_image(weight, dtype, n_out, role):
     B.check(L.lidal_conv_weight_image(B.ptr(w), B.dtype_code(w.dtype), role, B.ptr(img), code,
                                       k, n_red, n_col, n_out, B.stream()), 'conv_weight_image')
     if key is not None:
-        if cache is None or next(iter(cache))[0] != weight._version:      # drop images of older versions
+        if cache is None or next(iter(cache))[0] != B.weights_key(weight):      # drop images of older versions
             cache = {}
             weight._lidal_images = cache
         cache[key] = img
@@ -228,12 +228,13 @@ class _ImageBank:
     """Training: the image pairs of every convolution weight, rebuilt by ONE launch per step.
     A weight registers itself at its first use (its images then live in a persistent buffer, keyed by
     the tilings the two row counts select); whenever a requested image is older than its weight
-    (`_version` moved: the optimizer stepped), ALL registered weights of that device / dtype whose
+    (backend.weights_key: a backward pass has ended since, or the version counter moved), ALL
+    registered weights of that device / dtype whose
     images are stale are rebuilt together (lidal_conv_weight_image_batch) -- 42 launches of ~7 us
     become one.  LIDAL_IMAGE_BATCH=0 rebuilds per call as before.
-    The version counter is what torch's optimizers, `copy_` and `load_state_dict` move; a write through
-    `param.data` (which carries its own counter) is invisible to it -- as it is to the inference caches --
-    and needs `param._version`-moving code (e.g. `param.add_(0)` under `no_grad`) or LIDAL_IMAGE_BATCH=0."""
+    A write to a parameter that neither moves its version counter nor follows a backward pass (e.g.
+    through `param.data` in a pure inference process) is invisible to every cache of this package:
+    call `backend._bump_epoch()` after it."""
 
     def __init__(self):
         self.entries = {}           # id(weight) -> entry dict
@@ -262,7 +263,7 @@ class _ImageBank:
                  'n_out': (n_out_fwd, n_out_bwd), 'shape': (k, ci, co), 'role': role,
                  'group': (str(weight.device), code, B.dtype_code(weight.dtype))}
             self.entries[wid] = e
-        if e['version'] != weight._version:
+        if e['version'] != B.weights_key(weight):
             self._rebuild(e['group'])
         return e['img_f'], e['img_b']
 
@@ -272,7 +273,7 @@ class _ImageBank:
         stale = []
         for e in self.entries.values():
             w = e['ref']()
-            if w is not None and e['group'] == group and e['version'] != w._version:
+            if w is not None and e['group'] == group and e['version'] != B.weights_key(w):
                 stale.append((e, w))
         sig = tuple(e['serial'] for e, _ in stale)
         cached = self.tables.get(group)
@@ -296,7 +297,7 @@ class _ImageBank:
         B.check(L.lidal_conv_weight_image_batch(B.ptr(table), n_jobs, total, group[2], group[1], B.stream()),
                 'conv_weight_image')
         for e, w in stale:
-            e['version'] = w._version
+            e['version'] = B.weights_key(w)
 
 
 _IMAGE_BANK = _ImageBank()
@@ -424,6 +425,7 @@ class ConvolutionFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output, grad_skip=None):
+        B.note_backward()
         x, weight = ctx.saved_tensors
         kmap, transposed = ctx.kmap, ctx.transposed
         g = grad_output.contiguous().to(x.dtype)

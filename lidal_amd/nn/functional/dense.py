@@ -139,7 +139,7 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
         # (grad mode is also off inside RowsMatmul.forward: `with_bwd_image` tells training apart)
         if not with_bwd_image and not torch.is_grad_enabled():     # inference: the image of an unchanged parameter is re-used
             code = B.dtype_code(cdtype)
-            img_key = (w._version, w.data_ptr(), linear, code, pad,
+            img_key = (B.weights_key(w), linear, code, pad,
                        B.lib().lidal_conv_weight_image_tiling(xc.shape[1], co + pad, code, xc.shape[0]))
             cache = getattr(w, '_lidal_images', None)
             if cache is not None and img_key in cache:
@@ -148,7 +148,7 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
                 from .conv import _weight_image
                 with torch.enable_grad():       # (bypass the per-tensor cache of the temporary operand)
                     img_f = _weight_image(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], 0)
-                if cache is None or next(iter(cache))[0] != w._version:
+                if cache is None or next(iter(cache))[0] != B.weights_key(w):
                     cache = {}
                     w._lidal_images = cache
                 cache[img_key] = img_f
@@ -201,6 +201,7 @@ class RowsMatmul(Function):
 
     @staticmethod
     def backward(ctx, g):
+        B.note_backward()
         xc, w = ctx.saved_tensors
         linear = ctx.linear
         g = g.to(xc.dtype)

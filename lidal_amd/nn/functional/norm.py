@@ -73,6 +73,7 @@ class BatchNormRows(Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        B.note_backward()
         x, w, b, mean, invstd = ctx.saved_tensors
         n, c = x.shape
         # a channel slice of a concatenation's gradient (up stages) is read in place by the kernels

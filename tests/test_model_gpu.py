@@ -290,8 +290,8 @@ def test_config1_10k_point_scan_forward(golden_dir):
     assert np.array_equal(logits.argmax(1).cpu().numpy(), g['spvcnn_logits'].argmax(1))
 
 
-@pytest.mark.parametrize('autocast', [False, True])
-def test_batched_weight_images_equal_per_layer_images(autocast):
+@pytest.mark.parametrize('autocast,fused', [(False, False), (True, False), (True, True)])
+def test_batched_weight_images_equal_per_layer_images(autocast, fused):
     """Training rebuilds the LDS images of ALL convolution weights with one launch per step
     (nn/functional/conv.py: _ImageBank, keyed on the weights' version counters); five Adam steps must
     give bitwise the losses and parameters of per-layer rebuilds -- a stale image (an optimizer step
@@ -311,7 +311,7 @@ def test_batched_weight_images_equal_per_layer_images(autocast):
             torch.manual_seed(0)
             model = _models()['spvcnn'](19).to(DEV).train()
             model.dropout.p = 0.0
-            opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=fused)       # bench.py trains with fused=True
             losses = [train_step(model, opt, f, c, lab, autocast=autocast)[0].item() for _ in range(5)]
             runs.append((losses, [p.detach().clone() for p in model.parameters()]))
     finally:
@@ -319,3 +319,40 @@ def test_batched_weight_images_equal_per_layer_images(autocast):
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert all(torch.equal(a, bb) for a, bb in zip(runs[0][1], runs[1][1]))
     assert runs[0][0][-1] != runs[0][0][0]
+
+
+def test_inference_caches_follow_training():
+    """Weight images, dense-layer images and folded BatchNorm maps are cached per parameter at
+    inference.  torch.optim.Adam(fused=True) updates parameters WITHOUT moving their version counters
+    (and the BatchNorm kernels update running statistics in place), so the caches are keyed on
+    backend.weights_key (an epoch that moves when a backward pass ends): evaluate -> train -> evaluate
+    must give bitwise what a fresh model loaded with the same state_dict gives."""
+    import lidal_amd
+    from lidal_amd import synth
+    from lidal_amd.train_step import train_step
+    b = synth.make_train_batch(n_frames=1, n_points=6000, seed=9)
+    c = torch.from_numpy(b['coords_v_b']).to(DEV)
+    f = torch.from_numpy(b['feats_v_b']).to(DEV)
+    lab = torch.from_numpy(b['labels_v_b']).to(DEV)
+    torch.manual_seed(1)
+    model = _models()['spvcnn'](19).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+
+    def evaluate(m):
+        m.eval()
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            out = m(lidal_amd.SparseTensor(f, c))[0].float().clone()
+        m.train()
+        return out
+    model.train()
+    for _ in range(2):
+        train_step(model, opt, f, c, lab, autocast=True)
+    first = evaluate(model)                       # fills the inference caches
+    for _ in range(2):
+        train_step(model, opt, f, c, lab, autocast=True)
+    second = evaluate(model)
+    fresh = _models()['spvcnn'](19).to(DEV)
+    fresh.load_state_dict(model.state_dict())
+    want = evaluate(fresh)
+    assert torch.equal(second, want)
+    assert not torch.equal(first, second)

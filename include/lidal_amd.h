@@ -262,7 +262,10 @@ int64_t lidal_bn_workspace_bytes(int64_t n, int c);
 /* `relu` != 0 fuses the ReLU that follows the normalisation in the model (forward: max(y, 0);
  * backward: dy is taken where y > 0, y recomputed from x). */
 /* num_batches_tracked (nn.BatchNorm1d's i64 scalar buffer, may be NULL) is incremented by one. */
-/* residual (same dtype [n, c], may be NULL): y = act(bn(x)) + residual -- the point-branch sum of
+/* relu: bit 1 = ReLU on the normalised value, bit 2 (with a residual) = ReLU after the residual sum
+ * (the end of a residual block, network/utils.py:171; the backward of that form takes dy already
+ * masked by y > 0, e.g. from lidal_add_relu_bwd, and relu = 0).
+ * residual (same dtype [n, c], may be NULL): y = act(bn(x)) + residual -- the point-branch sum of
  * network/spvcnn.py:104,111,118 (`z1.F = z1.F + point_transforms(z.F)`) inside the normalising pass;
  * its gradient is grad_y unchanged. */
 int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,

@@ -245,7 +245,8 @@ _OVERLAP = os.environ.get('LIDAL_WGRAD_STREAM', 'auto')
 
 
 # gradient fan-in fused into the producing kernels (residual-block input, point features); 0 = off
-FORK = int(os.environ.get('LIDAL_FORK', '7'))       # bit 0: residual blocks, bit 1: point features, bit 2: point-branch sum in BatchNorm
+FORK = int(os.environ.get('LIDAL_FORK', '15'))      # bit 0: residual blocks, bit 1: point features, bit 2: point-branch
+                                                    # sum in BatchNorm, bit 3: relu(bn + shortcut) in BatchNorm
 
 
 _OVERLAP_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAM_ROWS', '0'))

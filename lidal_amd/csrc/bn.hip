@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(NT) bn_stats_final_kernel(const P* __restrict_
 
 // y = (x - mean) * invstd * gamma + beta  ==  x * sc + sh   (per-channel sc, sh held in registers)
 // `res` (may be null): y = act(...) rounded to T, + res -- the sum of the point branch
-// (network/spvcnn.py:104 `z1.F = z1.F + point_transforms(z.F)`) without a pass of its own
+// (network/spvcnn.py:104 `z1.F = z1.F + point_transforms(z.F)`) without a pass of its own; relu bit 1 =
+// ReLU before that sum, bit 2 = ReLU after it (network/utils.py:171 `relu(net(x) + downsample(x))`)
 template <typename T, bool VAR_IN>
 __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, int64_t n, int c,
                                                       const float* __restrict__ mean,
@@ -217,8 +218,11 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
-      if (relu) f[i] = fmaxf(f[i], 0.f);
-      if (res != nullptr) f[i] = (float)(T)f[i] + fr[i];       // as the stand-alone sum of two T rows
+      if (relu & 1) f[i] = fmaxf(f[i], 0.f);
+      if (res != nullptr) {
+        f[i] = (float)(T)f[i] + fr[i];       // as the stand-alone sum of two T rows
+        if (relu & 2) f[i] = fmaxf(f[i], 0.f);       // relu(bn(x) + shortcut): the end of a residual block
+      }
     }
     *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
   };

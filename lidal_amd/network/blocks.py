@@ -55,6 +55,11 @@ class ConvNormSequential(nn.Sequential):
                 x = m(x, residual=residual)         # training: the sum rides in the normalising pass
                 residual = None
                 i += 1
+            elif (isinstance(m, spnn.BatchNorm) and not torch.is_tensor(x) and i + 1 == len(mods)
+                  and residual is not None and relu_after and m.training and (B.FORK & 8)):
+                x = m(x, residual=residual, relu_after=True)    # training: relu(bn(x) + shortcut) in the normalising pass
+                residual = None
+                i += 1
             else:
                 x = m(x)
                 i += 1

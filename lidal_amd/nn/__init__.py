@@ -91,27 +91,29 @@ class BatchNorm1d(nn.BatchNorm1d):
 
     fused_relu = False      # set by lidal_amd.network where a ReLU directly follows the norm
 
-    def forward(self, feats, residual=None):
-        """`residual` ([N, C]): returns norm(feats) (+ ReLU) + residual; in training the sum happens
-        inside the normalising pass."""
+    def forward(self, feats, residual=None, relu_after=False):
+        """`residual` ([N, C]): returns norm(feats) (+ ReLU) + residual (ReLU'd if `relu_after`); in
+        training the sum happens inside the normalising pass."""
         from .functional import norm
         if (not norm.supported(feats, self.weight, self.bias) or not self.track_running_stats
                 or self.momentum is None):
             B.hit('torch_fallback:BatchNorm1d')
             out = super().forward(feats)
             out = torch.relu(out) if self.fused_relu else out
-            return out if residual is None else out + residual
+            if residual is None:
+                return out
+            return torch.relu(out + residual) if relu_after else out + residual
         return norm.batch_norm_rows(feats, self.weight, self.bias, self.running_mean,
                                     self.running_var, self.training, self.momentum, self.eps,
                                     self.fused_relu, self.num_batches_tracked,
-                                    getattr(feats, '_lidal_bn_stats', None), residual)
+                                    getattr(feats, '_lidal_bn_stats', None), residual, relu_after)
 
 
 class BatchNorm(BatchNorm1d):
     """spnn.BatchNorm: BatchNorm1d applied to the .feats of a SparseTensor."""
 
-    def forward(self, input):
-        return fapply(input, super().forward)
+    def forward(self, input, residual=None, relu_after=False):
+        return fapply(input, super().forward, residual, relu_after)
 
 
 class ReLU(nn.ReLU):

@@ -30,11 +30,12 @@ def _ws(n, c, dev):
 class BatchNormRows(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu,
-                num_batches_tracked=None, tile_stats=None, residual=None):
+                num_batches_tracked=None, tile_stats=None, residual=None, relu_after=False):
         x = x.contiguous()
         if residual is not None:        # y = act(bn(x)) + residual in the normalising pass (training)
             assert training and residual.shape == x.shape
             residual = residual.contiguous().to(x.dtype)
+        relu = int(bool(relu)) | (2 if (relu_after and residual is not None) else 0)
         n, c = x.shape
         dev = x.device
         y = torch.empty_like(x)
@@ -66,16 +67,26 @@ class BatchNormRows(Function):
                                               B.ptr(running_mean), B.ptr(running_var), float(eps),
                                               int(relu), B.ptr(y), B.stream()), 'bn_eval_fwd')
         ctx.training = training
-        ctx.relu = bool(relu)
+        ctx.relu = bool(relu & 1)
+        ctx.relu_after = bool(relu & 2)
         ctx.has_residual = residual is not None
-        ctx.save_for_backward(x, w, b, mean, invstd)
+        if ctx.relu_after:              # the output is the mask of the trailing ReLU
+            ctx.save_for_backward(x, w, b, mean, invstd, y)
+        else:
+            ctx.save_for_backward(x, w, b, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, grad_out):
         B.note_backward()
-        x, w, b, mean, invstd = ctx.saved_tensors
+        x, w, b, mean, invstd = ctx.saved_tensors[:5]
         n, c = x.shape
+        if ctx.relu_after:              # relu(bn(x) + residual): dy where the output is positive, for both
+            y = ctx.saved_tensors[5]
+            g0 = grad_out.contiguous().to(y.dtype)
+            grad_out = torch.empty_like(y)
+            B.check(B.lib().lidal_add_relu_bwd(B.ptr(y), B.ptr(g0), B.ptr(grad_out), y.numel(),
+                                               B.dtype_code(y.dtype), B.stream()), 'add_relu_bwd')
         # a channel slice of a concatenation's gradient (up stages) is read in place by the kernels
         vec = 8 if x.dtype == torch.bfloat16 else 4
         if (grad_out.dim() == 2 and grad_out.dtype == x.dtype and grad_out.stride(1) == 1 and ctx.training
@@ -90,7 +101,7 @@ class BatchNormRows(Function):
             if ctx.relu:
                 gf = gf * ((xhat * w + b) > 0)
             return ((gf * (w * invstd)).to(x.dtype), (gf * xhat).sum(0), gf.sum(0), None, None,
-                    None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None, None)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         gg = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -102,15 +113,16 @@ class BatchNormRows(Function):
                                      B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
         # the residual passes straight through: its gradient is grad_out itself
         return (dx, gg, gb, None, None, None, None, None, None, None, None,
-                grad_out if ctx.has_residual and ctx.needs_input_grad[11] else None)
+                grad_out if ctx.has_residual and ctx.needs_input_grad[11] else None, None)
 
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                    relu=False, num_batches_tracked=None, tile_stats=None, residual=None):
+                    relu=False, num_batches_tracked=None, tile_stats=None, residual=None, relu_after=False):
     """`num_batches_tracked` (i64 scalar buffer, training only) is incremented inside the kernel.
     `tile_stats` (training only): f32 [ceil(N/128), C, 3] (count, mean, M2) per 128-row tile, written
     by the convolution that produced x (conv3d(..., want_stats=True)): no statistics pass over x.
-    `residual` (training only, [N, C]): returns act(bn(x)) + residual from the same pass."""
+    `residual` (training only, [N, C]): returns act(bn(x)) + residual from the same pass, with a ReLU
+    on the sum if `relu_after` (the end of a residual block)."""
     if tile_stats is not None and not (training and tile_stats.shape == (-(-x.shape[0] // 128), x.shape[1], 3)):
         tile_stats = None
     if not training and not B.wants_grad(x, weight, bias):      # inference: one kernel, no node
@@ -122,10 +134,12 @@ def batch_norm_rows(x, weight, bias, running_mean, running_var, training, moment
                                           B.stream()), 'bn_eval_fwd')
         return y
     if residual is not None and not training:
-        return batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps, relu,
-                               num_batches_tracked, tile_stats) + residual
+        y = batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps, relu,
+                            num_batches_tracked, tile_stats) + residual
+        return torch.relu(y) if relu_after else y
     return BatchNormRows.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
-                               relu, num_batches_tracked if training else None, tile_stats, residual)
+                               relu, num_batches_tracked if training else None, tile_stats, residual,
+                               relu_after)
 
 
 def column_sum(x):

@@ -824,6 +824,35 @@ def test_wgrad_dma_exact_products_of_bf16_operands(ca, cb):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batch_norm_shortcut_sum_and_relu_ride_in_the_normalising_pass(dtype):
+    """The end of a residual block, relu(bn(x) + shortcut) (network/utils.py:171), from the BatchNorm's
+    normalising pass: bitwise the output and gradients of BatchNorm -> add_relu."""
+    from lidal_amd.nn.functional.fused import add_relu
+    from lidal_amd.nn.functional.norm import batch_norm_rows
+    g = torch.Generator().manual_seed(12)
+    n, c = 4999, 96
+    x = torch.randn(n, c, generator=g).to(DEV).to(dtype)
+    res = torch.randn(n, c, generator=g).to(DEV).to(dtype)
+    go = torch.randn(n, c, generator=g).to(DEV).to(dtype)
+    w = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    b = torch.randn(c, generator=g).to(DEV)
+    outs = []
+    for fused in (False, True):
+        xi, ri = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        if fused:
+            y = batch_norm_rows(xi, wi, bi, rm, rv, True, 0.1, 1e-5, False, None, None, ri, True)
+        else:
+            y = add_relu(batch_norm_rows(xi, wi, bi, rm, rv, True, 0.1, 1e-5, False), ri)
+        y.backward(go)
+        outs.append((y.detach(), xi.grad, ri.grad, wi.grad, bi.grad, rm, rv))
+    for a, bb in zip(*outs):
+        assert torch.equal(a, bb)
+    assert (outs[1][0] == 0).any() and (outs[1][0] > 0).any()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_batch_norm_residual_rides_in_the_normalising_pass(dtype):
     """y = relu(bn(x)) + residual from ONE pass (the point-branch sum of network/spvcnn.py:104,111,118)
     is bitwise what the stand-alone sum of the normalised rows and the residual gives, statistics

@@ -59,6 +59,9 @@ constexpr int MAXK = 32;
 #define LIDAL_NB4_LIMIT 384
 #endif
 // ---- tiling policy, shared by the image packer and the launcher ------------------------------
+#ifndef LIDAL_RB256
+#define LIDAL_RB256(row_bytes, co) 0
+#endif
 struct Tiling { int nb; int row_bytes; };       // 16-column blocks per workgroup, staged bytes per pass
 
 __host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int esz) {
@@ -68,6 +71,9 @@ __host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int
   // multiples (96 bf16 channels), 64 for the other rows that 128 does not divide (32 bf16 channels)
   t.row_bytes = (row_bytes % 192 == 0 && row_bytes % 128 != 0) ? 192
                 : (row_bytes % 128 != 0 && row_bytes % 64 == 0) ? 64 : 128;
+  // 256-byte slices where the rows allow it: half the phases (barriers, waits) per offset on the
+  // layers of >= 128 channels (LIDAL_RB256: which (ci bytes, co) take them)
+  if (row_bytes % 256 == 0 && LIDAL_RB256(row_bytes, co)) t.row_bytes = 256;
   if (co <= 32) t.nb = 2;
   else if (co <= 64 || (co % 64 == 0 && ((n_out + 127) / 128) * ((co + 127) / 128) <= LIDAL_NB4_LIMIT)) t.nb = 4;
   else if (co % 128 != 0 && (co % 96 == 0 || co < 128)) t.nb = 6;
@@ -606,7 +612,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   constexpr int DMA_WAVES = PIECES / PPW;                // waves that move a share
   static_assert(PIECES % PPW == 0 && DMA_WAVES <= NWAVES, "a DMA wave moves a whole share");
   static_assert(ROW_BYTES % 64 == 0 && SLAB % 1024 == 0, "slices are whole MFMA steps / DMA pieces");
-  static_assert(BM % 128 == 0, "tile masks are per 128 rows");
+  static_assert(BM % 128 == 0 || BM == 64, "tile masks are per 128 rows (a 64-row tile takes its parent's)");
   typedef typename DT<T>::frag frag;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -625,7 +631,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
     unsigned m = 0u;
     const int64_t t0 = ((int64_t)blockIdx.x * BM) >> 7;
 #pragma unroll
-    for (int h = 0; h < BM / 128; ++h)
+    for (int h = 0; h < (BM >= 128 ? BM / 128 : 1); ++h)
       if ((t0 + h) * 128 < n_out) m |= tmasks[t0 + h];
     if (kflip) m = __brev(m) >> (32 - K);
     tmask = __builtin_amdgcn_readfirstlane(m);
@@ -682,11 +688,17 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
     constexpr int slot = decltype(slot_c)::value;
     if (dma_wave && !(LIDAL_IMG_ABL & 2)) {
       const unsigned soff = (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base;
-      auto* dst = (__attribute__((address_space(3))) void*)(dma_dst + slot * SLAB);
-      static_assert(PPW <= 3, "immediate offsets of the DMA share");
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 0, 0);
-      if constexpr (PPW >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 1024, 0);
-      if constexpr (PPW >= 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 2048, 0);
+      static_assert(PPW <= 12, "DMA share");
+      // four 1-KiB pieces per M0 value (the immediate offset field ends at 4095)
+#pragma unroll
+      for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
+        auto* dst = (__attribute__((address_space(3))) void*)(dma_dst + slot * SLAB + c4 * 4096);
+        const unsigned so = soff + (unsigned)(c4 * 4096);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
+        if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
+        if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
+        if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
+      }
     }
   };
   // A fragments of (neighbour rows idx, slice pass); returns the ballot of rows that have a rule.
@@ -1133,6 +1145,7 @@ int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, con
   IMG_CASE(2, 64) IMG_CASE(4, 64) IMG_CASE(6, 64) IMG_CASE(8, 64)
   IMG_CASE(2, 128) IMG_CASE(4, 128) IMG_CASE(6, 128) IMG_CASE(8, 128)
   IMG_CASE(2, 192) IMG_CASE(4, 192) IMG_CASE(6, 192) IMG_CASE(8, 192)
+  IMG_CASE(2, 256) IMG_CASE(4, 256) IMG_CASE(6, 256) IMG_CASE(8, 256)
 #undef IMG_CASE
   set_error("conv_apply_image: no kernel for tiling nb=%d row_bytes=%d", t.nb, t.row_bytes);
   return 2;

@@ -51,12 +51,19 @@ def main():
             B.check(L.lidal_bn_bwd(B.ptr(x), B.ptr(go), c, 1, n, c, B.ptr(w), B.ptr(b), 1, B.ptr(mean),
                                    B.ptr(invstd), B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(ws), nbytes,
                                    B.stream()), 'bwd')
+        def bwd_params():       # statistics of the backward only (dx = NULL): the reducing pass + its final
+            B.check(L.lidal_bn_bwd(B.ptr(x), B.ptr(go), c, 1, n, c, B.ptr(w), B.ptr(b), 1, B.ptr(mean),
+                                   B.ptr(invstd), None, B.ptr(gg), B.ptr(gb), B.ptr(ws), nbytes,
+                                   B.stream()), 'bwd')
         fwd()
         t = [timeit(fwd), timeit(fwd_tiles), timeit(bwd)]
+        tp = timeit(bwd_params)
         by = n * c * 2
         tot = [a + b_ for a, b_ in zip(tot, t)]
         print('%7d x %3d   fwd %6.1f us (%5.2f TB/s)   fwd on tile stats %6.1f us (%5.2f TB/s)   bwd %6.1f us (%5.2f TB/s)'
-              % (n, c, t[0], 3 * by / t[0] / 1e6, t[1], 2 * by / t[1] / 1e6, t[2], 5 * by / t[2] / 1e6), flush=True)
+              % (n, c, t[0], 3 * by / t[0] / 1e6, t[1], 2 * by / t[1] / 1e6, t[2], 5 * by / t[2] / 1e6)
+              + '   [reduce %5.1f us (%4.2f TB/s), dx %5.1f us (%4.2f TB/s)]'
+              % (tp, 2 * by / tp / 1e6, t[2] - tp, 3 * by / (t[2] - tp) / 1e6), flush=True)
     print('sum fwd %.1f  fwd_tiles %.1f  bwd %.1f us' % tuple(tot))
 
 

@@ -18,8 +18,9 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
                 algorithmic bytes / FLOPs and roofline fraction per kernel family
                 (sparse conv fwd+dgrad, weight gradient, BatchNorm, kernel maps, point<->voxel,
                 fused elementwise), and of the whole step
-  variants      the same step on ONE scan (BASELINE.json's literal "@120k pts"), in the f32 parity
-                mode, and with the second backbone (MinkUNet, configs[2])
+  variants      the same step on ONE scan (BASELINE.json's literal "@120k pts"), with a freshly
+                augmented batch every step (new coordinates / sizes / kernel maps, as the reference's
+                loader produces), in the f32 parity mode, and with the second backbone (MinkUNet, configs[2])
   secondary     frames/s of prob_inference (8 views) + LiDAL inter-frame scoring (configs[3..4]),
                 frame-sharded, 32 frames per rank, neighbour windows 10 and 24, with its own CPU
                 baseline (oracle worker_func restatement under a process pool, LiDAL.py:204-206)
@@ -130,11 +131,41 @@ def make_batch(frames, points, seed, dev):
             torch.from_numpy(batch['labels_v_b']).to(dev))
 
 
+def make_fresh_batches(frames, points, seed, dev, n_batches):
+    """`n_batches` batches of the SAME `frames` scans, each under a newly drawn augmentation
+    (dataset/sk_dataset.py:143-171: affine + flip + rotation, x20, random translation, int cast,
+    unique rows), voxelised and collated ON THE GPU (lidal_voxelize_points, lidal_amd/data.py): new
+    voxel coordinates, new row counts and new kernel maps every step, as in the reference's loop."""
+    from lidal_amd import data, synth
+    rng = np.random.default_rng(seed)
+    world = synth.make_world(seed)
+    scans = []
+    for f in range(frames):
+        pts, inten = synth.raycast_scan(world, (10.0 + 7.0 * f, 0.0), rng, n_points=points)
+        labels_p = rng.integers(0, 19, size=pts.shape[0]).astype(np.int64)
+        labels_p[rng.random(pts.shape[0]) < 0.1] = 255
+        scans.append((torch.from_numpy(pts).to(dev), torch.from_numpy(inten).to(dev),
+                      torch.from_numpy(labels_p).to(dev)))
+    aug = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_batches):
+        samples = []
+        for pts, inten, labels_p in scans:
+            trans_m, rnd = data.draw_augmentation(aug)
+            coords_v, feats_v, uniq, _ = data.voxelize_scan(pts, inten, trans_m, rnd)
+            samples.append({'coords_v': coords_v, 'feats_v': feats_v, 'labels_v': labels_p[uniq]})
+        b = data.collate(samples)
+        out.append((b['coords_v_b'].contiguous(), b['feats_v_b'].contiguous(), b['labels_v_b'].contiguous()))
+    torch.cuda.synchronize()
+    return out
+
+
 def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=True):
-    """Times `steps` iterations of train.py:127-140 on the resident `batch` (coords, feats, labels)."""
+    """Times `steps` iterations of train.py:127-140 on the resident `batch` (coords, feats, labels) --
+    or, if `batch` is a list of such tuples, on a different one of them every step."""
     from lidal_amd.network import SPVCNN, MinkUNet
     from lidal_amd.train_step import train_step
-    coords, feats, labels = batch
+    batches = batch if isinstance(batch, list) else [batch]
     torch.manual_seed(7122)
     model = (SPVCNN if model_name == 'spvcnn' else MinkUNet)(19).to(dev).train()
     net = model
@@ -144,14 +175,18 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
     # implementation of the same update (the default path calls .item() once per parameter on the host)
     opt = torch.optim.Adam(net.parameters(), fused=True)
     autocast = dtype == 'bf16'
+    count = [0]
 
     def step():
+        coords, feats, labels = batches[count[0] % len(batches)]
+        count[0] += 1
         return train_step(net, opt, feats, coords, labels, autocast=autocast)
 
     for i in range(warmup):
         step()
         torch.cuda.synchronize()
     barrier_sync(world if ddp else 1)
+    first = count[0]
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, _ = step()
@@ -160,13 +195,14 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
     if ddp:
         dt = max_over_ranks(dt, world, dev)
     assert np.isfinite(loss.item()), 'training diverged'
-    return {'model': model, 'step': step, 'seconds': dt, 'steps': steps, 'voxels': int(coords.shape[0]),
+    voxels = sum(int(batches[(first + i) % len(batches)][0].shape[0]) for i in range(steps)) / steps
+    return {'model': model, 'step': step, 'seconds': dt, 'steps': steps, 'voxels': voxels,
             'loss': float(loss.item())}
 
 
 def variant_line(res):
     ms = res['seconds'] / res['steps'] * 1e3
-    return {'ms_per_step': round(ms, 3), 'voxels_per_step': res['voxels'],
+    return {'ms_per_step': round(ms, 3), 'voxels_per_step': int(res['voxels']),
             'voxels_per_s': round(res['voxels'] / ms * 1e3, 1), 'steps': res['steps'],
             'loss': round(res['loss'], 4)}
 
@@ -243,7 +279,7 @@ FAMILY_OF = {
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
     'lidal_downsample': 'kernel_maps', 'lidal_kmap_build': 'kernel_maps', 'lidal_kmap_invert': 'kernel_maps',
-    'lidal_kmap_order': 'kernel_maps',
+    'lidal_kmap_order': 'kernel_maps', 'lidal_floor_coords': 'kernel_maps',
     'lidal_count': 'point_voxel', 'lidal_voxelize_fwd': 'point_voxel', 'lidal_voxelize_bwd': 'point_voxel',
     'lidal_devoxelize_fwd': 'point_voxel', 'lidal_devoxelize_bwd': 'point_voxel',
     'lidal_invlist_build': 'point_voxel', 'lidal_voxelize_fwd_sorted': 'point_voxel',
@@ -295,7 +331,8 @@ def family_table(step, coords, dtype_name, step_ms):
     finally:
         B.set_call_timer(None)
     fam = {}
-    fwd_shape = {}                      # input pointer of a forward conv -> (n_in, n_out)
+    fwd_convs = []                      # (k, n_in, n_out, ci, co, b) of the forward convolutions, for `compulsory`
+    in_backward = False
 
     def rules_of(k, n_in, n_out):
         if k == 1:
@@ -314,14 +351,15 @@ def family_table(step, coords, dtype_name, step_ms):
             m = rules_of(k, n_in, n_out)
             by = b * (n_in * ci + n_out * co) + b * k * ci * co + 8 * m
             fl = 2.0 * m * ci * co
-            fwd_shape[a[0]] = (n_in, n_out)
+            if not in_backward:
+                fwd_convs.append((k, n_in, n_out, ci, co, b, m))
         elif name == 'lidal_conv_wgrad':
-            k, ca, cb, dt = a[11], a[12], a[13], a[14]
+            # (a, b, n_a, n_b, pairs, koff, a_col, gw, partial, n_slabs, k, ca, cb, dtype, stream)
+            n_a, n_b, k, ca, cb, dt = a[2], a[3], a[10], a[11], a[12], a[13]
             b = 2 if dt == 1 else 4
-            # a = the saved input x [n_in, ca] of the forward conv, b = grad_out [n_out, cb]
-            n_in, n_out = fwd_shape.get(a[0], (coords.shape[0], coords.shape[0]))
-            m = rules_of(k, n_in, n_out)
-            by = b * (n_in * ca + n_out * cb) + 4 * k * ca * cb + 8 * m
+            # a = the saved input x [n_a, ca] of the forward conv, b = grad_out [n_b, cb]
+            m = rules_of(k, n_a, n_b)
+            by = b * (n_a * ca + n_b * cb) + 4 * k * ca * cb + 8 * m
             fl = 2.0 * m * ca * cb
         elif name == 'lidal_conv_weight_pack':
             by = (4 + b_el) * a[5] * a[6] * a[7]
@@ -339,11 +377,36 @@ def family_table(step, coords, dtype_name, step_ms):
         elif name in ('lidal_add_relu_fwd', 'lidal_add_relu_bwd'):
             by = 3 * a[3] * (2 if a[4] == 1 else 4)
         elif name in ('lidal_ce_fwd', 'lidal_ce_bwd'):
+            in_backward = in_backward or name == 'lidal_ce_bwd'
             by = a[3] * (a[4] * (2 if a[1] == 1 else 4) + 8) * (1 if name == 'lidal_ce_fwd' else 2)
         elif name == 'lidal_kmap_build':
             n_out, k = a[3], a[5]
             n_in = a[1] // 24 if a[1] else n_out                # table: 12 B per slot, 2 slots per key
             by = 16 * n_in + 16 * n_out + 8 * rules_of(k, n_in, n_out)
+        elif name == 'lidal_hash':
+            by = (16 + 8) * a[1]
+        elif name == 'lidal_floor_coords':
+            by = (16 + 16) * a[1]
+        elif name == 'lidal_kernel_hash':
+            by = 16 * a[1] + 8 * a[3] * a[1]
+        elif name == 'lidal_hash_table_build':
+            by = (8 + 12) * a[1]                                # key in, one slot written
+        elif name == 'lidal_hash_table_query':
+            by = (8 + 12 + 8) * a[3]                            # query in, one slot probed, index out
+        elif name == 'lidal_unique_sorted_i64':
+            by = (8 + 8) * a[1]
+        elif name == 'lidal_downsample':
+            by = 16 * a[1] + 16 * a[1] // 4                     # rows in, ~1/4 of them out
+        elif name == 'lidal_kmap_invert':
+            by = 4 * a[2] * (a[1] + a[4])                       # [k, n_out] read, [k, n_in] written
+        elif name == 'lidal_kmap_order':
+            by = 4 * a[2] * a[1] * 2 + 8 * a[1]                 # table read + permuted table written + perm / masks
+        elif name == 'lidal_count':
+            by = 4 * a[1] + 4 * a[3]
+        elif name == 'lidal_ti_weights':
+            by = a[3] * (16 + 64 + 32 + 32)                     # coords + idx i64 [8] in, w f32 [8] + idx i32 [8] out
+        elif name == 'lidal_invlist_build':
+            by = a[2] * (4 + 4 + 4) + 8 * a[3]
         elif name in ('lidal_voxelize_fwd_sorted', 'lidal_devoxelize_bwd_sorted'):
             m_rows, c, dt, n_ent = a[5], a[6], a[7], a[8]
             by = (n_ent + m_rows) * c * (2 if dt == 1 else 4)
@@ -370,12 +433,29 @@ def family_table(step, coords, dtype_name, step_ms):
             row['GFLOP'] = round(d['flops'] / 1e9, 1)
             row['mfma_frac'] = round(d['flops'] / (d['ms'] * 1e-3) / 1e12 / peak_tf, 4)
         out[f] = row
+    # self-check of the pricing: the weight gradients do 2 M Ci Co per layer, the forward + data gradient
+    # 4 M Ci Co (the stem's data gradient is not computed, the rest is) -> the ratio sits at ~0.5
+    if 'conv_apply' in fam and 'conv_wgrad' in fam and fam['conv_apply']['flops'] > 0:
+        ratio = fam['conv_wgrad']['flops'] / fam['conv_apply']['flops']
+        assert 0.4 <= ratio <= 0.6, 'family pricing is off: wgrad / (fwd + dgrad) FLOPs = %.3f' % ratio
+    # COMPULSORY bytes of the step, SURVEY.md 8(d): every convolution moves each feature row once
+    # forward and (2 in + 1 out) backward, its weights and rule pairs; a BatchNorm / ReLU / residual sum
+    # that directly follows a convolution costs nothing extra (fusable); kernel maps, point<->voxel and
+    # the loss as priced above
+    comp = 0.0
+    for k, n_in, n_out, ci, co, b, m in fwd_convs:
+        comp += b * (n_in * ci + n_out * co) + b * k * ci * co + 8 * m                      # forward
+        comp += b * (2 * n_in * ci + n_out * co + k * ci * co) + 4 * k * ci * co + 8 * m    # backward
+    for f in ('kernel_maps', 'point_voxel'):
+        comp += fam.get(f, {'bytes': 0.0})['bytes']
     out['other'] = {'ms': round(max(step_ms - tot_ms, 0.0), 3),
                     'what': 'torch ops between library calls (Adam, cat, dropout, casts) + gaps'}
     out['whole_step'] = {
         'ms': round(step_ms, 3), 'profiled_step_ms': round(prof_ms, 3), 'algorithmic_GB': round(tot_by / 1e9, 3),
         'GFLOP': round(tot_fl / 1e9, 1),
         'hbm_frac': round(tot_by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        'compulsory_GB': round(comp / 1e9, 3),
+        'hbm_frac_compulsory': round(comp / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         'mfma_frac': round(tot_fl / (step_ms * 1e-3) / 1e12 / peak_tf, 4),
         'ms_at_hbm_roof': round(tot_by / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
         'ms_at_mfma_roof': round(tot_fl / (peak_tf * 1e12) * 1e3, 3)}
@@ -605,6 +685,13 @@ def main():
         one = make_batch(1, args.points, 7122, dev)
         var['single_scan'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, one,
                                                       max(args.steps, 10), 3, ddp=False))
+        # the reference draws a new augmentation per iteration (sk_dataset.py:143-171): 8 differently
+        # augmented batches of the same scans, voxelised on the GPU outside the timed region, one per step
+        fresh = make_fresh_batches(args.frames, args.points, 7122, dev, 8)
+        var['fresh_coords'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, fresh,
+                                                       max(args.steps, 16), 8, ddp=False))
+        var['fresh_coords']['voxels_per_batch'] = [int(b[0].shape[0]) for b in fresh]
+        del fresh
         other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
         var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
                                                     max(3, args.steps // 2), 2, ddp=False))

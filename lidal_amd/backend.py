@@ -206,6 +206,11 @@ def stream():
 # operators: parameters only change between a backward pass and the next forward.
 WEIGHT_EPOCH = [0]
 _epoch_queued = [False]
+_epoch_task = [-1]          # id of the autograd graph task whose end-of-backward callback is queued
+
+
+def _graph_task():
+    return torch._C._current_graph_task_id()        # -1 outside a backward pass
 
 
 def _bump_epoch():
@@ -213,18 +218,33 @@ def _bump_epoch():
     _epoch_queued[0] = False
 
 
+def _settle():
+    """A backward pass that RAISED never ran its final callbacks (the engine drops them): the latches
+    would stay set for the rest of the process -- the epoch frozen (stale weight images under
+    Adam(fused=True)) and the side-stream events never waited for.  Called where a stale latch can be
+    seen: from the next backward pass (a different graph task) and from the next forward (no graph task)."""
+    if _epoch_queued[0] and _graph_task() != _epoch_task[0]:
+        _bump_epoch()
+    if _join_queued[0] and _graph_task() != _join_task[0]:
+        join_side_streams()
+
+
 def note_backward():
     """Called from the operators' backward functions: the epoch moves when this backward pass ends."""
+    _settle()
     if not _epoch_queued[0]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_bump_epoch)
             _epoch_queued[0] = True
+            _epoch_task[0] = _graph_task()
         except RuntimeError:            # not inside a backward pass (a backward function called by hand)
             _bump_epoch()
 
 
 def weights_key(t):
     """What a cached operand of parameter / buffer `t` is valid for."""
+    if _epoch_queued[0] or _join_queued[0]:
+        _settle()
     return (WEIGHT_EPOCH[0], t._version, t.data_ptr())
 
 
@@ -241,6 +261,8 @@ def weights_key(t):
 _side_streams = {}
 _pending = []
 _join_queued = [False]
+_join_task = [-1]
+_seen_weights = set()        # id(weight) of the weight gradients launched on the side stream, this backward pass
 _OVERLAP = os.environ.get('LIDAL_WGRAD_STREAM', 'auto')
 
 
@@ -267,8 +289,9 @@ def side_stream(device):
 
 
 def join_side_streams():
-    """Make the current stream wait for every weight gradient launched beside it."""
+    """Make the current stream wait for every weight gradient launched beside it.  Idempotent."""
     _join_queued[0] = False
+    _seen_weights.clear()
     if _pending:
         cur = torch.cuda.current_stream()
         for ev in _pending:
@@ -276,17 +299,37 @@ def join_side_streams():
         del _pending[:]
 
 
-def beside(device, inputs):
-    """Context for work that may run beside the current stream: `with beside(dev, (x, g)) as done:`
+def _may_defer(weight):
+    """May the main stream's wait for this weight gradient be put off to the end of the backward
+    pass?  Only if nothing on the main stream can touch the gradient before then: autograd believes
+    it was produced on the main stream, so an accumulation into an existing `.grad` (gradient
+    accumulation, zero_grad(set_to_none=False)), the sum of two uses of a shared weight, a tensor or
+    post-accumulate hook, or DDP's bucket copy (at ANY world size) would read it unsynchronised."""
+    import torch.distributed as dist
+    if weight is None or weight.grad is not None:
+        return False
+    if dist.is_available() and dist.is_initialized():
+        return False
+    if getattr(weight, '_backward_hooks', None) or getattr(weight, '_post_accumulate_grad_hooks', None):
+        return False
+    if id(weight) in _seen_weights:         # second use of a shared weight in this backward pass
+        return False
+    return True
+
+
+def beside(device, inputs, weight=None):
+    """`weight`: the parameter whose gradient is produced (decides whether the join may be deferred,
+    _may_defer; None = join at once).  Context for work that may run beside the current stream: `with beside(dev, (x, g)) as done:`
     ... launch ...; `done(outputs)`.  The side stream first waits for everything already enqueued on
     the current stream (so call this BEFORE enqueueing the work it should overlap with); the current
     stream waits for the side work at the end of the backward pass -- or, when gradients are reduced
     across ranks by hooks that fire during the backward pass, at once."""
-    return _Beside(device, inputs)
+    return _Beside(device, inputs, weight)
 
 
 class _Beside:
-    def __init__(self, device, inputs):
+    def __init__(self, device, inputs, weight=None):
+        self.weight = weight
         self.main = torch.cuda.current_stream(device)
         self.side = side_stream(device)
         self.inputs = inputs
@@ -309,16 +352,19 @@ class _Beside:
         self.ctx.__exit__(*exc)
         if exc[0] is not None:
             return False
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if not _may_defer(self.weight):
             self.deferred = False
+            if self.weight is not None and id(self.weight) in _seen_weights:
+                join_side_streams()         # the earlier gradient of this shared weight is summed with this one
         else:
             self.deferred = True
+            _seen_weights.add(id(self.weight))
             _pending.append(self.event)
             if not _join_queued[0]:
                 try:          # inside a backward pass: join when it ends
                     torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
                     _join_queued[0] = True
+                    _join_task[0] = _graph_task()
                 except RuntimeError:
                     join_side_streams()
         return False

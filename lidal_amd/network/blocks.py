@@ -159,7 +159,9 @@ class ResidualBlock(nn.Module):
         self.relu = spnn.ReLU(True)
 
     def forward(self, x):
-        if (B.FORK & 1) and B.wants_grad(x.F) and x.F.requires_grad and self.net[0].bias is None:
+        first = self.net[0]
+        if ((B.FORK & 1) and B.wants_grad(x.F) and x.F.requires_grad and first.bias is None
+                and first.kernel_size != (1, 1, 1) and not first.transposed):
             # training: x feeds the first convolution AND the shortcut; fork it inside that
             # convolution so the shortcut's gradient is added in the data-gradient kernel's epilogue
             # (16 blocks: 16 fewer passes of autograd's gradient accumulation per step)

@@ -399,7 +399,8 @@ def _conv(feats, weight, kmap, transposed, epilogue=None, want_stats=False, fork
     data-gradient kernel's epilogue instead of by a separate pass (autograd's accumulation)."""
     if B.wants_grad(feats, weight):
         assert epilogue is None, 'the fused BatchNorm epilogue is inference-only'
-        fused = fork and feats.requires_grad and feats.shape[1] == weight.shape[1]
+        # (the fused sum needs the skip gradient in the data gradient's own width: no channel padding)
+        fused = fork and feats.requires_grad and _pad_channels(feats.shape[1], B.compute_dtype(feats)) == 0
         res = ConvolutionFunction.apply(feats, weight, kmap, transposed, want_stats, fused)
         out, skip = res if fused else (res, feats)
         if ConvolutionFunction.last_stats is not None:      # from the Function's own output to autograd's
@@ -449,7 +450,7 @@ class ConvolutionFunction(Function):
         if ctx.needs_input_grad[1]:
             if B.overlap_wgrad(x.dtype, max(n_in, n_out)) and ctx.needs_input_grad[0]:
                 _ = kmap.koff                   # the rule lists are built on the main stream
-                side = B.beside(x.device, (x, g, kmap._nbmaps_cap, kmap.koff))
+                side = B.beside(x.device, (x, g, kmap._nbmaps_cap, kmap.koff), weight)
                 with side as done:              # beside the data gradient below
                     grad_w = wgrad()
                     done(grad_w)

@@ -1,7 +1,8 @@
 """Dense per-row products on [N, C] feature matrices: the 1x1x1 convolutions (F.conv3d's first
 branch, `feats.matmul(weight)`) and the point-branch nn.Linear layers (network/spvcnn.py:85-101).
 
-Forward and data gradient are plain library GEMMs, as upstream.  The WEIGHT gradient
+Forward and data gradient run on the sparse convolution kernel with the identity rule list (bf16 and
+f32 alike: exact f32 MFMA in the parity mode -- no library GEMM on the path).  The WEIGHT gradient
 x^T [Cin, N] @ g [N, Cout] reduces over N ~ 4e5 rows into a tiny [Cin, Cout] tile: a library GEMM
 runs that in a few workgroups (0.8 ms measured for 128x96), so it goes through the split-K MFMA
 kernel used for the sparse weight gradients (lidal_conv_wgrad with the identity rule list)."""
@@ -52,10 +53,8 @@ def _vec(dtype):
 def _gemm_ok(x, ci, co):
     if not x.is_cuda or x.shape[0] == 0 or x.shape[0] * ci * x.element_size() >= 0x7FFFFFF0:
         return False
-    # bf16 only: the f32 mode is the parity mode and keeps the library GEMM, whose summation order
-    # the end-to-end gradient goldens were pinned with (the two differ by ~1e-4 at the stem after
-    # 49 layers, which is the goldens' own floor)
-    return x.dtype == torch.bfloat16 and ci % 8 == 0 and co % 8 == 0
+    vec = _vec(x.dtype) if x.dtype in (torch.float32, torch.bfloat16) else 0
+    return vec > 0 and ci % vec == 0 and co % vec == 0
 
 
 def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None, img=None, want_stats=False):
@@ -166,7 +165,7 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
             y = y + residual.to(cdtype)
             y = torch.relu(y) if int(relu) & 2 else y
         return xc, wc, pad, y, img_b
-    B.hit('library_gemm:rows')        # f32 parity mode (by design) or a shape the kernel does not take
+    B.hit('library_gemm:rows')        # a shape the kernel does not take (channels not a multiple of 16 bytes)
     y = xc @ wc
     y = y[:, :co] if pad else y
     if epilogue is not None:
@@ -221,7 +220,7 @@ class RowsMatmul(Function):
         side = None
         if ctx.needs_input_grad[1]:
             if B.overlap_wgrad(xc.dtype) and ctx.needs_input_grad[0] and g.is_cuda:
-                side = B.beside(g.device, (xc, g))
+                side = B.beside(g.device, (xc, g), w)
                 with side as done:              # beside the data gradient below (backend.beside)
                     gw = wgrad()
                     done(gw)

@@ -66,6 +66,13 @@ class BatchNormRows(Function):
             B.check(B.lib().lidal_bn_eval_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b),
                                               B.ptr(running_mean), B.ptr(running_var), float(eps),
                                               int(relu), B.ptr(y), B.stream()), 'bn_eval_fwd')
+        if training:
+            # the kernels wrote the running statistics through raw pointers: move their version counters,
+            # which key the folded eval-mode maps (network/blocks.py _fold) -- a train-mode forward
+            # that no backward pass follows (recalibration under no_grad) must invalidate them too
+            for t in (running_mean, running_var):
+                if t is not None:
+                    torch.autograd.graph.increment_version(t)
         ctx.training = training
         ctx.relu = bool(relu & 1)
         ctx.relu_after = bool(relu & 2)

@@ -1,0 +1,241 @@
+"""Parity AT the benchmarked size (BASELINE.json configs[1..4]): what bench.py times is what these
+tests check.
+
+  (a) one ~120 k-point scan (~83 k voxels) through a whole TRAIN step (train.py:127-140), SPVCNN
+      and MinkUNet: f32 on the HIP path against the CPU oracle run in f64 (loss / logits 1e-4;
+      sampled gradient norms within 2x the f32 oracle's own deviation from its f64 run, measured
+      here at this size), then the bench dtype (bf16 autocast): cosine >= 0.99 on every sampled
+      parameter.
+  (b) the weight-gradient plan and the flipped-offset data gradient bench.py runs (5 scans,
+      ~4e5 rows: W = 256 resident workgroups, 64-rule stages crossing offset boundaries, 32-bit
+      byte offsets near 76 MB) through the C-ABI against f64 products computed by torch on the GPU
+      from the same bf16 operands.
+  (c) the inter-frame scorer on 120 k-point frames (NN grid of 120 k points, p x n_nei match
+      threads, 63-bit cell-key sort), neighbour windows 10 and 24, against
+      oracle.scoring_ref.score_frame (LiDAL.py:59-98).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+GKEYS = ['stem.0.kernel', 'stage2.1.net.0.kernel', 'stage4.2.net.3.kernel', 'up1.0.net.0.kernel',
+         'up4.1.1.net.3.kernel', 'up4.1.0.net.0.kernel', 'classifier.0.weight', 'stage1.0.net.1.weight',
+         'up3.1.0.downsample.0.kernel']
+
+
+@pytest.fixture(scope='module')
+def one_scan():
+    from lidal_amd import synth
+    b = synth.make_train_batch(n_frames=1, n_points=120000, seed=7122)
+    return (torch.from_numpy(b['coords_v_b']), torch.from_numpy(b['feats_v_b']),
+            torch.from_numpy(b['labels_v_b']))
+
+
+@pytest.fixture(scope='module')
+def bench_batch():
+    from lidal_amd import synth
+    b = synth.make_train_batch(n_frames=5, n_points=120000, seed=7122)
+    return torch.from_numpy(b['coords_v_b']).to(DEV)
+
+
+def _oracle_step(cls, dt, coords, feats, labels, keys):
+    from oracle import tsref
+    from weights import fill_state_dict
+    model = fill_state_dict(cls(19)).to(dt).train()
+    if hasattr(model, 'dropout'):
+        model.dropout.p = 0.0
+    logits, _ = model(tsref.SparseTensor(feats.clone().to(dt), coords.clone()))
+    loss = torch.nn.functional.cross_entropy(logits, labels, ignore_index=255, reduction='mean')
+    loss.backward()
+    named = dict(model.named_parameters())
+    return loss.item(), logits.detach(), {k: named[k].grad.detach().double() for k in keys if k in named}
+
+
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_train_step_at_bench_size_matches_oracle(name, one_scan):
+    from lidal_amd.network import SPVCNN, MinkUNet
+    from lidal_amd.train_step import forward_backward
+    from oracle.models_ref import MinkUNetRef, SPVCNNRef
+    from weights import fill_state_dict
+    coords, feats, labels = one_scan
+    assert coords.shape[0] > 70000
+    torch.set_num_threads(min(32, max(torch.get_num_threads(), (__import__('os').cpu_count() or 8))))
+    ref_cls = {'spvcnn': SPVCNNRef, 'minkunet': MinkUNetRef}[name]
+    keys = GKEYS + (['point_transforms.1.0.weight'] if name == 'spvcnn' else [])
+    loss64, logits64, g64 = _oracle_step(ref_cls, torch.float64, coords, feats, labels, keys)
+    loss32, _, g32 = _oracle_step(ref_cls, torch.float32, coords, feats, labels, keys)
+
+    def run(autocast):
+        model = fill_state_dict({'spvcnn': SPVCNN, 'minkunet': MinkUNet}[name](19)).to(DEV).train()
+        if hasattr(model, 'dropout'):
+            model.dropout.p = 0.0
+        loss, logits = forward_backward(model, feats.to(DEV), coords.to(DEV), labels.to(DEV), autocast=autocast)
+        named = dict(model.named_parameters())
+        return loss.item(), logits.detach().float().cpu(), {k: named[k].grad.double().cpu() for k in g64}
+
+    # ---- f32: the parity mode
+    loss, logits, grads = run(False)
+    assert abs(loss - loss64) < 1e-4 * abs(loss64), (loss, loss64)
+    rel = ((logits.double() - logits64).abs().max() / logits64.abs().max()).item()
+    assert rel < 1e-4, rel
+    dev_gpu = {k: abs(grads[k].norm().item() / g64[k].norm().item() - 1) for k in g64}
+    dev_f32 = {k: abs(g32[k].norm().item() / g64[k].norm().item() - 1) for k in g64}
+    print(name, 'f32 |g| deviation: hip', {k: '%.1e' % v for k, v in dev_gpu.items()})
+    print(name, 'f32 |g| deviation: cpu f32 oracle', {k: '%.1e' % v for k, v in dev_f32.items()})
+    bar = max(1e-4, 2 * max(dev_f32.values()))
+    assert max(dev_gpu.values()) <= bar, (dev_gpu, dev_f32)
+    for k in g64:                               # directions, whole tensors
+        cos = (grads[k] * g64[k]).sum() / (grads[k].norm() * g64[k].norm())
+        assert cos > 1 - 1e-6, (k, cos.item())
+
+    # ---- bf16 autocast: the bench dtype.  83 k rows behind every BatchNorm statistic: bf16 rounding,
+    # not statistics noise, is what is left
+    loss16, logits16, grads16 = run(True)
+    assert abs(loss16 - loss64) < 1e-2 * abs(loss64), (loss16, loss64)
+    report = {}
+    for k in g64:
+        cos = ((grads16[k] * g64[k]).sum() / (grads16[k].norm() * g64[k].norm())).item()
+        report[k] = (round(cos, 5), round(grads16[k].norm().item() / g64[k].norm().item(), 4))
+    print(name, 'bf16 (cosine, |g| ratio):', report)
+    for k, (cos, ratio) in report.items():
+        assert cos >= 0.99, report
+        assert abs(ratio - 1) <= 0.05, report
+
+
+def _f64_wgrad(a, b, pairs, koff, a_col, k):
+    ko = koff.cpu().tolist()
+    ref = torch.zeros(k, a.shape[1], b.shape[1], dtype=torch.float64, device=a.device)
+    for kk in range(k):
+        if ko[kk + 1] == ko[kk]:
+            continue
+        if pairs is None:
+            ia = ib = torch.arange(ko[kk], ko[kk + 1], device=a.device)
+        else:
+            pr = pairs[ko[kk]:ko[kk + 1]].long()
+            ia, ib = (pr[:, 1], pr[:, 0]) if a_col else (pr[:, 0], pr[:, 1])
+        ref[kk] = a[ia].double().t() @ b[ib].double()
+    return ref
+
+
+@pytest.mark.parametrize('ca,cb,k', [(96, 96, 27), (128, 96, 27), (128, 96, 1), (32, 32, 27)])
+def test_wgrad_plan_of_the_bench_batch(ca, cb, k, bench_batch):
+    """lidal_conv_wgrad with the plan bench.py's level-0 layers get (396 662 rows) vs f64."""
+    from lidal_amd import backend as B
+    from lidal_amd.nn import functional as F
+    from lidal_amd.nn.functional.conv import wgrad_scratch
+    coords = bench_batch
+    n = coords.shape[0]
+    assert n > 350000
+    g = torch.Generator().manual_seed(ca + cb + k)
+    a = torch.randn(n, ca, generator=g).to(DEV).bfloat16()
+    b = torch.randn(n, cb, generator=g).to(DEV).bfloat16()
+    if k == 27:
+        km, _ = F.build_kernel_map(coords, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+        pairs, koff = km._nbmaps_cap, km.koff
+    else:
+        pairs, koff = None, torch.tensor([0, n], dtype=torch.int64, device=DEV)
+
+    def run():
+        gw = torch.full((k, ca, cb), float('nan'), dtype=torch.float32, device=DEV)
+        part = wgrad_scratch(n, n, k, ca, cb, a.dtype, DEV)
+        B.check(B.lib().lidal_conv_wgrad(B.ptr(a), B.ptr(b), n, n, B.ptr(pairs), B.ptr(koff), 0, B.ptr(gw),
+                                         B.ptr(part), part.shape[0], k, ca, cb, B.dtype_code(a.dtype),
+                                         B.stream()), 'conv_wgrad')
+        return gw
+    got, again = run(), run()
+    assert torch.equal(got, again)
+    ref = _f64_wgrad(a, b, pairs, koff, 0, k)
+    err = ((got.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize('ci,co', [(96, 96), (128, 96), (32, 32)])
+def test_conv_forward_and_flipped_dgrad_of_the_bench_batch(ci, co, bench_batch):
+    """Forward and data gradient (the `kflip` walk over nbr_out of a symmetric map) of a level-0
+    k3 layer at ~4e5 rows, bf16 operands, against f64 index_select / matmul / index_add on the GPU."""
+    import lidal_amd
+    from lidal_amd.nn import functional as F
+    coords = bench_batch
+    n = coords.shape[0]
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    x = torch.randn(n, ci, generator=g).to(DEV).bfloat16().requires_grad_(True)
+    w = (torch.randn(27, ci, co, generator=g) * 0.05).to(DEV).bfloat16().requires_grad_(True)
+    gy = torch.randn(n, co, generator=g).to(DEV).bfloat16()
+    st = lidal_amd.SparseTensor(x, coords, 1)
+    y = F.conv3d(st, w, 3).F
+    y.backward(gy)
+    km = st.kmaps[((1, 1, 1), (3, 3, 3), (1, 1, 1), (1, 1, 1))]
+    assert km.symmetric
+    maps, ko = km.nbmaps.long(), km.koff.cpu().tolist()
+    xd, wd, gd = x.detach().double(), w.detach().double(), gy.double()
+    y_ref = torch.zeros(n, co, dtype=torch.float64, device=DEV)
+    gx_ref = torch.zeros(n, ci, dtype=torch.float64, device=DEV)
+    gw_ref = torch.zeros(27, ci, co, dtype=torch.float64, device=DEV)
+    for kk in range(27):
+        pr = maps[ko[kk]:ko[kk + 1]]
+        if pr.shape[0] == 0:
+            continue
+        y_ref.index_add_(0, pr[:, 1], xd[pr[:, 0]] @ wd[kk])
+        gx_ref.index_add_(0, pr[:, 0], gd[pr[:, 1]] @ wd[kk].t())
+        gw_ref[kk] = xd[pr[:, 0]].t() @ gd[pr[:, 1]]
+
+    def rel(a, ref):
+        return ((a.double() - ref).abs().max() / ref.abs().max()).item()
+    # outputs are ROUNDED to bf16 (2^-9 relative per element) from f32 accumulators: elementwise bound
+    def close(a, ref):
+        return bool(((a.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-4 * ref.abs().max()).all())
+    assert close(y, y_ref), rel(y, y_ref)
+    assert close(x.grad, gx_ref), rel(x.grad, gx_ref)
+    assert close(w.grad, gw_ref), rel(w.grad, gw_ref)       # returned in the weight's dtype (bf16 here)
+    # f32 parameters under autocast (what the model does): the weight gradient comes back unrounded
+    xs = x.detach().float().requires_grad_(True)
+    ws = w.detach().float().requires_grad_(True)
+    st = lidal_amd.SparseTensor(xs, coords, 1)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y32 = F.conv3d(st, ws, 3).F
+    y32.backward(gy)
+    assert ws.grad.dtype == torch.float32
+    assert rel(ws.grad, gw_ref) < 1e-4, rel(ws.grad, gw_ref)
+
+
+def _frames_120k(n_frames):
+    from lidal_amd import synth
+    frames = synth.make_sequence(n_frames, n_points=120000, seed=7122)
+    rng = np.random.default_rng(5)
+    probs = []
+    for f in frames:
+        w = f['world']
+        lg = rng.standard_normal((w.shape[0], 19)).astype(np.float32) + np.sin(w[:, :1] * 0.7).astype(np.float32) * 2
+        p = np.exp(lg - lg.max(1, keepdims=True))
+        probs.append((p / p.sum(1, keepdims=True)).astype(np.float32))
+    return frames, probs
+
+
+@pytest.mark.parametrize('nei,n_frames,queries', [(10, 13, (0, 6, 12)), (24, 27, (0, 13, 26))])
+def test_scoring_at_120k_points_matches_oracle(nei, n_frames, queries):
+    from lidal_amd.score import FrameBank, interframe
+    from oracle import scoring_ref
+    frames, probs = _frames_120k(n_frames)
+    worlds = [f['world'] for f in frames]
+    assert worlds[0].shape[0] >= 100000
+    bank = FrameBank(0.1)
+    for p, w in zip(probs, worlds):
+        bank.add(torch.from_numpy(w).to(DEV), torch.from_numpy(p).to(DEV))
+    matched = 0
+    for i in queries:
+        sv2point = frames[i]['sv2point']
+        rd, re, rn, rc, pd, pe = scoring_ref.score_frame(i, probs, worlds, sv2point, nei, 0.1, return_points=True)
+        interd, intere, cnt = interframe.score_points(bank, i, nei)
+        matched += int((cnt > 0).sum())
+        assert np.abs(interd.cpu().numpy() - pd).max() <= 1e-4 * max(np.abs(pd).max(), 1e-12)
+        assert np.abs(intere.cpu().numpy() - pe).max() <= 1e-4 * np.abs(pe).max()
+        ptr, idx, lens = interframe.sv_csr(sv2point, DEV)
+        d, e, c = interframe.score_frame(bank, i, ptr, idx, nei)
+        assert np.allclose(d.cpu().numpy(), rd, rtol=1e-4, atol=1e-7)
+        assert np.allclose(e.cpu().numpy(), re, rtol=1e-4, atol=1e-7)
+        assert np.allclose(c.cpu().numpy(), rc, rtol=1e-5, atol=1e-5)
+        assert np.array_equal(lens, rn)
+    assert matched > 50000, matched

@@ -261,18 +261,26 @@ def test_bf16_train_step_gradients_point_the_same_way(name, golden_dir):
 
 
 def test_f32_mode_hits_the_hip_kernels(golden_dir):
-    """The f32 parity mode: BatchNorm / Linear modules on the HIP kernels; the only library calls are
-    the f32 dense products (by design, nn/functional/dense.py)."""
+    """The f32 parity mode: convolutions, dense layers (1x1x1 convs, Linear), BatchNorm all on the HIP
+    kernels, inference and training alike: no library GEMM and no torch fallback anywhere."""
     import lidal_amd
     from lidal_amd import backend as B
+    from lidal_amd.train_step import forward_backward
     from weights import fill_state_dict
     g = _load(golden_dir)
     model = fill_state_dict(_models()['spvcnn'](19)).to(DEV).eval()
     B.HITS.clear()
     with torch.no_grad():
         model(lidal_amd.SparseTensor(torch.from_numpy(g['feats']).to(DEV), torch.from_numpy(g['coords']).to(DEV)))
-    assert not any(k.startswith('torch_fallback') for k in B.HITS), B.HITS
+    assert not any(k.startswith(('torch_fallback', 'library_gemm')) for k in B.HITS), B.HITS
     assert B.HITS.get('conv_apply', 0) >= 42 and B.HITS.get('kmap_build', 0) == 9, B.HITS
+    assert B.HITS.get('conv_apply(dense)', 0) >= 11, B.HITS          # 7 1x1x1 convs + 3 Linear + classifier
+    B.HITS.clear()
+    model.train()
+    forward_backward(model, torch.from_numpy(g['feats']).to(DEV), torch.from_numpy(g['coords']).to(DEV),
+                     torch.from_numpy(g['labels']).to(DEV))
+    assert not any(k.startswith(('torch_fallback', 'library_gemm')) for k in B.HITS), B.HITS
+    assert B.HITS.get('conv_apply(dense)', 0) >= 21 and B.HITS.get('conv_wgrad(dense)', 0) >= 11, B.HITS
 
 
 def test_config1_10k_point_scan_forward(golden_dir):
@@ -356,3 +364,127 @@ def test_inference_caches_follow_training():
     want = evaluate(fresh)
     assert torch.equal(second, want)
     assert not torch.equal(first, second)
+
+
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_plain_torchsparse_surface_unet_equals_the_fused_network(name, golden_dir):
+    """A U-Net written PURELY against the torchsparse surface -- nn.Sequential(spnn.Conv3d, spnn.BatchNorm,
+    spnn.ReLU(True)), SparseTensor.__add__, torchsparse.cat, F.sp* (the composition of the reference's
+    network/utils.py:105-172; the architecture text is oracle/models_ref.py, instantiated over
+    `lidal_amd` instead of the CPU oracle) -- uses none of the flags lidal_amd.network sets (bn_follows,
+    fused_relu, fork, epilogues, prefetch).  It must agree with the fused network: eval logits, train
+    loss and gradients."""
+    import lidal_amd
+    from lidal_amd import backend as B
+    from lidal_amd.nn.functional.fused import cross_entropy
+    from oracle.models_ref import build_models
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    plain_cls = build_models(lidal_amd)[0 if name == 'minkunet' else 1]
+    feats, coords = torch.from_numpy(g['feats']).to(DEV), torch.from_numpy(g['coords']).to(DEV)
+    labels = torch.from_numpy(g['labels']).to(DEV)
+    plain = fill_state_dict(plain_cls(19)).to(DEV).eval()
+    fused = fill_state_dict(_models()[name](19)).to(DEV).eval()
+    assert list(plain.state_dict().keys()) == list(fused.state_dict().keys())
+    B.HITS.clear()
+    with torch.no_grad():
+        lp, fp = plain(lidal_amd.SparseTensor(feats, coords))
+    assert B.HITS.get('conv_apply', 0) >= 42 and B.HITS.get('bn_eval_fwd', 0) >= 49, B.HITS
+    with torch.no_grad():
+        lf, ff = fused(lidal_amd.SparseTensor(feats, coords))
+    assert _rel(lp.cpu().numpy(), g[name + '_logits']) < 1e-4         # the reference files' own output
+    assert _rel(lp.cpu().numpy(), lf.cpu().numpy()) < 2e-5
+    assert _rel(fp.cpu().numpy(), ff.cpu().numpy()) < 2e-5
+    grads = []
+    for model in (plain, fused):
+        model.train()
+        if hasattr(model, 'dropout'):
+            model.dropout.p = 0.0
+        logits, _ = model(lidal_amd.SparseTensor(feats, coords))
+        loss = cross_entropy(logits, labels, ignore_index=255)
+        loss.backward()
+        grads.append((loss.item(), {k: p.grad.double().cpu() for k, p in model.named_parameters()}))
+    assert abs(grads[0][0] - grads[1][0]) < 2e-5 * abs(grads[1][0])
+    assert abs(grads[0][0] - float(g[name + '_train_loss'])) < 1e-4 * abs(float(g[name + '_train_loss']))
+    worst = 0.0
+    for k in g[name + '_grad_keys']:
+        a, b = grads[0][1][str(k)], grads[1][1][str(k)]
+        worst = max(worst, abs(a.norm().item() / b.norm().item() - 1))
+    assert worst < 5e-4, worst
+
+
+def test_side_stream_weight_gradients_survive_gradient_accumulation():
+    """f32 weight gradients run on a second stream (backend.beside).  Accumulating two micro-batches into
+    existing .grad tensors makes autograd ADD the second gradient on the main stream: the join must then
+    happen at once (backend._may_defer), or the sum reads a gradient still being written."""
+    from lidal_amd import backend as B
+    from lidal_amd import synth
+    from lidal_amd.train_step import forward_backward
+    batches = []
+    for seed in (11, 12):
+        b = synth.make_train_batch(n_frames=1, n_points=30000, seed=seed)
+        batches.append(tuple(torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b', 'labels_v_b')))
+    saved = B._OVERLAP
+    out = {}
+    try:
+        for mode in ('0', '1'):
+            B._OVERLAP = mode
+            torch.manual_seed(3)
+            model = _models()['minkunet'](19).to(DEV).train()
+            model.zero_grad(set_to_none=False)
+            for p in model.parameters():
+                p.grad = torch.zeros_like(p)
+            for f, c, lab in batches:
+                forward_backward(model, f, c, lab)
+            torch.cuda.synchronize()
+            out[mode] = [p.grad.clone() for p in model.parameters()]
+    finally:
+        B._OVERLAP = saved
+    assert all(torch.equal(a, b) for a, b in zip(out['0'], out['1']))
+
+
+def test_a_failed_backward_does_not_freeze_the_weight_epoch():
+    """Autograd drops its end-of-backward callbacks when backward raises; the epoch latch must not stay
+    set (stale weight images under Adam(fused=True) otherwise)."""
+    from lidal_amd import backend as B
+    from lidal_amd import synth
+    from lidal_amd.train_step import train_step
+    b = synth.make_train_batch(n_frames=1, n_points=6000, seed=21)
+    f, c, lab = (torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b', 'labels_v_b'))
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+
+    def run(fail):
+        torch.manual_seed(5)
+        model = _models()['minkunet'](19).to(DEV).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+        losses = [train_step(model, opt, f, c, lab, autocast=True)[0].item()]
+        if fail:
+            # the classifier's backward has run (its epoch callback is queued) when the stem-side node raises
+            x = lidal_amd_input(f, c)
+            x.feats = Boom.apply(x.feats.requires_grad_(True))
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                logits, _ = model(x)
+            with pytest.raises(RuntimeError, match='boom'):
+                logits.float().sum().backward()
+            opt.zero_grad()
+        losses += [train_step(model, opt, f, c, lab, autocast=True)[0].item() for _ in range(3)]
+        return losses
+
+    def lidal_amd_input(f, c):
+        import lidal_amd
+        return lidal_amd.SparseTensor(f.clone(), c)
+    epoch0 = B.WEIGHT_EPOCH[0]
+    clean, failed = run(False), run(True)
+    assert B.WEIGHT_EPOCH[0] >= epoch0 + 8
+    assert not B._epoch_queued[0] and not B._join_queued[0]
+    # BatchNorm running statistics saw one extra forward in the failed run, the weights did not (no
+    # optimizer step): the training losses (batch statistics) are unaffected by it
+    assert clean == failed, (clean, failed)

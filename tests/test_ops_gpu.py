@@ -951,3 +951,22 @@ def test_floor_coords_is_the_reference_expression(stride):
     want = torch.cat([torch.floor(c[:, :3] / stride).int() * stride, c[:, -1].int().view(-1, 1)], 1)
     got = _floor_to_stride(PointTensor(torch.zeros(c.shape[0], 1, device=DEV), c), stride)
     assert got.dtype == torch.int32 and torch.equal(got, want)
+
+
+@pytest.mark.parametrize('stride', [1, 2, 4, 8])
+def test_trilinear_devoxelize_reproduces_a_linear_field(stride):
+    """The HIP hash / query / ti-weights / devoxelize chain of voxel_to_point (network/utils.py:66-102)
+    interpolates an affine field exactly: pins the z-fastest corner order of the 2x2x2 offsets against
+    the 4 dx + 2 dy + dz numbering of the weights, independently of the oracle."""
+    from test_oracle_cpu import _linear_field_case
+    F = _F()
+    from lidal_amd.nn.utils import get_kernel_offsets
+    vox, field, pts, want = _linear_field_case(stride, n_pts=3000, seed=stride)
+    vox, field, pts = vox.to(DEV), field.to(DEV), pts.to(DEV)
+    off = get_kernel_offsets(2, stride, 1, device=DEV)
+    floor = torch.cat([torch.floor(pts[:, :3] / stride).int() * stride, pts[:, -1:].int()], 1)
+    idx = F.sphashquery(F.sphash(floor, off), F.sphash(vox))
+    assert (idx >= 0).all()
+    w = F.calc_ti_weights(pts, idx, scale=stride).transpose(0, 1).contiguous()
+    got = F.spdevoxelize(field, idx.transpose(0, 1).contiguous().int(), w)
+    assert torch.allclose(got.cpu(), want, rtol=1e-5, atol=1e-4 * stride), (got.cpu() - want).abs().max()

@@ -154,3 +154,36 @@ def test_voxelize_oracle_reproduces_reference_dataset(golden_dir):
                                                      g['trans_m%d' % i], g['rnd%d' % i])
         assert np.array_equal(cv, g['coords_v%d' % i]) and np.array_equal(inv, g['inverse%d' % i])
         assert np.array_equal(fv, g['feats_v%d' % i])
+
+
+def _linear_field_case(stride, n_pts=400, seed=0):
+    """A dense block of voxels at tensor stride `stride` carrying the affine field f = a x + b y + c z + d
+    (distinct a, b, c: a wrong corner order cannot cancel), and points strictly inside the block."""
+    g = torch.Generator().manual_seed(seed)
+    D = 5
+    ax = torch.arange(D) * stride
+    xx, yy, zz = torch.meshgrid(ax, ax, ax, indexing='ij')
+    vox = torch.stack([xx, yy, zz, torch.zeros_like(xx)], -1).reshape(-1, 4).int()
+    vox = vox[torch.randperm(vox.shape[0], generator=g)]           # row order must not matter
+    coef = torch.tensor([0.37, -1.3, 2.9])
+    field = (vox[:, :3].float() * coef).sum(1, keepdim=True) + 0.5
+    pts = torch.rand(n_pts, 3, generator=g) * (D - 1) * stride * 0.999
+    pts = torch.cat([pts, torch.zeros(n_pts, 1)], 1)
+    want = (pts[:, :3] * coef).sum(1, keepdim=True) + 0.5
+    return vox, field, pts, want
+
+
+def test_trilinear_devoxelize_reproduces_a_linear_field():
+    """Independent pin of the even-kernel corner order: get_kernel_offsets(2, s) enumerates the 8 corners
+    z-fastest and calc_ti_weights numbers its weights 4 dx + 2 dy + dz (network/utils.py:69-83); only if
+    the two agree does trilinear interpolation reproduce an affine field exactly."""
+    for stride in (1, 2, 4, 8):
+        vox, field, pts, want = _linear_field_case(stride)
+        off = get_kernel_offsets(2, stride, 1)
+        floor = torch.cat([torch.floor(pts[:, :3] / stride).int() * stride, pts[:, -1:].int()], 1)
+        idx = RF.sphashquery(RF.sphash(floor, off), RF.sphash(vox))                # [8, N]
+        assert (idx >= 0).all()
+        w = RF.calc_ti_weights(pts, idx, scale=stride).transpose(0, 1).contiguous()
+        assert torch.allclose(w.sum(1), torch.ones(pts.shape[0]), atol=1e-6)
+        got = RF.spdevoxelize(field, idx.transpose(0, 1).contiguous(), w)
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-4 * stride), (stride, (got - want).abs().max())

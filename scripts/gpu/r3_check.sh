@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/r3_${1:-x}; mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 > $O/gpu_tests.log 2>&1; tail -30 $O/gpu_tests.log
+timeout 2400 python -m pytest tests -m gpu -q --durations=15 > $O/gpu_tests.log 2>&1; tail -30 $O/gpu_tests.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.err; python3 - <<PY
 import json
 try:
@@ -15,8 +15,8 @@ except Exception as e:
     print('bench parse failed', e)
 PY
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-secondary --no-families --no-roofline --no-variants > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-secondary --no-families --no-roofline --no-variants > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
 cd $GRAFT_REPO_ROOT
 find $O/prof -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/step_kernel_stats.csv
-find $O/prof -name '*.csv' ! -name '*kernel_stats.csv' -delete; find $O/prof -name '*.db' -delete
+rm -rf $O/prof
 python3 scripts/gpu/stats_table.py $O/step_kernel_stats.csv 7 | head -60

@@ -113,12 +113,16 @@ int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr
  * row), nbr_perm i32 [k, n_rows] = nbr[:, perm], tile_masks u32 [ceil(n_rows/128)] = OR of the row
  * patterns of each 128-row tile (may be NULL).  With them a tile only touches the offsets of its
  * own patterns. */
-/* the library's own stable LSD radix sort of (u32 key, i32 value) pairs by the low `bits` key bits
- * (csrc/sort.hip; what lidal_kmap_order sorts the 8-bit masks of the 2x2x2 maps with), exported for tests:
- * keys_in / vals_in are not written; ws >= lidal_sort_pairs_workspace_bytes(n). */
+/* the library's own stable LSD radix sort (csrc/sort.hip: Onesweep, 8 bits per pass, 1 + ceil(bits/8)
+ * launches) of (u32 or u64 key, i32 value) pairs by the low `bits` key bits -- what every sorted order
+ * of this library comes from (row orders, torch.unique of hashes / packed coordinates, contributor
+ * lists, the scorer's cell keys); exported for tests.  keys_in / vals_in are not written;
+ * ws >= lidal_sort_pairs_workspace_bytes(n). */
 int64_t lidal_sort_pairs_workspace_bytes(int64_t n);
 int lidal_sort_pairs(const uint32_t* keys_in, const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out,
                      int64_t n, int bits, void* ws, int64_t ws_bytes, void* stream);
+int lidal_sort_pairs_u64(const uint64_t* keys_in, const int32_t* vals_in, uint64_t* keys_out, int32_t* vals_out,
+                         int64_t n, int bits, void* ws, int64_t ws_bytes, void* stream);
 int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows);
 int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32_t* perm, int32_t* nbr_perm,
                      uint32_t* tile_masks, void* ws, int64_t ws_bytes, void* stream);

@@ -36,8 +36,8 @@ void set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
-static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
-static inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+__host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 
 constexpr int kWave = 64;
 
@@ -141,8 +141,12 @@ int wgrad_dma(const void* a, const void* b, int64_t n_a, int64_t n_b, const int*
               const int64_t* koff, int a_col, float* gw, float* partial, int W, int K, int ca,
               int cb, hipStream_t s);
 
-// sort.hip: stable LSD radix sort of (u32 key, i32 value) pairs by the low `bits` key bits, 1 + ceil(bits/8)
-// launches; keys_in / vals_in are not written
+// sort.hip: stable LSD radix sort (Onesweep) of u32 / u64 keys with an optional i32 payload by key bits
+// [0, end_bit): 1 + ceil(end_bit / 8) launches; keys_in / vals_in are not written; vals_in == NULL sorts
+// keys only
+int64_t radix_sort_ws_bytes(int64_t n, int key_bytes, bool has_val);
+int radix_sort(const void* keys_in, const int* vals_in, void* keys_out, int* vals_out, int64_t n,
+               int key_bytes, int end_bit, void* ws, int64_t ws_bytes, hipStream_t s);
 int64_t sort_pairs_ws_bytes(int64_t n);
 int sort_pairs_u32(const unsigned* keys_in, const int* vals_in, unsigned* keys_out, int* vals_out,
                    int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s);

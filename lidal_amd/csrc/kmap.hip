@@ -8,8 +8,6 @@
 //   pass 3  per-block ordered compaction               (ballot rank + wave offsets in LDS)
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "common.h"
 
 // The reference computes these quantities with numpy (separately rounded products and sums); hipcc
@@ -127,9 +125,7 @@ struct UniqueWs {
 UniqueWs carve_unique_ws(void* ws, int64_t n) {
   UniqueWs u;
   int64_t nblocks = cdiv(n > 0 ? n : 1, kTile);
-  size_t tmp = 0;
-  (void)rocprim::radix_sort_keys((void*)nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                           (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+  const size_t tmp = (size_t)radix_sort_ws_bytes(n > 0 ? n : 1, 8, false);
   char* p = (char*)ws;
   int64_t o = 0;
   u.sorted = (uint64_t*)(p + o); o += align_up(8 * (n > 0 ? n : 1), 256);
@@ -150,8 +146,8 @@ int unique_sorted_u64(const uint64_t* keys, int64_t n, int64_t* out, int64_t* n_
   UniqueWs u = carve_unique_ws(ws, n);
   LIDAL_REQUIRE(ws_bytes >= u.total, "unique workspace too small: %lld < %lld",
                 (long long)ws_bytes, (long long)u.total);
-  size_t tmp = u.sort_tmp_bytes;
-  LIDAL_HIP(rocprim::radix_sort_keys(u.sort_tmp, tmp, keys, u.sorted, (size_t)n, 0, end_bit, s));
+  if (int rc = radix_sort(keys, nullptr, u.sorted, nullptr, n, 8, end_bit, u.sort_tmp, (int64_t)u.sort_tmp_bytes, s))
+    return rc;
   int64_t nblocks = cdiv(n, kTile);
   head_count_kernel<<<(int)nblocks, kBlock, 0, s>>>(u.sorted, n, u.counts);
   LIDAL_CHECK_LAUNCH("head_count");
@@ -431,24 +427,6 @@ __global__ void __launch_bounds__(256) tile_or_kernel(const unsigned* __restrict
   }
 }
 
-// rocprim sorts anything up to 1M items by merge sort, whatever the key width; for the 8-bit masks
-// of the 2x2x2 maps one Onesweep pass is 3x faster from ~100k rows up (scripts/sort_bench.hip:
-// 400k pairs 114 us vs 36 us), so those go through a config whose merge-sort limit is 64k.
-using NarrowKeySort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                 rocprim::default_config, 65536>;
-size_t mask_sort_tmp_bytes(int64_t n) {
-  size_t tmp = 0, tmp2 = 0;
-  (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr,
-                                  (const int*)nullptr, (int*)nullptr, (size_t)(n > 0 ? n : 1), 0,
-                                  32, (hipStream_t)0);
-  (void)rocprim::radix_sort_pairs<NarrowKeySort>((void*)nullptr, tmp2, (const unsigned*)nullptr,
-                                                 (unsigned*)nullptr, (const int*)nullptr,
-                                                 (int*)nullptr, (size_t)(n > 0 ? n : 1), 0, 8,
-                                                 (hipStream_t)0);
-  return tmp > tmp2 ? tmp : tmp2;
-}
-
-
 // ---------------- input voxelisation (dataset/sk_dataset.py:143-171 on the GPU) ------------------
 // 1. affine: p' = p(f32 -> f64) * M (f64, row vector times matrix, k = 0,1,2 in order, no FMA);
 //    feats = (f32)p', intensity;  scaled = p' * scale;  per-block min/max of `scaled`
@@ -591,13 +569,7 @@ __global__ void __launch_bounds__(kBlock) rows_compact_kernel(const uint64_t* __
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = offsets[nblocks];
 }
 
-size_t voxel_sort_tmp_bytes(int64_t n) {
-  size_t tmp = 0;
-  (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                  (const int*)nullptr, (int*)nullptr, (size_t)(n > 0 ? n : 1), 0,
-                                  39, (hipStream_t)0);
-  return tmp;
-}
+size_t voxel_sort_tmp_bytes(int64_t n) { return (size_t)radix_sort_ws_bytes(n > 0 ? n : 1, 8, true); }
 
 }  // namespace
 
@@ -709,10 +681,7 @@ extern "C" int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, i
   return 0;
 }
 
-static int64_t order_sort_tmp_bytes(int64_t q) {
-  const int64_t a = (int64_t)mask_sort_tmp_bytes(q), b = sort_pairs_ws_bytes(q);
-  return a > b ? a : b;
-}
+static int64_t order_sort_tmp_bytes(int64_t q) { return sort_pairs_ws_bytes(q); }
 
 extern "C" int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows) {
   int64_t q = n_rows > 0 ? n_rows : 1;
@@ -731,23 +700,10 @@ extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32
   unsigned* skeys = (unsigned*)((char*)ws + a);
   int* vals = (int*)((char*)ws + 2 * a);
   void* tmp = (char*)ws + 3 * a;
-  size_t tmp_bytes = mask_sort_tmp_bytes(q);
   const BitRank rank = bit_rank(k);
   row_mask_kernel<<<(unsigned)cdiv(q, 256), 256, 0, s>>>(nbr, q, k, rank, keys, vals);
   LIDAL_CHECK_LAUNCH("row_mask");
-  // 8-bit masks (2x2x2 maps): the library's own one-pass radix sort (csrc/sort.hip: 19-28 us for
-  // 226k-397k pairs against Onesweep's 36); wider masks stay on rocPRIM's merge sort, which sort.hip
-  // does not beat (4 passes with scattered 4-byte writes: 168 us against 114 for 397k 27-bit pairs)
-#ifndef LIDAL_ROCPRIM_SORT
-  if (k <= 8) {
-    if (int rc = sort_pairs_u32(keys, vals, skeys, perm, q, k, tmp, order_sort_tmp_bytes(q), s)) return rc;
-  } else
-#endif
-  if (k <= 8)
-    LIDAL_HIP(rocprim::radix_sort_pairs<NarrowKeySort>(tmp, tmp_bytes, keys, skeys, vals, perm,
-                                                       (size_t)q, 0, k, s));
-  else
-    LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, perm, (size_t)q, 0, k, s));
+  if (int rc = sort_pairs_u32(keys, vals, skeys, perm, q, k, tmp, order_sort_tmp_bytes(q), s)) return rc;
   permute_table_kernel<<<dim3((unsigned)cdiv(q, 256), (unsigned)k), 256, 0, s>>>(nbr, q, perm,
                                                                                  nbr_perm);
   LIDAL_CHECK_LAUNCH("permute_table");
@@ -798,14 +754,13 @@ extern "C" int lidal_voxelize_points(const float* points, const float* intensity
   int* counts = (int*)w;            w += align_up(4 * nb, 256);
   int64_t* offs = (int64_t*)w;      w += align_up(8 * (nb + 1), 256);
   void* tmp = (void*)w;
-  size_t tmp_bytes = voxel_sort_tmp_bytes(p);
   affine_kernel<<<(unsigned)blocks, 256, 0, s>>>(points, intensity, p, m_dev, scale, feats_p, scaled, part);
   LIDAL_CHECK_LAUNCH("affine");
   voxel_offset_kernel<<<1, 256, 0, s>>>(part, blocks, rnd_dev, (double)full_scale, offset);
   LIDAL_CHECK_LAUNCH("voxel_offset");
   voxel_keys_kernel<<<(unsigned)blocks, 256, 0, s>>>(scaled, p, offset, full_scale, keys, ids, n_invalid_dev);
   LIDAL_CHECK_LAUNCH("voxel_keys");
-  LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, ids, sids, (size_t)p, 0, 39, s));
+  if (int rc = radix_sort(keys, ids, skeys, sids, p, 8, 39, tmp, (int64_t)voxel_sort_tmp_bytes(p), s)) return rc;
   head_count_kernel<<<(unsigned)nb, kBlock, 0, s>>>(skeys, p, counts);
   LIDAL_CHECK_LAUNCH("head_count");
   scan_counts_kernel<<<1, 1024, 0, s>>>(counts, nb, offs);

@@ -6,7 +6,6 @@
 // (f32 pairwise-8 row sums, f64 KL terms rounded to f32, f64 divergence accumulator).
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -345,13 +344,7 @@ supervoxel_reduce_kernel(const double* __restrict__ interd, const float* __restr
   }
 }
 
-size_t sort_pairs_tmp_bytes(int64_t p) {
-  size_t tmp = 0;
-  (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const uint64_t*)nullptr,
-                                  (uint64_t*)nullptr, (const int*)nullptr, (int*)nullptr,
-                                  (size_t)(p > 0 ? p : 1), 0, 63, (hipStream_t)0);
-  return tmp;
-}
+size_t sort_pairs_tmp_bytes(int64_t p) { return (size_t)radix_sort_ws_bytes(p > 0 ? p : 1, 8, true); }
 
 }  // namespace
 
@@ -392,12 +385,11 @@ extern "C" int lidal_nn_grid_build(const double* pts, int64_t p, double cell, vo
   uint64_t* keys = (uint64_t*)ws;
   int* idx = (int*)((char*)ws + align_up(8 * q, 256));
   void* tmp = (char*)ws + align_up(8 * q, 256) + align_up(4 * q, 256);
-  size_t tmp_bytes = sort_pairs_tmp_bytes(q);
   uint64_t* skeys = (uint64_t*)(base + cap * 12);
   int* sidx = (int*)(base + cap * 12 + align_up(8 * q, 256));
   grid_keys_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(pts, p, cell, keys, idx);
   LIDAL_CHECK_LAUNCH("grid_keys");
-  LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, idx, sidx, (size_t)p, 0, 63, s));
+  if (int rc = radix_sort(keys, idx, skeys, sidx, p, 8, 63, tmp, (int64_t)sort_pairs_tmp_bytes(q), s)) return rc;
   TableView t;
   t.keys = (unsigned long long*)base;
   t.vals = (int*)(base + cap * 8);

@@ -1,237 +1,340 @@
-// Stable LSD radix sort of (u32 key, i32 value) pairs for the sizes of this path (10^3 .. 5*10^6 items,
-// 8 .. 32 significant key bits), written for the occupancy-pattern row orders (lidal_kmap_order).
+// Stable LSD radix sort for gfx950 -- the one sort of this library (kernel-map row orders, sorted
+// unique of coordinate hashes and packed coordinates, point->voxel contributor lists, the scorer's
+// cell keys).  Keys u32 or u64, optional i32 payload, 8 bits per pass, 1 + ceil(bits / 8) launches:
 //
-// Where it stands (scripts/sort_bench.py, us per sort, against rocPRIM through torch.sort):
-//     397k pairs,  8 bits   28 (Onesweep path of rocPRIM: 36)      226k pairs, 8 bits   19
-//     397k pairs, 27 bits  168 (merge sort: 114-137)               3.2M pairs, 19 bits 364 (175)
-// One pass is competitive; several are not: every pass scatters its items as single 4-byte writes
-// (a 1024-item round holds ~4 items per digit, so runs are 16 bytes), where Onesweep first orders
-// ~8k items per workgroup in LDS and writes runs of 128 bytes.  (Tried here too: 8192-item rounds
-// ordered in LDS before the write-out -- 177 us for the 27-bit case: with coalesced writes the
-// counting of the next digit at the landing place, ~400k contended global atomics per pass, is what
-// remains; counting in a launch of its own instead costs what a pass costs.)  The library therefore uses this
-// sort for the 8-bit occupancy masks of the 2x2x2 maps only; the 27-bit masks, the voxel
-// lists and the 60-bit coordinate keys stay on rocPRIM.  1 + P launches for P = ceil(bits / 8):
-//   * the items are cut into NB <= 256 contiguous ranges, one workgroup each;
-//   * `hist0` counts the first digit per range (a private row per workgroup: no atomics) and zeroes
-//     the rows of the later digits' tables;
-//   * pass p: every workgroup derives its 256 start offsets from the table of digit p (thread d adds
-//     the column of digit d over the ranges before its own: NB coalesced 1-KiB reads), then walks its
-//     range in index order, 1024 items per round: a wave ranks each 64 of its 256 items among equal
-//     digits with 8 ballots (multisplit), the waves' counts are prefixed through LDS, and each item
-//     is written to its final place of this pass -- where its NEXT digit is counted
-//     into the next table for the range it landed in (integer atomics: the counts do not depend on
-//     the order of arrival), so no pass needs a counting launch of its own.
-// Stable (equal keys keep their input order), hence the output is unique: bit-equal to any other
-// stable sort (tests/test_ops_gpu.py compares with torch.sort(stable=True)).
+//   hist     every digit position's histogram in ONE pass over the keys: <= 64 workgroups, each with
+//            private LDS tables written out as part[block][pass][256] (no global atomics, nothing to
+//            zero beforehand); the same launch zeroes the look-back state of all passes.
+//   pass p   "one sweep": a tile of 8192 consecutive items per workgroup (512 threads x 16), taken in
+//            order through an atomic ticket.  The tile's items are ranked in index order -- per wave a
+//            multisplit by 8 ballots per item, the waves' counts prefixed through LDS -- which gives
+//            the tile's digit counts; those are published (AGGREGATE) in status[pass][tile][256], the
+//            counts of the tiles before it are collected by decoupled look-back (thread d walks digit d
+//            backwards, 8 status rows in flight, until it meets an INCLUSIVE entry) and the tile's own
+//            inclusive counts are published.  Items go through an LDS stage in tile-sorted order, so
+//            the write-out moves runs (32 items per digit on average), not single words.
+//
+// Stable, hence unique: bit-equal to torch.sort(stable=True) (tests/test_ops_gpu.py).  The first
+// generation of this file (per-range digit tables, next digit counted where an item lands) won only
+// its one-pass form against rocPRIM (168 vs 114 us for 397k 27-bit pairs): its passes scattered single
+// 4-byte writes and counted with ~400k contended global atomics per pass; this form has neither.
 #include "common.h"
 
 using namespace lidal;
 
 namespace {
 
-constexpr int SB = 256;          // threads per workgroup = items per round = radix
-constexpr int MAX_RANGES = 256;
+constexpr int RADIX = 256;
+constexpr int THREADS = 512;
+constexpr int WAVES = THREADS / 64;
+constexpr int ITEMS = 16;
+constexpr int TILE = THREADS * ITEMS;            // 8192 items per workgroup
+constexpr int MAX_PASSES = 8;
+constexpr int HIST_BLOCKS = 64;
 
-struct Plan { int nb; int64_t per; int passes; };
+constexpr unsigned FLAG_AGG = 1u << 30, FLAG_INC = 2u << 30, FLAG_MASK = 3u << 30, COUNT_MASK = (1u << 30) - 1u;
 
-static Plan plan_for(int64_t n, int bits) {
-  Plan p;
-  p.passes = (bits + 7) / 8;
-  if (p.passes < 1) p.passes = 1;
-  // ranges: >= 2 rounds each; up to 64 (one batch of table rows per workgroup) while that keeps a
-  // range within ~8 rounds, then up to MAX_RANGES
-  int64_t nb = cdiv(n, 2 * 1024);
-  if (nb < 1) nb = 1;
-  if (nb > 64) nb = cdiv(n, 8 * 1024) > 64 ? cdiv(n, 8 * 1024) : 64;
-  if (nb > MAX_RANGES) nb = MAX_RANGES;
-  p.per = align_up(cdiv(n, nb), SB);          // (ranges need not be whole rounds)
-  p.nb = (int)cdiv(n, p.per);
-  return p;
+struct Layout {
+  int passes, hist_blocks;
+  int64_t tiles;
+  int64_t off_part, off_ticket, off_status, off_ktmp, off_vtmp, total;
+};
+
+Layout layout_for(int64_t n, int key_bytes, bool has_val, int end_bit) {
+  Layout L;
+  const int64_t q = n > 0 ? n : 1;
+  L.passes = (end_bit + 7) / 8;
+  if (L.passes < 1) L.passes = 1;
+  if (L.passes > MAX_PASSES) L.passes = MAX_PASSES;
+  L.tiles = cdiv(q, TILE);
+  L.hist_blocks = (int)(L.tiles < HIST_BLOCKS ? L.tiles : HIST_BLOCKS);
+  int64_t o = 0;
+  L.off_part = o;   o += align_up((int64_t)HIST_BLOCKS * MAX_PASSES * RADIX * 4, 256);
+  L.off_ticket = o; o += 256;
+  L.off_status = o; o += align_up((int64_t)MAX_PASSES * L.tiles * RADIX * 4, 256);
+  L.off_ktmp = o;   o += align_up(q * key_bytes, 256);
+  L.off_vtmp = o;   o += has_val ? align_up(q * 4, 256) : 0;
+  L.total = o;
+  return L;
 }
 
-__global__ void __launch_bounds__(SB) sort_hist0_kernel(const unsigned* __restrict__ keys, int64_t n,
-                                                        int64_t per, int passes,
-                                                        int* __restrict__ tables) {
-  __shared__ int h[256];
-  const int b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
-  h[tid] = 0;
-  __syncthreads();
-  const int64_t beg = (int64_t)b * per, end = (beg + per < n) ? beg + per : n;
-  for (int64_t i = beg + tid; i < end; i += SB) atomicAdd(&h[keys[i] & 255u], 1);
-  __syncthreads();
-  tables[(int64_t)b * 256 + tid] = h[tid];
-  for (int p = 1; p < passes; ++p) tables[((int64_t)p * nb + b) * 256 + tid] = 0;
+__device__ __forceinline__ unsigned ld_status(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_status(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One pass.  A round = ROUND = 1024 consecutive items: wave w owns items [256 w, 256 w + 256) of the
-// round and walks them as four 64-item steps, so the items of a digit keep their index order when
-//   place = start of the digit for this range (off)  +  the digit's count in the earlier waves of
-//           the round (phase 2)  +  its count in the wave's earlier steps  +  rank inside the step.
-// Three barriers per 1024 items (the first form of this kernel took a turn per wave and per 256
-// items, 16 barriers per 1024, with the loads of a round exposed: 110 us for 396k 27-bit pairs).
-constexpr int ROUND = 1024;
-__global__ void __launch_bounds__(SB) sort_pass_kernel(const unsigned* __restrict__ kin,
-                                                       const int* __restrict__ vin,
-                                                       unsigned* __restrict__ kout,
-                                                       int* __restrict__ vout, int64_t n, int64_t per,
-                                                       int shift, const int* __restrict__ table,
-                                                       int* __restrict__ next_table) {
-  __shared__ int off[256];            // running start of every digit for this range
-  __shared__ int scan[256];
-  __shared__ int wh[4][256];          // per wave: digit counts of the round, then running places
-  const int b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
+// ---- all digit histograms in one pass; zeroes tickets and look-back state -------------------
+template <typename K>
+__global__ void __launch_bounds__(THREADS) sort_hist_kernel(const K* __restrict__ keys, int64_t n, int passes,
+                                                            int end_bit, unsigned* __restrict__ part,
+                                                            unsigned* __restrict__ zero_from, int64_t zero_words) {
+  __shared__ unsigned h[MAX_PASSES][RADIX];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < MAX_PASSES * RADIX; i += THREADS) (&h[0][0])[i] = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < zero_words; i += (int64_t)gridDim.x * THREADS)
+    zero_from[i] = 0u;
+  __syncthreads();
+  // contiguous share of the items per block, 16-item strips per thread
+  const int64_t per = align_up(cdiv(n, gridDim.x), THREADS);
+  const int64_t beg = (int64_t)blockIdx.x * per, end = (beg + per < n) ? beg + per : n;
+  const K top_mask = (end_bit >= (int)sizeof(K) * 8) ? ~(K)0 : (((K)1 << end_bit) - 1);
+  for (int64_t i0 = beg; i0 < end; i0 += (int64_t)THREADS * 4) {
+    K k[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * THREADS + tid;
+      ok[u] = i < end;
+      k[u] = ok[u] ? keys[i] : (K)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const K kk = k[u] & top_mask;
+      for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(unsigned)(kk >> (8 * p)) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < passes * RADIX; i += THREADS)
+    part[(int64_t)blockIdx.x * MAX_PASSES * RADIX + i] = (&h[0][0])[i];
+}
+
+// exclusive scan of one value per thread over the first 256 threads (4 waves); all threads call it
+__device__ __forceinline__ unsigned scan256_exclusive(unsigned v, unsigned* wsum /*[4] LDS*/, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  // start offset of digit `tid` for this range: all smaller digits everywhere + this digit in the
-  // ranges before this one
-  // (up to 64 coalesced 1-KiB rows in flight per batch: with 8 in flight the 129 rows of a 396k-item
-  // sort were 16 dependent batches, ~13 us of every pass)
-  int before = 0, total = 0;
-  for (int r0 = 0; r0 < nb; r0 += 64) {
-    int c[64];
+  unsigned incl = v;
 #pragma unroll
-    for (int u = 0; u < 64; ++u) c[u] = (r0 + u < nb) ? table[(int64_t)(r0 + u) * 256 + tid] : 0;
-#pragma unroll
-    for (int u = 0; u < 64; ++u) {
-      before += (r0 + u < b) ? c[u] : 0;
-      total += c[u];
-    }
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
   }
-  scan[tid] = total;
+  if (lane == 63 && wave < 4) wsum[wave] = incl;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const int t = tid >= d ? scan[tid - d] : 0;
-    __syncthreads();
-    scan[tid] += t;
-    __syncthreads();
-  }
-  off[tid] = scan[tid] - total + before;
+  unsigned off = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) off += (w < wave) ? wsum[w] : 0u;
+  __syncthreads();
+  return off + incl - v;
+}
 
-  const int64_t beg = (int64_t)b * per, end = (beg + per < n) ? beg + per : n;
-  // this lane's four items of a round: steps t = 0..3, item = i0 + 256 wave + 64 t + lane
-  unsigned key[4], nkey[4];
-  int val[4], nval[4];
-  auto load = [&](int64_t i0, unsigned (&k)[4], int (&v)[4]) __attribute__((always_inline)) {
+template <typename K, bool HAS_VAL>
+__global__ void __launch_bounds__(THREADS) sort_onesweep_kernel(const K* __restrict__ kin, const int* __restrict__ vin,
+                                                                K* __restrict__ kout, int* __restrict__ vout,
+                                                                int64_t n, int shift, int bits,
+                                                                const unsigned* __restrict__ part, int hist_blocks,
+                                                                unsigned* __restrict__ ticket,
+                                                                unsigned* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];
+  K* skey = reinterpret_cast<K*>(stage_raw);
+  int* sval = reinterpret_cast<int*>(stage_raw + (size_t)TILE * sizeof(K));
+  __shared__ unsigned whist[WAVES][RADIX];
+  __shared__ unsigned tstart[RADIX];        // first tile-sorted position of digit d
+  __shared__ unsigned goff[RADIX];          // global position = tile-sorted position + goff[d]   (mod 2^32)
+  __shared__ unsigned wsum[4];
+  __shared__ unsigned tile_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) tile_s = atomicAdd(ticket, 1u);
+  for (int i = tid; i < WAVES * RADIX; i += THREADS) (&whist[0][0])[i] = 0u;
+  __syncthreads();
+  const int64_t tile = tile_s;
+  const int64_t base = tile * TILE;
+  const int64_t left = n - base;
+  const int nvalid = left >= TILE ? TILE : (int)left;
+  const unsigned dmask = (1u << bits) - 1u;
+
+  // ---- load: wave w owns items [w * 1024, w * 1024 + 1024) of the tile, item (i, lane) = i * 64 + lane
+  K key[ITEMS];
+  int val[ITEMS];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int64_t i = i0 + 256 * wave + 64 * t + lane;
-      const bool ok = i < end;
-      k[t] = ok ? kin[i] : 0u;
-      v[t] = ok ? vin[i] : 0;
-    }
-  };
-  load(beg, key, val);
-  for (int64_t i0 = beg; i0 < end; i0 += ROUND) {
-    if (i0 + ROUND < end) load(i0 + ROUND, nkey, nval);        // next round's items travel meanwhile
+  for (int i = 0; i < ITEMS; ++i) {
+    const int li = wave * (64 * ITEMS) + i * 64 + lane;
+    const bool ok = li < nvalid;
+    key[i] = ok ? kin[base + li] : ~(K)0;
+    if (HAS_VAL) val[i] = ok ? vin[base + li] : 0;
+  }
+  // ---- rank inside the wave, items in index order.  Items past the end carry the all-ones digit and
+  // sit behind every valid item of that digit (they are the last items of the last tile)
+  unsigned short lrank[ITEMS];
+  unsigned char dig[ITEMS];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
-    __syncthreads();
-    // phase 1: digit counts of this wave's 256 items
-    unsigned long long peers[4];
-    int rank[4];
+  for (int i = 0; i < ITEMS; ++i) {
+    const unsigned d = ((unsigned)(key[i] >> shift)) & dmask;
+    unsigned long long m = ~0ull;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool valid = i0 + 256 * wave + 64 * t + lane < end;
-      const unsigned digit = (key[t] >> shift) & 255u;
-      unsigned long long m = __ballot(valid);
-#pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const bool set = (digit >> bit) & 1u;
+    for (int b = 0; b < 8; ++b) {
+      if (b < bits) {
+        const bool set = (d >> b) & 1u;
         const unsigned long long bb = __ballot(set);
         m &= set ? bb : ~bb;
       }
-      peers[t] = valid ? m : 0ull;
-      rank[t] = __popcll(m & ((1ull << lane) - 1ull));
-      if (valid && rank[t] == 0) wh[wave][digit] += __popcll(m);       // one lane per digit and step; steps in order
     }
-    __syncthreads();
-    // phase 2: wave w's places of digit `tid` start behind the earlier waves'; the range's running
-    // start moves past the round
-    {
-      int run = off[tid];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int c = wh[w][tid];
-        wh[w][tid] = run;
-        run += c;
-      }
-      off[tid] = run;
+    const int r = __popcll(m & ((1ull << lane) - 1ull));
+    unsigned before = 0;
+    if (r == 0) {                       // one lane per digit and step; the wave's steps run in order
+      before = whist[wave][d];
+      whist[wave][d] = before + (unsigned)__popcll(m);
     }
-    __syncthreads();
-    // phase 3: the wave's steps in order; the leader lane of a digit takes its places and moves
-    // the wave's running place past them
+    before = __shfl(before, __builtin_ctzll(m), 64);
+    lrank[i] = (unsigned short)(before + r);
+    dig[i] = (unsigned char)d;
+  }
+  __syncthreads();
+  // ---- per digit: prefix over the waves, tile count, tile start, global start
+  unsigned cnt = 0;
+  if (tid < RADIX) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const unsigned digit = (key[t] >> shift) & 255u;
-      const bool valid = peers[t] != 0ull;
-      int base = 0;
-      if (valid && rank[t] == 0) {
-        base = wh[wave][digit];
-        wh[wave][digit] = base + __popcll(peers[t]);
-      }
-      base = __shfl(base, valid ? __builtin_ctzll(peers[t]) : 0, 64);
-      if (valid) {
-        const int64_t pos = (int64_t)base + rank[t];
-        kout[pos] = key[t];
-        vout[pos] = val[t];
-        if (next_table != nullptr)
-          atomicAdd(&next_table[(pos / per) * 256 + ((key[t] >> (shift + 8)) & 255u)], 1);
-      }
+    for (int w = 0; w < WAVES; ++w) {
+      const unsigned c = whist[w][tid];
+      whist[w][tid] = cnt;
+      cnt += c;
     }
-    __syncthreads();                    // wh is zeroed again at the top
+  }
+  unsigned valid_cnt = cnt;
+  if (tid == (int)dmask && nvalid < TILE) valid_cnt -= (unsigned)(TILE - nvalid);      // the padding is not data
+  const unsigned ts = scan256_exclusive(tid < RADIX ? cnt : 0u, wsum, tid);
+  unsigned total = 0;
+  if (tid < RADIX) {
+    for (int b0 = 0; b0 < hist_blocks; b0 += 16) {
+      unsigned c[16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { key[t] = nkey[t]; val[t] = nval[t]; }
+      for (int u = 0; u < 16; ++u)
+        c[u] = (b0 + u < hist_blocks) ? part[(int64_t)(b0 + u) * MAX_PASSES * RADIX + tid] : 0u;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) total += c[u];
+    }
+  }
+  const unsigned gbase = scan256_exclusive(tid < RADIX ? total : 0u, wsum, tid);
+  if (tid < RADIX) {
+    unsigned* st = status + tile * RADIX + tid;
+    st_status(st, (tile == 0 ? FLAG_INC : FLAG_AGG) | valid_cnt);
+    unsigned excl = 0;
+    int64_t t = tile - 1;
+    bool done = tile == 0;
+    while (!done) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (t - u >= 0) ? ld_status(status + (t - u) * RADIX + tid) : FLAG_INC;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (done) break;
+        while ((v[u] & FLAG_MASK) == 0u) v[u] = ld_status(status + (t - u) * RADIX + tid);
+        excl += v[u] & COUNT_MASK;
+        done = (v[u] & FLAG_INC) != 0u;
+      }
+      t -= 8;
+    }
+    if (tile != 0) st_status(st, FLAG_INC | (excl + valid_cnt));
+    tstart[tid] = ts;
+    goff[tid] = gbase + excl - ts;
+  }
+  __syncthreads();
+  // ---- tile-sorted order in LDS, then runs to their global places
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const unsigned d = dig[i];
+    const unsigned pos = tstart[d] + whist[wave][d] + lrank[i];
+    skey[pos] = key[i];
+    if (HAS_VAL) sval[pos] = val[i];
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int j = tid; j < nvalid; j += THREADS) {
+    const K k = skey[j];
+    const unsigned d = ((unsigned)(k >> shift)) & dmask;
+    const unsigned pos = (unsigned)j + goff[d];
+    kout[pos] = k;
+    if (HAS_VAL) vout[pos] = sval[j];
   }
 }
 
-}  // namespace
-
-namespace lidal {
-
-// scratch: ping-pong buffers for keys and values + the digit tables
-int64_t sort_pairs_ws_bytes(int64_t n) {
-  const int64_t q = n > 0 ? n : 1;
-  return 2 * align_up(4 * q, 256) + align_up((int64_t)4 * MAX_RANGES * 256 * 4, 256);
-}
-
-// keys_in / vals_in are not written; keys_out / vals_out receive the sorted pairs (`bits` low key bits
-// significant, the higher ones must be zero).  keys_out is also the ping-pong partner of the
-// scratch buffer, so it cannot be omitted.
-int sort_pairs_u32(const unsigned* keys_in, const int* vals_in, unsigned* keys_out, int* vals_out,
-                   int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s) {
-  if (n == 0) return 0;
-  LIDAL_REQUIRE(bits >= 1 && bits <= 32 && n < (1ll << 31), "sort: %d bits, %lld items", bits, (long long)n);
-  LIDAL_REQUIRE(ws_bytes >= sort_pairs_ws_bytes(n), "sort workspace too small");
-  const Plan p = plan_for(n, bits);
-  const int64_t a = align_up(4 * n, 256);
-  unsigned* ktmp = (unsigned*)ws;
-  int* vtmp = (int*)((char*)ws + a);
-  int* tables = (int*)((char*)ws + 2 * a);
-  sort_hist0_kernel<<<p.nb, SB, 0, s>>>(keys_in, n, p.per, p.passes, tables);
-  LIDAL_CHECK_LAUNCH("sort_hist0");
-  const unsigned* kin = keys_in;
+template <typename K, bool HAS_VAL>
+int run_sort(const K* keys_in, const int* vals_in, K* keys_out, int* vals_out, int64_t n, int end_bit,
+             void* ws, const Layout& L, hipStream_t s) {
+  char* w = (char*)ws;
+  unsigned* part = (unsigned*)(w + L.off_part);
+  unsigned* ticket = (unsigned*)(w + L.off_ticket);
+  unsigned* status = (unsigned*)(w + L.off_status);
+  K* ktmp = (K*)(w + L.off_ktmp);
+  int* vtmp = HAS_VAL ? (int*)(w + L.off_vtmp) : nullptr;
+  const int64_t zero_words = (L.off_ktmp - L.off_ticket) / 4;         // tickets + status of every pass
+  sort_hist_kernel<K><<<L.hist_blocks, THREADS, 0, s>>>(keys_in, n, L.passes, end_bit, part, ticket, zero_words);
+  LIDAL_CHECK_LAUNCH("sort_hist");
+  const size_t lds = (size_t)TILE * (sizeof(K) + (HAS_VAL ? 4 : 0));
+  auto kern = sort_onesweep_kernel<K, HAS_VAL>;
+  static size_t attr_set[MAX_DEVICES] = {};
+  const int dev = current_device();
+  if (attr_set[dev] < lds) {
+    LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[dev] = lds;
+  }
+  const K* kin = keys_in;
   const int* vin = vals_in;
-  for (int pass = 0; pass < p.passes; ++pass) {
-    // the last pass must land in the caller's buffers: alternate backwards from there
-    const bool to_out = ((p.passes - 1 - pass) & 1) == 0;
-    unsigned* ko = to_out ? keys_out : ktmp;
+  for (int p = 0; p < L.passes; ++p) {
+    const bool to_out = ((L.passes - 1 - p) & 1) == 0;       // the last pass lands in the caller's buffers
+    K* ko = to_out ? keys_out : ktmp;
     int* vo = to_out ? vals_out : vtmp;
-    sort_pass_kernel<<<p.nb, SB, 0, s>>>(kin, vin, ko, vo, n, p.per, 8 * pass,
-                                         tables + (int64_t)pass * p.nb * 256,
-                                         pass + 1 < p.passes ? tables + (int64_t)(pass + 1) * p.nb * 256 : nullptr);
-    LIDAL_CHECK_LAUNCH("sort_pass");
+    int bits = end_bit - 8 * p;
+    if (bits > 8) bits = 8;
+    if (bits < 1) bits = 1;
+    kern<<<(unsigned)L.tiles, THREADS, lds, s>>>(kin, vin, ko, vo, n, 8 * p, bits, part + (int64_t)p * RADIX,
+                                                 L.hist_blocks, ticket + p, status + (int64_t)p * L.tiles * RADIX);
+    LIDAL_CHECK_LAUNCH("sort_onesweep");
     kin = ko;
     vin = vo;
   }
   return 0;
 }
 
+}  // namespace
+
+namespace lidal {
+
+int64_t radix_sort_ws_bytes(int64_t n, int key_bytes, bool has_val) {
+  return layout_for(n, key_bytes, has_val, 8 * key_bytes).total;
+}
+
+// keys_in / vals_in are not written; keys_out (and vals_out if vals_in != NULL) receive the pairs sorted
+// by key bits [0, end_bit) -- the higher bits are ignored by the order but travel with the key.
+int radix_sort(const void* keys_in, const int* vals_in, void* keys_out, int* vals_out, int64_t n,
+               int key_bytes, int end_bit, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (n == 0) return 0;
+  LIDAL_REQUIRE(key_bytes == 4 || key_bytes == 8, "sort: keys of %d bytes", key_bytes);
+  LIDAL_REQUIRE(end_bit >= 1 && end_bit <= 8 * key_bytes && n < (1ll << 30), "sort: %d bits, %lld items", end_bit,
+                (long long)n);
+  const bool has_val = vals_in != nullptr;
+  const Layout L = layout_for(n, key_bytes, has_val, end_bit);
+  LIDAL_REQUIRE(ws_bytes >= L.total, "sort workspace too small: %lld < %lld", (long long)ws_bytes, (long long)L.total);
+  if (key_bytes == 4)
+    return has_val ? run_sort<unsigned, true>((const unsigned*)keys_in, vals_in, (unsigned*)keys_out, vals_out, n,
+                                              end_bit, ws, L, s)
+                   : run_sort<unsigned, false>((const unsigned*)keys_in, nullptr, (unsigned*)keys_out, nullptr, n,
+                                               end_bit, ws, L, s);
+  return has_val ? run_sort<unsigned long long, true>((const unsigned long long*)keys_in, vals_in,
+                                                      (unsigned long long*)keys_out, vals_out, n, end_bit, ws, L, s)
+                 : run_sort<unsigned long long, false>((const unsigned long long*)keys_in, nullptr,
+                                                       (unsigned long long*)keys_out, nullptr, n, end_bit, ws, L, s);
+}
+
+int64_t sort_pairs_ws_bytes(int64_t n) { return radix_sort_ws_bytes(n, 4, true); }
+
+int sort_pairs_u32(const unsigned* keys_in, const int* vals_in, unsigned* keys_out, int* vals_out,
+                   int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s) {
+  return radix_sort(keys_in, vals_in, keys_out, vals_out, n, 4, bits, ws, ws_bytes, s);
+}
+
 }  // namespace lidal
 
-// test / bench entry: sorts device pairs, stable, by the low `bits` bits of the keys
-extern "C" int64_t lidal_sort_pairs_workspace_bytes(int64_t n) { return sort_pairs_ws_bytes(n); }
+// test / bench entries: stable sort of device (key, value) pairs by the low `bits` bits of the keys
+extern "C" int64_t lidal_sort_pairs_workspace_bytes(int64_t n) { return radix_sort_ws_bytes(n, 8, true); }
 extern "C" int lidal_sort_pairs(const uint32_t* keys_in, const int32_t* vals_in, uint32_t* keys_out,
                                 int32_t* vals_out, int64_t n, int bits, void* ws, int64_t ws_bytes,
                                 void* stream) {
-  return sort_pairs_u32(keys_in, vals_in, keys_out, vals_out, n, bits, ws, ws_bytes, (hipStream_t)stream);
+  return radix_sort(keys_in, vals_in, keys_out, vals_out, n, 4, bits, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int lidal_sort_pairs_u64(const uint64_t* keys_in, const int32_t* vals_in, uint64_t* keys_out,
+                                    int32_t* vals_out, int64_t n, int bits, void* ws, int64_t ws_bytes,
+                                    void* stream) {
+  return radix_sort(keys_in, vals_in, keys_out, vals_out, n, 8, bits, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -5,7 +5,6 @@
 // a 16-byte load/store and a row is covered by C/4 consecutive lanes.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -409,23 +408,6 @@ static inline int segment_parts(int64_t n_entries, int64_t m, int c) {
   return parts;
 }
 
-// rocprim merge-sorts up to 1M items whatever the key width; voxel indices of the coarse levels
-// need 15-17 bits, i.e. two Onesweep passes (scripts/sort_bench.hip: 400k pairs, 17 bits: 95 us
-// against 117 us), so lists of >= 64k entries with <= 16-bit keys take the radix path.
-using NarrowKeySort = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                 rocprim::default_config, 65536>;
-size_t inv_sort_tmp_bytes(int64_t n) {
-  size_t tmp = 0, tmp2 = 0;
-  (void)rocprim::radix_sort_pairs((void*)nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr,
-                                  (const int*)nullptr, (int*)nullptr, (size_t)(n > 0 ? n : 1), 0,
-                                  32, (hipStream_t)0);
-  (void)rocprim::radix_sort_pairs<NarrowKeySort>((void*)nullptr, tmp2, (const unsigned*)nullptr,
-                                                 (unsigned*)nullptr, (const int*)nullptr,
-                                                 (int*)nullptr, (size_t)(n > 0 ? n : 1), 0, 16,
-                                                 (hipStream_t)0);
-  return tmp > tmp2 ? tmp : tmp2;
-}
-
 template <typename T, bool DEVOX>
 int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, const float* w,
                        const int* counts, T* out, int64_t m, int c, int64_t n_entries, void* ws,
@@ -558,10 +540,7 @@ extern "C" int lidal_ti_weights(const float* coords, int cstride, const int64_t*
   return 0;
 }
 
-static int64_t inv_tmp_bytes(int64_t q) {
-  const int64_t a = (int64_t)inv_sort_tmp_bytes(q), b = sort_pairs_ws_bytes(q);
-  return a > b ? a : b;
-}
+static int64_t inv_tmp_bytes(int64_t q) { return sort_pairs_ws_bytes(q); }
 
 extern "C" int64_t lidal_invlist_workspace_bytes(int64_t n_entries) {
   int64_t q = n_entries > 0 ? n_entries : 1;
@@ -583,16 +562,11 @@ extern "C" int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n
   unsigned* skeys = (unsigned*)((char*)ws + align_up(4 * q, 256));
   int* vals = (int*)((char*)ws + 2 * align_up(4 * q, 256));
   void* tmp = (char*)ws + 3 * align_up(4 * q, 256);
-  size_t tmp_bytes = inv_sort_tmp_bytes(q);
   inv_keys_kernel<<<(unsigned)cdiv(q, 256), 256, 0, s>>>(idx, w, q, m, keys, vals);
   LIDAL_CHECK_LAUNCH("inv_keys");
   int bits = 1;
   while ((1ll << bits) <= m) ++bits;
-  if (bits <= 16)
-    LIDAL_HIP(rocprim::radix_sort_pairs<NarrowKeySort>(tmp, tmp_bytes, keys, skeys, vals, order,
-                                                       (size_t)q, 0, bits, s));
-  else
-    LIDAL_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, order, (size_t)q, 0, bits, s));
+  if (int rc = sort_pairs_u32(keys, vals, skeys, order, q, bits, tmp, inv_tmp_bytes(q), s)) return rc;
   inv_segptr_kernel<<<(unsigned)cdiv(m + 1, 256), 256, 0, s>>>(skeys, q, m, seg_ptr);
   LIDAL_CHECK_LAUNCH("inv_segptr");
   return 0;

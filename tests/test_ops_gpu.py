@@ -970,3 +970,36 @@ def test_trilinear_devoxelize_reproduces_a_linear_field(stride):
     w = F.calc_ti_weights(pts, idx, scale=stride).transpose(0, 1).contiguous()
     got = F.spdevoxelize(field, idx.transpose(0, 1).contiguous().int(), w)
     assert torch.allclose(got.cpu(), want, rtol=1e-5, atol=1e-4 * stride), (got.cpu() - want).abs().max()
+
+
+@pytest.mark.parametrize('n,bits,with_vals', [(1, 64, True), (8191, 60, False), (8192, 63, True), (8193, 39, True),
+                                              (396662, 60, False), (396662, 63, True), (120000, 63, True),
+                                              (1500000, 48, False)])
+def test_radix_sort_u64_is_the_stable_sort(n, bits, with_vals):
+    """The 64-bit form of csrc/sort.hip (sorted unique of coordinate hashes / packed coordinates, the
+    voxeliser's row keys, the scorer's cell keys): bit-equal to torch.sort(stable=True), keys only or
+    with a payload; tiles that end exactly at, one short of and one past a tile boundary."""
+    from lidal_amd import backend as B
+    g = torch.Generator().manual_seed(n + bits)
+    keys = torch.randint(0, 2 ** 62, (n,), generator=g, dtype=torch.int64)
+    if bits < 62:
+        keys = keys >> (62 - bits)
+    elif bits > 62:
+        keys = keys | (torch.randint(0, 2, (n,), generator=g, dtype=torch.int64) << 62)
+    if n > 1000:
+        keys[n // 3: n // 3 + n // 5] = keys[0]           # a long run of equal keys spanning tiles
+        keys[-1], keys[1] = (1 << min(bits, 63)) - 1, 0
+    vals = torch.randperm(n, generator=g).int().to(DEV)
+    k_dev = keys.to(DEV)
+    k_in = k_dev.clone()
+    ko, vo = torch.empty_like(k_dev), torch.empty_like(vals)
+    nbytes = B.lib().lidal_sort_pairs_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    B.check(B.lib().lidal_sort_pairs_u64(B.ptr(k_dev), B.ptr(vals) if with_vals else None, B.ptr(ko),
+                                         B.ptr(vo) if with_vals else None, n, bits, B.ptr(ws), nbytes, B.stream()),
+            'sort_pairs_u64')
+    sk, order = torch.sort(k_dev, stable=True)
+    assert torch.equal(ko, sk)
+    if with_vals:
+        assert torch.equal(vo, vals[order])
+    assert torch.equal(k_dev, k_in)

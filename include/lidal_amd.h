@@ -124,6 +124,12 @@ int lidal_sort_pairs(const uint32_t* keys_in, const int32_t* vals_in, uint32_t* 
 int lidal_sort_pairs_u64(const uint64_t* keys_in, const int32_t* vals_in, uint64_t* keys_out, int32_t* vals_out,
                          int64_t n, int bits, void* ws, int64_t ws_bytes, void* stream);
 int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows);
+/* The same for n_jobs (<= 16) tables of ONE kernel volume k in one go (host arrays of device pointers /
+ * row counts; ws >= lidal_kmap_order_workspace_bytes(sum of the row counts)): one key array, one sort.
+ * Results are identical to n_jobs calls of lidal_kmap_order. */
+int lidal_kmap_order_batch(const int32_t* const* nbr, const int64_t* n_rows, int n_jobs, int k,
+                           int32_t* const* perm, int32_t* const* nbr_perm, uint32_t* const* tile_masks,
+                           void* ws, int64_t ws_bytes, void* stream);
 int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32_t* perm, int32_t* nbr_perm,
                      uint32_t* tile_masks, void* ws, int64_t ws_bytes, void* stream);
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     'lidal_sort_pairs_u64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     'lidal_kmap_order_workspace_bytes': (_i64, [_i64]),
     'lidal_kmap_order': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'lidal_kmap_order_batch': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
                                 _vp, _i32, _vp, _vp]),
     'lidal_conv_weight_image_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),

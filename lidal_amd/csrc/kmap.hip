@@ -685,7 +685,7 @@ static int64_t order_sort_tmp_bytes(int64_t q) { return sort_pairs_ws_bytes(q); 
 
 extern "C" int64_t lidal_kmap_order_workspace_bytes(int64_t n_rows) {
   int64_t q = n_rows > 0 ? n_rows : 1;
-  return 3 * align_up(4 * q, 256) + align_up(order_sort_tmp_bytes(q), 256) + 256;
+  return 4 * align_up(4 * q, 256) + align_up(order_sort_tmp_bytes(q), 256) + 256;
 }
 
 extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32_t* perm,
@@ -712,6 +712,126 @@ extern "C" int lidal_kmap_order(const int32_t* nbr, int64_t n_rows, int k, int32
     tile_or_kernel<<<(unsigned)cdiv(tiles, 4), 256, 0, s>>>(skeys, q, rank, tile_masks, tiles);
     LIDAL_CHECK_LAUNCH("tile_or");
   }
+  return 0;
+}
+
+// ---- the row orders of SEVERAL tables of one kernel volume in one go ---------------------------
+// A U-Net builds 5 3x3x3 maps and 4 2x2x2 maps (the latter ordered in both directions): 13 row orders
+// per step, each a chain of row_mask -> sort (hist + ceil(k/8) passes) -> permute -> tile_or on a few
+// 10^4 .. 10^5 rows, i.e. launch latency.  Here the rows of all tables of a volume are ONE key array,
+// key = table index << k | Gray-ranked mask, sorted once; every kernel takes the table descriptors by
+// value (no device-side descriptor buffer, nothing to upload).
+namespace {
+constexpr int MAX_ORDER_JOBS = 16;
+struct OrderBatch {
+  const int* nbr[MAX_ORDER_JOBS];
+  int* perm[MAX_ORDER_JOBS];
+  int* nbr_perm[MAX_ORDER_JOBS];
+  unsigned* tmask[MAX_ORDER_JOBS];
+  long long row0[MAX_ORDER_JOBS + 1];       // first row of table j in the concatenated arrays
+  long long tile0[MAX_ORDER_JOBS + 1];      // first 128-row tile of table j
+  int n_jobs, k;
+};
+__device__ __forceinline__ int job_of(const long long* first, int n_jobs, long long i) {
+  int j = 0;
+#pragma unroll 1
+  for (int t = 1; t < n_jobs; ++t) j += (i >= first[t]) ? 1 : 0;
+  return j;
+}
+
+__global__ void __launch_bounds__(256) row_mask_batch_kernel(OrderBatch b, BitRank rank,
+                                                             unsigned* __restrict__ keys,
+                                                             int* __restrict__ vals) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.row0[b.n_jobs]) return;
+  const int j = job_of(b.row0, b.n_jobs, i);
+  const long long r = i - b.row0[j], n = b.row0[j + 1] - b.row0[j];
+  const int* nbr = b.nbr[j];
+  unsigned m = 0u;
+  for (int k = 0; k < b.k; ++k)
+    if (nbr[(long long)k * n + r] >= 0) m |= 1u << rank.to_key[k];
+  m ^= m >> 1; m ^= m >> 2; m ^= m >> 4; m ^= m >> 8; m ^= m >> 16;
+  keys[i] = m | ((unsigned)j << b.k);
+  vals[i] = (int)r;
+}
+
+__global__ void __launch_bounds__(256) permute_table_batch_kernel(OrderBatch b, const int* __restrict__ svals) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= b.row0[b.n_jobs]) return;
+  const int j = job_of(b.row0, b.n_jobs, i);           // sorted by table first: table j's rows sit at [row0, row0 + n)
+  const long long r = i - b.row0[j], n = b.row0[j + 1] - b.row0[j];
+  const int src = svals[i];
+  if (k == 0) b.perm[j][r] = src;
+  b.nbr_perm[j][(long long)k * n + r] = b.nbr[j][(long long)k * n + src];
+}
+
+__global__ void __launch_bounds__(256) tile_or_batch_kernel(OrderBatch b, BitRank rank,
+                                                            const unsigned* __restrict__ skeys) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= b.tile0[b.n_jobs]) return;
+  const int j = job_of(b.tile0, b.n_jobs, t);
+  if (b.tmask[j] == nullptr) return;
+  const long long lt = t - b.tile0[j], n = b.row0[j + 1] - b.row0[j];
+  const unsigned kmask = (b.k >= 32) ? ~0u : ((1u << b.k) - 1u);
+  unsigned m = 0u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const long long r = lt * 128 + h * 64 + lane;
+    if (r < n) { const unsigned g = skeys[b.row0[j] + r] & kmask; m |= g ^ (g >> 1); }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, 64);
+  if (lane == 0) {
+    unsigned real = 0u;
+    for (int bit = 0; bit < 32; ++bit)
+      if ((m >> bit) & 1u) real |= 1u << rank.to_mask[bit];
+    b.tmask[j][lt] = real;
+  }
+}
+}  // namespace
+
+extern "C" int lidal_kmap_order_batch(const int32_t* const* nbr, const int64_t* n_rows, int n_jobs, int k,
+                                      int32_t* const* perm, int32_t* const* nbr_perm,
+                                      uint32_t* const* tile_masks, void* ws, int64_t ws_bytes,
+                                      void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(n_jobs >= 0 && n_jobs <= MAX_ORDER_JOBS, "kmap_order_batch: at most %d tables", MAX_ORDER_JOBS);
+  int jbits = 0;
+  while ((1 << jbits) < n_jobs) ++jbits;
+  LIDAL_REQUIRE(k > 0 && k + jbits <= 32, "kmap_order_batch: kernel volume %d with %d tables does not fit a 32-bit key",
+                k, n_jobs);
+  OrderBatch b;
+  memset(&b, 0, sizeof(b));
+  b.n_jobs = n_jobs; b.k = k;
+  long long rows = 0, tiles = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    LIDAL_REQUIRE(n_rows[j] >= 0, "kmap_order_batch: bad row count");
+    b.nbr[j] = nbr[j]; b.perm[j] = perm[j]; b.nbr_perm[j] = nbr_perm[j];
+    b.tmask[j] = tile_masks ? tile_masks[j] : nullptr;
+    b.row0[j] = rows; b.tile0[j] = tiles;
+    rows += n_rows[j]; tiles += cdiv(n_rows[j], 128);
+  }
+  for (int j = n_jobs; j <= MAX_ORDER_JOBS; ++j) { b.row0[j] = rows; b.tile0[j] = tiles; }
+  if (rows == 0) return 0;
+  LIDAL_REQUIRE(ws_bytes >= lidal_kmap_order_workspace_bytes(rows), "kmap_order_batch ws too small");
+  const int64_t a = align_up(4 * rows, 256);
+  unsigned* keys = (unsigned*)ws;
+  unsigned* skeys = (unsigned*)((char*)ws + a);
+  int* vals = (int*)((char*)ws + 2 * a);
+  // the sorted row ids land in the first table's perm-sized scratch? no: perm arrays are per table, so
+  // the sorted ids go to a scratch slice and permute_table_batch distributes them
+  int* svals = (int*)((char*)ws + 3 * a);
+  void* tmp = (char*)ws + 4 * a;
+  const BitRank rank = bit_rank(k);
+  row_mask_batch_kernel<<<(unsigned)cdiv(rows, 256), 256, 0, s>>>(b, rank, keys, vals);
+  LIDAL_CHECK_LAUNCH("row_mask_batch");
+  if (int rc = sort_pairs_u32(keys, vals, skeys, svals, rows, k + jbits, tmp, order_sort_tmp_bytes(rows), s)) return rc;
+  permute_table_batch_kernel<<<dim3((unsigned)cdiv(rows, 256), (unsigned)k), 256, 0, s>>>(b, svals);
+  LIDAL_CHECK_LAUNCH("permute_table_batch");
+  tile_or_batch_kernel<<<(unsigned)cdiv(tiles, 4), 256, 0, s>>>(b, rank, skeys);
+  LIDAL_CHECK_LAUNCH("tile_or_batch");
   return 0;
 }
 

@@ -32,18 +32,51 @@ class RowOrder:
     """A neighbour table re-ordered by occupancy pattern (lidal_kmap_order): `perm` maps sorted
     position -> row, `table` = nbr[:, perm].  Built once per table, shared by every conv using it."""
 
-    def __init__(self, nbr):
+    def __init__(self, nbr, build=True):
         k, n = nbr.shape
         dev = nbr.device
         self.n_rows = n
         self.perm = torch.empty(max(n, 1), dtype=torch.int, device=dev)
         self.table = torch.empty((k, n), dtype=torch.int, device=dev)
         self.tile_masks = torch.empty(max(1, -(-n // 128)), dtype=torch.int32, device=dev)
-        ws_bytes = B.lib().lidal_kmap_order_workspace_bytes(n)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        B.check(B.lib().lidal_kmap_order(B.ptr(nbr), n, k, B.ptr(self.perm), B.ptr(self.table),
-                                         B.ptr(self.tile_masks), B.ptr(ws), ws_bytes, B.stream()),
-                'kmap_order')
+        if build:
+            ws_bytes = B.lib().lidal_kmap_order_workspace_bytes(n)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            B.check(B.lib().lidal_kmap_order(B.ptr(nbr), n, k, B.ptr(self.perm), B.ptr(self.table),
+                                             B.ptr(self.tile_masks), B.ptr(ws), ws_bytes, B.stream()),
+                    'kmap_order')
+
+    @staticmethod
+    def build_many(tables):
+        """RowOrders of several neighbour tables: the tables of one kernel volume go through ONE key
+        array and one sort (lidal_kmap_order_batch, <= 16 tables per call) -- a U-Net's 13 row orders
+        per step are two calls instead of 13 chains of small launches.  Same results as RowOrder(t)."""
+        import ctypes
+        out = [None] * len(tables)
+        by_k = {}
+        for i, t in enumerate(tables):
+            by_k.setdefault((t.shape[0], str(t.device)), []).append(i)
+        for (k, _), ids in by_k.items():
+            for c0 in range(0, len(ids), 16):
+                chunk = ids[c0:c0 + 16]
+                if len(chunk) == 1:
+                    out[chunk[0]] = RowOrder(tables[chunk[0]])
+                    continue
+                orders = [RowOrder(tables[i], build=False) for i in chunk]
+                n = len(chunk)
+                total = sum(o.n_rows for o in orders)
+                dev = tables[chunk[0]].device
+                ws_bytes = B.lib().lidal_kmap_order_workspace_bytes(total)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                vp, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+                B.check(B.lib().lidal_kmap_order_batch(
+                    vp(*[tables[i].data_ptr() for i in chunk]), i64(*[o.n_rows for o in orders]), n, k,
+                    vp(*[o.perm.data_ptr() for o in orders]), vp(*[o.table.data_ptr() for o in orders]),
+                    vp(*[o.tile_masks.data_ptr() for o in orders]), B.ptr(ws), ws_bytes, B.stream()),
+                    'kmap_order')
+                for i, o in zip(chunk, orders):
+                    out[i] = o
+        return out
 
 
 class KernelMap:
@@ -174,6 +207,7 @@ def prefetch_kernel_maps(x, plan, transposed=True):
     prepares the transposed tables the decoder uses."""
     coords, cur = x.coords, tuple(x.stride)
     x.cmaps.setdefault(cur, coords)
+    want = []                   # (kmap, 'out' | 'in') whose row order is still to be built
     for kernel_size, stride in plan:
         kernel_size = make_ntuple(kernel_size, ndim=3)
         stride = make_ntuple(stride, ndim=3)
@@ -187,11 +221,19 @@ def prefetch_kernel_maps(x, plan, transposed=True):
             x.kmaps[key] = kmap
             if any(s > 1 for s in stride):
                 x.cmaps.setdefault(out_stride, out_coords)
-        kmap.order_out
+        if kmap._order_out is None:
+            want.append((kmap, 'out'))
         if any(s > 1 for s in stride):
-            if transposed:
-                kmap.order_in
+            if transposed and kmap._order_in is None:
+                want.append((kmap, 'in'))
             coords, cur = x.cmaps[out_stride], out_stride
+    if want:                    # all row orders of the network: one sort per kernel volume
+        orders = RowOrder.build_many([km.nbr_out if side == 'out' else km.nbr_in for km, side in want])
+        for (km, side), o in zip(want, orders):
+            if side == 'out':
+                km._order_out = o
+            else:
+                km._order_in = o
     return x
 
 

@@ -19,4 +19,4 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_
 cd $GRAFT_REPO_ROOT
 find $O/prof -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/step_kernel_stats.csv
 rm -rf $O/prof
-python3 scripts/gpu/stats_table.py $O/step_kernel_stats.csv 7 | head -60
+python3 scripts/gpu/stats_table.py $O/step_kernel_stats.csv 10 | head -70

@@ -34,7 +34,7 @@ def main64():
     dev = 'cuda'
     print('%10s %5s %5s %12s %14s' % ('items', 'bits', 'vals', 'sort.hip us', 'torch.sort us'))
     for n, bits, with_vals in ((396662, 60, False), (180000, 48, False), (75000, 48, False), (28000, 48, False),
-                               (120000, 63, True), (120000, 39, True)):
+                               (120000, 62, True), (120000, 39, True)):
         keys = torch.randint(0, 1 << bits, (n,), device=dev, dtype=torch.int64)
         vals = torch.arange(n, device=dev, dtype=torch.int32)
         ko, vo = torch.empty_like(keys), torch.empty_like(vals)

@@ -99,9 +99,11 @@ def test_train_step_at_bench_size_matches_oracle(name, one_scan):
     print(name, 'f32 |g| deviation: cpu f32 oracle, worst of 3 summation orders', {k: '%.1e' % v for k, v in dev_f32.items()})
     bar = max(3e-4, 2 * max(dev_f32.values()))
     assert max(dev_gpu.values()) <= bar, (dev_gpu, dev_f32)
-    for k in g64:                               # directions, whole tensors
-        cos = (grads[k] * g64[k]).sum() / (grads[k].norm() * g64[k].norm())
-        assert cos > 1 - 1e-5, (k, cos.item())
+    def miss(a, ref):                           # 1 - cosine, whole tensors
+        return 1.0 - ((a * ref).sum() / (a.norm() * ref.norm())).item()
+    miss_f32 = max(miss(g32[k], g64[k]) for g32 in f32_runs for k in g64)
+    for k in g64:                               # directions: same calibration
+        assert miss(grads[k], g64[k]) <= max(1e-6, 4 * miss_f32), (k, miss(grads[k], g64[k]), miss_f32)
 
     # ---- bf16 autocast: the bench dtype.  With 83 k rows behind every BatchNorm statistic what is left
     # is bf16 rounding (2^-9 per stored activation / gradient element) AMPLIFIED by the conditioning of

@@ -94,18 +94,18 @@ __global__ void __launch_bounds__(THREADS) sort_hist_kernel(const K* __restrict_
       const K kk = k[u] & top_mask;
       const unsigned long long live = __ballot(ok[u]);
       for (int p = 0; p < passes; ++p) {
-        // Real keys are skewed (occupancy masks: a third of the rows share one value; packed coordinates:
-        // the high bytes are constant; contributor lists: consecutive points fall into one voxel), and 64
-        // lanes adding to ONE LDS counter serialise (measured: 35-45 us for this kernel on a step's lists,
-        // 4 us on uniform keys).  So the wave first peels off up to four digit values shared by many of
-        // its lanes -- one lane adds the whole count -- and only the lanes left over add one by one.
+        // Real keys are skewed -- packed coordinates and occupancy masks have constant high bytes,
+        // consecutive points of a contributor list fall into one voxel -- and 64 lanes adding to ONE LDS
+        // counter serialise (measured: 35-45 us for this kernel on a step's lists against 4 us on uniform
+        // keys).  So the lanes that share the first lane's digit are counted by that lane alone; only
+        // the others add one by one.  (Peeling up to four values in a loop cost more scalar work than it
+        // saved: +37 us on 397k uniform keys.)
         const unsigned d = (unsigned)(kk >> (8 * p)) & 255u;
         unsigned long long rem = live;
-#pragma unroll 1
-        for (int it = 0; it < 4 && rem != 0ull; ++it) {
-          const int leader = __builtin_ctzll(rem);
+        if (live != 0ull) {
+          const int leader = __builtin_ctzll(live);
           const unsigned f = (unsigned)__builtin_amdgcn_readlane((int)d, leader);
-          const unsigned long long same = __ballot(d == f) & rem;
+          const unsigned long long same = __ballot(d == f) & live;
           if ((tid & 63) == leader) atomicAdd(&h[p][f], (unsigned)__popcll(same));
           rem &= ~same;
         }

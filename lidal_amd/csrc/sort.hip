@@ -2,9 +2,10 @@
 // unique of coordinate hashes and packed coordinates, point->voxel contributor lists, the scorer's
 // cell keys).  Keys u32 or u64, optional i32 payload, 8 bits per pass, 1 + ceil(bits / 8) launches:
 //
-//   hist     every digit position's histogram in ONE pass over the keys: <= 64 workgroups, each with
+//   hist     every digit position's histogram in ONE pass over the keys: <= 256 workgroups, each with
 //            private LDS tables written out as part[block][pass][256] (no global atomics, nothing to
-//            zero beforehand); the same launch zeroes the look-back state of all passes.
+//            zero beforehand; more than 32 tables are added up by one more small launch); the same
+//            launch zeroes the look-back state of all passes.
 //   pass p   "one sweep": a tile of 8192 consecutive items per workgroup (512 threads x 16), taken in
 //            order through an atomic ticket.  The tile's items are ranked in index order -- per wave a
 //            multisplit by 8 ballots per item, the waves' counts prefixed through LDS -- which gives
@@ -30,14 +31,15 @@ constexpr int WAVES = THREADS / 64;
 constexpr int ITEMS = 16;
 constexpr int TILE = THREADS * ITEMS;            // 8192 items per workgroup
 constexpr int MAX_PASSES = 8;
-constexpr int HIST_BLOCKS = 64;
+constexpr int HIST_BLOCKS = 256;         // partial tables of the histogram launch, at most
+constexpr int HIST_DIRECT = 32;          // up to this many, the passes add the partial tables up themselves
 
 constexpr unsigned FLAG_AGG = 1u << 30, FLAG_INC = 2u << 30, FLAG_MASK = 3u << 30, COUNT_MASK = (1u << 30) - 1u;
 
 struct Layout {
   int passes, hist_blocks;
   int64_t tiles;
-  int64_t off_part, off_ticket, off_status, off_ktmp, off_vtmp, total;
+  int64_t off_part, off_total, off_ticket, off_status, off_ktmp, off_vtmp, total;
 };
 
 Layout layout_for(int64_t n, int key_bytes, bool has_val, int end_bit) {
@@ -50,6 +52,7 @@ Layout layout_for(int64_t n, int key_bytes, bool has_val, int end_bit) {
   L.hist_blocks = (int)(L.tiles < HIST_BLOCKS ? L.tiles : HIST_BLOCKS);
   int64_t o = 0;
   L.off_part = o;   o += align_up((int64_t)HIST_BLOCKS * MAX_PASSES * RADIX * 4, 256);
+  L.off_total = o;  o += align_up((int64_t)MAX_PASSES * RADIX * 4, 256);
   L.off_ticket = o; o += 256;
   L.off_status = o; o += align_up((int64_t)MAX_PASSES * L.tiles * RADIX * 4, 256);
   L.off_ktmp = o;   o += align_up(q * key_bytes, 256);
@@ -116,6 +119,22 @@ __global__ void __launch_bounds__(THREADS) sort_hist_kernel(const K* __restrict_
   __syncthreads();
   for (int i = tid; i < passes * RADIX; i += THREADS)
     part[(int64_t)blockIdx.x * MAX_PASSES * RADIX + i] = (&h[0][0])[i];
+}
+
+// many partial tables (large lists: one histogram workgroup per CU) are added up once, not by every tile of
+// every pass: total[p][d] = sum_b part[b][p][d]
+__global__ void __launch_bounds__(RADIX) sort_hist_reduce_kernel(const unsigned* __restrict__ part, int blocks,
+                                                                 unsigned* __restrict__ total) {
+  const int p = blockIdx.x, d = threadIdx.x;
+  unsigned t = 0;
+  for (int b0 = 0; b0 < blocks; b0 += 16) {
+    unsigned c[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) c[u] = (b0 + u < blocks) ? part[((int64_t)(b0 + u) * MAX_PASSES + p) * RADIX + d] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += c[u];
+  }
+  total[p * RADIX + d] = t;
 }
 
 // exclusive scan of one value per thread over the first 256 threads (4 waves); all threads call it
@@ -275,9 +294,17 @@ int run_sort(const K* keys_in, const int* vals_in, K* keys_out, int* vals_out, i
   unsigned* status = (unsigned*)(w + L.off_status);
   K* ktmp = (K*)(w + L.off_ktmp);
   int* vtmp = HAS_VAL ? (int*)(w + L.off_vtmp) : nullptr;
-  const int64_t zero_words = (L.off_ktmp - L.off_ticket) / 4;         // tickets + status of every pass
+  const int64_t zero_words = (L.off_status - L.off_ticket) / 4 + (int64_t)L.passes * L.tiles * RADIX;   // tickets + the passes' status
   sort_hist_kernel<K><<<L.hist_blocks, THREADS, 0, s>>>(keys_in, n, L.passes, end_bit, part, ticket, zero_words);
   LIDAL_CHECK_LAUNCH("sort_hist");
+  int hist_rows = L.hist_blocks;
+  if (L.hist_blocks > HIST_DIRECT) {
+    unsigned* total = (unsigned*)(w + L.off_total);
+    sort_hist_reduce_kernel<<<L.passes, RADIX, 0, s>>>(part, L.hist_blocks, total);
+    LIDAL_CHECK_LAUNCH("sort_hist_reduce");
+    part = total;
+    hist_rows = 1;
+  }
   const size_t lds = (size_t)TILE * (sizeof(K) + (HAS_VAL ? 4 : 0));
   auto kern = sort_onesweep_kernel<K, HAS_VAL>;
   static size_t attr_set[MAX_DEVICES] = {};
@@ -296,7 +323,7 @@ int run_sort(const K* keys_in, const int* vals_in, K* keys_out, int* vals_out, i
     if (bits > 8) bits = 8;
     if (bits < 1) bits = 1;
     kern<<<(unsigned)L.tiles, THREADS, lds, s>>>(kin, vin, ko, vo, n, 8 * p, bits, part + (int64_t)p * RADIX,
-                                                 L.hist_blocks, ticket + p, status + (int64_t)p * L.tiles * RADIX);
+                                                 hist_rows, ticket + p, status + (int64_t)p * L.tiles * RADIX);
     LIDAL_CHECK_LAUNCH("sort_onesweep");
     kin = ko;
     vin = vo;

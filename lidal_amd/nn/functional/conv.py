@@ -25,7 +25,7 @@ from .downsample import spdownsample
 from .hash import sphash
 from .query import coords_table
 
-__all__ = ['conv3d', 'KernelMap', 'RowOrder', 'build_kernel_map', 'prefetch_kernel_maps']
+__all__ = ['conv3d', 'KernelMap', 'RowOrder', 'build_kernel_map', 'prefetch_kernel_maps', 'conv_backward']
 
 
 class RowOrder:
@@ -453,6 +453,53 @@ def _conv(feats, weight, kmap, transposed, epilogue=None, want_stats=False, fork
     return (out, feats) if fork else out
 
 
+def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=None, need_gx=True, need_gw=True):
+    """Backward of a sparse convolution on raw tensors: x = the (compute-dtype, channel-padded) input
+    _forward returned, img_bwd = its data-gradient image.  -> (grad_in or None, grad_w or None).
+    `grad_skip`: a gradient reaching the input through a second consumer, added in the data-gradient
+    kernel's epilogue.  Shared by ConvolutionFunction and the fused block Functions of lidal_amd.network."""
+    g = grad_output.contiguous().to(x.dtype)
+    n_in, n_out = kmap.sizes
+    grad_in = grad_w = None
+    k, ci_w, co = weight.shape
+    ci = x.shape[1]                          # >= ci_w when the input was channel-padded
+
+    def wgrad():
+        gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
+        partial = wgrad_scratch(x.shape[0], g.shape[0], k, ci, co, x.dtype, x.device)
+        B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), x.shape[0], g.shape[0],
+                                         B.ptr(kmap._nbmaps_cap), B.ptr(kmap.koff),
+                                         1 if transposed else 0, B.ptr(gw), B.ptr(partial),
+                                         partial.shape[0], k, ci, co, B.dtype_code(x.dtype),
+                                         B.stream()), 'conv_wgrad')
+        gw = gw[:, :ci_w].contiguous() if ci != ci_w else gw
+        return gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
+
+    side = None
+    if need_gw:
+        if B.overlap_wgrad(x.dtype, max(n_in, n_out)) and need_gx:
+            _ = kmap.koff                   # the rule lists are built on the main stream
+            side = B.beside(x.device, (x, g, kmap._nbmaps_cap, kmap.koff), weight)
+            with side as done:              # beside the data gradient below
+                grad_w = wgrad()
+                done(grad_w)
+        else:
+            grad_w = wgrad()
+    if need_gx:
+        # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci (of the padded input), reduction
+        # over co; the operand image was built together with the forward one
+        order, kflip = _bwd_order(kmap, transposed)
+        # the gradient of the forked alias joins in the epilogue (out = acc + residual)
+        ep = (None, None, 0, grad_skip) if grad_skip is not None else None
+        grad_in = _apply(g, img_bwd, k, x.shape[1], order, kflip, ep)
+        grad_in = grad_in[:, :ci_w]                     # drop the padding channels, if any
+    elif grad_skip is not None:
+        grad_in = grad_skip
+    if side is not None:
+        side.finish()
+    return grad_in, grad_w
+
+
 class ConvolutionFunction(Function):
     last_stats = None           # tile statistics of the latest forward (a non-differentiable side output)
 
@@ -470,46 +517,8 @@ class ConvolutionFunction(Function):
     def backward(ctx, grad_output, grad_skip=None):
         B.note_backward()
         x, weight = ctx.saved_tensors
-        kmap, transposed = ctx.kmap, ctx.transposed
-        g = grad_output.contiguous().to(x.dtype)
-        n_in, n_out = kmap.sizes
-        grad_in = grad_w = None
-        k, ci_w, co = weight.shape
-        ci = x.shape[1]                          # >= ci_w when the input was channel-padded
-
-        def wgrad():
-            gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
-            partial = wgrad_scratch(x.shape[0], g.shape[0], k, ci, co, x.dtype, x.device)
-            B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), x.shape[0], g.shape[0],
-                                             B.ptr(kmap._nbmaps_cap), B.ptr(kmap.koff),
-                                             1 if transposed else 0, B.ptr(gw), B.ptr(partial),
-                                             partial.shape[0], k, ci, co, B.dtype_code(x.dtype),
-                                             B.stream()), 'conv_wgrad')
-            gw = gw[:, :ci_w].contiguous() if ci != ci_w else gw
-            return gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
-
-        side = None
-        if ctx.needs_input_grad[1]:
-            if B.overlap_wgrad(x.dtype, max(n_in, n_out)) and ctx.needs_input_grad[0]:
-                _ = kmap.koff                   # the rule lists are built on the main stream
-                side = B.beside(x.device, (x, g, kmap._nbmaps_cap, kmap.koff), weight)
-                with side as done:              # beside the data gradient below
-                    grad_w = wgrad()
-                    done(grad_w)
-            else:
-                grad_w = wgrad()
-        if ctx.needs_input_grad[0]:
-            # gin[i] = sum_k gout[.] @ W[k]^T : "output channels" are ci (of the padded input), reduction
-            # over co; the operand image was built together with the forward one
-            order, kflip = _bwd_order(kmap, transposed)
-            # the gradient of the forked alias joins in the epilogue (out = acc + residual)
-            ep = (None, None, 0, grad_skip) if grad_skip is not None else None
-            grad_in = _apply(g, ctx.img_bwd, k, x.shape[1], order, kflip, ep)
-            grad_in = grad_in[:, :ci_w]                     # drop the padding channels, if any
-        elif grad_skip is not None:
-            grad_in = grad_skip
-        if side is not None:
-            side.finish()
+        grad_in, grad_w = conv_backward(x, weight, ctx.kmap, ctx.transposed, ctx.img_bwd, grad_output, grad_skip,
+                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return grad_in, grad_w, None, None, None, None
 
 

@@ -12,7 +12,7 @@ from torch.autograd import Function
 from ... import backend as B
 from .conv import wgrad_scratch
 
-__all__ = ['rows_matmul', 'rows_linear']
+__all__ = ['rows_matmul', 'rows_linear', 'rows_backward']
 
 _koff_cache = {}
 
@@ -202,44 +202,53 @@ class RowsMatmul(Function):
     def backward(ctx, g):
         B.note_backward()
         xc, w = ctx.saved_tensors
-        linear = ctx.linear
-        g = g.to(xc.dtype)
-        co = w.shape[0] if linear else w.shape[1]
-        if ctx.pad:
-            g = torch.nn.functional.pad(g, (0, ctx.pad))
-        g = g.contiguous()
-        gx = gw = gb = None
+        return rows_backward(xc, w, ctx.wc, ctx.img_bwd, ctx.pad, ctx.linear, g, ctx.needs_input_grad[0],
+                             ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]) + (None, None)
 
-        def wgrad():
-            if _ok(xc, xc.shape[1], g.shape[1]):
-                gw_ = _wgrad_dense(xc, g)[:, :co]
-            else:
-                gw_ = (xc.float().t() @ g.float())[:, :co]
-            return (gw_.t().contiguous() if linear else gw_.contiguous()).to(w.dtype)
 
-        side = None
-        if ctx.needs_input_grad[1]:
-            if B.overlap_wgrad(xc.dtype) and ctx.needs_input_grad[0] and g.is_cuda:
-                side = B.beside(g.device, (xc, g), w)
-                with side as done:              # beside the data gradient below (backend.beside)
-                    gw = wgrad()
-                    done(gw)
-            else:
+def rows_backward(xc, w, wc, img_bwd, pad, linear, g, need_gx=True, need_gw=True, need_gb=False, grad_skip=None):
+    """Backward of y = x @ w on raw tensors (xc, wc, img_bwd, pad as _forward returned them):
+    -> (gx, gw, gb).  `grad_skip` ([N, Cin], the compute dtype): added to gx in the kernel's epilogue.
+    Shared by RowsMatmul and the fused block Functions of lidal_amd.network."""
+    g = g.to(xc.dtype)
+    co = w.shape[0] if linear else w.shape[1]
+    if pad:
+        g = torch.nn.functional.pad(g, (0, pad))
+    g = g.contiguous()
+    gx = gw = gb = None
+
+    def wgrad():
+        if _ok(xc, xc.shape[1], g.shape[1]):
+            gw_ = _wgrad_dense(xc, g)[:, :co]
+        else:
+            gw_ = (xc.float().t() @ g.float())[:, :co]
+        return (gw_.t().contiguous() if linear else gw_.contiguous()).to(w.dtype)
+
+    side = None
+    if need_gw:
+        if B.overlap_wgrad(xc.dtype) and need_gx and g.is_cuda:
+            side = B.beside(g.device, (xc, g), w)
+            with side as done:              # beside the data gradient below (backend.beside)
                 gw = wgrad()
-        if ctx.needs_input_grad[0]:
-            if _gemm_ok(g, g.shape[1], xc.shape[1]):
-                gx = _rows_gemm(g, ctx.wc, 1, img=ctx.img_bwd)             # reduction over co
-            else:
-                gx = g @ ctx.wc.t()
-        if side is not None:
-            side.finish()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            from .norm import column_sum
-            if g.is_cuda and g.shape[1] % _vec(g.dtype) == 0 and g.shape[1] // _vec(g.dtype) <= 256:
-                gb = column_sum(g)[:co]
-            else:
-                gb = g.float().sum(0)[:co]
-        return gx, gw, gb, None, None
+                done(gw)
+        else:
+            gw = wgrad()
+    if need_gx:
+        if _gemm_ok(g, g.shape[1], xc.shape[1]):
+            gx = _rows_gemm(g, wc, 1, residual=grad_skip, img=img_bwd)             # reduction over co
+        else:
+            gx = g @ wc.t()
+            if grad_skip is not None:
+                gx = gx + grad_skip
+    if side is not None:
+        side.finish()
+    if need_gb:
+        from .norm import column_sum
+        if g.is_cuda and g.shape[1] % _vec(g.dtype) == 0 and g.shape[1] // _vec(g.dtype) <= 256:
+            gb = column_sum(g)[:co]
+        else:
+            gb = g.float().sum(0)[:co]
+    return gx, gw, gb
 
 
 def _rows(x, w, bias, linear, epilogue=None, want_stats=False):

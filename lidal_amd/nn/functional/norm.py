@@ -6,7 +6,7 @@ from torch.autograd import Function
 
 from ... import backend as B
 
-__all__ = ['batch_norm_rows', 'column_sum', 'supported']
+__all__ = ['batch_norm_rows', 'column_sum', 'supported', 'train_forward', 'train_backward']
 
 
 def supported(x, weight, bias):
@@ -27,55 +27,101 @@ def _ws(n, c, dev):
     return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
 
 
+def train_forward(x, weight, bias, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None,
+                  tile_stats=None, residual=None, relu_after=False):
+    """The training forward on raw tensors (no autograd): -> (y, save_mean, save_invstd, x contiguous, w, b).
+    `relu` / `residual` / `relu_after` as in batch_norm_rows.  Shared by BatchNormRows and the fused
+    block Functions of lidal_amd.network (which keep the saved tensors themselves)."""
+    x = x.contiguous()
+    if residual is not None:        # y = act(bn(x)) + residual in the normalising pass
+        assert residual.shape == x.shape
+        residual = residual.contiguous().to(x.dtype)
+    relu = int(bool(relu)) | (2 if (relu_after and residual is not None) else 0)
+    n, c = x.shape
+    dev = x.device
+    y = torch.empty_like(x)
+    w, b = weight.detach().contiguous(), bias.detach().contiguous()
+    code = B.dtype_code(x.dtype)
+    mean = torch.empty(c, dtype=torch.float32, device=dev)
+    invstd = torch.empty(c, dtype=torch.float32, device=dev)
+    if tile_stats is not None and tile_stats.shape != (-(-n // 128), c, 3):
+        tile_stats = None
+    if tile_stats is not None:      # statistics came with x from the producing convolution
+        B.check(B.lib().lidal_bn_train_fwd_tiles(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
+                                                 float(momentum), B.ptr(running_mean),
+                                                 B.ptr(running_var), B.ptr(num_batches_tracked),
+                                                 int(relu), B.ptr(residual), B.ptr(y), B.ptr(mean),
+                                                 B.ptr(invstd), B.ptr(tile_stats),
+                                                 tile_stats.shape[0], B.stream()),
+                'bn_train_fwd')
+    else:
+        ws, nbytes = _ws(n, c, dev)
+        B.check(B.lib().lidal_bn_train_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
+                                           float(momentum), B.ptr(running_mean),
+                                           B.ptr(running_var), B.ptr(num_batches_tracked), int(relu),
+                                           B.ptr(residual), B.ptr(y), B.ptr(mean),
+                                           B.ptr(invstd), B.ptr(ws), nbytes, B.stream()),
+                'bn_train_fwd')
+    # the kernels wrote the running statistics through raw pointers: move their version counters,
+    # which key the folded eval-mode maps (network/blocks.py _fold) -- a train-mode forward
+    # that no backward pass follows (recalibration under no_grad) must invalidate them too
+    for t in (running_mean, running_var):
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+    return y, mean, invstd, x, w, b
+
+
+def train_backward(x, w, b, mean, invstd, relu, grad_out, need_dx=True, mask_from=None):
+    """The training backward on raw tensors: -> (dx or None, grad_gamma f32 [C], grad_beta f32 [C], dy).
+    `mask_from` (the block output y = relu(bn(x) + residual)): grad_out is first masked where y <= 0;
+    the masked gradient `dy` (what also flows to the residual) is returned as the 4th value."""
+    n, c = x.shape
+    if mask_from is not None:       # relu(bn(x) + residual): dy where the output is positive, for both
+        g0 = grad_out.contiguous().to(mask_from.dtype)
+        grad_out = torch.empty_like(mask_from)
+        B.check(B.lib().lidal_add_relu_bwd(B.ptr(mask_from), B.ptr(g0), B.ptr(grad_out), mask_from.numel(),
+                                           B.dtype_code(mask_from.dtype), B.stream()), 'add_relu_bwd')
+    # a channel slice of a concatenation's gradient (up stages) is read in place by the kernels
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if (grad_out.dim() == 2 and grad_out.dtype == x.dtype and grad_out.stride(1) == 1
+            and grad_out.stride(0) >= c and grad_out.stride(0) % vec == 0
+            and grad_out.storage_offset() % vec == 0):
+        g = grad_out
+    else:
+        g = grad_out.contiguous().to(x.dtype)
+    dx = torch.empty_like(x) if need_dx else None
+    gg = torch.empty(c, dtype=torch.float32, device=x.device)
+    gb = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws, nbytes = _ws(n, c, x.device)
+    B.check(B.lib().lidal_bn_bwd(B.ptr(x), B.ptr(g), g.stride(0), B.dtype_code(x.dtype), n, c, B.ptr(w),
+                                 B.ptr(b), int(relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),
+                                 B.ptr(gg), B.ptr(gb),
+                                 B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
+    return dx, gg, gb, grad_out
+
+
 class BatchNormRows(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu,
                 num_batches_tracked=None, tile_stats=None, residual=None, relu_after=False):
-        x = x.contiguous()
-        if residual is not None:        # y = act(bn(x)) + residual in the normalising pass (training)
-            assert training and residual.shape == x.shape
-            residual = residual.contiguous().to(x.dtype)
-        relu = int(bool(relu)) | (2 if (relu_after and residual is not None) else 0)
-        n, c = x.shape
-        dev = x.device
-        y = torch.empty_like(x)
-        w, b = weight.detach().contiguous(), bias.detach().contiguous()
-        code = B.dtype_code(x.dtype)
+        if residual is not None:
+            assert training
+        relu_bits = int(bool(relu)) | (2 if (relu_after and residual is not None) else 0)
         if training:
-            mean = torch.empty(c, dtype=torch.float32, device=dev)
-            invstd = torch.empty(c, dtype=torch.float32, device=dev)
-            if tile_stats is not None:      # statistics came with x from the producing convolution
-                B.check(B.lib().lidal_bn_train_fwd_tiles(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
-                                                         float(momentum), B.ptr(running_mean),
-                                                         B.ptr(running_var), B.ptr(num_batches_tracked),
-                                                         int(relu), B.ptr(residual), B.ptr(y), B.ptr(mean),
-                                                         B.ptr(invstd), B.ptr(tile_stats),
-                                                         tile_stats.shape[0], B.stream()),
-                        'bn_train_fwd')
-            else:
-                ws, nbytes = _ws(n, c, dev)
-                B.check(B.lib().lidal_bn_train_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
-                                                   float(momentum), B.ptr(running_mean),
-                                                   B.ptr(running_var), B.ptr(num_batches_tracked), int(relu),
-                                                   B.ptr(residual), B.ptr(y), B.ptr(mean),
-                                                   B.ptr(invstd), B.ptr(ws), nbytes, B.stream()),
-                        'bn_train_fwd')
+            y, mean, invstd, x, w, b = train_forward(x, weight, bias, running_mean, running_var, momentum, eps,
+                                                     relu, num_batches_tracked, tile_stats, residual, relu_after)
         else:
+            x = x.contiguous()
+            y = torch.empty_like(x)
+            w, b = weight.detach().contiguous(), bias.detach().contiguous()
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
-            B.check(B.lib().lidal_bn_eval_fwd(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b),
-                                              B.ptr(running_mean), B.ptr(running_var), float(eps),
-                                              int(relu), B.ptr(y), B.stream()), 'bn_eval_fwd')
-        if training:
-            # the kernels wrote the running statistics through raw pointers: move their version counters,
-            # which key the folded eval-mode maps (network/blocks.py _fold) -- a train-mode forward
-            # that no backward pass follows (recalibration under no_grad) must invalidate them too
-            for t in (running_mean, running_var):
-                if t is not None:
-                    torch.autograd.graph.increment_version(t)
+            B.check(B.lib().lidal_bn_eval_fwd(B.ptr(x), B.dtype_code(x.dtype), x.shape[0], x.shape[1], B.ptr(w),
+                                              B.ptr(b), B.ptr(running_mean), B.ptr(running_var), float(eps),
+                                              int(relu_bits), B.ptr(y), B.stream()), 'bn_eval_fwd')
         ctx.training = training
-        ctx.relu = bool(relu & 1)
-        ctx.relu_after = bool(relu & 2)
+        ctx.relu = bool(relu_bits & 1)
+        ctx.relu_after = bool(relu_bits & 2)
         ctx.has_residual = residual is not None
         if ctx.relu_after:              # the output is the mask of the trailing ReLU
             ctx.save_for_backward(x, w, b, mean, invstd, y)
@@ -87,40 +133,19 @@ class BatchNormRows(Function):
     def backward(ctx, grad_out):
         B.note_backward()
         x, w, b, mean, invstd = ctx.saved_tensors[:5]
-        n, c = x.shape
-        if ctx.relu_after:              # relu(bn(x) + residual): dy where the output is positive, for both
-            y = ctx.saved_tensors[5]
-            g0 = grad_out.contiguous().to(y.dtype)
-            grad_out = torch.empty_like(y)
-            B.check(B.lib().lidal_add_relu_bwd(B.ptr(y), B.ptr(g0), B.ptr(grad_out), y.numel(),
-                                               B.dtype_code(y.dtype), B.stream()), 'add_relu_bwd')
-        # a channel slice of a concatenation's gradient (up stages) is read in place by the kernels
-        vec = 8 if x.dtype == torch.bfloat16 else 4
-        if (grad_out.dim() == 2 and grad_out.dtype == x.dtype and grad_out.stride(1) == 1 and ctx.training
-                and grad_out.stride(0) >= c and grad_out.stride(0) % vec == 0
-                and grad_out.storage_offset() % vec == 0):
-            g = grad_out
-        else:
-            g = grad_out.contiguous().to(x.dtype)
         if not ctx.training:            # eval-mode backward (not on the LiDAL path): plain torch
+            g = grad_out.contiguous().to(x.dtype)
             xhat = (x.float() - mean) * invstd
             gf = g.float()
             if ctx.relu:
                 gf = gf * ((xhat * w + b) > 0)
             return ((gf * (w * invstd)).to(x.dtype), (gf * xhat).sum(0), gf.sum(0), None, None,
                     None, None, None, None, None, None, None, None)
-        need_dx = ctx.needs_input_grad[0]
-        dx = torch.empty_like(x) if need_dx else None
-        gg = torch.empty(c, dtype=torch.float32, device=x.device)
-        gb = torch.empty(c, dtype=torch.float32, device=x.device)
-        ws, nbytes = _ws(n, c, x.device)
-        B.check(B.lib().lidal_bn_bwd(B.ptr(x), B.ptr(g), g.stride(0), B.dtype_code(x.dtype), n, c, B.ptr(w),
-                                     B.ptr(b), int(ctx.relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),
-                                     B.ptr(gg), B.ptr(gb),
-                                     B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
-        # the residual passes straight through: its gradient is grad_out itself
+        dx, gg, gb, dy = train_backward(x, w, b, mean, invstd, ctx.relu, grad_out, ctx.needs_input_grad[0],
+                                        ctx.saved_tensors[5] if ctx.relu_after else None)
+        # the residual passes straight through: its gradient is grad_out itself (masked, if a ReLU followed)
         return (dx, gg, gb, None, None, None, None, None, None, None, None,
-                grad_out if ctx.has_residual and ctx.needs_input_grad[11] else None, None)
+                dy if ctx.has_residual and ctx.needs_input_grad[11] else None, None)
 
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, training, momentum, eps,

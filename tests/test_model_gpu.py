@@ -488,3 +488,45 @@ def test_a_failed_backward_does_not_freeze_the_weight_epoch():
     # BatchNorm running statistics saw one extra forward in the failed run, the weights did not (no
     # optimizer step): the training losses (batch statistics) are unaffected by it
     assert clean == failed, (clean, failed)
+
+
+@pytest.mark.parametrize('name,autocast', [('spvcnn', True), ('minkunet', True), ('minkunet', False)])
+def test_fused_block_functions_are_bitwise_the_per_operator_path(name, autocast, golden_dir):
+    """Training runs every Conv3d -> BatchNorm -> ReLU unit and every residual block as ONE autograd node
+    (network/blocks.py: _ConvNormAct, _Residual) built from the same raw operator calls as the per-operator
+    Functions: loss, logits and every parameter gradient must be bitwise equal, and the fused path must
+    really be taken (far fewer autograd nodes)."""
+    from lidal_amd.network import blocks
+    from lidal_amd.train_step import forward_backward
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    feats, coords = torch.from_numpy(g['feats']).to(DEV), torch.from_numpy(g['coords']).to(DEV)
+    labels = torch.from_numpy(g['labels']).to(DEV)
+    runs = []
+    saved = blocks.FUSE_BLOCKS
+    try:
+        for fuse in (False, True):
+            blocks.FUSE_BLOCKS = fuse
+            model = fill_state_dict(_models()[name](19)).to(DEV).train()
+            if hasattr(model, 'dropout'):
+                model.dropout.p = 0.0
+            loss, logits = forward_backward(model, feats, coords, labels, autocast=autocast)
+            nodes, seen, stack = 0, set(), [loss.grad_fn]
+            while stack:
+                fn = stack.pop()
+                if fn is None or fn in seen:
+                    continue
+                seen.add(fn)
+                nodes += 1
+                stack.extend(f for f, _ in fn.next_functions)
+            runs.append((loss.item(), logits.detach().clone(), [p.grad.clone() for p in model.parameters()],
+                         [b.clone() for b in model.buffers()], nodes))
+    finally:
+        blocks.FUSE_BLOCKS = saved
+    (l0, lg0, g0, b0, n0), (l1, lg1, g1, b1, n1) = runs
+    assert l0 == l1 and torch.equal(lg0, lg1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    for a, b in zip(b0, b1):                # running statistics / num_batches_tracked
+        assert torch.equal(a, b)
+    assert n1 < 0.6 * n0, (n0, n1)

@@ -249,7 +249,7 @@ def _weight_image(weight, dtype, n_out, role):
     L = B.lib()
     key = cache = None
     if not torch.is_grad_enabled():
-        key = (B.weights_key(weight), role, code, L.lidal_conv_weight_image_tiling(n_red, n_col, code, n_out))
+        key = (B.weights_key(weight), role, code, _tiling(n_red, n_col, code, n_out))
         cache = getattr(weight, '_lidal_images', None)
         if cache is not None and key in cache:
             return cache[key]
@@ -264,6 +264,20 @@ def _weight_image(weight, dtype, n_out, role):
             weight._lidal_images = cache
         cache[key] = img
     return img
+
+
+_TILING = {}
+
+
+def _tiling(n_red, n_col, code, n_out):
+    """lidal_conv_weight_image_tiling, memoised: a pure function, asked ~100 times per step."""
+    key = (n_red, n_col, code, n_out)
+    t = _TILING.get(key)
+    if t is None:
+        if len(_TILING) > 4096:
+            _TILING.clear()
+        t = _TILING[key] = B.lib().lidal_conv_weight_image_tiling(n_red, n_col, code, n_out)
+    return t
 
 
 class _ImageBank:
@@ -290,8 +304,7 @@ class _ImageBank:
         k, ci, co = shape if shape is not None else weight.shape
         code = B.dtype_code(dtype)
         L = B.lib()
-        key = (weight.data_ptr(), code, weight.dtype, L.lidal_conv_weight_image_tiling(ci, co, code, n_out_fwd),
-               L.lidal_conv_weight_image_tiling(co, ci, code, n_out_bwd), role)
+        key = (weight.data_ptr(), code, weight.dtype, _tiling(ci, co, code, n_out_fwd), _tiling(co, ci, code, n_out_bwd), role)
         e = self.entries.get(id(weight))
         if e is None or e['ref']() is not weight or e['key'] != key:
             nf = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out_fwd)

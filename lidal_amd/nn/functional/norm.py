@@ -40,7 +40,9 @@ def train_forward(x, weight, bias, running_mean, running_var, momentum, eps, rel
     n, c = x.shape
     dev = x.device
     y = torch.empty_like(x)
-    w, b = weight.detach().contiguous(), bias.detach().contiguous()
+    # (inside an autograd Function nothing is tracked: the parameters themselves, no detached copies)
+    w = weight if weight.is_contiguous() else weight.detach().contiguous()
+    b = bias if bias.is_contiguous() else bias.detach().contiguous()
     code = B.dtype_code(x.dtype)
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     invstd = torch.empty(c, dtype=torch.float32, device=dev)

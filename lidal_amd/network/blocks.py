@@ -48,9 +48,9 @@ class _ConvNormAct(torch.autograd.Function):
     """Conv3d (regular / strided / transposed) -> train-mode BatchNorm -> ReLU."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, gamma, beta, kmap, transposed, bn, relu):
+    def forward(ctx, feats, kernel, gamma, beta, kmap, transposed, bn, relu, stats):
         need_gx = ctx.needs_input_grad[0]
-        xc, x1, ctx.img_bwd = _C._forward(feats, kernel, kmap, transposed, None, need_gx, True)
+        xc, x1, ctx.img_bwd = _C._forward(feats, kernel, kmap, transposed, None, need_gx, stats)
         y, mean, invstd, x1, w, b = _N.train_forward(x1, gamma, beta, bn.running_mean, bn.running_var, bn.momentum,
                                                      bn.eps, relu, bn.num_batches_tracked,
                                                      getattr(x1, '_lidal_bn_stats', None))
@@ -65,23 +65,24 @@ class _ConvNormAct(torch.autograd.Function):
         dx, gg, gb, _ = _N.train_backward(x1, w, b, mean, invstd, ctx.relu, g, True)
         gx, gk = _C.conv_backward(xc, kernel, ctx.kmap, ctx.transposed, ctx.img_bwd, dx, None,
                                   ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gx, gk, gg, gb, None, None, None, None
+        return gx, gk, gg, gb, None, None, None, None, None
 
 
 class _Residual(torch.autograd.Function):
     """relu(bn2(conv2(relu(bn1(conv1(x))))) + shortcut(x)), shortcut = identity or bn_s(x @ ks)."""
 
     @staticmethod
-    def forward(ctx, feats, k1, g1, b1, k2, g2, b2, ks, gs, bs, kmap, bn1, bn2, bns):
+    def forward(ctx, feats, k1, g1, b1, k2, g2, b2, ks, gs, bs, kmap, bn1, bn2, bns, stats):
+        # `stats` = (s1, s2, ss): does the kernel of conv1 / conv2 / the shortcut leave its BatchNorm's statistics?
         need_gx = ctx.needs_input_grad[0]
-        xc, x1, ctx.img1 = _C._forward(feats, k1, kmap, False, None, need_gx, True)
+        xc, x1, ctx.img1 = _C._forward(feats, k1, kmap, False, None, need_gx, stats[0])
         y1, mean1, inv1, x1, w1, c1 = _N.train_forward(x1, g1, b1, bn1.running_mean, bn1.running_var, bn1.momentum,
                                                        bn1.eps, True, bn1.num_batches_tracked,
                                                        getattr(x1, '_lidal_bn_stats', None))
-        _, x2, ctx.img2 = _C._forward(y1, k2, kmap, False, None, True, True)
+        _, x2, ctx.img2 = _C._forward(y1, k2, kmap, False, None, True, stats[1])
         ctx.shortcut = ks is not None
         if ctx.shortcut:
-            xs_in, ctx.wcs, ctx.pads, xs, ctx.imgs = _D._forward(feats, ks, None, False, None, need_gx, True)
+            xs_in, ctx.wcs, ctx.pads, xs, ctx.imgs = _D._forward(feats, ks, None, False, None, need_gx, stats[2])
             res, means, invs, xs, ws, cs = _N.train_forward(xs, gs, bs, bns.running_mean, bns.running_var,
                                                             bns.momentum, bns.eps, False, bns.num_batches_tracked,
                                                             getattr(xs, '_lidal_bn_stats', None))
@@ -117,7 +118,7 @@ class _Residual(torch.autograd.Function):
         dx1, gg1, gb1, _ = _N.train_backward(x1, w1, c1, mean1, inv1, True, dy1, True)
         gx, gk1 = _C.conv_backward(xc, k1, ctx.kmap, False, ctx.img1, dx1, g_skip if need_gx else None, need_gx,
                                    ctx.needs_input_grad[1])
-        return gx, gk1, gg1, gb1, gk2, gg2, gb2, gks, ggs, gbs, None, None, None, None
+        return gx, gk1, gg1, gb1, gk2, gg2, gb2, gks, ggs, gbs, None, None, None, None, None
 
 
 def _kmap_of(x, conv):
@@ -158,7 +159,8 @@ def fused_conv_norm_act(x, conv, bn):
             and isinstance(bn, spnn.BatchNorm)):
         return None
     kmap, coords, stride = _kmap_of(x, conv)
-    y = _ConvNormAct.apply(x.F, conv.kernel, bn.weight, bn.bias, kmap, conv.transposed, bn, bool(bn.fused_relu))
+    y = _ConvNormAct.apply(x.F, conv.kernel, bn.weight, bn.bias, kmap, conv.transposed, bn, bool(bn.fused_relu),
+                           bool(conv.bn_follows))
     return _wrap(y, coords, stride, x)
 
 
@@ -331,8 +333,9 @@ class ResidualBlock(nn.Module):
         elif x.F.shape[1] != c2.out_channels:
             return None
         kmap, coords, stride = _kmap_of(x, c1)
+        stats = (bool(c1.bn_follows), bool(c2.bn_follows), bool(ks is not None and self.downsample[0].bn_follows))
         out = _Residual.apply(x.F, c1.kernel, n1.weight, n1.bias, c2.kernel, n2.weight, n2.bias, ks, gs, bs, kmap,
-                              n1, n2, ns)
+                              n1, n2, ns, stats)
         return _wrap(out, coords, stride, x)
 
     def forward(self, x):

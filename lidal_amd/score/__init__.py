@@ -5,7 +5,7 @@ from .interframe import FrameBank, neighbour_ids, score_frame
 from .pipeline import ScoreBoard, collect_sequence, score_sequence
 from .prob_inference import infer_frame
 from .selection import select
-from .sharding import frame_range, gather_frames
+from .sharding import HaloExchange, frame_range, gather_frames, needed_frames
 
 __all__ = ['infer_frame', 'FrameBank', 'neighbour_ids', 'score_frame', 'score_sequence', 'collect_sequence', 'ScoreBoard', 'select',
-           'frame_range', 'gather_frames']
+           'frame_range', 'gather_frames', 'needed_frames', 'HaloExchange']

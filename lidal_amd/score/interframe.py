@@ -30,24 +30,30 @@ def neighbour_ids(i, n_frames, nei_num):
 
 
 class FrameBank:
-    """Device-resident frames of one sequence + lazily built nearest-neighbour grids."""
+    """Device-resident frames of one sequence + lazily built nearest-neighbour grids.  Frames are keyed
+    by their id in the sequence; a bank may hold only SOME of them (a rank's block and its halo,
+    score/sharding.py HaloExchange): pass `n_frames` (the sequence length, which the neighbour rule
+    needs) and `frame_id` to add()."""
 
-    def __init__(self, dis_thresh=0.1):
+    def __init__(self, dis_thresh=0.1, n_frames=None):
         self.dis_thresh = float(dis_thresh)
-        self.world = []       # f64 [P,3]
-        self.prob = []        # f32 [P,C]
-        self._grid = []
+        self.n_frames = n_frames
+        self.world = {}       # frame id -> f64 [P,3]
+        self.prob = {}        # frame id -> f32 [P,C]
+        self._grid = {}
 
     def __len__(self):
-        return len(self.world)
+        return self.n_frames if self.n_frames is not None else len(self.world)
 
-    def add(self, world, prob):
+    def add(self, world, prob, frame_id=None):
         B.require_gpu(world, prob)
         assert world.dtype == torch.float64 and world.shape[1] == 3
         assert prob.dtype == torch.float32 and prob.shape[0] == world.shape[0]
-        self.world.append(world.contiguous())
-        self.prob.append(prob.contiguous())
-        self._grid.append(None)
+        f = len(self.world) if frame_id is None else int(frame_id)
+        assert f not in self.world
+        self.world[f] = world.contiguous()
+        self.prob[f] = prob.contiguous()
+        self._grid[f] = None
 
     def grid(self, i):
         if self._grid[i] is None:

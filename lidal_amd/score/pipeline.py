@@ -16,34 +16,60 @@ import torch.distributed as dist
 from .interframe import FrameBank, score_frame
 from .prob_inference import infer_frame
 from .selection import select
-from .sharding import gather_frames, is_sharded
+from .sharding import HaloExchange, gather_frames, is_sharded
 
 __all__ = ['score_sequence', 'collect_sequence', 'ScoreBoard']
 
 
 def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_thresh=0.1,
-                   inf_reps=8, autocast=False, group=None):
+                   inf_reps=8, autocast=False, group=None, exchange='halo'):
     """local_frames: list of dicts for frames first_frame, first_frame+1, ... owned by this rank,
     each with device tensors coords (i32 [N,4]), feats (f32 [N,4]), inverse (i64 [reps*P]),
     world (f64 [P,3]), sv_ptr / sv_idx (CSR of the supervoxels).
     Returns a list (one entry per local frame) of (sv_interds f32 [S], sv_interes f32 [S],
-    sv_centers f32 [S,3]) device tensors."""
-    probs, worlds = {}, {}
-    n_class = None
-    for s, d in enumerate(local_frames):
-        prob, _ = infer_frame(model, d['coords'], d['feats'], d['inverse'], inf_reps,
-                              autocast=autocast)
-        probs[first_frame + s] = prob
-        worlds[first_frame + s] = d['world']
-        n_class = prob.shape[1]
-    if n_class is None:                       # a rank without frames still joins the collectives
-        n_class = model.num_classes if hasattr(model, 'num_classes') else 19
+    sv_centers f32 [S,3]) device tensors.
+    exchange: 'halo' (default) -- every rank receives only the frames its block reads (its neighbours'
+    edge frames + the wrap-rule frames at the ends of the sequence), point to point; the frames other
+    ranks read are inferred first and travel under the inference of the rest; 'allgather' -- every frame to every rank
+    (one padded all_gather_into_tensor per array).  Same scores bit for bit."""
+    n_class = model.num_classes if hasattr(model, 'num_classes') else 19
     dev = local_frames[0]['world'].device if local_frames else None
-    all_prob = gather_frames(probs, n_total, (n_class,), torch.float32, group=group, device=dev)
-    all_world = gather_frames(worlds, n_total, (3,), torch.float64, group=group, device=dev)
-    bank = FrameBank(dis_thresh)
-    for w, p in zip(all_world, all_prob):
-        bank.add(w, p)
+    if exchange == 'allgather' or not is_sharded(group):
+        probs, worlds = {}, {}
+        for s, d in enumerate(local_frames):
+            prob, _ = infer_frame(model, d['coords'], d['feats'], d['inverse'], inf_reps, autocast=autocast)
+            probs[first_frame + s] = prob
+            worlds[first_frame + s] = d['world']
+            n_class = prob.shape[1]
+        all_prob = gather_frames(probs, n_total, (n_class,), torch.float32, group=group, device=dev)
+        all_world = gather_frames(worlds, n_total, (3,), torch.float64, group=group, device=dev)
+        bank = FrameBank(dis_thresh)
+        for w, p in zip(all_world, all_prob):
+            bank.add(w, p)
+    else:
+        assert exchange == 'halo', exchange
+        if dev is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        by_id = {first_frame + s: d for s, d in enumerate(local_frames)}
+        hx = HaloExchange(n_total, nei_num, {f: d['world'].shape[0] for f, d in by_id.items()}, group=group,
+                          device=dev)
+        worlds = {f: d['world'] for f, d in by_id.items()}
+        hx.exchange('world', (3,), torch.float64, worlds)
+        probs = {}
+
+        def infer(f):
+            d = by_id[f]
+            probs[f], _ = infer_frame(model, d['coords'], d['feats'], d['inverse'], inf_reps, autocast=autocast)
+        for f in hx.exports:            # the frames other ranks read: first, so that their transfer ...
+            infer(f)
+        hx.exchange('prob', (n_class,), torch.float32, probs)
+        for f in by_id:                 # ... runs under the inference of the rest
+            if f not in probs:
+                infer(f)
+        have = hx.finish({'world': worlds, 'prob': probs})
+        bank = FrameBank(dis_thresh, n_frames=n_total)
+        for f in sorted(have['world']):
+            bank.add(have['world'][f], have['prob'][f], frame_id=f)
     return [score_frame(bank, first_frame + s, d['sv_ptr'], d['sv_idx'], nei_num)
             for s, d in enumerate(local_frames)]
 

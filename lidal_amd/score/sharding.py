@@ -10,13 +10,20 @@
                     +-nei window.
                     The same call carries the return leg (score/pipeline.py collect_sequence:
                     ~40 kB of per-supervoxel results per sequence, consumed by rank 0).
+  HaloExchange      the bounded-memory form of that hand-off: a query frame touches only the nei/2
+                    frames either side of it (plus, at the two ends of a sequence, the wrap-rule frames
+                    of LiDAL.py:41-42), so a rank needs its own block and a halo -- not the sequence.
+                    Point-to-point sends (batch_isend_irecv), posted per frame as soon as that frame's
+                    probabilities exist, so the exchange runs under the inference of the next frames;
+                    memory per rank is (block + nei) frames whatever the sequence length (SemanticKITTI
+                    seq 00: 4 541 frames x 12 MB would be 54 GB per rank through the all-gather).
 """
 import math
 
 import torch
 import torch.distributed as dist
 
-__all__ = ['frame_range', 'gather_frames', 'collective_device', 'is_sharded']
+__all__ = ['frame_range', 'gather_frames', 'collective_device', 'is_sharded', 'needed_frames', 'HaloExchange']
 
 
 def frame_range(n_frames, world_size, rank):
@@ -72,3 +79,108 @@ def gather_frames(local, n_frames, tail, dtype, group=None, device=None):
         r, s = divmod(f, per)
         out.append(blocks[r, s, :int(all_lens[r, s])])
     return out
+
+
+def needed_frames(n_frames, world_size, rank, nei_num):
+    """Sorted frame ids rank `rank` reads when it scores its own block with a window of nei_num
+    neighbours: its frames and their neighbour ids under the reference's wrap rules (LiDAL.py:41-42)."""
+    from .interframe import neighbour_ids
+    need = set()
+    for i in frame_range(n_frames, world_size, rank):
+        need.add(i)
+        need.update(neighbour_ids(i, n_frames, nei_num))
+    assert all(0 <= f < n_frames for f in need), 'sequence shorter than the neighbour window'
+    return sorted(need)
+
+
+class HaloExchange:
+    """Per-frame arrays (probabilities f32 [P, C], world coordinates f64 [P, 3]) travel only to the ranks
+    whose blocks read them.  Usage (every rank, same order of calls):
+
+        hx = HaloExchange(n_frames, nei_num, lengths_of_my_frames, group)   # one tiny all-gather (lengths)
+        hx.exchange('world', (3,), torch.float64, {f: world_f for my frames})           # exists already
+        for f in hx.exports: prob[f] = infer(f)                  # the frames other ranks read, FIRST
+        hx.exchange('prob', (C,), torch.float32, prob)           # starts; returns at once
+        for f in the rest of my frames: prob[f] = infer(f)       # ... the exchange runs under these
+        frames = hx.finish({'prob': prob})   # {kind: {frame id: tensor}} for every frame this rank needs
+
+    The plan (who sends which frame to whom) is a pure function of (n_frames, world size, nei_num): no
+    negotiation.  Each exchange() is ONE batch_isend_irecv group holding this rank's receives AND sends of
+    that kind (a receive group queued in front of the matching send group of the same rank would deadlock
+    two RCCL ranks against each other; within one group they progress together)."""
+
+    def __init__(self, n_frames, nei_num, local_lengths, group=None, device=None):
+        self.group = group
+        self.n_frames = n_frames
+        self.world = dist.get_world_size(group) if is_sharded(group) else 1
+        self.rank = dist.get_rank(group) if is_sharded(group) else 0
+        self.mine = list(frame_range(n_frames, self.world, self.rank))
+        self.need = needed_frames(n_frames, self.world, self.rank, nei_num)
+        self.cdev = collective_device(group) if self.world > 1 else None
+        self.device = device
+        per = math.ceil(n_frames / self.world)
+        self.per = per
+        # dst ranks of each of my frames
+        self.dst = {f: [] for f in self.mine}
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            for f in needed_frames(n_frames, self.world, r, nei_num):
+                if f in self.dst:
+                    self.dst[f].append(r)
+        self.exports = [f for f in self.mine if self.dst[f]]
+        # lengths of every frame: one small all-gather (a rank without frames joins with zeros)
+        if self.world > 1:
+            lens = torch.zeros(per, dtype=torch.int64)
+            for s_, f in enumerate(self.mine):
+                lens[s_] = int(local_lengths[f])
+            lens = lens.to(self.cdev)
+            all_lens = torch.empty(self.world * per, dtype=torch.int64, device=self.cdev)
+            dist.all_gather_into_tensor(all_lens, lens, group=group)
+            all_lens = all_lens.cpu().tolist()
+            self.lengths = {f: all_lens[f] for f in range(n_frames)}
+        else:
+            self.lengths = {f: int(local_lengths[f]) for f in self.mine}
+        self.recv = {}          # kind -> {frame: staging tensor on the collective device}
+        self.reqs = []
+        self.keep = []          # send staging buffers stay alive until finish()
+
+    def _global_rank(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def exchange(self, kind, tail, dtype, frames):
+        """Start the transfers of `kind`: `frames` holds (at least) this rank's export frames."""
+        self.recv[kind] = {}
+        if self.world == 1:
+            return
+        ops = []
+        for f in self.need:                      # receives, ascending frame id ...
+            if f in self.dst:
+                continue
+            buf = torch.empty((self.lengths[f],) + tuple(tail), dtype=dtype, device=self.cdev)
+            self.recv[kind][f] = buf
+            ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(f // self.per), group=self.group))
+        for f in self.exports:                   # ... and sends, ascending frame id: per pair the orders match
+            t = frames[f]
+            assert tuple(t.shape[1:]) == tuple(tail) and t.dtype == dtype and t.shape[0] == self.lengths[f]
+            staged = t.contiguous().to(self.cdev)
+            self.keep.append(staged)
+            for r in self.dst[f]:
+                ops.append(dist.P2POp(dist.isend, staged, self._global_rank(r), group=self.group))
+        if ops:
+            self.reqs += dist.batch_isend_irecv(ops)
+
+    def finish(self, local):
+        """local: {kind: {frame id: tensor}} of this rank's own frames.  Waits for the transfers and
+        returns {kind: {frame id: tensor on `device`}} for every frame this rank needs."""
+        for r in self.reqs:
+            r.wait()
+        self.reqs, self.keep = [], []
+        out = {}
+        for kind, own in local.items():
+            have = {f: own[f] for f in self.mine}
+            for f, buf in self.recv.get(kind, {}).items():
+                have[f] = buf if (self.device is None or buf.device == self.device) else buf.to(self.device)
+            out[kind] = have
+        self.recv = {}
+        return out

@@ -22,7 +22,7 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda', 0)
-    if mode == 'score':
+    if mode in ('score', 'score_allgather'):
         from lidal_amd.score import collect_sequence, frame_range, score_sequence
         model = mc.make_model(dev).eval()
         frames = mc.make_frames()
@@ -30,11 +30,12 @@ def main():
         local = [mc.to_device(frames[f], dev) for f in mine]
         first = mine[0] if mine else 0
         scores = score_sequence(model, local, first, len(frames), nei_num=mc.NEI, dis_thresh=0.1,
-                                inf_reps=mc.REPS, autocast=False)
+                                inf_reps=mc.REPS, autocast=False,
+                                exchange='halo' if mode == 'score' else 'allgather')
         got = collect_sequence(scores, [frames[f]['sv_id'] for f in mine],
                                [d['sv_ptr'] for d in local], first, len(frames))
         if rank == 0:
-            np.savez(os.path.join(out_dir, 'score_2rank.npz'),
+            np.savez(os.path.join(out_dir, '%s_2rank.npz' % mode),
                      **{'%s_%d' % (k, f): v for f, t in enumerate(got)
                         for k, v in zip(('id', 'd', 'e', 'n', 'c'), t)})
     elif mode == 'ddp':

@@ -2,7 +2,8 @@
 cuda:0 (tests/_multirank_child.py) and must reproduce the single-process results.
 
   * scoring (configs 4/5): frames split in the reference's contiguous blocks
-    (dataset/sk_dataloader.py:196-198), probabilities + world coordinates exchanged, every rank
+    (dataset/sk_dataloader.py:196-198), probabilities + world coordinates exchanged (halo exchange and
+    all-gather), every rank
     scores its own frames, per-supervoxel results collected on rank 0 -- every number BIT-EQUAL to
     the 1-rank run (each frame's inference and scoring is the same kernel sequence on the same
     inputs whichever rank runs it; the kernels are order-deterministic);
@@ -59,14 +60,17 @@ def test_two_rank_scoring_is_bit_equal_to_one_rank(tmp_path):
                             inf_reps=mc.REPS, autocast=False)
     one = collect_sequence(scores, [f['sv_id'] for f in frames], [d['sv_ptr'] for d in local], 0, len(frames))
     torch.cuda.synchronize()
-    _spawn('score', tmp_path)
-    two = np.load(os.path.join(str(tmp_path), 'score_2rank.npz'))
-    matched = 0
-    for f, t in enumerate(one):
-        for k, v in zip(('id', 'd', 'e', 'n', 'c'), t):
-            assert np.array_equal(two['%s_%d' % (k, f)], v), (k, f)
-        matched += int((t[1] != 0).sum())
-    assert matched > 0, 'degenerate fixture: no supervoxel saw an inter-frame match'
+    # both hand-offs: the halo exchange (default: each rank receives only the frames its block reads,
+    # score/sharding.py HaloExchange) and the all-gather of every frame to every rank
+    for mode in ('score', 'score_allgather'):
+        _spawn(mode, tmp_path)
+        two = np.load(os.path.join(str(tmp_path), '%s_2rank.npz' % mode))
+        matched = 0
+        for f, t in enumerate(one):
+            for k, v in zip(('id', 'd', 'e', 'n', 'c'), t):
+                assert np.array_equal(two['%s_%d' % (k, f)], v), (mode, k, f)
+            matched += int((t[1] != 0).sum())
+        assert matched > 0, 'degenerate fixture: no supervoxel saw an inter-frame match'
 
 
 def test_two_rank_ddp_gradient_is_the_mean_of_the_rank_gradients(tmp_path):

@@ -132,3 +132,50 @@ def test_collection_single_process_matches_reference_flags():
         board.add_sequence(s_i, collect_sequence(scores, ids, ptrs, 0, n_frames))
     assert np.array_equal(board.sv_centers, g['sv_centers'])
     assert np.array_equal(board.select(g['flags_in'], int(g['train_point_num'])), g['flags_out'])
+
+
+def test_needed_frames_is_the_union_of_the_neighbour_windows():
+    from lidal_amd.score import frame_range, needed_frames, neighbour_ids
+    for n, world, nei in ((13, 2, 10), (40, 3, 24), (256, 8, 10), (4, 3, 2)):
+        seen = set()
+        for r in range(world):
+            need = needed_frames(n, world, r, nei)
+            want = set()
+            for i in frame_range(n, world, r):
+                want |= {i} | set(neighbour_ids(i, n, nei))
+            assert need == sorted(want)
+            seen |= set(frame_range(n, world, r))
+            # bounded: a block plus its halo plus the wrap-rule frames -- never the whole long sequence
+            assert len(need) <= len(frame_range(n, world, r)) + 2 * nei
+        assert seen == set(range(n))
+    assert len(needed_frames(4541, 8, 3, 24)) == 568 + 24          # SemanticKITTI seq 00 on 8 GPUs
+
+
+def _halo_worker(rank, world, port, n_frames, nei, out_dir):
+    _init(rank, world, port)
+    from lidal_amd.score import HaloExchange, frame_range, needed_frames
+    frames = _frames(n_frames)
+    mine = list(frame_range(n_frames, world, rank))
+    probs = {f: frames[f] for f in mine}
+    worlds = {f: frames[f][:, :3].double() for f in mine}
+    hx = HaloExchange(n_frames, nei, {f: frames[f].shape[0] for f in mine})
+    hx.exchange('world', (3,), torch.float64, worlds)
+    hx.exchange('prob', (19,), torch.float32, {f: probs[f] for f in hx.exports})
+    have = hx.finish({'world': worlds, 'prob': probs})
+    need = needed_frames(n_frames, world, rank, nei)
+    ok = sorted(have['prob']) == need and sorted(have['world']) == need
+    ok = ok and all(torch.equal(have['prob'][f], frames[f]) for f in need)
+    ok = ok and all(torch.equal(have['world'][f], frames[f][:, :3].double()) for f in need)
+    torch.save(bool(ok), os.path.join(out_dir, 'halo_%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_delivers_exactly_the_needed_frames_gloo(tmp_path):
+    """The bounded-memory exchange (score/sharding.py HaloExchange): every rank ends up with its block,
+    its halo and the wrap-rule frames -- bit-equal to the originals, nothing else -- for 2 and 3 ranks,
+    windows 10 and 24, and a rank that owns no frame at all."""
+    for world, n_frames, nei in ((2, 13, 10), (2, 27, 24), (3, 40, 10), (3, 4, 2)):
+        port = _free_port()
+        mp.spawn(_halo_worker, args=(world, port, n_frames, nei, str(tmp_path)), nprocs=world, join=True)
+        assert all(torch.load(os.path.join(str(tmp_path), 'halo_%d.pt' % r)) for r in range(world)), (world, n_frames)

@@ -103,6 +103,13 @@ int lidal_kmap_build(const void* table, int64_t table_bytes, const int32_t* out_
                      int64_t n_out, const int32_t* offsets, int k, int symmetric, int32_t* nbr_out,
                      int32_t* nbmaps, int32_t* nbsizes, int64_t* koff, int mode, void* ws,
                      int64_t ws_bytes, void* stream);
+/* From torchsparse-order rule lists (what backend.convolution_forward_cuda(in, out, W, nbmaps, nbsizes,
+ * transposed) receives: nbmaps i32 [n_rules, 2] = (in, out) grouped by offset, nbsizes i32 [k], both on
+ * the device; n_rules = capacity of nbmaps >= sum(nbsizes)) to the neighbour table lidal_kmap_order /
+ * lidal_conv_apply_image consume: nbr_out i32 [k, n_out], -1 where an offset has no rule for a row.
+ * n_bad_dev i32 [1] counts rules with an index out of range (0 = fine). */
+int lidal_kmap_from_rules(const int32_t* nbmaps, const int32_t* nbsizes, int k, int64_t n_rules,
+                          int64_t n_in, int64_t n_out, int32_t* nbr_out, int32_t* n_bad_dev, void* stream);
 /* nbr_in i32 [k, n_in]: output row fed by input row i through offset k, or -1 (inverse table, used
  * by data-gradient and transposed convolution). */
 int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr_in, int64_t n_in,
@@ -219,6 +226,9 @@ int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const i
  * output column, (count, mean, M2) of the values as stored -- the batch statistics of a train-mode
  * BatchNorm that follows (network/utils.py:115), taken in the epilogue instead of by a pass over the
  * stored matrix; merged by lidal_bn_train_fwd_tiles. */
+/* Rows per tile of the per-tile BatchNorm statistics lidal_conv_apply_image can leave (tile_stats is
+ * f32 [ceil(n_out / rows), co, 3]): size the buffer from this, not from a constant. */
+int lidal_conv_stats_tile_rows(void);
 int64_t lidal_conv_weight_image_bytes(int k, int ci, int co, int dtype, int64_t n_out);
 /* identifies the tiling an image is built for (two n_out with the same value share images: a
  * host-side cache key for weights that do not change between calls, i.e. inference) */

@@ -47,6 +47,7 @@ SIGNATURES = {
     'lidal_kmap_build': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                 _i64, _vp]),
     'lidal_kmap_invert': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp]),
+    'lidal_kmap_from_rules': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     'lidal_count': (_i32, [_vp, _i64, _vp, _i64, _vp]),
     'lidal_voxelize_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     'lidal_voxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     'lidal_kmap_order_batch': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
                                 _vp, _i32, _vp, _vp]),
+    'lidal_conv_stats_tile_rows': (_i32, []),
     'lidal_conv_weight_image_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
     'lidal_conv_weight_image_tiling': (_i32, [_i32, _i32, _i32, _i64]),
     'lidal_conv_weight_image': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
@@ -115,7 +117,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._handle, name)
-        if fn.restype is not _i32 or name.endswith(('_bytes', '_tiling')) or name == 'lidal_version':
+        if fn.restype is not _i32 or name.endswith(('_bytes', '_tiling', '_rows')) or name == 'lidal_version':
             return fn                               # size queries: no kernel behind them
         sink = self._sink
 
@@ -407,3 +409,13 @@ def compute_dtype(x):
     if torch.is_autocast_enabled():
         return torch.bfloat16 if torch.get_autocast_dtype('cuda') == torch.bfloat16 else torch.float32
     return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+
+
+_STATS_ROWS = [0]
+
+
+def stats_tile_rows():
+    """Rows per tile of the BatchNorm statistics the convolution kernels leave (asked of the library once)."""
+    if not _STATS_ROWS[0]:
+        _STATS_ROWS[0] = int(lib_handle().lidal_conv_stats_tile_rows())
+    return _STATS_ROWS[0]

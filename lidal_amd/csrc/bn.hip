@@ -13,10 +13,7 @@ using namespace lidal;
 namespace {
 
 constexpr int NT = 256;
-#ifndef LIDAL_BN_UNR
-#define LIDAL_BN_UNR 4
-#endif
-constexpr int UNR = LIDAL_BN_UNR;      // row loads in flight per thread (per operand)
+constexpr int UNR = 4;      // row loads in flight per thread (per operand)
 constexpr int MIN_ROWS_PER_WG = 32;    // rows per workgroup (one statistics partial each), at least
 
 template <typename T> struct IO;
@@ -400,11 +397,9 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
 // (per-channel parameters, and an LDS tree in the reducing kernels), so fewer and larger slabs win
 // as long as every CU has one; and an equal share per CU matters: with 512-row slabs the 396k-row
 // level ran as 775 workgroups, 3.03 per CU (measured sweep: profiles/README.md).
-#ifndef LIDAL_BN_WGS
-#define LIDAL_BN_WGS 256
-#endif
+constexpr int BN_WGS = 256;
 static inline int slab_rows(int64_t n) {
-  int64_t rpw = (n + LIDAL_BN_WGS - 1) / LIDAL_BN_WGS;
+  int64_t rpw = (n + BN_WGS - 1) / BN_WGS;
   if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
   return (int)rpw;
 }

@@ -44,18 +44,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // 96-column kernels, 4 waves x 2 groups (each weight fragment read from LDS feeds two MFMAs)
 // elsewhere in bf16 (scripts/ablate_conv.py: 96->96 137.9 -> 127.3 us, 64->64 35.7 -> 34.5, but 32->32
 // 45.7 -> 47.4 and 256->256 at stride 16 106 -> 112); the f32 kernels (MFMA-bound, 4x the MFMA
-// issue slots per fragment) gain 6-19 % from 8 x 1 at every width.  -DLIDAL_G / -DLIDAL_NWAVES force
-// one shape.
-#if defined(LIDAL_G) && defined(LIDAL_NWAVES)
-constexpr int conv_groups(int, bool) { return LIDAL_G; }
-constexpr int conv_waves(int, bool) { return LIDAL_NWAVES; }
-#elif defined(LIDAL_G)
-constexpr int conv_groups(int, bool) { return LIDAL_G; }
-constexpr int conv_waves(int, bool) { return 4; }
-#else
+// issue slots per fragment) gain 6-19 % from 8 x 1 at every width.
 constexpr int conv_groups(int nb, bool f32) { return (f32 || nb == 4 || nb == 6) ? 1 : 2; }
 constexpr int conv_waves(int nb, bool f32) { return (f32 || nb == 4 || nb == 6) ? 8 : 4; }
-#endif
 
 // 16 raw bytes of a lane's operand fragment: the A fragments travel through the software pipeline
 // in this type (as <8 x bf16> hipcc splits them into halves at every loop-carried value, which
@@ -110,34 +101,13 @@ __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b
 // result is first touched by the MFMA (no exec-masked control flow, no early vmcnt waits).
 __device__ __attribute__((aligned(16))) unsigned char g_zero_page[512];
 
-// Diagnostic build only (-DLIDAL_STAMP, scripts/ablate_conv.py): cycle stamps around the four
-// segments of a phase, summed per wave and added into g_stamp at the end of the kernel.  The
-// fences a stamp needs forbid overlaps the real kernel has: read the SHARES, not the run time.
-#ifdef LIDAL_STAMP
-__device__ unsigned long long g_stamp[8];
-#define LIDAL_STAMP_AT(t)                                                          \
-  do {                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");      \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-  } while (0)
-#endif
 
 // ------------------------------------------------------------------------------------------
 // conv_apply
 // ------------------------------------------------------------------------------------------
 constexpr int MAXK = 32;         // kernel volume limit (27 and 8 on this path)
 
-#ifndef LIDAL_MINWAVES
-#define LIDAL_MINWAVES(nb) 2      /* 3 for nb <= 6 measured no better (scripts/ablate_conv.py) */
-#endif
-
-// Timing-only ablation builds (scripts/ablate_conv.py): -DLIDAL_ABLATE=<mask> removes one cost at a
-// time; results are wrong by construction.  1: no A gather  2: no weight staging  4: no MFMA
-// 16: no epilogue store
-#ifndef LIDAL_ABLATE
-#define LIDAL_ABLATE 0
-#endif
+constexpr int CONV_MINWAVES = 2;       // 3 for nb <= 6 measured no better
 
 // LDS layout (dynamic): weights T [2][BN][WSTRIDE] | nidx int [4 waves][K][G*16]
 // (the weight region is re-used as the epilogue staging tile)
@@ -146,7 +116,7 @@ constexpr int MAXK = 32;         // kernel volume limit (27 and 8 on this path)
 // wholly inside the row or wholly masked, which keeps the gathers branch-free and un-serialised
 // (the guarded form made hipcc wait vmcnt(0) after every load).
 template <typename T, int NB, int ROW_BYTES, bool GUARD, int G, int NWAVES>
-__global__ void __launch_bounds__(64 * NWAVES, LIDAL_MINWAVES(NB))
+__global__ void __launch_bounds__(64 * NWAVES, CONV_MINWAVES)
 conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int* __restrict__ nbr,
                   const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
                   T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
@@ -268,7 +238,7 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     const int sidx = tid + t * NTHREADS;
     const int col = sidx / SEGS, x = (sidx - col * SEGS) * VEC;
     wx[t] = x;
-    woff[t] = (sidx < BN * SEGS && n0 + col < co && !(LIDAL_ABLATE & 2))
+    woff[t] = (sidx < BN * SEGS && n0 + col < co)
                   ? (unsigned)((col * ci + x) * (int)sizeof(T)) : OOB_OFF;
   }
   // `live` false turns every load of a phase into an out-of-range one by OR-ing the top offset bit;
@@ -330,13 +300,13 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
 #pragma unroll
         for (int cc = 0; cc < MAXCC; ++cc) {
           const int x = cc * CH + gsel * VEC;
-          const bool ok = src >= 0 && x < kc && !(LIDAL_ABLATE & 1);
+          const bool ok = src >= 0 && x < kc;
           frag f = DT<T>::zero();
           if (ok) f = load_frag_guarded<T>(in + (int64_t)src * ci + c0 + x, kc - x);
           a[g][cc] = __builtin_bit_cast(raw4, f);
         }
       } else {
-        const unsigned base = ((src >= 0 && !(LIDAL_ABLATE & 1)) ? (unsigned)src * row_bytes + lane_off
+        const unsigned base = ((src >= 0) ? (unsigned)src * row_bytes + lane_off
                                                                   : OOB_OFF) | kill;
 #pragma unroll
         for (int cc = 0; cc < MAXCC; ++cc) {
@@ -378,15 +348,8 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
   }
   __syncthreads();            // slab 0 visible
 
-#ifdef LIDAL_STAMP
-  unsigned long long st_sum[4] = {0ull, 0ull, 0ull, 0ull};
-#endif
   auto phase = [&](int p, raw4 (&a_cur)[G][MAXCC], unsigned long long (&pres_cur)[G],
                    raw4 (&a_nxt)[G][MAXCC], unsigned long long (&pres_nxt)[G]) {
-#ifdef LIDAL_STAMP
-    unsigned long long st0, st1, st2, st3, st4;
-    LIDAL_STAMP_AT(st0);
-#endif
     const int c0 = (p % npass) * KC;
     const int kc = min(KC, ci - c0);
     const T* wbuf = wl + (p & 1) * BN * WSTRIDE;
@@ -400,9 +363,6 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     load_a(a_nxt, pres_nxt, idx_nxt, w1.pass * KC, more);
     walk_next(w1);
     read_idx(idx_nxt, w1.k);               // for the phase after next; first used a phase from now
-#ifdef LIDAL_STAMP
-    LIDAL_STAMP_AT(st1);
-#endif
     // ---- MFMAs: every B fragment read from LDS feeds the G row groups; accumulators stay in
     //      registers for all K offsets.  A wave skips the phase when none of its 32 rows has a rule
     //      for this offset; otherwise the MFMA block is branch-free (per-group skipping cost more
@@ -410,7 +370,7 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
     bool any_present = false;
 #pragma unroll
     for (int g = 0; g < G; ++g) any_present |= pres_cur[g] != 0ull;
-    if (any_present && !(LIDAL_ABLATE & 4)) {
+    if (any_present) {
       const T* wbase = wbuf + row16 * WSTRIDE + gsel * VEC;
 #pragma unroll
       for (int cc = 0; cc < MAXCC; ++cc) {
@@ -424,34 +384,16 @@ conv_apply_kernel(const T* __restrict__ in, const T* __restrict__ wk, const int*
         }
       }
     }
-#ifdef LIDAL_STAMP
-    LIDAL_STAMP_AT(st2);
-#endif
     if (more) stage_store((p + 1) & 1);     // waits for the slab loads only: they were issued first
-#ifdef LIDAL_STAMP
-    LIDAL_STAMP_AT(st3);
-#endif
     __syncthreads();
-#ifdef LIDAL_STAMP
-    LIDAL_STAMP_AT(st4);
-    st_sum[0] += st1 - st0; st_sum[1] += st2 - st1; st_sum[2] += st3 - st2; st_sum[3] += st4 - st3;
-#endif
   };
   for (int p = 0; p < nphase; p += 2) {
     phase(p, a0, pres0, a1, pres1);
     if (p + 1 < nphase) phase(p + 1, a1, pres1, a0, pres0);
   }
-#ifdef LIDAL_STAMP
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) atomicAdd(&g_stamp[i], st_sum[i]);
-    atomicAdd(&g_stamp[4], (unsigned long long)nphase);
-  }
-#endif
 
   // ---- epilogue: accumulators (D layout: col = lane&15, row = 4*(lane>>4) + r) -> wave-private
   //      LDS tile in T -> whole rows to HBM with 16-byte stores
-  if (LIDAL_ABLATE & 16) return;
   T* et = wl + wave * RW * ESTRIDE;
   if (ep_scale != nullptr) {       // inference: y = act(acc * scale[col] + shift[col]) (folded BN)
 #pragma unroll
@@ -570,9 +512,6 @@ int dispatch_conv_apply(const void* in, const void* wk, const int* nbr, const in
   const int row_bytes = ci * (int)sizeof(T);
   if (ci % DT<T>::VEC != 0)       // irregular channel count (4-channel bf16 stem): guarded loads
     return dispatch_conv_cols<T, 128, true>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
-#ifdef LIDAL_ROWB_OVERRIDE
-  return dispatch_conv_cols<T, LIDAL_ROWB_OVERRIDE, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
-#endif
   if (row_bytes % 192 == 0 && row_bytes % 128 != 0)
     return dispatch_conv_cols<T, 192, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
   return dispatch_conv_cols<T, 128, false>(in, wk, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
@@ -754,9 +693,6 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // exactly that from the row-major tiles the 16-byte gathers produce, so no transposing store is
 // needed.  BPB = 64 rules per step (two MFMA k-steps), LDS tiles double-buffered, gathered rows of
 // the next step are in flight in registers while this step's MFMAs run; one barrier per step.
-#ifndef LIDAL_WGRAD_ABL
-#define LIDAL_WGRAD_ABL 0      /* timing-only probes (results wrong): 1 = both gathers folded into 2048 rows */
-#endif
 constexpr int BPB = 64;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
@@ -811,7 +747,6 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
       int2 pr = pairs ? pairs[pc] : make_int2((int)pc, (int)pc);
       if (pi >= p_end) pr = make_int2(-1, -1);
       ia[t] = a_col ? pr.y : pr.x;
-      if (LIDAL_WGRAD_ABL & 1) ia[t] = ia[t] < 0 ? ia[t] : (ia[t] & 2047);     // timing probe: L2-resident gathers
     }
 #pragma unroll
     for (int t = 0; t < PT_B; ++t) {
@@ -820,7 +755,6 @@ conv_wgrad_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ 
       int2 pr = pairs ? pairs[pc] : make_int2((int)pc, (int)pc);
       if (pi >= p_end) pr = make_int2(-1, -1);
       ib[t] = a_col ? pr.x : pr.y;
-      if (LIDAL_WGRAD_ABL & 1) ib[t] = ib[t] < 0 ? ib[t] : (ib[t] & 2047);
     }
   };
   auto load_rows = [&]() {
@@ -936,11 +870,7 @@ int launch_wgrad(const void* a, const void* b, const int* pairs, const int64_t* 
   dim3 grid((unsigned)splits, (unsigned)K, (unsigned)(tiles_a * tiles_b));
   if constexpr (sizeof(T) == 2) {
     const size_t lds = 2 * BPB * ((TA + 8) + (TB + 8)) * sizeof(__bf16);
-#ifdef LIDAL_WGRAD_FORCE_GUARD
-    const bool guard = true;
-#else
     const bool guard = (ca % 8 != 0) || (cb % 8 != 0);
-#endif
     auto kern = guard ? conv_wgrad_bf16_kernel<MI, NI, true> : conv_wgrad_bf16_kernel<MI, NI, false>;
     static size_t attr_set[2][MAX_DEVICES] = {};
     const int dev = current_device();
@@ -979,17 +909,6 @@ int dispatch_wgrad(const void* a, const void* b, const int* pairs, const int64_t
 
 }  // namespace
 
-#ifdef LIDAL_STAMP
-extern "C" int lidal_debug_stamps(unsigned long long* out8, int reset) {
-  LIDAL_HIP(hipDeviceSynchronize());
-  LIDAL_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8));
-  if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    LIDAL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)));
-  }
-  return 0;
-}
-#endif
 
 extern "C" int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void* wc, int wt_dtype,
                                       int k, int ci, int co, void* stream) {

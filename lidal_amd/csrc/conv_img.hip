@@ -55,13 +55,8 @@ __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b
 
 constexpr int MAXK = 32;
 
-#ifndef LIDAL_NB4_LIMIT
-#define LIDAL_NB4_LIMIT 384
-#endif
+constexpr int NB4_LIMIT = 384;        // tiles up to which a 64-multiple column count takes 64-column blocks
 // ---- tiling policy, shared by the image packer and the launcher ------------------------------
-#ifndef LIDAL_RB256
-#define LIDAL_RB256(row_bytes, co) 0
-#endif
 struct Tiling { int nb; int row_bytes; };       // 16-column blocks per workgroup, staged bytes per pass
 
 __host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int esz) {
@@ -71,11 +66,10 @@ __host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int
   // multiples (96 bf16 channels), 64 for the other rows that 128 does not divide (32 bf16 channels)
   t.row_bytes = (row_bytes % 192 == 0 && row_bytes % 128 != 0) ? 192
                 : (row_bytes % 128 != 0 && row_bytes % 64 == 0) ? 64 : 128;
-  // 256-byte slices where the rows allow it: half the phases (barriers, waits) per offset on the
-  // layers of >= 128 channels (LIDAL_RB256: which (ci bytes, co) take them)
-  if (row_bytes % 256 == 0 && LIDAL_RB256(row_bytes, co)) t.row_bytes = 256;
+  // (256-byte slices -- half the phases per offset on the layers of >= 128 channels -- measured no
+  // better, profiles/README.md; the 256-byte kernels stay instantiated for the image packer's sake)
   if (co <= 32) t.nb = 2;
-  else if (co <= 64 || (co % 64 == 0 && ((n_out + 127) / 128) * ((co + 127) / 128) <= LIDAL_NB4_LIMIT)) t.nb = 4;
+  else if (co <= 64 || (co % 64 == 0 && ((n_out + 127) / 128) * ((co + 127) / 128) <= NB4_LIMIT)) t.nb = 4;
   else if (co % 128 != 0 && (co % 96 == 0 || co < 128)) t.nb = 6;
   else t.nb = 8;
   return t;
@@ -155,24 +149,10 @@ weight_image_batch_kernel(const ImageJob* __restrict__ jobs, int n_jobs, int64_t
     image_segment<TI, TO>((const TI*)j.w, (TO*)j.img_b, j.n_col, j.n_red, j.role ^ 1, j.nb_b, j.kc_b, l - j.segs_a);
 }
 
-// Timing-only ablation builds (scripts/exp_img.py with an A/B library): results are wrong by
-// construction.  1: A gathers folded into the first 2048 rows (L2-resident: what perfect gather
-// locality would buy)  2: no weight DMA  4: no MFMA / fragment reads  8: no A gathers  16: no epilogue
-#ifndef LIDAL_LEAN_BBATCH
-#define LIDAL_LEAN_BBATCH(nb) (nb)
-#endif
-#ifndef LIDAL_LEAN_WAVES
-#define LIDAL_LEAN_WAVES(nb, row_bytes) 8
-#endif
-#ifndef LIDAL_LEAN_NOSKIP
-#define LIDAL_LEAN_NOSKIP 0
-#endif
-#ifndef LIDAL_LEAN_MINWAVES
-#define LIDAL_LEAN_MINWAVES 4      /* waves per SIMD the register budget must allow: 2 workgroups per CU */
-#endif
-#ifndef LIDAL_IMG_ABL
-#define LIDAL_IMG_ABL 0
-#endif
+// Tuning constants of the lean kernel (the measured alternatives are in profiles/README.md; the timing-only
+// ablation switches of rounds 1-2 lived here and are gone: scripts/exp/README.md names the commit that has them)
+constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (16 waves / 256 rows measured slower)
+constexpr int LEAN_MINWAVES = 4;       // waves per SIMD the register budget must allow: 2 workgroups per CU
 
 // ---- epilogue shared by the kernels of this file (as conv.hip): accumulators (D layout: col =
 // lane&15, row = 4*(lane>>4) + r) -> wave-private LDS tile in T -> whole rows to HBM, 16-byte stores,
@@ -194,7 +174,6 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
   constexpr int ESTRIDE = BN + VEC;
   typedef typename DT<T>::frag frag;
   const int row16 = lane & 15, gsel = lane >> 4;
-  if (LIDAL_IMG_ABL & 16) return;
   T* et = reinterpret_cast<T*>(wl) + wave * RW * ESTRIDE;
   if (ep_scale != nullptr) {
 #pragma unroll
@@ -314,9 +293,7 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
-#ifndef LIDAL_IMG_MINWAVES
-#define LIDAL_IMG_MINWAVES 2
-#endif
+constexpr int IMG_MINWAVES = 2;
 
 // LDS (dynamic): ring of D+1 weight slabs (re-used as the epilogue tile) | dump 1 KiB.  The
 // neighbour indices never touch LDS: each lane loads the index of ITS row straight from the permuted
@@ -415,7 +392,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
       const int piece = wave + t * NWAVES;
       const bool ok = live && piece < PIECES;
       unsigned char* dst = ok ? wl + slot * SLAB + piece * 1024 : dump;
-      const unsigned soff = (ok && !(LIDAL_IMG_ABL & 2)) ? slab_off + (unsigned)piece * 1024u : OOB_OFF;
+      const unsigned soff = ok ? slab_off + (unsigned)piece * 1024u : OOB_OFF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)dst, 16,
                                                (unsigned)lane * 16u, soff, 0, 0);
     }
@@ -455,8 +432,6 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       int src = row_ok[g] ? idx[g] : -1;
-      if ((LIDAL_IMG_ABL & 1) && src >= 0) src &= 2047;
-      if (LIDAL_IMG_ABL & 8) src = (src >= 0) ? -2 : -1;
       present[g] = __ballot(src != -1) & live_mask;
       const unsigned base = ((src >= 0) ? (unsigned)src * row_bytes + lane_off : OOB_OFF) | kill;
 #pragma unroll
@@ -534,7 +509,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
     bool any_present = false;
 #pragma unroll
     for (int g = 0; g < G; ++g) any_present |= pres[s][g] != 0ull;
-    if (any_present && !(LIDAL_IMG_ABL & 4)) {
+    if (any_present) {
       const unsigned char* wbase = wbuf + (gsel * NB) * 256 + row16 * 16;
 #pragma unroll
       for (int cc = 0; cc < MAXCC; ++cc) {
@@ -547,12 +522,6 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
           }
         }
       }
-    }
-    if (LIDAL_IMG_ABL & 4) {        // keep the gathers alive without their consumer
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int cc = 0; cc < MAXCC; ++cc) asm volatile("" ::"v"(a[s][g][cc]));
     }
     __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));       // slab(p+1) landed
     __syncthreads();
@@ -594,7 +563,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
 // into the MFMA lane layout (the addresser merges a quad into one request: the loads alone got
 // 8-18 % cheaper in a timing probe, but the twelve bpermutes per phase cost more: 99 vs 94 us).
 template <typename T, int NB, int ROW_BYTES, int NWAVES, bool DENSE>
-__global__ void __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? LIDAL_LEAN_MINWAVES : 4))
+__global__ void __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? LEAN_MINWAVES : 4))
 conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int* __restrict__ nbr,
                  const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
@@ -686,7 +655,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   };
   auto issue_dma = [&](int k, int pass, auto slot_c) {
     constexpr int slot = decltype(slot_c)::value;
-    if (dma_wave && !(LIDAL_IMG_ABL & 2)) {
+    if (dma_wave) {
       const unsigned soff = (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base;
       static_assert(PPW <= 12, "DMA share");
       // four 1-KiB pieces per M0 value (the immediate offset field ends at 4095)
@@ -705,9 +674,8 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   // Lanes of rows without one aim out of range: zeros, no memory access.
   auto issue_a = [&](raw4 (&a)[MAXCC], int idx, int pass) __attribute__((always_inline)) -> unsigned long long {
     const bool has = idx >= 0 && row_in;
-    if (LIDAL_IMG_ABL & 1) idx &= 2047;
     unsigned off = __umul24((unsigned)idx, row_bytes) + lane_off;
-    off = (has && !(LIDAL_IMG_ABL & 8)) ? off : OOB_OFF;
+    off = has ? off : OOB_OFF;
     const unsigned soff = (unsigned)pass * (unsigned)ROW_BYTES;
 #pragma unroll
     for (int cc = 0; cc < MAXCC; ++cc)
@@ -721,8 +689,8 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
 
   auto compute = [&](const raw4 (&a)[MAXCC], unsigned long long have, auto slot_c) __attribute__((always_inline)) {
     constexpr int slot = decltype(slot_c)::value;
-    if (have != 0ull && !(LIDAL_IMG_ABL & 4)) {       // a wave none of whose 16 rows has a rule skips
-      constexpr int BB = LIDAL_LEAN_BBATCH(NB);       // fragment reads issued as one batch
+    if (have != 0ull) {       // a wave none of whose 16 rows has a rule skips
+      constexpr int BB = NB;          // fragment reads issued as one batch
 #pragma unroll
       for (int cc = 0; cc < MAXCC; ++cc) {
 #pragma unroll
@@ -735,10 +703,6 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
           for (int j = 0; j < BB; ++j) mma(acc[0][nb0 + j], __builtin_bit_cast(frag, a[cc]), b[j]);
         }
       }
-    }
-    if (LIDAL_IMG_ABL & 4) {
-#pragma unroll
-      for (int cc = 0; cc < MAXCC; ++cc) asm volatile("" ::"v"(a[cc]));
     }
   };
   // the next slab has landed: of this wave's loads only the MAXCC gathers issued behind its DMA may
@@ -793,312 +757,32 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
 }
 
 
-// ------------------------------------------------------------------------------------------
-// EXPERIMENT (not in the shipped library; -DLIDAL_CONV_DMA builds it): rows AND weights by LDS-DMA
-// ------------------------------------------------------------------------------------------
-// Measured (scripts/exp_img.py, bit-equal to the shipped kernels on every shape), 96->96 on 396k rows,
-// lean kernel 92 us:
-//   * one tile per workgroup, ring of 3 (rows + slab) stages = 129 KB, one workgroup per CU: 160 us
-//     (156 at depth 1) -- a tile is ~7 phases, its prologue (ids, then rows: two memory round trips)
-//     and write-out are covered by nothing;
-//   * the persistent form below (one phase stream through all tiles of a workgroup, next tile's loads
-//     in flight during the write-out): 182 us.  Ablations: without the row gathers 186 us, without the
-//     LDS reads / MFMAs 109 us, with neither 87 us.  Not the memory: four waves per CU (one per
-//     SIMD) expose every latency of the issue path (id reads, 12 DMA issues with their M0 writes,
-//     three scalar walks: ~1 us per phase) and of the fragment reads (~1.2 us per phase), and they
-//     add up instead of overlapping.
-// The weight gradient (wgrad_dma.hip) wins with the same data path because its stages carry the same
-// bytes with a third of the bookkeeping and nothing to write out.  What would be needed here is a
-// producer/consumer split with 8 consumer waves -- whose weight-fragment reads then fill the LDS
-// pipe (144 KB per phase).  Kept as the record of the experiment.
-#ifdef LIDAL_CONV_DMA
-template <int SEG>
-__device__ __forceinline__ int swz_a(int row, int seg) {
-  if constexpr (SEG == 12) { const int s = seg + ((row >> 2) & 3); return s >= 12 ? s - 12 : s; }
-  if constexpr (SEG == 8) return seg ^ ((row >> 1) & 7);
-  if constexpr (SEG == 4) return seg ^ ((row >> 2) & 3);
-  return seg;
-}
-template <int SEG>
-__device__ __forceinline__ int unswz_a(int row, int phys) {
-  if constexpr (SEG == 12) { const int s = phys - ((row >> 2) & 3); return s < 0 ? s + 12 : s; }
-  return swz_a<SEG>(row, phys);
-}
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long p = (unsigned long long)base;
-  return u32x4{(unsigned)p, (unsigned)(p >> 32) & 0xFFFFu, bytes, 0x00020000u};
-}
-__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_base, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ void dma4(u32x4 rsrc, unsigned lds_base, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
-               :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
-}
-#ifndef LIDAL_DMA_DEPTH
-#define LIDAL_DMA_DEPTH 2
-#endif
-
-#ifndef LIDAL_DMA_PERSIST
-#define LIDAL_DMA_PERSIST 256        /* workgroups per column block: one per CU */
-#endif
-constexpr int DMA_MAX_TILES = 256;    // tiles one persistent workgroup may own (its masks sit in LDS)
-
-// Persistent form: workgroup b owns tiles b, b + P, b + 2P, ... and runs ONE phase stream through
-// all of them -- the ids / weights / rows of the next tile are already in flight while this tile is
-// written out, so a tile's prologue and epilogue cost no memory idle time (the one-tile-per-workgroup
-// form above measured 160 us on the roofline layer: ~13 us per 7-phase tile).
-// LDS: A ring [3][128 rows x slice] | W ring [2][slab] | ids ring [5][512 B] | dump 1 KiB |
-//      tile masks [256] | epilogue tile + statistics.
-// Issue order of phase q: ids(q+4), W(q+1), A(q+2); the wait at the top of phase q needs W(q) (issued
-// a phase ago) and everything older, so only the A share issued behind it may still be in flight.
-template <int NB, int ROW_BYTES>
-__global__ void __launch_bounds__(256)
-conv_dma_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wimg,
-                const int* __restrict__ nbr, const int* __restrict__ perm,
-                const unsigned* __restrict__ tmasks, __bf16* __restrict__ out, int64_t n_out, int ci,
-                int co, int K, int kflip, const float* __restrict__ ep_scale,
-                const float* __restrict__ ep_shift, int ep_relu, const __bf16* __restrict__ ep_res,
-                unsigned in_bytes, unsigned img_bytes, unsigned nbr_bytes,
-                float* __restrict__ tile_stats, int n_tiles) {
-  typedef __bf16 T;
-  constexpr int NW = 4, G = 2, BM = NW * G * 16, BN = 16 * NB;
-  constexpr int KC = ROW_BYTES / 2, MAXCC = ROW_BYTES / 64, SEG = ROW_BYTES / 16;
-  constexpr int A_BYTES = BM * ROW_BYTES, SLAB = BN * ROW_BYTES;
-  constexpr int RA = 3, RW_ = 2, IDS_R = 5, IDS_BYTES = BM * 4;
-  constexpr int IA = A_BYTES / 1024 / NW;                 // row DMAs per wave and phase
-  constexpr int WP = SLAB / 1024, IW = (WP + NW - 1) / NW;      // slab pieces; per wave (surplus -> dump)
-  constexpr int EPI = NW * G * 16 * (BN + 8) * 2 + NW * BN * 2 * (int)sizeof(float);
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  static_assert(A_BYTES % (1024 * NW) == 0 && SLAB % 1024 == 0 && IA < 64, "DMA shares");
-  typedef DT<T>::frag frag;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr int OFF_W = RA * A_BYTES, OFF_IDS = OFF_W + RW_ * SLAB, OFF_DUMP = OFF_IDS + IDS_R * IDS_BYTES;
-  constexpr int OFF_MASK = OFF_DUMP + 1024, OFF_EPI = OFF_MASK + DMA_MAX_TILES * 4;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  unsigned* lmask = reinterpret_cast<unsigned*>(smem + OFF_MASK);
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int row16 = lane & 15, gsel = lane >> 4;
-  const int n0 = blockIdx.y * BN;
-  const int npass = ci / KC;
-  const int P = gridDim.x, bx = blockIdx.x;
-  const int my_tiles = (n_tiles - bx + P - 1) / P;
-
-  for (int t = threadIdx.x; t < my_tiles; t += 256) {
-    unsigned m = tmasks[bx + t * P];
-    if (kflip) m = __brev(m) >> (32 - K);
-    lmask[t] = m;
-  }
-  __syncthreads();
-
-  const u32x4 rs_in = raw_rsrc(in, in_bytes), rs_w = raw_rsrc(wimg, img_bytes), rs_nbr = raw_rsrc(nbr, nbr_bytes);
-  const unsigned row_bytes = (unsigned)ci * 2u;
-  const unsigned k_stride = (unsigned)n_out * 4u;
-  const unsigned slab_k = (unsigned)gridDim.y * (unsigned)npass * (unsigned)SLAB;
-  const unsigned slab_blk = (unsigned)blockIdx.y * (unsigned)npass * (unsigned)SLAB;
-
-  // this lane's share of an A stage: tile row + byte offset inside the slice for each row DMA
-  int arow[IA];
-  unsigned acol[IA];
-#pragma unroll
-  for (int i = 0; i < IA; ++i) {
-    const int sg = 64 * (wave * IA + i) + lane, row = sg / SEG;
-    arow[i] = row;
-    acol[i] = (unsigned)unswz_a<SEG>(row, sg % SEG) * 16u;
-  }
-
-  // a walk over the workgroup's phase stream: tiles in order, inside a tile its (active offset, slice)
-  struct Walk { int i; unsigned rem; int k, pass, q; long long rt; bool live; };
-  auto walk_init = [&](int q0) { Walk w; w.i = -1; w.rem = 0u; w.k = 0; w.pass = npass - 1; w.q = q0; w.rt = 0; w.live = true; return w; };
-  auto walk_next = [&](Walk& w) __attribute__((always_inline)) {
-    ++w.q;
-    if (!w.live) return;
-    if (++w.pass == npass) {
-      w.pass = 0;
-      while (w.rem == 0u) {
-        if (++w.i >= my_tiles) { w.live = false; return; }
-        w.rem = __builtin_amdgcn_readfirstlane(lmask[w.i]);
-        w.rt = (long long)(bx + w.i * P) * BM;
-      }
-      w.k = __builtin_ctz(w.rem);
-      w.rem &= w.rem - 1u;
-    }
-  };
-  // ids of phase q: the tile's 128 entries of one offset's table row; waves 0 / 1 bring rows 0..63 /
-  // 64..127, waves 2 / 3 repeat them (every wave keeps the same number of loads in flight)
-  Walk wi = walk_init(-1), ww = walk_init(-1), wr = walk_init(-1);
-  auto issue_ids = [&]() __attribute__((always_inline)) {
-    walk_next(wi);
-    const long long r = wi.rt + 64 * (wave & 1) + lane;
-    const unsigned kk = (unsigned)(kflip ? (K - 1 - wi.k) : wi.k);
-    const unsigned off = (wi.live && r < n_out) ? (unsigned)r * 4u + kk * k_stride : OOB;
-    dma4(rs_nbr, lds0 + OFF_IDS + (unsigned)(wi.q % IDS_R) * IDS_BYTES + (unsigned)(wave & 1) * 256u, off);
-  };
-  auto issue_w = [&]() __attribute__((always_inline)) {
-    walk_next(ww);
-    const unsigned dst = lds0 + OFF_W + (unsigned)(ww.q % RW_) * SLAB;
-    const unsigned wsrc = (unsigned)ww.k * slab_k + slab_blk + (unsigned)ww.pass * (unsigned)SLAB + (unsigned)lane * 16u;
-#pragma unroll
-    for (int i = 0; i < IW; ++i) {
-      const int piece = wave * IW + i;
-      const bool okw = ww.live && piece < WP && !(LIDAL_IMG_ABL & 2);
-      dma16(rs_w, piece < WP ? dst + (unsigned)piece * 1024u : lds0 + OFF_DUMP, okw ? wsrc + (unsigned)piece * 1024u : OOB);
-    }
-  };
-  auto issue_a = [&]() __attribute__((always_inline)) {
-    walk_next(wr);
-    const unsigned stage = lds0 + (unsigned)(wr.q % RA) * A_BYTES;
-    const unsigned char* ids = smem + OFF_IDS + (wr.q % IDS_R) * IDS_BYTES;
-    int id[IA];
-#pragma unroll
-    for (int i = 0; i < IA; ++i) id[i] = *reinterpret_cast<const int*>(ids + arow[i] * 4);
-#pragma unroll
-    for (int i = 0; i < IA; ++i) asm volatile("" : "+v"(id[i]));
-    const unsigned pass_off = (unsigned)wr.pass * (unsigned)ROW_BYTES;
-#pragma unroll
-    for (int i = 0; i < IA; ++i) {
-      if (LIDAL_IMG_ABL & 1) id[i] = id[i] < 0 ? id[i] : (id[i] & 2047);
-      const bool ok = wr.live && id[i] >= 0 && wr.rt + arow[i] < n_out && !(LIDAL_IMG_ABL & 8);
-      const unsigned off = ok ? (unsigned)id[i] * row_bytes + pass_off + acol[i] : OOB;
-      dma16(rs_in, stage + (unsigned)(wave * IA + i) * 1024u, off);
-    }
-  };
-
-  // fragment addresses: A rows of this wave's two groups (segment permutation by row), weight base
-  int fa[G][MAXCC];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int cc = 0; cc < MAXCC; ++cc) {
-      const int row = wave * 32 + g * 16 + row16;
-      fa[g][cc] = row * ROW_BYTES + swz_a<SEG>(row, cc * 4 + gsel) * 16;
-    }
-  const int fw = OFF_W + (gsel * NB) * 256 + row16 * 16;
-
-  // prologue: ids of the first two phases, then two issue rounds in the loop's own order
-  issue_ids();
-  issue_ids();
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  issue_ids();                    // ids(2)
-  {                               // W(-1): nothing to bring, the same number of loads
-#pragma unroll
-    for (int i = 0; i < IW; ++i) dma16(rs_w, lds0 + OFF_DUMP, OOB);
-  }
-  issue_a();                      // A(0)
-  issue_ids();                    // ids(3)
-  issue_w();                      // W(0)
-  issue_a();                      // A(1)
-
-  int q = 0;
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    const long long rt = (long long)(bx + ti * P) * BM;
-    const int64_t r0 = rt + wave * 32;
-    const int nph = __popc(__builtin_amdgcn_readfirstlane(lmask[ti])) * npass;
-    int perm_v = 0;
-    if (perm != nullptr && lane < 32 && r0 + lane < n_out) perm_v = perm[r0 + lane];
-    f32x4 acc[G][NB];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[g][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p = 0; p < nph; ++p, ++q) {
-      __builtin_amdgcn_s_waitcnt(0x0F70 | (IA & 15) | ((IA >> 4) << 14));
-      __syncthreads();
-      issue_ids();                // ids(q+4)
-      issue_w();                  // W(q+1)
-      issue_a();                  // A(q+2)
-      if (!(LIDAL_IMG_ABL & 4)) {
-        const unsigned char* sa = smem + (q % RA) * A_BYTES;
-        const unsigned char* sw = smem + (q % RW_) * SLAB;
-#pragma unroll
-        for (int cc = 0; cc < MAXCC; ++cc) {
-          frag a[G], b[NB];
-#pragma unroll
-          for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const frag*>(sa + fa[g][cc]);
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const frag*>(sw + fw + (cc * 4 * NB + nb) * 256);
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int g = 0; g < G; ++g) mma(acc[g][nb], a[g], b[nb]);
-        }
-      }
-    }
-    __syncthreads();              // the statistics area of the previous tile's write-out is free
-    store_tile<T, NB, G, NW>(acc, smem + OFF_EPI, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift,
-                             ep_relu, ep_res, true, perm_v, tile_stats, (int)(rt >> 7));
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);           // the zero fills past the end, before LDS is released
-}
-#endif  // LIDAL_CONV_DMA
 
 struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; };
 
-#ifndef LIDAL_IMG_G
-#define LIDAL_IMG_G 1
-#endif
-#ifndef LIDAL_IMG_NWAVES
-#define LIDAL_IMG_NWAVES 8
-#endif
-#ifndef LIDAL_IMG_DEPTH
-#define LIDAL_IMG_DEPTH 1
-#endif
+constexpr int IMG_G = 1, IMG_NWAVES = 8, IMG_DEPTH = 1;       // generic kernel: row groups per wave, waves, pipeline depth
+// rows per workgroup tile of every kernel of this file == rows per BatchNorm statistics triple
+constexpr int TILE_ROWS = 128;
 
 template <typename T, int NB, int ROW_BYTES>
 int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm, const unsigned* tmasks,
                void* out, int64_t n_out, int ci, int co, int K, int kflip, Epi ep, hipStream_t s) {
-  constexpr int G = LIDAL_IMG_G, NWAVES = LIDAL_IMG_NWAVES;
+  constexpr int G = IMG_G, NWAVES = IMG_NWAVES;
   constexpr int NTHREADS = 64 * NWAVES, BM = NWAVES * G * 16, BN = 16 * NB;
   constexpr int SLAB = BN * ROW_BYTES;
   constexpr int EPI = NWAVES * G * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
-  constexpr int D = LIDAL_IMG_DEPTH;
+  constexpr int D = IMG_DEPTH;
   constexpr int WREGION = ((D + 1) * SLAB > EPI) ? (D + 1) * SLAB : EPI;
-  static_assert(BM % 128 == 0, "tile masks are per 128 rows");
-#ifdef LIDAL_CONV_DMA      /* experiment builds: -D'LIDAL_CONV_DMA(nb,row_bytes,n_in,n_out)=1' picks the layers */
-  if constexpr (sizeof(T) == 2) {
-    const int64_t n_in = (int64_t)(ep.in_bytes / ((unsigned)ci * sizeof(T)));
-    if (nbr != nullptr && ci % (ROW_BYTES / 2) == 0 && (int64_t)n_in * ci * 2 < 0xFFFFFFF0ll &&
-        LIDAL_CONV_DMA(NB, ROW_BYTES, n_in, n_out)) {
-      constexpr int DEPI = 4 * 32 * (BN + 8) * 2 + 4 * BN * 2 * (int)sizeof(float);
-      constexpr int DLDS = 3 * 128 * ROW_BYTES + 2 * SLAB + 5 * 512 + 1024 + DMA_MAX_TILES * 4 + DEPI;
-      const int n_tiles = (int)cdiv(n_out, 128);
-      int persist = LIDAL_DMA_PERSIST;
-      if (persist > n_tiles) persist = n_tiles;
-      if (n_tiles > (int64_t)persist * DMA_MAX_TILES) persist = (int)cdiv(n_tiles, DMA_MAX_TILES);
-      auto dk = conv_dma_kernel<NB, ROW_BYTES>;
-      static size_t dma_attr[MAX_DEVICES] = {};
-      const int ddev = current_device();
-      if (dma_attr[ddev] < (size_t)DLDS) {
-        LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dk),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, DLDS));
-        dma_attr[ddev] = DLDS;
-      }
-      dim3 dgrid((unsigned)persist, (unsigned)cdiv(co, BN));
-      dk<<<dgrid, 256, DLDS, s>>>((const __bf16*)in, (const __bf16*)wimg, nbr, perm, tmasks, (__bf16*)out, n_out,
-                                  ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const __bf16*)ep.res,
-                                  ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, n_tiles);
-      LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(dma)");
-      return 0;
-    }
-  }
-#endif
-#ifndef LIDAL_IMG_NOLEAN
+  static_assert(BM == TILE_ROWS, "tile masks and BatchNorm statistics triples are per 128-row tile");
   if constexpr (G == 1 && NWAVES == 8) {
     if (ci % (ROW_BYTES / (int)sizeof(T)) == 0 && ep.in_bytes / ((unsigned)ci * sizeof(T)) < (1u << 24)) {
       // 256-row tiles (16 waves) where the weight slab outweighs the gathers of a 128-row tile
-      constexpr int LW = LIDAL_LEAN_WAVES(NB, ROW_BYTES);
+      constexpr int LW = LEAN_WAVES;
       constexpr int LBM = LW * 16;
+      static_assert(LBM == TILE_ROWS, "tile masks and BatchNorm statistics triples are per 128-row tile");
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
-#ifndef LIDAL_LEAN_LDS_PAD
-#define LIDAL_LEAN_LDS_PAD 0        /* experiment: extra LDS bytes = fewer resident workgroups */
-#endif
-      constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + LIDAL_LEAN_LDS_PAD;
+      constexpr int LEAN_LDS = (2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS;
       auto lk = nbr ? conv_lean_kernel<T, NB, ROW_BYTES, LW, false>
                     : conv_lean_kernel<T, NB, ROW_BYTES, LW, true>;
       static size_t lean_attr[2][MAX_DEVICES] = {};
@@ -1116,10 +800,9 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       return 0;
     }
   }
-#endif
   const size_t lds = WREGION + 1024 + NWAVES * BN * 2 * sizeof(float);
-  auto kern = nbr ? conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, false, D>
-                  : conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, LIDAL_IMG_MINWAVES, true, D>;
+  auto kern = nbr ? conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, IMG_MINWAVES, false, D>
+                  : conv_apply_img_kernel<T, NB, ROW_BYTES, G, NWAVES, IMG_MINWAVES, true, D>;
   static size_t attr_set[2][MAX_DEVICES] = {};
   const int dev = current_device();
   if (attr_set[nbr ? 0 : 1][dev] < lds) {
@@ -1152,6 +835,8 @@ int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, con
 }
 
 }  // namespace
+
+extern "C" int lidal_conv_stats_tile_rows(void) { return TILE_ROWS; }
 
 extern "C" int lidal_conv_weight_image_tiling(int ci, int co, int dtype, int64_t n_out) {
   const Tiling t = pick_tiling(ci, co, n_out, dtype == LIDAL_BF16 ? 2 : 4);

@@ -670,6 +670,48 @@ extern "C" int lidal_kmap_build(const void* table, int64_t table_bytes, const in
   return 0;
 }
 
+// torchsparse-order rule lists -> neighbour table: nbr_out[k][out] = in for every rule (in, out) of offset
+// k (the rules of offset k are nbmaps[koff[k] .. koff[k] + nbsizes[k])), -1 elsewhere.  For a caller that
+// holds what backend.convolution_forward_cuda(in, out, W, nbmaps, nbsizes, transposed) receives.
+namespace {
+__global__ void __launch_bounds__(256) kmap_from_rules_kernel(const int2* __restrict__ nbmaps,
+                                                              const int* __restrict__ nbsizes, int K,
+                                                              int64_t total, int64_t n_in, int64_t n_out,
+                                                              int* __restrict__ nbr_out, int* __restrict__ bad) {
+  __shared__ long long start[33];
+  if (threadIdx.x == 0) {
+    long long a = 0;
+    for (int k = 0; k < K; ++k) { start[k] = a; a += nbsizes[k]; }
+    start[K] = a;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  if (i >= start[K]) return;                 // capacity beyond the true rule count
+  int k = 0;
+  while (k + 1 < K && i >= start[k + 1]) ++k;
+  const int2 r = nbmaps[i];
+  if (r.x < 0 || r.x >= n_in || r.y < 0 || r.y >= n_out) { atomicAdd(bad, 1); return; }
+  nbr_out[(int64_t)k * n_out + r.y] = r.x;
+}
+}  // namespace
+
+extern "C" int lidal_kmap_from_rules(const int32_t* nbmaps, const int32_t* nbsizes, int k, int64_t n_rules,
+                                     int64_t n_in, int64_t n_out, int32_t* nbr_out, int32_t* n_bad_dev,
+                                     void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(k > 0 && k <= 32, "kmap_from_rules: kernel volume %d must be in 1..32", k);
+  LIDAL_REQUIRE(n_rules >= 0 && n_in >= 0 && n_out >= 0, "kmap_from_rules: bad sizes");
+  if (n_bad_dev != nullptr) LIDAL_HIP(hipMemsetAsync(n_bad_dev, 0, 4, s));
+  if (n_out > 0) LIDAL_HIP(hipMemsetAsync(nbr_out, 0xFF, 4 * n_out * k, s));
+  if (n_rules == 0 || n_out == 0) return 0;
+  LIDAL_REQUIRE(n_bad_dev != nullptr, "kmap_from_rules: needs the i32 error counter");
+  kmap_from_rules_kernel<<<(unsigned)cdiv(n_rules, 256), 256, 0, s>>>((const int2*)nbmaps, nbsizes, k, n_rules,
+                                                                      n_in, n_out, nbr_out, n_bad_dev);
+  LIDAL_CHECK_LAUNCH("lidal_kmap_from_rules");
+  return 0;
+}
+
 extern "C" int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr_in,
                                  int64_t n_in, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -6,7 +6,7 @@
 // pairs/koff).  conv.hip's first bf16 kernel staged the gathered rows global -> registers -> LDS with
 // ONE 64-rule stage in flight per workgroup: with 460 workgroups of 64 dependent steps on 256 CUs
 // the launch moved 722 MB in 156 us and did not get faster when every gather hit L2 (144 us, the
-// LIDAL_WGRAD_ABL probe) -- a latency chain, 45 KB in flight per CU where HBM needs ~64 KB.
+// timing probe of round 2) -- a latency chain, 45 KB in flight per CU where HBM needs ~64 KB.
 //
 // This kernel keeps D stages in flight per workgroup without holding them in registers:
 //   * each of the 4 waves issues its share of a stage's rows as `buffer_load_dwordx4 ... lds`
@@ -46,18 +46,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-#ifndef LIDAL_WGRAD_ABL
-#define LIDAL_WGRAD_ABL 0      /* timing-only probes (results wrong): 1 = gathers folded into 2048 rows,
-                                  2 = no gathers (every lane out of range), 4 = no LDS reads / MFMAs,
-                                  8 = LDS reads without MFMAs, 16 = MFMAs without LDS reads */
-#endif
-#ifndef LIDAL_WGRAD_DEPTH
 /* stages in flight per workgroup.  1 (the next stage travels while this one is multiplied; two LDS
    slots) measured best at every layer shape of the model -- scripts/ablate_wgrad.py, 396k..16k rows:
    96->96 135 us against 154 at depth 2, 128->128 67 against 109, 256->256 99 against 157 -- the
    deeper rings cost a resident workgroup per CU and their extra lines in flight thrash the 4 MB L2 */
-#define LIDAL_WGRAD_DEPTH(stage_bytes) 1
-#endif
+constexpr int wgrad_depth(int /*stage_bytes*/) { return 1; }
 
 constexpr int WT = 256;        // 4 waves as 2 x 2
 constexpr int RPS = 64;        // rules per stage (two MFMA k-steps)
@@ -106,7 +99,7 @@ wgrad_dma_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, uns
   constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
   constexpr int SEG_A = TA / 8, SEG_B = TB / 8;
   constexpr int A_BYTES = RPS * TA * 2, B_BYTES = RPS * TB * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int D = LIDAL_WGRAD_DEPTH(STAGE), R = D + 1;
+  constexpr int D = wgrad_depth(STAGE), R = D + 1;
   constexpr int IDS_R = 2 * D + 1, IDS_BYTES = RPS * 8;
   constexpr int IA = SEG_A / 4, IB = SEG_B / 4;          // DMA instructions per wave and stage
   constexpr int PER_STAGE = IA + IB + (DENSE ? 0 : 1);
@@ -196,15 +189,13 @@ wgrad_dma_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, uns
     for (int i = 0; i < IB; ++i) asm volatile("" : "+v"(ib[i]));
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      if (LIDAL_WGRAD_ABL & 1) ia[i] &= 2047;
-      const bool ok = r0 + row_a[i] < n_rules && col_a[i] != OOB && !(LIDAL_WGRAD_ABL & 2);
+      const bool ok = r0 + row_a[i] < n_rules && col_a[i] != OOB;
       const unsigned off = ok ? (unsigned)ia[i] * rb_a + col_a[i] : OOB;
       dma16(rs_a, stage + (wave * IA + i) * 1024, off);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      if (LIDAL_WGRAD_ABL & 1) ib[i] &= 2047;
-      const bool ok = r0 + row_b[i] < n_rules && col_b[i] != OOB && !(LIDAL_WGRAD_ABL & 2);
+      const bool ok = r0 + row_b[i] < n_rules && col_b[i] != OOB;
       const unsigned off = ok ? (unsigned)ib[i] * rb_b + col_b[i] : OOB;
       dma16(rs_b, stage + A_BYTES + (wave * IB + i) * 1024, off);
     }
@@ -260,45 +251,31 @@ wgrad_dma_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, uns
       issue_rows(step + D);            // into the slot of stage step-1 (past the end: zeros)
       const unsigned char* st = smem + (step % R) * STAGE;
 #pragma unroll
-      for (int ks = 0; ks < ((LIDAL_WGRAD_ABL & 4) ? 0 : RPS / 32); ++ks) {
+      for (int ks = 0; ks < RPS / 32; ++ks) {
         bf16x8 af[MI], bf[NI];
-        if constexpr (!(LIDAL_WGRAD_ABL & 16)) {
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            const unsigned char* base = st + fa[mi] + ks * 32 * (SEG_A * 16);
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(base));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(base + 4 * (SEG_A * 16)));
-            af[mi] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          }
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const unsigned char* base = st + fb[ni] + ks * 32 * (SEG_B * 16);
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(base));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(base + 4 * (SEG_B * 16)));
-            bf[ni] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          }
-        } else {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) asm volatile("" : "=v"(af[mi]));
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) asm volatile("" : "=v"(bf[ni]));
+        for (int mi = 0; mi < MI; ++mi) {
+          const unsigned char* base = st + fa[mi] + ks * 32 * (SEG_A * 16);
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(base));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(base + 4 * (SEG_A * 16)));
+          af[mi] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        if constexpr (LIDAL_WGRAD_ABL & 8) {
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) asm volatile("" :: "v"(af[mi]));
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) asm volatile("" :: "v"(bf[ni]));
-        } else {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) {
+          const unsigned char* base = st + fb[ni] + ks * 32 * (SEG_B * 16);
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(base));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(base + 4 * (SEG_B * 16)));
+          bf[ni] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
       }
     }
     // the zero-fill DMAs past the end have landed and every wave is done reading before the next
@@ -386,7 +363,7 @@ wgrad_dma_reduce_kernel(const float* __restrict__ partial, const int64_t* __rest
 }
 
 constexpr int lds_bytes(int ta, int tb) {
-  const int stage = RPS * (ta + tb) * 2, d = LIDAL_WGRAD_DEPTH(stage);
+  const int stage = RPS * (ta + tb) * 2, d = wgrad_depth(stage);
   return (d + 1) * stage + (2 * d + 1) * RPS * 8;
 }
 
@@ -427,9 +404,6 @@ int launch(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* pa
 namespace lidal {
 
 bool wgrad_dma_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb) {
-#ifdef LIDAL_WGRAD_NO_DMA
-  return false;
-#endif
   if (ca % 8 != 0 || cb % 8 != 0 || k > 64) return false;      // 16-byte segments of whole rows
   return n_a * ca * 2 < (int64_t)OOB && n_b * cb * 2 < (int64_t)OOB;      // 32-bit byte offsets
 }
@@ -445,24 +419,20 @@ bool wgrad_dma_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb) {
 //   * no more than leaves each run ~8 stages of the ESTIMATED rule count (the true one is only
 //     known on the device; ~6 rules per row for a 3x3x3 map on LiDAR surfaces, one per row for the
 //     2x2x2 maps and dense layers).
-#ifndef LIDAL_WGRAD_RESIDENT
-#define LIDAL_WGRAD_RESIDENT 0         /* 0 = the rule above */
-#endif
-#ifndef LIDAL_WGRAD_MIN_STAGES
-#define LIDAL_WGRAD_MIN_STAGES 8
-#endif
+constexpr int WGRAD_RESIDENT = 0;          // 0 = the rule above
+constexpr int WGRAD_MIN_STAGES = 8;
 int wgrad_dma_workgroups(int64_t n_a, int64_t n_b, int k, int ca, int cb) {
   const int ta = wgrad_blocks(ca) * 32, tb = wgrad_blocks(cb) * 32;
   const int64_t tiles = cdiv(ca, ta) * cdiv(cb, tb);
   const int64_t n_rows = n_a > n_b ? n_a : n_b;
-  int64_t resident = LIDAL_WGRAD_RESIDENT;
+  int64_t resident = WGRAD_RESIDENT;
   if (resident == 0)
     resident = (RPS * (ta + tb) * 2 >= 16384 && (n_a * ca + n_b * cb) * 2 > (48ll << 20)) ? 1 : 2;
   const int64_t fit = (160 * 1024) / lds_bytes(ta, tb);
   if (resident > fit) resident = fit < 1 ? 1 : fit;
   int64_t w = 256 * resident / tiles;
   const int64_t stages = (k > 8 ? 6 : 1) * n_rows / RPS;
-  if (w > stages / LIDAL_WGRAD_MIN_STAGES) w = stages / LIDAL_WGRAD_MIN_STAGES;
+  if (w > stages / WGRAD_MIN_STAGES) w = stages / WGRAD_MIN_STAGES;
   if (w * tiles >= 256) w = (w * tiles / 256) * 256 / tiles;
   return (int)(w < 1 ? 1 : w);
 }

@@ -12,8 +12,6 @@ from ..nn.utils import get_kernel_offsets
 
 __all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point']
 
-import os as _os
-_L0_ORDER = _os.environ.get('LIDAL_L0_ORDER', 'hash')
 
 
 def _floor_to_stride(z, s):
@@ -40,19 +38,6 @@ def initial_voxelize(z, init_res, after_res):
     sparse_hash = F.unique_sorted(pc_hash)
     idx_query = F.sphashquery(pc_hash, sparse_hash)
     counts = F.spcount(idx_query.int(), len(sparse_hash))
-    if _L0_ORDER == 'lex':
-        # EXPERIMENT (LIDAL_L0_ORDER=lex): the reference's level-0 row order is the sorted order of the
-        # coordinate HASHES -- random in space.  Renumbering the voxels in (batch, x, y, z) order changes
-        # no per-point result beyond summation order, and lets the gathers of neighbouring rows share
-        # cache lines and L2.  Off by default: every per-voxel fixture is pinned to the reference order.
-        vox = F.spvoxelize(floored, idx_query, counts)
-        c = torch.round(vox).long()
-        key = ((c[:, 3] << 48) | ((c[:, 0] + 32768) << 32) | ((c[:, 1] + 32768) << 16) | (c[:, 2] + 32768))
-        perm = torch.argsort(key)
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(perm.numel(), device=perm.device)
-        idx_query = inv[idx_query]
-        counts = counts[perm].contiguous()
     inserted_coords = torch.round(F.spvoxelize(floored, idx_query, counts)).int()
     inserted_feat = F.spvoxelize(z.F, idx_query, counts)
     new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)

@@ -396,7 +396,7 @@ def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False):
     # their own f64-accumulated pass (an ill-conditioned gamma gradient of the golden model notices)
     want_stats = want_stats and feats.dtype == torch.bfloat16
     if want_stats:              # (count, mean, M2) per 128-row tile and column, for the BatchNorm that follows
-        stats = torch.empty((-(-n_out // 128), co, 3), dtype=torch.float32, device=feats.device)
+        stats = torch.empty((-(-n_out // B.stats_tile_rows()), co, 3), dtype=torch.float32, device=feats.device)
     B.check(B.lib().lidal_conv_apply_image(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
                                            B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
                                            co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(scale),

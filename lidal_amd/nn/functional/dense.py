@@ -77,7 +77,7 @@ def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None, im
         scale = torch.ones(n_col, dtype=torch.float32, device=x.device)
     stats = None
     if want_stats:
-        stats = torch.empty((-(-n // 128), n_col, 3), dtype=torch.float32, device=x.device)
+        stats = torch.empty((-(-n // B.stats_tile_rows()), n_col, 3), dtype=torch.float32, device=x.device)
     B.check(B.lib().lidal_conv_apply_image(B.ptr(x), B.ptr(img), None, None, None, B.ptr(out),
                                            n, n, n_red, n_col, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
                                            B.ptr(shift), int(relu), B.ptr(residual), B.ptr(stats),

@@ -46,7 +46,7 @@ def train_forward(x, weight, bias, running_mean, running_var, momentum, eps, rel
     code = B.dtype_code(x.dtype)
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     invstd = torch.empty(c, dtype=torch.float32, device=dev)
-    if tile_stats is not None and tile_stats.shape != (-(-n // 128), c, 3):
+    if tile_stats is not None and tile_stats.shape != (-(-n // B.stats_tile_rows()), c, 3):
         tile_stats = None
     if tile_stats is not None:      # statistics came with x from the producing convolution
         B.check(B.lib().lidal_bn_train_fwd_tiles(B.ptr(x), code, n, c, B.ptr(w), B.ptr(b), float(eps),
@@ -157,7 +157,7 @@ def batch_norm_rows(x, weight, bias, running_mean, running_var, training, moment
     by the convolution that produced x (conv3d(..., want_stats=True)): no statistics pass over x.
     `residual` (training only, [N, C]): returns act(bn(x)) + residual from the same pass, with a ReLU
     on the sum if `relu_after` (the end of a residual block)."""
-    if tile_stats is not None and not (training and tile_stats.shape == (-(-x.shape[0] // 128), x.shape[1], 3)):
+    if tile_stats is not None and not (training and tile_stats.shape == (-(-x.shape[0] // B.stats_tile_rows()), x.shape[1], 3)):
         tile_stats = None
     if not training and not B.wants_grad(x, weight, bias):      # inference: one kernel, no node
         x = x.contiguous()

@@ -32,9 +32,17 @@ def view_mean_softmax(logits, inverse_indices, inf_reps):
 
 
 @torch.no_grad()
-def infer_frame(model, coords_v_b, feats_v_b, inverse_indices_b, inf_reps=8, autocast=False):
+def infer_frame(model, coords_v_b, feats_v_b, inverse_indices_b, inf_reps=8, autocast=False, return_feat=False):
     """model.eval() forward over the `inf_reps` augmented views of ONE frame, then the fused
-    voxel->point gather + softmax + view mean + argmax.  Returns (prob [P,C], pred [P])."""
+    voxel->point gather + softmax + view mean + argmax.  Returns (prob [P,C], pred [P]).
+    return_feat (prob_inference.py:103-105,116-118: `outfeat`, saved when r_id == 0 or the metric is
+    ReDAL / CSET): also the [P, 96] feature of every point, the view mean of feat[inverse_indices] as the
+    reference computes it -- (prob, pred, feat)."""
     with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
-        logits, _ = model(SparseTensor(feats_v_b, coords_v_b))
-    return view_mean_softmax(logits, inverse_indices_b, inf_reps)
+        logits, feat = model(SparseTensor(feats_v_b, coords_v_b))
+    prob, pred = view_mean_softmax(logits, inverse_indices_b, inf_reps)
+    if not return_feat:
+        return prob, pred
+    p = inverse_indices_b.numel() // inf_reps
+    feat_p = feat.float()[inverse_indices_b].reshape(inf_reps, p, feat.shape[1]).mean(0)
+    return prob, pred, feat_p

@@ -1003,3 +1003,30 @@ def test_radix_sort_u64_is_the_stable_sort(n, bits, with_vals):
     if with_vals:
         assert torch.equal(vo, vals[order])
     assert torch.equal(k_dev, k_in)
+
+
+@pytest.mark.parametrize('ks,stride', [(3, 1), (2, 2)])
+def test_neighbour_table_from_torchsparse_rule_lists(ks, stride):
+    """lidal_kmap_from_rules: a caller holding what backend.convolution_forward_cuda receives (nbmaps,
+    nbsizes in torchsparse order) gets the table the convolution kernels consume -- equal to the one
+    the library builds itself -- and out-of-range rules are counted, not written."""
+    from lidal_amd import backend as B
+    F = _F()
+    c = _surface_coords(40, 2, seed=ks).to(DEV)
+    km, oc = F.build_kernel_map(c, (1, 1, 1), (ks,) * 3, (stride,) * 3)
+    k, n_out = km.nbr_out.shape
+    maps = km.nbmaps.contiguous()
+    got = torch.empty_like(km.nbr_out)
+    bad = torch.empty(1, dtype=torch.int32, device=DEV)
+    B.check(B.lib().lidal_kmap_from_rules(B.ptr(maps), B.ptr(km.nbsizes), k, maps.shape[0], c.shape[0], n_out,
+                                          B.ptr(got), B.ptr(bad), B.stream()), 'kmap_from_rules')
+    assert int(bad.item()) == 0 and torch.equal(got, km.nbr_out)
+    # with spare capacity behind the rules (torchsparse's buffer) and one corrupt rule
+    cap = torch.cat([maps, torch.full((7, 2), 123456789, dtype=torch.int, device=DEV)])
+    cap[3, 0] = c.shape[0] + 5
+    B.check(B.lib().lidal_kmap_from_rules(B.ptr(cap), B.ptr(km.nbsizes), k, cap.shape[0], c.shape[0], n_out,
+                                          B.ptr(got), B.ptr(bad), B.stream()), 'kmap_from_rules')
+    assert int(bad.item()) == 1
+    # ... and the convolution runs from it
+    order = F.conv.RowOrder(got)
+    assert order.n_rows == n_out

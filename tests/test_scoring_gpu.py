@@ -175,3 +175,32 @@ def test_score_sequence_pipeline_matches_oracle_end_to_end():
         assert np.allclose(d.cpu().numpy(), rd, rtol=2e-3, atol=1e-6), i     # probabilities differ by
         assert np.allclose(e.cpu().numpy(), re, rtol=2e-3, atol=1e-6), i     # 1e-4 before the KL
         assert np.allclose(c.cpu().numpy(), rc, rtol=1e-5, atol=1e-5), i
+
+
+def test_infer_frame_returns_the_point_features_on_request():
+    """prob_inference.py:103-105,116-118 (`outfeat`, r_id == 0 / ReDAL / CSET): the [P, 96] view-mean of
+    feat[inverse_indices], against the oracle model + the reference expression."""
+    from lidal_amd import synth
+    from lidal_amd.network import MinkUNet
+    from lidal_amd.score import infer_frame
+    from oracle import harness_ref
+    from oracle.models_ref import MinkUNetRef
+    from weights import fill_state_dict
+    rng = np.random.default_rng(2)
+    world = synth.make_world(6)
+    pts, inten = synth.raycast_scan(world, (20.0, 0.0), rng, n_beams=16, n_az=128)
+    batch = synth.make_score_batch(pts, inten, rng, inf_reps=8)
+    coords, feats = torch.from_numpy(batch['coords_v_b']), torch.from_numpy(batch['feats_v_b'])
+    inverse = torch.from_numpy(batch['inverse_indices_b'])
+    model = fill_state_dict(MinkUNet(19)).eval()
+    ref_model = MinkUNetRef(19)
+    ref_model.load_state_dict(model.state_dict(), strict=True)
+    ref_model.eval()
+    prob, pred, feat = infer_frame(model.to(DEV), coords.to(DEV), feats.to(DEV), inverse.to(DEV), 8, return_feat=True)
+    prob2, pred2 = infer_frame(model, coords.to(DEV), feats.to(DEV), inverse.to(DEV), 8)
+    assert torch.equal(prob, prob2) and torch.equal(pred, pred2)
+    with torch.no_grad():
+        _, feat_ref = ref_model(__import__('oracle').tsref.SparseTensor(feats, coords))
+    want = feat_ref[inverse].numpy().reshape(8, -1, feat_ref.shape[1]).mean(0)
+    assert feat.shape == want.shape
+    assert np.abs(feat.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()

@@ -256,6 +256,17 @@ int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
                            int ci, int co, int k, int kflip, int dtype, const float* ep_scale,
                            const float* ep_shift, int ep_relu, const void* ep_residual,
                            float* tile_stats, void* stream);
+/* The data gradient of a convolution whose INPUT was y = act(bn(x)) (torchsparse: convolution_backward_cuda's
+ * grad_input half, followed by the BatchNorm backward of network/utils.py:115): lidal_conv_apply_image on
+ * (gout, data-gradient image) -> gin, and in the same launch the backward sums of that BatchNorm per 128-row
+ * tile of gin's rows: bn_sums f32 [ceil(n_gin / tile rows), c_gin, 2] = (sum dy', sum dy' xhat), dy' = gin where
+ * the fused ReLU (bn_relu) let the value through, xhat = (bn_x - mean) * invstd; bn_x [n_gin, c_gin] in `dtype`.
+ * Feed bn_sums to lidal_bn_bwd_tiles.  c_gin must be whole 16-byte vectors. */
+int lidal_conv_dgrad_bn_sums(const void* gout, const void* wimg, const int32_t* nbr, const int32_t* perm,
+                             const uint32_t* tile_masks, void* gin, int64_t n_gout, int64_t n_gin, int c_gout,
+                             int c_gin, int k, int kflip, int dtype, const void* bn_x, const float* bn_mean,
+                             const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_relu,
+                             float* bn_sums, void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
  * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device); n_a, n_b = rows of a and b.
@@ -312,6 +323,13 @@ int lidal_bn_bwd(const void* x, const void* dy, int64_t dy_stride, int dtype, in
                  void* stream);
 /* Column sums of x [n, c] -> out f32 [c] (bias gradients of the 1x1 / Linear layers);
  * ws >= lidal_bn_workspace_bytes(n, c) + 12*c bytes. */
+/* BatchNorm backward whose per-column sums came with dy: tile_sums f32 [n_tiles, c, 2] = (sum dy', sum dy' xhat)
+ * per 128-row tile (lidal_conv_stats_tile_rows), left by lidal_conv_dgrad_bn_sums.  Merges the tiles in f64
+ * (-> grad_beta, grad_gamma) and writes dx; no pass over (x, dy) for the sums. */
+int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c,
+                       const float* gamma, const float* beta, int relu, const float* save_mean,
+                       const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
+                       const float* tile_sums, int64_t n_tiles, void* stream);
 /* eval-mode BatchNorm as a per-channel affine map (scale = gamma / sqrt(var + eps),
  * shift = beta - mean * scale), the operands of lidal_conv_apply's epilogue. */
 int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,

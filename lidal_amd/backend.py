@@ -78,6 +78,8 @@ SIGNATURES = {
     'lidal_conv_weight_image_batch': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp]),
     'lidal_conv_apply_image': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
                                       _vp, _i32, _vp, _vp, _vp]),
+    'lidal_conv_dgrad_bn_sums': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
+                                        _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     'lidal_conv_wgrad_slabs': (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     'lidal_conv_wgrad': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'lidal_bn_workspace_bytes': (_i64, [_i64, _i32]),
@@ -88,6 +90,8 @@ SIGNATURES = {
     'lidal_bn_eval_fwd': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp]),
     'lidal_bn_bwd': (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                             _i64, _vp]),
+    'lidal_bn_bwd_tiles': (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _i64, _vp]),
     'lidal_bn_fold': (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
     'lidal_colsum': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp]),
     'lidal_add_relu_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),

@@ -602,6 +602,56 @@ extern "C" int lidal_bn_bwd(const void* x, const void* dy, int64_t dy_stride, in
                         grad_beta, (double*)ws, s);
 }
 
+// The backward sums came with dy from the data-gradient launch that produced it (conv_img.hip, BnBwd: f32
+// (sum dy', sum dy' xhat) per 128-row tile and column): merge the tiles in f64, then the dx pass.  No
+// bn_bwd_partial pass over x and dy.
+__global__ void __launch_bounds__(NT) bn_bwd_tiles_final_kernel(const float* __restrict__ part, int nparts, int c,
+                                                                float* __restrict__ sum_dy,
+                                                                float* __restrict__ sum_dy_xhat) {
+  __shared__ double sa[NT], sb[NT];
+  const int tid = threadIdx.x, ch = blockIdx.x;
+  double a = 0., b = 0.;
+  for (int p = tid; p < nparts; p += NT) {
+    const float* s = part + ((int64_t)p * c + ch) * 2;
+    a += (double)s[0]; b += (double)s[1];
+  }
+  sa[tid] = a; sb[tid] = b;
+  for (int st = NT / 2; st >= 1; st >>= 1) {
+    __syncthreads();
+    if (tid < st) { sa[tid] += sa[tid + st]; sb[tid] += sb[tid + st]; }
+  }
+  if (tid == 0) {
+    sum_dy[ch] = (float)sa[0];            // = grad_beta
+    sum_dy_xhat[ch] = (float)sb[0];       // = grad_gamma
+  }
+}
+
+extern "C" int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c,
+                                  const float* gamma, const float* beta, int relu, const float* save_mean,
+                                  const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
+                                  const float* tile_sums, int64_t n_tiles, void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  LIDAL_REQUIRE(n > 0 && n_tiles > 0 && tile_sums != nullptr, "bn_bwd_tiles: needs rows and tile sums");
+  const int vec = dtype == LIDAL_F32 ? 4 : 8;
+  LIDAL_REQUIRE(dy_stride >= c && dy_stride % vec == 0, "bn_bwd_tiles: dy row stride %lld (rows of %d, 16-byte steps)",
+                (long long)dy_stride, c);
+  hipStream_t s = (hipStream_t)stream;
+  bn_bwd_tiles_final_kernel<<<(unsigned)c, NT, 0, s>>>(tile_sums, (int)n_tiles, c, grad_beta, grad_gamma);
+  LIDAL_CHECK_LAUNCH("bn_bwd_final(tiles)");
+  if (dx != nullptr) {
+    if (dtype == LIDAL_F32)
+      bn_bwd_dx_kernel<float><<<nslabs_ew(n), NT, 0, s>>>((const float*)x, (const float*)dy, n, c, save_mean,
+                                                          save_invstd, gamma, beta, relu, grad_beta, grad_gamma,
+                                                          (float*)dx, rows_per_wg_ew(n), dy_stride);
+    else
+      bn_bwd_dx_kernel<__bf16><<<nslabs_ew(n), NT, 0, s>>>((const __bf16*)x, (const __bf16*)dy, n, c, save_mean,
+                                                           save_invstd, gamma, beta, relu, grad_beta, grad_gamma,
+                                                           (__bf16*)dx, rows_per_wg_ew(n), dy_stride);
+    LIDAL_CHECK_LAUNCH("bn_bwd_dx");
+  }
+  return 0;
+}
+
 extern "C" int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                              const float* running_var, float eps, int c, float* scale,
                              float* shift, void* stream) {

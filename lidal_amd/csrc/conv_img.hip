@@ -154,6 +154,17 @@ weight_image_batch_kernel(const ImageJob* __restrict__ jobs, int n_jobs, int64_t
 constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (16 waves / 256 rows measured slower)
 constexpr int LEAN_MINWAVES = 4;       // waves per SIMD the register budget must allow: 2 workgroups per CU
 
+// Optional second job of a DATA-GRADIENT launch: the tile's share of the backward sums of the BatchNorm
+// whose output gradient this launch produces (out = dy of y = act(bn(x))): per column sum(dy') and
+// sum(dy' * xhat), dy' = dy where the fused ReLU let the value through, xhat = (x - mean) * invstd -- x read
+// row by row at the tile's own output rows.  lidal_bn_bwd_tiles merges the tiles (in f64); the separate
+// pass over x and dy (bn_bwd_partial_kernel, two of BatchNorm backward's five passes) is gone.
+struct BnBwd {
+  const void* x; const float* mean; const float* invstd; const float* gamma; const float* beta;
+  float* sums;          // f32 [tiles][co][2], or NULL: no such job
+  int relu;
+};
+
 // ---- epilogue shared by the kernels of this file (as conv.hip): accumulators (D layout: col =
 // lane&15, row = 4*(lane>>4) + r) -> wave-private LDS tile in T -> whole rows to HBM, 16-byte stores,
 // with the optional affine map / ReLU / residual of the inference paths
@@ -165,7 +176,7 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
                                            const float* __restrict__ ep_shift, int ep_relu,
                                            const T* __restrict__ ep_res, bool perm_in_reg = false,
                                            int perm_v = 0, float* __restrict__ tile_stats = nullptr,
-                                           int stats_tile = -1) {
+                                           int stats_tile = -1, const BnBwd* bnb = nullptr) {
   // perm_in_reg: lane l (< 16 G) of the wave holds perm[r0 + l] in perm_v, loaded when the tile began
   // (the lean kernel: no dependent load in front of the stores)
   constexpr int VEC = DT<T>::VEC;
@@ -288,6 +299,63 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[G][NB], unsigned char* w
       dst[0] = na; dst[1] = ma; dst[2] = qa;
     }
   }
+  // ---- BatchNorm backward sums of the tile (see BnBwd): this wave's rows of x come in as whole rows (16-byte
+  // lane loads, the tile's own output rows) through the wave's epilogue tile, which the write-out has left
+  if (bnb != nullptr && bnb->sums != nullptr) {
+    constexpr int EPI_BYTES = NWAVES * RW * ESTRIDE * (int)sizeof(T);
+    float* st = reinterpret_cast<float*>(wl + EPI_BYTES);          // [NWAVES][BN][2]
+    const T* bx = reinterpret_cast<const T*>(bnb->x);
+    const int64_t left = n_out - r0;
+    const int nvalid = left <= 0 ? 0 : (left < RW ? (int)left : RW);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                            // the write-out's LDS reads are done
+    for (int i = lane; i < RW * RSEGS; i += 64) {
+      const int r = i / RSEGS, cseg = (i - r * RSEGS) * VEC;
+      const int prow = perm_in_reg ? __shfl(perm_v, r & (RW - 1), 64) : 0;
+      frag v;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = DT<T>::from_f32(0.f);
+      if (r < nvalid && n0 + cseg + VEC <= co) {
+        const int64_t row = perm ? (perm_in_reg ? (int64_t)prow : (int64_t)perm[r0 + r]) : r0 + r;
+        v = *reinterpret_cast<const frag*>(bx + row * co + n0 + cseg);
+      }
+      *reinterpret_cast<frag*>(et + r * ESTRIDE + cseg) = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = n0 + nb * 16 + row16;
+      const bool cok = col < co;
+      const float mu = cok ? bnb->mean[col] : 0.f, is = cok ? bnb->invstd[col] : 0.f;
+      const float ga = (cok && bnb->gamma) ? bnb->gamma[col] : 1.f, be = (cok && bnb->beta) ? bnb->beta[col] : 0.f;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = g * 16 + gsel * 4 + r;
+          if (rr < nvalid) {
+            const float xh = (DT<T>::to_f32(et[rr * ESTRIDE + nb * 16 + row16]) - mu) * is;
+            float dy = DT<T>::to_f32(DT<T>::from_f32(acc[g][nb][r]));          // as stored
+            if (bnb->relu && !(xh * ga + be > 0.f)) dy = 0.f;
+            a += dy; b += dy * xh;
+          }
+        }
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (gsel == 0) {
+        st[(wave * BN + nb * 16 + row16) * 2] = a;
+        st[(wave * BN + nb * 16 + row16) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    const int c = wave * 64 + lane;
+    if (c < BN && n0 + c < co) {
+      float a = 0.f, b = 0.f;
+      for (int w = 0; w < NWAVES; ++w) { a += st[(w * BN + c) * 2]; b += st[(w * BN + c) * 2 + 1]; }
+      float* dst = bnb->sums + ((int64_t)(stats_tile >= 0 ? stats_tile : (int)blockIdx.x) * co + n0 + c) * 2;
+      dst[0] = a; dst[1] = b;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -306,7 +374,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
                       int ci, int co, int K, int kflip, const float* __restrict__ ep_scale,
                       const float* __restrict__ ep_shift, int ep_relu, const T* __restrict__ ep_res,
                       unsigned in_bytes, unsigned img_bytes, unsigned nbr_bytes,
-                      float* __restrict__ tile_stats) {
+                      float* __restrict__ tile_stats, BnBwd bnb) {
   constexpr int NTHREADS = 64 * NWAVES;
   constexpr int BM = NWAVES * G * 16;
   constexpr int BN = 16 * NB;
@@ -534,7 +602,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
   }
 
   store_tile<T, NB, G, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
-                               ep_res, false, 0, tile_stats);
+                               ep_res, false, 0, tile_stats, -1, &bnb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -569,7 +637,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
                  const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int ep_relu,
                  const T* __restrict__ ep_res, unsigned in_bytes, unsigned img_bytes,
-                 unsigned nbr_bytes, float* __restrict__ tile_stats) {
+                 unsigned nbr_bytes, float* __restrict__ tile_stats, BnBwd bnb) {
   constexpr int BM = NWAVES * 16;
   constexpr int BN = 16 * NB;
   constexpr int CH = DT<T>::CH;
@@ -753,12 +821,12 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
     __syncthreads();                                // every wave is done with the last slab
   }
   store_tile<T, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
-                               ep_res, true, perm_v, tile_stats);
+                               ep_res, true, perm_v, tile_stats, -1, &bnb);
 }
 
 
 
-struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; };
+struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; BnBwd bnb; };
 
 constexpr int IMG_G = 1, IMG_NWAVES = 8, IMG_DEPTH = 1;       // generic kernel: row groups per wave, waves, pipeline depth
 // rows per workgroup tile of every kernel of this file == rows per BatchNorm statistics triple
@@ -795,7 +863,7 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       dim3 lgrid((unsigned)cdiv(n_out, LBM), (unsigned)cdiv(co, BN));
       lk<<<lgrid, 64 * LW, LEAN_LDS, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
                                           ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
-                                          ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats);
+                                          ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, ep.bnb);
       LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(lean)");
       return 0;
     }
@@ -813,7 +881,7 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
   dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
   kern<<<grid, NTHREADS, lds, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out, ci,
                                    co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
-                                   ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats);
+                                   ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, ep.bnb);
   LIDAL_CHECK_LAUNCH("lidal_conv_apply_image");
   return 0;
 }
@@ -940,13 +1008,10 @@ extern "C" int lidal_conv_weight_image_batch(const void* jobs, int n_jobs, int64
   return 0;
 }
 
-extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
-                                      const int32_t* perm, const uint32_t* tile_masks, void* out,
-                                      int64_t n_in, int64_t n_out, int ci, int co, int k, int kflip,
-                                      int dtype, const float* ep_scale, const float* ep_shift,
-                                      int ep_relu, const void* ep_residual, float* tile_stats,
-                                      void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int conv_apply_image(const void* in, const void* wimg, const int32_t* nbr, const int32_t* perm,
+                            const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out, int ci, int co,
+                            int k, int kflip, int dtype, const float* ep_scale, const float* ep_shift,
+                            int ep_relu, const void* ep_residual, float* tile_stats, BnBwd bnb, hipStream_t s) {
   if (n_out == 0 || co == 0) return 0;
   LIDAL_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv_apply_image: scale and shift go together");
   LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16, "conv_apply_image: bad dtype %d", dtype);
@@ -957,14 +1022,39 @@ extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const in
                 vec, MAXK, ci, co, k);
   LIDAL_REQUIRE(nbr == nullptr ? (k == 1 && n_in == n_out) : (tile_masks != nullptr),
                 "conv_apply_image: needs lidal_kmap_order's tile masks (or NULL table = identity, k = 1)");
+  LIDAL_REQUIRE(bnb.sums == nullptr || (co % vec == 0 && ep_residual == nullptr && ep_scale == nullptr &&
+                                        tile_stats == nullptr && bnb.x && bnb.mean && bnb.invstd),
+                "conv_apply_image: BatchNorm backward sums need whole 16-byte column vectors, no other epilogue");
   const Tiling t = pick_tiling(ci, co, n_out, esz);
   const int64_t ib = image_bytes(k, ci, co, t, esz);
   LIDAL_REQUIRE(n_in >= 0 && n_in * ci * esz < 0x7FFFFFF0ll && ib < 0x7FFFFFF0ll,
                 "conv_apply_image: the input matrix and the weight image must each stay below 2 GiB");
   LIDAL_REQUIRE((int64_t)k * n_out * 4 < 0x7FFFFFF0ll, "conv_apply_image: neighbour table above 2 GiB");
   Epi ep{ep_scale, ep_shift, ep_relu, ep_residual, (unsigned)(n_in * ci * esz), (unsigned)ib,
-         (unsigned)((int64_t)k * n_out * 4), tile_stats};
+         (unsigned)((int64_t)k * n_out * 4), tile_stats, bnb};
   if (dtype == LIDAL_F32)
     return dispatch_img<float>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
   return dispatch_img<__bf16>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
+}
+
+extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
+                                      const int32_t* perm, const uint32_t* tile_masks, void* out,
+                                      int64_t n_in, int64_t n_out, int ci, int co, int k, int kflip,
+                                      int dtype, const float* ep_scale, const float* ep_shift,
+                                      int ep_relu, const void* ep_residual, float* tile_stats,
+                                      void* stream) {
+  BnBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  return conv_apply_image(in, wimg, nbr, perm, tile_masks, out, n_in, n_out, ci, co, k, kflip, dtype, ep_scale,
+                          ep_shift, ep_relu, ep_residual, tile_stats, none, (hipStream_t)stream);
+}
+
+extern "C" int lidal_conv_dgrad_bn_sums(const void* gout, const void* wimg, const int32_t* nbr,
+                                        const int32_t* perm, const uint32_t* tile_masks, void* gin,
+                                        int64_t n_gout, int64_t n_gin, int c_gout, int c_gin, int k, int kflip,
+                                        int dtype, const void* bn_x, const float* bn_mean,
+                                        const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                        int bn_relu, float* bn_sums, void* stream) {
+  BnBwd b{bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_sums, bn_relu};
+  return conv_apply_image(gout, wimg, nbr, perm, tile_masks, gin, n_gout, n_gin, c_gout, c_gin, k, kflip, dtype,
+                          nullptr, nullptr, 0, nullptr, nullptr, b, (hipStream_t)stream);
 }

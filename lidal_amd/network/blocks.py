@@ -33,6 +33,7 @@ from ..nn.functional import dense as _D
 from ..nn.functional import norm as _N
 
 FUSE_BLOCKS = _os.environ.get('LIDAL_FUSE_BLOCKS', '1') != '0'
+BN_SUMS = _os.environ.get('LIDAL_BN_SUMS', '1') != '0'       # BatchNorm backward sums from the data-gradient launches
 
 
 def _bn_args(bn):
@@ -114,8 +115,12 @@ class _Residual(torch.autograd.Function):
                                               ctx.needs_input_grad[7], False)
         else:
             g_skip = gm
-        dy1, gk2 = _C.conv_backward(y1, k2, ctx.kmap, False, ctx.img2, dx2, None, True, ctx.needs_input_grad[4])
-        dx1, gg1, gb1, _ = _N.train_backward(x1, w1, c1, mean1, inv1, True, dy1, True)
+        # conv2's data gradient IS the output gradient of bn1 (y1 has no other consumer): the launch that writes it
+        # also leaves bn1's backward sums per tile (BN_SUMS; bf16), and bn1's backward skips its pass for them
+        dy1, gk2 = _C.conv_backward(y1, k2, ctx.kmap, False, ctx.img2, dx2, None, True, ctx.needs_input_grad[4],
+                                    (x1, mean1, inv1, w1, c1, True) if BN_SUMS else None)
+        dx1, gg1, gb1, _ = _N.train_backward(x1, w1, c1, mean1, inv1, True, dy1, True, None,
+                                             getattr(dy1, '_lidal_bnb_sums', None))
         gx, gk1 = _C.conv_backward(xc, k1, ctx.kmap, False, ctx.img1, dx1, g_skip if need_gx else None, need_gx,
                                    ctx.needs_input_grad[1])
         return gx, gk1, gg1, gb1, gk2, gg2, gb2, gks, ggs, gbs, None, None, None, None, None

@@ -378,7 +378,7 @@ def _weight_image_pair(weight, dtype, n_out_fwd, n_out_bwd):
     return img_f, img_b
 
 
-def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False):
+def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False, bnb=None):
     """out[j] = sum_k feats[nbr[kk][j]] @ W_k with the weights as the LDS image `img` (built for
     (ci = feats.shape[1], co, k, feats.dtype, n_out = order.n_rows)); `order` = RowOrder(nbr).
     epilogue = (scale f32 [co], shift f32 [co], relu[, residual [n_out, co]]): in-kernel
@@ -397,6 +397,18 @@ def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False):
     want_stats = want_stats and feats.dtype == torch.bfloat16
     if want_stats:              # (count, mean, M2) per 128-row tile and column, for the BatchNorm that follows
         stats = torch.empty((-(-n_out // B.stats_tile_rows()), co, 3), dtype=torch.float32, device=feats.device)
+    if bnb is not None:         # a data gradient that also leaves the backward sums of the BatchNorm in front of it
+        bx, mean, invstd, gamma, beta, relu_bn = bnb
+        assert epilogue is None and not want_stats and bx.shape == (n_out, co) and bx.dtype == feats.dtype
+        sums = torch.empty((-(-n_out // B.stats_tile_rows()), co, 2), dtype=torch.float32, device=feats.device)
+        B.check(B.lib().lidal_conv_dgrad_bn_sums(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
+                                                 B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
+                                                 co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(bx),
+                                                 B.ptr(mean), B.ptr(invstd), B.ptr(gamma), B.ptr(beta),
+                                                 int(bool(relu_bn)), B.ptr(sums), B.stream()),
+                'conv_apply')
+        out._lidal_bnb_sums = sums
+        return out
     B.check(B.lib().lidal_conv_apply_image(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
                                            B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
                                            co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(scale),
@@ -466,11 +478,15 @@ def _conv(feats, weight, kmap, transposed, epilogue=None, want_stats=False, fork
     return (out, feats) if fork else out
 
 
-def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=None, need_gx=True, need_gw=True):
+def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=None, need_gx=True, need_gw=True,
+                  bnb=None):
     """Backward of a sparse convolution on raw tensors: x = the (compute-dtype, channel-padded) input
     _forward returned, img_bwd = its data-gradient image.  -> (grad_in or None, grad_w or None).
     `grad_skip`: a gradient reaching the input through a second consumer, added in the data-gradient
-    kernel's epilogue.  Shared by ConvolutionFunction and the fused block Functions of lidal_amd.network."""
+    kernel's epilogue.  `bnb` = (bn_x, mean, invstd, gamma, beta, relu): the input was act(bn(bn_x)) and has
+    no other consumer -- the data-gradient launch then also leaves that BatchNorm's backward sums per tile
+    on grad_in (`_lidal_bnb_sums`, for norm.train_backward): bf16, no channel padding, no grad_skip.
+    Shared by ConvolutionFunction and the fused block Functions of lidal_amd.network."""
     g = grad_output.contiguous().to(x.dtype)
     n_in, n_out = kmap.sizes
     grad_in = grad_w = None
@@ -504,8 +520,13 @@ def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=N
         order, kflip = _bwd_order(kmap, transposed)
         # the gradient of the forked alias joins in the epilogue (out = acc + residual)
         ep = (None, None, 0, grad_skip) if grad_skip is not None else None
-        grad_in = _apply(g, img_bwd, k, x.shape[1], order, kflip, ep)
-        grad_in = grad_in[:, :ci_w]                     # drop the padding channels, if any
+        if bnb is not None and (ep is not None or ci != ci_w or g.dtype != torch.bfloat16 or ci % 8 != 0
+                                or tuple(bnb[0].shape) != (n_out if transposed else n_in, ci)
+                                or bnb[0].dtype != g.dtype or not bnb[0].is_contiguous()):
+            bnb = None
+        grad_in = _apply(g, img_bwd, k, x.shape[1], order, kflip, ep, False, bnb)
+        if ci != ci_w:
+            grad_in = grad_in[:, :ci_w]                 # drop the padding channels, if any
     elif grad_skip is not None:
         grad_in = grad_skip
     if side is not None:

@@ -73,10 +73,12 @@ def train_forward(x, weight, bias, running_mean, running_var, momentum, eps, rel
     return y, mean, invstd, x, w, b
 
 
-def train_backward(x, w, b, mean, invstd, relu, grad_out, need_dx=True, mask_from=None):
+def train_backward(x, w, b, mean, invstd, relu, grad_out, need_dx=True, mask_from=None, tile_sums=None):
     """The training backward on raw tensors: -> (dx or None, grad_gamma f32 [C], grad_beta f32 [C], dy).
     `mask_from` (the block output y = relu(bn(x) + residual)): grad_out is first masked where y <= 0;
-    the masked gradient `dy` (what also flows to the residual) is returned as the 4th value."""
+    the masked gradient `dy` (what also flows to the residual) is returned as the 4th value.
+    `tile_sums` (f32 [tiles, C, 2], left on grad_out by the data-gradient launch that produced it,
+    conv.conv_backward(bnb=...)): the backward sums per tile -- no pass over (x, dy) for them."""
     n, c = x.shape
     if mask_from is not None:       # relu(bn(x) + residual): dy where the output is positive, for both
         g0 = grad_out.contiguous().to(mask_from.dtype)
@@ -94,6 +96,14 @@ def train_backward(x, w, b, mean, invstd, relu, grad_out, need_dx=True, mask_fro
     dx = torch.empty_like(x) if need_dx else None
     gg = torch.empty(c, dtype=torch.float32, device=x.device)
     gb = torch.empty(c, dtype=torch.float32, device=x.device)
+    if (tile_sums is not None and mask_from is None
+            and tuple(tile_sums.shape) == (-(-n // B.stats_tile_rows()), c, 2)):
+        B.check(B.lib().lidal_bn_bwd_tiles(B.ptr(x), B.ptr(g), g.stride(0), B.dtype_code(x.dtype), n, c, B.ptr(w),
+                                           B.ptr(b), int(relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),
+                                           B.ptr(gg), B.ptr(gb), B.ptr(tile_sums), tile_sums.shape[0],
+                                           B.stream()), 'bn_bwd')
+        B.hit('bn_bwd(tile sums)')
+        return dx, gg, gb, grad_out
     ws, nbytes = _ws(n, c, x.device)
     B.check(B.lib().lidal_bn_bwd(B.ptr(x), B.ptr(g), g.stride(0), B.dtype_code(x.dtype), n, c, B.ptr(w),
                                  B.ptr(b), int(relu), B.ptr(mean), B.ptr(invstd), B.ptr(dx),

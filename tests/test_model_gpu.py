@@ -503,8 +503,9 @@ def test_fused_block_functions_are_bitwise_the_per_operator_path(name, autocast,
     feats, coords = torch.from_numpy(g['feats']).to(DEV), torch.from_numpy(g['coords']).to(DEV)
     labels = torch.from_numpy(g['labels']).to(DEV)
     runs = []
-    saved = blocks.FUSE_BLOCKS
+    saved = blocks.FUSE_BLOCKS, blocks.BN_SUMS
     try:
+        blocks.BN_SUMS = False          # (sums from the data-gradient launches differ in rounding: their own test below)
         for fuse in (False, True):
             blocks.FUSE_BLOCKS = fuse
             model = fill_state_dict(_models()[name](19)).to(DEV).train()
@@ -522,7 +523,7 @@ def test_fused_block_functions_are_bitwise_the_per_operator_path(name, autocast,
             runs.append((loss.item(), logits.detach().clone(), [p.grad.clone() for p in model.parameters()],
                          [b.clone() for b in model.buffers()], nodes))
     finally:
-        blocks.FUSE_BLOCKS = saved
+        blocks.FUSE_BLOCKS, blocks.BN_SUMS = saved
     (l0, lg0, g0, b0, n0), (l1, lg1, g1, b1, n1) = runs
     assert l0 == l1 and torch.equal(lg0, lg1)
     for a, b in zip(g0, g1):
@@ -530,3 +531,40 @@ def test_fused_block_functions_are_bitwise_the_per_operator_path(name, autocast,
     for a, b in zip(b0, b1):                # running statistics / num_batches_tracked
         assert torch.equal(a, b)
     assert n1 < 0.8 * n0, (n0, n1)          # measured 253 -> 181 (SPVCNN), the rest are point-branch / glue nodes
+
+
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_bn_backward_sums_from_the_data_gradient_launches(name, golden_dir):
+    """Inside a residual block conv2's data gradient is bn1's output gradient: the launch that writes it also
+    leaves bn1's backward sums per 128-row tile (csrc/conv_img.hip BnBwd), and bn1's backward merges those
+    instead of making its own pass over (x, dy).  Same gradients up to the summation order of two
+    per-channel sums (f32 per tile + f64 merge against f64 throughout), and the path must really be taken."""
+    from lidal_amd import backend as B
+    from lidal_amd.network import blocks
+    from lidal_amd.train_step import forward_backward
+    from weights import fill_state_dict
+    g = _load(golden_dir)
+    feats, coords = torch.from_numpy(g['feats']).to(DEV), torch.from_numpy(g['coords']).to(DEV)
+    labels = torch.from_numpy(g['labels']).to(DEV)
+    runs = []
+    saved = blocks.BN_SUMS
+    try:
+        for on in (False, True):
+            blocks.BN_SUMS = on
+            model = fill_state_dict(_models()[name](19)).to(DEV).train()
+            if hasattr(model, 'dropout'):
+                model.dropout.p = 0.0
+            B.HITS.clear()
+            loss, _ = forward_backward(model, feats, coords, labels, autocast=True)
+            runs.append((loss.item(), {k: p.grad.double().cpu() for k, p in model.named_parameters()},
+                         B.HITS.get('bn_bwd(tile sums)', 0)))
+    finally:
+        blocks.BN_SUMS = saved
+    (l0, g0, h0), (l1, g1, h1) = runs
+    assert h0 == 0 and h1 == 16, (h0, h1)           # bn1 of the 16 residual blocks
+    assert l0 == l1                                 # the forward pass is untouched
+    worst = 0.0
+    for k in g0:
+        cos = ((g0[k] * g1[k]).sum() / (g0[k].norm() * g1[k].norm())).item()
+        worst = max(worst, 1 - cos, abs(g1[k].norm().item() / g0[k].norm().item() - 1))
+    assert worst < 2e-3, worst                      # bf16 storage downstream amplifies the last-bit change of the sums

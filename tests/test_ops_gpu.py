@@ -1030,3 +1030,37 @@ def test_neighbour_table_from_torchsparse_rule_lists(ks, stride):
     # ... and the convolution runs from it
     order = F.conv.RowOrder(got)
     assert order.n_rows == n_out
+
+
+@pytest.mark.parametrize('c,relu', [(32, True), (96, True), (128, False), (256, True)])
+def test_data_gradient_launch_leaves_the_batch_norm_backward_sums(c, relu):
+    """lidal_conv_dgrad_bn_sums + lidal_bn_bwd_tiles against the separate route (lidal_conv_apply_image, then
+    lidal_bn_bwd with its own pass for the sums): the data gradient is bitwise the same, grad_gamma /
+    grad_beta agree to 1e-5 of the largest (f32 per-tile sums merged in f64 against f64 throughout), dx
+    to bf16 rounding."""
+    from lidal_amd.nn.functional import conv as C
+    from lidal_amd.nn.functional import norm as N
+    F = _F()
+    coords = _surface_coords(60, 2, seed=c).to(DEV)
+    n = coords.shape[0]
+    km, _ = F.build_kernel_map(coords, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    g = torch.Generator().manual_seed(c)
+    w = (torch.randn(27, c, c, generator=g) * 0.05).to(DEV)
+    x_bn = (torch.randn(n, c, generator=g) * 1.5 + 0.3).to(DEV).bfloat16()       # bn input (conv1 output)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(c, generator=g) * 0.2).to(DEV)
+    mean = x_bn.float().mean(0)
+    invstd = torch.rsqrt(x_bn.float().var(0, unbiased=False) + 1e-5)
+    gout = torch.randn(n, c, generator=g).to(DEV).bfloat16()
+    order, kflip = C._bwd_order(km, False)
+    img = C._weight_image(w, torch.bfloat16, n, 1)
+    plain = C._apply(gout, img, 27, c, order, kflip)
+    fused = C._apply(gout, img, 27, c, order, kflip, None, False, (x_bn, mean, invstd, gamma, beta, relu))
+    assert torch.equal(plain, fused)
+    sums = fused._lidal_bnb_sums
+    assert sums.shape == (-(-n // 128), c, 2)
+    dx0, gg0, gb0, _ = N.train_backward(x_bn, gamma, beta, mean, invstd, relu, plain, True)
+    dx1, gg1, gb1, _ = N.train_backward(x_bn, gamma, beta, mean, invstd, relu, fused, True, None, sums)
+    for a, b in ((gg1, gg0), (gb1, gb0)):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max(), ((a - b).abs().max(), b.abs().max())
+    assert (dx1.float() - dx0.float()).abs().max() <= 2 ** -7 * dx0.float().abs().max()

@@ -58,8 +58,6 @@ constexpr int MAXK = 32;
 constexpr int NB4_LIMIT = 384;        // tiles up to which a 64-multiple column count takes 64-column blocks
 // ---- tiling policy, shared by the image packer and the launcher ------------------------------
 struct Tiling { int nb; int row_bytes; };       // 16-column blocks per workgroup, staged bytes per pass
-static int g_force_nb = 0;          // EXPERIMENT (temporary): lidal_debug_set(0, nb) forces the column blocks of wide layers
-static int g_tall = 0;              // EXPERIMENT (temporary): lidal_debug_set(1, mode) 1: G=4 x 2 waves, 2: G=2 x 4 waves
 
 __host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int esz) {
   Tiling t;
@@ -74,9 +72,6 @@ __host__ __device__ inline Tiling pick_tiling(int ci, int co, int64_t n_out, int
   else if (co <= 64 || (co % 64 == 0 && ((n_out + 127) / 128) * ((co + 127) / 128) <= NB4_LIMIT)) t.nb = 4;
   else if (co % 128 != 0 && (co % 96 == 0 || co < 128)) t.nb = 6;
   else t.nb = 8;
-#ifndef __HIP_DEVICE_COMPILE__
-  if (g_force_nb && co >= 128 && co % (16 * g_force_nb) == 0) t.nb = g_force_nb;
-#endif
   return t;
 }
 __host__ __device__ inline int64_t image_bytes(int k, int ci, int co, Tiling t, int esz) {
@@ -847,33 +842,6 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
   constexpr int D = IMG_DEPTH;
   constexpr int WREGION = ((D + 1) * SLAB > EPI) ? (D + 1) * SLAB : EPI;
   static_assert(BM == TILE_ROWS, "tile masks and BatchNorm statistics triples are per 128-row tile");
-  if constexpr (sizeof(T) == 2 && (ROW_BYTES == 128) && (NB == 4 || NB == 8)) {
-    if (g_tall && nbr != nullptr && ci % (ROW_BYTES / (int)sizeof(T)) == 0) {
-      auto launch_tall = [&](auto gc, auto wc) -> int {
-        constexpr int TG = decltype(gc)::value, TW = decltype(wc)::value;
-        constexpr int TEPI = TW * TG * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
-        constexpr int TWREG = (2 * SLAB > TEPI) ? 2 * SLAB : TEPI;
-        const size_t tl = TWREG + 1024 + TW * BN * 2 * sizeof(float);
-        auto tk = conv_apply_img_kernel<T, NB, ROW_BYTES, TG, TW, 2, false, 1>;
-        static size_t tattr[MAX_DEVICES] = {};
-        const int td = current_device();
-        if (tattr[td] < tl) {
-          LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
-          tattr[td] = tl;
-        }
-        dim3 tg((unsigned)cdiv(n_out, TW * TG * 16), (unsigned)cdiv(co, BN));
-        tk<<<tg, 64 * TW, tl, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out, ci, co, K, kflip,
-                                   ep.scale, ep.shift, ep.relu, (const T*)ep.res, ep.in_bytes, ep.img_bytes,
-                                   ep.nbr_bytes, ep.tile_stats, ep.bnb);
-        LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(tall)");
-        return 0;
-      };
-      if (g_tall == 1) return launch_tall(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
-      if (g_tall == 2) return launch_tall(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
-      if (g_tall == 3) return launch_tall(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-      if (g_tall == 4) return launch_tall(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
-    }
-  }
   if constexpr (G == 1 && NWAVES == 8) {
     if (ci % (ROW_BYTES / (int)sizeof(T)) == 0 && ep.in_bytes / ((unsigned)ci * sizeof(T)) < (1u << 24)) {
       // 256-row tiles (16 waves) where the weight slab outweighs the gathers of a 128-row tile
@@ -937,7 +905,6 @@ int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, con
 }  // namespace
 
 extern "C" int lidal_conv_stats_tile_rows(void) { return TILE_ROWS; }
-extern "C" int lidal_debug_set(int key, int value) { if (key == 0) g_force_nb = value; else g_tall = value; return 0; }
 
 extern "C" int lidal_conv_weight_image_tiling(int ci, int co, int dtype, int64_t n_out) {
   const Tiling t = pick_tiling(ci, co, n_out, dtype == LIDAL_BF16 ? 2 : 4);

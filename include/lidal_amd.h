@@ -67,6 +67,16 @@ int64_t lidal_downsample_workspace_bytes(int64_t n);
 int lidal_downsample(const int32_t* coords, int64_t n, int sx, int sy, int sz, int32_t* out,
                      int64_t* n_out_dev, void* ws, int64_t ws_bytes, void* stream);
 
+/* Every coarser level of a stride-2 encoder at once (the four F.spdownsample calls of network/spvcnn.py:28,34,
+ * 40,46 chained): level l = 1..levels is the sorted unique of floor(c / (2^l s)) * (2^l s) over the rows of
+ * `coords` (tensor stride s) -- the same rows in the same (batch, x, y, z) order as l chained lidal_downsample
+ * calls, from ONE sort and with ONE set of row counts to read back.  out i32 [levels * n, 4] capacity; level l
+ * occupies rows [starts[l-1], starts[l]); starts_dev i64 [levels + 1].  0 <= x, y, z < 65536, 0 <= batch < 8192,
+ * levels <= 4. */
+int64_t lidal_downsample_pyramid_workspace_bytes(int64_t n, int levels);
+int lidal_downsample_pyramid(const int32_t* coords, int64_t n, int sx, int sy, int sz, int levels, int32_t* out,
+                             int64_t* starts_dev, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- input voxelisation ("next" row 8f-1) ---------------------------------------------------- */
 /* replaces dataset/sk_dataset.py:143-171 for one scan: affine augmentation p*M (f64), feats =
  * (transformed metres, intensity), x`scale`, random translation into [0, full_scale)^3 from the

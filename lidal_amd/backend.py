@@ -40,6 +40,8 @@ SIGNATURES = {
     'lidal_unique_sorted_i64': (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     'lidal_downsample_workspace_bytes': (_i64, [_i64]),
     'lidal_downsample': (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    'lidal_downsample_pyramid_workspace_bytes': (_i64, [_i64, _i32]),
+    'lidal_downsample_pyramid': (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     'lidal_voxelize_points_workspace_bytes': (_i64, [_i64]),
     'lidal_voxelize_points': (_i32, [_vp, _vp, _i64, _vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _i64, _vp]),

@@ -610,6 +610,99 @@ extern "C" int lidal_downsample(const int32_t* coords, int64_t n, int sx, int sy
   return 0;
 }
 
+// ---- every coarser level of a stride-2 pyramid from ONE sort ---------------------------------
+// The encoder halves the resolution L times (network/spvcnn.py:28,34,40,46): level l is the sorted unique
+// of floor(c / (2^l s)) (2^l s) over the INPUT voxels -- chaining F.spdownsample gives the same sets
+// (floor of a floor) in the same (batch, x, y, z) order.  So instead of L dependent sorts with a host round
+// trip between them (each level's row count), the L key arrays of the input voxels are one array,
+// key = (level - 1) << 61 | batch << 48 | x << 32 | y << 16 | z, sorted once; the run heads are the levels'
+// voxels, level l's heads sit between sorted positions (l-1) n and l n.  One sync for all row counts.
+namespace {
+__global__ void __launch_bounds__(256) pyramid_keys_kernel(const int4* __restrict__ coords, int64_t n, int levels,
+                                                           int sx, int sy, int sz,
+                                                           uint64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  for (int l = 1; l <= levels; ++l) {
+    const int fx = sx << l, fy = sy << l, fz = sz << l;
+    const uint64_t x = (uint64_t)((c.x / fx) * fx), y = (uint64_t)((c.y / fy) * fy), z = (uint64_t)((c.z / fz) * fz);
+    keys[(int64_t)(l - 1) * n + i] = ((uint64_t)(l - 1) << 61) | ((uint64_t)c.w << 48) | (x << 32) | (y << 16) | z;
+  }
+}
+
+// run heads of the sorted keys -> coordinates; the thread that owns sorted position l * n also records how
+// many heads come before it: the first output row of level l + 1 (starts[levels] = all heads)
+__global__ void __launch_bounds__(kBlock) pyramid_compact_kernel(const uint64_t* __restrict__ s, int64_t total,
+                                                                 int64_t n, int levels,
+                                                                 const int64_t* __restrict__ offsets,
+                                                                 int64_t nblocks, int4* __restrict__ out,
+                                                                 int64_t* __restrict__ starts) {
+  __shared__ int wave_cnt[kBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  int64_t pos = offsets[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int64_t i = base + it * kBlock + threadIdx.x;
+    const uint64_t v = (i < total) ? s[i] : 0;
+    const bool head = (i < total) && (i == 0 || v != s[i - 1]);
+    int tot;
+    const int r = block_rank(head, wave_cnt, &tot);
+    if (i < total && i % n == 0) starts[i / n] = pos + r;         // (position l n is always a head: a new level)
+    if (head) {
+      int4 c;
+      c.w = (int)((v >> 48) & 0x1FFF);
+      c.x = (int)((v >> 32) & 0xFFFF);
+      c.y = (int)((v >> 16) & 0xFFFF);
+      c.z = (int)(v & 0xFFFF);
+      out[pos + r] = c;
+    }
+    pos += tot;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) starts[levels] = offsets[nblocks];
+}
+}  // namespace
+
+extern "C" int64_t lidal_downsample_pyramid_workspace_bytes(int64_t n, int levels) {
+  const int64_t q = (n > 0 ? n : 1) * (levels > 0 ? levels : 1);
+  const int64_t nblocks = cdiv(q, kTile);
+  return 2 * align_up(8 * q, 256) + align_up(4 * nblocks, 256) + align_up(8 * (nblocks + 1), 256) +
+         align_up(radix_sort_ws_bytes(q, 8, false), 256) + 256;
+}
+
+// coords i32 [n, 4] at tensor stride (sx, sy, sz); out i32 [levels * n, 4] capacity: level l (1-based: stride
+// 2^l s) occupies rows [starts[l-1], starts[l]); starts_dev i64 [levels + 1].  Requires 0 <= x, y, z < 65536,
+// 0 <= batch < 8192, levels <= 4.
+extern "C" int lidal_downsample_pyramid(const int32_t* coords, int64_t n, int sx, int sy, int sz, int levels,
+                                        int32_t* out, int64_t* starts_dev, void* ws, int64_t ws_bytes,
+                                        void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(sx > 0 && sy > 0 && sz > 0 && levels >= 1 && levels <= 4, "downsample_pyramid: bad stride / levels");
+  if (n == 0) {
+    LIDAL_HIP(hipMemsetAsync(starts_dev, 0, 8 * (levels + 1), s));
+    return 0;
+  }
+  LIDAL_REQUIRE(ws_bytes >= lidal_downsample_pyramid_workspace_bytes(n, levels), "downsample_pyramid ws too small");
+  const int64_t q = n * levels, nblocks = cdiv(q, kTile);
+  char* w = (char*)ws;
+  uint64_t* keys = (uint64_t*)w;    w += align_up(8 * q, 256);
+  uint64_t* sorted = (uint64_t*)w;  w += align_up(8 * q, 256);
+  int* counts = (int*)w;            w += align_up(4 * nblocks, 256);
+  int64_t* offs = (int64_t*)w;      w += align_up(8 * (nblocks + 1), 256);
+  void* tmp = (void*)w;
+  pyramid_keys_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>((const int4*)coords, n, levels, sx, sy, sz, keys);
+  LIDAL_CHECK_LAUNCH("pyramid_keys");
+  if (int rc = radix_sort(keys, nullptr, sorted, nullptr, q, 8, 63, tmp, radix_sort_ws_bytes(q, 8, false), s)) return rc;
+  head_count_kernel<<<(unsigned)nblocks, kBlock, 0, s>>>(sorted, q, counts);
+  LIDAL_CHECK_LAUNCH("head_count");
+  scan_counts_kernel<<<1, 1024, 0, s>>>(counts, nblocks, offs);
+  LIDAL_CHECK_LAUNCH("scan_counts");
+  pyramid_compact_kernel<<<(unsigned)nblocks, kBlock, 0, s>>>(sorted, q, n, levels, offs, nblocks, (int4*)out,
+                                                              starts_dev);
+  LIDAL_CHECK_LAUNCH("pyramid_compact");
+  return 0;
+}
+
 extern "C" int64_t lidal_downsample_workspace_bytes(int64_t n) {
   return 2 * align_up(8 * (n > 0 ? n : 1), 256) + lidal_unique_workspace_bytes(n);
 }

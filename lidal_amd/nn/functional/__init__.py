@@ -3,13 +3,13 @@ sphash, sphashquery, spcount, spvoxelize, spdevoxelize, calc_ti_weights, spdowns
 from .conv import KernelMap, build_kernel_map, conv3d
 from .count import spcount
 from .devoxelize import calc_ti_weights, spdevoxelize, ti_weights_and_index
-from .downsample import spdownsample, unique_sorted
+from .downsample import downsample_pyramid, spdownsample, unique_sorted
 from .fused import add_relu, cross_entropy
 from .hash import sphash
 from .query import HashTable, coords_table, sphashquery
 from .voxelize import spvoxelize
 
 __all__ = ['sphash', 'sphashquery', 'HashTable', 'coords_table', 'spcount', 'spvoxelize', 'spdevoxelize',
-           'calc_ti_weights', 'ti_weights_and_index', 'spdownsample', 'unique_sorted', 'conv3d',
+           'calc_ti_weights', 'ti_weights_and_index', 'spdownsample', 'downsample_pyramid', 'unique_sorted', 'conv3d',
            'add_relu', 'cross_entropy',
            'KernelMap', 'build_kernel_map']

@@ -172,7 +172,11 @@ def build_kernel_map(coords, in_stride, kernel_size, stride, scope=None):
     table = coords_table(coords, scope)
     out_coords = coords
     if any(s > 1 for s in stride):
-        out_coords = spdownsample(coords, stride, kernel_size, in_stride)
+        # (prefetch_kernel_maps may have produced every level's coordinates already, from one sort)
+        out_stride = tuple(in_stride[k] * stride[k] for k in range(3))
+        out_coords = scope.get(out_stride) if scope is not None else None
+        if out_coords is None:
+            out_coords = spdownsample(coords, stride, kernel_size, in_stride)
     n_in, n_out = coords.shape[0], out_coords.shape[0]
     nbr_out = torch.empty((volume, n_out), dtype=torch.int, device=dev)
     ws_bytes = B.lib().lidal_kmap_workspace_bytes(n_out, volume)
@@ -207,6 +211,17 @@ def prefetch_kernel_maps(x, plan, transposed=True):
     prepares the transposed tables the decoder uses."""
     coords, cur = x.coords, tuple(x.stride)
     x.cmaps.setdefault(cur, coords)
+    # the coordinates of every coarser level from ONE sort (F.downsample_pyramid) when the encoder is the usual
+    # chain of stride-2 / kernel-2 downsamplings: one host round trip instead of one per level
+    downs = [(make_ntuple(k, ndim=3), make_ntuple(s_, ndim=3)) for k, s_ in plan
+             if any(v > 1 for v in make_ntuple(s_, ndim=3))]
+    if (1 <= len(downs) <= 4 and all(k == (2, 2, 2) and s_ == (2, 2, 2) for k, s_ in downs)
+            and coords.is_cuda and coords.shape[0] > 0 and max(cur) << len(downs) < 65536):
+        strides = [tuple(c << (l + 1) for c in cur) for l in range(len(downs))]
+        if not any(st in x.cmaps for st in strides):
+            from .downsample import downsample_pyramid
+            for st, c in zip(strides, downsample_pyramid(coords, len(downs), cur)):
+                x.cmaps[st] = c
     want = []                   # (kmap, 'out' | 'in') whose row order is still to be built
     for kernel_size, stride in plan:
         kernel_size = make_ntuple(kernel_size, ndim=3)

@@ -6,7 +6,7 @@ import torch
 from ... import backend as B
 from ...utils import make_ntuple
 
-__all__ = ['spdownsample', 'unique_sorted']
+__all__ = ['spdownsample', 'unique_sorted', 'downsample_pyramid']
 
 
 def unique_sorted(keys):
@@ -43,3 +43,24 @@ def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
     B.check(B.lib().lidal_downsample(B.ptr(coords), n, ss[0], ss[1], ss[2], B.ptr(out),
                                      B.ptr(n_out), B.ptr(ws), ws_bytes, B.stream()), 'downsample')
     return out[:int(n_out.item())]
+
+
+def downsample_pyramid(coords, levels, tensor_stride=1):
+    """[spdownsample(spdownsample(... coords ...))] for `levels` chained stride-2 / kernel-2 downsamplings
+    (the encoder of network/spvcnn.py:28-46), all from one sort of the input voxels and with one host
+    round trip for all row counts: a list of `levels` coordinate tensors (views of one buffer), the l-th
+    at tensor stride 2^(l+1) * tensor_stride.  Same rows, same order as the chain."""
+    tensor_stride = make_ntuple(tensor_stride, ndim=3)
+    B.require_gpu(coords)
+    assert coords.dtype == torch.int and coords.shape[1] == 4 and 1 <= levels <= 4
+    coords = coords.contiguous()
+    n = coords.shape[0]
+    out = torch.empty((max(n * levels, 1), 4), dtype=torch.int, device=coords.device)
+    starts = torch.empty(levels + 1, dtype=torch.int64, device=coords.device)
+    ws_bytes = B.lib().lidal_downsample_pyramid_workspace_bytes(n, levels)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=coords.device)
+    B.check(B.lib().lidal_downsample_pyramid(B.ptr(coords), n, tensor_stride[0], tensor_stride[1], tensor_stride[2],
+                                             levels, B.ptr(out), B.ptr(starts), B.ptr(ws), ws_bytes, B.stream()),
+            'downsample')
+    st = starts.tolist()
+    return [out[st[l]:st[l + 1]] for l in range(levels)]

@@ -1064,3 +1064,19 @@ def test_data_gradient_launch_leaves_the_batch_norm_backward_sums(c, relu):
     for a, b in ((gg1, gg0), (gb1, gb0)):
         assert (a - b).abs().max() <= 1e-5 * b.abs().max(), ((a - b).abs().max(), b.abs().max())
     assert (dx1.float() - dx0.float()).abs().max() <= 2 ** -7 * dx0.float().abs().max()
+
+
+@pytest.mark.parametrize('ts,levels', [(1, 4), (2, 3), (1, 1)])
+def test_downsample_pyramid_equals_the_chained_downsamples(ts, levels):
+    """F.downsample_pyramid: every coarser level from one sort of the input voxels == spdownsample chained
+    `levels` times (same rows, same (batch, x, y, z) order), on a ragged batch with non-contiguous batch ids."""
+    F = _F()
+    c = _coords(40000, extent=300, batches=3, seed=ts, stride=ts).to(DEV)
+    c[:, 3] = c[:, 3] * 5 + 2                                     # batch ids 2, 7, 12
+    pyr = F.downsample_pyramid(c, levels, ts)
+    cur, s = c, ts
+    for l in range(levels):
+        cur = F.spdownsample(cur, 2, 2, s)
+        s *= 2
+        assert torch.equal(pyr[l], cur), l
+    assert len(F.downsample_pyramid(torch.zeros((0, 4), dtype=torch.int, device=DEV), 2, 1)[1]) == 0

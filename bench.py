@@ -248,7 +248,7 @@ def roofline_conv(args, coords, dev, reps=20):
     # `bench.py --roofline-only`, corrected as MI355X_MICROARCH.md prescribes) and kept under
     # profiles/; reported only if that record is of this exact workload
     traffic, traffic_src = None, None
-    for name in ('r02_pmc_conv_apply.json',):
+    for name in ('r03_pmc_conv_apply.json', 'r02_pmc_conv_apply.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             wl = rec['workload']
@@ -271,15 +271,17 @@ def roofline_conv(args, coords, dev, reps=20):
 # per-family roofline of one whole step
 # ---------------------------------------------------------------------------------------------
 FAMILY_OF = {
-    'lidal_conv_apply': 'conv_apply', 'lidal_conv_apply_image': 'conv_apply', 'lidal_conv_wgrad': 'conv_wgrad',
+    'lidal_conv_apply': 'conv_apply', 'lidal_conv_apply_image': 'conv_apply', 'lidal_conv_dgrad_bn_sums': 'conv_apply',
+    'lidal_conv_wgrad': 'conv_wgrad',
     'lidal_conv_weight_pack': 'weight_pack', 'lidal_conv_weight_image': 'weight_pack',
     'lidal_conv_weight_image_pair': 'weight_pack',
-    'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
+    'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_bwd_tiles': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
     'lidal_downsample': 'kernel_maps', 'lidal_kmap_build': 'kernel_maps', 'lidal_kmap_invert': 'kernel_maps',
-    'lidal_kmap_order': 'kernel_maps', 'lidal_floor_coords': 'kernel_maps',
+    'lidal_kmap_order': 'kernel_maps', 'lidal_floor_coords': 'kernel_maps', 'lidal_kmap_order_batch': 'kernel_maps',
+    'lidal_downsample_pyramid': 'kernel_maps', 'lidal_kmap_from_rules': 'kernel_maps',
     'lidal_count': 'point_voxel', 'lidal_voxelize_fwd': 'point_voxel', 'lidal_voxelize_bwd': 'point_voxel',
     'lidal_devoxelize_fwd': 'point_voxel', 'lidal_devoxelize_bwd': 'point_voxel',
     'lidal_invlist_build': 'point_voxel', 'lidal_voxelize_fwd_sorted': 'point_voxel',
@@ -345,7 +347,7 @@ def family_table(step, coords, dtype_name, step_ms):
         f = FAMILY_OF.get(name, 'other_lib')
         ms = e0.elapsed_time(e1)
         by = fl = 0.0
-        if name in ('lidal_conv_apply', 'lidal_conv_apply_image'):
+        if name in ('lidal_conv_apply', 'lidal_conv_apply_image', 'lidal_conv_dgrad_bn_sums'):
             n_in, n_out, ci, co, k, dt = a[6], a[7], a[8], a[9], a[10], a[12]
             b = 2 if dt == 1 else 4
             m = rules_of(k, n_in, n_out)
@@ -370,7 +372,8 @@ def family_table(step, coords, dtype_name, step_ms):
         elif name in ('lidal_bn_train_fwd', 'lidal_bn_eval_fwd', 'lidal_bn_train_fwd_tiles'):
             # the statistics pass that `_tiles` no longer makes stays in the algorithmic count (3 N C b)
             by = (2 if name == 'lidal_bn_eval_fwd' else 3) * a[2] * a[3] * (2 if a[1] == 1 else 4)
-        elif name == 'lidal_bn_bwd':
+        elif name in ('lidal_bn_bwd', 'lidal_bn_bwd_tiles'):
+            # (x, dy, dy_stride, dtype, n, c, ...): the sums pass `_tiles` no longer makes stays in the count (5 N C b)
             by = 5 * a[4] * a[5] * (2 if a[3] == 1 else 4)
         elif name == 'lidal_colsum':
             by = a[2] * a[3] * (2 if a[1] == 1 else 4)
@@ -397,6 +400,10 @@ def family_table(step, coords, dtype_name, step_ms):
             by = (8 + 8) * a[1]
         elif name == 'lidal_downsample':
             by = 16 * a[1] + 16 * a[1] // 4                     # rows in, ~1/4 of them out
+        elif name == 'lidal_downsample_pyramid':
+            by = 16 * a[1] + 16 * a[1] // 2                     # rows in, all coarser levels out (~1/2 of them together)
+        elif name == 'lidal_kmap_order_batch':
+            pass                                                # (host arrays of pointers: priced with lidal_kmap_build's rules)
         elif name == 'lidal_kmap_invert':
             by = 4 * a[2] * (a[1] + a[4])                       # [k, n_out] read, [k, n_in] written
         elif name == 'lidal_kmap_order':
@@ -435,9 +442,10 @@ def family_table(step, coords, dtype_name, step_ms):
         out[f] = row
     # self-check of the pricing: the weight gradients do 2 M Ci Co per layer, the forward + data gradient
     # 4 M Ci Co (the stem's data gradient is not computed, the rest is) -> the ratio sits at ~0.5
+    pricing_check = None
     if 'conv_apply' in fam and 'conv_wgrad' in fam and fam['conv_apply']['flops'] > 0:
         ratio = fam['conv_wgrad']['flops'] / fam['conv_apply']['flops']
-        assert 0.4 <= ratio <= 0.6, 'family pricing is off: wgrad / (fwd + dgrad) FLOPs = %.3f' % ratio
+        pricing_check = {'wgrad_over_fwd_plus_dgrad_flops': round(ratio, 3), 'ok': bool(0.4 <= ratio <= 0.6)}
     # COMPULSORY bytes of the step, SURVEY.md 8(d): every convolution moves each feature row once
     # forward and (2 in + 1 out) backward, its weights and rule pairs; a BatchNorm / ReLU / residual sum
     # that directly follows a convolution costs nothing extra (fusable); kernel maps, point<->voxel and
@@ -454,6 +462,7 @@ def family_table(step, coords, dtype_name, step_ms):
         'ms': round(step_ms, 3), 'profiled_step_ms': round(prof_ms, 3), 'algorithmic_GB': round(tot_by / 1e9, 3),
         'GFLOP': round(tot_fl / 1e9, 1),
         'hbm_frac': round(tot_by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        'pricing_check': pricing_check,
         'compulsory_GB': round(comp / 1e9, 3),
         'hbm_frac_compulsory': round(comp / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         'mfma_frac': round(tot_fl / (step_ms * 1e-3) / 1e12 / peak_tf, 4),
@@ -630,6 +639,35 @@ def bench_scoring(args, model, world, rank, dev, frames, batches):
     return out
 
 
+def guarded(fn, *a):
+    """The extras of the line (roofline, families, variants, secondary) never cost the contract fields."""
+    try:
+        return fn(*a)
+    except Exception as e:              # noqa: BLE001
+        return {'error': repr(e)}
+
+
+def run_variants(args, batch, dev):
+    var = {}
+    one = make_batch(1, args.points, 7122, dev)
+    var['single_scan'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, one,
+                                                  max(args.steps, 10), 3, ddp=False))
+    # the reference draws a new augmentation per iteration (sk_dataset.py:143-171): 8 differently
+    # augmented batches of the same scans, voxelised on the GPU outside the timed region, one per step
+    fresh = make_fresh_batches(args.frames, args.points, 7122, dev, 8)
+    var['fresh_coords'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, fresh,
+                                                   max(args.steps, 16), 8, ddp=False))
+    var['fresh_coords']['voxels_per_batch'] = [int(b[0].shape[0]) for b in fresh]
+    del fresh
+    other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
+    var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
+                                                max(3, args.steps // 2), 2, ddp=False))
+    other_model = 'minkunet' if args.model == 'spvcnn' else 'spvcnn'
+    var[other_model] = variant_line(bench_train(1, 0, dev, other_model, args.dtype, batch,
+                                                args.steps, 3, ddp=False))
+    return var
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -643,10 +681,10 @@ def main():
         frames, batches = make_scoring_inputs(args, world, rank)
         log('scoring inputs generated')
         if solo and not args.no_cpu_baseline:
-            cpu_lines['secondary'] = scoring_cpu_baseline(frames, args.nei[0])
+            cpu_lines['secondary'] = guarded(scoring_cpu_baseline, frames, args.nei[0])
             log('scoring cpu baseline', cpu_lines['secondary'])
     if solo and not args.no_cpu_baseline and not args.roofline_only:
-        cpu_lines['train'] = cpu_baseline(args)
+        cpu_lines['train'] = guarded(cpu_baseline, args)
         log('train cpu baseline', cpu_lines['train'])
     # ---- GPU
     world, rank, dev = dist_setup(args)
@@ -675,33 +713,17 @@ def main():
                    'parallelism': 'dp%d' % world, 'loss': round(res['loss'], 4)},
     }
     if rank == 0 and not args.no_roofline:
-        line['roofline'] = roofline_conv(args, batch[0], dev)
+        line['roofline'] = guarded(roofline_conv, args, batch[0], dev)
         log('roofline', line['roofline'])
     if solo and not args.no_families:
-        line['families'] = family_table(res['step'], batch[0], args.dtype, ms)
+        line['families'] = guarded(family_table, res['step'], batch[0], args.dtype, ms)
         log('families', line['families'])
     if solo and not args.no_variants:
-        var = {}
-        one = make_batch(1, args.points, 7122, dev)
-        var['single_scan'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, one,
-                                                      max(args.steps, 10), 3, ddp=False))
-        # the reference draws a new augmentation per iteration (sk_dataset.py:143-171): 8 differently
-        # augmented batches of the same scans, voxelised on the GPU outside the timed region, one per step
-        fresh = make_fresh_batches(args.frames, args.points, 7122, dev, 8)
-        var['fresh_coords'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, fresh,
-                                                       max(args.steps, 16), 8, ddp=False))
-        var['fresh_coords']['voxels_per_batch'] = [int(b[0].shape[0]) for b in fresh]
-        del fresh
-        other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
-        var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
-                                                    max(3, args.steps // 2), 2, ddp=False))
-        other_model = 'minkunet' if args.model == 'spvcnn' else 'spvcnn'
-        var[other_model] = variant_line(bench_train(1, 0, dev, other_model, args.dtype, batch,
-                                                    args.steps, 3, ddp=False))
-        line['variants'] = var
-        log('variants', var)
+        line['variants'] = guarded(run_variants, args, batch, dev)
+        log('variants', line['variants'])
     if frames is not None:
-        sec = bench_scoring(args, res['model'], world, rank, dev, frames, batches)
+        sec = (guarded(bench_scoring, args, res['model'], world, rank, dev, frames, batches) if world == 1
+               else bench_scoring(args, res['model'], world, rank, dev, frames, batches))
         log('secondary', sec)
         if rank == 0:
             line['secondary'] = sec

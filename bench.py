@@ -505,6 +505,9 @@ def cpu_baseline(args, rank_seed=7122, sample_points=None, max_threads=32, runs=
     times = sorted(times[1:])
     tot, fwd, bwd = times[len(times) // 2]
     n = coords.shape[0]
+    # the intra-op pool of the CPU run must not linger: its (spinning) workers compete with the one Python
+    # thread that issues the GPU work -- the host-bound single-scan variant measured 2-3 ms slower after it
+    torch.set_num_threads(1)
     return {'value': round(n / tot, 1), 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
             'sample': '1 synthetic scan of %d points (%d voxels), %s f32 fwd+CE+bwd on the CPU oracle: '
                       'median of %d runs after 1 warm-up (fwd %.1f s, bwd %.1f s)'

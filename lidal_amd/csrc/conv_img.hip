@@ -151,8 +151,11 @@ weight_image_batch_kernel(const ImageJob* __restrict__ jobs, int n_jobs, int64_t
 
 // Tuning constants of the lean kernel (the measured alternatives are in profiles/README.md; the timing-only
 // ablation switches of rounds 1-2 lived here and are gone: scripts/exp/README.md names the commit that has them)
+// rows per workgroup tile of every kernel of this file == rows per BatchNorm statistics triple
+constexpr int TILE_ROWS = 128;
 constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (16 waves / 256 rows measured slower)
 constexpr int LEAN_MINWAVES = 4;       // waves per SIMD the register budget must allow: 2 workgroups per CU
+static int64_t DEEP_MAX_ROWS = 150000;  // up to this many output rows the deep form of the lean kernel runs
 
 // Optional second job of a DATA-GRADIENT launch: the tile's share of the backward sums of the BatchNorm
 // whose output gradient this launch produces (out = dy of y = act(bn(x))): per column sum(dy') and
@@ -826,11 +829,217 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
 
 
 
+// ------------------------------------------------------------------------------------------
+// the deep form of the lean kernel: slabs and gathers TWO phases ahead (rings of three)
+// ------------------------------------------------------------------------------------------
+// On the coarse levels a launch is as long as its heaviest tile: a 128-row tile that touches all 27
+// offsets of a 256-channel layer runs 27 x 4 slices = 108 phases back to back, ~1.2 us each
+// (profiles/README.md, round 3) -- and a phase computes for only ~0.4 us: the rest is the latency of
+// the next slab (the 3.5 MB weight image of such a layer does not stay in the 4 MB L2 next to the
+// gathered rows) that ONE phase of look-ahead does not cover, with too few workgroups per CU to
+// hide it (1-2.6).  Here phase p issues index(p+3), slab(p+2) and A(p+2); same accumulation order
+// (offsets ascending, slices ascending), hence bitwise the lean kernel's results.  Used where the
+// rows are few (launch_img); on the fine levels -- gather-throughput bound, 3 resident workgroups --
+// two phases of look-ahead measured slower (round 2).
+template <typename T, int NB, int ROW_BYTES, int NWAVES, bool DENSE>
+__global__ void __launch_bounds__(64 * NWAVES, LEAN_MINWAVES)
+conv_lean_deep_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int* __restrict__ nbr,
+                      const int* __restrict__ perm, const unsigned* __restrict__ tmasks,
+                      T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
+                      const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int ep_relu,
+                      const T* __restrict__ ep_res, unsigned in_bytes, unsigned img_bytes,
+                      unsigned nbr_bytes, float* __restrict__ tile_stats, BnBwd bnb) {
+  constexpr int BM = NWAVES * 16;
+  constexpr int BN = 16 * NB;
+  constexpr int CH = DT<T>::CH;
+  constexpr int KC = ROW_BYTES / (int)sizeof(T);
+  constexpr int MAXCC = KC / CH;
+  constexpr int SLAB = BN * ROW_BYTES;
+  constexpr int PIECES = SLAB / 1024;
+  constexpr int PPW = (PIECES + NWAVES - 1) / NWAVES;
+  constexpr int DMA_WAVES = PIECES / PPW;
+  constexpr int IL = DENSE ? 0 : 1;
+  static_assert(PIECES % PPW == 0 && DMA_WAVES <= NWAVES, "a DMA wave moves a whole share");
+  static_assert(ROW_BYTES % 64 == 0 && SLAB % 1024 == 0, "slices are whole MFMA steps / DMA pieces");
+  static_assert(BM == TILE_ROWS, "tile masks are per 128 rows");
+  typedef typename DT<T>::frag frag;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;                              // [3][SLAB], re-used as the epilogue tile
+  constexpr int EPI = NWAVES * 16 * (BN + DT<T>::VEC) * (int)sizeof(T) + NWAVES * BN * 2 * (int)sizeof(float);
+  constexpr int WREGION = (3 * SLAB > EPI) ? 3 * SLAB : EPI;
+  unsigned char* dump = smem + WREGION;                  // 4 KiB: where the DMA of a phase past the end lands
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row16 = lane & 15;
+  const int gsel = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * 16;
+  const int n0 = blockIdx.y * BN;
+  const int npass = ci / KC;
+
+  unsigned tmask = 1u;
+  if constexpr (!DENSE) {
+    unsigned m = 0u;
+    const int64_t t0 = ((int64_t)blockIdx.x * BM) >> 7;
+    if (t0 * 128 < n_out) m = tmasks[t0];
+    if (kflip) m = __brev(m) >> (32 - K);
+    tmask = __builtin_amdgcn_readfirstlane(m);
+  }
+  const int nphase = __popc(tmask) * npass;
+
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wimg), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nbr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, (int)nbr_bytes, 0x00020000);
+
+  constexpr unsigned OOB_OFF = 0x80000000u;
+  const unsigned row_bytes = (unsigned)ci * (unsigned)sizeof(T);
+  const unsigned lane_off = (unsigned)gsel * 16u;
+  const unsigned idx_voff = (unsigned)((r0 + row16) * 4);
+  const bool row_in = r0 + row16 < n_out;
+  const unsigned k_stride = (unsigned)n_out * 4u;
+  const unsigned slab_k = (unsigned)gridDim.y * (unsigned)npass * (unsigned)SLAB;
+  const unsigned slab_base = (unsigned)blockIdx.y * (unsigned)npass * (unsigned)SLAB + (unsigned)(wave * PPW) * 1024u;
+  const unsigned dma_voff = (unsigned)lane * 16u;
+  const bool dma_wave = wave < DMA_WAVES;
+  unsigned char* const dma_dst = wl + (wave * PPW) * 1024;
+  const unsigned char* const wbase = wl + (gsel * NB) * 256 + row16 * 16;
+
+  const __amdgpu_buffer_rsrc_t rs_perm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int*>(perm), 0, perm != nullptr ? (int)k_stride : 0, 0x00020000);
+  const int perm_v = __builtin_amdgcn_raw_buffer_load_b32(rs_perm, idx_voff, 0, 0);
+
+  unsigned rem = tmask;
+  int wk = 0, wpass = npass - 1;
+  auto advance = [&]() {
+    if (++wpass == npass) {
+      wpass = 0;
+      wk = rem ? __builtin_ctz(rem) : 0;
+      rem &= rem - 1u;
+    }
+  };
+  auto issue_idx = [&](int k) -> int {
+    if constexpr (DENSE) {
+      return (int)(r0 + row16);
+    } else {
+      const unsigned kk = (unsigned)(kflip ? (K - 1 - k) : k);
+      return __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, idx_voff, kk * k_stride, 0);
+    }
+  };
+  // every DMA wave issues its PPW pieces in EVERY phase (a phase past the end reads out of range -- zeros,
+  // no memory traffic -- into the dump): the counted waits below rely on it
+  auto issue_dma = [&](int k, int pass, auto slot_c, bool live) {
+    constexpr int slot = decltype(slot_c)::value;
+    if (dma_wave) {
+      const unsigned soff = live ? (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base : OOB_OFF;
+      unsigned char* base = live ? dma_dst + slot * SLAB : dump;
+      static_assert(PPW <= 12, "DMA share");
+#pragma unroll
+      for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
+        auto* dst = (__attribute__((address_space(3))) void*)(base + (live ? c4 * 4096 : 0));
+        const unsigned so = live ? soff + (unsigned)(c4 * 4096) : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
+        if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
+        if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
+        if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
+      }
+    }
+  };
+  auto issue_a = [&](raw4 (&a)[MAXCC], int idx, int pass, bool live) __attribute__((always_inline)) -> unsigned long long {
+    const bool has = idx >= 0 && row_in && live;
+    unsigned off = __umul24((unsigned)idx, row_bytes) + lane_off;
+    off = has ? off : OOB_OFF;
+    const unsigned soff = (unsigned)pass * (unsigned)ROW_BYTES;
+#pragma unroll
+    for (int cc = 0; cc < MAXCC; ++cc)
+      a[cc] = __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + (unsigned)(cc * 64), soff, 0));
+    return __ballot(has);
+  };
+
+  f32x4 acc[1][NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[0][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const raw4 (&a)[MAXCC], unsigned long long have, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+    if (have != 0ull) {
+#pragma unroll
+      for (int cc = 0; cc < MAXCC; ++cc) {
+        frag b[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          b[j] = *reinterpret_cast<const frag*>(wbase + slot * SLAB + (cc * 4 * NB + j) * 256);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mma(acc[0][j], __builtin_bit_cast(frag, a[cc]), b[j]);
+      }
+    }
+  };
+  // slab(p+1) has landed: behind it only A(p+1), and this phase's index load, slab(p+2) share and A(p+2)
+  constexpr int TAIL = 2 * MAXCC + IL + PPW;
+  auto slab_wait = [&]() {
+    if (dma_wave) __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));
+    __syncthreads();
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+
+  raw4 a0[MAXCC], a1[MAXCC], a2[MAXCC];
+  unsigned long long h0 = 0ull, h1 = 0ull, h2 = 0ull;
+  if (nphase > 0) {
+    advance();
+    int k0 = wk, p0 = wpass, i0 = issue_idx(k0);
+    advance();
+    int k1 = wk, p1 = wpass, i1 = issue_idx(k1);
+    advance();
+    int k2 = wk, p2 = wpass, i2 = issue_idx(k2);
+    issue_dma(k0, p0, S0{}, true);
+    h0 = issue_a(a0, i0, p0, true);
+    issue_dma(k1, p1, S1{}, 1 < nphase);
+    h1 = issue_a(a1, i1, p1, 1 < nphase);
+    // slab(0) has landed: behind it A(0), slab(1), A(1)
+    if (dma_wave) {
+      constexpr int T0 = 2 * MAXCC + PPW;
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (T0 & 15) | ((T0 >> 4) << 14));
+    }
+    __syncthreads();
+    int p = 0;
+    while (true) {
+      // phase p in slot 0: index(p+3) -> (k0, i0), slab(p+2) / A(p+2) -> slot 2
+      advance(); k0 = wk; p0 = wpass; i0 = issue_idx(k0);
+      issue_dma(k2, p2, S2{}, p + 2 < nphase);
+      h2 = issue_a(a2, i2, p2, p + 2 < nphase);
+      compute(a0, h0, S0{});
+      slab_wait();
+      if (++p >= nphase) break;
+      // phase p in slot 1: index(p+3) -> (k1, i1), slab(p+2) / A(p+2) -> slot 0
+      advance(); k1 = wk; p1 = wpass; i1 = issue_idx(k1);
+      issue_dma(k0, p0, S0{}, p + 2 < nphase);
+      h0 = issue_a(a0, i0, p0, p + 2 < nphase);
+      compute(a1, h1, S1{});
+      slab_wait();
+      if (++p >= nphase) break;
+      // phase p in slot 2: index(p+3) -> (k2, i2), slab(p+2) / A(p+2) -> slot 1
+      advance(); k2 = wk; p2 = wpass; i2 = issue_idx(k2);
+      issue_dma(k1, p1, S1{}, p + 2 < nphase);
+      h1 = issue_a(a1, i1, p1, p + 2 < nphase);
+      compute(a2, h2, S2{});
+      slab_wait();
+      if (++p >= nphase) break;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);               // the dump writes of the phases past the end are done
+  __syncthreads();
+  store_tile<T, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
+                               ep_res, true, perm_v, tile_stats, -1, &bnb);
+}
+
 struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; BnBwd bnb; };
 
 constexpr int IMG_G = 1, IMG_NWAVES = 8, IMG_DEPTH = 1;       // generic kernel: row groups per wave, waves, pipeline depth
-// rows per workgroup tile of every kernel of this file == rows per BatchNorm statistics triple
-constexpr int TILE_ROWS = 128;
 
 template <typename T, int NB, int ROW_BYTES>
 int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm, const unsigned* tmasks,
@@ -851,6 +1060,26 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
       constexpr int LEAN_LDS = (2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS;
+      // few rows (coarse levels): the launch is as long as its heaviest tile's chain of phases -> two phases
+      // of look-ahead (conv_lean_deep_kernel); many rows: gather throughput, three resident workgroups
+      if (nbr != nullptr && n_out <= DEEP_MAX_ROWS && (ROW_BYTES == 128 || ROW_BYTES == 256 || NB >= 6)) {
+        constexpr int DEPI = LEPI + LSTATS;
+        constexpr int DEEP_LDS = ((3 * SLAB > DEPI) ? 3 * SLAB : DEPI) + 4096;
+        auto dk = conv_lean_deep_kernel<T, NB, ROW_BYTES, LW, false>;
+        static size_t deep_attr[MAX_DEVICES] = {};
+        const int ddev = current_device();
+        if (deep_attr[ddev] < (size_t)DEEP_LDS) {
+          LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dk),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS));
+          deep_attr[ddev] = DEEP_LDS;
+        }
+        dim3 dgrid((unsigned)cdiv(n_out, LBM), (unsigned)cdiv(co, BN));
+        dk<<<dgrid, 64 * LW, DEEP_LDS, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
+                                            ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
+                                            ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, ep.bnb);
+        LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(deep)");
+        return 0;
+      }
       auto lk = nbr ? conv_lean_kernel<T, NB, ROW_BYTES, LW, false>
                     : conv_lean_kernel<T, NB, ROW_BYTES, LW, true>;
       static size_t lean_attr[2][MAX_DEVICES] = {};
@@ -905,6 +1134,8 @@ int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, con
 }  // namespace
 
 extern "C" int lidal_conv_stats_tile_rows(void) { return TILE_ROWS; }
+// (tuning hook of scripts/exp/deep_rows.py: the row count up to which the two-phase look-ahead kernel runs)
+extern "C" int lidal_debug_set_deep_rows(int64_t rows) { DEEP_MAX_ROWS = rows; return 0; }
 
 extern "C" int lidal_conv_weight_image_tiling(int ci, int co, int dtype, int64_t n_out) {
   const Tiling t = pick_tiling(ci, co, n_out, dtype == LIDAL_BF16 ? 2 : 4);

@@ -155,7 +155,7 @@ weight_image_batch_kernel(const ImageJob* __restrict__ jobs, int n_jobs, int64_t
 constexpr int TILE_ROWS = 128;
 constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (16 waves / 256 rows measured slower)
 constexpr int LEAN_MINWAVES = 4;       // waves per SIMD the register budget must allow: 2 workgroups per CU
-static int64_t DEEP_MAX_ROWS = 150000;  // up to this many output rows the deep form of the lean kernel runs
+constexpr int64_t DEEP_MAX_ROWS = 150000;      // up to this many output rows the deep form of the lean kernel runs
 
 // Optional second job of a DATA-GRADIENT launch: the tile's share of the backward sums of the BatchNorm
 // whose output gradient this launch produces (out = dy of y = act(bn(x))): per column sum(dy') and
@@ -1060,9 +1060,12 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
       constexpr int LEAN_LDS = (2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS;
-      // few rows (coarse levels): the launch is as long as its heaviest tile's chain of phases -> two phases
-      // of look-ahead (conv_lean_deep_kernel); many rows: gather throughput, three resident workgroups
-      if (nbr != nullptr && n_out <= DEEP_MAX_ROWS && (ROW_BYTES == 128 || ROW_BYTES == 256 || NB >= 6)) {
+      // the 256-wide layers of the coarse levels (4+ slices per offset, few rows): two phases of look-ahead,
+      // conv_lean_deep_kernel -- measured on every layer shape of the model (scripts/exp/deep_rows.py, bit-equal
+      // everywhere): 256->256 on 43k rows 131 -> 112 us, 384->256 194 -> 163; neutral to 6 % slower on the
+      // others (and on every shape of a single scan), which therefore keep the lean kernel
+      if constexpr (sizeof(T) == 2 && NB == 8 && ROW_BYTES == 128) {
+       if (nbr != nullptr && n_out <= DEEP_MAX_ROWS && n_out >= 30000 && ci >= 256) {
         constexpr int DEPI = LEPI + LSTATS;
         constexpr int DEEP_LDS = ((3 * SLAB > DEPI) ? 3 * SLAB : DEPI) + 4096;
         auto dk = conv_lean_deep_kernel<T, NB, ROW_BYTES, LW, false>;
@@ -1079,6 +1082,7 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
                                             ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, ep.bnb);
         LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(deep)");
         return 0;
+       }
       }
       auto lk = nbr ? conv_lean_kernel<T, NB, ROW_BYTES, LW, false>
                     : conv_lean_kernel<T, NB, ROW_BYTES, LW, true>;
@@ -1134,8 +1138,6 @@ int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, con
 }  // namespace
 
 extern "C" int lidal_conv_stats_tile_rows(void) { return TILE_ROWS; }
-// (tuning hook of scripts/exp/deep_rows.py: the row count up to which the two-phase look-ahead kernel runs)
-extern "C" int lidal_debug_set_deep_rows(int64_t rows) { DEEP_MAX_ROWS = rows; return 0; }
 
 extern "C" int lidal_conv_weight_image_tiling(int ci, int co, int dtype, int64_t n_out) {
   const Tiling t = pick_tiling(ci, co, n_out, dtype == LIDAL_BF16 ? 2 : 4);

@@ -1,5 +1,7 @@
 """GPU: the lean convolution kernel against its deep form (slabs and gathers two phases ahead) on every layer
-shape of the U-Net, bench batch (FRAMES scans): bitwise equality and time.  lidal_debug_set_deep_rows picks."""
+shape of the U-Net, bench batch (FRAMES scans): bitwise equality and time.  RECORD: it drove a temporary
+lidal_debug_set_deep_rows(rows) hook and a launcher that offered the deep kernel for every tiling (commit
+"conv_lean_deep_kernel: slabs and gathers two phases ahead ..."); results in profiles/README.md."""
 import ctypes
 import os
 import sys

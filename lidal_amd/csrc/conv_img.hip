@@ -657,6 +657,8 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* wl = smem;                              // [2][SLAB], re-used as the epilogue tile
+  constexpr int LEPI_ALL = NWAVES * 16 * (BN + DT<T>::VEC) * (int)sizeof(T) + NWAVES * BN * 2 * (int)sizeof(float);
+  unsigned char* const dump = smem + ((2 * SLAB > LEPI_ALL) ? 2 * SLAB : LEPI_ALL);     // 4 KiB
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -724,21 +726,25 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
       return __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, idx_voff, kk * k_stride, 0);
     }
   };
+  // EVERY wave issues PPW DMA instructions per phase -- a wave without a share of the slab aims out of range
+  // (zeros, no memory traffic) at the dump: hipcc counts vector-memory operations statically, and behind a
+  // wave-dependent branch it could not count these -- its wait for a phase's A fragments then also covered the
+  // index load and the first DMA pieces issued IN that phase: one exposed memory round trip per phase
+  // (0.55 us from L2 at stride 16, 1.2 us beyond it at stride 8; profiles/README.md, round 3)
   auto issue_dma = [&](int k, int pass, auto slot_c) {
     constexpr int slot = decltype(slot_c)::value;
-    if (dma_wave) {
-      const unsigned soff = (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base;
-      static_assert(PPW <= 12, "DMA share");
-      // four 1-KiB pieces per M0 value (the immediate offset field ends at 4095)
+    const unsigned soff = dma_wave ? (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base : OOB_OFF;
+    unsigned char* const base = dma_wave ? dma_dst + slot * SLAB : dump;
+    static_assert(PPW <= 12, "DMA share");
+    // four 1-KiB pieces per M0 value (the immediate offset field ends at 4095)
 #pragma unroll
-      for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
-        auto* dst = (__attribute__((address_space(3))) void*)(dma_dst + slot * SLAB + c4 * 4096);
-        const unsigned so = soff + (unsigned)(c4 * 4096);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
-        if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
-        if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
-        if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
-      }
+    for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
+      auto* dst = (__attribute__((address_space(3))) void*)(base + (dma_wave ? c4 * 4096 : 0));
+      const unsigned so = dma_wave ? soff + (unsigned)(c4 * 4096) : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
+      if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
+      if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
+      if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
     }
   };
   // A fragments of (neighbour rows idx, slice pass); returns the ballot of rows that have a rule.
@@ -779,7 +785,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   // the next slab has landed: of this wave's loads only the MAXCC gathers issued behind its DMA may
   // still be in flight (waves without a DMA share have nothing to wait for)
   auto slab_wait = [&]() {
-    if (dma_wave) __builtin_amdgcn_s_waitcnt(0x0F70 | (MAXCC & 15) | ((MAXCC >> 4) << 14));
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (MAXCC & 15) | ((MAXCC >> 4) << 14));
     __syncthreads();
   };
   using S0 = std::integral_constant<int, 0>;
@@ -931,21 +937,20 @@ conv_lean_deep_kernel(const T* __restrict__ in, const T* __restrict__ wimg, cons
   };
   // every DMA wave issues its PPW pieces in EVERY phase (a phase past the end reads out of range -- zeros,
   // no memory traffic -- into the dump): the counted waits below rely on it
-  auto issue_dma = [&](int k, int pass, auto slot_c, bool live) {
+  auto issue_dma = [&](int k, int pass, auto slot_c, bool live_phase) {
     constexpr int slot = decltype(slot_c)::value;
-    if (dma_wave) {
-      const unsigned soff = live ? (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base : OOB_OFF;
-      unsigned char* base = live ? dma_dst + slot * SLAB : dump;
-      static_assert(PPW <= 12, "DMA share");
+    const bool live = live_phase && dma_wave;           // (every wave issues, see the lean kernel)
+    const unsigned soff = live ? (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base : OOB_OFF;
+    unsigned char* base = live ? dma_dst + slot * SLAB : dump;
+    static_assert(PPW <= 12, "DMA share");
 #pragma unroll
-      for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
-        auto* dst = (__attribute__((address_space(3))) void*)(base + (live ? c4 * 4096 : 0));
-        const unsigned so = live ? soff + (unsigned)(c4 * 4096) : OOB_OFF;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
-        if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
-        if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
-        if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
-      }
+    for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
+      auto* dst = (__attribute__((address_space(3))) void*)(base + (live ? c4 * 4096 : 0));
+      const unsigned so = live ? soff + (unsigned)(c4 * 4096) : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
+      if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
+      if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
+      if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
     }
   };
   auto issue_a = [&](raw4 (&a)[MAXCC], int idx, int pass, bool live) __attribute__((always_inline)) -> unsigned long long {
@@ -980,7 +985,7 @@ conv_lean_deep_kernel(const T* __restrict__ in, const T* __restrict__ wimg, cons
   // slab(p+1) has landed: behind it only A(p+1), and this phase's index load, slab(p+2) share and A(p+2)
   constexpr int TAIL = 2 * MAXCC + IL + PPW;
   auto slab_wait = [&]() {
-    if (dma_wave) __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (TAIL & 15) | ((TAIL >> 4) << 14));
     __syncthreads();
   };
   using S0 = std::integral_constant<int, 0>;
@@ -1001,7 +1006,7 @@ conv_lean_deep_kernel(const T* __restrict__ in, const T* __restrict__ wimg, cons
     issue_dma(k1, p1, S1{}, 1 < nphase);
     h1 = issue_a(a1, i1, p1, 1 < nphase);
     // slab(0) has landed: behind it A(0), slab(1), A(1)
-    if (dma_wave) {
+    {
       constexpr int T0 = 2 * MAXCC + PPW;
       __builtin_amdgcn_s_waitcnt(0x0F70 | (T0 & 15) | ((T0 >> 4) << 14));
     }
@@ -1059,7 +1064,7 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       static_assert(LBM == TILE_ROWS, "tile masks and BatchNorm statistics triples are per 128-row tile");
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
-      constexpr int LEAN_LDS = (2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS;
+      constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + 4096;      // + the DMA dump
       // the 256-wide layers of the coarse levels (4+ slices per offset, few rows): two phases of look-ahead,
       // conv_lean_deep_kernel -- measured on every layer shape of the model (scripts/exp/deep_rows.py, bit-equal
       // everywhere): 256->256 on 43k rows 131 -> 112 us, 384->256 194 -> 163; neutral to 6 % slower on the

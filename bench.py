@@ -283,6 +283,7 @@ FAMILY_OF = {
     'lidal_kmap_order': 'kernel_maps', 'lidal_floor_coords': 'kernel_maps', 'lidal_kmap_order_batch': 'kernel_maps',
     'lidal_downsample_pyramid': 'kernel_maps', 'lidal_kmap_from_rules': 'kernel_maps',
     'lidal_count': 'point_voxel', 'lidal_voxelize_fwd': 'point_voxel', 'lidal_voxelize_bwd': 'point_voxel',
+    'lidal_voxelize_fwd_1to1': 'point_voxel',
     'lidal_devoxelize_fwd': 'point_voxel', 'lidal_devoxelize_bwd': 'point_voxel',
     'lidal_invlist_build': 'point_voxel', 'lidal_voxelize_fwd_sorted': 'point_voxel',
     'lidal_devoxelize_bwd_sorted': 'point_voxel', 'lidal_ti_weights': 'point_voxel',
@@ -417,6 +418,8 @@ def family_table(step, coords, dtype_name, step_ms):
         elif name in ('lidal_voxelize_fwd_sorted', 'lidal_devoxelize_bwd_sorted'):
             m_rows, c, dt, n_ent = a[5], a[6], a[7], a[8]
             by = (n_ent + m_rows) * c * (2 if dt == 1 else 4)
+        elif name == 'lidal_voxelize_fwd_1to1':
+            by = 2 * a[3] * a[4] * (2 if a[5] == 1 else 4)                          # a row in, a row out
         elif name == 'lidal_voxelize_bwd':
             by = ((2 if a[3] else 1) * a[5] + a[6]) * a[7] * (2 if a[8] == 1 else 4)     # gin (+ residual) + gout rows
         elif name == 'lidal_devoxelize_fwd':

@@ -157,6 +157,10 @@ int lidal_count(const int32_t* idx, int64_t n, int32_t* out, int64_t m, void* st
  * network/utils.py:22,25,56).  out[idx[i]] += feat[i] / counts[idx[i]]; f32 only. */
 int lidal_voxelize_fwd(const float* feat, const int32_t* idx, const int32_t* counts, float* out,
                        int64_t n, int64_t m, int c, void* stream);
+/* The same when every voxel holds exactly one point (idx a permutation of 0..n-1; LiDAL's scans arrive
+ * voxelised, network/spvcnn.py:114): out[idx[i]] = feat[i], bit-equal to the mean form, f32 or bf16 rows. */
+int lidal_voxelize_fwd_1to1(const void* feat, const int32_t* idx, void* out, int64_t n, int c, int dtype,
+                            void* stream);
 /* backward: gin[i] = gout[idx[i]] / counts[idx[i]] (+ residual[i], same dtype [n, c], may be NULL:
  * the gradient reaching the same point rows through a second consumer of the features). */
 int lidal_voxelize_bwd(const void* gout, const int32_t* idx, const int32_t* counts,

@@ -52,6 +52,7 @@ SIGNATURES = {
     'lidal_kmap_from_rules': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     'lidal_count': (_i32, [_vp, _i64, _vp, _i64, _vp]),
     'lidal_voxelize_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    'lidal_voxelize_fwd_1to1': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'lidal_voxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     'lidal_devoxelize_fwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     'lidal_devoxelize_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),

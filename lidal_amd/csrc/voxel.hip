@@ -490,6 +490,41 @@ extern "C" int lidal_voxelize_fwd(const float* feat, const int32_t* idx, const i
   return 0;
 }
 
+// Every voxel has exactly ONE point (LiDAL: the dataset already voxelised the scan, network/spvcnn.py:114 with
+// pres == vres): the mean over a voxel's points is the point row itself, `out[idx[i]] = feat[i]` -- a row
+// permutation, no contributor lists (their sort) and no wave per voxel.  idx must be a permutation of 0..n-1
+// (the caller knows: as many distinct voxel hashes as points).
+namespace {
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) voxelize_1to1_kernel(const T* __restrict__ feat, const int* __restrict__ idx,
+                                                            T* __restrict__ out, int64_t n, int c) {
+  const int cv = c / VEC;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * cv) return;
+  const int64_t i = t / cv;
+  const int j = (int)(t - i * cv) * VEC;
+  const int pos = idx[i];
+  if (pos < 0 || pos >= n) return;
+  const T* src = feat + i * c + j;
+  T* dst = out + (int64_t)pos * c + j;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) dst[v] = src[v];
+}
+}  // namespace
+
+extern "C" int lidal_voxelize_fwd_1to1(const void* feat, const int32_t* idx, void* out, int64_t n, int c,
+                                       int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0 || c == 0) return 0;
+  if (dtype == LIDAL_F32)
+    DISPATCH_TVEC(voxelize_1to1_kernel, float, c, n, (const float*)feat, idx, (float*)out, n, c);
+  else if (dtype == LIDAL_BF16)
+    DISPATCH_TVEC(voxelize_1to1_kernel, __bf16, c, n, (const __bf16*)feat, idx, (__bf16*)out, n, c);
+  else { set_error("voxelize_fwd_1to1: bad dtype %d", dtype); return 2; }
+  LIDAL_CHECK_LAUNCH("lidal_voxelize_fwd_1to1");
+  return 0;
+}
+
 extern "C" int lidal_voxelize_bwd(const void* gout, const int32_t* idx, const int32_t* counts,
                                   const void* residual, void* gin, int64_t n, int64_t m, int c,
                                   int dtype, void* stream) {

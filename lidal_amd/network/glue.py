@@ -38,6 +38,10 @@ def initial_voxelize(z, init_res, after_res):
     sparse_hash = F.unique_sorted(pc_hash)
     idx_query = F.sphashquery(pc_hash, sparse_hash)
     counts = F.spcount(idx_query.int(), len(sparse_hash))
+    if len(sparse_hash) == pc_hash.numel():
+        # as many voxels as points (the reference's datasets voxelise the scans at this very resolution,
+        # sk_dataset.py:160-171): the index is a permutation and every count is 1 -- F.spvoxelize then moves rows
+        idx_query._lidal_one_to_one = True
     inserted_coords = torch.round(F.spvoxelize(floored, idx_query, counts)).int()
     inserted_feat = F.spvoxelize(z.F, idx_query, counts)
     new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)

@@ -31,7 +31,12 @@ class VoxelizeFunction(Function):
         n, c = feats.shape
         m = counts.shape[0]
         out = torch.empty((m, c), dtype=feats.dtype, device=feats.device)
-        if c % 4 == 0:      # ordered per-voxel gather: no atomics, reproducible
+        if getattr(coords, '_lidal_one_to_one', False) and n == m:
+            # one point per voxel (network/glue.py initial_voxelize found as many voxels as points): the mean is
+            # the row itself -- a row permutation instead of contributor lists + one wave per voxel
+            B.check(B.lib().lidal_voxelize_fwd_1to1(B.ptr(feats), B.ptr(idx32), B.ptr(out), n, c,
+                                                    B.dtype_code(feats.dtype), B.stream()), 'voxelize_fwd_1to1')
+        elif c % 4 == 0:    # ordered per-voxel gather: no atomics, reproducible
             order, seg_ptr = inverse_lists(idx32, m)
             ws, nbytes = segment_workspace(n, m, c, feats.device)
             B.check(B.lib().lidal_voxelize_fwd_sorted(B.ptr(feats), B.ptr(order), B.ptr(seg_ptr),

@@ -1080,3 +1080,27 @@ def test_downsample_pyramid_equals_the_chained_downsamples(ts, levels):
         s *= 2
         assert torch.equal(pyr[l], cur), l
     assert len(F.downsample_pyramid(torch.zeros((0, 4), dtype=torch.int, device=DEV), 2, 1)[1]) == 0
+
+
+@pytest.mark.parametrize('dtype,c', [(torch.float32, 4), (torch.float32, 32), (torch.bfloat16, 32), (torch.bfloat16, 256)])
+def test_one_point_per_voxel_voxelize_is_the_mean_form(dtype, c):
+    """When every voxel holds exactly one point (what initial_voxelize finds on LiDAL's pre-voxelised scans),
+    F.spvoxelize moves rows (lidal_voxelize_fwd_1to1) instead of building contributor lists: bit-equal output
+    and gradient to the general form."""
+    F = _F()
+    g = torch.Generator().manual_seed(c)
+    n = 50001
+    idx = torch.randperm(n, generator=g).to(DEV)
+    counts = torch.ones(n, dtype=torch.int, device=DEV)
+    x = torch.randn(n, c, generator=g).to(DEV).to(dtype)
+    outs = []
+    for fast in (False, True):
+        i2 = idx.clone()
+        if fast:
+            i2._lidal_one_to_one = True
+        xi = x.clone().requires_grad_(True)
+        y = F.spvoxelize(xi, i2, counts)
+        y.backward(torch.arange(n * c, device=DEV).reshape(n, c).to(dtype) * 1e-3)
+        outs.append((y.detach(), xi.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[1][0][idx], x)

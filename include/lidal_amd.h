@@ -120,6 +120,16 @@ int lidal_kmap_build(const void* table, int64_t table_bytes, const int32_t* out_
  * n_bad_dev i32 [1] counts rules with an index out of range (0 = fine). */
 int lidal_kmap_from_rules(const int32_t* nbmaps, const int32_t* nbsizes, int k, int64_t n_rules,
                           int64_t n_in, int64_t n_out, int32_t* nbr_out, int32_t* n_bad_dev, void* stream);
+/* All kernel maps of a network in one chain of launches (n_jobs <= 12; HOST arrays of length n_jobs holding,
+ * per map, the arguments of lidal_kmap_build; nbmaps[j] == NULL: neighbour table only): every stage (fill,
+ * probe, count, scan, compact, sizes) is one launch over all maps.  Results per map are those of
+ * lidal_kmap_build.  ws >= lidal_kmap_build_batch_workspace_bytes(n_out, k, n_jobs). */
+int64_t lidal_kmap_build_batch_workspace_bytes(const int64_t* n_out, const int32_t* k, int n_jobs);
+int lidal_kmap_build_batch(const void* const* tables, const int64_t* table_bytes,
+                           const int32_t* const* out_coords, const int64_t* n_out,
+                           const int32_t* const* offsets, const int32_t* k, const int32_t* symmetric,
+                           int32_t* const* nbr_out, int32_t* const* nbmaps, int32_t* const* nbsizes,
+                           int64_t* const* koff, int n_jobs, void* ws, int64_t ws_bytes, void* stream);
 /* nbr_in i32 [k, n_in]: output row fed by input row i through offset k, or -1 (inverse table, used
  * by data-gradient and transposed convolution). */
 int lidal_kmap_invert(const int32_t* nbr_out, int64_t n_out, int k, int32_t* nbr_in, int64_t n_in,

@@ -48,6 +48,8 @@ SIGNATURES = {
     'lidal_kmap_workspace_bytes': (_i64, [_i64, _i32]),
     'lidal_kmap_build': (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                 _i64, _vp]),
+    'lidal_kmap_build_batch_workspace_bytes': (_i64, [_vp, _vp, _i32]),
+    'lidal_kmap_build_batch': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     'lidal_kmap_invert': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp]),
     'lidal_kmap_from_rules': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     'lidal_count': (_i32, [_vp, _i64, _vp, _i64, _vp]),

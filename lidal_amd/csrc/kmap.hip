@@ -23,9 +23,8 @@ constexpr int kItems = 4;                    // elements per thread
 constexpr int kTile = kBlock * kItems;       // elements per workgroup
 
 // Exclusive scan of `counts[n]` (int) -> offsets[n] (int64), total -> offsets[n].
-__global__ void __launch_bounds__(1024) scan_counts_kernel(const int* __restrict__ counts,
-                                                           int64_t n,
-                                                           int64_t* __restrict__ offsets) {
+__device__ __forceinline__ void scan_counts_body(const int* __restrict__ counts, int64_t n,
+                                                 int64_t* __restrict__ offsets) {
   __shared__ int64_t wave_sum[16];
   __shared__ int64_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
@@ -50,6 +49,10 @@ __global__ void __launch_bounds__(1024) scan_counts_kernel(const int* __restrict
     __syncthreads();
   }
   if (threadIdx.x == 0) offsets[n] = carry_s;
+}
+__global__ void __launch_bounds__(1024) scan_counts_kernel(const int* __restrict__ counts, int64_t n,
+                                                           int64_t* __restrict__ offsets) {
+  scan_counts_body(counts, n, offsets);
 }
 
 // block-level ordered rank: returns the exclusive rank of this thread's kept element among the
@@ -217,19 +220,14 @@ __device__ __forceinline__ void lookup_batch(const TableView& t, const uint64_t 
 // thread per (row, offset) pair x kItems rows: the K look-ups of a row are independent, so they run
 // as separate threads rather than one serial chain per row); nbr_out[k][j] stores are coalesced
 // along j; counts[k][b] = hits of the block.
-__global__ void __launch_bounds__(kBlock) kmap_probe_kernel(TableView t,
-                                                            const int4* __restrict__ coords,
-                                                            int64_t n_out,
-                                                            const int* __restrict__ offsets, int K,
-                                                            int* __restrict__ nbr_out,
-                                                            int* __restrict__ counts,
-                                                            int64_t nblocks) {
+__device__ __forceinline__ void kmap_probe_body(const TableView& t, const int4* __restrict__ coords, int64_t n_out,
+                                                const int* __restrict__ offsets, int* __restrict__ nbr_out,
+                                                int* __restrict__ counts, int64_t nblocks, int64_t bx, int k) {
   __shared__ int cnt;
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  const int k = blockIdx.y;
   const int ox = offsets[k * 3 + 0], oy = offsets[k * 3 + 1], oz = offsets[k * 3 + 2];
-  const int64_t base = (int64_t)blockIdx.x * kTile;
+  const int64_t base = bx * kTile;
   uint64_t key[kItems];
   bool ok[kItems];
   int r[kItems];
@@ -250,21 +248,24 @@ __global__ void __launch_bounds__(kBlock) kmap_probe_kernel(TableView t,
   }
   if (lane_id() == 0) atomicAdd(&cnt, found);
   __syncthreads();
-  if (threadIdx.x == 0) counts[(int64_t)k * nblocks + blockIdx.x] = cnt;
+  if (threadIdx.x == 0) counts[(int64_t)k * nblocks + bx] = cnt;
+}
+__global__ void __launch_bounds__(kBlock) kmap_probe_kernel(TableView t, const int4* __restrict__ coords,
+                                                            int64_t n_out, const int* __restrict__ offsets, int K,
+                                                            int* __restrict__ nbr_out, int* __restrict__ counts,
+                                                            int64_t nblocks) {
+  kmap_probe_body(t, coords, n_out, offsets, nbr_out, counts, nblocks, blockIdx.x, blockIdx.y);
 }
 
 // pass 1 (symmetric form): when the output coordinates ARE the input coordinates and the kernel is
 // odd and centred (every k3 stride-1 conv), rule (i, j, k) implies rule (j, i, K-1-k) and the centre
 // offset is the identity.  Only the first K/2 offsets are probed (grid.y = K/2); each hit also
 // fills its mirror entry (a unique (offset, row) slot, so no write conflicts).  Halves the probes.
-__global__ void __launch_bounds__(kBlock) kmap_probe_sym_kernel(TableView t,
-                                                                const int4* __restrict__ coords,
-                                                                int64_t n,
-                                                                const int* __restrict__ offsets,
-                                                                int K, int* __restrict__ nbr_out) {
-  const int64_t base = (int64_t)blockIdx.x * kTile;
+__device__ __forceinline__ void kmap_probe_sym_body(const TableView& t, const int4* __restrict__ coords, int64_t n,
+                                                    const int* __restrict__ offsets, int K,
+                                                    int* __restrict__ nbr_out, int64_t bx, int k) {
+  const int64_t base = bx * kTile;
   const int half = K / 2;
-  const int k = blockIdx.y;
   const int ox = offsets[k * 3 + 0], oy = offsets[k * 3 + 1], oz = offsets[k * 3 + 2];
   uint64_t key[kItems];
   bool ok[kItems];
@@ -286,17 +287,19 @@ __global__ void __launch_bounds__(kBlock) kmap_probe_sym_kernel(TableView t,
     if (r[it] >= 0) nbr_out[(int64_t)(K - 1 - k) * n + r[it]] = (int)j;
   }
 }
+__global__ void __launch_bounds__(kBlock) kmap_probe_sym_kernel(TableView t, const int4* __restrict__ coords,
+                                                                int64_t n, const int* __restrict__ offsets, int K,
+                                                                int* __restrict__ nbr_out) {
+  kmap_probe_sym_body(t, coords, n, offsets, K, nbr_out, blockIdx.x, blockIdx.y);
+}
 
 // per-(offset, block) counts of an already filled table (feeds the same scan + compaction)
-__global__ void __launch_bounds__(kBlock) kmap_count_kernel(const int* __restrict__ nbr_out,
-                                                            int64_t n_out, int K,
-                                                            int* __restrict__ counts,
-                                                            int64_t nblocks) {
+__device__ __forceinline__ void kmap_count_body(const int* __restrict__ nbr_out, int64_t n_out,
+                                                int* __restrict__ counts, int64_t nblocks, int64_t bx, int k) {
   __shared__ int cnt;
-  const int k = blockIdx.y;
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  int64_t base = (int64_t)blockIdx.x * kTile;
+  int64_t base = bx * kTile;
   int found = 0;
 #pragma unroll
   for (int it = 0; it < kItems; ++it) {
@@ -306,19 +309,20 @@ __global__ void __launch_bounds__(kBlock) kmap_count_kernel(const int* __restric
   }
   if (lane_id() == 0) atomicAdd(&cnt, found);
   __syncthreads();
-  if (threadIdx.x == 0) counts[(int64_t)k * nblocks + blockIdx.x] = cnt;
+  if (threadIdx.x == 0) counts[(int64_t)k * nblocks + bx] = cnt;
+}
+__global__ void __launch_bounds__(kBlock) kmap_count_kernel(const int* __restrict__ nbr_out, int64_t n_out, int K,
+                                                            int* __restrict__ counts, int64_t nblocks) {
+  kmap_count_body(nbr_out, n_out, counts, nblocks, blockIdx.x, blockIdx.y);
 }
 
 // pass 3: ordered compaction of (in_idx, out_idx) pairs, block (b, k).
-__global__ void __launch_bounds__(kBlock) kmap_compact_kernel(const int* __restrict__ nbr_out,
-                                                              int64_t n_out,
-                                                              const int64_t* __restrict__ offsets,
-                                                              int64_t nblocks,
-                                                              int2* __restrict__ nbmaps) {
+__device__ __forceinline__ void kmap_compact_body(const int* __restrict__ nbr_out, int64_t n_out,
+                                                  const int64_t* __restrict__ offsets, int64_t nblocks,
+                                                  int2* __restrict__ nbmaps, int64_t bx, int k) {
   __shared__ int wave_cnt[kBlock / 64];
-  int k = blockIdx.y;
-  int64_t base = (int64_t)blockIdx.x * kTile;
-  int64_t pos = offsets[(int64_t)k * nblocks + blockIdx.x];
+  int64_t base = bx * kTile;
+  int64_t pos = offsets[(int64_t)k * nblocks + bx];
 #pragma unroll
   for (int it = 0; it < kItems; ++it) {
     int64_t j = base + it * kBlock + threadIdx.x;
@@ -328,6 +332,11 @@ __global__ void __launch_bounds__(kBlock) kmap_compact_kernel(const int* __restr
     if (r >= 0) nbmaps[pos + rank] = make_int2(r, (int)j);
     pos += tot;
   }
+}
+__global__ void __launch_bounds__(kBlock) kmap_compact_kernel(const int* __restrict__ nbr_out, int64_t n_out,
+                                                              const int64_t* __restrict__ offsets, int64_t nblocks,
+                                                              int2* __restrict__ nbmaps) {
+  kmap_compact_body(nbr_out, n_out, offsets, nblocks, nbmaps, blockIdx.x, blockIdx.y);
 }
 
 __global__ void kmap_sizes_kernel(const int64_t* __restrict__ offsets, int64_t nblocks, int K,
@@ -802,6 +811,148 @@ extern "C" int lidal_kmap_from_rules(const int32_t* nbmaps, const int32_t* nbsiz
   kmap_from_rules_kernel<<<(unsigned)cdiv(n_rules, 256), 256, 0, s>>>((const int2*)nbmaps, nbsizes, k, n_rules,
                                                                       n_in, n_out, nbr_out, n_bad_dev);
   LIDAL_CHECK_LAUNCH("lidal_kmap_from_rules");
+  return 0;
+}
+
+// ---- all kernel maps of a network in one chain of launches ------------------------------------
+// A U-Net builds 9 maps per step, each a chain of 4-6 small launches (fill, probe, count, scan, compact,
+// sizes): 46 launches of ~5 us of latency each.  Here every stage is ONE launch over all maps, the map
+// descriptors travelling by value in the kernel arguments; each map's results are exactly those of
+// lidal_kmap_build (the same device functions, the same block -> rows assignment).
+namespace {
+constexpr int MAX_KMAP_JOBS = 12;
+struct KmapBatch {
+  unsigned long long* tkeys[MAX_KMAP_JOBS]; int* tvals[MAX_KMAP_JOBS]; unsigned long long tmask[MAX_KMAP_JOBS];
+  const int4* coords[MAX_KMAP_JOBS]; const int* offsets[MAX_KMAP_JOBS];
+  int* nbr[MAX_KMAP_JOBS]; int2* nbmaps[MAX_KMAP_JOBS]; int* nbsizes[MAX_KMAP_JOBS]; long long* koff[MAX_KMAP_JOBS];
+  int* counts[MAX_KMAP_JOBS]; long long* offs[MAX_KMAP_JOBS];
+  long long n_out[MAX_KMAP_JOBS], nblocks[MAX_KMAP_JOBS];
+  long long probe0[MAX_KMAP_JOBS + 1];        // first block of map j in the probe launch (nblocks x k, or k/2 if symmetric)
+  long long full0[MAX_KMAP_JOBS + 1];         // first block of map j in the count / compact launches (nblocks x k)
+  long long fill0[MAX_KMAP_JOBS + 1];         // first element of map j in the fill launch (symmetric maps: the mirrored half)
+  int k[MAX_KMAP_JOBS], sym[MAX_KMAP_JOBS], rules[MAX_KMAP_JOBS];
+  int n_jobs;
+};
+__device__ __forceinline__ int kjob_of(const long long* first, int n_jobs, long long i) {
+  int j = 0;
+#pragma unroll 1
+  for (int t = 1; t < n_jobs; ++t) j += (i >= first[t]) ? 1 : 0;
+  return j;
+}
+__global__ void __launch_bounds__(256) kmap_fill_batch_kernel(KmapBatch b) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.fill0[b.n_jobs]) return;
+  const int j = kjob_of(b.fill0, b.n_jobs, i);
+  const int K = b.k[j];
+  b.nbr[j][(long long)(K / 2 + 1) * b.n_out[j] + (i - b.fill0[j])] = -1;
+}
+__global__ void __launch_bounds__(kBlock) kmap_probe_batch_kernel(KmapBatch b) {
+  const long long blk = blockIdx.x;
+  const int j = kjob_of(b.probe0, b.n_jobs, blk);
+  const long long l = blk - b.probe0[j];
+  const long long bx = l % b.nblocks[j];
+  const int k = (int)(l / b.nblocks[j]);
+  TableView t;
+  t.keys = b.tkeys[j]; t.vals = b.tvals[j]; t.mask = b.tmask[j];
+  if (b.sym[j]) kmap_probe_sym_body(t, b.coords[j], b.n_out[j], b.offsets[j], b.k[j], b.nbr[j], bx, k);
+  else kmap_probe_body(t, b.coords[j], b.n_out[j], b.offsets[j], b.nbr[j], b.counts[j], b.nblocks[j], bx, k);
+}
+__global__ void __launch_bounds__(kBlock) kmap_count_batch_kernel(KmapBatch b) {
+  const long long blk = blockIdx.x;
+  const int j = kjob_of(b.full0, b.n_jobs, blk);
+  if (!b.sym[j] || !b.rules[j]) return;           // counted by its probe / no rule lists wanted
+  const long long l = blk - b.full0[j];
+  kmap_count_body(b.nbr[j], b.n_out[j], b.counts[j], b.nblocks[j], l % b.nblocks[j], (int)(l / b.nblocks[j]));
+}
+__global__ void __launch_bounds__(1024) kmap_scan_batch_kernel(KmapBatch b) {
+  const int j = blockIdx.x;
+  if (!b.rules[j]) return;
+  scan_counts_body(b.counts[j], b.nblocks[j] * b.k[j], (int64_t*)b.offs[j]);
+}
+__global__ void __launch_bounds__(kBlock) kmap_compact_batch_kernel(KmapBatch b) {
+  const long long blk = blockIdx.x;
+  const int j = kjob_of(b.full0, b.n_jobs, blk);
+  if (!b.rules[j]) return;
+  const long long l = blk - b.full0[j];
+  kmap_compact_body(b.nbr[j], b.n_out[j], (const int64_t*)b.offs[j], b.nblocks[j], b.nbmaps[j], l % b.nblocks[j],
+                    (int)(l / b.nblocks[j]));
+}
+__global__ void __launch_bounds__(64) kmap_sizes_batch_kernel(KmapBatch b) {
+  const int j = blockIdx.x, k = threadIdx.x, K = b.k[j];
+  if (!b.rules[j]) return;
+  const long long* offsets = b.offs[j];
+  const long long nblocks = b.nblocks[j];
+  if (k < K) {
+    const long long a = offsets[(long long)k * nblocks], e = offsets[(long long)(k + 1) * nblocks];
+    b.nbsizes[j][k] = (int)(e - a);
+    b.koff[j][k] = a;
+  }
+  if (k == K) b.koff[j][K] = offsets[(long long)K * nblocks];
+}
+}  // namespace
+
+extern "C" int64_t lidal_kmap_build_batch_workspace_bytes(const int64_t* n_out, const int32_t* k, int n_jobs) {
+  int64_t total = 256;
+  for (int j = 0; j < n_jobs; ++j) total += lidal_kmap_workspace_bytes(n_out[j], k[j]);
+  return total;
+}
+
+// Host arrays of length n_jobs (<= 12): the arguments of lidal_kmap_build per map.  nbmaps[j] == NULL: table only.
+extern "C" int lidal_kmap_build_batch(const void* const* tables, const int64_t* table_bytes,
+                                      const int32_t* const* out_coords, const int64_t* n_out,
+                                      const int32_t* const* offsets, const int32_t* k, const int32_t* symmetric,
+                                      int32_t* const* nbr_out, int32_t* const* nbmaps, int32_t* const* nbsizes,
+                                      int64_t* const* koff, int n_jobs, void* ws, int64_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_REQUIRE(n_jobs >= 0 && n_jobs <= MAX_KMAP_JOBS, "kmap_build_batch: at most %d maps", MAX_KMAP_JOBS);
+  if (n_jobs == 0) return 0;
+  LIDAL_REQUIRE(ws_bytes >= lidal_kmap_build_batch_workspace_bytes(n_out, k, n_jobs), "kmap_build_batch ws too small");
+  KmapBatch b;
+  memset(&b, 0, sizeof(b));
+  b.n_jobs = n_jobs;
+  char* w = (char*)ws;
+  long long probe = 0, full = 0, fill = 0;
+  bool any_rules = false, any_sym_rules = false;
+  for (int j = 0; j < n_jobs; ++j) {
+    LIDAL_REQUIRE(k[j] > 0 && k[j] < 64 && n_out[j] > 0, "kmap_build_batch: bad map %d (k=%d, rows=%lld)", j, k[j],
+                  (long long)n_out[j]);
+    const TableView t = table_view(tables[j], table_bytes[j]);
+    b.tkeys[j] = t.keys; b.tvals[j] = t.vals; b.tmask[j] = t.mask;
+    b.coords[j] = (const int4*)out_coords[j]; b.offsets[j] = offsets[j];
+    b.nbr[j] = nbr_out[j]; b.nbmaps[j] = (int2*)nbmaps[j]; b.nbsizes[j] = nbsizes[j]; b.koff[j] = (long long*)koff[j];
+    b.n_out[j] = n_out[j]; b.k[j] = k[j];
+    b.sym[j] = (symmetric[j] && (k[j] & 1) && k[j] >= 3) ? 1 : 0;
+    b.rules[j] = nbmaps[j] != nullptr ? 1 : 0;
+    any_rules |= b.rules[j] != 0;
+    any_sym_rules |= b.rules[j] && b.sym[j];
+    const int64_t nblocks = cdiv(n_out[j], kTile);
+    b.nblocks[j] = nblocks;
+    b.counts[j] = (int*)w;
+    b.offs[j] = (long long*)(w + align_up(4 * nblocks * k[j], 256));
+    w += lidal_kmap_workspace_bytes(n_out[j], k[j]);
+    b.probe0[j] = probe; b.full0[j] = full; b.fill0[j] = fill;
+    probe += nblocks * (b.sym[j] ? k[j] / 2 : k[j]);
+    full += nblocks * k[j];
+    fill += b.sym[j] ? n_out[j] * (k[j] / 2) : 0;
+  }
+  for (int j = n_jobs; j <= MAX_KMAP_JOBS; ++j) { b.probe0[j] = probe; b.full0[j] = full; b.fill0[j] = fill; }
+  if (fill > 0) {
+    kmap_fill_batch_kernel<<<(unsigned)cdiv(fill, 256), 256, 0, s>>>(b);
+    LIDAL_CHECK_LAUNCH("kmap_fill_batch");
+  }
+  kmap_probe_batch_kernel<<<(unsigned)probe, kBlock, 0, s>>>(b);
+  LIDAL_CHECK_LAUNCH("kmap_probe_batch");
+  if (!any_rules) return 0;
+  if (any_sym_rules) {
+    kmap_count_batch_kernel<<<(unsigned)full, kBlock, 0, s>>>(b);
+    LIDAL_CHECK_LAUNCH("kmap_count_batch");
+  }
+  kmap_scan_batch_kernel<<<(unsigned)n_jobs, 1024, 0, s>>>(b);
+  LIDAL_CHECK_LAUNCH("kmap_scan_batch");
+  kmap_compact_batch_kernel<<<(unsigned)full, kBlock, 0, s>>>(b);
+  LIDAL_CHECK_LAUNCH("kmap_compact_batch");
+  kmap_sizes_batch_kernel<<<(unsigned)n_jobs, 64, 0, s>>>(b);
+  LIDAL_CHECK_LAUNCH("kmap_sizes_batch");
   return 0;
 }
 

@@ -201,6 +201,56 @@ def build_kernel_map(coords, in_stride, kernel_size, stride, scope=None):
     return kmap, out_coords
 
 
+def build_kernel_maps(jobs, scope):
+    """Several kernel maps in one chain of launches (lidal_kmap_build_batch).  jobs: list of
+    (in_coords, in_stride, kernel_size, stride, out_coords) with out_coords given (the level's own coordinates,
+    or those of the coarser level: F.downsample_pyramid).  -> list of KernelMap, each what build_kernel_map
+    returns for the same arguments."""
+    import ctypes
+    if not jobs:
+        return []
+    dev = jobs[0][0].device
+    want_rules = torch.is_grad_enabled()
+    rows = []
+    for coords, in_stride, kernel_size, stride, out_coords in jobs:
+        assert coords.dtype == torch.int and out_coords.dtype == torch.int
+        coords, out_coords = coords.contiguous(), out_coords.contiguous()
+        offsets = get_kernel_offsets(kernel_size, stride=in_stride, device=dev)
+        volume = offsets.shape[0]
+        table = coords_table(coords, scope)
+        n_in, n_out = coords.shape[0], out_coords.shape[0]
+        nbr_out = torch.empty((volume, n_out), dtype=torch.int, device=dev)
+        symmetric = (volume % 2 == 1) and all(s_ == 1 for s_ in stride)
+        rules = None
+        if want_rules:
+            rules = (torch.empty((volume * n_out, 2), dtype=torch.int, device=dev),
+                     torch.empty(volume, dtype=torch.int, device=dev),
+                     torch.empty(volume + 1, dtype=torch.int64, device=dev))
+        rows.append((table, out_coords, offsets, volume, symmetric, nbr_out, rules, n_in, n_out))
+    out = []
+    for c0 in range(0, len(rows), 12):
+        chunk = rows[c0:c0 + 12]
+        n = len(chunk)
+        vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+        n_out_a, k_a = i64(*[r[8] for r in chunk]), i32(*[r[3] for r in chunk])
+        L = B.lib()
+        ws_bytes = L.lidal_kmap_build_batch_workspace_bytes(n_out_a, k_a, n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        B.check(L.lidal_kmap_build_batch(
+            vp(*[r[0].buf.data_ptr() for r in chunk]), i64(*[r[0].nbytes for r in chunk]),
+            vp(*[r[1].data_ptr() for r in chunk]), n_out_a, vp(*[r[2].data_ptr() for r in chunk]), k_a,
+            i32(*[int(r[4]) for r in chunk]), vp(*[r[5].data_ptr() for r in chunk]),
+            vp(*[(r[6][0].data_ptr() if r[6] else None) for r in chunk]),
+            vp(*[(r[6][1].data_ptr() if r[6] else None) for r in chunk]),
+            vp(*[(r[6][2].data_ptr() if r[6] else None) for r in chunk]), n, B.ptr(ws), ws_bytes, B.stream()),
+            'kmap_build')
+        for table, out_coords, offsets, volume, symmetric, nbr_out, rules, n_in, n_out in chunk:
+            kmap = KernelMap(nbr_out, (n_in, n_out), volume, symmetric)
+            kmap._rules = rules
+            out.append(kmap)
+    return out
+
+
 def prefetch_kernel_maps(x, plan, transposed=True):
     """Build, ahead of the feature kernels, every coordinate set and kernel map a network will ask
     for: `plan` is the sequence of (kernel_size, stride) of its non-transposed convs along the
@@ -222,6 +272,29 @@ def prefetch_kernel_maps(x, plan, transposed=True):
             from .downsample import downsample_pyramid
             for st, c in zip(strides, downsample_pyramid(coords, len(downs), cur)):
                 x.cmaps[st] = c
+    # ... and with every level's coordinates known, all kernel maps in one chain of launches
+    todo, keys_todo = [], []
+    c_, cur_ = coords, cur
+    for kernel_size, stride in plan:
+        kernel_size = make_ntuple(kernel_size, ndim=3)
+        stride = make_ntuple(stride, ndim=3)
+        if kernel_size == (1, 1, 1) and stride == (1, 1, 1):
+            continue
+        key = (cur_, kernel_size, stride, (1, 1, 1))
+        out_stride = tuple(cur_[k] * stride[k] for k in range(3))
+        strided = any(s_ > 1 for s_ in stride)
+        out_c = x.cmaps.get(out_stride) if strided else c_
+        if out_c is None or c_.shape[0] == 0 or out_c.shape[0] == 0 or not c_.is_cuda:
+            todo = []
+            break                                   # a level without coordinates yet: the one-by-one path below
+        if key not in x.kmaps and key not in keys_todo:
+            todo.append((c_, cur_, kernel_size, stride, out_c))
+            keys_todo.append(key)
+        if strided:
+            c_, cur_ = out_c, out_stride
+    if len(todo) > 1:
+        for key, kmap in zip(keys_todo, build_kernel_maps(todo, x.cmaps)):
+            x.kmaps[key] = kmap
     want = []                   # (kmap, 'out' | 'in') whose row order is still to be built
     for kernel_size, stride in plan:
         kernel_size = make_ntuple(kernel_size, ndim=3)

@@ -618,8 +618,8 @@ def bench_scoring(args, model, world, rank, dev, frames, batches):
     out = {'metric': 'frames/sec prob_inference(8 views)+LiDAL scoring', 'unit': 'frames/s',
            'frames': total, 'frames_per_rank': per, 'points_per_frame': args.points,
            'voxels_per_frame': int(np.mean([d['coords'].shape[0] for d in dev_frames])),
-           'exchange': ('all_gather_into_tensor(prob f32 [P,19]) + (world f64 [P,3]) + sv results to rank 0'
-                        if world > 1 else 'none (1 rank)'), 'by_nei': {}}
+           'exchange': ('halo exchange (batch_isend_irecv of the prob f32 [P,19] / world f64 [P,3] frames other ranks read) '
+                        '+ sv results to rank 0' if world > 1 else 'none (1 rank)'), 'by_nei': {}}
 
     def run(nei):
         scores = score_sequence(model, dev_frames, rank * per, total, nei_num=nei, dis_thresh=0.1,

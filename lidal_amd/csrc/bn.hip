@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_masked_kernel(
     const float* __restrict__ mean_s, const float* __restrict__ invstd_s, T* __restrict__ gm,
     double* __restrict__ part, double* __restrict__ part_s, int rpw) {
   constexpr int VEC = IO<T>::VEC;
+  constexpr int MU = 2;          // rows in flight per thread and operand (four operands: two keep the registers of UNR = 4 x two)
   extern __shared__ double sh[];                // [2][NT][VEC]
   const int cg_n = c / VEC, rpi = NT / cg_n;
   const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
@@ -363,10 +364,10 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_masked_kernel(
       }
     };
     int64_t r = r_beg + rl;
-    for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
-      typename IO<T>::vec vx[UNR], vy[UNR], vg[UNR], vs[UNR];
+    for (; r + (MU - 1) * rpi < r_end; r += MU * rpi) {
+      typename IO<T>::vec vx[MU], vy[MU], vg[MU], vs[MU];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
+      for (int u = 0; u < MU; ++u) {
         vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
         vy[u] = *reinterpret_cast<const typename IO<T>::vec*>(y + (r + u * rpi) * c + cg * VEC);
         vg[u] = *reinterpret_cast<const typename IO<T>::vec*>(g + (r + u * rpi) * ldg + cg * VEC);
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_masked_kernel(
         else vs[u] = vx[u];
       }
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) one(vx[u], vy[u], vg[u], vs[u], r + u * rpi);
+      for (int u = 0; u < MU; ++u) one(vx[u], vy[u], vg[u], vs[u], r + u * rpi);
     }
     for (; r < r_end; r += rpi) {
       const typename IO<T>::vec vx = *reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC);

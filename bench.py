@@ -275,7 +275,7 @@ FAMILY_OF = {
     'lidal_conv_wgrad': 'conv_wgrad',
     'lidal_conv_weight_pack': 'weight_pack', 'lidal_conv_weight_image': 'weight_pack',
     'lidal_conv_weight_image_pair': 'weight_pack',
-    'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_bwd_tiles': 'batch_norm', 'lidal_bn_bwd_block_tail': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
+    'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_bwd_tiles': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
@@ -376,9 +376,6 @@ def family_table(step, coords, dtype_name, step_ms):
         elif name in ('lidal_bn_bwd', 'lidal_bn_bwd_tiles'):
             # (x, dy, dy_stride, dtype, n, c, ...): the sums pass `_tiles` no longer makes stays in the count (5 N C b)
             by = 5 * a[4] * a[5] * (2 if a[3] == 1 else 4)
-        elif name == 'lidal_bn_bwd_block_tail':
-            # (x, out, g, g_stride, dtype, n, c, ..., xs at 14): relu(a + b) backward 3 N C b + BatchNorm backward 5 N C b (x2 with a shortcut BatchNorm)
-            by = (3 + 5 * (2 if a[14] else 1)) * a[5] * a[6] * (2 if a[4] == 1 else 4)
         elif name == 'lidal_colsum':
             by = a[2] * a[3] * (2 if a[1] == 1 else 4)
         elif name in ('lidal_add_relu_fwd', 'lidal_add_relu_bwd'):

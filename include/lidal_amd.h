@@ -354,17 +354,6 @@ int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stride, int dty
                        const float* gamma, const float* beta, int relu, const float* save_mean,
                        const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
                        const float* tile_sums, int64_t n_tiles, void* stream);
-/* Backward of the tail of a residual block, out = relu(bn(x) + shortcut) (network/utils.py:171), shortcut =
- * identity (xs == NULL) or bn_s(xs): gm = g where out > 0 (written: it is the gradient of both summands), the
- * backward of bn on gm (dx, grad_gamma, grad_beta) and, if xs != NULL, of bn_s (dxs, ...), with the sums of both
- * accumulated in the pass that masks g.  Bitwise lidal_add_relu_bwd + lidal_bn_bwd (+ lidal_bn_bwd).
- * ws >= 2 * lidal_bn_workspace_bytes(n, c). */
-int lidal_bn_bwd_block_tail(const void* x, const void* out, const void* g, int64_t g_stride, int dtype,
-                            int64_t n, int c, const float* gamma, const float* save_mean,
-                            const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta, void* gm,
-                            const void* xs, const float* gamma_s, const float* mean_s, const float* invstd_s,
-                            void* dxs, float* grad_gamma_s, float* grad_beta_s, void* ws, int64_t ws_bytes,
-                            void* stream);
 /* eval-mode BatchNorm as a per-channel affine map (scale = gamma / sqrt(var + eps),
  * shift = beta - mean * scale), the operands of lidal_conv_apply's epilogue. */
 int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,

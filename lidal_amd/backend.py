@@ -97,8 +97,6 @@ SIGNATURES = {
                             _i64, _vp]),
     'lidal_bn_bwd_tiles': (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _i64, _vp]),
-    'lidal_bn_bwd_block_tail': (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                       _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'lidal_bn_fold': (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
     'lidal_colsum': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp]),
     'lidal_add_relu_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),

@@ -314,104 +314,6 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
   }
 }
 
-// The tail of a residual block, relu(bn2(x2) + shortcut) (network/utils.py:171), backwards in one pass: the
-// incoming gradient is masked where the block output y is not positive (what lidal_add_relu_bwd did in a
-// pass of its own), written out (it is the gradient of BOTH summands), and the backward sums of bn2 -- and,
-// if the shortcut is a Conv3d -> BatchNorm (xs != NULL), of that BatchNorm too -- are accumulated from it in
-// the same pass: the same rows per workgroup, the same f64 accumulation order as bn_bwd_partial_kernel (no
-// ReLU inside these two BatchNorms), hence bitwise its sums.
-template <typename T, bool TWO>
-__global__ void __launch_bounds__(NT) bn_bwd_partial_masked_kernel(
-    const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ g, int64_t ldg, const T* __restrict__ xs,
-    int64_t n, int c, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ mean_s, const float* __restrict__ invstd_s, T* __restrict__ gm,
-    double* __restrict__ part, double* __restrict__ part_s, int rpw) {
-  constexpr int VEC = IO<T>::VEC;
-  constexpr int MU = 2;          // rows in flight per thread and operand (four operands: two keep the registers of UNR = 4 x two)
-  extern __shared__ double sh[];                // [2][NT][VEC]
-  const int cg_n = c / VEC, rpi = NT / cg_n;
-  const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
-  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
-  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
-  double a[VEC], b[VEC], as[VEC], bs[VEC];
-  float mu[VEC], is[VEC], mus[VEC], iss[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) { a[i] = b[i] = as[i] = bs[i] = 0.; mu[i] = is[i] = mus[i] = iss[i] = 0.f; }
-  if (rl < rpi) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      mu[i] = mean[cg * VEC + i]; is[i] = invstd[cg * VEC + i];
-      if (TWO) { mus[i] = mean_s[cg * VEC + i]; iss[i] = invstd_s[cg * VEC + i]; }
-    }
-    auto one = [&](const typename IO<T>::vec& vx, const typename IO<T>::vec& vy, const typename IO<T>::vec& vg,
-                   const typename IO<T>::vec& vs, int64_t r) {
-      float fx[VEC], fy[VEC], fg[VEC], fs[VEC];
-      IO<T>::unpack(vx, fx);
-      IO<T>::unpack(vy, fy);
-      IO<T>::unpack(vg, fg);
-      if (TWO) IO<T>::unpack(vs, fs);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) fg[i] = fy[i] > 0.f ? fg[i] : 0.f;
-      *reinterpret_cast<typename IO<T>::vec*>(gm + r * c + cg * VEC) = IO<T>::pack(fg);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float xhat = (fx[i] - mu[i]) * is[i];
-        a[i] += (double)fg[i]; b[i] += (double)fg[i] * (double)xhat;
-        if (TWO) {
-          const float xh2 = (fs[i] - mus[i]) * iss[i];
-          as[i] += (double)fg[i]; bs[i] += (double)fg[i] * (double)xh2;
-        }
-      }
-    };
-    int64_t r = r_beg + rl;
-    for (; r + (MU - 1) * rpi < r_end; r += MU * rpi) {
-      typename IO<T>::vec vx[MU], vy[MU], vg[MU], vs[MU];
-#pragma unroll
-      for (int u = 0; u < MU; ++u) {
-        vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
-        vy[u] = *reinterpret_cast<const typename IO<T>::vec*>(y + (r + u * rpi) * c + cg * VEC);
-        vg[u] = *reinterpret_cast<const typename IO<T>::vec*>(g + (r + u * rpi) * ldg + cg * VEC);
-        if (TWO) vs[u] = *reinterpret_cast<const typename IO<T>::vec*>(xs + (r + u * rpi) * c + cg * VEC);
-        else vs[u] = vx[u];
-      }
-#pragma unroll
-      for (int u = 0; u < MU; ++u) one(vx[u], vy[u], vg[u], vs[u], r + u * rpi);
-    }
-    for (; r < r_end; r += rpi) {
-      const typename IO<T>::vec vx = *reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC);
-      one(vx, *reinterpret_cast<const typename IO<T>::vec*>(y + r * c + cg * VEC),
-          *reinterpret_cast<const typename IO<T>::vec*>(g + r * ldg + cg * VEC),
-          TWO ? *reinterpret_cast<const typename IO<T>::vec*>(xs + r * c + cg * VEC) : vx, r);
-    }
-  }
-  double* sa = sh; double* sb = sh + NT * VEC;
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) { sa[tid * VEC + i] = a[i]; sb[tid * VEC + i] = b[i]; }
-  tree_sum_rows<VEC, double>(sa, tid, cg_n, rpi, rl);
-  tree_sum_rows<VEC, double>(sb, tid, cg_n, rpi, rl);
-  if (rl == 0) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      double* dst = part + ((int64_t)blockIdx.x * c + cg * VEC + i) * 2;
-      dst[0] = sa[tid * VEC + i]; dst[1] = sb[tid * VEC + i];
-    }
-  }
-  if (TWO) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { sa[tid * VEC + i] = as[i]; sb[tid * VEC + i] = bs[i]; }
-    tree_sum_rows<VEC, double>(sa, tid, cg_n, rpi, rl);
-    tree_sum_rows<VEC, double>(sb, tid, cg_n, rpi, rl);
-    if (rl == 0) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        double* dst = part_s + ((int64_t)blockIdx.x * c + cg * VEC + i) * 2;
-        dst[0] = sa[tid * VEC + i]; dst[1] = sb[tid * VEC + i];
-      }
-    }
-  }
-}
-
 __global__ void __launch_bounds__(NT) bn_bwd_final_kernel(const double* __restrict__ part,
                                                           int nparts, int c,
                                                           float* __restrict__ sum_dy,
@@ -748,67 +650,6 @@ extern "C" int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stri
     LIDAL_CHECK_LAUNCH("bn_bwd_dx");
   }
   return 0;
-}
-
-template <typename T>
-static int bn_bwd_masked(const void* x, const void* y, const void* g, int64_t ldg, int64_t n, int c,
-                         const float* gamma, const float* mean, const float* invstd, void* dx, float* gg, float* gb,
-                         void* gm, const void* xs, const float* gamma_s, const float* mean_s, const float* invstd_s,
-                         void* dxs, float* ggs, float* gbs, double* part, hipStream_t s) {
-  constexpr int VEC = IO<T>::VEC;
-  const int np = nparts_for(n);
-  double* part_s = part + (int64_t)np * c * 2;
-  const size_t lds = 2 * NT * VEC * sizeof(double);
-  if (xs != nullptr)
-    bn_bwd_partial_masked_kernel<T, true><<<np, NT, lds, s>>>((const T*)x, (const T*)y, (const T*)g, ldg, (const T*)xs, n,
-                                                            c, mean, invstd, mean_s, invstd_s, (T*)gm, part, part_s,
-                                                            rows_per_wg(n));
-  else
-    bn_bwd_partial_masked_kernel<T, false><<<np, NT, lds, s>>>((const T*)x, (const T*)y, (const T*)g, ldg, nullptr, n, c,
-                                                             mean, invstd, nullptr, nullptr, (T*)gm, part, part_s,
-                                                             rows_per_wg(n));
-  LIDAL_CHECK_LAUNCH("bn_bwd_partial_masked");
-  bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gb, gg);
-  LIDAL_CHECK_LAUNCH("bn_bwd_final");
-  if (dx != nullptr) {
-    bn_bwd_dx_kernel<T><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, (const T*)gm, n, c, mean, invstd, gamma, nullptr, 0, gb,
-                                                    gg, (T*)dx, rows_per_wg_ew(n), (int64_t)c);
-    LIDAL_CHECK_LAUNCH("bn_bwd_dx");
-  }
-  if (xs != nullptr) {
-    bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part_s, np, c, gbs, ggs);
-    LIDAL_CHECK_LAUNCH("bn_bwd_final");
-    if (dxs != nullptr) {
-      bn_bwd_dx_kernel<T><<<nslabs_ew(n), NT, 0, s>>>((const T*)xs, (const T*)gm, n, c, mean_s, invstd_s, gamma_s, nullptr,
-                                                      0, gbs, ggs, (T*)dxs, rows_per_wg_ew(n), (int64_t)c);
-      LIDAL_CHECK_LAUNCH("bn_bwd_dx");
-    }
-  }
-  return 0;
-}
-
-// Backward of the tail of a residual block, out = relu(bn(x) + shortcut) with shortcut = identity (xs == NULL) or
-// bn_s(xs): gm = g where out > 0 (written: the gradient of both summands), then the backward of bn (no ReLU inside)
-// on gm -> dx, grad_gamma, grad_beta, and of bn_s -> dxs, ggs, gbs.  Bitwise lidal_add_relu_bwd followed by
-// lidal_bn_bwd (x2), in 4 (6) launches instead of 4 (7) and without the passes that re-read gm for the sums.
-// ws >= 2 * lidal_bn_workspace_bytes(n, c).
-extern "C" int lidal_bn_bwd_block_tail(const void* x, const void* out, const void* g, int64_t g_stride, int dtype,
-                                       int64_t n, int c, const float* gamma, const float* save_mean,
-                                       const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
-                                       void* gm, const void* xs, const float* gamma_s, const float* mean_s,
-                                       const float* invstd_s, void* dxs, float* grad_gamma_s, float* grad_beta_s,
-                                       void* ws, int64_t ws_bytes, void* stream) {
-  if (int rc = bn_check(n, c, dtype)) return rc;
-  LIDAL_REQUIRE(n > 0 && gm != nullptr, "bn_bwd_block_tail: needs rows and the masked-gradient buffer");
-  LIDAL_REQUIRE(ws_bytes >= 2 * lidal_bn_workspace_bytes(n, c), "bn_bwd_block_tail workspace too small");
-  const int vec = dtype == LIDAL_F32 ? 4 : 8;
-  LIDAL_REQUIRE(g_stride >= c && g_stride % vec == 0, "bn_bwd_block_tail: gradient row stride %lld", (long long)g_stride);
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == LIDAL_F32)
-    return bn_bwd_masked<float>(x, out, g, g_stride, n, c, gamma, save_mean, save_invstd, dx, grad_gamma, grad_beta, gm,
-                                xs, gamma_s, mean_s, invstd_s, dxs, grad_gamma_s, grad_beta_s, (double*)ws, s);
-  return bn_bwd_masked<__bf16>(x, out, g, g_stride, n, c, gamma, save_mean, save_invstd, dx, grad_gamma, grad_beta, gm,
-                               xs, gamma_s, mean_s, invstd_s, dxs, grad_gamma_s, grad_beta_s, (double*)ws, s);
 }
 
 extern "C" int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,

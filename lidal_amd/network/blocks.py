@@ -34,7 +34,6 @@ from ..nn.functional import norm as _N
 
 FUSE_BLOCKS = _os.environ.get('LIDAL_FUSE_BLOCKS', '1') != '0'
 BN_SUMS = _os.environ.get('LIDAL_BN_SUMS', '1') != '0'       # BatchNorm backward sums from the data-gradient launches
-BLOCK_TAIL = _os.environ.get('LIDAL_BLOCK_TAIL', '1') != '0' # the tail of a residual block backwards in one pass
 
 
 def _bn_args(bn):
@@ -106,25 +105,15 @@ class _Residual(torch.autograd.Function):
         t = ctx.saved_tensors
         xc, k1, x1, w1, c1, mean1, inv1, y1, k2, x2, w2, c2, mean2, inv2, out = t[:15]
         need_gx = ctx.needs_input_grad[0]
-        # relu(bn2 + shortcut): the gradient where the output is positive, for both summands -- masked, written
-        # and summed for bn2 (and the shortcut's BatchNorm) in ONE pass (norm.block_tail_backward)
+        # relu(bn2 + shortcut): the gradient where the output is positive, for both summands
+        dx2, gg2, gb2, gm = _N.train_backward(x2, w2, c2, mean2, inv2, False, g, True, out)
         gks = ggs = gbs = None
-        if not BLOCK_TAIL:
-            dx2, gg2, gb2, gm = _N.train_backward(x2, w2, c2, mean2, inv2, False, g, True, out)
-            if ctx.shortcut:
-                xs_in, ks, xs, ws, cs, means, invs = t[15:]
-                dxs, ggs, gbs, _ = _N.train_backward(xs, ws, cs, means, invs, False, gm, True)
-                g_skip, gks, _ = _D.rows_backward(xs_in, ks, ctx.wcs, ctx.imgs, ctx.pads, False, dxs, need_gx,
-                                                  ctx.needs_input_grad[7], False)
-            else:
-                g_skip = gm
-        elif ctx.shortcut:
+        if ctx.shortcut:
             xs_in, ks, xs, ws, cs, means, invs = t[15:]
-            dx2, gg2, gb2, gm, dxs, ggs, gbs = _N.block_tail_backward(x2, w2, mean2, inv2, out, g, (xs, ws, means, invs))
+            dxs, ggs, gbs, _ = _N.train_backward(xs, ws, cs, means, invs, False, gm, True)
             g_skip, gks, _ = _D.rows_backward(xs_in, ks, ctx.wcs, ctx.imgs, ctx.pads, False, dxs, need_gx,
                                               ctx.needs_input_grad[7], False)
         else:
-            dx2, gg2, gb2, gm, _, _, _ = _N.block_tail_backward(x2, w2, mean2, inv2, out, g)
             g_skip = gm
         # conv2's data gradient IS the output gradient of bn1 (y1 has no other consumer): the launch that writes it
         # also leaves bn1's backward sums per tile (BN_SUMS; bf16), and bn1's backward skips its pass for them

@@ -6,7 +6,7 @@ from torch.autograd import Function
 
 from ... import backend as B
 
-__all__ = ['batch_norm_rows', 'column_sum', 'supported', 'train_forward', 'train_backward', 'block_tail_backward']
+__all__ = ['batch_norm_rows', 'column_sum', 'supported', 'train_forward', 'train_backward']
 
 
 def supported(x, weight, bias):
@@ -110,41 +110,6 @@ def train_backward(x, w, b, mean, invstd, relu, grad_out, need_dx=True, mask_fro
                                  B.ptr(gg), B.ptr(gb),
                                  B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
     return dx, gg, gb, grad_out
-
-
-def block_tail_backward(x, w, mean, invstd, out, grad_out, shortcut=None):
-    """Backward of out = relu(bn(x) + shortcut) on raw tensors (the tail of a residual block,
-    network/utils.py:171): -> (dx, grad_gamma, grad_beta, gm, dxs, grad_gamma_s, grad_beta_s) with gm = grad_out
-    where out > 0 (the gradient of both summands) and, for shortcut = (xs, ws, mean_s, invstd_s) (a Conv3d ->
-    BatchNorm shortcut), the backward of that BatchNorm too.  One pass masks the gradient AND accumulates the
-    sums of both BatchNorms (lidal_bn_bwd_block_tail): bitwise train_backward(mask_from=out) followed by
-    train_backward on the shortcut."""
-    n, c = x.shape
-    vec = 8 if x.dtype == torch.bfloat16 else 4
-    if (grad_out.dim() == 2 and grad_out.dtype == x.dtype and grad_out.stride(1) == 1
-            and grad_out.stride(0) >= c and grad_out.stride(0) % vec == 0 and grad_out.storage_offset() % vec == 0):
-        g = grad_out
-    else:
-        g = grad_out.contiguous().to(x.dtype)
-    dev = x.device
-    gm = torch.empty_like(out)
-    dx = torch.empty_like(x)
-    sums = torch.empty((4, c), dtype=torch.float32, device=dev)         # gg, gb, ggs, gbs
-    xs = ws_ = mean_s = invstd_s = dxs = None
-    if shortcut is not None:
-        xs, ws_, mean_s, invstd_s = shortcut
-        dxs = torch.empty_like(xs)
-    nbytes = 2 * B.lib().lidal_bn_workspace_bytes(n, c)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    B.check(B.lib().lidal_bn_bwd_block_tail(B.ptr(x), B.ptr(out), B.ptr(g), g.stride(0), B.dtype_code(x.dtype), n, c,
-                                            B.ptr(w), B.ptr(mean), B.ptr(invstd), B.ptr(dx), B.ptr(sums[0]),
-                                            B.ptr(sums[1]), B.ptr(gm), B.ptr(xs), B.ptr(ws_), B.ptr(mean_s),
-                                            B.ptr(invstd_s), B.ptr(dxs), B.ptr(sums[2]), B.ptr(sums[3]), B.ptr(ws),
-                                            nbytes, B.stream()), 'bn_bwd')
-    if shortcut is None:
-        return dx, sums[0], sums[1], gm, None, None, None
-    B.hit('bn_bwd')             # (two BatchNorm backward passes in this call)
-    return dx, sums[0], sums[1], gm, dxs, sums[2], sums[3]
 
 
 class BatchNormRows(Function):

@@ -1104,27 +1104,3 @@ def test_one_point_per_voxel_voxelize_is_the_mean_form(dtype, c):
         outs.append((y.detach(), xi.grad))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[1][0][idx], x)
-
-
-@pytest.mark.parametrize('dtype,c,two', [(torch.bfloat16, 96, False), (torch.bfloat16, 96, True), (torch.float32, 32, True),
-                                         (torch.bfloat16, 256, True)])
-def test_block_tail_backward_is_bitwise_the_three_separate_passes(dtype, c, two):
-    """lidal_bn_bwd_block_tail (relu(bn(x) + shortcut) backwards: mask, write, sum for one or two BatchNorms in one
-    pass) == lidal_add_relu_bwd, then lidal_bn_bwd on bn, then on the shortcut's BatchNorm -- bit for bit."""
-    from lidal_amd.nn.functional import norm as N
-    g = torch.Generator().manual_seed(c)
-    n = 70001
-    x = (torch.randn(n, c, generator=g) * 1.3 + 0.2).to(DEV).to(dtype)
-    xs = (torch.randn(n, c, generator=g) * 0.7 - 0.1).to(DEV).to(dtype)
-    out = torch.randn(n, c, generator=g).to(DEV).to(dtype)                  # the block output: sign = the mask
-    grad = torch.randn(n, c, generator=g).to(DEV).to(dtype)
-    w, ws = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.rand(c, generator=g) + 0.5).to(DEV)
-    b = torch.zeros(c, device=DEV)
-    mean, mean_s = x.float().mean(0), xs.float().mean(0)
-    inv, inv_s = torch.rsqrt(x.float().var(0, unbiased=False) + 1e-5), torch.rsqrt(xs.float().var(0, unbiased=False) + 1e-5)
-    dx0, gg0, gb0, gm0 = N.train_backward(x, w, b, mean, inv, False, grad, True, out)
-    got = N.block_tail_backward(x, w, mean, inv, out, grad, (xs, ws, mean_s, inv_s) if two else None)
-    assert torch.equal(got[3], gm0) and torch.equal(got[0], dx0) and torch.equal(got[1], gg0) and torch.equal(got[2], gb0)
-    if two:
-        dxs0, ggs0, gbs0, _ = N.train_backward(xs, ws, b, mean_s, inv_s, False, gm0, True)
-        assert torch.equal(got[4], dxs0) and torch.equal(got[5], ggs0) and torch.equal(got[6], gbs0)

@@ -404,7 +404,13 @@ static inline int slab_rows(int64_t n) {
   return (int)rpw;
 }
 static inline int rows_per_wg(int64_t n) { return slab_rows(n); }
-static inline int rows_per_wg_ew(int64_t n) { return slab_rows(n); }
+static int g_ew_wgs = 256;      // EXPERIMENT (temporary): workgroups of the element-wise kernels (apply, dx)
+static inline int rows_per_wg_ew(int64_t n) {
+  int64_t rpw = (n + g_ew_wgs - 1) / g_ew_wgs;
+  if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
+  return (int)rpw;
+}
+extern "C" int lidal_debug_set_bn_ew_wgs(int v) { g_ew_wgs = v; return 0; }
 static inline int nslabs_ew(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg_ew(n)); }
 static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg(n)); }
 template <typename T>

@@ -21,6 +21,19 @@ def main():
     dev = torch.device('cuda')
     print('lib', B.LIB_PATH)
     L = B.lib()
+    import ctypes
+    for wgs in [int(v) for v in os.environ.get('EW_WGS', '256').split(',')]:
+        try:
+            f = B.lib_handle().lidal_debug_set_bn_ew_wgs
+            f.argtypes = [ctypes.c_int]
+            f(wgs)
+        except AttributeError:
+            pass
+        print('element-wise workgroups:', wgs)
+        sweep(dev, L)
+
+
+def sweep(dev, L):
     tot = [0.0, 0.0, 0.0]
     for n, c in SHAPES:
         x = torch.randn(n, c, device=dev).bfloat16()

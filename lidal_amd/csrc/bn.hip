@@ -403,7 +403,13 @@ static inline int slab_rows(int64_t n) {
   if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
   return (int)rpw;
 }
-static inline int rows_per_wg(int64_t n) { return slab_rows(n); }
+static int g_red_wgs = 256;     // EXPERIMENT (temporary): workgroups of the reducing kernels
+static inline int rows_per_wg(int64_t n) {
+  int64_t rpw = (n + g_red_wgs - 1) / g_red_wgs;
+  if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
+  return (int)rpw;
+}
+extern "C" int lidal_debug_set_bn_red_wgs(int v) { g_red_wgs = v; return 0; }
 static int g_ew_wgs = 256;      // EXPERIMENT (temporary): workgroups of the element-wise kernels (apply, dx)
 static inline int rows_per_wg_ew(int64_t n) {
   int64_t rpw = (n + g_ew_wgs - 1) / g_ew_wgs;
@@ -478,7 +484,7 @@ static int bn_check(int64_t n, int c, int dtype) {
 }
 
 extern "C" int64_t lidal_bn_workspace_bytes(int64_t n, int c) {
-  return (int64_t)nparts_for(n) * c * 3 * sizeof(double) + 256;
+  return (int64_t)(nparts_for(n) > 2048 ? nparts_for(n) : 2048) * c * 3 * sizeof(double) + 256;
 }
 
 extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,

@@ -29,8 +29,15 @@ def main():
             f(wgs)
         except AttributeError:
             pass
-        print('element-wise workgroups:', wgs)
-        sweep(dev, L)
+        for red in [int(v) for v in os.environ.get('RED_WGS', '256').split(',')]:
+            try:
+                f = B.lib_handle().lidal_debug_set_bn_red_wgs
+                f.argtypes = [ctypes.c_int]
+                f(red)
+            except AttributeError:
+                pass
+            print('element-wise workgroups:', wgs, ' reducing workgroups:', red)
+            sweep(dev, L)
 
 
 def sweep(dev, L):

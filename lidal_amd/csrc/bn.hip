@@ -403,21 +403,21 @@ static inline int slab_rows(int64_t n) {
   if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
   return (int)rpw;
 }
-static int g_red_wgs = 256;     // EXPERIMENT (temporary): workgroups of the reducing kernels
-static inline int rows_per_wg(int64_t n) {
-  int64_t rpw = (n + g_red_wgs - 1) / g_red_wgs;
+static inline int rows_per_wg(int64_t n) { return slab_rows(n); }
+// The element-wise kernels (apply, dx) have no tree and a light set-up, and at one workgroup per CU the
+// large levels are short of bytes in flight: 512 workgroups took dx at 396662 x 96 bf16 from 61.7 to
+// 44.3 us (3.7 -> 5.2 TB/s), while the small levels lost (43000 x 128: 14.4 -> 18.3 us) and 1024 lost
+// everywhere.  The reducing kernels are best at 256 on every level (sweep: profiles/README.md).
+constexpr int64_t EW_WIDE_BYTES = 12ll << 20;
+static inline int rows_per_wg_ew(int64_t n, int64_t row_bytes) {
+  const int wgs = n * row_bytes >= EW_WIDE_BYTES ? 2 * BN_WGS : BN_WGS;
+  int64_t rpw = (n + wgs - 1) / wgs;
   if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
   return (int)rpw;
 }
-extern "C" int lidal_debug_set_bn_red_wgs(int v) { g_red_wgs = v; return 0; }
-static int g_ew_wgs = 256;      // EXPERIMENT (temporary): workgroups of the element-wise kernels (apply, dx)
-static inline int rows_per_wg_ew(int64_t n) {
-  int64_t rpw = (n + g_ew_wgs - 1) / g_ew_wgs;
-  if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
-  return (int)rpw;
+static inline int nslabs_ew(int64_t n, int64_t row_bytes) {
+  return (int)cdiv(n > 0 ? n : 1, rows_per_wg_ew(n, row_bytes));
 }
-extern "C" int lidal_debug_set_bn_ew_wgs(int v) { g_ew_wgs = v; return 0; }
-static inline int nslabs_ew(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg_ew(n)); }
 static inline int nparts_for(int64_t n) { return (int)cdiv(n > 0 ? n : 1, rows_per_wg(n)); }
 template <typename T>
 int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
@@ -431,9 +431,9 @@ int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const floa
   bn_stats_final_kernel<double><<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
                                                              invstd, rm, rv, nbt);
   LIDAL_CHECK_LAUNCH("bn_stats_final");
-  bn_apply_kernel<T, false><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma,
+  bn_apply_kernel<T, false><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma,
                                                         beta, eps, relu, (const T*)res, (T*)y,
-                                                        rows_per_wg_ew(n));
+                                                        rows_per_wg_ew(n, (int64_t)c * sizeof(T)));
   LIDAL_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -450,9 +450,9 @@ int bn_bwd(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const f
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gbeta, ggamma);
   LIDAL_CHECK_LAUNCH("bn_bwd_final");
   if (dx != nullptr) {
-    bn_bwd_dx_kernel<T><<<nslabs_ew(n), NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd,
+    bn_bwd_dx_kernel<T><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd,
                                                     gamma, beta, relu, gbeta, ggamma, (T*)dx,
-                                                    rows_per_wg_ew(n), ldy);
+                                                    rows_per_wg_ew(n, (int64_t)c * sizeof(T)), ldy);
     LIDAL_CHECK_LAUNCH("bn_bwd_dx");
   }
   return 0;
@@ -484,7 +484,7 @@ static int bn_check(int64_t n, int c, int dtype) {
 }
 
 extern "C" int64_t lidal_bn_workspace_bytes(int64_t n, int c) {
-  return (int64_t)(nparts_for(n) > 2048 ? nparts_for(n) : 2048) * c * 3 * sizeof(double) + 256;
+  return (int64_t)nparts_for(n) * c * 3 * sizeof(double) + 256;
 }
 
 extern "C" int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* gamma,
@@ -563,15 +563,15 @@ extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int
                                                    (long long*)num_batches_tracked);
   LIDAL_CHECK_LAUNCH("bn_stats_final(tiles)");
   if (dtype == LIDAL_F32)
-    bn_apply_kernel<float, false><<<nslabs_ew(n), NT, 0, s>>>((const float*)x, n, c, save_mean, save_invstd,
+    bn_apply_kernel<float, false><<<nslabs_ew(n, (int64_t)c * 4), NT, 0, s>>>((const float*)x, n, c, save_mean, save_invstd,
                                                               gamma, beta, eps, relu,
                                                               (const float*)residual, (float*)y,
-                                                              rows_per_wg_ew(n));
+                                                              rows_per_wg_ew(n, (int64_t)c * 4));
   else
-    bn_apply_kernel<__bf16, false><<<nslabs_ew(n), NT, 0, s>>>((const __bf16*)x, n, c, save_mean,
+    bn_apply_kernel<__bf16, false><<<nslabs_ew(n, (int64_t)c * 2), NT, 0, s>>>((const __bf16*)x, n, c, save_mean,
                                                                save_invstd, gamma, beta, eps, relu,
                                                                (const __bf16*)residual, (__bf16*)y,
-                                                               rows_per_wg_ew(n));
+                                                               rows_per_wg_ew(n, (int64_t)c * 2));
   LIDAL_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -584,13 +584,13 @@ extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, con
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
-    bn_apply_kernel<float, true><<<nslabs_ew(n), NT, 0, s>>>(
+    bn_apply_kernel<float, true><<<nslabs_ew(n, (int64_t)c * 4), NT, 0, s>>>(
         (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, nullptr, (float*)y,
-        rows_per_wg_ew(n));
+        rows_per_wg_ew(n, (int64_t)c * 4));
   else
-    bn_apply_kernel<__bf16, true><<<nslabs_ew(n), NT, 0, s>>>(
+    bn_apply_kernel<__bf16, true><<<nslabs_ew(n, (int64_t)c * 2), NT, 0, s>>>(
         (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, nullptr, (__bf16*)y,
-        rows_per_wg_ew(n));
+        rows_per_wg_ew(n, (int64_t)c * 2));
   LIDAL_CHECK_LAUNCH("lidal_bn_eval_fwd");
   return 0;
 }
@@ -652,13 +652,13 @@ extern "C" int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stri
   LIDAL_CHECK_LAUNCH("bn_bwd_final(tiles)");
   if (dx != nullptr) {
     if (dtype == LIDAL_F32)
-      bn_bwd_dx_kernel<float><<<nslabs_ew(n), NT, 0, s>>>((const float*)x, (const float*)dy, n, c, save_mean,
+      bn_bwd_dx_kernel<float><<<nslabs_ew(n, (int64_t)c * 4), NT, 0, s>>>((const float*)x, (const float*)dy, n, c, save_mean,
                                                           save_invstd, gamma, beta, relu, grad_beta, grad_gamma,
-                                                          (float*)dx, rows_per_wg_ew(n), dy_stride);
+                                                          (float*)dx, rows_per_wg_ew(n, (int64_t)c * 4), dy_stride);
     else
-      bn_bwd_dx_kernel<__bf16><<<nslabs_ew(n), NT, 0, s>>>((const __bf16*)x, (const __bf16*)dy, n, c, save_mean,
+      bn_bwd_dx_kernel<__bf16><<<nslabs_ew(n, (int64_t)c * 2), NT, 0, s>>>((const __bf16*)x, (const __bf16*)dy, n, c, save_mean,
                                                            save_invstd, gamma, beta, relu, grad_beta, grad_gamma,
-                                                           (__bf16*)dx, rows_per_wg_ew(n), dy_stride);
+                                                           (__bf16*)dx, rows_per_wg_ew(n, (int64_t)c * 2), dy_stride);
     LIDAL_CHECK_LAUNCH("bn_bwd_dx");
   }
   return 0;

@@ -21,23 +21,7 @@ def main():
     dev = torch.device('cuda')
     print('lib', B.LIB_PATH)
     L = B.lib()
-    import ctypes
-    for wgs in [int(v) for v in os.environ.get('EW_WGS', '256').split(',')]:
-        try:
-            f = B.lib_handle().lidal_debug_set_bn_ew_wgs
-            f.argtypes = [ctypes.c_int]
-            f(wgs)
-        except AttributeError:
-            pass
-        for red in [int(v) for v in os.environ.get('RED_WGS', '256').split(',')]:
-            try:
-                f = B.lib_handle().lidal_debug_set_bn_red_wgs
-                f.argtypes = [ctypes.c_int]
-                f(red)
-            except AttributeError:
-                pass
-            print('element-wise workgroups:', wgs, ' reducing workgroups:', red)
-            sweep(dev, L)
+    sweep(dev, L)
 
 
 def sweep(dev, L):

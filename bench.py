@@ -160,10 +160,14 @@ def make_fresh_batches(frames, points, seed, dev, n_batches):
     return out
 
 
-def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=True):
+def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=True, prefetch=True):
     """Times `steps` iterations of train.py:127-140 on the resident `batch` (coords, feats, labels) --
-    or, if `batch` is a list of such tuples, on a different one of them every step."""
-    from lidal_amd.network import SPVCNN, MinkUNet
+    or, if `batch` is a list of such tuples, on a different one of them every step.
+    prefetch: every step builds the coordinate tables (voxel index, kernel maps, row orders, point <-> voxel
+    tables) of the NEXT step's batch on a second stream right after queueing its own forward + backward
+    (lidal_amd.network.GeometryPrefetcher) -- one build per step, as with prefetch=False, where the forward pass
+    builds its own tables in line (the reference's order of work)."""
+    from lidal_amd.network import SPVCNN, MinkUNet, GeometryPrefetcher
     from lidal_amd.train_step import train_step
     batches = batch if isinstance(batch, list) else [batch]
     torch.manual_seed(7122)
@@ -176,11 +180,16 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
     opt = torch.optim.Adam(net.parameters(), fused=True)
     autocast = dtype == 'bf16'
     count = [0]
+    pf = GeometryPrefetcher(model, device=dev) if prefetch else None
+    ahead = [pf.submit(batches[0][0]) if prefetch else None]
 
     def step():
         coords, feats, labels = batches[count[0] % len(batches)]
         count[0] += 1
-        return train_step(net, opt, feats, coords, labels, autocast=autocast)
+        out = train_step(net, opt, feats, coords, labels, autocast=autocast, geometry=ahead[0])
+        if prefetch:
+            ahead[0] = pf.submit(batches[count[0] % len(batches)][0])
+        return out
 
     for i in range(warmup):
         step()
@@ -653,8 +662,12 @@ def guarded(fn, *a):
         return {'error': repr(e)}
 
 
-def run_variants(args, batch, dev):
+def run_variants(args, batch, dev, inline=None):
     var = {}
+    if inline is not None:
+        var['inline_geometry'] = variant_line(inline)
+        var['inline_geometry']['what'] = ('the same step with the coordinate tables built inside the forward pass '
+                                          '(no second stream): the order of work of the reference and of rounds 1-3a')
     one = make_batch(1, args.points, 7122, dev)
     var['single_scan'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, one,
                                                   max(args.steps, 10), 3, ddp=False))
@@ -713,7 +726,9 @@ def main():
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': '%s train step (train.py:127-140: fwd + CE + bwd + Adam), %d scans x ~%dk pts '
-                               'per GPU, 0.05 m voxels, kernel maps rebuilt every step'
+                               'per GPU, 0.05 m voxels, kernel maps rebuilt every step (each step builds the '
+                               'next step\'s coordinate tables on a second stream; variants.inline_geometry: '
+                               'built inside the forward pass)'
                                % (args.model, args.frames, args.points // 1000),
                    'voxels_per_step_per_gpu': int(voxels / world),
                    'parallelism': 'dp%d' % world, 'loss': round(res['loss'], 4)},
@@ -721,11 +736,23 @@ def main():
     if rank == 0 and not args.no_roofline:
         line['roofline'] = guarded(roofline_conv, args, batch[0], dev)
         log('roofline', line['roofline'])
-    if solo and not args.no_families:
-        line['families'] = guarded(family_table, res['step'], batch[0], args.dtype, ms)
+    inline = None
+    if solo and not (args.no_families and args.no_variants):
+        # the same step with its tables built in line: the serial cost of every family (on two streams the
+        # bracketed intervals overlap and would not add up), and the A/B of the second stream
+        inline = guarded(bench_train, 1, 0, dev, args.model, args.dtype, batch, args.steps, args.warmup, False, False)
+        if 'error' in inline:
+            log('inline step failed', inline)
+            inline = None
+    if solo and not args.no_families and inline is not None:
+        inline_ms = inline['seconds'] / inline['steps'] * 1e3
+        line['families'] = guarded(family_table, inline['step'], batch[0], args.dtype, inline_ms)
+        if isinstance(line['families'], dict) and 'whole_step' in line['families']:
+            line['families']['whole_step']['what'] = ('the step with its coordinate tables built in line (%.3f ms); '
+                                                      'the headline step builds them on a second stream' % inline_ms)
         log('families', line['families'])
     if solo and not args.no_variants:
-        line['variants'] = guarded(run_variants, args, batch, dev)
+        line['variants'] = guarded(run_variants, args, batch, dev, inline)
         log('variants', line['variants'])
     if frames is not None:
         sec = (guarded(bench_scoring, args, res['model'], world, rank, dev, frames, batches) if world == 1

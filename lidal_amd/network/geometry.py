@@ -1,0 +1,160 @@
+"""The coordinate-only part of a forward pass, built ahead of the features -- optionally on a second stream.
+
+Everything SPVCNN / MinkUNet derive from the voxel coordinates alone -- the re-voxelisation index
+(network/utils.py:14-31), the coordinates of the four coarser levels, the nine kernel maps with their row
+orders and rule lists (torchsparse conv3d's cache-miss branch), the point <-> voxel indices, trilinear weights
+and contributor lists at strides 1 / 16 / 4 (network/utils.py:39-53,67-92) -- depends on neither the features
+nor the weights.  The reference builds all of it inside `model(x)`, every iteration, and so does this package by
+default.  Inside the forward pass it costs more than its kernels: the sizes of the data-dependent outputs
+(number of voxels, rows per level, rules per map) come back to the host through three stream synchronisations,
+each of which first drains everything queued before it -- the previous step's backward pass, or the previous
+frame's forward -- and then leaves the GPU idle while the host queues the next small launches.
+
+`Geometry.build(model, coords)` runs that part by itself; `GeometryPrefetcher.submit(coords)` runs it on a second
+HIP stream, so its synchronisations wait only for its own short queue while the main stream keeps working on
+the previous batch (the reference overlaps the same way one stage earlier: its DataLoader workers voxelise the
+next scans on the CPU while the GPU trains, dataset/sk_dataloader.py:21,53).  Hand the result to the forward pass
+with `x.geometry = g` (train_step / infer_frame take it as `geometry=`): the model finds every table in its
+caches and launches feature kernels only.  Same tables, bit for bit, as the in-line path builds
+(tests/test_model_gpu.py::test_prefetched_geometry_*); every batch still gets its own build.
+"""
+import torch
+
+from .. import PointTensor, SparseTensor
+from ..nn import functional as F
+from ..nn.functional.conv import prefetch_kernel_maps
+from ..nn.functional.devoxelize import prepare_devoxelize
+from ..nn.functional.voxelize import prepare_voxelize
+from .glue import corner_tables, initial_tables, point_tables
+
+__all__ = ['Geometry', 'GeometryPrefetcher']
+
+
+def _walk(obj, seen, out):
+    """Every tensor reachable from obj (containers, the map / order / table objects, and the caches this package
+    hangs on tensors)."""
+    if obj is None or isinstance(obj, (int, float, str, bool, torch.dtype, torch.device)) or id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        out.append(obj)
+        for name in ('_lidal_invlist', '_lidal_i32', '_lidal_table'):
+            _walk(getattr(obj, name, None), seen, out)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _walk(v, seen, out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _walk(v, seen, out)
+    elif hasattr(obj, '__dict__') and type(obj).__module__.startswith('lidal_amd'):
+        _walk(vars(obj), seen, out)
+
+
+class Geometry:
+    """What one forward pass of `kind` ('SPVCNN' / 'MinkUNet') derives from `coords` (i32 [N,4], batch last)."""
+
+    def __init__(self, coords, kind, grad):
+        self.coords = coords
+        self.kind = kind
+        self.grad = grad                # rule lists / backward contributor lists included
+        self.x0 = None                  # SparseTensor without features: level-0 coordinates + cmaps / kmaps
+        self.z = None                   # SPVCNN: PointTensor without features carrying the point caches
+        self.ready = None               # event on the stream the tables were built on (None: the caller's own stream)
+        self._stream = None
+        self._seen_by = set()           # streams that already wait for `ready`
+
+    @staticmethod
+    def build(model, coords, grad=None):
+        """Build on the current stream.  grad: also what only a backward pass reads (default: model.training and
+        gradients enabled)."""
+        from .unet import SPVCNN
+        if grad is None:
+            grad = model.training and torch.is_grad_enabled()
+        g = Geometry(coords, type(model).__name__, bool(grad))
+        with torch.set_grad_enabled(bool(grad)):          # the map builder includes the rule lists iff gradients are on
+            if isinstance(model, SPVCNN):
+                z = PointTensor(None, coords.float())
+                x0 = SparseTensor(None, initial_tables(z, model.pres, model.vres), 1)
+                x0.cmaps.setdefault(x0.stride, x0.coords)
+                prefetch_kernel_maps(x0, model.MAP_PLAN)
+                for s in model.POINT_STRIDES:
+                    xs = SparseTensor(None, x0.cmaps[(s, s, s)], s)
+                    xs.cmaps, xs.kmaps = x0.cmaps, x0.kmaps
+                    idx, w = corner_tables(xs, z)
+                    pidx, counts = point_tables(xs, z)
+                    prepare_voxelize(pidx, counts)
+                    if grad:
+                        prepare_devoxelize(idx, w, xs.C.shape[0])
+                g.z = z
+            else:
+                x0 = SparseTensor(None, coords, 1)
+                prefetch_kernel_maps(x0, model.MAP_PLAN)
+            g.x0 = x0
+        return g
+
+    def tensors(self):
+        out = []
+        _walk([self.x0, self.z], set(), out)
+        return out
+
+    def enter(self, x, kind):
+        """Called by the model's forward with its input: checks that the tables are x's, makes the current stream
+        wait for them, and returns (x0 with x's features, z or None)."""
+        if kind != self.kind:
+            raise RuntimeError('lidal_amd: geometry built for %s handed to %s' % (self.kind, kind))
+        c = x.C
+        if tuple(x.s) != (1, 1, 1):
+            raise RuntimeError('lidal_amd: geometries are built for stride-1 inputs, got stride %s' % (x.s,))
+        if not (c is self.coords or (c.data_ptr() == self.coords.data_ptr() and c.shape == self.coords.shape
+                                     and c.dtype == self.coords.dtype)):
+            raise RuntimeError('lidal_amd: x.geometry was built for other coordinates than x.C')
+        if self.ready is not None:
+            cur = torch.cuda.current_stream(c.device)
+            if cur != self._stream and cur.cuda_stream not in self._seen_by:
+                cur.wait_event(self.ready)
+                # the tables were allocated on the other stream: tell the allocator who reads them now, or it would
+                # hand their memory to that stream's next build while this stream's kernels may still be reading
+                for t in self.tensors():
+                    t.record_stream(cur)
+                self._seen_by.add(cur.cuda_stream)
+        if self.z is None:
+            x0 = SparseTensor(x.F, x.C, x.s)
+            x0.cmaps, x0.kmaps = self.x0.cmaps, self.x0.kmaps
+            return x0, None
+        z = PointTensor(x.F, self.z.C, idx_query=self.z.idx_query, weights=self.z.weights)
+        z.additional_features = self.z.additional_features
+        feats = F.spvoxelize(z.F, z.additional_features['idx_query'][1], z.additional_features['counts'][1])
+        x0 = SparseTensor(feats, self.x0.C, 1)
+        x0.cmaps, x0.kmaps = self.x0.cmaps, self.x0.kmaps
+        return x0, z
+
+
+class GeometryPrefetcher:
+    """Builds geometries on a second stream of `device`:
+
+        g = pf.submit(coords_0)
+        for batch in batches:
+            train_step(model, opt, feats, coords, labels, geometry=g)     # queues the step on the current stream
+            g = pf.submit(next_coords)        # next batch's tables, built beside that step on the GPU
+
+    submit() returns when the tables' sizes are known to the host (it waits for ITS stream only).  `coords` must
+    be valid on submission (resident, or pass the event after which they are as `ready=`)."""
+
+    def __init__(self, model, device=None):
+        self.model = model
+        if device is None:
+            device = next(model.parameters()).device
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device, priority=-1)
+
+    def submit(self, coords, grad=None, ready=None):
+        if grad is None:
+            grad = self.model.training and torch.is_grad_enabled()
+        with torch.cuda.stream(self.stream):
+            if ready is not None:
+                self.stream.wait_event(ready)
+            coords.record_stream(self.stream)
+            g = Geometry.build(self.model, coords, grad)
+            g.ready = self.stream.record_event()
+            g._stream = self.stream
+        return g

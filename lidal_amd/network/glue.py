@@ -10,7 +10,7 @@ from .. import backend as B
 from ..nn import functional as F
 from ..nn.utils import get_kernel_offsets
 
-__all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point']
+__all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point', 'initial_tables', 'point_tables', 'corner_tables']
 
 
 
@@ -26,9 +26,10 @@ def _floor_to_stride(z, s):
     return torch.cat([xyz, c[:, -1].int().view(-1, 1)], 1)
 
 
-def initial_voxelize(z, init_res, after_res):
-    """utils.py:13-33: re-voxelise the points at `after_res`; the voxel order is the SORTED order
-    of the distinct 60-bit coordinate hashes (torch.unique at :18)."""
+def initial_tables(z, init_res, after_res):
+    """The coordinate half of initial_voxelize (utils.py:14-22,28-31): point -> voxel index, counts and the voxel
+    coordinates, left in z's caches; returns the coordinates.  Also what network/geometry.py runs ahead of the
+    features."""
     # true IEEE division: torch's GPU `tensor / python_scalar` multiplies by the reciprocal, which
     # leaves voxel centres 1e-7 off the integers the CPU path produces (SURVEY.md H8)
     res = torch.full((), after_res, dtype=z.C.dtype, device=z.C.device)
@@ -43,18 +44,25 @@ def initial_voxelize(z, init_res, after_res):
         # sk_dataset.py:160-171): the index is a permutation and every count is 1 -- F.spvoxelize then moves rows
         idx_query._lidal_one_to_one = True
     inserted_coords = torch.round(F.spvoxelize(floored, idx_query, counts)).int()
-    inserted_feat = F.spvoxelize(z.F, idx_query, counts)
-    new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
-    new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
     z.additional_features['idx_query'][1] = idx_query
     z.additional_features['counts'][1] = counts
     z.additional_features['init_coords'] = inserted_coords     # the rows that index refers to
     z.C = new_float_coord
+    return inserted_coords
+
+
+def initial_voxelize(z, init_res, after_res):
+    """utils.py:13-33: re-voxelise the points at `after_res`; the voxel order is the SORTED order
+    of the distinct 60-bit coordinate hashes (torch.unique at :18)."""
+    inserted_coords = initial_tables(z, init_res, after_res)
+    inserted_feat = F.spvoxelize(z.F, z.additional_features['idx_query'][1], z.additional_features['counts'][1])
+    new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
+    new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
     return new_tensor
 
 
-def point_to_voxel(x, z):
-    """utils.py:38-61: mean of the point features falling into each voxel of x."""
+def point_tables(x, z):
+    """The point -> voxel index and counts of point_to_voxel (utils.py:39-53) at x's stride, in z's caches."""
     cache_i, cache_c = z.additional_features['idx_query'], z.additional_features['counts']
     if cache_i.get(x.s) is None and tuple(x.s) == (1, 1, 1) and cache_i.get(1) is not None \
             and x.C is z.additional_features.get('init_coords'):
@@ -67,22 +75,28 @@ def point_to_voxel(x, z):
         idx_query = F.coords_table(x.C, x.cmaps).query(pc_hash)     # == F.sphashquery(pc_hash, F.sphash(x.C))
         cache_i[x.s] = idx_query
         cache_c[x.s] = F.spcount(idx_query.int(), x.C.shape[0])
+    return cache_i[x.s], cache_c[x.s]
+
+
+def point_to_voxel(x, z):
+    """utils.py:38-61: mean of the point features falling into each voxel of x."""
+    idx_query, counts = point_tables(x, z)
     # z.F has a second consumer downstream (the point-branch Linear of SPVCNN.forward): it gets an
     # alias whose gradient joins the voxelize backward in-kernel (F.spvoxelize, fork)
     if B.FORK & 2:
-        feats, z.F = F.spvoxelize(z.F, cache_i[x.s], cache_c[x.s], fork=True)
+        feats, z.F = F.spvoxelize(z.F, idx_query, counts, fork=True)
     else:
-        feats = F.spvoxelize(z.F, cache_i[x.s], cache_c[x.s])
+        feats = F.spvoxelize(z.F, idx_query, counts)
     new_tensor = SparseTensor(feats, x.C, x.s)
     new_tensor.cmaps = x.cmaps
     new_tensor.kmaps = x.kmaps
     return new_tensor
 
 
-def voxel_to_point(x, z, nearest=False):
-    """utils.py:66-102: trilinear interpolation of the 8 surrounding voxels of x at each point."""
+def corner_tables(x, z, nearest=False):
+    """The 8-corner index and trilinear weights of voxel_to_point (utils.py:67-92) at x's stride, in z's caches."""
     if z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
-        off = get_kernel_offsets(2, x.s, 1, device=z.F.device)
+        off = get_kernel_offsets(2, x.s, 1, device=z.C.device)
         old_hash = F.sphash(_floor_to_stride(z, x.s[0]), off)          # [8, N]
         idx_query = F.coords_table(x.C, x.cmaps).query(old_hash)    # == F.sphashquery(old_hash, F.sphash(x.C))
         weights, idx_query = F.ti_weights_and_index(z.C, idx_query, scale=x.s[0])   # [N,8] both
@@ -91,7 +105,13 @@ def voxel_to_point(x, z, nearest=False):
             idx_query[:, 1:] = -1
         z.idx_query[x.s] = idx_query
         z.weights[x.s] = weights
-    new_feat = F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s])
+    return z.idx_query[x.s], z.weights[x.s]
+
+
+def voxel_to_point(x, z, nearest=False):
+    """utils.py:66-102: trilinear interpolation of the 8 surrounding voxels of x at each point."""
+    idx_query, weights = corner_tables(x, z, nearest)
+    new_feat = F.spdevoxelize(x.F, idx_query, weights)
     new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
     new_tensor.additional_features = z.additional_features
     return new_tensor

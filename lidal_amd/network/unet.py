@@ -63,7 +63,11 @@ class MinkUNet(_SparseUNet):
         self.weight_initialization()
 
     def forward(self, x):
-        prefetch_kernel_maps(x, self.MAP_PLAN)
+        g = getattr(x, 'geometry', None)            # tables built ahead of the features (network/geometry.py)
+        if g is not None:
+            x, _ = g.enter(x, 'MinkUNet')
+        else:
+            prefetch_kernel_maps(x, self.MAP_PLAN)
         x0 = self.stem(x)
         x1 = self.stage1(x0)
         x2 = self.stage2(x1)
@@ -91,9 +95,17 @@ class SPVCNN(_SparseUNet):
         self.weight_initialization()
         self.dropout = nn.Dropout(0.3, True)
 
+    # strides at which features cross between the point and the voxel branch (forward below)
+    POINT_STRIDES = (1, 16, 4)
+
     def forward(self, x):
-        z = PointTensor(x.F, x.C.float())
-        x0 = self.stem(prefetch_kernel_maps(initial_voxelize(z, self.pres, self.vres), self.MAP_PLAN))
+        g = getattr(x, 'geometry', None)            # tables built ahead of the features (network/geometry.py)
+        if g is not None:
+            x0, z = g.enter(x, 'SPVCNN')
+            x0 = self.stem(x0)
+        else:
+            z = PointTensor(x.F, x.C.float())
+            x0 = self.stem(prefetch_kernel_maps(initial_voxelize(z, self.pres, self.vres), self.MAP_PLAN))
         z0 = voxel_to_point(x0, z, nearest=False)
 
         x1 = self.stage1(point_to_voxel(x0, z0))

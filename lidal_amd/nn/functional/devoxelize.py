@@ -6,7 +6,7 @@ from torch.autograd import Function
 from ... import backend as B
 from .invlist import inverse_lists, segment_workspace
 
-__all__ = ['spdevoxelize', 'calc_ti_weights', 'ti_weights_and_index']
+__all__ = ['spdevoxelize', 'calc_ti_weights', 'ti_weights_and_index', 'prepare_devoxelize']
 
 
 def ti_weights_and_index(coords, idx_query, scale=1):
@@ -73,6 +73,14 @@ class DevoxelizeFunction(Function):
             B.check(B.lib().lidal_devoxelize_bwd(B.ptr(g), B.ptr(coords), B.ptr(weights),
                                                  B.ptr(gin), n, m, c, B.stream()), 'devoxelize_bwd')
         return gin.to(in_dtype), None, None
+
+
+def prepare_devoxelize(coords, weights, m):
+    """What the backward of F.spdevoxelize derives from index and weights alone (network/geometry.py): the
+    per-voxel contributor lists of the ordered scatter sum.  coords i32 [N,8], weights f32 [N,8], m voxels."""
+    if coords.dtype == torch.int and coords.is_contiguous() and weights.dtype == torch.float32 \
+            and weights.is_contiguous():
+        inverse_lists(coords, m, weights)
 
 
 def spdevoxelize(feats, coords, weights):

@@ -6,7 +6,26 @@ from torch.autograd import Function
 from ... import backend as B
 from .invlist import inverse_lists, segment_workspace
 
-__all__ = ['spvoxelize']
+__all__ = ['spvoxelize', 'prepare_voxelize']
+
+
+def _index32(coords):
+    """int32 copy of a point -> voxel index, cached on the index tensor (keyed on its version counter and storage)."""
+    key = (coords._version, coords.data_ptr(), coords.numel())
+    cached = getattr(coords, '_lidal_i32', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    idx32 = coords.contiguous().int()
+    coords._lidal_i32 = (key, idx32)
+    return idx32
+
+
+def prepare_voxelize(coords, counts):
+    """What F.spvoxelize derives from the index alone, ahead of the features (network/geometry.py): the int32 copy
+    and, unless every voxel has one point, the per-voxel contributor lists of the ordered forward."""
+    idx32 = _index32(coords)
+    if not (getattr(coords, '_lidal_one_to_one', False) and coords.numel() == counts.shape[0]):
+        inverse_lists(idx32, counts.shape[0])
 
 
 class VoxelizeFunction(Function):
@@ -19,14 +38,7 @@ class VoxelizeFunction(Function):
         # ordered path applies; everything else computes on an f32 copy
         native = in_dtype == torch.bfloat16 and feats.shape[1] % 4 == 0
         feats = feats.contiguous() if native else feats.contiguous().float()
-        # int32 copy cached on the index tensor, keyed on its version counter and storage
-        key = (coords._version, coords.data_ptr(), coords.numel())
-        cached = getattr(coords, '_lidal_i32', None)
-        if cached is not None and cached[0] == key:
-            idx32 = cached[1]
-        else:
-            idx32 = coords.contiguous().int()
-            coords._lidal_i32 = (key, idx32)
+        idx32 = _index32(coords)
         counts = counts.contiguous().int()
         n, c = feats.shape
         m = counts.shape[0]

@@ -21,8 +21,35 @@ from .sharding import HaloExchange, gather_frames, is_sharded
 __all__ = ['score_sequence', 'collect_sequence', 'ScoreBoard']
 
 
+class _Inference:
+    """infer_frame over this rank's frames in a fixed order, the coordinate tables of the NEXT frame built on a
+    second stream beside the forward pass of the current one (network/geometry.py): a frame's forward then never
+    waits for the host to learn the sizes of its own maps."""
+
+    def __init__(self, model, by_id, order, inf_reps, autocast, prefetch):
+        self.model, self.by_id, self.order = model, by_id, list(order)
+        self.inf_reps, self.autocast = inf_reps, autocast
+        self.pos = 0
+        self.pf = self.g = None
+        if prefetch and self.order:
+            from ..network import GeometryPrefetcher
+            self.pf = GeometryPrefetcher(model, device=by_id[self.order[0]]['coords'].device)
+            self.g = self.pf.submit(by_id[self.order[0]]['coords'], grad=False)
+
+    def __call__(self, f):
+        assert f == self.order[self.pos], 'frames are inferred in the announced order'
+        d = self.by_id[f]
+        prob, _ = infer_frame(self.model, d['coords'], d['feats'], d['inverse'], self.inf_reps,
+                              autocast=self.autocast, geometry=self.g)
+        self.pos += 1
+        if self.pf is not None:
+            self.g = (self.pf.submit(self.by_id[self.order[self.pos]]['coords'], grad=False)
+                      if self.pos < len(self.order) else None)
+        return prob
+
+
 def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_thresh=0.1,
-                   inf_reps=8, autocast=False, group=None, exchange='halo'):
+                   inf_reps=8, autocast=False, group=None, exchange='halo', prefetch=True):
     """local_frames: list of dicts for frames first_frame, first_frame+1, ... owned by this rank,
     each with device tensors coords (i32 [N,4]), feats (f32 [N,4]), inverse (i64 [reps*P]),
     world (f64 [P,3]), sv_ptr / sv_idx (CSR of the supervoxels).
@@ -31,16 +58,18 @@ def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_th
     exchange: 'halo' (default) -- every rank receives only the frames its block reads (its neighbours'
     edge frames + the wrap-rule frames at the ends of the sequence), point to point; the frames other
     ranks read are inferred first and travel under the inference of the rest; 'allgather' -- every frame to every rank
-    (one padded all_gather_into_tensor per array).  Same scores bit for bit."""
+    (one padded all_gather_into_tensor per array).  Same scores bit for bit.
+    prefetch: build each frame's coordinate tables one frame ahead on a second stream (same tables)."""
     n_class = model.num_classes if hasattr(model, 'num_classes') else 19
     dev = local_frames[0]['world'].device if local_frames else None
     if exchange == 'allgather' or not is_sharded(group):
         probs, worlds = {}, {}
-        for s, d in enumerate(local_frames):
-            prob, _ = infer_frame(model, d['coords'], d['feats'], d['inverse'], inf_reps, autocast=autocast)
-            probs[first_frame + s] = prob
-            worlds[first_frame + s] = d['world']
-            n_class = prob.shape[1]
+        by_id = {first_frame + s: d for s, d in enumerate(local_frames)}
+        infer = _Inference(model, by_id, list(by_id), inf_reps, autocast, prefetch)
+        for f, d in by_id.items():
+            probs[f] = infer(f)
+            worlds[f] = d['world']
+            n_class = probs[f].shape[1]
         all_prob = gather_frames(probs, n_total, (n_class,), torch.float32, group=group, device=dev)
         all_world = gather_frames(worlds, n_total, (3,), torch.float64, group=group, device=dev)
         bank = FrameBank(dis_thresh)
@@ -56,16 +85,14 @@ def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_th
         worlds = {f: d['world'] for f, d in by_id.items()}
         hx.exchange('world', (3,), torch.float64, worlds)
         probs = {}
-
-        def infer(f):
-            d = by_id[f]
-            probs[f], _ = infer_frame(model, d['coords'], d['feats'], d['inverse'], inf_reps, autocast=autocast)
-        for f in hx.exports:            # the frames other ranks read: first, so that their transfer ...
-            infer(f)
+        first = [f for f in hx.exports if f in by_id]
+        rest = [f for f in by_id if f not in set(first)]
+        infer = _Inference(model, by_id, first + rest, inf_reps, autocast, prefetch)
+        for f in first:                 # the frames other ranks read: first, so that their transfer ...
+            probs[f] = infer(f)
         hx.exchange('prob', (n_class,), torch.float32, probs)
-        for f in by_id:                 # ... runs under the inference of the rest
-            if f not in probs:
-                infer(f)
+        for f in rest:                  # ... runs under the inference of the rest
+            probs[f] = infer(f)
         have = hx.finish({'world': worlds, 'prob': probs})
         bank = FrameBank(dis_thresh, n_frames=n_total)
         for f in sorted(have['world']):

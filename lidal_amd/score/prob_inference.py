@@ -32,14 +32,18 @@ def view_mean_softmax(logits, inverse_indices, inf_reps):
 
 
 @torch.no_grad()
-def infer_frame(model, coords_v_b, feats_v_b, inverse_indices_b, inf_reps=8, autocast=False, return_feat=False):
+def infer_frame(model, coords_v_b, feats_v_b, inverse_indices_b, inf_reps=8, autocast=False, return_feat=False,
+                geometry=None):
     """model.eval() forward over the `inf_reps` augmented views of ONE frame, then the fused
     voxel->point gather + softmax + view mean + argmax.  Returns (prob [P,C], pred [P]).
     return_feat (prob_inference.py:103-105,116-118: `outfeat`, saved when r_id == 0 or the metric is
     ReDAL / CSET): also the [P, 96] feature of every point, the view mean of feat[inverse_indices] as the
     reference computes it -- (prob, pred, feat)."""
+    x = SparseTensor(feats_v_b, coords_v_b)
+    if geometry is not None:        # the frame's coordinate tables, built ahead (lidal_amd.network.GeometryPrefetcher)
+        x.geometry = geometry
     with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
-        logits, feat = model(SparseTensor(feats_v_b, coords_v_b))
+        logits, feat = model(x)
     prob, pred = view_mean_softmax(logits, inverse_indices_b, inf_reps)
     if not return_feat:
         return prob, pred

@@ -9,16 +9,19 @@ from .nn.functional.fused import cross_entropy
 __all__ = ['train_step', 'forward_backward']
 
 
-def forward_backward(model, feats_v_b, coords_v_b, labels_v_b, autocast=False):
+def forward_backward(model, feats_v_b, coords_v_b, labels_v_b, autocast=False, geometry=None):
+    x = SparseTensor(feats_v_b, coords_v_b)
+    if geometry is not None:        # the batch's coordinate tables, built ahead (lidal_amd.network.GeometryPrefetcher)
+        x.geometry = geometry
     with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
-        logits, _ = model(SparseTensor(feats_v_b, coords_v_b))
+        logits, _ = model(x)
     loss = cross_entropy(logits, labels_v_b, ignore_index=255)
     loss.backward()
     return loss, logits
 
 
-def train_step(model, optimizer, feats_v_b, coords_v_b, labels_v_b, autocast=False):
+def train_step(model, optimizer, feats_v_b, coords_v_b, labels_v_b, autocast=False, geometry=None):
     optimizer.zero_grad()
-    loss, logits = forward_backward(model, feats_v_b, coords_v_b, labels_v_b, autocast)
+    loss, logits = forward_backward(model, feats_v_b, coords_v_b, labels_v_b, autocast, geometry)
     optimizer.step()
     return loss.detach(), logits.detach()

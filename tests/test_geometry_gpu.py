@@ -1,0 +1,130 @@
+"""The coordinate tables of a forward pass built AHEAD of it (lidal_amd/network/geometry.py), on the same or on a
+second stream, against the in-line build inside `model(x)` (the reference's order of work: torchsparse builds its
+maps on first use inside the forward pass, network/utils.py:13-102 the point tables): same results bit for bit,
+for training steps on changing batches and for the 8-view inference step."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _models():
+    from lidal_amd.network import SPVCNN, MinkUNet
+    return {'spvcnn': SPVCNN, 'minkunet': MinkUNet}
+
+
+def _batches(n, points=6000, frames=2):
+    from lidal_amd import synth
+    out = []
+    for i in range(n):
+        b = synth.make_train_batch(n_frames=frames, n_points=points + 700 * i, seed=100 + i)
+        out.append(tuple(torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b', 'labels_v_b')))
+    return out
+
+
+def _run(model, batches, autocast, prefetch):
+    from lidal_amd.network import GeometryPrefetcher
+    from lidal_amd.train_step import train_step
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    torch.manual_seed(5)                    # dropout masks (SPVCNN): the same in both runs
+    losses, logits = [], None
+    pf = GeometryPrefetcher(model) if prefetch else None
+    g = pf.submit(batches[0][1]) if prefetch else None
+    for i, (feats, coords, labels) in enumerate(batches):
+        loss, logits = train_step(model, opt, feats, coords, labels, autocast=autocast, geometry=g)
+        if prefetch and i + 1 < len(batches):
+            g = pf.submit(batches[i + 1][1])        # beside the step just queued
+        losses.append(loss)
+    torch.cuda.synchronize()
+    return [float(v) for v in losses], logits
+
+
+@pytest.mark.parametrize('name,autocast', [('spvcnn', True), ('spvcnn', False), ('minkunet', True)])
+def test_prefetched_geometry_train_steps_are_bitwise_the_inline_steps(name, autocast):
+    torch.manual_seed(0)
+    a = _models()[name](19).to(DEV).train()
+    b = copy.deepcopy(a)
+    batches = _batches(4)
+    la, ya = _run(a, batches, autocast, prefetch=False)
+    lb, yb = _run(b, batches, autocast, prefetch=True)
+    assert la == lb, (la, lb)
+    assert torch.equal(ya, yb)
+    for (k, p), q in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(p, q), k
+
+
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_prefetched_geometry_holds_every_table_the_forward_asks_for(name):
+    """With a geometry the forward pass launches no map / table / list builder: counted at the C-ABI."""
+    from lidal_amd import SparseTensor, backend as B
+    from lidal_amd.network import Geometry
+    torch.manual_seed(0)
+    model = _models()[name](19).to(DEV).train()
+    feats, coords, labels = _batches(1)[0]
+    g = Geometry.build(model, coords)
+    builders = ('lidal_kmap_build', 'lidal_kmap_build_batch', 'lidal_kmap_order', 'lidal_kmap_order_batch',
+                'lidal_hash_table_build', 'lidal_hash_table_query', 'lidal_invlist_build', 'lidal_ti_weights',
+                'lidal_downsample_pyramid', 'lidal_downsample', 'lidal_unique_sorted_i64', 'lidal_kmap_invert',
+                'lidal_hash', 'lidal_kernel_hash', 'lidal_count', 'lidal_floor_coords')
+    assert all(b in B.SIGNATURES for b in builders)
+    seen = []
+    B.set_call_timer(lambda name, args, e0, e1: seen.append(name))
+    try:
+        x = SparseTensor(feats, coords)
+        x.geometry = g
+        logits, _ = model(x)
+        logits.float().sum().backward()
+    finally:
+        B.set_call_timer(None)
+    torch.cuda.synchronize()
+    names = set(seen)
+    assert names and not names & set(builders), sorted(names & set(builders))
+
+
+def test_a_geometry_is_refused_for_other_coordinates_or_another_network():
+    from lidal_amd import SparseTensor
+    from lidal_amd.network import Geometry
+    models = _models()
+    torch.manual_seed(0)
+    spv, mink = models['spvcnn'](19).to(DEV).eval(), models['minkunet'](19).to(DEV).eval()
+    (f0, c0, _), (f1, c1, _) = _batches(2)
+    g = Geometry.build(spv, c0)
+    with torch.no_grad():
+        x = SparseTensor(f1, c1)
+        x.geometry = g
+        with pytest.raises(RuntimeError, match='other coordinates'):
+            spv(x)
+        x = SparseTensor(f0, c0)
+        x.geometry = g
+        with pytest.raises(RuntimeError, match='built for SPVCNN'):
+            mink(x)
+        spv(x)
+
+
+def test_prefetched_geometry_inference_step_is_bitwise():
+    from lidal_amd import synth
+    from lidal_amd.network import GeometryPrefetcher
+    from lidal_amd.score.prob_inference import infer_frame
+    torch.manual_seed(0)
+    model = _models()['spvcnn'](19).to(DEV).eval()
+    frames = []
+    world = synth.make_world(5)
+    for i in range(3):
+        rng = np.random.default_rng(40 + i)
+        pts, inten = synth.raycast_scan(world, (20.0 + 3 * i, 0.0), rng, n_beams=16 + 2 * i, n_az=128)
+        d = synth.make_score_batch(pts, inten, rng, inf_reps=8)
+        frames.append(tuple(torch.from_numpy(d[k]).to(DEV) for k in ('coords_v_b', 'feats_v_b', 'inverse_indices_b')))
+    want = [infer_frame(model, c, f, inv, 8, autocast=True, return_feat=True) for c, f, inv in frames]
+    pf = GeometryPrefetcher(model)
+    g = pf.submit(frames[0][0])
+    assert not g.grad
+    for i, (c, f, inv) in enumerate(frames):
+        got = infer_frame(model, c, f, inv, 8, autocast=True, return_feat=True, geometry=g)
+        if i + 1 < len(frames):
+            g = pf.submit(frames[i + 1][0])
+        for a, b in zip(want[i], got):
+            assert torch.equal(a, b)

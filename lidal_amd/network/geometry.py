@@ -16,7 +16,7 @@ the previous batch (the reference overlaps the same way one stage earlier: its D
 next scans on the CPU while the GPU trains, dataset/sk_dataloader.py:21,53).  Hand the result to the forward pass
 with `x.geometry = g` (train_step / infer_frame take it as `geometry=`): the model finds every table in its
 caches and launches feature kernels only.  Same tables, bit for bit, as the in-line path builds
-(tests/test_model_gpu.py::test_prefetched_geometry_*); every batch still gets its own build.
+(tests/test_geometry_gpu.py); every batch still gets its own build.
 """
 import torch
 
@@ -30,26 +30,6 @@ from .glue import corner_tables, initial_tables, point_tables
 __all__ = ['Geometry', 'GeometryPrefetcher']
 
 
-def _walk(obj, seen, out):
-    """Every tensor reachable from obj (containers, the map / order / table objects, and the caches this package
-    hangs on tensors)."""
-    if obj is None or isinstance(obj, (int, float, str, bool, torch.dtype, torch.device)) or id(obj) in seen:
-        return
-    seen.add(id(obj))
-    if isinstance(obj, torch.Tensor):
-        out.append(obj)
-        for name in ('_lidal_invlist', '_lidal_i32', '_lidal_table'):
-            _walk(getattr(obj, name, None), seen, out)
-    elif isinstance(obj, dict):
-        for v in obj.values():
-            _walk(v, seen, out)
-    elif isinstance(obj, (list, tuple)):
-        for v in obj:
-            _walk(v, seen, out)
-    elif hasattr(obj, '__dict__') and type(obj).__module__.startswith('lidal_amd'):
-        _walk(vars(obj), seen, out)
-
-
 class Geometry:
     """What one forward pass of `kind` ('SPVCNN' / 'MinkUNet') derives from `coords` (i32 [N,4], batch last)."""
 
@@ -61,7 +41,7 @@ class Geometry:
         self.z = None                   # SPVCNN: PointTensor without features carrying the point caches
         self.ready = None               # event on the stream the tables were built on (None: the caller's own stream)
         self._stream = None
-        self._seen_by = set()           # streams that already wait for `ready`
+        self._age = 0                   # submissions to the same prefetcher stream since this one
 
     @staticmethod
     def build(model, coords, grad=None):
@@ -92,11 +72,6 @@ class Geometry:
             g.x0 = x0
         return g
 
-    def tensors(self):
-        out = []
-        _walk([self.x0, self.z], set(), out)
-        return out
-
     def enter(self, x, kind):
         """Called by the model's forward with its input: checks that the tables are x's, makes the current stream
         wait for them, and returns (x0 with x's features, z or None)."""
@@ -109,14 +84,12 @@ class Geometry:
                                      and c.dtype == self.coords.dtype)):
             raise RuntimeError('lidal_amd: x.geometry was built for other coordinates than x.C')
         if self.ready is not None:
+            if self._age >= 2:
+                raise RuntimeError('lidal_amd: this geometry is stale -- two newer ones have been submitted to its '
+                                   'prefetcher since; its memory may already serve another build (GeometryPrefetcher)')
             cur = torch.cuda.current_stream(c.device)
-            if cur != self._stream and cur.cuda_stream not in self._seen_by:
+            if cur != self._stream:
                 cur.wait_event(self.ready)
-                # the tables were allocated on the other stream: tell the allocator who reads them now, or it would
-                # hand their memory to that stream's next build while this stream's kernels may still be reading
-                for t in self.tensors():
-                    t.record_stream(cur)
-                self._seen_by.add(cur.cuda_stream)
         if self.z is None:
             x0 = SparseTensor(x.F, x.C, x.s)
             x0.cmaps, x0.kmaps = self.x0.cmaps, self.x0.kmaps
@@ -129,6 +102,20 @@ class Geometry:
         return x0, z
 
 
+# per device: the second stream and the geometries whose tables the consumer stream may still be reading.  Module
+# state, not prefetcher state: the caching allocator keeps one pool per stream (a new stream per prefetcher would
+# start from an empty pool every time), and the tables of a prefetcher that went away still have readers.
+_STATE = {}
+
+
+def _state(device):
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _STATE:
+        _STATE[key] = {'stream': torch.cuda.Stream(device=device, priority=-1), 'held': []}
+    return _STATE[key]
+
+
 class GeometryPrefetcher:
     """Builds geometries on a second stream of `device`:
 
@@ -138,18 +125,37 @@ class GeometryPrefetcher:
             g = pf.submit(next_coords)        # next batch's tables, built beside that step on the GPU
 
     submit() returns when the tables' sizes are known to the host (it waits for ITS stream only).  `coords` must
-    be valid on submission (resident, or pass the event after which they are as `ready=`)."""
+    be valid on submission (resident, or pass the event after which they are as `ready=`).
+
+    Memory.  The tables are allocated on the second stream and read by the consumer's stream, so their memory
+    must not return to the second stream's pool while a consumer kernel may still read it.  Instead of marking
+    each of the ~150 tensors for the allocator (record_stream: an event per tensor and step, and -- measured --
+    blocks that cannot be re-used in time, so the pool kept growing by hipMalloc), the prefetcher keeps every
+    geometry alive itself: at the SECOND submit() after a geometry's own it records one event on the consumer
+    stream, and lets go of the geometry once that event has passed.  The contract that makes this safe: whatever
+    consumes a geometry -- forward AND backward pass -- is queued before the second submit() after its own (the
+    loop above queues it before the first); a geometry handed to a forward pass later than that is refused.  The
+    stream that is current when submit() is called is taken to be the consumer's."""
 
     def __init__(self, model, device=None):
         self.model = model
         if device is None:
             device = next(model.parameters()).device
-        self.device = device
-        self.stream = torch.cuda.Stream(device=device, priority=-1)
+        self.device = torch.device(device)
+        self._st = _state(self.device)
+        self.stream = self._st['stream']
 
     def submit(self, coords, grad=None, ready=None):
         if grad is None:
             grad = self.model.training and torch.is_grad_enabled()
+        fence = None
+        for h in self._st['held']:
+            h[0]._age += 1
+            if h[0]._age == 2:
+                if fence is None:
+                    fence = torch.cuda.current_stream(self.device).record_event()
+                h[1] = fence
+        self._st['held'] = [h for h in self._st['held'] if h[1] is None or not h[1].query()]
         with torch.cuda.stream(self.stream):
             if ready is not None:
                 self.stream.wait_event(ready)
@@ -157,4 +163,5 @@ class GeometryPrefetcher:
             g = Geometry.build(self.model, coords, grad)
             g.ready = self.stream.record_event()
             g._stream = self.stream
+        self._st['held'].append([g, None])
         return g

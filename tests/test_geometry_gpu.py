@@ -128,3 +128,27 @@ def test_prefetched_geometry_inference_step_is_bitwise():
             g = pf.submit(frames[i + 1][0])
         for a, b in zip(want[i], got):
             assert torch.equal(a, b)
+
+
+def test_a_stale_prefetched_geometry_is_refused():
+    """The prefetcher lets go of a geometry's memory after the second submit that follows its own: handing it to a
+    forward pass after that must fail loudly, not read tables that another build may be writing."""
+    from lidal_amd import SparseTensor
+    from lidal_amd.network import GeometryPrefetcher
+    torch.manual_seed(0)
+    model = _models()['minkunet'](19).to(DEV).eval()
+    (f0, c0, _), (f1, c1, _) = _batches(2)
+    pf = GeometryPrefetcher(model)
+    g0 = pf.submit(c0)
+    g1 = pf.submit(c1)
+    with torch.no_grad():
+        x = SparseTensor(f0, c0)
+        x.geometry = g0
+        model(x)                        # one newer submission: fine
+        pf.submit(c1)
+        with pytest.raises(RuntimeError, match='stale'):
+            model(x)
+        x = SparseTensor(f1, c1)
+        x.geometry = g1
+        model(x)
+    torch.cuda.synchronize()

@@ -27,6 +27,54 @@ __device__ __forceinline__ void st4(__bf16* p, float4 v) {
   *reinterpret_cast<bf16x4_t*>(p) = o;
 }
 
+// VEC consecutive row elements as f32: one 16-byte access for 4 f32 or 8 bf16, 8 bytes for 4 bf16, scalar otherwise
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* p, float (&a)[VEC]) {
+  if constexpr (VEC == 4) { float4 v = ld4(p); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+  else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[v] = p[v];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void ldv(const __bf16* p, float (&a)[VEC]) {
+  if constexpr (VEC == 8) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned q[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      a[2 * v] = __uint_as_float(q[v] << 16);
+      a[2 * v + 1] = __uint_as_float(q[v] & 0xFFFF0000u);
+    }
+  } else if constexpr (VEC == 4) { float4 v = ld4(p); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+  else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[v] = (float)p[v];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&a)[VEC]) {
+  if constexpr (VEC == 4) st4(p, make_float4(a[0], a[1], a[2], a[3]));
+  else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) p[v] = a[v];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(__bf16* p, const float (&a)[VEC]) {
+  if constexpr (VEC == 8) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+    bf16x8_t o;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) o[v] = (__bf16)a[v];
+    *reinterpret_cast<bf16x8_t*>(p) = o;
+  } else if constexpr (VEC == 4) st4(p, make_float4(a[0], a[1], a[2], a[3]));
+  else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) p[v] = (__bf16)a[v];
+  }
+}
+
 __global__ void __launch_bounds__(256) count_kernel(const int* __restrict__ idx, int64_t n,
                                                     int* __restrict__ out, int64_t m) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -78,26 +126,23 @@ __global__ void __launch_bounds__(256) voxelize_bwd_kernel(const T* __restrict__
   int64_t i = t / cv;
   int j = (int)(t - i * cv) * VEC;
   int pos = idx[i];
-  T* dst = gin + i * c + j;
   const bool dead = pos < 0 || pos >= m || counts[pos] == 0;
   const float div = dead ? 1.f : (float)counts[pos];
-  const T* src = gout + (int64_t)(dead ? 0 : pos) * c + j;
-  if constexpr (VEC == 4) {
-    float4 x = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(src);
-    x = make_float4(x.x / div, x.y / div, x.z / div, x.w / div);
-    if (res != nullptr) {
-      // the quotient is rounded to T first, as the stand-alone result would be, then the sum
-      const float4 r = ld4(res + i * c + j);
-      x = make_float4((float)(T)x.x + r.x, (float)(T)x.y + r.y, (float)(T)x.z + r.z, (float)(T)x.w + r.w);
-    }
-    st4(dst, x);
-  } else {
+  float x[VEC], r[VEC];
+  if (dead) {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      T q = dead ? (T)0.f : (T)((float)src[v] / div);
-      dst[v] = res != nullptr ? (T)((float)q + (float)res[i * c + j + v]) : q;
-    }
+    for (int v = 0; v < VEC; ++v) x[v] = 0.f;
+  } else {
+    ldv<VEC>(gout + (int64_t)pos * c + j, x);
   }
+  if (res != nullptr) ldv<VEC>(res + i * c + j, r);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    x[v] = x[v] / div;
+    // the quotient is rounded to T first, as the stand-alone result would be, then the sum
+    if (res != nullptr) x[v] = (float)(T)x[v] + r[v];
+  }
+  stv<VEC>(gin + i * c + j, x);
 }
 
 // 64 bytes of zeros: corners without a voxel or with an exactly zero weight read from here, so the
@@ -120,27 +165,30 @@ __global__ void __launch_bounds__(256) devoxelize_fwd_kernel(const T* __restrict
   float acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-  if constexpr (VEC == 4) {
+  if constexpr (VEC >= 4) {
     // the point's 8 indices and weights as four 16-byte loads, then 8 row loads in flight
     const int4 p0 = *reinterpret_cast<const int4*>(idx + i * 8), p1 = *reinterpret_cast<const int4*>(idx + i * 8 + 4);
     const float4 w0 = *reinterpret_cast<const float4*>(w + i * 8), w1 = *reinterpret_cast<const float4*>(w + i * 8 + 4);
     const int pos[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
     const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-    float4 x[8];
+    float x[8][VEC];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       // exact zeros: points on a cell face/corner (all of stride 1) -- skipped as upstream's sum
       // would add 0 * row (finite rows; the reference never holds inf/nan features here)
       const bool live = pos[k] >= 0 && pos[k] < m && wk[k] != 0.f;
       const T* src = live ? feat + (int64_t)pos[k] * c + j : reinterpret_cast<const T*>(g_zero_row);
-      x[k] = ld4(src);
+      ldv<VEC>(src, x[k]);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const bool live = pos[k] >= 0 && pos[k] < m && wk[k] != 0.f;
-      if (live) { acc[0] += wk[k] * x[k].x; acc[1] += wk[k] * x[k].y; acc[2] += wk[k] * x[k].z; acc[3] += wk[k] * x[k].w; }
+      if (live) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += wk[k] * x[k][v];
+      }
     }
-    st4(out + i * c + j, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    stv<VEC>(out + i * c + j, acc);
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -266,58 +314,60 @@ __global__ void __launch_bounds__(256) inv_segptr_kernel(const unsigned* __restr
 // out[v][:] = sum_{j in list(v)} scale(j) * src[row(j)][:]
 //   voxelize:   row = e,      scale = 1 / counts[v]
 //   devox bwd:  row = e >> 3, scale = w[e]
-// One wave per voxel; LPR lanes cover a row with float4 each, the 64/LPR lane groups take list
-// elements round-robin (4 independent row loads in flight per lane), fixed xor-tree at the end.
-// Wave-level body: lanes 0..LPR-1 return sum_{j in [beg, end)} scale(j) * src[row(j)][4l .. 4l+3]
-// (every lane group takes list elements round-robin, fixed xor-tree at the end).
-template <typename T, int LPR, bool DEVOX>
-__device__ __forceinline__ float4 segment_wave_sum(const T* __restrict__ src,
-                                                   const int* __restrict__ order,
-                                                   const float* __restrict__ w, int64_t beg,
-                                                   int64_t end, float inv, int c, int lane) {
+// Wave-level body: LPR lanes cover a row with VEC elements (16 bytes: 4 f32 / 8 bf16) each, the 64/LPR lane
+// groups take list elements round-robin (4 independent row loads in flight per lane), fixed xor-tree at the end:
+// lanes 0..LPR-1 end with sum_{j in [beg, end)} scale(j) * src[row(j)][VEC l .. VEC l + VEC - 1].
+template <typename T, int LPR, int VEC, bool DEVOX>
+__device__ __forceinline__ void segment_wave_sum(const T* __restrict__ src, const int* __restrict__ order,
+                                                 const float* __restrict__ w, int64_t beg, int64_t end,
+                                                 float inv, int c, int lane, float (&acc)[VEC]) {
   constexpr int RPW = 64 / LPR;
   const int l = lane % LPR, grp = lane / LPR;
-  const bool act = 4 * l < c;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool act = VEC * l < c;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+  auto add = [&](const float (&x)[VEC], float sc) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] += DEVOX ? sc * x[q] : x[q] / inv;
+  };
   int64_t j = beg + grp;
   for (; j + 3 * RPW < end; j += 4 * RPW) {
-    int e[4]; float sc[4]; float4 x[4];
+    int e[4]; float sc[4]; float x[4][VEC];
 #pragma unroll
     for (int u = 0; u < 4; ++u) e[u] = order[j + u * RPW];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t row = DEVOX ? (e[u] >> 3) : e[u];
       sc[u] = DEVOX ? w[e[u]] : 1.f;
-      x[u] = act ? ld4(src + row * c + 4 * l) : make_float4(0, 0, 0, 0);
+      if (act) ldv<VEC>(src + row * c + VEC * l, x[u]);
+      else {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) x[u][q] = 0.f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (DEVOX) { acc.x += sc[u] * x[u].x; acc.y += sc[u] * x[u].y; acc.z += sc[u] * x[u].z; acc.w += sc[u] * x[u].w; }
-      else { acc.x += x[u].x / inv; acc.y += x[u].y / inv; acc.z += x[u].z / inv; acc.w += x[u].w / inv; }
-    }
+    for (int u = 0; u < 4; ++u) add(x[u], sc[u]);
   }
   for (; j < end; j += RPW) {
     const int e = order[j];
     const int64_t row = DEVOX ? (e >> 3) : e;
-    const float sc = DEVOX ? w[e] : 1.f;
-    float4 x = act ? ld4(src + row * c + 4 * l) : make_float4(0, 0, 0, 0);
-    if (DEVOX) { acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w; }
-    else { acc.x += x.x / inv; acc.y += x.y / inv; acc.z += x.z / inv; acc.w += x.w / inv; }
+    float x[VEC];
+    if (act) ldv<VEC>(src + row * c + VEC * l, x);
+    else {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) x[q] = 0.f;
+    }
+    add(x, DEVOX ? w[e] : 1.f);
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
-    acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
-    acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
   }
-  return acc;
 }
 
-// out[v][:] = sum_{j in list(v)} scale(j) * src[row(j)][:]
-//   voxelize:   row = e,      scale = 1 / counts[v]
-//   devox bwd:  row = e >> 3, scale = w[e]
-// One wave per voxel (the fine levels: a handful of contributors per voxel); LPR lanes cover a
-// row with 4 channels each, 4 independent row loads in flight per lane.
-template <typename T, int LPR, bool DEVOX>
+// One wave per voxel (tens of contributors per voxel).
+template <typename T, int LPR, int VEC, bool DEVOX>
 __global__ void __launch_bounds__(256) segment_sum_kernel(const T* __restrict__ src,
                                                           const int* __restrict__ order,
                                                           const int64_t* __restrict__ seg_ptr,
@@ -331,15 +381,16 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(const T* __restrict__ 
   const int l = lane % LPR, grp = lane / LPR;
   float inv = 1.f;
   if (!DEVOX) { int cv = counts[v]; inv = cv > 0 ? (float)cv : 1.f; }
-  float4 acc = segment_wave_sum<T, LPR, DEVOX>(src, order, w, seg_ptr[v], seg_ptr[v + 1], inv, c, lane);
-  if (grp == 0 && 4 * l < c) st4(out + v * c + 4 * l, acc);
+  float acc[VEC];
+  segment_wave_sum<T, LPR, VEC, DEVOX>(src, order, w, seg_ptr[v], seg_ptr[v + 1], inv, c, lane, acc);
+  if (grp == 0 && VEC * l < c) stv<VEC>(out + v * c + VEC * l, acc);
 }
 
 // The coarse levels (hundreds of contributors per voxel, few voxels): `parts` workgroups per
 // voxel, each wave sums a contiguous 1/(4*parts) of the list, the 4 waves are folded through LDS
 // in wave order; with parts == 1 the result is final, otherwise it lands in an f32 partial row
 // (v * parts + part) that segment_fold_kernel adds up in part order.  No atomics anywhere.
-template <typename T, int LPR, bool DEVOX>
+template <typename T, int LPR, int VEC, bool DEVOX>
 __global__ void __launch_bounds__(256) segment_sum_wg_kernel(const T* __restrict__ src,
                                                              const int* __restrict__ order,
                                                              const int64_t* __restrict__ seg_ptr,
@@ -348,7 +399,7 @@ __global__ void __launch_bounds__(256) segment_sum_wg_kernel(const T* __restrict
                                                              T* __restrict__ out,
                                                              float* __restrict__ partial,
                                                              int64_t m, int c, int parts) {
-  __shared__ float4 red[4][64];
+  __shared__ float red[4][LPR][VEC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t v = blockIdx.x / parts;
   const int part = (int)(blockIdx.x - v * parts);
@@ -361,19 +412,70 @@ __global__ void __launch_bounds__(256) segment_sum_wg_kernel(const T* __restrict
   if (b1 > end) b1 = end;
   float inv = 1.f;
   if (!DEVOX) { int cv = counts[v]; inv = cv > 0 ? (float)cv : 1.f; }
-  float4 acc = segment_wave_sum<T, LPR, DEVOX>(src, order, w, b0, b1, inv, c, lane);
-  if (grp == 0) red[wave][l] = acc;
+  float acc[VEC];
+  segment_wave_sum<T, LPR, VEC, DEVOX>(src, order, w, b0, b1, inv, c, lane, acc);
+  if (grp == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) red[wave][l][q] = acc[q];
+  }
   __syncthreads();
-  if (wave == 0 && grp == 0 && 4 * l < c) {
-    float4 a = red[0][l];
+  if (wave == 0 && grp == 0 && VEC * l < c) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = red[0][l][q];
 #pragma unroll
     for (int u = 1; u < 4; ++u) {
-      float4 b = red[u][l];
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) acc[q] += red[u][l][q];
     }
-    if (parts == 1) st4(out + v * c + 4 * l, a);
-    else st4(partial + ((int64_t)v * parts + part) * c + 4 * l, a);
+    if (parts == 1) stv<VEC>(out + v * c + VEC * l, acc);
+    else stv<VEC>(partial + ((int64_t)v * parts + part) * c + VEC * l, acc);
   }
+}
+
+// The fine levels (stride 1: every voxel has ONE contributor, the trilinear weights of integer points being
+// (1, 0, .. 0); stride 2-4: a handful): a wave per voxel leaves most lanes idle and costs a wave launch per
+// 64-256 bytes.  Here LPR lanes own a voxel -- 16 bytes of the row each -- and walk its list in order, four rows
+// in flight; 64 / LPR voxels per wave.
+template <typename T, int LPR, int VEC, bool DEVOX>
+__global__ void __launch_bounds__(256) segment_sum_group_kernel(const T* __restrict__ src,
+                                                                const int* __restrict__ order,
+                                                                const int64_t* __restrict__ seg_ptr,
+                                                                const float* __restrict__ w,
+                                                                const int* __restrict__ counts,
+                                                                T* __restrict__ out, int64_t m, int c) {
+  const int l = threadIdx.x % LPR;
+  const int64_t v = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  if (v >= m || l * VEC >= c) return;
+  const int64_t beg = seg_ptr[v], end = seg_ptr[v + 1];
+  float inv = 1.f;
+  if (!DEVOX) { int cv = counts[v]; inv = cv > 0 ? (float)cv : 1.f; }
+  float acc[VEC];
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) acc[u] = 0.f;
+  auto add = [&](const float (&x)[VEC], float sc) {
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) acc[u] += DEVOX ? sc * x[u] : x[u] / inv;
+  };
+  int64_t j = beg;
+  for (; j + 3 < end; j += 4) {
+    int e[4]; float sc[4]; float x[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = order[j + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sc[u] = DEVOX ? w[e[u]] : 1.f;
+      ldv<VEC>(src + (int64_t)(DEVOX ? (e[u] >> 3) : e[u]) * c + l * VEC, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add(x[u], sc[u]);
+  }
+  for (; j < end; ++j) {
+    const int e = order[j];
+    float x[VEC];
+    ldv<VEC>(src + (int64_t)(DEVOX ? (e >> 3) : e) * c + l * VEC, x);
+    add(x, DEVOX ? w[e] : 1.f);
+  }
+  stv<VEC>(out + v * c + l * VEC, acc);
 }
 
 template <typename T>
@@ -393,53 +495,84 @@ __global__ void __launch_bounds__(256) segment_fold_kernel(const float* __restri
   st4(out + v * c + j, a);
 }
 
-// A wave sums RPW = 64 / LPR rows per step, 4 steps in flight: lists that would keep one wave
-// busy for ~5 such rounds or more (on average; measured crossover on the SPVCNN levels: 15 rows
-// per lane group still favours one wave per voxel, 23 the workgroup kernel) go to the workgroup
-// kernel, with enough workgroups per voxel that a wave sees ~4 rounds.  0 = wave-per-voxel kernel.
-static inline int segment_parts(int64_t n_entries, int64_t m, int c) {
+// Which form: a wave sums RPW = 64 / LPR rows per step, 4 steps in flight.  One wave per voxel (0) while the lists
+// are short -- or while there are voxels enough to fill the chip with waves; the workgroup kernel otherwise, with
+// enough workgroups per voxel that a wave sees ~4 rounds.  Measured on the bench batch (bf16, us; parts 0 / 1 / 2 / 4):
+//   voxelize forward, stride 16, 16 730 voxels x 24 rows of 256:     158 /  87 /  95 / 136
+//   devoxelize backward, stride 16, 16 730 voxels x ~170 rows of 256: 371 / 196 / 177 / 188
+//   devoxelize backward, stride 4, 105 363 voxels x ~20 rows of 128:   81 / 149 / 282 / 520
+static inline int row_lanes(int c, int vec) {        // lanes per row: the power of two that covers c / vec
+  const int need = (c + vec - 1) / vec;
+  int lpr = 4;
+  while (lpr < need) lpr <<= 1;
+  return lpr > 64 ? 64 : lpr;
+}
+static inline int segment_vec(int c, int esz) { return (esz == 2 && c % 8 == 0) ? 8 : 4; }
+static inline int segment_parts(int64_t n_entries, int64_t m, int c, int esz) {
   if (m <= 0) return 0;
-  const int lpr = c <= 32 ? 8 : c <= 64 ? 16 : c <= 128 ? 32 : 64;
+  const int lpr = row_lanes(c, segment_vec(c, esz));
   const int64_t rpw = 64 / lpr, avg = n_entries / m;
-  if (avg < 20 * rpw) return 0;
+  if (avg < 20 * rpw && (m >= 65536 || avg < 8 * rpw)) return 0;
   const int64_t waves = (avg + 16 * rpw - 1) / (16 * rpw);
   int parts = 1;
   while (parts < 4 && (int64_t)parts * 4 < waves) parts <<= 1;
   return parts;
 }
 
+// lists of at most this many entries per voxel (on average; an upper bound for devoxelize backward, whose zero
+// weights are not in the lists) take the lane-group kernel
+constexpr int64_t GROUP_MAX_AVG = 12;
+
+template <typename T, int VEC, bool DEVOX>
+void launch_group(const T* src, const int* order, const int64_t* seg_ptr, const float* w, const int* counts,
+                  T* out, int64_t m, int c, hipStream_t s) {
+  const int need = (c + VEC - 1) / VEC;           // lanes per row
+#define LIDAL_GROUP(LPR)                                                                               \
+  segment_sum_group_kernel<T, LPR, VEC, DEVOX><<<(unsigned)cdiv(m, 256 / LPR), 256, 0, s>>>(src, order, seg_ptr, w, \
+                                                                                          counts, out, m, c)
+  if (need <= 4) LIDAL_GROUP(4);
+  else if (need <= 8) LIDAL_GROUP(8);
+  else if (need <= 16) LIDAL_GROUP(16);
+  else if (need <= 32) LIDAL_GROUP(32);
+  else LIDAL_GROUP(64);
+#undef LIDAL_GROUP
+}
+
 template <typename T, bool DEVOX>
 int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, const float* w,
                        const int* counts, T* out, int64_t m, int c, int64_t n_entries, void* ws,
                        int64_t ws_bytes, hipStream_t s) {
-  const int parts = segment_parts(n_entries, m, c);
-  if (parts == 0) {
-    unsigned grid = (unsigned)cdiv(m, 4);
-    if (c <= 32)
-      segment_sum_kernel<T, 8, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
-    else if (c <= 64)
-      segment_sum_kernel<T, 16, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
-    else if (c <= 128)
-      segment_sum_kernel<T, 32, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
-    else
-      segment_sum_kernel<T, 64, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, m, c);
-    LIDAL_CHECK_LAUNCH("segment_sum");
+  if (m > 0 && n_entries / m <= GROUP_MAX_AVG && c <= 512) {
+    if (sizeof(T) == 2 && c % 8 == 0) launch_group<T, 8, DEVOX>(src, order, seg_ptr, w, counts, out, m, c, s);
+    else launch_group<T, 4, DEVOX>(src, order, seg_ptr, w, counts, out, m, c, s);
+    LIDAL_CHECK_LAUNCH("segment_sum_group");
     return 0;
   }
-  LIDAL_REQUIRE(c <= 256, "segment_sum: at most 256 channels");
+  const int parts = segment_parts(n_entries, m, c, (int)sizeof(T));
+  LIDAL_REQUIRE(c <= 512, "segment_sum: at most 512 channels");
   float* partial = (float*)ws;
   if (parts > 1)
     LIDAL_REQUIRE(ws != nullptr && ws_bytes >= (int64_t)m * parts * c * 4, "segment_sum workspace too small");
-  unsigned grid = (unsigned)(m * parts);
-  if (c <= 32)
-    segment_sum_wg_kernel<T, 8, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, partial, m, c, parts);
-  else if (c <= 64)
-    segment_sum_wg_kernel<T, 16, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, partial, m, c, parts);
-  else if (c <= 128)
-    segment_sum_wg_kernel<T, 32, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, partial, m, c, parts);
-  else
-    segment_sum_wg_kernel<T, 64, DEVOX><<<grid, 256, 0, s>>>(src, order, seg_ptr, w, counts, out, partial, m, c, parts);
-  LIDAL_CHECK_LAUNCH("segment_sum_wg");
+  const bool wide = segment_vec(c, (int)sizeof(T)) == 8;
+  const int lpr = row_lanes(c, wide ? 8 : 4);
+#define LIDAL_SEG(LPR, VEC)                                                                              \
+  do {                                                                                                   \
+    if (parts == 0)                                                                                      \
+      segment_sum_kernel<T, LPR, VEC, DEVOX><<<(unsigned)cdiv(m, 4), 256, 0, s>>>(src, order, seg_ptr, w, counts, \
+                                                                                 out, m, c);             \
+    else                                                                                                 \
+      segment_sum_wg_kernel<T, LPR, VEC, DEVOX><<<(unsigned)(m * parts), 256, 0, s>>>(                   \
+          src, order, seg_ptr, w, counts, out, partial, m, c, parts);                                    \
+  } while (0)
+  if (wide) {
+    if (lpr <= 4) LIDAL_SEG(4, 8); else if (lpr == 8) LIDAL_SEG(8, 8); else if (lpr == 16) LIDAL_SEG(16, 8);
+    else if (lpr == 32) LIDAL_SEG(32, 8); else LIDAL_SEG(64, 8);
+  } else {
+    if (lpr <= 8) LIDAL_SEG(8, 4); else if (lpr == 16) LIDAL_SEG(16, 4); else if (lpr == 32) LIDAL_SEG(32, 4);
+    else LIDAL_SEG(64, 4);
+  }
+#undef LIDAL_SEG
+  LIDAL_CHECK_LAUNCH("segment_sum");
   if (parts > 1) {
     segment_fold_kernel<T><<<(unsigned)cdiv(m * (c / 4), 256), 256, 0, s>>>(partial, out, m, c, parts);
     LIDAL_CHECK_LAUNCH("segment_fold");
@@ -462,7 +595,10 @@ int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, c
 
 #define DISPATCH_TVEC(kernel, T, c, total_rows, ...)                                         \
   do {                                                                                       \
-    if ((c) % 4 == 0) {                                                                      \
+    if (sizeof(T) == 2 && (c) % 8 == 0) {     /* 16-byte accesses on bf16 rows */             \
+      int64_t t__ = (total_rows) * ((c) / 8);                                                \
+      kernel<T, 8><<<(unsigned)cdiv(t__, 256), 256, 0, s>>>(__VA_ARGS__);                    \
+    } else if ((c) % 4 == 0) {                                                                      \
       int64_t t__ = (total_rows) * ((c) / 4);                                                \
       kernel<T, 4><<<(unsigned)cdiv(t__, 256), 256, 0, s>>>(__VA_ARGS__);                    \
     } else {                                                                                 \
@@ -608,7 +744,9 @@ extern "C" int lidal_invlist_build(const int32_t* idx, const float* w, int64_t n
 }
 
 extern "C" int64_t lidal_segment_workspace_bytes(int64_t n_entries, int64_t m, int c) {
-  int parts = segment_parts(n_entries, m, c);
+  // (f32 rows never need less than bf16 rows: the split is chosen per element size, the larger one is reported)
+  int parts = segment_parts(n_entries, m, c, 2), parts4 = segment_parts(n_entries, m, c, 4);
+  if (parts4 > parts) parts = parts4;
   return parts > 1 ? (int64_t)m * parts * c * 4 : 0;
 }
 

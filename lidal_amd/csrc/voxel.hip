@@ -519,9 +519,12 @@ static inline int segment_parts(int64_t n_entries, int64_t m, int c, int esz) {
   return parts;
 }
 
-// lists of at most this many entries per voxel (on average; an upper bound for devoxelize backward, whose zero
-// weights are not in the lists) take the lane-group kernel
-constexpr int64_t GROUP_MAX_AVG = 12;
+// Lists of at most this many entries per voxel (on average; an upper bound for devoxelize backward, whose zero
+// weights are not in the lists) take the lane-group kernel -- on levels with many voxels.  A lane group walks its
+// list alone, so the launch is as long as the longest list: at stride 16 (16 730 voxels, 24 points on average but
+// hundreds in the cells next to the sensor) it took 241 us against the workgroup kernel's 106; at stride 4
+// (105 363 voxels, <= 30 entries) 62 against the wave kernel's 89.
+constexpr int64_t GROUP_MAX_AVG = 32, GROUP_MAX_AVG_FEW = 12, GROUP_MANY_VOXELS = 65536;
 
 template <typename T, int VEC, bool DEVOX>
 void launch_group(const T* src, const int* order, const int64_t* seg_ptr, const float* w, const int* counts,
@@ -542,7 +545,7 @@ template <typename T, bool DEVOX>
 int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, const float* w,
                        const int* counts, T* out, int64_t m, int c, int64_t n_entries, void* ws,
                        int64_t ws_bytes, hipStream_t s) {
-  if (m > 0 && n_entries / m <= GROUP_MAX_AVG && c <= 512) {
+  if (m > 0 && n_entries / m <= (m >= GROUP_MANY_VOXELS ? GROUP_MAX_AVG : GROUP_MAX_AVG_FEW) && c <= 512) {
     if (sizeof(T) == 2 && c % 8 == 0) launch_group<T, 8, DEVOX>(src, order, seg_ptr, w, counts, out, m, c, s);
     else launch_group<T, 4, DEVOX>(src, order, seg_ptr, w, counts, out, m, c, s);
     LIDAL_CHECK_LAUNCH("segment_sum_group");

@@ -15,6 +15,13 @@ OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'liblidal_amd.so')
 SOURCES = ['error.cpp', 'hash.hip', 'kmap.hip', 'voxel.hip', 'conv.hip', 'conv_img.hip', 'wgrad_dma.hip', 'sort.hip', 'bn.hip', 'elementwise.hip', 'score.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
+# No packed-f32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in this library.  Measured on MI355X
+# (scripts/exp/victim/, profiles/README.md "A packed multiply beside v_mfma_f32_16x16x32_bf16"): while a wave of ANOTHER
+# kernel executes v_mfma_f32_16x16x32_bf16 on the same SIMD, v_pk_mul_f32 / v_pk_fma_f32 whose low result takes the HIGH
+# half of a source (op_sel:[0,1]) sporadically return a wrong low result.  Kernels of one stream never overlap, but the
+# coordinate tables may be built on a second stream beside the bf16 convolutions (network/geometry.py): hipcc had put
+# exactly that form into ti_weights_kernel, and ~1 % of the points got a zero trilinear weight.
+NO_PACKED_F32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 # units that restate numpy arithmetic (separately rounded products and sums): no fma contraction
 NO_CONTRACT = {'score.hip', 'kmap.hip'}
 
@@ -31,7 +38,7 @@ def _compile(src):
     deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'common.h'),
             os.path.join(HERE, '..', 'include', 'lidal_amd.h'), os.path.abspath(__file__)]
     if _stale(obj, deps):
-        cmd = ['hipcc'] + FLAGS + (['-ffp-contract=off'] if src in NO_CONTRACT else []) + \
+        cmd = ['hipcc'] + FLAGS + NO_PACKED_F32 + (['-ffp-contract=off'] if src in NO_CONTRACT else []) + \
               (['-x', 'hip'] if src.endswith('.cpp') else []) + \
               ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -262,9 +262,13 @@ __global__ void __launch_bounds__(256) ti_weights_kernel(const float* __restrict
   float s3 = scale * scale * scale;
   float sum = 0.f;
   int id[8];
+  // all eight corner indices first (eight loads in flight), through 32-bit element offsets
+  int64_t qs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) qs[k] = idx[(unsigned)k * (unsigned)n + (unsigned)i];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    int64_t q = idx[(int64_t)k * n + i];
+    const int64_t q = qs[k];
     id[k] = (int)q;
     if (scale != 1.f) ww[k] /= s3;
     if (q == -1) ww[k] = 0.f;

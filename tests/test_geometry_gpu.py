@@ -152,3 +152,66 @@ def test_a_stale_prefetched_geometry_is_refused():
         x.geometry = g1
         model(x)
     torch.cuda.synchronize()
+
+
+def _tables(g):
+    """(path, tensor) of every table of a geometry; the rule lists up to their true length."""
+    out, seen = [], set()
+
+    def walk(obj, path):
+        if obj is None or isinstance(obj, (int, float, str, bool, torch.dtype, torch.device)) or id(obj) in seen:
+            return
+        seen.add(id(obj))
+        if isinstance(obj, torch.Tensor):
+            out.append((path, obj))
+            for name in ('_lidal_invlist', '_lidal_i32'):
+                walk(getattr(obj, name, None), path + '.' + name)
+        elif isinstance(obj, dict):
+            for k in sorted(obj, key=str):
+                walk(obj[k], '%s[%s]' % (path, k))
+        elif isinstance(obj, (list, tuple)):
+            for i, v in enumerate(obj):
+                walk(v, '%s[%d]' % (path, i))
+        elif type(obj).__name__ == 'KernelMap':
+            for k in sorted(vars(obj)):
+                if k == '_rules' and obj._rules is not None:
+                    nbmaps, nbsizes, koff = obj._rules
+                    walk(nbmaps[:int(koff[-1])], path + '._rules.nbmaps')       # capacity rows beyond `total`: never written
+                    walk(nbsizes, path + '._rules.nbsizes')
+                    walk(koff, path + '._rules.koff')
+                else:
+                    walk(vars(obj)[k], path + '.' + k)
+        elif hasattr(obj, '__dict__') and type(obj).__module__.startswith('lidal_amd'):
+            for k in sorted(vars(obj)):
+                walk(vars(obj)[k], path + '.' + k)
+    walk({'x0': g.x0, 'z': g.z}, 'g')
+    return out
+
+
+def test_tables_built_beside_the_bf16_convolutions_are_the_tables_built_alone():
+    """The second stream runs beside the main stream's kernels.  On MI355X a wave executing v_mfma_f32_16x16x32_bf16
+    disturbs packed-f32 instructions with op_sel of OTHER waves on its SIMD (profiles/README.md, round 3): hipcc had put
+    one into ti_weights_kernel and ~1 % of the trilinear weights came out with a zero corner.  The library is built
+    without packed f32 instructions; here every table of a geometry built beside a training step must equal, bit for
+    bit, the table built on an idle GPU."""
+    from lidal_amd.network import Geometry, GeometryPrefetcher
+    from lidal_amd.train_step import train_step
+    torch.manual_seed(0)
+    model = _models()['spvcnn'](19).to(DEV).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    (f_big, c_big, l_big), = _batches(1, points=60000, frames=4)
+    (_, c_small, _), = _batches(1, points=30000, frames=2)
+    ref = Geometry.build(model, c_small, grad=True)
+    torch.cuda.synchronize()
+    want = [(p, t.clone()) for p, t in _tables(ref)]
+    pf = GeometryPrefetcher(model)
+    g_big = pf.submit(c_big)
+    for it in range(25):
+        train_step(model, opt, f_big, c_big, l_big, autocast=True, geometry=g_big)       # bf16 convolutions on the main stream
+        g = pf.submit(c_small, grad=True)                                                   # ... and the tables beside them
+        g_big = pf.submit(c_big)
+        torch.cuda.synchronize()
+        got = _tables(g)
+        assert [p for p, _ in got] == [p for p, _ in want]
+        for (p, a), (_, b) in zip(want, got):
+            assert torch.equal(a, b), (it, p, int((a != b).sum()) if a.shape == b.shape else (a.shape, b.shape))

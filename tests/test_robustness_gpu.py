@@ -1,0 +1,49 @@
+"""Properties of the whole step that no single-operator test sees."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('name,autocast', [('spvcnn', True), ('minkunet', False)])
+def test_results_do_not_depend_on_the_contents_of_fresh_buffers(name, autocast, monkeypatch):
+    """Every buffer this package allocates comes from torch.empty / empty_like: with those filled with 0x00, 0xFF
+    (NaN as floats, -1 as integers) or 0x7F bytes, three training steps must give the same losses and the same
+    parameters bit for bit -- no kernel reads memory that neither it nor a kernel before it wrote (tile statistics of
+    the last partial tile, capacity tails of the rule lists, padded weight images, workspaces of the sorts ...)."""
+    from lidal_amd import synth
+    from lidal_amd.network import SPVCNN, MinkUNet
+    from lidal_amd.train_step import train_step
+    pattern = [0]
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+
+    def fill(t):
+        if t.is_cuda and t.numel() and t.is_contiguous():
+            t.view(-1).view(torch.uint8).fill_(pattern[0])
+        return t
+    monkeypatch.setattr(torch, 'empty', lambda *a, **k: fill(real_empty(*a, **k)))
+    monkeypatch.setattr(torch, 'empty_like', lambda *a, **k: fill(real_empty_like(*a, **k)))
+    batches = []
+    for i in range(2):
+        b = synth.make_train_batch(n_frames=2, n_points=9000 + 1500 * i, seed=100 + i)
+        batches.append(tuple(torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b', 'labels_v_b')))
+    torch.manual_seed(0)
+    base = (SPVCNN if name == 'spvcnn' else MinkUNet)(19).to(DEV).train()
+
+    def run(p):
+        pattern[0] = p
+        model = copy.deepcopy(base)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        torch.manual_seed(1)
+        losses = []
+        for s in range(3):
+            f, c, lab = batches[s % 2]
+            loss, _ = train_step(model, opt, f, c, lab, autocast=autocast)
+            losses.append(float(loss))
+        return losses, torch.cat([q.detach().flatten().float() for q in model.parameters()])
+    (l0, p0), (l1, p1), (l2, p2) = run(0x00), run(0xFF), run(0x7F)
+    assert l0 == l1 == l2, (l0, l1, l2)
+    assert torch.equal(p0, p1) and torch.equal(p0, p2)

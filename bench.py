@@ -268,7 +268,7 @@ def roofline_conv(args, coords, dev, reps=20):
             pass
     return {'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
-            'kernel': 'conv_apply_img_kernel (k3 s1 96->96, %s)' % args.dtype,
+            'kernel': 'conv_lean_kernel<%s,6,192,8> through lidal_conv_apply_image (k3 s1 96->96)' % args.dtype,
             'launch_us': round(sec * 1e6, 2), 'rows': n, 'rules': m,
             'algorithmic_bytes_per_launch': int(algo_bytes),
             'mfma': {'achieved': round(flops / sec / 1e12, 3), 'peak': MFMA_PEAK_TFLOPS[args.dtype],

@@ -430,10 +430,10 @@ class Branch:
         """The trunk waits for the branch; its tensors (allocated on the branch's stream) are now read on the trunk's."""
         self.main.wait_event(self.event)
         for t in self.inputs:
-            if torch.is_tensor(t) and t.is_cuda:
+            if t is not None:
                 t.record_stream(self.side)
         for t in outputs:
-            if torch.is_tensor(t) and t.is_cuda:
+            if torch.is_tensor(t):
                 t.record_stream(self.main)
 
 

@@ -390,53 +390,6 @@ class _Beside:
             self.main.wait_event(self.event)
 
 
-# ---- a branch of a block beside its trunk ------------------------------------------------------
-# The shortcut of a residual block (1x1x1 conv + BatchNorm, network/utils.py:159-166) is independent of the block's
-# trunk until the final sum.  Inside the block's single autograd node (network/blocks.py: _Residual) it can run on
-# its own stream beside the trunk, forward and backward; the node joins the streams before it returns, so nothing
-# outside the node ever overlaps with the branch.  LIDAL_BRANCH_STREAM=0 keeps everything on one stream.
-BRANCH = os.environ.get('LIDAL_BRANCH_STREAM', '1') != '0'
-_branch_streams = {}
-
-
-def branch_stream(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    if key not in _branch_streams:
-        _branch_streams[key] = torch.cuda.Stream(device=device)
-    return _branch_streams[key]
-
-
-class Branch:
-    """`with Branch(device, inputs) as br:` ... launches of the branch ...; later `br.join(outputs)` on the trunk's
-    stream.  The branch starts behind everything queued on the trunk's stream so far."""
-
-    def __init__(self, device, inputs):
-        self.main = torch.cuda.current_stream(device)
-        self.side = branch_stream(device)
-        self.inputs = inputs
-
-    def __enter__(self):
-        self.side.wait_stream(self.main)
-        self.ctx = torch.cuda.stream(self.side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        self.event = self.side.record_event()
-        self.ctx.__exit__(*exc)
-        return False
-
-    def join(self, outputs):
-        """The trunk waits for the branch; its tensors (allocated on the branch's stream) are now read on the trunk's."""
-        self.main.wait_event(self.event)
-        for t in self.inputs:
-            if t is not None:
-                t.record_stream(self.side)
-        for t in outputs:
-            if torch.is_tensor(t):
-                t.record_stream(self.main)
-
-
 def dtype_code(dt):
     if dt == torch.float32:
         return F32

@@ -36,13 +36,6 @@ FUSE_BLOCKS = _os.environ.get('LIDAL_FUSE_BLOCKS', '1') != '0'
 BN_SUMS = _os.environ.get('LIDAL_BN_SUMS', '1') != '0'       # BatchNorm backward sums from the data-gradient launches
 
 
-def _branch_ok(t):
-    """The shortcut on its own stream?  Only where no weight gradient is itself put beside the current stream
-    (backend.beside: f32), i.e. in the bf16 mode."""
-    return (B.BRANCH and t.is_cuda and torch.is_autocast_enabled()
-            and not B.overlap_wgrad(torch.bfloat16 if torch.get_autocast_dtype('cuda') == torch.bfloat16 else torch.float32))
-
-
 def _bn_args(bn):
     return (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
 
@@ -83,29 +76,19 @@ class _Residual(torch.autograd.Function):
     def forward(ctx, feats, k1, g1, b1, k2, g2, b2, ks, gs, bs, kmap, bn1, bn2, bns, stats):
         # `stats` = (s1, s2, ss): does the kernel of conv1 / conv2 / the shortcut leave its BatchNorm's statistics?
         need_gx = ctx.needs_input_grad[0]
-        ctx.shortcut = ks is not None
         xc, x1, ctx.img1 = _C._forward(feats, k1, kmap, False, None, need_gx, stats[0])
-        # the shortcut beside the rest of the trunk (backend.Branch), on its own stream.  (Behind conv1: the first
-        # request of a step to the weight-image bank rebuilds every stale image on the stream it arrives on.)
-        branch = None
-        if ctx.shortcut and _branch_ok(feats):
-            branch = B.Branch(feats.device, (feats,))
-            branch.__enter__()
+        y1, mean1, inv1, x1, w1, c1 = _N.train_forward(x1, g1, b1, bn1.running_mean, bn1.running_var, bn1.momentum,
+                                                       bn1.eps, True, bn1.num_batches_tracked,
+                                                       getattr(x1, '_lidal_bn_stats', None))
+        _, x2, ctx.img2 = _C._forward(y1, k2, kmap, False, None, True, stats[1])
+        ctx.shortcut = ks is not None
         if ctx.shortcut:
             xs_in, ctx.wcs, ctx.pads, xs, ctx.imgs = _D._forward(feats, ks, None, False, None, need_gx, stats[2])
             res, means, invs, xs, ws, cs = _N.train_forward(xs, gs, bs, bns.running_mean, bns.running_var,
                                                             bns.momentum, bns.eps, False, bns.num_batches_tracked,
                                                             getattr(xs, '_lidal_bn_stats', None))
-            if branch is not None:
-                branch.__exit__(None, None, None)
         else:
             res = feats
-        y1, mean1, inv1, x1, w1, c1 = _N.train_forward(x1, g1, b1, bn1.running_mean, bn1.running_var, bn1.momentum,
-                                                       bn1.eps, True, bn1.num_batches_tracked,
-                                                       getattr(x1, '_lidal_bn_stats', None))
-        _, x2, ctx.img2 = _C._forward(y1, k2, kmap, False, None, True, stats[1])
-        if branch is not None:
-            branch.join((xs_in, xs, res, means, invs, ws, cs, ctx.wcs, ctx.imgs))
         out, mean2, inv2, x2, w2, c2 = _N.train_forward(x2, g2, b2, bn2.running_mean, bn2.running_var, bn2.momentum,
                                                         bn2.eps, False, bn2.num_batches_tracked,
                                                         getattr(x2, '_lidal_bn_stats', None), res, True)
@@ -125,17 +108,11 @@ class _Residual(torch.autograd.Function):
         # relu(bn2 + shortcut): the gradient where the output is positive, for both summands
         dx2, gg2, gb2, gm = _N.train_backward(x2, w2, c2, mean2, inv2, False, g, True, out)
         gks = ggs = gbs = None
-        branch = None
         if ctx.shortcut:
             xs_in, ks, xs, ws, cs, means, invs = t[15:]
-            if _branch_ok(gm):
-                branch = B.Branch(gm.device, (gm, xs, xs_in))
-                branch.__enter__()
             dxs, ggs, gbs, _ = _N.train_backward(xs, ws, cs, means, invs, False, gm, True)
             g_skip, gks, _ = _D.rows_backward(xs_in, ks, ctx.wcs, ctx.imgs, ctx.pads, False, dxs, need_gx,
                                               ctx.needs_input_grad[7], False)
-            if branch is not None:
-                branch.__exit__(None, None, None)
         else:
             g_skip = gm
         # conv2's data gradient IS the output gradient of bn1 (y1 has no other consumer): the launch that writes it
@@ -144,8 +121,6 @@ class _Residual(torch.autograd.Function):
                                     (x1, mean1, inv1, w1, c1, True) if BN_SUMS else None)
         dx1, gg1, gb1, _ = _N.train_backward(x1, w1, c1, mean1, inv1, True, dy1, True, None,
                                              getattr(dy1, '_lidal_bnb_sums', None))
-        if branch is not None:
-            branch.join((dxs, g_skip, gks, ggs, gbs))
         gx, gk1 = _C.conv_backward(xc, k1, ctx.kmap, False, ctx.img1, dx1, g_skip if need_gx else None, need_gx,
                                    ctx.needs_input_grad[1])
         return gx, gk1, gg1, gb1, gk2, gg2, gb2, gks, ggs, gbs, None, None, None, None, None

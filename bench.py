@@ -289,7 +289,7 @@ FAMILY_OF = {
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
     'lidal_downsample': 'kernel_maps', 'lidal_kmap_build': 'kernel_maps', 'lidal_kmap_invert': 'kernel_maps',
-    'lidal_kmap_order': 'kernel_maps', 'lidal_floor_coords': 'kernel_maps', 'lidal_kmap_order_batch': 'kernel_maps',
+    'lidal_kmap_order': 'kernel_maps', 'lidal_floor_coords': 'kernel_maps', 'lidal_revoxelize_coords': 'kernel_maps', 'lidal_kmap_order_batch': 'kernel_maps',
     'lidal_downsample_pyramid': 'kernel_maps', 'lidal_kmap_from_rules': 'kernel_maps',
     'lidal_count': 'point_voxel', 'lidal_voxelize_fwd': 'point_voxel', 'lidal_voxelize_bwd': 'point_voxel',
     'lidal_voxelize_fwd_1to1': 'point_voxel',
@@ -400,6 +400,8 @@ def family_table(step, coords, dtype_name, step_ms):
             by = (16 + 8) * a[1]
         elif name == 'lidal_floor_coords':
             by = (16 + 16) * a[1]
+        elif name == 'lidal_revoxelize_coords':
+            by = (16 + 16 + 16) * a[1]
         elif name == 'lidal_kernel_hash':
             by = 16 * a[1] + 8 * a[3] * a[1]
         elif name == 'lidal_hash_table_build':

@@ -38,6 +38,11 @@ int lidal_hash(const int32_t* coords, int64_t n, int64_t* out, void* stream);
 /* network/utils.py:44-47,72-75: float rows (x, y, z, b) [n,4] -> int32 rows (floor(x/s) s, floor(y/s) s,
  * floor(z/s) s, (int)b), the voxel a point falls into at tensor stride s, in one pass. */
 int lidal_floor_coords(const float* coords, int64_t n, int stride, int32_t* out, void* stream);
+/* network/utils.py:14-17 (initial_voxelize): float rows (x, y, z, b) [n,4] -> out_float = ((x * init_res) / after_res,
+ * ..., b) and out_floor = (int)floor(out_float), both [n,4]; IEEE f32 multiply and divide, as torch computes
+ * `(C[:, :3] * init_res) / after_res` -- one pass instead of mul, div, cat, floor, int. */
+int lidal_revoxelize_coords(const float* coords, int64_t n, float init_res, float after_res, float* out_float,
+                            int32_t* out_floor, void* stream);
 /* replaces backend.kernel_hash_cuda  (F.sphash(coords, offsets): network/utils.py:70-74).
  * offsets i32 [k,3]; out i64 [k,n], hash of (xyz + offset_k, batch). */
 int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t* offsets, int k,

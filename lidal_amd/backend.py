@@ -31,6 +31,7 @@ SIGNATURES = {
     'lidal_last_error': (ctypes.c_char_p, []),
     'lidal_version': (_i32, []),
     'lidal_floor_coords': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'lidal_revoxelize_coords': (_i32, [_vp, _i64, _f32, _f32, _vp, _vp, _vp]),
     'lidal_hash': (_i32, [_vp, _i64, _vp, _vp]),
     'lidal_kernel_hash': (_i32, [_vp, _i64, _vp, _i32, _vp, _vp]),
     'lidal_hash_table_bytes': (_i64, [_i64]),

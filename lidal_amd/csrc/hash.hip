@@ -95,6 +95,31 @@ extern "C" int lidal_floor_coords(const float* coords, int64_t n, int stride, in
   return 0;
 }
 
+// network/utils.py:14-17: new = ((x, y, z) * init_res) / after_res, batch column kept; floored = floor(new).int().
+// Separately rounded multiply and divide (torch computes two element-wise passes).
+__global__ void __launch_bounds__(256) revoxelize_coords_kernel(const float4* __restrict__ c, int64_t n, float init_res,
+                                                                float after_res, float4* __restrict__ out_float,
+                                                                int4* __restrict__ out_floor) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = c[i];
+  const float x = __fdiv_rn(__fmul_rn(v.x, init_res), after_res);
+  const float y = __fdiv_rn(__fmul_rn(v.y, init_res), after_res);
+  const float z = __fdiv_rn(__fmul_rn(v.z, init_res), after_res);
+  out_float[i] = make_float4(x, y, z, v.w);
+  out_floor[i] = make_int4((int)floorf(x), (int)floorf(y), (int)floorf(z), (int)floorf(v.w));
+}
+
+extern "C" int lidal_revoxelize_coords(const float* coords, int64_t n, float init_res, float after_res, float* out_float,
+                                       int32_t* out_floor, void* stream) {
+  if (n == 0) return 0;
+  LIDAL_REQUIRE(after_res != 0.f, "revoxelize_coords: after_res is zero");
+  revoxelize_coords_kernel<<<grid_for(n, 256, 1 << 30), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)coords, n, init_res, after_res, (float4*)out_float, (int4*)out_floor);
+  LIDAL_CHECK_LAUNCH("lidal_revoxelize_coords");
+  return 0;
+}
+
 extern "C" int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t* offsets, int k,
                                  int64_t* out, void* stream) {
   if (n == 0 || k == 0) return 0;

@@ -32,10 +32,20 @@ def initial_tables(z, init_res, after_res):
     features."""
     # true IEEE division: torch's GPU `tensor / python_scalar` multiplies by the reciprocal, which
     # leaves voxel centres 1e-7 off the integers the CPU path produces (SURVEY.md H8)
-    res = torch.full((), after_res, dtype=z.C.dtype, device=z.C.device)
-    new_float_coord = torch.cat([(z.C[:, :3] * init_res) / res, z.C[:, -1].view(-1, 1)], 1)
-    floored = torch.floor(new_float_coord)
-    pc_hash = F.sphash(floored.int())
+    c = z.C
+    if c.is_cuda and c.dtype == torch.float32 and c.dim() == 2 and c.shape[1] == 4 and c.is_contiguous():
+        # one pass (csrc/hash.hip), the same separately rounded multiply and divide
+        new_float_coord = torch.empty_like(c)
+        floored_int = torch.empty(c.shape, dtype=torch.int32, device=c.device)
+        B.check(B.lib().lidal_revoxelize_coords(B.ptr(c), c.shape[0], float(init_res), float(after_res),
+                                                B.ptr(new_float_coord), B.ptr(floored_int), B.stream()), 'revoxelize_coords')
+        floored = None
+    else:
+        res = torch.full((), after_res, dtype=z.C.dtype, device=z.C.device)
+        new_float_coord = torch.cat([(z.C[:, :3] * init_res) / res, z.C[:, -1].view(-1, 1)], 1)
+        floored = torch.floor(new_float_coord)
+        floored_int = floored.int()
+    pc_hash = F.sphash(floored_int)
     sparse_hash = F.unique_sorted(pc_hash)
     idx_query = F.sphashquery(pc_hash, sparse_hash)
     counts = F.spcount(idx_query.int(), len(sparse_hash))
@@ -43,7 +53,13 @@ def initial_tables(z, init_res, after_res):
         # as many voxels as points (the reference's datasets voxelise the scans at this very resolution,
         # sk_dataset.py:160-171): the index is a permutation and every count is 1 -- F.spvoxelize then moves rows
         idx_query._lidal_one_to_one = True
-    inserted_coords = torch.round(F.spvoxelize(floored, idx_query, counts)).int()
+    if getattr(idx_query, '_lidal_one_to_one', False):
+        # mean of ONE row, rounded: the row itself -- the int rows permuted bit for bit (the 1:1 kernel copies 16-byte rows)
+        inserted_coords = F.spvoxelize(floored_int.view(torch.float32), idx_query, counts).view(torch.int32)
+    else:
+        if floored is None:
+            floored = floored_int.float()
+        inserted_coords = torch.round(F.spvoxelize(floored, idx_query, counts)).int()
     z.additional_features['idx_query'][1] = idx_query
     z.additional_features['counts'][1] = counts
     z.additional_features['init_coords'] = inserted_coords     # the rows that index refers to

@@ -69,7 +69,7 @@ def test_prefetched_geometry_holds_every_table_the_forward_asks_for(name):
     builders = ('lidal_kmap_build', 'lidal_kmap_build_batch', 'lidal_kmap_order', 'lidal_kmap_order_batch',
                 'lidal_hash_table_build', 'lidal_hash_table_query', 'lidal_invlist_build', 'lidal_ti_weights',
                 'lidal_downsample_pyramid', 'lidal_downsample', 'lidal_unique_sorted_i64', 'lidal_kmap_invert',
-                'lidal_hash', 'lidal_kernel_hash', 'lidal_count', 'lidal_floor_coords')
+                'lidal_hash', 'lidal_kernel_hash', 'lidal_count', 'lidal_floor_coords', 'lidal_revoxelize_coords')
     assert all(b in B.SIGNATURES for b in builders)
     seen = []
     B.set_call_timer(lambda name, args, e0, e1: seen.append(name))

@@ -1112,3 +1112,23 @@ def test_one_point_per_voxel_voxelize_is_the_mean_form(dtype, c):
         outs.append((y.detach(), xi.grad))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[1][0][idx], x)
+
+
+def test_revoxelize_coords_is_the_reference_expression_bit_for_bit():
+    """lidal_revoxelize_coords == `cat([(C[:, :3] * init_res) / after_res, C[:, -1:]], 1)` and its floor().int()
+    (network/utils.py:14-17) computed by torch on the CPU: separately rounded IEEE multiply and divide."""
+    from lidal_amd import backend as B
+    g = torch.Generator().manual_seed(21)
+    n = 200001
+    c = torch.cat([torch.randint(0, 8192, (n, 3), generator=g).float(), torch.randint(0, 5, (n, 1), generator=g).float()], 1)
+    c[:1000, :3] += torch.rand(1000, 3, generator=g)            # not only integers
+    for init_res, after_res in ((0.05, 0.05), (0.05, 0.1), (1.0, 3.0), (0.3, 0.05)):
+        res = torch.full((), after_res, dtype=torch.float32)
+        want = torch.cat([(c[:, :3] * init_res) / res, c[:, -1].view(-1, 1)], 1)
+        cg = c.to(DEV)
+        got_f = torch.empty_like(cg)
+        got_i = torch.empty(cg.shape, dtype=torch.int32, device=DEV)
+        B.check(B.lib().lidal_revoxelize_coords(B.ptr(cg), n, init_res, after_res, B.ptr(got_f), B.ptr(got_i), B.stream()),
+                'revoxelize_coords')
+        assert torch.equal(got_f.cpu(), want), (init_res, after_res)
+        assert torch.equal(got_i.cpu(), torch.floor(want).int())

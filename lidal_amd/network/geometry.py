@@ -47,7 +47,15 @@ class Geometry:
     def build(model, coords, grad=None):
         """Build on the current stream.  grad: also what only a backward pass reads (default: model.training and
         gradients enabled)."""
-        from .unet import SPVCNN
+        from .unet import SPVCNN, MinkUNet
+        from .. import backend as B
+        if not isinstance(model, (SPVCNN, MinkUNet)):
+            raise TypeError('lidal_amd: Geometry.build knows the coordinate work of SPVCNN and MinkUNet, not of %s'
+                            % type(model).__name__)
+        B.require_gpu(coords)
+        if coords.dtype != torch.int32 or coords.dim() != 2 or coords.shape[1] != 4 or not coords.is_contiguous():
+            raise ValueError('lidal_amd: Geometry.build wants contiguous int32 coordinates [N, 4] = (x, y, z, batch), got '
+                             '%s %s' % (coords.dtype, tuple(coords.shape)))
         if grad is None:
             grad = model.training and torch.is_grad_enabled()
         g = Geometry(coords, type(model).__name__, bool(grad))

@@ -280,3 +280,16 @@ def test_reference_model_files_construct_over_lidal_amd(tmp_path):
     r = subprocess.run([sys.executable, '-c', _REF_DROPIN % {'root': ROOT, 'tmp': str(tmp_path)}],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'DROPIN_OK' in r.stdout, r.stderr[-3000:]
+
+
+def test_geometry_build_refuses_cpu_tensors_and_foreign_networks():
+    """The coordinate tables are a GPU product like everything else: no CPU path, loud errors."""
+    import pytest
+    import torch
+    from lidal_amd.network import Geometry, MinkUNet
+    model = MinkUNet(19)
+    coords = torch.zeros((10, 4), dtype=torch.int32)
+    with pytest.raises(RuntimeError, match='GPU only'):
+        Geometry.build(model, coords)
+    with pytest.raises(TypeError, match='SPVCNN and MinkUNet'):
+        Geometry.build(torch.nn.Linear(4, 4), coords)

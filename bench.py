@@ -676,8 +676,9 @@ def run_variants(args, batch, dev, inline=None):
     # the reference draws a new augmentation per iteration (sk_dataset.py:143-171): 8 differently
     # augmented batches of the same scans, voxelised on the GPU outside the timed region, one per step
     fresh = make_fresh_batches(args.frames, args.points, 7122, dev, 8)
+    # (two untimed cycles through the 8 batches: the allocator's pools then hold blocks of every size the cycle asks for)
     var['fresh_coords'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, fresh,
-                                                   max(args.steps, 16), 8, ddp=False))
+                                                   max(args.steps, 16), 16, ddp=False))
     var['fresh_coords']['voxels_per_batch'] = [int(b[0].shape[0]) for b in fresh]
     del fresh
     other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'

@@ -15,6 +15,8 @@ from exp_img import timeit  # noqa: E402
 
 SHAPES = [(396662, 32), (396662, 96), (226000, 32), (226000, 64), (105000, 64), (105000, 128), (43000, 128),
           (43000, 256), (16000, 256)]
+if os.environ.get('BN_SHAPES'):         # e.g. BN_SHAPES=396662x96 for a counter pass over one shape
+    SHAPES = [tuple(int(v) for v in t.split('x')) for t in os.environ['BN_SHAPES'].split(',')]
 
 
 def main():

@@ -549,14 +549,16 @@ template <typename T, bool DEVOX>
 int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, const float* w,
                        const int* counts, T* out, int64_t m, int c, int64_t n_entries, void* ws,
                        int64_t ws_bytes, hipStream_t s) {
-  if (m > 0 && n_entries / m <= (m >= GROUP_MANY_VOXELS ? GROUP_MAX_AVG : GROUP_MAX_AVG_FEW) && c <= 512) {
+  // a row is covered by at most 64 lanes of VEC channels each
+  LIDAL_REQUIRE(c <= 64 * segment_vec(c, (int)sizeof(T)), "segment_sum: at most %d channels per row for this element type",
+                64 * segment_vec(c, (int)sizeof(T)));
+  if (m > 0 && n_entries / m <= (m >= GROUP_MANY_VOXELS ? GROUP_MAX_AVG : GROUP_MAX_AVG_FEW)) {
     if (sizeof(T) == 2 && c % 8 == 0) launch_group<T, 8, DEVOX>(src, order, seg_ptr, w, counts, out, m, c, s);
     else launch_group<T, 4, DEVOX>(src, order, seg_ptr, w, counts, out, m, c, s);
     LIDAL_CHECK_LAUNCH("segment_sum_group");
     return 0;
   }
   const int parts = segment_parts(n_entries, m, c, (int)sizeof(T));
-  LIDAL_REQUIRE(c <= 512, "segment_sum: at most 512 channels");
   float* partial = (float*)ws;
   if (parts > 1)
     LIDAL_REQUIRE(ws != nullptr && ws_bytes >= (int64_t)m * parts * c * 4, "segment_sum workspace too small");

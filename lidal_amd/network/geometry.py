@@ -173,3 +173,12 @@ class GeometryPrefetcher:
             g._stream = self.stream
         self._st['held'].append([g, None])
         return g
+
+    def drain(self):
+        """Let go of every geometry this device's prefetchers still hold (the last two of a loop stay alive until
+        the next submit): waits for the consumer stream, after which nothing can still be reading them."""
+        torch.cuda.current_stream(self.device).synchronize()
+        self.stream.synchronize()
+        for h in self._st['held']:
+            h[0]._age = max(h[0]._age, 2)           # a drained geometry must not be handed to a forward pass any more
+        self._st['held'] = []

@@ -151,6 +151,11 @@ def test_a_stale_prefetched_geometry_is_refused():
         x = SparseTensor(f1, c1)
         x.geometry = g1
         model(x)
+        g2 = pf.submit(c1)
+        pf.drain()                      # end of a loop: nothing is held any more, and what was is refused
+        with pytest.raises(RuntimeError, match='stale'):
+            x.geometry = g2
+            model(x)
     torch.cuda.synchronize()
 
 

@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace lidal
 
 extern "C" const char* lidal_last_error(void) { return lidal::g_err; }
-extern "C" int lidal_version(void) { return 122; }   // 1.21: weight images + LDS-DMA conv (conv_img.hip), image pairs
+extern "C" int lidal_version(void) { return 130; }   // 1.30 (round 3): own radix sort, batched maps / orders / pyramid, BatchNorm backward sums, 16-byte point<->voxel kernels, lidal_revoxelize_coords; built without packed f32 instructions

@@ -209,6 +209,118 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
             'loss': float(loss.item())}
 
 
+def host_calls(model_name, dtype, batch, dev, prefetch=True):
+    """What one step costs the host in calls: autograd Function nodes behind the loss, library calls made from Python
+    (backend.HITS: every ctypes call into liblidal_amd.so, the table build of the next step included) and the
+    operations executed inside launch plans -- counted on one step after a warm-up one."""
+    from lidal_amd import backend as B
+    from lidal_amd.network import SPVCNN, MinkUNet, GeometryPrefetcher, plan
+    from lidal_amd.train_step import forward_backward
+    torch.manual_seed(7122)
+    model = (SPVCNN if model_name == 'spvcnn' else MinkUNet)(19).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), fused=True)
+    coords, feats, labels = batch
+    pf = GeometryPrefetcher(model, device=dev) if prefetch else None
+    g = pf.submit(coords) if prefetch else None
+    out = {}
+    for it in range(2):
+        opt.zero_grad()
+        B.HITS.clear()
+        ops0 = plan.COUNTERS['ops']
+        loss, _ = forward_backward(model, feats, coords, labels, autocast=dtype == 'bf16', geometry=g)
+        nodes, seen, stack = 0, set(), [loss.grad_fn]
+        while stack:
+            fn = stack.pop()
+            if fn is None or fn in seen:
+                continue
+            seen.add(fn)
+            nodes += hasattr(fn, '_forward_cls')
+            stack.extend(f for f, _ in fn.next_functions)
+        opt.step()
+        fb = sum(B.HITS.values())
+        if prefetch:
+            g = pf.submit(coords)
+        out = {'autograd_function_nodes': int(nodes), 'library_calls_from_python': int(sum(B.HITS.values())),
+               'of_which_forward_backward': int(fb), 'of_which_plan_run': int(B.HITS.get('plan_run', 0)),
+               'operations_inside_plans': int(plan.COUNTERS['ops'] - ops0), 'launch_plan': bool(plan.ENABLED)}
+    if pf is not None:
+        pf.drain()
+    torch.cuda.synchronize()
+    return out
+
+
+def bench_fresh_stream(dev, model_name, dtype, frames, points, steps, warmup=3, seed=7122):
+    """The reference's real input stream inside the timed loop: EVERY step trains on a batch that did not exist before
+    -- a new augmentation drawn on the host per scan (dataset/sk_dataset.py:143-147,156), the scans voxelised and
+    collated on the GPU (lidal_voxelize_points, data.collate: sk_dataset.py:148-171,188-242) and the batch's coordinate
+    tables built, all on the second stream beside the step before (GeometryPrefetcher.submit_batch) -- what the
+    reference's DataLoader workers do ahead of the GPU (dataset/sk_dataloader.py:21,53).  No batch repeats; nothing is
+    pre-warmed beyond `warmup` steps.  Reports ms/step, the allocator's reserved bytes and device allocations."""
+    from lidal_amd import data, synth
+    from lidal_amd.network import SPVCNN, MinkUNet, GeometryPrefetcher
+    from lidal_amd.train_step import train_step
+    rng = np.random.default_rng(seed)
+    world = synth.make_world(seed)
+    scans = []
+    for f in range(frames):
+        pts, inten = synth.raycast_scan(world, (10.0 + 7.0 * f, 0.0), rng, n_points=points)
+        labels_p = rng.integers(0, 19, size=pts.shape[0]).astype(np.int64)
+        labels_p[rng.random(pts.shape[0]) < 0.1] = 255
+        scans.append((torch.from_numpy(pts).to(dev), torch.from_numpy(inten).to(dev), torch.from_numpy(labels_p).to(dev)))
+    torch.manual_seed(7122)
+    model = (SPVCNN if model_name == 'spvcnn' else MinkUNet)(19).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), fused=True)
+    aug = np.random.RandomState(seed)
+    pf = GeometryPrefetcher(model, device=dev)
+
+    def make():
+        samples = []
+        for pts, inten, labels_p in scans:
+            trans_m, rnd = data.draw_augmentation(aug)
+            coords_v, feats_v, uniq, _ = data.voxelize_scan(pts, inten, trans_m, rnd)
+            samples.append({'coords_v': coords_v, 'feats_v': feats_v, 'labels_v': labels_p[uniq]})
+        b = data.collate(samples)
+        return {k: (v.contiguous() if v is not None else None) for k, v in b.items()}
+
+    autocast = dtype == 'bf16'
+    g = pf.submit_batch(make)
+    sizes, reserved, segs = [], [], []
+
+    def step():
+        nonlocal g
+        b = g.payload
+        sizes.append(int(b['coords_v_b'].shape[0]))
+        out = train_step(model, opt, b['feats_v_b'], b['coords_v_b'], b['labels_v_b'], autocast=autocast, geometry=g)
+        g = pf.submit_batch(make)
+        reserved.append(int(torch.cuda.memory_reserved(dev)))
+        segs.append(int(torch.cuda.memory_stats(dev).get('segment.all.allocated', 0)))
+        return out
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    first = len(sizes)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pf.drain()
+    assert np.isfinite(loss.item())
+    timed = sizes[first:]
+    ms = dt / steps * 1e3
+    return {'ms_per_step': round(ms, 3), 'steps': steps, 'warmup': warmup,
+            'voxels_per_step': int(np.mean(timed)), 'voxels_per_s': round(float(np.sum(timed)) / dt, 1),
+            'distinct_batches': len(set(sizes)), 'voxels_min_max': [int(min(timed)), int(max(timed))],
+            'reserved_MB': {'after_warmup': reserved[first - 1] >> 20, 'step_10': reserved[min(first + 9, len(reserved) - 1)] >> 20,
+                            'end': reserved[-1] >> 20},
+            'device_allocations': {'after_warmup': segs[first - 1], 'step_10': segs[min(first + 9, len(segs) - 1)],
+                                   'end': segs[-1]},
+            'loss': round(float(loss.item()), 4),
+            'what': 'every step: new augmentation per scan (host draws), GPU voxelisation + collate + coordinate tables of '
+                    'the NEXT batch on the second stream; no batch repeats (sk_dataset.py:143-171, sk_dataloader.py:21,53)'}
+
+
 def variant_line(res):
     ms = res['seconds'] / res['steps'] * 1e3
     return {'ms_per_step': round(ms, 3), 'voxels_per_step': int(res['voxels']),
@@ -334,14 +446,23 @@ def family_table(step, coords, dtype_name, step_ms):
                 rules[km.sizes[1]] = km.total
     torch.cuda.synchronize()
     calls = []
+    # the profiled step runs operator by operator (LIDAL_PLAN=0's path): the launch plan issues the same kernels with
+    # the same arguments (tests/test_plan_gpu.py: bitwise), but as words of one call that no per-call timer can bracket
+    from lidal_amd.network import plan as _plan
+    planned = _plan.ENABLED
+    _plan.ENABLED = False
     B.set_call_timer(lambda name, a, e0, e1: calls.append((name, [_val(v) for v in a], e0, e1)))
     try:
+        step()                              # (registers what the per-operator path keeps to itself)
+        torch.cuda.synchronize()
+        del calls[:]
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
         prof_ms = (time.perf_counter() - t0) * 1e3
     finally:
         B.set_call_timer(None)
+        _plan.ENABLED = planned
     fam = {}
     fwd_convs = []                      # (k, n_in, n_out, ci, co, b) of the forward convolutions, for `compulsory`
     in_backward = False
@@ -473,7 +594,9 @@ def family_table(step, coords, dtype_name, step_ms):
     out['other'] = {'ms': round(max(step_ms - tot_ms, 0.0), 3),
                     'what': 'torch ops between library calls (Adam, cat, dropout, casts) + gaps'}
     out['whole_step'] = {
-        'ms': round(step_ms, 3), 'profiled_step_ms': round(prof_ms, 3), 'algorithmic_GB': round(tot_by / 1e9, 3),
+        'ms': round(step_ms, 3), 'profiled_step_ms': round(prof_ms, 3),
+        'profiled_on': 'the per-operator path (LIDAL_PLAN=0): the kernels of the planned step, one call each',
+        'algorithmic_GB': round(tot_by / 1e9, 3),
         'GFLOP': round(tot_fl / 1e9, 1),
         'hbm_frac': round(tot_by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         'pricing_check': pricing_check,
@@ -673,6 +796,7 @@ def run_variants(args, batch, dev, inline=None):
     one = make_batch(1, args.points, 7122, dev)
     var['single_scan'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, one,
                                                   max(args.steps, 10), 3, ddp=False))
+    var['single_scan']['host'] = guarded(host_calls, args.model, args.dtype, one, dev)
     # the reference draws a new augmentation per iteration (sk_dataset.py:143-171): 8 differently
     # augmented batches of the same scans, voxelised on the GPU outside the timed region, one per step
     fresh = make_fresh_batches(args.frames, args.points, 7122, dev, 8)
@@ -681,6 +805,8 @@ def run_variants(args, batch, dev, inline=None):
                                                    max(args.steps, 16), 16, ddp=False))
     var['fresh_coords']['voxels_per_batch'] = [int(b[0].shape[0]) for b in fresh]
     del fresh
+    var['fresh_stream'] = guarded(bench_fresh_stream, dev, args.model, args.dtype, args.frames, args.points,
+                                  max(2 * args.steps, 40))
     other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
     var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
                                                 max(3, args.steps // 2), 2, ddp=False))
@@ -736,6 +862,8 @@ def main():
                    'voxels_per_step_per_gpu': int(voxels / world),
                    'parallelism': 'dp%d' % world, 'loss': round(res['loss'], 4)},
     }
+    if solo:
+        line['host'] = guarded(host_calls, args.model, args.dtype, batch, dev)
     if rank == 0 and not args.no_roofline:
         line['roofline'] = guarded(roofline_conv, args, batch[0], dev)
         log('roofline', line['roofline'])

@@ -77,7 +77,7 @@ int lidal_downsample(const int32_t* coords, int64_t n, int sx, int sy, int sz, i
  * `coords` (tensor stride s) -- the same rows in the same (batch, x, y, z) order as l chained lidal_downsample
  * calls, from ONE sort and with ONE set of row counts to read back.  out i32 [levels * n, 4] capacity; level l
  * occupies rows [starts[l-1], starts[l]); starts_dev i64 [levels + 1].  0 <= x, y, z < 65536, 0 <= batch < 8192,
- * levels <= 4. */
+ * levels <= 4; a row outside these ranges is reported as starts[levels] = -1 (no other output is valid then). */
 int64_t lidal_downsample_pyramid_workspace_bytes(int64_t n, int levels);
 int lidal_downsample_pyramid(const int32_t* coords, int64_t n, int sx, int sy, int sz, int levels, int32_t* out,
                              int64_t* starts_dev, void* ws, int64_t ws_bytes, void* stream);
@@ -427,6 +427,51 @@ int lidal_interframe_score(const double* q_pts, const float* q_prob, int64_t p, 
 int lidal_supervoxel_reduce(const double* interd, const float* intere, const double* pts,
                             const int64_t* sv_ptr, const int64_t* sv_idx, int s, float* sv_interd,
                             float* sv_intere, float* sv_center, void* stream);
+
+/* ---- row-wise helpers of a planned step (what torch glue did between the operators) ------------- */
+/* dst[r][0 : row_bytes) = src[r][0 : row_bytes), dst[r][row_bytes : row_bytes + zero_bytes) = 0 for r < rows; rows
+ * `src_pitch` / `dst_pitch` bytes apart.  One call per summand is torchsparse.cat (operators.py; network/spvcnn.py:
+ * 133,137,145,149) into the channel slices of one buffer; with zero_bytes > 0 it is the channel padding of the
+ * 19-class logit gradient; with src_pitch > row_bytes the contiguous copy of a channel slice. */
+int lidal_copy2d(const void* src, int64_t src_pitch, void* dst, int64_t dst_pitch, int64_t rows, int64_t row_bytes,
+                 int64_t zero_bytes, void* stream);
+/* out[r][:c] = a[r][:c] + b[r][:c] (f32 sum rounded once to `dtype`): the sum autograd forms where a tensor has
+ * two consumers (an encoder level feeds the next stage AND a decoder concatenation: network/spvcnn.py:120-128);
+ * row strides in elements (a channel slice of a concatenation's gradient is read in place); c and the strides
+ * whole 16-byte vectors. */
+int lidal_add2d(const void* a, int64_t a_stride, const void* b, int64_t b_stride, void* out, int64_t out_stride,
+                int64_t rows, int c, int dtype, void* stream);
+/* dst f32 [cols][rows] = transpose of src f32 [rows][cols] (rows `src_stride` floats apart): nn.Linear keeps its
+ * weight as [Cout][Cin], the weight-gradient kernel produces x^T g = [Cin][Cout]. */
+int lidal_transpose_f32(const float* src, int64_t src_stride, float* dst, int rows, int cols, void* stream);
+/* dst bf16 [n][c_dst] = src f32 [n][c_src] rounded to nearest even, channels c_src.. zero-filled (the 4-channel
+ * input of the stem under bf16: 8-byte rows padded to one 16-byte vector, nn/functional/conv.py _pad_channels). */
+int lidal_cast_rows_bf16(const float* src, int c_src, void* dst, int c_dst, int64_t n, void* stream);
+
+/* ---- launch plans ----------------------------------------------------------------------------------- */
+/* A whole forward or backward pass as ONE call: `words` is a stream of n_ops operations,
+ *     kind | flags << 16,  arg 0, arg 1, ...
+ * one 64-bit word each; an operation of kind LIDAL_OP_X calls lidal_x with the words as its arguments IN THE ORDER
+ * OF ITS PROTOTYPE ABOVE, stream excluded: pointers as addresses, integers as such, float arguments as the bit
+ * pattern of a double (lidal_plan_op_args(kind) words).  The operations are queued on `stream` in order --
+ * exactly the launches the same calls made one by one would queue (train.py:127-140 / prob_inference.py:91-113
+ * issue theirs one Python call at a time); nothing is captured or cached, every call walks the words it is given.
+ * LIDAL_OP_FLAG_SIDE queues an operation on `side_stream` instead (may be NULL if unused), between a
+ * LIDAL_OP_FORK_SIDE (side stream waits for what `stream` holds so far) and a LIDAL_OP_JOIN_SIDE (`stream` waits for
+ * the side stream).  Stops at the first failing operation; lidal_last_error() names its index and kind. */
+enum {
+  LIDAL_OP_CONV_WEIGHT_IMAGE_BATCH = 1, LIDAL_OP_CONV_APPLY_IMAGE = 2, LIDAL_OP_CONV_DGRAD_BN_SUMS = 3,
+  LIDAL_OP_CONV_WGRAD = 4, LIDAL_OP_BN_TRAIN_FWD = 5, LIDAL_OP_BN_TRAIN_FWD_TILES = 6, LIDAL_OP_BN_BWD = 7,
+  LIDAL_OP_BN_BWD_TILES = 8, LIDAL_OP_BN_EVAL_FWD = 9, LIDAL_OP_BN_FOLD = 10, LIDAL_OP_COLSUM = 11,
+  LIDAL_OP_ADD_RELU_FWD = 12, LIDAL_OP_ADD_RELU_BWD = 13, LIDAL_OP_VOXELIZE_FWD_1TO1 = 14,
+  LIDAL_OP_VOXELIZE_FWD_SORTED = 15, LIDAL_OP_VOXELIZE_BWD = 16, LIDAL_OP_DEVOXELIZE_FWD = 17,
+  LIDAL_OP_DEVOXELIZE_BWD_SORTED = 18, LIDAL_OP_CE_FWD = 19, LIDAL_OP_CE_BWD = 20, LIDAL_OP_COPY2D = 21,
+  LIDAL_OP_ADD2D = 22, LIDAL_OP_TRANSPOSE_F32 = 23, LIDAL_OP_CAST_ROWS_BF16 = 24, LIDAL_OP_VIEW_MEAN_SOFTMAX = 25,
+  LIDAL_OP_FORK_SIDE = 26, LIDAL_OP_JOIN_SIDE = 27
+};
+#define LIDAL_OP_FLAG_SIDE 1
+int lidal_plan_op_args(int kind);
+int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_ops, void* stream, void* side_stream);
 
 #ifdef __cplusplus
 }

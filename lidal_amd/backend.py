@@ -115,6 +115,12 @@ SIGNATURES = {
     'lidal_interframe_score': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp,
                                       _vp, _vp, _vp, _i64, _vp]),
     'lidal_supervoxel_reduce': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    'lidal_copy2d': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
+    'lidal_add2d': (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    'lidal_transpose_f32': (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
+    'lidal_cast_rows_bf16': (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
+    'lidal_plan_op_args': (_i32, [_i32]),
+    'lidal_plan_run': (_i32, [_vp, _i64, _i64, _vp, _vp]),
 }
 
 

@@ -629,10 +629,12 @@ extern "C" int lidal_downsample(const int32_t* coords, int64_t n, int sx, int sy
 namespace {
 __global__ void __launch_bounds__(256) pyramid_keys_kernel(const int4* __restrict__ coords, int64_t n, int levels,
                                                            int sx, int sy, int sz,
-                                                           uint64_t* __restrict__ keys) {
+                                                           uint64_t* __restrict__ keys, int* __restrict__ bad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = coords[i];
+  // the key has 16 bits per coordinate and 13 for the batch index: anything else would spill into its neighbours
+  if (((unsigned)c.x | (unsigned)c.y | (unsigned)c.z) >> 16 || (unsigned)c.w >> 13) *bad = 1;
   for (int l = 1; l <= levels; ++l) {
     const int fx = sx << l, fy = sy << l, fz = sz << l;
     const uint64_t x = (uint64_t)((c.x / fx) * fx), y = (uint64_t)((c.y / fy) * fy), z = (uint64_t)((c.z / fz) * fz);
@@ -646,7 +648,8 @@ __global__ void __launch_bounds__(kBlock) pyramid_compact_kernel(const uint64_t*
                                                                  int64_t n, int levels,
                                                                  const int64_t* __restrict__ offsets,
                                                                  int64_t nblocks, int4* __restrict__ out,
-                                                                 int64_t* __restrict__ starts) {
+                                                                 int64_t* __restrict__ starts,
+                                                                 const int* __restrict__ bad) {
   __shared__ int wave_cnt[kBlock / 64];
   const int64_t base = (int64_t)blockIdx.x * kTile;
   int64_t pos = offsets[blockIdx.x];
@@ -668,7 +671,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_compact_kernel(const uint64_t*
     }
     pos += tot;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) starts[levels] = offsets[nblocks];
+  if (blockIdx.x == 0 && threadIdx.x == 0) starts[levels] = *bad ? -1 : offsets[nblocks];
 }
 }  // namespace
 
@@ -681,7 +684,7 @@ extern "C" int64_t lidal_downsample_pyramid_workspace_bytes(int64_t n, int level
 
 // coords i32 [n, 4] at tensor stride (sx, sy, sz); out i32 [levels * n, 4] capacity: level l (1-based: stride
 // 2^l s) occupies rows [starts[l-1], starts[l]); starts_dev i64 [levels + 1].  Requires 0 <= x, y, z < 65536,
-// 0 <= batch < 8192, levels <= 4.
+// 0 <= batch < 8192, levels <= 4; a row outside these ranges makes starts[levels] = -1 (nothing else is valid then).
 extern "C" int lidal_downsample_pyramid(const int32_t* coords, int64_t n, int sx, int sy, int sz, int levels,
                                         int32_t* out, int64_t* starts_dev, void* ws, int64_t ws_bytes,
                                         void* stream) {
@@ -699,7 +702,9 @@ extern "C" int lidal_downsample_pyramid(const int32_t* coords, int64_t n, int sx
   int* counts = (int*)w;            w += align_up(4 * nblocks, 256);
   int64_t* offs = (int64_t*)w;      w += align_up(8 * (nblocks + 1), 256);
   void* tmp = (void*)w;
-  pyramid_keys_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>((const int4*)coords, n, levels, sx, sy, sz, keys);
+  int* bad = (int*)((char*)ws + lidal_downsample_pyramid_workspace_bytes(n, levels) - 256);      // (the slack at the end)
+  LIDAL_HIP(hipMemsetAsync(bad, 0, 4, s));
+  pyramid_keys_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>((const int4*)coords, n, levels, sx, sy, sz, keys, bad);
   LIDAL_CHECK_LAUNCH("pyramid_keys");
   if (int rc = radix_sort(keys, nullptr, sorted, nullptr, q, 8, 63, tmp, radix_sort_ws_bytes(q, 8, false), s)) return rc;
   head_count_kernel<<<(unsigned)nblocks, kBlock, 0, s>>>(sorted, q, counts);
@@ -707,7 +712,7 @@ extern "C" int lidal_downsample_pyramid(const int32_t* coords, int64_t n, int sx
   scan_counts_kernel<<<1, 1024, 0, s>>>(counts, nblocks, offs);
   LIDAL_CHECK_LAUNCH("scan_counts");
   pyramid_compact_kernel<<<(unsigned)nblocks, kBlock, 0, s>>>(sorted, q, n, levels, offs, nblocks, (int4*)out,
-                                                              starts_dev);
+                                                              starts_dev, bad);
   LIDAL_CHECK_LAUNCH("pyramid_compact");
   return 0;
 }

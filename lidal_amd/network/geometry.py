@@ -41,7 +41,9 @@ class Geometry:
         self.z = None                   # SPVCNN: PointTensor without features carrying the point caches
         self.ready = None               # event on the stream the tables were built on (None: the caller's own stream)
         self._stream = None
-        self._age = 0                   # submissions to the same prefetcher stream since this one
+        self._consumer = None           # the stream whose kernels read the tables (fenced by the prefetcher)
+        self.payload = None             # GeometryPrefetcher.submit_batch: the input batch built on the same stream
+        self._age = 0                   # submissions to the same prefetcher since this one
 
     @staticmethod
     def build(model, coords, grad=None):
@@ -78,11 +80,15 @@ class Geometry:
                 x0 = SparseTensor(None, coords, 1)
                 prefetch_kernel_maps(x0, model.MAP_PLAN)
             g.x0 = x0
+        import weakref
+        me = weakref.ref(g)
+        for km in x0.kmaps.values():        # a backward pass meets the geometry through its kernel maps (conv_backward)
+            km._owner = me
         return g
 
-    def enter(self, x, kind):
-        """Called by the model's forward with its input: checks that the tables are x's, makes the current stream
-        wait for them, and returns (x0 with x's features, z or None)."""
+    def admit(self, x, kind):
+        """The checks of enter() without the feature work: the tables are x's, they are still alive, and the current
+        stream waits for the stream that built them.  (What a planned step calls, network/plan.py.)"""
         if kind != self.kind:
             raise RuntimeError('lidal_amd: geometry built for %s handed to %s' % (self.kind, kind))
         c = x.C
@@ -98,6 +104,17 @@ class Geometry:
             cur = torch.cuda.current_stream(c.device)
             if cur != self._stream:
                 cur.wait_event(self.ready)
+            self._consumer = cur                # the prefetcher fences THIS stream before it lets the tables go
+
+    def alive(self):
+        """May a kernel queued NOW still read the tables?  (False once two newer geometries have been submitted to the
+        prefetcher that built this one: the fence that protects the memory has been recorded by then.)"""
+        return self.ready is None or self._age < 2
+
+    def enter(self, x, kind):
+        """Called by the model's forward with its input: checks that the tables are x's, makes the current stream
+        wait for them, and returns (x0 with x's features, z or None)."""
+        self.admit(x, kind)
         if self.z is None:
             x0 = SparseTensor(x.F, x.C, x.s)
             x0.cmaps, x0.kmaps = self.x0.cmaps, self.x0.kmaps
@@ -110,9 +127,9 @@ class Geometry:
         return x0, z
 
 
-# per device: the second stream and the geometries whose tables the consumer stream may still be reading.  Module
-# state, not prefetcher state: the caching allocator keeps one pool per stream (a new stream per prefetcher would
-# start from an empty pool every time), and the tables of a prefetcher that went away still have readers.
+# per device: the second stream (module state, not prefetcher state: the caching allocator keeps one pool per stream, and
+# a new stream per prefetcher would start from an empty pool every time) and the geometries of prefetchers that went
+# away while a consumer stream could still be reading their tables.
 _STATE = {}
 
 
@@ -120,8 +137,12 @@ def _state(device):
     device = torch.device(device)
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _STATE:
-        _STATE[key] = {'stream': torch.cuda.Stream(device=device, priority=-1), 'held': []}
+        _STATE[key] = {'stream': torch.cuda.Stream(device=device, priority=-1), 'orphans': []}
     return _STATE[key]
+
+
+def _reap(st):
+    st['orphans'] = [h for h in st['orphans'] if not h[1].query()]
 
 
 class GeometryPrefetcher:
@@ -139,11 +160,14 @@ class GeometryPrefetcher:
     must not return to the second stream's pool while a consumer kernel may still read it.  Instead of marking
     each of the ~150 tensors for the allocator (record_stream: an event per tensor and step, and -- measured --
     blocks that cannot be re-used in time, so the pool kept growing by hipMalloc), the prefetcher keeps every
-    geometry alive itself: at the SECOND submit() after a geometry's own it records one event on the consumer
-    stream, and lets go of the geometry once that event has passed.  The contract that makes this safe: whatever
-    consumes a geometry -- forward AND backward pass -- is queued before the second submit() after its own (the
-    loop above queues it before the first); a geometry handed to a forward pass later than that is refused.  The
-    stream that is current when submit() is called is taken to be the consumer's."""
+    geometry alive itself: at the SECOND submit() of this prefetcher after a geometry's own it records one event on
+    the stream that consumed the geometry, and lets go of the geometry once that event has passed.  The contract
+    that makes this safe: whatever consumes a geometry -- forward AND backward pass -- is queued before the second
+    submit() after its own (the loop above queues it before the first); a geometry handed to a forward pass, or
+    met by a backward pass, later than that is refused (RuntimeError), not raced.  The consumer of a geometry is
+    the stream on which its forward pass runs (until then: the stream that was current at its submit()).  Ages and
+    fences are per prefetcher: another prefetcher on the same device (the scorer's, inside a training loop) neither
+    ages this one's geometries nor fences them on its own stream."""
 
     def __init__(self, model, device=None):
         self.model = model
@@ -152,18 +176,23 @@ class GeometryPrefetcher:
         self.device = torch.device(device)
         self._st = _state(self.device)
         self.stream = self._st['stream']
+        self.held = []              # [geometry, fence event or None]
 
     def submit(self, coords, grad=None, ready=None):
         if grad is None:
             grad = self.model.training and torch.is_grad_enabled()
-        fence = None
-        for h in self._st['held']:
-            h[0]._age += 1
-            if h[0]._age == 2:
-                if fence is None:
-                    fence = torch.cuda.current_stream(self.device).record_event()
-                h[1] = fence
-        self._st['held'] = [h for h in self._st['held'] if h[1] is None or not h[1].query()]
+        fences = {}
+        for h in self.held:
+            g = h[0]
+            g._age += 1
+            if g._age == 2 and h[1] is None:
+                c = g._consumer
+                if c not in fences:
+                    fences[c] = c.record_event()
+                h[1] = fences[c]
+        self.held = [h for h in self.held if h[1] is None or not h[1].query()]
+        _reap(self._st)
+        consumer = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.stream):
             if ready is not None:
                 self.stream.wait_event(ready)
@@ -171,14 +200,49 @@ class GeometryPrefetcher:
             g = Geometry.build(self.model, coords, grad)
             g.ready = self.stream.record_event()
             g._stream = self.stream
-        self._st['held'].append([g, None])
+            g._consumer = consumer
+        self.held.append([g, None])
+        return g
+
+    def submit_batch(self, make, grad=None):
+        """The INPUT of a step built ahead as well: `make()` is called under the second stream and returns the batch
+        as a dict with 'coords_v_b' (what lidal_amd.data.collate returns: the scans of the step voxelised under a
+        newly drawn augmentation, dataset/sk_dataset.py:143-171 + :188-242 -- the work the reference's DataLoader
+        workers do ahead of the GPU, dataset/sk_dataloader.py:21,53); its coordinate tables follow on the same
+        stream.  Returns the geometry with the batch as `.payload`: the batch tensors were allocated on the second
+        stream and live exactly as long as the tables do (the same fence)."""
+        if grad is None:
+            grad = self.model.training and torch.is_grad_enabled()
+        with torch.cuda.stream(self.stream):
+            batch = make()
+        g = self.submit(batch['coords_v_b'], grad)
+        g.payload = batch
         return g
 
     def drain(self):
-        """Let go of every geometry this device's prefetchers still hold (the last two of a loop stay alive until
-        the next submit): waits for the consumer stream, after which nothing can still be reading them."""
-        torch.cuda.current_stream(self.device).synchronize()
-        self.stream.synchronize()
-        for h in self._st['held']:
+        """Let go of every geometry this prefetcher still holds (the last two of a loop stay alive until the next
+        submit): waits for their consumer streams, after which nothing can still be reading them."""
+        for h in self.held:
+            h[0]._consumer.synchronize()
             h[0]._age = max(h[0]._age, 2)           # a drained geometry must not be handed to a forward pass any more
-        self._st['held'] = []
+        self.stream.synchronize()
+        self.held = []
+        _reap(self._st)
+
+    def close(self):
+        """The same without waiting on the host: every held geometry is fenced on its consumer stream now and kept by the
+        device's module state until that event has passed.  Called when a loop ends (and on garbage collection)."""
+        for h in self.held:
+            g = h[0]
+            g._age = max(g._age, 2)
+            if h[1] is None:
+                h[1] = g._consumer.record_event()
+            self._st['orphans'].append(h)
+        self.held = []
+        _reap(self._st)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:           # noqa: BLE001  (interpreter shutdown: the runtime may already be gone)
+            pass

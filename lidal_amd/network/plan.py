@@ -1,0 +1,1061 @@
+"""A training step of SPVCNN / MinkUNet as launch plans: the whole forward pass and the whole backward pass
+each cross the C-ABI ONCE (lidal_plan_run, csrc/plan.hip) instead of once per operator.
+
+Why.  /root/reference/train.py:127-140 queues its kernels one Python call at a time, and so did rounds 1-3 of
+this package (an autograd Function per block, ~230 ctypes calls, ~800 launches, a few tensor allocations per
+call): on ONE ~120 k-point scan -- BASELINE.json's literal configuration -- the step took 11 ms of wall time for
+~6 ms of GPU work, bound by the one Python thread.  Once the coordinate tables of a batch exist
+(network/geometry.py builds them ahead of the features) every row count of the step is known, so the host can
+lay the step out before its first feature kernel:
+
+  * `_Program` (once per model): the layers of the U-Net as flat records -- which parameter, which BatchNorm
+    buffers, channel counts, where each parameter's gradient lives in ONE flat f32 buffer;
+  * `_Run` (once per step): walks the program and writes the operator calls of the forward pass -- the SAME
+    entry points with the SAME arguments, in the SAME order as the per-operator path (nn/functional/*.py,
+    network/blocks.py) -- as 64-bit words into a list, carving every activation out of a few large blocks
+    (`_Arena`: bump allocation, no tensor objects, no allocator calls per activation); `lidal_plan_run`
+    executes the words in one call.  The backward pass is written the same way when autograd asks for it.
+  * autograd sees ONE node for the whole network (`_PlannedNet`); the cross-entropy stays the caller's
+    (train.py:136).
+
+Results are bitwise those of the per-operator path (tests/test_plan_gpu.py: loss, logits, every parameter
+gradient, every BatchNorm buffer, both networks, f32 and bf16), which stays in the package as the reference
+the plan is checked against (LIDAL_PLAN=0 selects it).
+
+What still goes through torch inside a planned step: the two in-place dropouts of SPVCNN (network/spvcnn.py:
+139,147: torch's generator decides the mask; the plan is cut in three around them), the flat gradient buffer and
+its per-parameter views (one call), and the optimizer.
+"""
+import array
+import os
+import struct
+
+import torch
+
+from .. import backend as B
+from ..nn.functional import conv as _C
+from ..nn.functional.invlist import inverse_lists
+from ..nn.functional.voxelize import _index32
+
+__all__ = ['planned_forward', 'enabled', 'COUNTERS']
+
+ENABLED = os.environ.get('LIDAL_PLAN', '1') != '0'
+BN_SUMS = None          # None: follow network.blocks.BN_SUMS
+
+# operation kinds of lidal_plan_run (include/lidal_amd.h; tests/test_host_cpu.py checks them against the header)
+OP_CONV_WEIGHT_IMAGE_BATCH, OP_CONV_APPLY_IMAGE, OP_CONV_DGRAD_BN_SUMS, OP_CONV_WGRAD = 1, 2, 3, 4
+OP_BN_TRAIN_FWD, OP_BN_TRAIN_FWD_TILES, OP_BN_BWD, OP_BN_BWD_TILES, OP_BN_EVAL_FWD, OP_BN_FOLD = 5, 6, 7, 8, 9, 10
+OP_COLSUM, OP_ADD_RELU_FWD, OP_ADD_RELU_BWD, OP_VOXELIZE_FWD_1TO1, OP_VOXELIZE_FWD_SORTED = 11, 12, 13, 14, 15
+OP_VOXELIZE_BWD, OP_DEVOXELIZE_FWD, OP_DEVOXELIZE_BWD_SORTED, OP_CE_FWD, OP_CE_BWD = 16, 17, 18, 19, 20
+OP_COPY2D, OP_ADD2D, OP_TRANSPOSE_F32, OP_CAST_ROWS_BF16, OP_VIEW_MEAN_SOFTMAX = 21, 22, 23, 24, 25
+OP_FORK_SIDE, OP_JOIN_SIDE = 26, 27
+
+# operations executed inside plans ('ops') and plans run ('plans') since import (backend.HITS counts every
+# library call made from Python, 'plan_run' among them)
+COUNTERS = {'ops': 0, 'plans': 0}
+# tests: also count the operations of every plan in backend.HITS under the names the per-operator path counts them
+# (walks the words in Python: off in production)
+TALLY = os.environ.get('LIDAL_PLAN_TALLY', '0') != '0'
+_NARGS = {}
+_HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
+              6: 'bn_train_fwd', 7: 'bn_bwd', 8: 'bn_bwd', 9: 'bn_eval_fwd', 10: 'bn_fold', 11: 'colsum',
+              12: 'add_relu_fwd', 13: 'add_relu_bwd', 14: 'voxelize_fwd_1to1', 15: 'voxelize_fwd_sorted',
+              16: 'voxelize_bwd', 17: 'devoxelize_fwd', 18: 'devoxelize_bwd_sorted', 19: 'ce_fwd', 20: 'ce_bwd',
+              21: 'copy2d', 22: 'add2d', 23: 'transpose_f32', 24: 'cast_rows_bf16', 25: 'view_mean_softmax',
+              26: 'fork_side', 27: 'join_side'}
+
+
+def _tally(words):
+    if not _NARGS:
+        L = B.lib_handle()
+        for k in _HIT_NAMES:
+            _NARGS[k] = int(L.lidal_plan_op_args(k))
+    i, n = 0, len(words)
+    while i < n:
+        kind = words[i] & 0xFFFF
+        name = _HIT_NAMES[kind]
+        if kind == OP_CONV_APPLY_IMAGE and words[i + 3] == 0:
+            name = 'conv_apply(dense)'
+        elif kind == OP_CONV_WGRAD and words[i + 5] == 0:
+            name = 'conv_wgrad(dense)'
+        elif kind == OP_BN_BWD_TILES:
+            B.hit('bn_bwd(tile sums)')
+        B.hit(name)
+        i += 1 + _NARGS[kind]
+
+
+def enabled():
+    return ENABLED
+
+
+def _dbits(x):
+    """A float argument as the bit pattern of a double (how lidal_plan_run takes float arguments)."""
+    return struct.unpack('<q', struct.pack('<d', float(x)))[0]
+
+
+# ---- memory --------------------------------------------------------------------------------------------
+class _Arena:
+    """Bump allocation out of a few large blocks of torch's caching allocator: an activation is an address,
+    not a tensor.  Blocks have one size (the allocator re-uses them exactly, step after step, whatever the
+    row counts of the step are); a buffer of more than a quarter block gets a block of its own, rounded up to
+    8 MiB."""
+    BLOCK = 256 << 20
+
+    def __init__(self, device):
+        self.device = device
+        self.blocks = []            # (address, size, uint8 tensor)
+        self.cur = self.end = 0
+
+    def alloc(self, nbytes):
+        nbytes = (nbytes + 255) & -256
+        if nbytes > (self.BLOCK >> 2):
+            size = (nbytes + (8 << 20) - 1) & -(8 << 20)
+            t = torch.empty(size, dtype=torch.uint8, device=self.device)
+            a = t.data_ptr()
+            self.blocks.append((a, size, t))
+            return a
+        a = self.cur
+        if a + nbytes > self.end:
+            t = torch.empty(self.BLOCK, dtype=torch.uint8, device=self.device)
+            a = t.data_ptr()
+            self.blocks.append((a, self.BLOCK, t))
+            self.end = a + self.BLOCK
+        self.cur = a + nbytes
+        return a
+
+    def tensor(self, addr, shape, dtype):
+        """A torch view of arena memory (for what leaves the plan: logits, features, dropout operands)."""
+        numel = 1
+        for s in shape:
+            numel *= s
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        for a, size, t in self.blocks:
+            if a <= addr and addr + nbytes <= a + size:
+                return t[addr - a:addr - a + nbytes].view(dtype).view(*shape)
+        raise RuntimeError('lidal_amd.plan: address outside the arena')
+
+    def release(self):
+        self.blocks = []
+        self.cur = self.end = 0
+
+
+_SCRATCH = {}       # (device index, stream) -> [tensor, address, size]: workspace of ONE operation at a time
+
+
+def _scratch(device, stream, nbytes, keep):
+    """Workspace that lives for one operation (BatchNorm partials, split-K slabs, segment partials): the
+    operations of a plan run one after the other on one stream, so they share one buffer per stream.  When a
+    request outgrows the buffer, the old one goes to `keep` (operations already written may point into it)."""
+    key = (device.index, stream)
+    s = _SCRATCH.get(key)
+    if s is None or s[2] < nbytes:
+        if s is not None:
+            keep.append(s[0])
+        size = max(32 << 20, (int(nbytes * 1.25) + (1 << 20)) & -(1 << 20))
+        t = torch.empty(size, dtype=torch.uint8, device=device)
+        s = _SCRATCH[key] = [t, t.data_ptr(), size]
+    return s[1]
+
+
+# ---- the program: the model as flat records --------------------------------------------------------------
+class _Conv:
+    __slots__ = ('w', 'k', 'ci', 'co', 'transposed', 'strided', 'shape', 'role', 'pad_in', 'img_f', 'img_b', 'tkey',
+                 'param')
+
+
+class _BN:
+    __slots__ = ('w', 'b', 'rm', 'rv', 'nbt', 'c', 'eps', 'mom', 'relu')
+
+
+class _Lin:
+    __slots__ = ('conv', 'b', 'ci', 'co', 'co_pad')
+
+
+class _Res:
+    __slots__ = ('c1', 'b1', 'c2', 'b2', 'cs', 'bs')
+
+
+class _Program:
+    """Compiled once per model instance (parameters are looked up by position, so a re-assigned parameter --
+    model.to(), .half() -- recompiles: `signature`)."""
+
+    def __init__(self, model):
+        from . import blocks
+        from .unet import SPVCNN
+        from .. import nn as spnn
+        self.kind = type(model).__name__
+        self.spvcnn = isinstance(model, SPVCNN)
+        self.params = list(model.parameters())
+        # (module, name, tensor) of every parameter and BatchNorm buffer: `valid()` re-checks them every step
+        self.where = [(m, k, p) for m in model.modules() for k, p in m._parameters.items() if p is not None]
+        self.where_buf = []
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        assert len(self.index) == len(self.params), 'shared parameters are not planned'
+        self.buffers = []
+        self.used = set()
+        self.convs = []
+        self.bns = []
+
+        def conv(m, pad_in=0):
+            c = _Conv()
+            c.param = m.kernel
+            c.w = self._p(m.kernel)
+            c.k, c.ci, c.co = m.kernel_volume, m.in_channels, m.out_channels
+            c.transposed = bool(m.transposed)
+            c.strided = any(s > 1 for s in m.stride)
+            c.shape = (c.k, c.ci, c.co)
+            c.role = 0
+            c.pad_in = pad_in
+            c.img_f = c.img_b = 0
+            c.tkey = None
+            assert m.bias is None and m.bn_follows
+            self.convs.append(c)
+            return c
+
+        def bn(m, relu):
+            r = _BN()
+            r.w, r.b = self._p(m.weight), self._p(m.bias)
+            r.rm, r.rv, r.nbt = self._b(m.running_mean), self._b(m.running_var), self._b(m.num_batches_tracked)
+            self.where_buf += [(m, 'running_mean', m.running_mean), (m, 'running_var', m.running_var),
+                               (m, 'num_batches_tracked', m.num_batches_tracked)]
+            r.c = m.num_features
+            r.eps, r.mom = _dbits(m.eps), _dbits(m.momentum)
+            r.relu = int(bool(relu))
+            assert bool(m.fused_relu) == bool(relu)
+            self.bns.append((r, m))
+            return r
+
+        def conv_bn(seq, at, relu):
+            return conv(seq[at]), bn(seq[at + 1], relu)
+
+        def res(m):
+            r = _Res()
+            r.c1, r.b1 = conv_bn(m.net, 0, True)
+            r.c2, r.b2 = conv_bn(m.net, 3, False)
+            r.cs = r.bs = None
+            if not isinstance(m.downsample, torch.nn.Identity):
+                r.cs, r.bs = conv_bn(m.downsample, 0, False)
+                assert r.cs.k == 1
+            else:
+                assert r.c1.ci == r.c2.co
+            return r
+
+        def lin(m, stats):
+            r = _Lin()
+            c = _Conv()
+            c.param = m.weight
+            c.w = self._p(m.weight)
+            c.k, c.ci, c.co = 1, m.in_features, m.out_features
+            c.transposed = c.strided = False
+            c.shape = (1, c.ci, c.co)
+            c.role = 1                      # nn.Linear keeps [Cout, Cin]
+            c.pad_in = 0
+            c.img_f = c.img_b = 0
+            c.tkey = None
+            self.convs.append(c)
+            r.conv = c
+            r.b = self._p(m.bias)
+            r.ci, r.co = c.ci, c.co
+            r.co_pad = c.co
+            assert bool(m.bn_follows) == bool(stats)
+            return r
+
+        self.stem = [conv_bn(model.stem, 0, True), conv_bn(model.stem, 3, True)]
+        self.stem[0][0].pad_in = 1          # 4 input channels: padded to one 16-byte vector under bf16
+        self.stages = []
+        for i in range(1, 5):
+            st = getattr(model, 'stage%d' % i)
+            self.stages.append((conv_bn(st[0].net, 0, True), res(st[1]), res(st[2])))
+        self.ups = []
+        for i in range(1, 5):
+            up = getattr(model, 'up%d' % i)
+            self.ups.append((conv_bn(up[0].net, 0, True), res(up[1][0]), res(up[1][1])))
+        self.classifier = lin(model.classifier[0], False)
+        self.n_class = self.classifier.co
+        self.points = []
+        self.dropout = None
+        if self.spvcnn:
+            for seq in model.point_transforms:
+                self.points.append((lin(seq[0], True), bn(seq[1], True)))
+            self.dropout = model.dropout
+        assert self.used == set(range(len(self.params))), 'a parameter of the model is not part of the plan'
+        # where each parameter's gradient lives in the flat f32 buffer (whole 16-byte vectors; the odd-sized ones last)
+        order = sorted(range(len(self.params)), key=lambda i: (self.params[i].numel() % 4 != 0, i))
+        self.slot = [0] * len(self.params)
+        off = 0
+        self.flat_order = order
+        for i in order:
+            self.slot[i] = off
+            off += self.params[i].numel()
+            if self.params[i].numel() % 4 and i != order[-1]:
+                off = (off + 3) & -4
+        self.flat_numel = off
+        self.flat_exact = all(self.params[i].numel() % 4 == 0 for i in order[:-1])
+        self.running = [t for r, m in self.bns for t in (m.running_mean, m.running_var)]
+        self.tensors = self.params + self.buffers
+        self.bn_modules = [m for _, m in self.bns]
+        assert len(self.where) == len(self.params)
+        self.ones = None
+        self.cls_shift = None
+
+    def _p(self, p):
+        i = self.index[id(p)]
+        assert i not in self.used, 'a parameter is used twice'
+        self.used.add(i)
+        return i
+
+    def _b(self, t):
+        self.buffers.append(t)
+        return len(self.params) + len(self.buffers) - 1
+
+    def valid(self):
+        """Is the model still the one this program was compiled from, in the configuration the plan covers?
+        (Parameters can be re-assigned, cast, moved or frozen, buffers are REPLACED by Module._apply, modules can be
+        put in eval mode: checked every step, ~50 us.)"""
+        f32 = torch.float32
+        dev = self.params[0].device
+        return (all(m._parameters.get(k) is p and p.dtype is f32 and p.requires_grad and p.device == dev
+                    for m, k, p in self.where)
+                and all(m._buffers.get(k) is t for m, k, t in self.where_buf)
+                and all(m.training and m.track_running_stats for m in self.bn_modules)
+                and dev.type == 'cuda')
+
+
+def _program(model):
+    """The compiled program of `model`, or None if the model is not in the planned configuration."""
+    prog = model.__dict__.get('_lidal_program')
+    if prog is not None and prog.valid():
+        return prog
+    try:
+        ok = all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() and p.requires_grad
+                 for p in model.parameters())
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                ok = ok and m.track_running_stats and m.momentum is not None and m.affine and m.training
+        prog = _Program(model) if ok else None
+    except (AssertionError, AttributeError, KeyError):
+        prog = None
+    model.__dict__['_lidal_program'] = prog
+    return prog
+
+
+def plannable(model, x):
+    """Is this forward pass the standard training configuration the plan covers?  (Anything else runs the
+    per-operator path: same results, one Python call per operator.)"""
+    from . import blocks
+    if not (ENABLED and model.training and torch.is_grad_enabled() and blocks.FUSE_BLOCKS and B.FORK == 15):
+        return False
+    f = x.F
+    if not (torch.is_tensor(f) and f.is_cuda and f.dtype == torch.float32 and f.dim() == 2 and f.shape[1] == 4
+            and f.is_contiguous() and not f.requires_grad and f.shape[0] > 1 and tuple(x.s) == (1, 1, 1)):
+        return False
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') != torch.bfloat16:
+        return False
+    return _program(model) is not None
+
+
+# ---- one step ---------------------------------------------------------------------------------------------
+_WS_BN = {}
+_WS_SLABS = {}
+_WS_SEG = {}
+
+
+def _bn_ws(n, c):
+    key = (n, c)
+    v = _WS_BN.get(key)
+    if v is None:
+        if len(_WS_BN) > 4096:
+            _WS_BN.clear()
+        v = _WS_BN[key] = int(B.lib_handle().lidal_bn_workspace_bytes(n, c))
+    return v
+
+
+def _slabs(n_a, n_b, k, ca, cb, code):
+    key = (n_a, n_b, k, ca, cb, code)
+    v = _WS_SLABS.get(key)
+    if v is None:
+        if len(_WS_SLABS) > 4096:
+            _WS_SLABS.clear()
+        v = _WS_SLABS[key] = int(B.lib_handle().lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, code))
+    return v
+
+
+def _seg_ws(n_entries, m, c):
+    key = (n_entries, m, c)
+    v = _WS_SEG.get(key)
+    if v is None:
+        if len(_WS_SEG) > 4096:
+            _WS_SEG.clear()
+        v = _WS_SEG[key] = int(B.lib_handle().lidal_segment_workspace_bytes(n_entries, m, c))
+    return v
+
+
+class _Tables:
+    """The addresses a step reads out of its Geometry, gathered once per geometry."""
+
+    def __init__(self, g, spvcnn):
+        x0 = g.x0
+        km, cm = x0.kmaps, x0.cmaps
+        self.n = []
+        self.k3 = []        # per level: (table, perm, masks, nbmaps, koff)
+        self.k2 = []        # per level l -> l + 1: (out table, perm, masks, in table, perm, masks, nbmaps, koff)
+        self.keep = []
+        for l in range(5):
+            s = 1 << l
+            st = (s, s, s)
+            self.n.append(int(cm[st].shape[0]))
+            k3 = km[(st, (3, 3, 3), (1, 1, 1), (1, 1, 1))]
+            oo = k3.order_out
+            self.k3.append((oo.table.data_ptr(), oo.perm.data_ptr(), oo.tile_masks.data_ptr(),
+                            k3._nbmaps_cap.data_ptr(), k3.koff.data_ptr()))
+            self.keep.append(k3)
+            if l < 4:
+                k2 = km[(st, (2, 2, 2), (2, 2, 2), (1, 1, 1))]
+                oo, oi = k2.order_out, k2.order_in
+                self.k2.append((oo.table.data_ptr(), oo.perm.data_ptr(), oo.tile_masks.data_ptr(),
+                                oi.table.data_ptr(), oi.perm.data_ptr(), oi.tile_masks.data_ptr(),
+                                k2._nbmaps_cap.data_ptr(), k2.koff.data_ptr()))
+                self.keep.append(k2)
+        self.pt = {}
+        self.p = 0
+        if spvcnn:
+            z = g.z
+            af = z.additional_features
+            self.p = int(z.C.shape[0])
+            for l, key in ((0, 1), (4, (16, 16, 16)), (2, (4, 4, 4))):
+                if l == 0 and af['idx_query'].get((1, 1, 1)) is not None:
+                    key_v = (1, 1, 1)
+                else:
+                    key_v = key
+                idx64, counts = af['idx_query'][key_v], af['counts'][key_v]
+                m = self.n[l]
+                idx32 = _index32(idx64)
+                one = bool(getattr(idx64, '_lidal_one_to_one', False)) and idx64.numel() == m
+                vorder = vseg = 0
+                if not one:
+                    o, sp = inverse_lists(idx32, m)
+                    vorder, vseg = o.data_ptr(), sp.data_ptr()
+                    self.keep += [o, sp]
+                s = 1 << l
+                idx8, w8 = z.idx_query[(s, s, s)], z.weights[(s, s, s)]
+                assert idx8.dtype == torch.int32 and idx8.is_contiguous() and w8.dtype == torch.float32
+                do, dsp = inverse_lists(idx8, m, w8)
+                cnt = counts if counts.dtype == torch.int32 and counts.is_contiguous() else counts.contiguous().int()
+                self.keep += [idx32, cnt, idx8, w8, do, dsp]
+                self.pt[l] = (idx32.data_ptr(), cnt.data_ptr(), int(one), vorder, vseg,
+                              idx8.data_ptr(), w8.data_ptr(), do.data_ptr(), dsp.data_ptr())
+
+
+def _tables(g, spvcnn):
+    t = g.__dict__.get('_plan_tables')
+    if t is None:
+        t = g.__dict__['_plan_tables'] = _Tables(g, spvcnn)
+    return t
+
+
+class _Run:
+    """One training step: the forward plan, what it saved, the backward plan."""
+
+    def __init__(self, model, prog, geometry, feats, code):
+        self.prog = prog
+        self.model = model
+        self.dev = feats.device
+        self.code = code
+        self.esz = 2 if code == B.BF16 else 4
+        self.vec = 8 if code == B.BF16 else 4
+        self.bf16 = code == B.BF16
+        self.dtype = torch.bfloat16 if self.bf16 else torch.float32
+        self.geometry = geometry
+        self.T = _tables(geometry, prog.spvcnn)
+        self.feats = feats
+        self.stream = B.stream()
+        self.arena = _Arena(self.dev)
+        self.barena = None
+        self.tile = B.stats_tile_rows()
+        from . import blocks
+        self.bn_sums = (blocks.BN_SUMS if BN_SUMS is None else BN_SUMS) and self.bf16
+        self.saved = {}
+        self.noise = []
+        self.keep = []
+        self.w = []
+        self.nops = 0
+        self.done = False
+        self.ptr = [t.data_ptr() for t in prog.tensors]
+        self._constants()
+        self._images()
+
+    # -- small persistent operands ---------------------------------------------------------------------
+    def _constants(self):
+        prog, T = self.prog, self.T
+        if prog.ones is None or prog.ones.device != self.dev:
+            prog.ones = torch.ones(512, dtype=torch.float32, device=self.dev)
+            prog.cls_shift = torch.zeros(64, dtype=torch.float32, device=self.dev)
+        self.ones = prog.ones.data_ptr()
+        self.cls_shift = prog.cls_shift.data_ptr()
+        # rule offsets [0, n] of the identity rule list, for every row count a dense weight gradient sees: one upload
+        ns = [T.p] + T.n if prog.spvcnn else T.n
+        host = []
+        for n in ns:
+            host += [0, n]
+        k = torch.tensor(host, dtype=torch.int64).to(self.dev, non_blocking=True)
+        self.koff_t = k
+        base = k.data_ptr()
+        self.koff = {n: base + 16 * i for i, n in reversed(list(enumerate(ns)))}
+
+    def _images(self):
+        """The LDS images of every weight: registered with the step's bank (nn/functional/conv.py _ImageBank) under
+        the tilings this step's row counts select, rebuilt by ONE launch."""
+        prog, T = self.prog, self.T
+        bank = _C._IMAGE_BANK
+        code, dtype = self.code, self.dtype
+        todo = []
+        for c, (nf, nb) in self._conv_rows():
+            key = (_C._tiling(c.ci, c.co, code, nf), _C._tiling(c.co, c.ci, code, nb), code)
+            if c.tkey != key:
+                todo.append((c, nf, nb, key))
+        for c, nf, nb, key in todo:
+            e_f, e_b = bank.get(c.param, dtype, nf, nb, c.shape if (c.role or c.k == 1) else None, c.role)
+            c.img_f, c.img_b, c.tkey = e_f.data_ptr(), e_b.data_ptr(), key
+        # (bank.get rebuilds every stale image of the group with one launch the first time it meets one; when no
+        # layer needed registering, ask for the rebuild directly)
+        first = prog.convs[0]
+        e = bank.entries.get(id(first.param))
+        if e is None or e['version'] != B.weights_key(first.param):
+            if e is None:
+                raise RuntimeError('lidal_amd.plan: weight image bank lost an entry')
+            bank._rebuild(e['group'])
+
+    def _conv_rows(self):
+        """(layer, (rows its forward produces, rows its data gradient produces)) for every weight of the program."""
+        prog, n = self.prog, self.T.n
+        out = []
+        for cb in prog.stem:
+            out.append((cb[0], (n[0], n[0])))
+        for l, (down, ra, rb) in enumerate(prog.stages):
+            out.append((down[0], (n[l + 1], n[l])))
+            for r in (ra, rb):
+                for c in (r.c1, r.c2, r.cs):
+                    if c is not None:
+                        out.append((c, (n[l + 1], n[l + 1])))
+        for i, (dec, ra, rb) in enumerate(prog.ups):
+            l = 3 - i                               # output level of up_{i+1}
+            out.append((dec[0], (n[l], n[l + 1])))
+            for r in (ra, rb):
+                for c in (r.c1, r.c2, r.cs):
+                    if c is not None:
+                        out.append((c, (n[l], n[l])))
+        rows = self.T.p if prog.spvcnn else n[0]
+        out.append((prog.classifier.conv, (rows, rows)))
+        for lin, _ in prog.points:
+            out.append((lin.conv, (self.T.p, self.T.p)))
+        return out
+
+    # -- running a stretch of the tape --------------------------------------------------------------------
+    def flush(self):
+        if not self.nops:
+            return
+        if TALLY:
+            _tally(self.w)
+        arr = array.array('q', self.w)
+        addr, n_words = arr.buffer_info()
+        L = B.lib_handle()
+        rc = L.lidal_plan_run(addr, n_words, self.nops, self.stream, None)
+        COUNTERS['plans'] += 1
+        COUNTERS['ops'] += self.nops
+        B.HITS['plan_run'] = B.HITS.get('plan_run', 0) + 1
+        self.w = []
+        self.nops = 0
+        if rc != 0:
+            raise RuntimeError('lidal_amd.plan_run failed (%d): %s' % (rc, L.lidal_last_error().decode()))
+
+    def scratch(self, nbytes):
+        return _scratch(self.dev, self.stream, nbytes, self.keep)
+
+    # ===================================== forward ========================================================
+    def f_conv(self, c, x, n_in, ci, table, n_out, stats):
+        """conv.py _apply: -> (out, tile statistics or 0)."""
+        A = self.arena
+        out = A.alloc(n_out * c.co * self.esz)
+        st = A.alloc(-(-n_out // self.tile) * c.co * 12) if (stats and self.bf16) else 0
+        self.w += (OP_CONV_APPLY_IMAGE, x, c.img_f, table[0], table[1], table[2], out, n_in, n_out, ci, c.co, c.k, 0,
+                   self.code, 0, 0, 0, 0, st)
+        self.nops += 1
+        return out, st
+
+    def f_dense(self, c, x, n, co, shift, stats):
+        """dense.py _rows_gemm (role 0): x [n, ci] @ W (+ shift) -> (out [n, co], tile statistics or 0)."""
+        A = self.arena
+        out = A.alloc(n * co * self.esz)
+        st = A.alloc(-(-n // self.tile) * co * 12) if (stats and self.bf16) else 0
+        self.w += (OP_CONV_APPLY_IMAGE, x, c.img_f, 0, 0, 0, out, n, n, c.ci, co, 1, 0, self.code,
+                   self.ones if shift else 0, shift, 0, 0, st)
+        self.nops += 1
+        return out, st
+
+    def f_bn(self, r, x, n, st, residual=0, relu_after=False):
+        """norm.py train_forward: -> (y, mean, invstd)."""
+        A, p = self.arena, self.ptr
+        c = r.c
+        y = A.alloc(n * c * self.esz)
+        mean = A.alloc(c * 4)
+        invstd = A.alloc(c * 4)
+        relu = r.relu | (2 if (relu_after and residual) else 0)
+        if st:
+            self.w += (OP_BN_TRAIN_FWD_TILES, x, self.code, n, c, p[r.w], p[r.b], r.eps, r.mom, p[r.rm], p[r.rv],
+                       p[r.nbt], relu, residual, y, mean, invstd, st, -(-n // self.tile))
+        else:
+            nb = _bn_ws(n, c)
+            self.w += (OP_BN_TRAIN_FWD, x, self.code, n, c, p[r.w], p[r.b], r.eps, r.mom, p[r.rm], p[r.rv],
+                       p[r.nbt], relu, residual, y, mean, invstd, self.scratch(nb), nb)
+        self.nops += 1
+        return y, mean, invstd
+
+    def f_conv_bn(self, cb, x, n_in, table, n_out, ci=None):
+        """blocks._ConvNormAct.forward; saves (x, conv output, mean, invstd)."""
+        c, r = cb
+        x1, st = self.f_conv(c, x, n_in, c.ci if ci is None else ci, table, n_out, True)
+        y, mean, invstd = self.f_bn(r, x1, n_out, st)
+        self.saved[id(cb)] = (x, x1, mean, invstd)
+        return y
+
+    def f_res(self, r, x, n, table):
+        """blocks._Residual.forward."""
+        x1, st1 = self.f_conv(r.c1, x, n, r.c1.ci, table, n, True)
+        y1, mean1, inv1 = self.f_bn(r.b1, x1, n, st1)
+        x2, st2 = self.f_conv(r.c2, y1, n, r.c2.ci, table, n, True)
+        if r.cs is not None:
+            xs, sts = self.f_dense(r.cs, x, n, r.cs.co, 0, True)
+            res, means, invs = self.f_bn(r.bs, xs, n, sts)
+        else:
+            xs = means = invs = 0
+            res = x
+        out, mean2, inv2 = self.f_bn(r.b2, x2, n, st2, res, True)
+        self.saved[id(r)] = (x, x1, mean1, inv1, y1, x2, mean2, inv2, out, xs, means, invs)
+        return out
+
+    def f_cat(self, a, ca, b, cb, n):
+        A, e = self.arena, self.esz
+        out = A.alloc(n * (ca + cb) * e)
+        pitch = (ca + cb) * e
+        self.w += (OP_COPY2D, a, ca * e, out, pitch, n, ca * e, 0,
+                   OP_COPY2D, b, cb * e, out + ca * e, pitch, n, cb * e, 0)
+        self.nops += 2
+        return out
+
+    def f_devox(self, x, lvl, c):
+        """devoxelize.py DevoxelizeFunction.forward at level `lvl`: [n_lvl, c] -> [P, c]."""
+        t = self.T.pt[lvl]
+        P = self.T.p
+        out = self.arena.alloc(P * c * self.esz)
+        self.w += (OP_DEVOXELIZE_FWD, x, t[5], t[6], out, P, self.T.n[lvl], c, self.code)
+        self.nops += 1
+        return out
+
+    def f_vox(self, z, lvl, c, code=None):
+        """voxelize.py VoxelizeFunction.forward at level `lvl`: [P, c] -> [n_lvl, c]."""
+        code = self.code if code is None else code
+        esz = 2 if code == B.BF16 else 4
+        t = self.T.pt[lvl]
+        P, m = self.T.p, self.T.n[lvl]
+        out = self.arena.alloc(m * c * esz)
+        if t[2]:
+            self.w += (OP_VOXELIZE_FWD_1TO1, z, t[0], out, P, c, code)
+        else:
+            nb = _seg_ws(P, m, c)
+            self.w += (OP_VOXELIZE_FWD_SORTED, z, t[3], t[4], t[1], out, m, c, code, P, self.scratch(nb) if nb else 0, nb)
+        self.nops += 1
+        return out
+
+    def f_point(self, pt, z_in, devox_out):
+        """Linear -> BatchNorm1d(+ReLU) + residual (network/spvcnn.py:136,143,151; blocks.ConvNormSequential)."""
+        lin, r = pt
+        P = self.T.p
+        x1, st = self.f_dense(lin.conv, z_in, P, lin.co, self.ptr[lin.b], True)
+        y, mean, invstd = self.f_bn(r, x1, P, st, devox_out, False)
+        self.saved[id(pt)] = (z_in, x1, mean, invstd)
+        return y
+
+    def f_classifier(self, x, n):
+        lin = self.prog.classifier
+        co_pad = lin.co + (-lin.co) % self.vec
+        lin.co_pad = co_pad
+        # shift = the bias padded with zeros (dense.py _forward); the padding columns of the persistent buffer stay zero
+        self.w += (OP_COPY2D, self.ptr[lin.b], lin.co * 4, self.cls_shift, co_pad * 4, 1, lin.co * 4, 0)
+        self.nops += 1
+        out, _ = self.f_dense(lin.conv, x, n, co_pad, self.cls_shift, False)
+        self.saved['cls'] = (x, n)
+        return out, co_pad
+
+    def f_dropout(self, addr, n, c):
+        """nn.Dropout(p, inplace=True) on arena memory, with torch's own kernels and generator (ATen Dropout.cpp
+        _dropout_impl, in-place form): noise = empty_like(x).bernoulli_(1 - p).div_(1 - p); x.mul_(noise)."""
+        d = self.prog.dropout
+        if d is None or not d.training or d.p == 0:
+            self.noise.append(None)
+            return
+        self.flush()
+        x = self.arena.tensor(addr, (n, c), self.dtype)
+        if d.p == 1:
+            x.zero_()
+            self.noise.append(0)
+            return
+        noise = torch.empty_like(x).bernoulli_(1 - d.p).div_(1 - d.p)
+        x.mul_(noise)
+        self.noise.append(noise)
+
+    def forward(self):
+        prog, T, A = self.prog, self.T, self.arena
+        n = T.n
+        k3, k2 = T.k3, T.k2
+        bf = self.bf16
+        x = self.feats.data_ptr()
+        if prog.spvcnn:                     # geometry.enter: the input voxelised on its own coordinates (f32 rows)
+            x = self.f_vox(x, 0, 4, B.F32)
+        c0 = prog.stem[0][0]
+        if bf:                              # conv.py _forward: cast, channels padded to one 16-byte vector
+            xc = A.alloc(n[0] * 8 * 2)
+            self.w += (OP_CAST_ROWS_BF16, x, 4, xc, 8, n[0])
+            self.nops += 1
+            x, ci0 = xc, 8
+        else:
+            ci0 = 4
+        y = self.f_conv_bn(prog.stem[0], x, n[0], k3[0], n[0], ci0)
+        x0 = self.f_conv_bn(prog.stem[1], y, n[0], k3[0], n[0])
+        skips = [x0]
+        cs = [c0.co]
+        if prog.spvcnn:
+            z0 = self.f_devox(x0, 0, cs[0])
+            y = self.f_vox(z0, 0, cs[0])
+        else:
+            y = x0
+        for l, (down, ra, rb) in enumerate(prog.stages):
+            y = self.f_conv_bn(down, y, n[l], k2[l][0:3], n[l + 1])
+            y = self.f_res(ra, y, n[l + 1], k3[l + 1])
+            y = self.f_res(rb, y, n[l + 1], k3[l + 1])
+            skips.append(y)
+            cs.append(rb.c2.co)
+        z = None
+        if prog.spvcnn:
+            z1 = self.f_point(prog.points[0], z0, self.f_devox(y, 4, cs[4]))
+            y = self.f_vox(z1, 4, cs[4])
+            self.f_dropout(y, n[4], cs[4])
+            z = z1
+        for i, (dec, ra, rb) in enumerate(prog.ups):
+            l = 3 - i
+            y = self.f_conv_bn(dec, y, n[l + 1], k2[l][3:6], n[l])
+            y = self.f_cat(y, dec[0].co, skips[l], cs[l], n[l])
+            y = self.f_res(ra, y, n[l], k3[l])
+            y = self.f_res(rb, y, n[l], k3[l])
+            c_out = rb.c2.co
+            if prog.spvcnn and i == 1:
+                z2 = self.f_point(prog.points[1], z, self.f_devox(y, 2, c_out))
+                y = self.f_vox(z2, 2, c_out)
+                self.f_dropout(y, n[2], c_out)
+                z = z2
+        if prog.spvcnn:
+            feat = self.f_point(prog.points[2], z, self.f_devox(y, 0, c_out))
+            rows = T.p
+        else:
+            feat, rows = y, n[0]
+        logits, co_pad = self.f_classifier(feat, rows)
+        self.flush()
+        torch.autograd.graph.increment_version(prog.running)
+        self.c_feat = c_out
+        logits_t = A.tensor(logits, (rows, co_pad), self.dtype)[:, :prog.n_class]
+        feat_t = A.tensor(feat, (rows, c_out), self.dtype)
+        return logits_t, feat_t
+
+    # ===================================== backward =======================================================
+    def galloc(self, nbytes):
+        return self.barena.alloc(nbytes)
+
+    def slot(self, i):
+        return self.flat + 4 * self.prog.slot[i]
+
+    def b_bn(self, r, x, n, mean, invstd, g, g_stride, sums=0, relu=None):
+        """norm.py train_backward (without the mask_from part): -> dx."""
+        p = self.ptr
+        c = r.c
+        dx = self.galloc(n * c * self.esz)
+        relu = r.relu if relu is None else relu
+        if sums:
+            self.w += (OP_BN_BWD_TILES, x, g, g_stride, self.code, n, c, p[r.w], p[r.b], relu, mean, invstd, dx,
+                       self.slot(r.w), self.slot(r.b), sums, -(-n // self.tile))
+        else:
+            nb = _bn_ws(n, c)
+            self.w += (OP_BN_BWD, x, g, g_stride, self.code, n, c, p[r.w], p[r.b], relu, mean, invstd, dx,
+                       self.slot(r.w), self.slot(r.b), self.scratch(nb), nb)
+        self.nops += 1
+        return dx
+
+    def b_wgrad(self, c, x, n_x, g, n_g, rules, ci=None):
+        """conv.py conv_backward's wgrad(): gw [k, ci, co] f32 straight into the parameter's gradient slot."""
+        ci = c.ci if ci is None else ci
+        slabs = _slabs(n_x, n_g, c.k, ci, c.co, self.code)
+        partial = self.scratch(slabs * ci * c.co * 4 + (c.k * ci * c.co * 4 if ci != c.ci else 0))
+        gw = self.slot(c.w)
+        if ci != c.ci:                      # the channel-padded stem: gw[:, :ci_w] of the padded gradient
+            gw = partial + slabs * ci * c.co * 4
+        self.w += (OP_CONV_WGRAD, x, g, n_x, n_g, rules[0], rules[1], 1 if c.transposed else 0, gw, partial, slabs,
+                   c.k, ci, c.co, self.code)
+        self.nops += 1
+        if ci != c.ci:
+            self.w += (OP_COPY2D, gw, ci * c.co * 4, self.slot(c.w), c.ci * c.co * 4, c.k, c.ci * c.co * 4, 0)
+            self.nops += 1
+
+    def b_dgrad(self, c, g, n_g, table, n_out, kflip, skip=0, bnb=None):
+        """conv.py conv_backward's data gradient: -> (gin [n_out, ci], tile sums or 0)."""
+        gin = self.galloc(n_out * c.ci * self.esz)
+        if bnb is not None:
+            sums = self.galloc(-(-n_out // self.tile) * c.ci * 8)
+            self.w += (OP_CONV_DGRAD_BN_SUMS, g, c.img_b, table[0], table[1], table[2], gin, n_g, n_out, c.co, c.ci,
+                       c.k, kflip, self.code) + bnb + (sums,)
+            self.nops += 1
+            return gin, sums
+        self.w += (OP_CONV_APPLY_IMAGE, g, c.img_b, table[0], table[1], table[2], gin, n_g, n_out, c.co, c.ci, c.k,
+                   kflip, self.code, 0, 0, 0, skip, 0)
+        self.nops += 1
+        return gin, 0
+
+    def b_dense(self, c, x, n, g, cg, need_gx=True, linear_slot=None):
+        """dense.py rows_backward (weight gradient x^T g, then the data gradient g W^T): -> gx or 0."""
+        ca, cb = c.ci, cg
+        slabs = _slabs(n, n, 1, ca, cb, self.code)
+        direct = linear_slot is None and cb == c.co
+        sc = self.scratch(slabs * ca * cb * 4 + (0 if direct else ca * cb * 4))
+        gw = self.slot(c.w) if direct else sc + slabs * ca * cb * 4
+        self.w += (OP_CONV_WGRAD, x, g, n, n, 0, self.koff[n], 0, gw, sc, slabs, 1, ca, cb, self.code)
+        self.nops += 1
+        if not direct:                      # nn.Linear: [Cout, Cin] = (x^T g)[:, :Cout]^T
+            self.w += (OP_TRANSPOSE_F32, gw, cb, self.slot(c.w), ca, c.co)
+            self.nops += 1
+        if not need_gx:
+            return 0
+        gx = self.galloc(n * ca * self.esz)
+        self.w += (OP_CONV_APPLY_IMAGE, g, c.img_b, 0, 0, 0, gx, n, n, cb, ca, 1, 0, self.code, 0, 0, 0, 0, 0)
+        self.nops += 1
+        return gx
+
+    def b_colsum(self, g, n, c, out):
+        nb = _bn_ws(n, c) + 12 * c
+        self.w += (OP_COLSUM, g, self.code, n, c, out, self.scratch(nb), nb)
+        self.nops += 1
+
+    def b_conv_bn(self, cb, g, g_stride, n_in, n_out, tables, need_gx=True, ci=None):
+        """blocks._ConvNormAct.backward: g = gradient of the block's output [n_out, co] (rows g_stride apart)."""
+        c, r = cb
+        x, x1, mean, invstd = self.saved[id(cb)]
+        dx = self.b_bn(r, x1, n_out, mean, invstd, g, g_stride)
+        if c.transposed:
+            rules, table, n_gin, kflip = tables[6:8], tables[0:3], n_in, 0
+        elif c.strided:
+            rules, table, n_gin, kflip = tables[6:8], tables[3:6], n_in, 0
+        else:
+            rules, table, n_gin, kflip = tables[3:5], tables[0:3], n_in, 1
+        self.b_wgrad(c, x, n_in, dx, n_out, rules, ci)
+        if not need_gx:
+            return 0
+        return self.b_dgrad(c, dx, n_out, table, n_gin, kflip)[0]
+
+    def b_res(self, r, g, n, k3):
+        """blocks._Residual.backward: g [n, co] contiguous -> gx [n, ci]."""
+        x, x1, mean1, inv1, y1, x2, mean2, inv2, out, xs, means, invs = self.saved[id(r)]
+        co = r.c2.co
+        gm = self.galloc(n * co * self.esz)
+        self.w += (OP_ADD_RELU_BWD, out, g, gm, n * co, self.code)
+        self.nops += 1
+        dx2 = self.b_bn(r.b2, x2, n, mean2, inv2, gm, co, 0, 0)
+        if r.cs is not None:
+            dxs = self.b_bn(r.bs, xs, n, means, invs, gm, co)
+            g_skip = self.b_dense(r.cs, x, n, dxs, co)
+        else:
+            g_skip = gm
+        table, rules = k3[0:3], k3[3:5]
+        self.b_wgrad(r.c2, y1, n, dx2, n, rules)
+        p = self.ptr
+        bnb = (x1, mean1, inv1, p[r.b1.w], p[r.b1.b], 1) if self.bn_sums else None
+        dy1, sums = self.b_dgrad(r.c2, dx2, n, table, n, 1, 0, bnb)
+        dx1 = self.b_bn(r.b1, x1, n, mean1, inv1, dy1, r.c1.co, sums)
+        self.b_wgrad(r.c1, x, n, dx1, n, rules)
+        return self.b_dgrad(r.c1, dx1, n, table, n, 1, g_skip)[0]
+
+    def b_add(self, a, a_stride, b, b_stride, n, c):
+        out = self.galloc(n * c * self.esz)
+        self.w += (OP_ADD2D, a, a_stride, b, b_stride, out, c, n, c, self.code)
+        self.nops += 1
+        return out
+
+    def b_devox(self, g, lvl, c):
+        """DevoxelizeFunction.backward: g [P, c] -> [n_lvl, c] (ordered per-voxel sums over the contributor lists)."""
+        t = self.T.pt[lvl]
+        P, m = self.T.p, self.T.n[lvl]
+        gin = self.galloc(m * c * self.esz)
+        nb = _seg_ws(8 * P, m, c)
+        self.w += (OP_DEVOXELIZE_BWD_SORTED, g, t[7], t[8], t[6], gin, m, c, self.code, 8 * P,
+                   self.scratch(nb) if nb else 0, nb)
+        self.nops += 1
+        return gin
+
+    def b_vox(self, g, lvl, c, skip):
+        """VoxelizeFunction.backward: g [n_lvl, c] (+ the gradient of the forked alias) -> [P, c]."""
+        t = self.T.pt[lvl]
+        P, m = self.T.p, self.T.n[lvl]
+        gin = self.galloc(P * c * self.esz)
+        self.w += (OP_VOXELIZE_BWD, g, t[0], t[1], skip, gin, P, m, c, self.code)
+        self.nops += 1
+        return gin
+
+    def b_point(self, pt, g, need_gx=True):
+        """Backward of f_point: g [P, co] -> gradient of the Linear's input [P, ci] (the residual's is g itself)."""
+        lin, r = pt
+        P = self.T.p
+        z_in, x1, mean, invstd = self.saved[id(pt)]
+        dx = self.b_bn(r, x1, P, mean, invstd, g, lin.co)
+        gx = self.b_dense(lin.conv, z_in, P, dx, lin.co, need_gx, True)
+        self.b_colsum(dx, P, lin.co, self.slot(lin.b))
+        return gx
+
+    def b_dropout(self, which, g, n, c):
+        noise = self.noise[which]
+        if noise is None:
+            return g
+        self.flush()
+        gt = self.barena.tensor(g, (n, c), self.dtype)
+        if isinstance(noise, int):
+            gt.zero_()
+        else:
+            torch.mul(gt, noise, out=gt)
+        return g
+
+    def backward(self, g_logits, g_feat):
+        if self.done:
+            raise RuntimeError('lidal_amd.plan: this step has already run its backward pass (its activations are '
+                               'released; retain_graph is not supported by the planned step)')
+        if not self.geometry.alive():
+            raise RuntimeError('lidal_amd: this backward pass reads the coordinate tables of a geometry that is stale -- two '
+                               'newer ones have been submitted to its prefetcher since (queue forward AND backward of a '
+                               'batch before the second submit() after its own: network/geometry.py GeometryPrefetcher)')
+        prog, T = self.prog, self.T
+        n, k3, k2 = T.n, T.k3, T.k2
+        e = self.esz
+        self.stream = B.stream()
+        self.barena = _Arena(self.dev)
+        flat = torch.empty(prog.flat_numel + 16, dtype=torch.float32, device=self.dev)
+        self.flat = flat.data_ptr()
+        assert self.flat % 16 == 0
+        # ---- classifier
+        lin = prog.classifier
+        x, rows = self.saved['cls']
+        co_pad = lin.co_pad
+        g = g_logits
+        if g.dtype != self.dtype or not g.is_contiguous():
+            g = g.contiguous().to(self.dtype)
+        gp = self.galloc(rows * co_pad * e)
+        self.w += (OP_COPY2D, g.data_ptr(), lin.co * e, gp, co_pad * e, rows, lin.co * e, (co_pad - lin.co) * e)
+        self.nops += 1
+        gy = self.b_dense(lin.conv, x, rows, gp, co_pad, True, True)
+        self.b_colsum(gp, rows, co_pad, self.slot(lin.b))          # (its slot is the last: the padding columns fall behind it)
+        c_out = self.c_feat
+        if g_feat is not None:
+            gf = g_feat if (g_feat.dtype == self.dtype and g_feat.is_contiguous()) else g_feat.contiguous().to(self.dtype)
+            self.keep_gf = gf
+            gy = self.b_add(gy, c_out, gf.data_ptr(), c_out, rows, c_out)
+        gz_lin = 0
+        if prog.spvcnn:
+            gz_lin = self.b_point(prog.points[2], gy)          # gradient of z2.F through the Linear
+            gy = self.b_devox(gy, 0, c_out)
+        g_skip = [0] * 5        # (address, row stride) of the concatenation's gradient slice of every encoder level
+        for i in (3, 2, 1, 0):
+            dec, ra, rb = prog.ups[i]
+            l = 3 - i
+            if prog.spvcnn and i == 1:
+                # y was vox(z2) with dropout, z2 = point(z1) + devox(up2 output)
+                c2 = rb.c2.co
+                gy = self.b_dropout(1, gy, n[2], c2)
+                gz = self.b_vox(gy, 2, c2, gz_lin)
+                gz_lin = self.b_point(prog.points[1], gz)
+                gy = self.b_devox(gz, 2, c2)
+            gy = self.b_res(rb, gy, n[l], k3[l])
+            gcat = self.b_res(ra, gy, n[l], k3[l])
+            c_up, c_cat = dec[0].co, ra.c1.ci
+            g_skip[l] = (gcat + c_up * e, c_cat)
+            gy = self.b_conv_bn(dec, gcat, c_cat, n[l + 1], n[l], k2[l])
+        cs4 = prog.stages[3][2].c2.co
+        if prog.spvcnn:
+            gy = self.b_dropout(0, gy, n[4], cs4)
+            gz = self.b_vox(gy, 4, cs4, gz_lin)
+            gz_lin = self.b_point(prog.points[0], gz)              # gradient of z0.F through the Linear
+            gy = self.b_devox(gz, 4, cs4)
+        for l in (3, 2, 1, 0):
+            down, ra, rb = prog.stages[l]
+            c = rb.c2.co
+            if l < 3:                       # the level also fed a decoder concatenation: autograd's sum of the two
+                gy = self.b_add(gy, c, g_skip[l + 1][0], g_skip[l + 1][1], n[l + 1], c)
+            gy = self.b_res(rb, gy, n[l + 1], k3[l + 1])
+            gy = self.b_res(ra, gy, n[l + 1], k3[l + 1])
+            gy = self.b_conv_bn(down, gy, down[0].co, n[l], n[l + 1], k2[l])
+        c0 = prog.stem[1][0].co
+        if prog.spvcnn:
+            gz0 = self.b_vox(gy, 0, c0, gz_lin)
+            gy = self.b_devox(gz0, 0, c0)
+        gy = self.b_add(gy, c0, g_skip[0][0], g_skip[0][1], n[0], c0)
+        gy = self.b_conv_bn(prog.stem[1], gy, c0, n[0], n[0], k3[0])
+        self.b_conv_bn(prog.stem[0], gy, prog.stem[0][0].co, n[0], n[0], k3[0], False, 8 if self.bf16 else 4)
+        self.flush()
+        self.done = True
+        # the activations (and this pass's gradients) go back to the allocator: every kernel that reads them is queued
+        self.arena.release()
+        self.barena.release()
+        self.saved = {}
+        self.noise = []
+        return self._grads(flat)
+
+    def _grads(self, flat):
+        prog = self.prog
+        views = [None] * len(prog.params)
+        if prog.flat_exact:
+            order = prog.flat_order
+            parts = flat[:prog.flat_numel].split_with_sizes([prog.params[i].numel() for i in order])
+            for i, t in zip(order, parts):
+                views[i] = t.view(prog.params[i].shape)
+        else:
+            for i, p in enumerate(prog.params):
+                views[i] = flat[prog.slot[i]:prog.slot[i] + p.numel()].view(p.shape)
+        return views
+
+
+class _PlannedNet(torch.autograd.Function):
+    """The whole network as one autograd node: forward = one plan, backward = one plan."""
+
+    @staticmethod
+    def forward(ctx, run, *params):
+        ctx.run = run
+        ctx.set_materialize_grads(False)
+        return run.forward()
+
+    @staticmethod
+    def backward(ctx, g_logits, g_feat):
+        B.note_backward()
+        run = ctx.run
+        if g_logits is None:
+            rows = run.T.p if run.prog.spvcnn else run.T.n[0]
+            g_logits = torch.zeros((rows, run.prog.n_class), dtype=run.dtype, device=run.dev)
+        return (None,) + tuple(run.backward(g_logits, g_feat))
+
+
+def planned_forward(model, x):
+    """model(x) in training as one planned autograd node, or None when the configuration is not the planned one."""
+    if not plannable(model, x):
+        return None
+    from .geometry import Geometry
+    g = getattr(x, 'geometry', None)
+    if g is None:
+        g = Geometry.build(model, x.C, True)
+    else:
+        g.admit(x, type(model).__name__)
+        if not g.grad:
+            return None
+    prog = model.__dict__['_lidal_program']
+    code = B.BF16 if B.compute_dtype(x.F) == torch.bfloat16 else B.F32
+    run = _Run(model, prog, g, x.F, code)
+    return _PlannedNet.apply(run, *prog.params)

@@ -14,6 +14,7 @@ from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, ConvNormSeq
                      ResidualBlock, conv_bn_relu)
 from ..nn.functional.conv import prefetch_kernel_maps
 from .glue import initial_voxelize, point_to_voxel, voxel_to_point
+from .plan import planned_forward
 
 __all__ = ['SPVCNN', 'MinkUNet']
 
@@ -31,6 +32,7 @@ class _SparseUNet(nn.Module):
         super().__init__()
         cs = [int(cr * c) for c in CHANNELS]
         self.cs = cs
+        self.num_classes = class_num        # (the scorer sizes its exchange buffers from it before any inference)
         self.stem = ConvNormSequential(*conv_bn_relu(4, cs[0], 3), *conv_bn_relu(cs[0], cs[0], 3))
         for i in range(1, 5):          # encoder: stride-2 conv then two residual blocks
             setattr(self, 'stage%d' % i, nn.Sequential(
@@ -63,6 +65,9 @@ class MinkUNet(_SparseUNet):
         self.weight_initialization()
 
     def forward(self, x):
+        out = planned_forward(self, x)              # training: the whole pass as one launch plan (network/plan.py)
+        if out is not None:
+            return out
         g = getattr(x, 'geometry', None)            # tables built ahead of the features (network/geometry.py)
         if g is not None:
             x, _ = g.enter(x, 'MinkUNet')
@@ -99,6 +104,9 @@ class SPVCNN(_SparseUNet):
     POINT_STRIDES = (1, 16, 4)
 
     def forward(self, x):
+        out = planned_forward(self, x)              # training: the whole pass as one launch plan (network/plan.py)
+        if out is not None:
+            return out
         g = getattr(x, 'geometry', None)            # tables built ahead of the features (network/geometry.py)
         if g is not None:
             x0, z = g.enter(x, 'SPVCNN')

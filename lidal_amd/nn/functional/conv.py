@@ -94,6 +94,16 @@ class KernelMap:
         self._total = None
         self._order_out = None
         self._order_in = None
+        self._owner = None                   # weakref to the network.geometry.Geometry that built the map ahead, if any
+
+    def check_alive(self):
+        """A map built ahead on a second stream lives until its prefetcher's fence (network/geometry.py): a backward pass
+        queued later than the contract allows would read memory that may already serve another build -- refuse it."""
+        g = self._owner() if self._owner is not None else None
+        if g is not None and not g.alive():
+            raise RuntimeError('lidal_amd: this backward pass reads the coordinate tables of a geometry that is stale -- two '
+                               'newer ones have been submitted to its prefetcher since (queue forward AND backward of a '
+                               'batch before the second submit() after its own: network/geometry.py GeometryPrefetcher)')
 
     def _build_rules(self):
         if self._rules is None:
@@ -270,8 +280,11 @@ def prefetch_kernel_maps(x, plan, transposed=True):
         strides = [tuple(c << (l + 1) for c in cur) for l in range(len(downs))]
         if not any(st in x.cmaps for st in strides):
             from .downsample import downsample_pyramid
-            for st, c in zip(strides, downsample_pyramid(coords, len(downs), cur)):
-                x.cmaps[st] = c
+            try:
+                for st, c in zip(strides, downsample_pyramid(coords, len(downs), cur)):
+                    x.cmaps[st] = c
+            except ValueError:          # a batch index >= 8192 / coordinates the packed key cannot hold: the level-by-level
+                pass                    # path below (F.spdownsample: batch < 32768) takes over
     # ... and with every level's coordinates known, all kernel maps in one chain of launches
     todo, keys_todo = [], []
     c_, cur_ = coords, cur
@@ -575,6 +588,7 @@ def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=N
     no other consumer -- the data-gradient launch then also leaves that BatchNorm's backward sums per tile
     on grad_in (`_lidal_bnb_sums`, for norm.train_backward): bf16, no channel padding, no grad_skip.
     Shared by ConvolutionFunction and the fused block Functions of lidal_amd.network."""
+    kmap.check_alive()
     g = grad_output.contiguous().to(x.dtype)
     n_in, n_out = kmap.sizes
     grad_in = grad_w = None

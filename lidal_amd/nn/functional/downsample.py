@@ -49,7 +49,8 @@ def downsample_pyramid(coords, levels, tensor_stride=1):
     """[spdownsample(spdownsample(... coords ...))] for `levels` chained stride-2 / kernel-2 downsamplings
     (the encoder of network/spvcnn.py:28-46), all from one sort of the input voxels and with one host
     round trip for all row counts: a list of `levels` coordinate tensors (views of one buffer), the l-th
-    at tensor stride 2^(l+1) * tensor_stride.  Same rows, same order as the chain."""
+    at tensor stride 2^(l+1) * tensor_stride.  Same rows, same order as the chain.  Raises ValueError for coordinates
+    outside 0 <= x, y, z < 65536 / 0 <= batch < 8192 (checked on the device, reported with the row counts)."""
     tensor_stride = make_ntuple(tensor_stride, ndim=3)
     B.require_gpu(coords)
     assert coords.dtype == torch.int and coords.shape[1] == 4 and 1 <= levels <= 4
@@ -63,4 +64,7 @@ def downsample_pyramid(coords, levels, tensor_stride=1):
                                              levels, B.ptr(out), B.ptr(starts), B.ptr(ws), ws_bytes, B.stream()),
             'downsample')
     st = starts.tolist()
+    if st[-1] < 0:          # the packed sort key has 16 bits per coordinate and 13 for the batch index
+        raise ValueError('lidal_amd: downsample_pyramid needs 0 <= x, y, z < 65536 and 0 <= batch < 8192 (the '
+                         'reference feeds voxel coordinates shifted into [0, full_scale), dataset/sk_dataset.py:156-161)')
     return [out[st[l]:st[l + 1]] for l in range(levels)]

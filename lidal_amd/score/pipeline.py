@@ -31,9 +31,12 @@ class _Inference:
         self.inf_reps, self.autocast = inf_reps, autocast
         self.pos = 0
         self.pf = self.g = None
-        if prefetch and self.order:
+        net = _backbone(model)
+        # (tables ahead of the features only for the networks whose coordinate work the package knows; any other model
+        # with the (logits, feat) contract -- wrapped, compiled, custom -- runs with its tables built in line)
+        if prefetch and self.order and net is not None:
             from ..network import GeometryPrefetcher
-            self.pf = GeometryPrefetcher(model, device=by_id[self.order[0]]['coords'].device)
+            self.pf = GeometryPrefetcher(net, device=by_id[self.order[0]]['coords'].device)
             self.g = self.pf.submit(by_id[self.order[0]]['coords'], grad=False)
 
     def __call__(self, f):
@@ -43,9 +46,39 @@ class _Inference:
                               autocast=self.autocast, geometry=self.g)
         self.pos += 1
         if self.pf is not None:
-            self.g = (self.pf.submit(self.by_id[self.order[self.pos]]['coords'], grad=False)
-                      if self.pos < len(self.order) else None)
+            if self.pos < len(self.order):
+                self.g = self.pf.submit(self.by_id[self.order[self.pos]]['coords'], grad=False)
+            else:                       # the last frame: fence the tables still held and hand them to the device state
+                self.g = None
+                self.pf.close()
         return prob
+
+
+def _backbone(model):
+    """The SPVCNN / MinkUNet behind `model` (itself, or the `.module` of a DistributedDataParallel-style wrapper), or
+    None."""
+    from ..network import SPVCNN, MinkUNet
+    for m in (model, getattr(model, 'module', None)):
+        if isinstance(m, (SPVCNN, MinkUNet)):
+            return m
+    return None
+
+
+def _num_classes(model):
+    """Classes of the model's output, known BEFORE any inference (the halo exchange sizes its receive buffers from it):
+    the attribute the package's networks carry, else the width of a `classifier` head, else SemanticKITTI's 19."""
+    for m in (model, getattr(model, 'module', None)):
+        if m is None:
+            continue
+        n = getattr(m, 'num_classes', None)
+        if isinstance(n, int) and n > 0:
+            return n
+        head = getattr(m, 'classifier', None)
+        if head is not None:
+            last = [c for c in head.modules() if hasattr(c, 'out_features')]
+            if last:
+                return int(last[-1].out_features)
+    return 19
 
 
 def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_thresh=0.1,
@@ -60,7 +93,7 @@ def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_th
     ranks read are inferred first and travel under the inference of the rest; 'allgather' -- every frame to every rank
     (one padded all_gather_into_tensor per array).  Same scores bit for bit.
     prefetch: build each frame's coordinate tables one frame ahead on a second stream (same tables)."""
-    n_class = model.num_classes if hasattr(model, 'num_classes') else 19
+    n_class = _num_classes(model)
     dev = local_frames[0]['world'].device if local_frames else None
     if exchange == 'allgather' or not is_sharded(group):
         probs, worlds = {}, {}

@@ -89,7 +89,12 @@ def needed_frames(n_frames, world_size, rank, nei_num):
     for i in frame_range(n_frames, world_size, rank):
         need.add(i)
         need.update(neighbour_ids(i, n_frames, nei_num))
-    assert all(0 <= f < n_frames for f in need), 'sequence shorter than the neighbour window'
+    if not all(0 <= f < n_frames for f in need):
+        # the reference has the same hole: /root/reference/score/sv_level/LiDAL.py:41-42 shifts the window of a frame
+        # near either end by nei_num without checking the sequence length, and indexes out of range
+        raise RuntimeError('lidal_amd: a sequence of %d frames is shorter than its neighbour window (nei_num %d needs '
+                           'at least %d frames; the reference, score/sv_level/LiDAL.py:41-42, fails on it too)'
+                           % (n_frames, nei_num, nei_num + 1))
     return sorted(need)
 
 

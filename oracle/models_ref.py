@@ -20,6 +20,112 @@ from oracle import tsref
 CS = [32, 32, 64, 128, 256, 256, 128, 96, 96]
 
 
+# ---- bf16 emulation (round 4) -------------------------------------------------------------------------------
+# The benchmarked dtype is "bf16 operands, f32 accumulation": the HIP path STORES every activation and every
+# activation gradient in bf16 and computes between the storage points in f32 / f64.  `emulate_bf16(model)` makes an
+# oracle model (run it in float64) round at exactly those storage points -- forward AND backward -- and nowhere
+# else, so that a bf16 train step of the HIP path can be compared with a reference computation AT ITS OWN
+# PRECISION instead of with an f64 run it cannot match:
+#   * every Conv3d / Linear output, every voxelize / devoxelize output, the logits: rounded (and, in the backward
+#     pass, the gradient arriving at that tensor is rounded: it is the gradient the HIP path stores);
+#   * weights of Conv3d / Linear: rounded on the way into the product (the LDS images are bf16), gradient passed
+#     through unrounded (the weight gradient is accumulated and kept in f32);
+#   * BatchNorm (+ReLU): rounded after the normalisation -- relu(round(x)) == round(relu(x)) -- EXCEPT where the
+#     HIP kernels fuse a sum into the normalising pass and round once: the last BatchNorm of a residual block
+#     (relu(bn2 + shortcut) is one kernel, network/utils.py:171) and the point-branch BatchNorm
+#     (relu(bn(lin)) + devoxelized features, network/spvcnn.py:136,143,151): there the SUM is rounded;
+#   * where the HIP path stores a gradient in bf16 BEFORE autograd would sum it with another one (the shortcut
+#     convolution's input gradient, the point-branch Linear's, each consumer of an encoder level, the
+#     concatenations), `_RoundBwd` rounds on that edge;
+#   * BatchNorm statistics, the loss, the parameter gradients: not rounded (f32 / f64 in the HIP path).
+# All helpers are the identity unless emulation was switched on for the model instance, so the pinned f32 / f64
+# behaviour of this file (tests/golden/make_golden.py) is untouched.
+class _Round(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+_EMULATE = [False]          # set around the forward pass of a model emulate_bf16() was applied to
+
+
+def _rb(x):
+    return _Round.apply(x) if _EMULATE[0] else x
+
+
+def _rb_bwd(x):
+    return _RoundBwd.apply(x) if (_EMULATE[0] and x.requires_grad) else x
+
+
+def _feats(t, fn):
+    """fn applied to the features of a SparseTensor-like `t` (same coordinates and caches), or to a plain tensor."""
+    if torch.is_tensor(t):
+        return fn(t)
+    out = type(t)(fn(t.feats), t.coords, t.stride)
+    out.cmaps, out.kmaps = t.cmaps, t.kmaps
+    return out
+
+
+def emulate_bf16(model):
+    """Switch the bf16 storage emulation on for this model INSTANCE (see above).  Returns the model."""
+    conv_t = type(model.stem[0])
+    bn_t = type(model.stem[1])
+    for m in model.modules():
+        if isinstance(m, (conv_t, nn.Linear)):
+            name = 'kernel' if isinstance(m, conv_t) else 'weight'
+
+            def pre(mod, args, name=name):              # the operand of the product is the bf16-rounded weight
+                w = mod._parameters[name]
+                mod._emul_saved = w
+                del mod._parameters[name]
+                setattr(mod, name, _RoundFwd.apply(w))
+
+            def post(mod, args, out, name=name):
+                delattr(mod, name)
+                mod._parameters[name] = mod._emul_saved
+                del mod._emul_saved
+                return _feats(out, _Round.apply)
+            m.register_forward_pre_hook(pre)
+            m.register_forward_hook(post)
+        elif isinstance(m, (bn_t, nn.BatchNorm1d)) and not getattr(m, '_emul_no_round', False):
+            m.register_forward_hook(lambda mod, args, out: _feats(out, _Round.apply))
+
+    def enter(mod, args):
+        _EMULATE[0] = True
+        x = args[0]
+        return (_feats(x, lambda f: f.detach().to(torch.bfloat16).to(f.dtype)),)        # the stem's operand is bf16
+
+    def leave(mod, args, out):
+        _EMULATE[0] = False
+    model.register_forward_pre_hook(enter)
+    model.register_forward_hook(leave, always_call=True)
+    return model
+
+
 def build_models(ts):
     """-> (MinkUNet class, SPVCNN class) over the torchsparse-like package `ts`."""
     import importlib
@@ -47,9 +153,14 @@ def build_models(ts):
             self.net = nn.Sequential(*_cb(i, o, 3), spnn.ReLU(True), *_cb(o, o, 3))
             self.downsample = nn.Identity() if i == o else nn.Sequential(*_cb(i, o, 1))
             self.relu = spnn.ReLU(True)
+            self.net[4]._emul_no_round = True          # (bf16 emulation: relu(bn2 + shortcut) is rounded as one)
 
         def forward(self, x):
-            return self.relu(self.net(x) + self.downsample(x))
+            if not _EMULATE[0]:
+                return self.relu(self.net(x) + self.downsample(x))
+            # the same expression with the HIP path's bf16 storage points (emulate_bf16 above)
+            skip = x if isinstance(self.downsample, nn.Identity) else self.downsample(_feats(x, _rb_bwd))
+            return _feats(self.relu(self.net(x) + skip), _rb)
 
 
     class _UNet(nn.Module):
@@ -70,16 +181,18 @@ def build_models(ts):
 
         @staticmethod
         def _up(stage, y, skip):
+            if _EMULATE[0]:         # every consumer's gradient is stored (rounded) before autograd sums them
+                return stage[1](_feats(ts.cat([stage[0](y), _feats(skip, _rb_bwd)]), _rb_bwd))
             return stage[1](ts.cat([stage[0](y), skip]))
 
 
     class MinkUNetRef(_UNet):                   # network/minkunet.py:97-122
         def forward(self, x):
             x0 = self.stem(x)
-            x1 = self.stage1(x0)
-            x2 = self.stage2(x1)
-            x3 = self.stage3(x2)
-            x4 = self.stage4(x3)
+            x1 = self.stage1(_feats(x0, _rb_bwd) if _EMULATE[0] else x0)
+            x2 = self.stage2(_feats(x1, _rb_bwd) if _EMULATE[0] else x1)
+            x3 = self.stage3(_feats(x2, _rb_bwd) if _EMULATE[0] else x2)
+            x4 = self.stage4(_feats(x3, _rb_bwd) if _EMULATE[0] else x3)
             y = self._up(self.up1, x4, x3)
             y = self._up(self.up2, y, x2)
             y = self._up(self.up3, y, x1)
@@ -110,7 +223,7 @@ def build_models(ts):
             idx_query = F.sphashquery(F.sphash(_floor_to_stride(z, x.s[0])), F.sphash(x.C))
             ci[x.s] = idx_query
             cc[x.s] = F.spcount(idx_query.int(), x.C.shape[0])
-        out = ts.SparseTensor(F.spvoxelize(z.F, ci[x.s], cc[x.s]), x.C, x.s)
+        out = ts.SparseTensor(_rb(F.spvoxelize(z.F, ci[x.s], cc[x.s])), x.C, x.s)
         out.cmaps, out.kmaps = x.cmaps, x.kmaps
         return out
 
@@ -121,7 +234,7 @@ def build_models(ts):
             idx_query = F.sphashquery(F.sphash(_floor_to_stride(z, x.s[0]), off), F.sphash(x.C))
             z.weights[x.s] = F.calc_ti_weights(z.C, idx_query, scale=x.s[0]).transpose(0, 1).contiguous()
             z.idx_query[x.s] = idx_query.transpose(0, 1).contiguous()
-        out = ts.PointTensor(F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s]), z.C,
+        out = ts.PointTensor(_rb(F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s])), z.C,
                                 idx_query=z.idx_query, weights=z.weights)
         out.additional_features = z.additional_features
         return out
@@ -135,8 +248,12 @@ def build_models(ts):
                 nn.Sequential(nn.Linear(a, b), nn.BatchNorm1d(b), nn.ReLU(True))
                 for a, b in ((cs[0], cs[4]), (cs[4], cs[6]), (cs[6], cs[8]))])
             self.dropout = nn.Dropout(0.3, True)
+            for seq in self.point_transforms:           # (bf16 emulation: relu(bn(lin)) + devoxelized rows is rounded as one)
+                seq[1]._emul_no_round = True
 
         def forward(self, x):
+            if _EMULATE[0]:
+                return self._forward_emulated(x)
             z = ts.PointTensor(x.F, x.C.float())
             x0 = self.stem(initial_voxelize(z, 0.05, 0.05))
             z0 = voxel_to_point(x0, z)
@@ -158,6 +275,32 @@ def build_models(ts):
             y4 = self._up(self.up4, y3, x0)
             z3 = voxel_to_point(y4, z2)
             z3.F = z3.F + self.point_transforms[2](z2.F)
+            return self.classifier(z3.F), z3.F
+
+        def _forward_emulated(self, x):
+            """forward() with the HIP path's bf16 storage points: the point-branch sums rounded once, and the
+            gradient of each consumer of a tensor rounded before autograd sums them."""
+            z = ts.PointTensor(x.F, x.C.float())
+            x0 = self.stem(initial_voxelize(z, 0.05, 0.05))
+            z0 = voxel_to_point(_feats(x0, _rb_bwd), z)
+            x1 = self.stage1(point_to_voxel(x0, z0))
+            x2 = self.stage2(_feats(x1, _rb_bwd))
+            x3 = self.stage3(_feats(x2, _rb_bwd))
+            x4 = self.stage4(_feats(x3, _rb_bwd))
+            z1 = voxel_to_point(x4, z0)
+            z1.F = _rb(z1.F + self.point_transforms[0](_rb_bwd(z0.F)))
+            y1 = point_to_voxel(x4, z1)
+            y1.F = self.dropout(y1.F)
+            y1 = self._up(self.up1, y1, x3)
+            y2 = self._up(self.up2, y1, x2)
+            z2 = voxel_to_point(y2, z1)
+            z2.F = _rb(z2.F + self.point_transforms[1](_rb_bwd(z1.F)))
+            y3 = point_to_voxel(y2, z2)
+            y3.F = self.dropout(y3.F)
+            y3 = self._up(self.up3, y3, x1)
+            y4 = self._up(self.up4, y3, x0)
+            z3 = voxel_to_point(y4, z2)
+            z3.F = _rb(z3.F + self.point_transforms[2](_rb_bwd(z2.F)))
             return self.classifier(z3.F), z3.F
 
     return MinkUNetRef, SPVCNNRef

@@ -22,7 +22,7 @@ def main():
     for s in LB.SOURCES:
         if s in srcs:
             obj = os.path.join(OUT, 'obj_' + name, s + '.o')
-            cmd = ['hipcc'] + LB.FLAGS + flags + (['-ffp-contract=off'] if s in LB.NO_CONTRACT else []) + \
+            cmd = ['hipcc'] + LB.FLAGS + LB.NO_PACKED_F32 + flags + (['-ffp-contract=off'] if s in LB.NO_CONTRACT else []) + \
                   (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', os.path.join(LB.CSRC, s), '-o', obj]
             subprocess.run(cmd, check=True)
         else:

@@ -78,7 +78,7 @@ glue.F.ti_weights_and_index = _spy
 if os.environ.get('STREAM_PRIORITY') is not None:
     from lidal_amd.network import geometry as _geo
     _geo._STATE[torch.cuda.current_device()] = {
-        'stream': torch.cuda.Stream(device=dev, priority=int(os.environ['STREAM_PRIORITY'])), 'held': []}
+        'stream': torch.cuda.Stream(device=dev, priority=int(os.environ['STREAM_PRIORITY'])), 'orphans': []}
 pf = GeometryPrefetcher(model)
 print('second stream priority', pf.stream.priority)
 g2 = pf.submit(coords2)

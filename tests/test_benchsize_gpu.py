@@ -147,6 +147,68 @@ def test_train_step_at_bench_size_matches_oracle(name, one_scan):
         assert abs(cos - cos_own) <= 0.04 and abs(ratio - ratio_own) <= 0.08, (k, report[k], report_own[k])
 
 
+@pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
+def test_bf16_train_step_matches_the_bf16_emulating_oracle(name, one_scan):
+    """The benchmarked dtype against a reference AT ITS OWN PRECISION (round 4): the oracle model run in float64 with
+    every activation and activation gradient rounded to bf16 exactly where the HIP path stores bf16
+    (oracle/models_ref.py emulate_bf16: conv / Linear / voxel-exchange outputs, BatchNorm outputs, the fused
+    relu(bn + shortcut) and point-branch sums rounded once, bf16 weight operands, f32 weight gradients).  What is
+    left between the two runs is the accumulation arithmetic between storage points (f32 MFMA / f32 tile
+    statistics against float64) -- no longer the 2^-9 per stored element that separates either run from the plain
+    f64 run (kept below as information).  One ~120 k-point scan (~83 k voxels), whole train step."""
+    from lidal_amd.network import SPVCNN, MinkUNet
+    from lidal_amd.train_step import forward_backward
+    from oracle import tsref
+    from oracle.models_ref import MinkUNetRef, SPVCNNRef, emulate_bf16
+    from weights import fill_state_dict
+    coords, feats, labels = one_scan
+    torch.set_num_threads(min(32, max(torch.get_num_threads(), (__import__('os').cpu_count() or 8))))
+    ref_cls = {'spvcnn': SPVCNNRef, 'minkunet': MinkUNetRef}[name]
+    keys = GKEYS + (['point_transforms.1.0.weight'] if name == 'spvcnn' else [])
+
+    def oracle(emulate):
+        model = fill_state_dict(ref_cls(19)).double().train()
+        if hasattr(model, 'dropout'):
+            model.dropout.p = 0.0
+        if emulate:
+            emulate_bf16(model)
+        logits, _ = model(tsref.SparseTensor(feats.clone().double(), coords.clone()))
+        loss = torch.nn.functional.cross_entropy(logits, labels, ignore_index=255, reduction='mean')
+        loss.backward()
+        named = dict(model.named_parameters())
+        return loss.item(), logits.detach(), {k: named[k].grad.detach().double() for k in keys if k in named}
+
+    loss_e, logits_e, g_e = oracle(True)
+    loss_64, logits_64, g_64 = oracle(False)
+    assert torch.equal(logits_e, logits_e.to(torch.bfloat16).double())          # the emulation really stores bf16
+    model = fill_state_dict({'spvcnn': SPVCNN, 'minkunet': MinkUNet}[name](19)).to(DEV).train()
+    if hasattr(model, 'dropout'):
+        model.dropout.p = 0.0
+    loss, logits = forward_backward(model, feats.to(DEV), coords.to(DEV), labels.to(DEV), autocast=True)
+    named = dict(model.named_parameters())
+    grads = {k: named[k].grad.double().cpu() for k in g_e}
+    logits = logits.detach().double().cpu()
+
+    def report_of(gr, ref):
+        rep = {}
+        for k in ref:
+            cos = ((gr[k] * ref[k]).sum() / (gr[k].norm() * ref[k].norm())).item()
+            rep[k] = (round(cos, 5), round(gr[k].norm().item() / ref[k].norm().item(), 4))
+        return rep
+    ulp = float(logits_e.abs().max()) * 2.0 ** -8           # one bf16 ulp at the largest logit
+    d_emul = float((logits - logits_e).abs().max())
+    d_f64 = float((logits - logits_64).abs().max())
+    rep_e, rep_64 = report_of(grads, g_e), report_of(grads, g_64)
+    print(name, 'bf16 HIP vs bf16-emulating oracle: loss %.6f / %.6f, max |dlogit| %.2f ulp (vs f64 oracle %.2f ulp)'
+          % (loss.item(), loss_e, d_emul / ulp, d_f64 / ulp))
+    print(name, '  gradients vs emulating oracle (cosine, |g| ratio):', rep_e)
+    print(name, '  gradients vs plain f64 oracle  (information)     :', rep_64)
+    assert abs(loss.item() - loss_e) < 1e-3 * abs(loss_e), (loss.item(), loss_e)
+    assert d_emul <= 4 * ulp, (d_emul / ulp, d_f64 / ulp)
+    for k, (cos, ratio) in rep_e.items():
+        assert cos >= 0.999 and abs(ratio - 1) <= 0.02, (k, rep_e, rep_64)
+
+
 def _f64_wgrad(a, b, pairs, koff, a_col, k):
     ko = koff.cpu().tolist()
     ref = torch.zeros(k, a.shape[1], b.shape[1], dtype=torch.float64, device=a.device)

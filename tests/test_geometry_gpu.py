@@ -159,6 +159,61 @@ def test_a_stale_prefetched_geometry_is_refused():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('planned', [True, False])
+def test_a_backward_pass_over_a_stale_geometry_is_refused(planned):
+    """The lifetime contract covers the BACKWARD pass too: two forwards, then two backwards (held graphs, micro-batch
+    accumulation) queue the first backward after two later submits -- its tables may already serve another build.
+    Refused with an error, on the planned step and on the per-operator path alike, not raced."""
+    from lidal_amd import SparseTensor
+    from lidal_amd.network import GeometryPrefetcher, plan
+    from lidal_amd.nn.functional.fused import cross_entropy
+    torch.manual_seed(0)
+    model = _models()['minkunet'](19).to(DEV).train()
+    (f0, c0, l0), (f1, c1, l1) = _batches(2)
+    saved = plan.ENABLED
+    plan.ENABLED = planned
+    try:
+        pf = GeometryPrefetcher(model)
+        g0 = pf.submit(c0)
+        x = SparseTensor(f0, c0)
+        x.geometry = g0
+        loss0 = cross_entropy(model(x)[0], l0)
+        g1 = pf.submit(c1)
+        x = SparseTensor(f1, c1)
+        x.geometry = g1
+        loss1 = cross_entropy(model(x)[0], l1)
+        loss1.backward()                # one newer submission at most: fine
+        pf.submit(c1)
+        with pytest.raises(RuntimeError, match='stale'):
+            loss0.backward()
+        pf.drain()
+    finally:
+        plan.ENABLED = saved
+    torch.cuda.synchronize()
+
+
+def test_prefetchers_of_one_device_do_not_age_each_other():
+    """Ages and fences are per prefetcher: a scorer's prefetcher run between a training loop's submit and its step must
+    not make the loop's geometry stale (round 3 kept the held list per device)."""
+    from lidal_amd import SparseTensor
+    from lidal_amd.network import GeometryPrefetcher
+    torch.manual_seed(0)
+    model = _models()['minkunet'](19).to(DEV).eval()
+    (f0, c0, _), (f1, c1, _) = _batches(2)
+    a, b = GeometryPrefetcher(model), GeometryPrefetcher(model)
+    g = a.submit(c0)
+    for _ in range(3):
+        b.submit(c1)
+    with torch.no_grad():
+        x = SparseTensor(f0, c0)
+        x.geometry = g
+        model(x)
+    b.close()
+    a.drain()
+    del a, b
+    torch.cuda.synchronize()
+
+
 def _tables(g):
     """(path, tensor) of every table of a geometry; the rule lists up to their true length."""
     out, seen = [], set()

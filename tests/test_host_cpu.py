@@ -28,6 +28,40 @@ def test_library_exports_every_declared_symbol():
     assert B.lib().lidal_last_error() is not None
 
 
+def test_plan_operation_kinds_match_the_header_and_the_prototypes():
+    """The launch plans (lidal_plan_run): lidal_amd/network/plan.py's operation kinds are the header's enum, and
+    every kind takes exactly the arguments of the entry point it stands for (prototype minus the stream); a plan
+    with an unknown kind or a truncated operation is refused before anything is launched (no GPU needed)."""
+    import array
+    from lidal_amd import backend as B
+    from lidal_amd.network import plan
+    header = open(os.path.join(ROOT, 'include', 'lidal_amd.h')).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r'LIDAL_OP_([A-Z0-9_]+) = (\d+)', header))
+    assert len(enum) >= 27
+    mine = {k[3:]: v for k, v in vars(plan).items() if k.startswith('OP_') and isinstance(v, int)}
+    assert mine == enum
+    L = B.lib()
+    protos = {}
+    for m in re.finditer(r'\b(?:int|int64_t)\s+lidal_([a-z0-9_]+)\s*\(([^)]*)\)\s*;', header):
+        protos[m.group(1)] = len([a for a in m.group(2).split(',') if a.strip() and a.strip() != 'void'])
+    for name, kind in enum.items():
+        n = L.lidal_plan_op_args(kind)
+        if name in ('FORK_SIDE', 'JOIN_SIDE'):
+            assert n == 0
+        else:
+            assert n == protos[name.lower()] - 1, (name, n, protos[name.lower()])
+            assert n == len(B.SIGNATURES['lidal_' + name.lower()][1]) - 1
+    assert L.lidal_plan_op_args(0) == -1 and L.lidal_plan_op_args(999) == -1
+    bad = array.array('q', [999, 0, 0])
+    assert L.lidal_plan_run(bad.buffer_info()[0], 3, 1, None, None) != 0
+    assert b'unknown kind' in L.lidal_last_error()
+    short = array.array('q', [plan.OP_COPY2D, 0, 0])
+    assert L.lidal_plan_run(short.buffer_info()[0], 3, 1, None, None) != 0
+    assert b'truncated' in L.lidal_last_error()
+    empty = array.array('q', [0])
+    assert L.lidal_plan_run(empty.buffer_info()[0], 0, 0, None, None) == 0
+
+
 def test_operators_have_no_cpu_fallback():
     from lidal_amd.nn import functional as F
     c = torch.zeros((4, 4), dtype=torch.int)

@@ -210,21 +210,14 @@ int lidal_ti_weights(const float* coords, int cstride, const int64_t* idx, int64
                      float* w, int32_t* idx32, void* stream);
 
 /* ---- sparse convolution ---------------------------------------------------------------------- */
-/* Weight re-layout (+ optional cast): W [k][ci][co] -> Wt [k][co][ci] in wt_dtype; when wc is
- * not NULL it also receives W cast to wt_dtype in the ORIGINAL layout (the data-gradient operand
- * of lidal_conv_apply), from the same read. */
-int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void* wc, int wt_dtype, int k,
-                           int ci, int co, void* stream);
 /* replaces backend.convolution_forward_cuda and the data-gradient half of
  * convolution_backward_cuda (every spnn.Conv3d.forward/backward, 49 per model pass).
  * Output-stationary fused gather-GEMM with register accumulators:
- *     out[row(j), :] = sum_k  in[ nbr[kk][j], : ] * Wk[k]^T,   kk = kflip ? K-1-k : k
- * with Wk laid out [k][co][ci] (reduction dim contiguous), nbr i32 [k, n_out] (-1 = no rule) and
- * row(j) = perm ? perm[j] : j  (pass lidal_kmap_order's perm together with its permuted table and,
- * optionally, its tile_masks, which spare the kernel the mask derivation and the index slices of
- * absent offsets).  n_in = rows of `in` (every nbr entry is < n_in; in and Wk are addressed with
- * 32-bit byte offsets, so each must stay below 2 GiB).  No atomics: each output row is written
- * exactly once => bitwise reproducible.
+ *     out[row(j), :] = sum_k  in[ nbr[kk][j], : ] * W[k],   kk = kflip ? K-1-k : k
+ * with nbr i32 [k, n_out] (-1 = no rule) and row(j) = perm ? perm[j] : j  (pass lidal_kmap_order's perm together
+ * with its permuted table and its tile_masks, which spare the kernel the offsets a tile has no rule for).
+ * n_in = rows of `in` (every nbr entry is < n_in; in and the weights are addressed with 32-bit byte offsets, so
+ * each must stay below 2 GiB).  No atomics: each output row is written exactly once => bitwise reproducible.
  * Optional epilogue (inference: the eval-mode spnn.BatchNorm and ReLU that follow the conv in
  * network/utils.py:110-114,147-155): ep_scale / ep_shift f32 [co] (both or neither; see
  * lidal_bn_fold) give out = act(acc * scale + shift), act = ReLU iff (ep_relu & 1); ep_residual
@@ -232,25 +225,22 @@ int lidal_conv_weight_pack(const void* w, int w_dtype, void* wt, void* wc, int w
  * point-branch sum network/spvcnn.py:136,143,151; the shortcut of a residual block,
  * network/utils.py:171, whose ReLU comes AFTER the sum: ep_relu & 2).  With k = 1 and nbr = NULL
  * (the identity rule list) the same kernel is the dense per-row product of the 1x1x1 convolutions
- * and nn.Linear layers. */
-int lidal_conv_apply(const void* in, const void* wk, const int32_t* nbr, const int32_t* perm,
-                     const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out, int ci,
-                     int co, int k, int kflip, int dtype, const float* ep_scale,
-                     const float* ep_shift, int ep_relu, const void* ep_residual, void* stream);
-/* Second-generation form of lidal_conv_apply (csrc/conv_img.hip): the same contraction with the
- * weights supplied as LDS IMAGES -- every slab (offset, column block, reduction slice) laid out in
- * global memory exactly as the MFMA B-fragment reads want it in LDS, so the kernel stages a slab by
+ * and nn.Linear layers.
+ * (Rounds 1-3 also exported a first generation, lidal_conv_apply + lidal_conv_weight_pack, with plain [k][co][ci]
+ * weights staged through registers; it left the library in round 4 and lives on as a test-only object,
+ * tests/native/conv_gen1.hip, that the kernels below are compared with bit for bit.)
+ * The weights are supplied as LDS IMAGES (csrc/conv_img.hip) -- every slab (offset, column block, reduction slice)
+ * laid out in global memory exactly as the MFMA B-fragment reads want it in LDS, so the kernel stages a slab by
  * LDS-DMA (no vector registers, no ds_write) and reads it bank-conflict free.
  *   lidal_conv_weight_image_bytes  size of the image of a [k][n_red][n_col] weight for a
  *                                  convolution producing n_out rows (the tiling depends on it)
  *   lidal_conv_weight_image        role 0: w is [k][n_red][n_col] (forward: n_red = ci, n_col = co)
  *                                  role 1: w is [k][n_col][n_red] (data gradient of the same
  *                                  parameter: n_red = co, n_col = ci); casts to `dtype`
- *   lidal_conv_apply_image         arguments as lidal_conv_apply, wimg = the image built for the
+ *   lidal_conv_apply_image         the contraction above; wimg = the image built for the
  *                                  SAME (ci = n_red, co = n_col, k, dtype, n_out); tile_masks are
  *                                  required with a table (nbr == NULL: identity rule list, k = 1);
  *                                  ci must be a multiple of 4 (f32) / 8 (bf16).
- * Results are bitwise those of lidal_conv_apply (same offset and reduction order).
  * tile_stats (NULL or f32 [ceil(n_out / 128)][co][3]): per 128-row tile of the kernel's row order and
  * output column, (count, mean, M2) of the values as stored -- the batch statistics of a train-mode
  * BatchNorm that follows (network/utils.py:115), taken in the epilogue instead of by a pass over the
@@ -471,6 +461,9 @@ enum {
 };
 #define LIDAL_OP_FLAG_SIDE 1
 int lidal_plan_op_args(int kind);
+/* test / debug aid: synchronous copy of `nbytes` of device memory at address `dev` to `host` (a plan names its
+ * buffers by address; tests that replay its operations against the oracle read the operands back with this) */
+int lidal_debug_read(const void* dev, void* host, int64_t nbytes);
 int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_ops, void* stream, void* side_stream);
 
 #ifdef __cplusplus

@@ -65,15 +65,12 @@ SIGNATURES = {
     'lidal_voxelize_fwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
     'lidal_devoxelize_bwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
     'lidal_ti_weights': (_i32, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp]),
-    'lidal_conv_weight_pack': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'lidal_sort_pairs_workspace_bytes': (_i64, [_i64]),
     'lidal_sort_pairs': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     'lidal_sort_pairs_u64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     'lidal_kmap_order_workspace_bytes': (_i64, [_i64]),
     'lidal_kmap_order': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'lidal_kmap_order_batch': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
-    'lidal_conv_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
-                                _vp, _i32, _vp, _vp]),
     'lidal_conv_stats_tile_rows': (_i32, []),
     'lidal_conv_weight_image_bytes': (_i64, [_i32, _i32, _i32, _i32, _i64]),
     'lidal_conv_weight_image_tiling': (_i32, [_i32, _i32, _i32, _i64]),
@@ -120,6 +117,7 @@ SIGNATURES = {
     'lidal_transpose_f32': (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     'lidal_cast_rows_bf16': (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
     'lidal_plan_op_args': (_i32, [_i32]),
+    'lidal_debug_read': (_i32, [_vp, _vp, _i64]),
     'lidal_plan_run': (_i32, [_vp, _i64, _i64, _vp, _vp]),
 }
 

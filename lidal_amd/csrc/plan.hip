@@ -183,6 +183,16 @@ extern "C" int lidal_cast_rows_bf16(const float* src, int c_src, void* dst, int 
   return 0;
 }
 
+// Test / debug aid: a synchronous copy of device memory to the host by ADDRESS -- a launch plan names its buffers by
+// address only (they are carved out of large blocks, not tensors), so a test that replays the plan's operators
+// against the oracle reads their operands back with this.
+extern "C" int lidal_debug_read(const void* dev, void* host, int64_t nbytes) {
+  LIDAL_REQUIRE(dev != nullptr && host != nullptr && nbytes >= 0, "debug_read: bad arguments");
+  LIDAL_HIP(hipDeviceSynchronize());
+  LIDAL_HIP(hipMemcpy(host, dev, (size_t)nbytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // ---- the runner ------------------------------------------------------------------------------------
 namespace {
 

@@ -14,6 +14,37 @@ __all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point', 'initial_tabl
 
 
 
+import os as _os
+_L0_ORDER = _os.environ.get('LIDAL_L0_ORDER', 'hash')
+
+
+def _part1by2(v):
+    v = v & 0x1FFFFF
+    v = (v | (v << 32)) & 0x1F00000000FFFF
+    v = (v | (v << 16)) & 0x1F0000FF0000FF
+    v = (v | (v << 8)) & 0x100F00F00F00F00F
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3
+    v = (v | (v << 2)) & 0x1249249249249249
+    return v
+
+
+def _morton_renumber(idx_query, counts, coords):
+    """Level-0 voxel rows re-ordered by (batch, Morton(x, y, z)) instead of by coordinate hash (torch ops: an experiment)."""
+    c = coords.long()
+    key = (c[:, 3] << 48) | _part1by2(c[:, 0] >> _MORTON_SHIFT) | (_part1by2(c[:, 1] >> _MORTON_SHIFT) << 1) \
+        | (_part1by2(c[:, 2] >> _MORTON_SHIFT) << 2)
+    perm = torch.argsort(key, stable=True)              # sorted position -> old row
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=perm.device)
+    new_idx = inv[idx_query]
+    if getattr(idx_query, '_lidal_one_to_one', False):
+        new_idx._lidal_one_to_one = True
+    return new_idx, counts[perm].contiguous(), coords[perm].contiguous()
+
+
+_MORTON_SHIFT = int(_os.environ.get('LIDAL_MORTON_SHIFT', '0'))
+
+
 def _floor_to_stride(z, s):
     """(floor(xyz / s).int() * s, batch.int()) as one int32 [N,4] tensor (utils.py:44-47,72-75)."""
     c = z.C
@@ -60,6 +91,8 @@ def initial_tables(z, init_res, after_res):
         if floored is None:
             floored = floored_int.float()
         inserted_coords = torch.round(F.spvoxelize(floored, idx_query, counts)).int()
+    if _L0_ORDER == 'morton':       # EXPERIMENT (scripts/exp): renumber the level-0 voxels along a Z-order curve
+        idx_query, counts, inserted_coords = _morton_renumber(idx_query, counts, inserted_coords)
     z.additional_features['idx_query'][1] = idx_query
     z.additional_features['counts'][1] = counts
     z.additional_features['init_coords'] = inserted_coords     # the rows that index refers to

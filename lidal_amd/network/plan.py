@@ -56,6 +56,11 @@ COUNTERS = {'ops': 0, 'plans': 0}
 # tests: also count the operations of every plan in backend.HITS under the names the per-operator path counts them
 # (walks the words in Python: off in production)
 TALLY = os.environ.get('LIDAL_PLAN_TALLY', '0') != '0'
+# tests: a list -> every training run appends itself when its backward pass has been queued, keeps the words of its
+# plans (`tapes`: (phase, words) per lidal_plan_run call) and does NOT give its memory back, so that a test can
+# replay every operation against the oracle on the operation's own stored operands (tests/test_teacher_forced_gpu.py);
+# the test calls run.release() when it is done
+TRACE = None
 _NARGS = {}
 _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
               6: 'bn_train_fwd', 7: 'bn_bwd', 8: 'bn_bwd', 9: 'bn_eval_fwd', 10: 'bn_fold', 11: 'colsum',
@@ -96,10 +101,12 @@ def _dbits(x):
 # ---- memory --------------------------------------------------------------------------------------------
 class _Arena:
     """Bump allocation out of a few large blocks of torch's caching allocator: an activation is an address,
-    not a tensor.  Blocks have one size (the allocator re-uses them exactly, step after step, whatever the
-    row counts of the step are); a buffer of more than a quarter block gets a block of its own, rounded up to
-    8 MiB."""
-    BLOCK = 256 << 20
+    not a tensor.  Blocks have ONE size -- 1 GiB: a 5-scan step's activations are three of them, 288 GB of HBM
+    do not notice the slack -- so the allocator re-uses them exactly, step after step, whatever the row counts of
+    the step are (per-activation tensors of ever-changing sizes fragment its pools: the reserved bytes of a
+    never-repeating input stream kept growing).  A buffer of more than a quarter block gets a block of its own,
+    rounded up to 64 MiB."""
+    BLOCK = int(os.environ.get('LIDAL_PLAN_BLOCK_MB', '1024')) << 20
 
     def __init__(self, device):
         self.device = device
@@ -109,7 +116,7 @@ class _Arena:
     def alloc(self, nbytes):
         nbytes = (nbytes + 255) & -256
         if nbytes > (self.BLOCK >> 2):
-            size = (nbytes + (8 << 20) - 1) & -(8 << 20)
+            size = (nbytes + (64 << 20) - 1) & -(64 << 20)
             t = torch.empty(size, dtype=torch.uint8, device=self.device)
             a = t.data_ptr()
             self.blocks.append((a, size, t))
@@ -160,15 +167,15 @@ def _scratch(device, stream, nbytes, keep):
 # ---- the program: the model as flat records --------------------------------------------------------------
 class _Conv:
     __slots__ = ('w', 'k', 'ci', 'co', 'transposed', 'strided', 'shape', 'role', 'pad_in', 'img_f', 'img_b', 'tkey',
-                 'param')
+                 'param', 'ptrs')
 
 
 class _BN:
-    __slots__ = ('w', 'b', 'rm', 'rv', 'nbt', 'c', 'eps', 'mom', 'relu')
+    __slots__ = ('w', 'b', 'rm', 'rv', 'nbt', 'c', 'eps', 'mom', 'relu', 'mod', 'scale', 'shift')
 
 
 class _Lin:
-    __slots__ = ('conv', 'b', 'ci', 'co', 'co_pad')
+    __slots__ = ('conv', 'b', 'ci', 'co', 'co_pad', 'bias')
 
 
 class _Res:
@@ -208,6 +215,7 @@ class _Program:
             c.pad_in = pad_in
             c.img_f = c.img_b = 0
             c.tkey = None
+            c.ptrs = {}
             assert m.bias is None and m.bn_follows
             self.convs.append(c)
             return c
@@ -221,6 +229,8 @@ class _Program:
             r.c = m.num_features
             r.eps, r.mom = _dbits(m.eps), _dbits(m.momentum)
             r.relu = int(bool(relu))
+            r.mod = m
+            r.scale = r.shift = 0
             assert bool(m.fused_relu) == bool(relu)
             self.bns.append((r, m))
             return r
@@ -252,9 +262,11 @@ class _Program:
             c.pad_in = 0
             c.img_f = c.img_b = 0
             c.tkey = None
+            c.ptrs = {}
             self.convs.append(c)
             r.conv = c
             r.b = self._p(m.bias)
+            r.bias = m.bias
             r.ci, r.co = c.ci, c.co
             r.co_pad = c.co
             assert bool(m.bn_follows) == bool(stats)
@@ -308,31 +320,56 @@ class _Program:
         self.buffers.append(t)
         return len(self.params) + len(self.buffers) - 1
 
-    def valid(self):
+    def valid(self, train=True):
         """Is the model still the one this program was compiled from, in the configuration the plan covers?
         (Parameters can be re-assigned, cast, moved or frozen, buffers are REPLACED by Module._apply, modules can be
-        put in eval mode: checked every step, ~50 us.)"""
+        put in eval / train mode one by one: checked every step, ~50 us.)"""
         f32 = torch.float32
         dev = self.params[0].device
-        return (all(m._parameters.get(k) is p and p.dtype is f32 and p.requires_grad and p.device == dev
-                    for m, k, p in self.where)
-                and all(m._buffers.get(k) is t for m, k, t in self.where_buf)
-                and all(m.training and m.track_running_stats for m in self.bn_modules)
-                and dev.type == 'cuda')
+        if not (dev.type == 'cuda'
+                and all(m._parameters.get(k) is p and p.dtype is f32 and p.device == dev for m, k, p in self.where)
+                and all(m._buffers.get(k) is t for m, k, t in self.where_buf)):
+            return False
+        if train:
+            return (all(p.requires_grad for p in self.params)
+                    and all(m.training and m.track_running_stats for m in self.bn_modules))
+        return not any(m.training for m in self.bn_modules) and all(m.track_running_stats for m in self.bn_modules)
+
+    def eval_operands(self, dev):
+        """Inference: the folded BatchNorm maps (blocks._fold: cached on the modules) and the point-branch shifts
+        `shift + bias * scale` (dense.py _forward) of the current parameters -- addresses, recomputed only when a
+        parameter or buffer has changed (version counters, weight epoch)."""
+        from .blocks import _fold
+        stamp = (B.WEIGHT_EPOCH[0], str(dev)) + tuple(t._version for t in self.tensors)
+        if getattr(self, '_eval_stamp', None) == stamp:
+            return
+        self._eval_keep = []
+        for r, m in self.bns:
+            sc, sh = _fold(m, dev)
+            r.scale, r.shift = sc.data_ptr(), sh.data_ptr()
+            self._eval_keep += [sc, sh]
+        self._point_shift = []
+        for lin, r in self.points:
+            sc, sh = _fold(r.mod, dev)
+            t = sh + lin.bias.detach().float() * sc
+            self._eval_keep.append(t)
+            self._point_shift.append(t.data_ptr())
+        self._eval_stamp = stamp
 
 
-def _program(model):
+def _program(model, train=True):
     """The compiled program of `model`, or None if the model is not in the planned configuration."""
     prog = model.__dict__.get('_lidal_program')
-    if prog is not None and prog.valid():
+    if prog is not None and prog.valid(train):
         return prog
     try:
-        ok = all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() and p.requires_grad
-                 for p in model.parameters())
+        ok = all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() for p in model.parameters())
         for m in model.modules():
             if isinstance(m, torch.nn.BatchNorm1d):
-                ok = ok and m.track_running_stats and m.momentum is not None and m.affine and m.training
+                ok = ok and m.track_running_stats and m.momentum is not None and m.affine
         prog = _Program(model) if ok else None
+        if prog is not None and not prog.valid(train):
+            return None                 # (compiled, but not in this mode's configuration right now)
     except (AssertionError, AttributeError, KeyError):
         prog = None
     model.__dict__['_lidal_program'] = prog
@@ -340,18 +377,27 @@ def _program(model):
 
 
 def plannable(model, x):
-    """Is this forward pass the standard training configuration the plan covers?  (Anything else runs the
-    per-operator path: same results, one Python call per operator.)"""
+    """'train' / 'eval' if this forward pass is one of the two standard configurations the plans cover (a training
+    step with gradients; inference under no_grad in eval mode), else None.  (Anything else runs the per-operator
+    path: same results, one Python call per operator.)"""
     from . import blocks
-    if not (ENABLED and model.training and torch.is_grad_enabled() and blocks.FUSE_BLOCKS and B.FORK == 15):
-        return False
+    if not ENABLED:
+        return None
+    if model.training and torch.is_grad_enabled():
+        if not (blocks.FUSE_BLOCKS and B.FORK == 15):
+            return None
+        mode = 'train'
+    elif not model.training and not torch.is_grad_enabled():
+        mode = 'eval'
+    else:
+        return None
     f = x.F
     if not (torch.is_tensor(f) and f.is_cuda and f.dtype == torch.float32 and f.dim() == 2 and f.shape[1] == 4
             and f.is_contiguous() and not f.requires_grad and f.shape[0] > 1 and tuple(x.s) == (1, 1, 1)):
-        return False
+        return None
     if torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') != torch.bfloat16:
-        return False
-    return _program(model) is not None
+        return None
+    return mode if _program(model, mode == 'train') is not None else None
 
 
 # ---- one step ---------------------------------------------------------------------------------------------
@@ -393,7 +439,7 @@ def _seg_ws(n_entries, m, c):
 class _Tables:
     """The addresses a step reads out of its Geometry, gathered once per geometry."""
 
-    def __init__(self, g, spvcnn):
+    def __init__(self, g, spvcnn, train):
         x0 = g.x0
         km, cm = x0.kmaps, x0.cmaps
         self.n = []
@@ -407,14 +453,14 @@ class _Tables:
             k3 = km[(st, (3, 3, 3), (1, 1, 1), (1, 1, 1))]
             oo = k3.order_out
             self.k3.append((oo.table.data_ptr(), oo.perm.data_ptr(), oo.tile_masks.data_ptr(),
-                            k3._nbmaps_cap.data_ptr(), k3.koff.data_ptr()))
+                            k3._nbmaps_cap.data_ptr() if train else 0, k3.koff.data_ptr() if train else 0))
             self.keep.append(k3)
             if l < 4:
                 k2 = km[(st, (2, 2, 2), (2, 2, 2), (1, 1, 1))]
                 oo, oi = k2.order_out, k2.order_in
                 self.k2.append((oo.table.data_ptr(), oo.perm.data_ptr(), oo.tile_masks.data_ptr(),
                                 oi.table.data_ptr(), oi.perm.data_ptr(), oi.tile_masks.data_ptr(),
-                                k2._nbmaps_cap.data_ptr(), k2.koff.data_ptr()))
+                                k2._nbmaps_cap.data_ptr() if train else 0, k2.koff.data_ptr() if train else 0))
                 self.keep.append(k2)
         self.pt = {}
         self.p = 0
@@ -439,22 +485,24 @@ class _Tables:
                 s = 1 << l
                 idx8, w8 = z.idx_query[(s, s, s)], z.weights[(s, s, s)]
                 assert idx8.dtype == torch.int32 and idx8.is_contiguous() and w8.dtype == torch.float32
-                do, dsp = inverse_lists(idx8, m, w8)
+                do, dsp = inverse_lists(idx8, m, w8) if train else (idx8, idx8)     # (backward only)
                 cnt = counts if counts.dtype == torch.int32 and counts.is_contiguous() else counts.contiguous().int()
                 self.keep += [idx32, cnt, idx8, w8, do, dsp]
                 self.pt[l] = (idx32.data_ptr(), cnt.data_ptr(), int(one), vorder, vseg,
                               idx8.data_ptr(), w8.data_ptr(), do.data_ptr(), dsp.data_ptr())
 
 
-def _tables(g, spvcnn):
-    t = g.__dict__.get('_plan_tables')
+def _tables(g, spvcnn, train):
+    key = '_plan_tables_train' if train else '_plan_tables'
+    t = g.__dict__.get(key) or (g.__dict__.get('_plan_tables_train') if not train else None)
     if t is None:
-        t = g.__dict__['_plan_tables'] = _Tables(g, spvcnn)
+        t = g.__dict__[key] = _Tables(g, spvcnn, train)
     return t
 
 
 class _Run:
     """One training step: the forward plan, what it saved, the backward plan."""
+    TRAIN = True
 
     def __init__(self, model, prog, geometry, feats, code):
         self.prog = prog
@@ -466,7 +514,7 @@ class _Run:
         self.bf16 = code == B.BF16
         self.dtype = torch.bfloat16 if self.bf16 else torch.float32
         self.geometry = geometry
-        self.T = _tables(geometry, prog.spvcnn)
+        self.T = _tables(geometry, prog.spvcnn, self.TRAIN)
         self.feats = feats
         self.stream = B.stream()
         self.arena = _Arena(self.dev)
@@ -477,6 +525,7 @@ class _Run:
         self.saved = {}
         self.noise = []
         self.keep = []
+        self.tapes = [] if (TRACE is not None and self.TRAIN) else None
         self.w = []
         self.nops = 0
         self.done = False
@@ -508,21 +557,28 @@ class _Run:
         prog, T = self.prog, self.T
         bank = _C._IMAGE_BANK
         code, dtype = self.code, self.dtype
-        todo = []
+        first = None
         for c, (nf, nb) in self._conv_rows():
             key = (_C._tiling(c.ci, c.co, code, nf), _C._tiling(c.co, c.ci, code, nb), code)
-            if c.tkey != key:
-                todo.append((c, nf, nb, key))
-        for c, nf, nb, key in todo:
-            e_f, e_b = bank.get(c.param, dtype, nf, nb, c.shape if (c.role or c.k == 1) else None, c.role)
-            c.img_f, c.img_b, c.tkey = e_f.data_ptr(), e_b.data_ptr(), key
-        # (bank.get rebuilds every stale image of the group with one launch the first time it meets one; when no
-        # layer needed registering, ask for the rebuild directly)
-        first = prog.convs[0]
-        e = bank.entries.get(id(first.param))
-        if e is None or e['version'] != B.weights_key(first.param):
-            if e is None:
-                raise RuntimeError('lidal_amd.plan: weight image bank lost an entry')
+            e = c.tkey.get(key) if c.tkey else None
+            if e is None or e['ref']() is not c.param or bank.entries.get((id(c.param), e['key'])) is not e:
+                bank.get(c.param, dtype, nf, nb, c.shape if (c.role or c.k == 1) else None, c.role)
+                e = bank.entry(c.param, key)
+                if c.tkey is None or len(c.tkey) > 8:
+                    c.tkey = {}
+                c.tkey[key] = e
+                c.ptrs = {}
+            p = c.ptrs.get(key)
+            if p is None:
+                p = c.ptrs[key] = (e['img_f'].data_ptr(), e['img_b'].data_ptr())
+            c.img_f, c.img_b = p
+            e['used'] = bank.tick
+            if first is None:
+                first = (e, c.param)
+        # one launch rebuilds every stale image of the group (bank.get does it when it meets a stale entry; when no
+        # layer needed registering, ask for it here)
+        e, w = first
+        if e['version'] != B.weights_key(w):
             bank._rebuild(e['group'])
 
     def _conv_rows(self):
@@ -556,6 +612,8 @@ class _Run:
             return
         if TALLY:
             _tally(self.w)
+        if self.tapes is not None:
+            self.tapes.append(('bwd' if self.barena is not None else 'fwd', list(self.w)))
         arr = array.array('q', self.w)
         addr, n_words = arr.buffer_info()
         L = B.lib_handle()
@@ -759,7 +817,8 @@ class _Run:
             feat, rows = y, n[0]
         logits, co_pad = self.f_classifier(feat, rows)
         self.flush()
-        torch.autograd.graph.increment_version(prog.running)
+        if self.TRAIN:                      # (the kernels wrote the running statistics through raw pointers)
+            torch.autograd.graph.increment_version(prog.running)
         self.c_feat = c_out
         logits_t = A.tensor(logits, (rows, co_pad), self.dtype)[:, :prog.n_class]
         feat_t = A.tensor(feat, (rows, c_out), self.dtype)
@@ -1003,12 +1062,23 @@ class _Run:
         self.b_conv_bn(prog.stem[0], gy, prog.stem[0][0].co, n[0], n[0], k3[0], False, 8 if self.bf16 else 4)
         self.flush()
         self.done = True
-        # the activations (and this pass's gradients) go back to the allocator: every kernel that reads them is queued
+        self.flat_t = None
+        if self.tapes is not None and TRACE is not None:         # (a test replays the plan: it releases the memory)
+            self.flat_t = flat
+            TRACE.append(self)
+        else:
+            self.release()
+        return self._grads(flat)
+
+    def release(self):
+        """The activations (and the backward pass's gradients) go back to the allocator: every kernel that reads
+        them is queued."""
         self.arena.release()
-        self.barena.release()
+        if self.barena is not None:
+            self.barena.release()
         self.saved = {}
         self.noise = []
-        return self._grads(flat)
+        self.flat_t = None
 
     def _grads(self, flat):
         prog = self.prog
@@ -1022,6 +1092,69 @@ class _Run:
             for i, p in enumerate(prog.params):
                 views[i] = flat[prog.slot[i]:prog.slot[i] + p.numel()].view(p.shape)
         return views
+
+
+class _EvalRun(_Run):
+    """One inference pass (score/prob_inference.py:97-99 under model.eval() / no_grad) as ONE plan: every
+    Conv3d -> BatchNorm (-> ReLU) is one kernel with the folded BatchNorm map in its epilogue, a residual block's sum
+    and final ReLU ride in its last convolution, the point-branch sum in the Linear's epilogue -- the launches of
+    blocks.ConvNormSequential's inference path, same arguments, nothing saved."""
+    TRAIN = False
+
+    def __init__(self, model, prog, geometry, feats, code):
+        prog.eval_operands(feats.device)
+        _Run.__init__(self, model, prog, geometry, feats, code)
+
+    def _constants(self):
+        prog = self.prog
+        if prog.ones is None or prog.ones.device != self.dev:
+            prog.ones = torch.ones(512, dtype=torch.float32, device=self.dev)
+            prog.cls_shift = torch.zeros(64, dtype=torch.float32, device=self.dev)
+        self.ones = prog.ones.data_ptr()
+        self.cls_shift = prog.cls_shift.data_ptr()
+
+    def f_conv_bn(self, cb, x, n_in, table, n_out, ci=None):
+        c, r = cb
+        out = self.arena.alloc(n_out * c.co * self.esz)
+        self.w += (OP_CONV_APPLY_IMAGE, x, c.img_f, table[0], table[1], table[2], out, n_in, n_out,
+                   c.ci if ci is None else ci, c.co, c.k, 0, self.code, r.scale, r.shift, r.relu, 0, 0)
+        self.nops += 1
+        return out
+
+    def f_res(self, r, x, n, table):
+        A, e = self.arena, self.esz
+        skip = x
+        if r.cs is not None:
+            skip = A.alloc(n * r.cs.co * e)
+            self.w += (OP_CONV_APPLY_IMAGE, x, r.cs.img_f, 0, 0, 0, skip, n, n, r.cs.ci, r.cs.co, 1, 0, self.code,
+                       r.bs.scale, r.bs.shift, 0, 0, 0)
+            self.nops += 1
+        y1 = A.alloc(n * r.c1.co * e)
+        out = A.alloc(n * r.c2.co * e)
+        self.w += (OP_CONV_APPLY_IMAGE, x, r.c1.img_f, table[0], table[1], table[2], y1, n, n, r.c1.ci, r.c1.co, r.c1.k,
+                   0, self.code, r.b1.scale, r.b1.shift, 1, 0, 0,
+                   OP_CONV_APPLY_IMAGE, y1, r.c2.img_f, table[0], table[1], table[2], out, n, n, r.c2.ci, r.c2.co,
+                   r.c2.k, 0, self.code, r.b2.scale, r.b2.shift, 2, skip, 0)
+        self.nops += 2
+        return out
+
+    def f_point(self, pt, z_in, devox_out):
+        lin, r = pt
+        P = self.T.p
+        out = self.arena.alloc(P * lin.co * self.esz)
+        shift = self.prog._point_shift[self.prog.points.index(pt)]
+        self.w += (OP_CONV_APPLY_IMAGE, z_in, lin.conv.img_f, 0, 0, 0, out, P, P, lin.ci, lin.co, 1, 0, self.code,
+                   r.scale, shift, 1, devox_out, 0)
+        self.nops += 1
+        return out
+
+    def f_dropout(self, addr, n, c):
+        return
+
+    def forward(self):
+        out = _Run.forward(self)
+        self.saved = {}
+        return out
 
 
 class _PlannedNet(torch.autograd.Function):
@@ -1044,18 +1177,22 @@ class _PlannedNet(torch.autograd.Function):
 
 
 def planned_forward(model, x):
-    """model(x) in training as one planned autograd node, or None when the configuration is not the planned one."""
-    if not plannable(model, x):
+    """model(x) as launch plans -- a training step as one planned autograd node, an inference pass (eval mode,
+    no_grad) as one plan -- or None when the configuration is not a planned one."""
+    mode = plannable(model, x)
+    if mode is None:
         return None
     from .geometry import Geometry
     g = getattr(x, 'geometry', None)
     if g is None:
-        g = Geometry.build(model, x.C, True)
+        g = Geometry.build(model, x.C, mode == 'train')
     else:
         g.admit(x, type(model).__name__)
-        if not g.grad:
+        if mode == 'train' and not g.grad:
             return None
     prog = model.__dict__['_lidal_program']
     code = B.BF16 if B.compute_dtype(x.F) == torch.bfloat16 else B.F32
+    if mode == 'eval':
+        return _EvalRun(model, prog, g, x.F, code).forward()
     run = _Run(model, prog, g, x.F, code)
     return _PlannedNet.apply(run, *prog.params)

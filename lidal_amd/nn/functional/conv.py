@@ -394,39 +394,62 @@ class _ImageBank:
     call `backend._bump_epoch()` after it."""
 
     def __init__(self):
-        self.entries = {}           # id(weight) -> entry dict
+        self.entries = {}           # (id(weight), key) -> entry dict; key = (storage, dtypes, the two tilings, role)
         self.serial = 0             # entries are told apart by a serial number (id()s get re-used)
         self.tables = {}            # (device, code, w_code) -> (signature, device table, n_jobs, total)
+    KEEP = 8                        # an entry nobody asked for during the last KEEP weight epochs (backward passes) is dropped
+
+    @property
+    def tick(self):
+        return B.WEIGHT_EPOCH[0]
 
     def get(self, weight, dtype, n_out_fwd, n_out_bwd, shape=None, role=0):
         """`shape` = (k, ci, co) of the operand when `weight` is not [k, ci, co] itself: a [ci, co]
-        1x1x1 kernel (role 0) or nn.Linear's [co, ci] weight (role 1)."""
+        1x1x1 kernel (role 0) or nn.Linear's [co, ci] weight (role 1).
+        A weight may have several entries at a time, one per pair of tilings its row counts have selected
+        recently (sizes that change from batch to batch straddle the tiling thresholds of a few layers): all of
+        them ride in the same launch, none is rebuilt for being asked under another tiling."""
         import weakref
         k, ci, co = shape if shape is not None else weight.shape
         code = B.dtype_code(dtype)
         L = B.lib()
         key = (weight.data_ptr(), code, weight.dtype, _tiling(ci, co, code, n_out_fwd), _tiling(co, ci, code, n_out_bwd), role)
-        e = self.entries.get(id(weight))
-        if e is None or e['ref']() is not weight or e['key'] != key:
+        ekey = (id(weight), key)
+        e = self.entries.get(ekey)
+        if e is None or e['ref']() is not weight:
             nf = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out_fwd)
             nb = L.lidal_conv_weight_image_bytes(k, co, ci, code, n_out_bwd)
             buf = torch.empty(nf + nb, dtype=torch.uint8, device=weight.device)
-            wid = id(weight)
             self.serial += 1
-            e = {'ref': weakref.ref(weight, lambda _r, wid=wid: self.entries.pop(wid, None)), 'key': key,
+            wid = id(weight)
+
+            def gone(_r, wid=wid):
+                for kk in [kk for kk in self.entries if kk[0] == wid]:
+                    self.entries.pop(kk, None)
+            e = {'ref': weakref.ref(weight, gone), 'key': key,
                  'serial': self.serial,
                  'buf': buf, 'img_f': buf[:nf], 'img_b': buf[nf:], 'version': -1, 'code': code,
-                 'n_out': (n_out_fwd, n_out_bwd), 'shape': (k, ci, co), 'role': role,
+                 'n_out': (n_out_fwd, n_out_bwd), 'shape': (k, ci, co), 'role': role, 'used': self.tick,
                  'group': (str(weight.device), code, B.dtype_code(weight.dtype))}
-            self.entries[wid] = e
+            self.entries[ekey] = e
+        e['used'] = self.tick
         if e['version'] != B.weights_key(weight):
             self._rebuild(e['group'])
         return e['img_f'], e['img_b']
+
+    def entry(self, weight, tkey):
+        """The entry of `weight` under the tilings / dtype `tkey` = (tiling_fwd, tiling_bwd, code), or None."""
+        for kk, e in self.entries.items():
+            if kk[0] == id(weight) and (kk[1][3], kk[1][4], kk[1][1]) == tkey and e['ref']() is weight:
+                return e
+        return None
 
     def _rebuild(self, group):
         """All stale images of `group` in one launch."""
         L = B.lib()
         stale = []
+        for kk in [kk for kk, e in self.entries.items() if e['used'] < self.tick - self.KEEP]:
+            del self.entries[kk]
         for e in self.entries.values():
             w = e['ref']()
             if w is not None and e['group'] == group and e['version'] != B.weights_key(w):

@@ -22,21 +22,18 @@ CS = [32, 32, 64, 128, 256, 256, 128, 96, 96]
 
 # ---- bf16 emulation (round 4) -------------------------------------------------------------------------------
 # The benchmarked dtype is "bf16 operands, f32 accumulation": the HIP path STORES every activation and every
-# activation gradient in bf16 and computes between the storage points in f32 / f64.  `emulate_bf16(model)` makes an
-# oracle model (run it in float64) round at exactly those storage points -- forward AND backward -- and nowhere
-# else, so that a bf16 train step of the HIP path can be compared with a reference computation AT ITS OWN
-# PRECISION instead of with an f64 run it cannot match:
-#   * every Conv3d / Linear output, every voxelize / devoxelize output, the logits: rounded (and, in the backward
-#     pass, the gradient arriving at that tensor is rounded: it is the gradient the HIP path stores);
-#   * weights of Conv3d / Linear: rounded on the way into the product (the LDS images are bf16), gradient passed
-#     through unrounded (the weight gradient is accumulated and kept in f32);
-#   * BatchNorm (+ReLU): rounded after the normalisation -- relu(round(x)) == round(relu(x)) -- EXCEPT where the
-#     HIP kernels fuse a sum into the normalising pass and round once: the last BatchNorm of a residual block
-#     (relu(bn2 + shortcut) is one kernel, network/utils.py:171) and the point-branch BatchNorm
-#     (relu(bn(lin)) + devoxelized features, network/spvcnn.py:136,143,151): there the SUM is rounded;
-#   * where the HIP path stores a gradient in bf16 BEFORE autograd would sum it with another one (the shortcut
-#     convolution's input gradient, the point-branch Linear's, each consumer of an encoder level, the
-#     concatenations), `_RoundBwd` rounds on that edge;
+# activation gradient in bf16 and computes between the storage points in f32 / f64.  Its fused kernels round exactly
+# as the separate operators would (a sum fused into a BatchNorm or into a convolution epilogue first rounds the
+# summand it produced, csrc/bn.hip bn_apply_kernel, csrc/conv_img.hip store_tile, csrc/voxel.hip), which is why they
+# are bitwise the per-operator path -- so the emulation is simply: ROUND THE OUTPUT OF EVERY OPERATOR, forward and
+# backward.  `emulate_bf16(model)` makes an oracle model (run it in float64) do that:
+#   * every Conv3d / Linear / BatchNorm output, every voxelize / devoxelize output, every sum (residual block,
+#     point branch), the logits: rounded; in the backward pass the gradient arriving at that tensor is rounded (the
+#     sum over its consumers, as the HIP path stores it);
+#   * the gradient each Conv3d / Linear / BatchNorm / voxelize / devoxelize hands to its input is rounded when it
+#     leaves the operator (before autograd adds another consumer's to it);
+#   * weights of Conv3d / Linear: rounded on the way into the product (the LDS images are bf16), their gradient
+#     passed through unrounded (accumulated and kept in f32);
 #   * BatchNorm statistics, the loss, the parameter gradients: not rounded (f32 / f64 in the HIP path).
 # All helpers are the identity unless emulation was switched on for the model instance, so the pinned f32 / f64
 # behaviour of this file (tests/golden/make_golden.py) is untouched.
@@ -94,6 +91,13 @@ def emulate_bf16(model):
     """Switch the bf16 storage emulation on for this model INSTANCE (see above).  Returns the model."""
     conv_t = type(model.stem[0])
     bn_t = type(model.stem[1])
+    res_t = type(model.stage1[1])
+
+    def edge(mod, args):                                # the gradient this operator hands to its input: rounded
+        return (_feats(args[0], _rb_bwd),) + tuple(args[1:])
+
+    def stored(mod, args, out):                         # the operator's output: rounded (and the gradient arriving at it)
+        return _feats(out, _Round.apply)
     for m in model.modules():
         if isinstance(m, (conv_t, nn.Linear)):
             name = 'kernel' if isinstance(m, conv_t) else 'weight'
@@ -103,6 +107,7 @@ def emulate_bf16(model):
                 mod._emul_saved = w
                 del mod._parameters[name]
                 setattr(mod, name, _RoundFwd.apply(w))
+                return edge(mod, args)
 
             def post(mod, args, out, name=name):
                 delattr(mod, name)
@@ -111,8 +116,11 @@ def emulate_bf16(model):
                 return _feats(out, _Round.apply)
             m.register_forward_pre_hook(pre)
             m.register_forward_hook(post)
-        elif isinstance(m, (bn_t, nn.BatchNorm1d)) and not getattr(m, '_emul_no_round', False):
-            m.register_forward_hook(lambda mod, args, out: _feats(out, _Round.apply))
+        elif isinstance(m, (bn_t, nn.BatchNorm1d)):
+            m.register_forward_pre_hook(edge)
+            m.register_forward_hook(stored)
+        elif isinstance(m, res_t):                      # relu(net(x) + shortcut(x)): the sum is an operator output
+            m.register_forward_hook(stored)
 
     def enter(mod, args):
         _EMULATE[0] = True
@@ -153,14 +161,9 @@ def build_models(ts):
             self.net = nn.Sequential(*_cb(i, o, 3), spnn.ReLU(True), *_cb(o, o, 3))
             self.downsample = nn.Identity() if i == o else nn.Sequential(*_cb(i, o, 1))
             self.relu = spnn.ReLU(True)
-            self.net[4]._emul_no_round = True          # (bf16 emulation: relu(bn2 + shortcut) is rounded as one)
 
         def forward(self, x):
-            if not _EMULATE[0]:
-                return self.relu(self.net(x) + self.downsample(x))
-            # the same expression with the HIP path's bf16 storage points (emulate_bf16 above)
-            skip = x if isinstance(self.downsample, nn.Identity) else self.downsample(_feats(x, _rb_bwd))
-            return _feats(self.relu(self.net(x) + skip), _rb)
+            return self.relu(self.net(x) + self.downsample(x))
 
 
     class _UNet(nn.Module):
@@ -181,18 +184,18 @@ def build_models(ts):
 
         @staticmethod
         def _up(stage, y, skip):
-            if _EMULATE[0]:         # every consumer's gradient is stored (rounded) before autograd sums them
-                return stage[1](_feats(ts.cat([stage[0](y), _feats(skip, _rb_bwd)]), _rb_bwd))
+            if _EMULATE[0]:         # bf16 emulation: the gradient of the concatenation (the sum over its consumers) is stored
+                return stage[1](_feats(ts.cat([stage[0](y), skip]), _rb_bwd))
             return stage[1](ts.cat([stage[0](y), skip]))
 
 
     class MinkUNetRef(_UNet):                   # network/minkunet.py:97-122
         def forward(self, x):
             x0 = self.stem(x)
-            x1 = self.stage1(_feats(x0, _rb_bwd) if _EMULATE[0] else x0)
-            x2 = self.stage2(_feats(x1, _rb_bwd) if _EMULATE[0] else x1)
-            x3 = self.stage3(_feats(x2, _rb_bwd) if _EMULATE[0] else x2)
-            x4 = self.stage4(_feats(x3, _rb_bwd) if _EMULATE[0] else x3)
+            x1 = self.stage1(x0)
+            x2 = self.stage2(x1)
+            x3 = self.stage3(x2)
+            x4 = self.stage4(x3)
             y = self._up(self.up1, x4, x3)
             y = self._up(self.up2, y, x2)
             y = self._up(self.up3, y, x1)
@@ -223,7 +226,7 @@ def build_models(ts):
             idx_query = F.sphashquery(F.sphash(_floor_to_stride(z, x.s[0])), F.sphash(x.C))
             ci[x.s] = idx_query
             cc[x.s] = F.spcount(idx_query.int(), x.C.shape[0])
-        out = ts.SparseTensor(_rb(F.spvoxelize(z.F, ci[x.s], cc[x.s])), x.C, x.s)
+        out = ts.SparseTensor(_rb(F.spvoxelize(_rb_bwd(z.F), ci[x.s], cc[x.s])), x.C, x.s)      # (_rb*: bf16 emulation, else identity)
         out.cmaps, out.kmaps = x.cmaps, x.kmaps
         return out
 
@@ -234,7 +237,7 @@ def build_models(ts):
             idx_query = F.sphashquery(F.sphash(_floor_to_stride(z, x.s[0]), off), F.sphash(x.C))
             z.weights[x.s] = F.calc_ti_weights(z.C, idx_query, scale=x.s[0]).transpose(0, 1).contiguous()
             z.idx_query[x.s] = idx_query.transpose(0, 1).contiguous()
-        out = ts.PointTensor(_rb(F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s])), z.C,
+        out = ts.PointTensor(_rb(F.spdevoxelize(_rb_bwd(x.F), z.idx_query[x.s], z.weights[x.s])), z.C,
                                 idx_query=z.idx_query, weights=z.weights)
         out.additional_features = z.additional_features
         return out
@@ -248,12 +251,8 @@ def build_models(ts):
                 nn.Sequential(nn.Linear(a, b), nn.BatchNorm1d(b), nn.ReLU(True))
                 for a, b in ((cs[0], cs[4]), (cs[4], cs[6]), (cs[6], cs[8]))])
             self.dropout = nn.Dropout(0.3, True)
-            for seq in self.point_transforms:           # (bf16 emulation: relu(bn(lin)) + devoxelized rows is rounded as one)
-                seq[1]._emul_no_round = True
 
         def forward(self, x):
-            if _EMULATE[0]:
-                return self._forward_emulated(x)
             z = ts.PointTensor(x.F, x.C.float())
             x0 = self.stem(initial_voxelize(z, 0.05, 0.05))
             z0 = voxel_to_point(x0, z)
@@ -262,45 +261,19 @@ def build_models(ts):
             x3 = self.stage3(x2)
             x4 = self.stage4(x3)
             z1 = voxel_to_point(x4, z0)
-            z1.F = z1.F + self.point_transforms[0](z0.F)
+            z1.F = _rb(z1.F + self.point_transforms[0](z0.F))       # (_rb: bf16 emulation, else identity)
             y1 = point_to_voxel(x4, z1)
             y1.F = self.dropout(y1.F)
             y1 = self._up(self.up1, y1, x3)
             y2 = self._up(self.up2, y1, x2)
             z2 = voxel_to_point(y2, z1)
-            z2.F = z2.F + self.point_transforms[1](z1.F)
+            z2.F = _rb(z2.F + self.point_transforms[1](z1.F))
             y3 = point_to_voxel(y2, z2)
             y3.F = self.dropout(y3.F)
             y3 = self._up(self.up3, y3, x1)
             y4 = self._up(self.up4, y3, x0)
             z3 = voxel_to_point(y4, z2)
-            z3.F = z3.F + self.point_transforms[2](z2.F)
-            return self.classifier(z3.F), z3.F
-
-        def _forward_emulated(self, x):
-            """forward() with the HIP path's bf16 storage points: the point-branch sums rounded once, and the
-            gradient of each consumer of a tensor rounded before autograd sums them."""
-            z = ts.PointTensor(x.F, x.C.float())
-            x0 = self.stem(initial_voxelize(z, 0.05, 0.05))
-            z0 = voxel_to_point(_feats(x0, _rb_bwd), z)
-            x1 = self.stage1(point_to_voxel(x0, z0))
-            x2 = self.stage2(_feats(x1, _rb_bwd))
-            x3 = self.stage3(_feats(x2, _rb_bwd))
-            x4 = self.stage4(_feats(x3, _rb_bwd))
-            z1 = voxel_to_point(x4, z0)
-            z1.F = _rb(z1.F + self.point_transforms[0](_rb_bwd(z0.F)))
-            y1 = point_to_voxel(x4, z1)
-            y1.F = self.dropout(y1.F)
-            y1 = self._up(self.up1, y1, x3)
-            y2 = self._up(self.up2, y1, x2)
-            z2 = voxel_to_point(y2, z1)
-            z2.F = _rb(z2.F + self.point_transforms[1](_rb_bwd(z1.F)))
-            y3 = point_to_voxel(y2, z2)
-            y3.F = self.dropout(y3.F)
-            y3 = self._up(self.up3, y3, x1)
-            y4 = self._up(self.up4, y3, x0)
-            z3 = voxel_to_point(y4, z2)
-            z3.F = _rb(z3.F + self.point_transforms[2](_rb_bwd(z2.F)))
+            z3.F = _rb(z3.F + self.point_transforms[2](z2.F))
             return self.classifier(z3.F), z3.F
 
     return MinkUNetRef, SPVCNNRef

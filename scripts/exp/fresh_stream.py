@@ -21,3 +21,20 @@ steps = int(os.environ.get('STEPS', '60'))
 res = bench.bench_fresh_stream(dev, 'spvcnn', 'bf16', frames, 120000, steps)
 res.pop('what')
 print(os.environ.get('ALLOC', 'default'), json.dumps(res))
+st = torch.cuda.memory_stats(dev)
+print({k: (st[k] >> 20) for k in ('reserved_bytes.large_pool.current', 'reserved_bytes.small_pool.current',
+                                   'active_bytes.all.peak', 'inactive_split_bytes.all.current',
+                                   'reserved_bytes.all.peak')}, 'MB;',
+      {k: st[k] for k in ('segment.large_pool.current', 'segment.small_pool.current', 'num_alloc_retries')})
+
+print({k: (st[k] >> 20) for k in ('active_bytes.all.current', 'allocated_bytes.all.current', 'reserved_bytes.all.current')}, 'MB current')
+import collections
+free = collections.Counter()
+used = collections.Counter()
+for seg in torch.cuda.memory_snapshot():
+    for blk in seg['blocks']:
+        (free if blk['state'] == 'inactive' else used)[(seg.get('stream', 0), blk['size'] >> 20)] += 1
+tot_free = sum(k[1] * v for k, v in free.items())
+print('cached free blocks: %d MB in %d blocks; by (stream, MB) x count, largest first:' % (tot_free, sum(free.values())))
+print(sorted(((k[1] * v, k, v) for k, v in free.items()), reverse=True)[:25])
+print('live blocks by (stream, MB):', sorted(((k[1] * v, k, v) for k, v in used.items()), reverse=True)[:15])

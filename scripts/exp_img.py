@@ -10,6 +10,17 @@ import sys
 import numpy as np
 import torch
 
+
+def _gen1():
+    """tests/native/liblidal_gen1.so: the first-generation kernel left the product library in round 4."""
+    import ctypes, os
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'native', 'liblidal_gen1.so'))
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    lib.lidal_conv_apply.restype = i32
+    lib.lidal_conv_apply.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
+    return lib
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'scripts'))
@@ -55,7 +66,7 @@ def run_pair(x, w_kio, tab, prm, tmk, n, dtype, k=27):
     o2 = torch.empty((n, co), dtype=dtype, device=x.device)
 
     def v1():
-        B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wt), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(o1),
+        B.check(_gen1().lidal_conv_apply(B.ptr(x), B.ptr(wt), B.ptr(tab), B.ptr(prm), B.ptr(tmk), B.ptr(o1),
                                          n, n, ci, co, k, 0, B.dtype_code(dtype), None, None, 0, None,
                                          B.stream()), 'v1')
 

@@ -8,6 +8,17 @@ import sys
 import numpy as np
 import torch
 
+
+def _gen1():
+    """tests/native/liblidal_gen1.so: the first-generation kernel left the product library in round 4."""
+    import ctypes, os
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'native', 'liblidal_gen1.so'))
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    lib.lidal_conv_apply.restype = i32
+    lib.lidal_conv_apply.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
+    return lib
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'scripts'))
@@ -37,7 +48,7 @@ def main():
             out = torch.empty((n, co), dtype=dtype, device=dev)
 
             def conv():
-                B.check(B.lib().lidal_conv_apply(B.ptr(x), B.ptr(wt), B.ptr(o.table), B.ptr(o.perm),
+                B.check(_gen1().lidal_conv_apply(B.ptr(x), B.ptr(wt), B.ptr(o.table), B.ptr(o.perm),
                                                  B.ptr(o.tile_masks), B.ptr(out), n, n, ci, co, 27, 0,
                                                  B.dtype_code(dtype), None, None, 0, None, B.stream()), 'conv')
             gw = torch.empty((27, ci, co), dtype=torch.float32, device=dev)

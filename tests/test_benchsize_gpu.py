@@ -149,13 +149,27 @@ def test_train_step_at_bench_size_matches_oracle(name, one_scan):
 
 @pytest.mark.parametrize('name', ['spvcnn', 'minkunet'])
 def test_bf16_train_step_matches_the_bf16_emulating_oracle(name, one_scan):
-    """The benchmarked dtype against a reference AT ITS OWN PRECISION (round 4): the oracle model run in float64 with
-    every activation and activation gradient rounded to bf16 exactly where the HIP path stores bf16
-    (oracle/models_ref.py emulate_bf16: conv / Linear / voxel-exchange outputs, BatchNorm outputs, the fused
-    relu(bn + shortcut) and point-branch sums rounded once, bf16 weight operands, f32 weight gradients).  What is
-    left between the two runs is the accumulation arithmetic between storage points (f32 MFMA / f32 tile
-    statistics against float64) -- no longer the 2^-9 per stored element that separates either run from the plain
-    f64 run (kept below as information).  One ~120 k-point scan (~83 k voxels), whole train step."""
+    """The benchmarked dtype against a reference AT ITS OWN PRECISION (round 4): the oracle model with every
+    activation and activation gradient rounded to bf16 exactly where the HIP path stores bf16 (oracle/models_ref.py
+    emulate_bf16: conv / Linear / voxel-exchange outputs, BatchNorm outputs, the fused relu(bn + shortcut) and
+    point-branch sums rounded once, each consumer's gradient rounded before autograd sums them, bf16 weight operands,
+    f32 weight gradients).  One ~120 k-point scan (~83 k voxels), whole train step.
+
+    Forward: loss within 1e-3, every logit within 4 bf16 ulps of the largest logit.
+
+    Gradients -- the FINDING of this test.  Two runs of the emulating oracle ITSELF that differ only in the arithmetic
+    BETWEEN the storage points (float64 against float32 accumulation, or float32 with the rows permuted) already
+    disagree on the deep parameters at cosine 0.93-0.99 (|g| within 2-9 %), hardly closer than either is to the plain
+    f64 run; permuting the rows under float64 changes nothing (cosine 1.00000).  With bf16 storage a last-bit
+    difference of an accumulation flips the rounding of a few stored elements by a whole bf16 ulp, and the randomly
+    initialised 49-layer train-mode-BatchNorm net amplifies that like any other perturbation: no implementation whose
+    f32 sums run in another order than its reference's can reach cosine 0.999 end to end, the reference against
+    itself included.  So the end-to-end gradient bar is calibrated on the reference's own spread (two samples of a
+    chaotic quantity: a factor of four, floors 1e-4 / 3 %) -- a sanity bound, not the parity statement; the last
+    layers (nothing upstream to amplify) are held to cosine 0.999 / 1 %.  The parity statement for the bf16 kernels
+    inside the whole step is tests/test_teacher_forced_gpu.py: every stored tensor of the SAME step against the
+    emulating reference operator applied to the step's own stored inputs, where nothing amplifies.  The distance to the
+    plain f64 run is printed as information."""
     from lidal_amd.network import SPVCNN, MinkUNet
     from lidal_amd.train_step import forward_backward
     from oracle import tsref
@@ -166,21 +180,24 @@ def test_bf16_train_step_matches_the_bf16_emulating_oracle(name, one_scan):
     ref_cls = {'spvcnn': SPVCNNRef, 'minkunet': MinkUNetRef}[name]
     keys = GKEYS + (['point_transforms.1.0.weight'] if name == 'spvcnn' else [])
 
-    def oracle(emulate):
-        model = fill_state_dict(ref_cls(19)).double().train()
+    def oracle(dt, emulate, perm=None):
+        model = fill_state_dict(ref_cls(19)).to(dt).train()
         if hasattr(model, 'dropout'):
             model.dropout.p = 0.0
         if emulate:
             emulate_bf16(model)
-        logits, _ = model(tsref.SparseTensor(feats.clone().double(), coords.clone()))
-        loss = torch.nn.functional.cross_entropy(logits, labels, ignore_index=255, reduction='mean')
+        c, f, lab = (coords, feats, labels) if perm is None else (coords[perm], feats[perm], labels[perm])
+        logits, _ = model(tsref.SparseTensor(f.clone().to(dt), c.clone()))
+        loss = torch.nn.functional.cross_entropy(logits, lab, ignore_index=255, reduction='mean')
         loss.backward()
         named = dict(model.named_parameters())
-        return loss.item(), logits.detach(), {k: named[k].grad.detach().double() for k in keys if k in named}
+        return loss.item(), logits.detach().double(), {k: named[k].grad.detach().double() for k in keys if k in named}
 
-    loss_e, logits_e, g_e = oracle(True)
-    loss_64, logits_64, g_64 = oracle(False)
+    loss_e, logits_e, g_e = oracle(torch.float64, True)
     assert torch.equal(logits_e, logits_e.to(torch.bfloat16).double())          # the emulation really stores bf16
+    perm = torch.randperm(coords.shape[0], generator=torch.Generator().manual_seed(1))
+    spread = [oracle(torch.float32, True)[2], oracle(torch.float32, True, perm)[2]]
+    g_64 = oracle(torch.float64, False)[2]
     model = fill_state_dict({'spvcnn': SPVCNN, 'minkunet': MinkUNet}[name](19)).to(DEV).train()
     if hasattr(model, 'dropout'):
         model.dropout.p = 0.0
@@ -189,24 +206,22 @@ def test_bf16_train_step_matches_the_bf16_emulating_oracle(name, one_scan):
     grads = {k: named[k].grad.double().cpu() for k in g_e}
     logits = logits.detach().double().cpu()
 
-    def report_of(gr, ref):
-        rep = {}
-        for k in ref:
-            cos = ((gr[k] * ref[k]).sum() / (gr[k].norm() * ref[k].norm())).item()
-            rep[k] = (round(cos, 5), round(gr[k].norm().item() / ref[k].norm().item(), 4))
-        return rep
+    def dist(a, ref):                           # (1 - cosine, | |a| / |ref| - 1 |), whole tensors
+        return (1.0 - ((a * ref).sum() / (a.norm() * ref.norm())).item(), abs(a.norm().item() / ref.norm().item() - 1.0))
     ulp = float(logits_e.abs().max()) * 2.0 ** -8           # one bf16 ulp at the largest logit
     d_emul = float((logits - logits_e).abs().max())
-    d_f64 = float((logits - logits_64).abs().max())
-    rep_e, rep_64 = report_of(grads, g_e), report_of(grads, g_64)
-    print(name, 'bf16 HIP vs bf16-emulating oracle: loss %.6f / %.6f, max |dlogit| %.2f ulp (vs f64 oracle %.2f ulp)'
-          % (loss.item(), loss_e, d_emul / ulp, d_f64 / ulp))
-    print(name, '  gradients vs emulating oracle (cosine, |g| ratio):', rep_e)
-    print(name, '  gradients vs plain f64 oracle  (information)     :', rep_64)
+    print(name, 'bf16 HIP vs bf16-emulating oracle: loss %.6f / %.6f, max |dlogit| %.2f ulp' % (loss.item(), loss_e, d_emul / ulp))
     assert abs(loss.item() - loss_e) < 1e-3 * abs(loss_e), (loss.item(), loss_e)
-    assert d_emul <= 4 * ulp, (d_emul / ulp, d_f64 / ulp)
-    for k, (cos, ratio) in rep_e.items():
-        assert cos >= 0.999 and abs(ratio - 1) <= 0.02, (k, rep_e, rep_64)
+    assert d_emul <= 4 * ulp, d_emul / ulp
+    print(name, '  %-30s %-22s %-22s %s' % ('parameter: (1-cos, |g| dev)', 'HIP ~ emulation(f64)', 'emulation(f32) ~ (f64)', 'HIP ~ plain f64'))
+    for k in g_e:
+        hip = dist(grads[k], g_e[k])
+        ref = (max(dist(g[k], g_e[k])[0] for g in spread), max(dist(g[k], g_e[k])[1] for g in spread))
+        info = dist(grads[k], g_64[k])
+        print(name, '  %-30s %.1e %.1e        %.1e %.1e        %.1e %.1e' % (k, hip[0], hip[1], ref[0], ref[1], info[0], info[1]))
+        if k in ('classifier.0.weight', 'up4.1.1.net.3.kernel'):        # the last layers: little depth to amplify
+            assert hip[0] <= 1e-3 and hip[1] <= 0.01, (k, hip)
+        assert hip[0] <= 4 * ref[0] + 1e-4 and hip[1] <= 4 * ref[1] + 3e-2, (k, hip, ref)
 
 
 def _f64_wgrad(a, b, pairs, koff, a_col, k):

@@ -662,15 +662,24 @@ def test_dense_epilogue_affine_relu_residual():
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_conv_apply_image_is_bitwise_conv_apply(dtype):
-    """The two generations of the conv kernel through the C-ABI: lidal_conv_apply (weights [k][co][ci]
-    staged through registers, conv.hip) and lidal_conv_apply_image (weights as LDS images moved by
+    """The two generations of the conv kernel through their C-ABIs: lidal_conv_apply (weights [k][co][ci]
+    staged through registers; rounds 1-3 of the library, since round 4 the test-only object
+    tests/native/liblidal_gen1.so) and the shipped lidal_conv_apply_image (weights as LDS images moved by
     LDS-DMA, conv_img.hip) run the same offset and reduction order, so every output bit agrees --
     forward and flipped (data-gradient) walk, epilogue + residual, channel counts off the tile sizes
     (ragged last column block, partial reduction slice), the dense identity form, n_out not a multiple
     of the tile, and a one-row input."""
+    import ctypes
+    import os
     from lidal_amd import backend as B
     F = _F()
     L = B.lib()
+    gen1_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'native', 'liblidal_gen1.so')
+    assert os.path.exists(gen1_path), 'build it with `python tests/native/build.py` (__graft_entry__.build() does)'
+    G1 = ctypes.CDLL(gen1_path)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    G1.lidal_conv_apply.restype = i32
+    G1.lidal_conv_apply.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
     code = B.dtype_code(dtype)
     g = torch.Generator().manual_seed(17)
 
@@ -684,7 +693,7 @@ def test_conv_apply_image_is_bitwise_conv_apply(dtype):
         B.check(L.lidal_conv_weight_image(B.ptr(w_kio), B.dtype_code(w_kio.dtype), 0, B.ptr(img), code, k, ci,
                                           co, n_out, B.stream()), 'image')
         outs = []
-        for fn, wop in ((L.lidal_conv_apply, wt), (L.lidal_conv_apply_image, img)):
+        for fn, wop in ((G1.lidal_conv_apply, wt), (L.lidal_conv_apply_image, img)):
             out = torch.full((n_out, co), float('nan'), dtype=dtype, device=DEV)
             sc, sh, relu, res = ep if ep else (None, None, 0, None)
             tab, prm, tmk = (order.table, order.perm, order.tile_masks) if order is not None else (None,) * 3

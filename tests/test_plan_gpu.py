@@ -187,3 +187,53 @@ def test_feature_output_gradient_flows_through_the_plan():
         plan.ENABLED = saved
     for k, p, q in zip([k for k, _ in a.named_parameters()], *out):
         assert torch.equal(p, q), k
+
+
+@pytest.mark.parametrize('name,autocast', [('spvcnn', True), ('spvcnn', False), ('minkunet', True)])
+def test_planned_inference_is_bitwise_the_per_operator_inference(name, autocast):
+    """The 8-view inference step (score/prob_inference.py:91-113) as ONE plan against the per-operator eval path
+    (blocks.ConvNormSequential: folded BatchNorm epilogues): probabilities, predictions and point features bitwise,
+    with the tables built in line and ahead, before and after the weights change."""
+    from lidal_amd import backend as B
+    from lidal_amd import synth
+    from lidal_amd.network import GeometryPrefetcher, plan
+    from lidal_amd.score.prob_inference import infer_frame
+    torch.manual_seed(4)
+    model = _models()[name](19).to(DEV).eval()
+    for m in model.modules():               # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+    frames = []
+    for i in range(2):
+        seq = synth.make_sequence(1, n_points=9000 + 2000 * i, seed=30 + i)[0]
+        sb = synth.make_score_batch(seq['points'], seq['intensity'], np.random.default_rng(i), inf_reps=8)
+        frames.append(tuple(torch.from_numpy(sb[k]).to(DEV) for k in ('coords_v_b', 'feats_v_b', 'inverse_indices_b')))
+    frames.append(frames[0])                # (sizes seen before: the last frame registers no new weight image)
+    saved = plan.ENABLED, plan.TALLY
+    plan.TALLY = False
+    try:
+        for round_ in range(2):
+            outs = {}
+            for planned in (False, True):
+                plan.ENABLED = planned
+                pf = GeometryPrefetcher(model)
+                res = []
+                for i, (c, f, inv) in enumerate(frames):
+                    g = pf.submit(c, grad=False) if i >= 1 else None
+                    B.HITS.clear()
+                    res.append(infer_frame(model, c, f, inv, 8, autocast=autocast, return_feat=True, geometry=g))
+                    calls = dict(B.HITS)
+                pf.drain()
+                outs[planned] = res
+                assert (calls.get('plan_run', 0) == 1) == planned, calls
+                if planned:
+                    assert sum(calls.values()) <= 3, calls         # the plan, the view mean (+ the images when the weights moved)
+            for a, b in zip(outs[False], outs[True]):
+                for u, v in zip(a, b):
+                    assert torch.equal(u, v)
+            with torch.no_grad():               # the weights move: every cached operand must follow
+                for p in model.parameters():
+                    p.mul_(1.01)
+    finally:
+        plan.ENABLED, plan.TALLY = saved

@@ -204,6 +204,91 @@ def require_gpu(*tensors):
                                'torch.cuda.device(...))' % (t.device, cur))
 
 
+# ---- memory of the coordinate work ------------------------------------------------------------------------
+# The tables a forward pass derives from its coordinates (kernel maps, row orders, hash tables, contributor lists,
+# the voxeliser's outputs) have sizes that follow the batch's voxel counts, and under the reference's per-iteration
+# augmentation (dataset/sk_dataset.py:143-171) no two batches have the same counts: as ~150 torch.empty calls of
+# never-repeating sizes they fragmented the caching allocator's pools (the reserved bytes of a never-repeating input
+# stream kept growing, bench.py variants.fresh_stream).  So the builders ask `empty()` / `workspace()`:
+#   * `empty` carves buffers of 1 MiB or more out of the blocks of the BlockArena that is current (network/geometry.py
+#     gives every Geometry its own: ONE block size, so the allocator re-uses the blocks exactly, whatever the counts;
+#     the tables of a geometry die together, and so do their blocks); without a current arena it rounds the size up to
+#     1/8 .. 1/16 steps of its power of two;
+#   * `workspace` is the scratch of ONE library call (sort buffers, scan partials): a persistent buffer per stream,
+#     grown when a call asks for more (calls of a stream run one after the other).
+_QUANT_MIN = 1 << 20
+_ARENA = [None]
+_WORKSPACE = {}         # (device index, stream) -> uint8 tensor
+
+
+class BlockArena:
+    BLOCK = int(os.environ.get('LIDAL_TABLE_BLOCK_MB', '512')) << 20
+
+    def __init__(self):
+        self.blocks = []
+        self.cur = None
+        self.off = 0
+
+    def take(self, nbytes, device):
+        nbytes = (nbytes + 255) & -256
+        if nbytes > (self.BLOCK >> 1):              # a block of its own, in 64 MiB steps
+            t = torch.empty((nbytes + (64 << 20) - 1) & -(64 << 20), dtype=torch.uint8, device=device)
+            self.blocks.append(t)
+            return t[:nbytes]
+        if self.cur is None or self.off + nbytes > self.BLOCK or self.cur.device != device:
+            self.cur = torch.empty(self.BLOCK, dtype=torch.uint8, device=device)
+            self.blocks.append(self.cur)
+            self.off = 0
+        v = self.cur[self.off:self.off + nbytes]
+        self.off += nbytes
+        return v
+
+
+class use_arena:
+    """with use_arena(arena): the large buffers of the coordinate builders come out of `arena`'s blocks."""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        self.saved = _ARENA[0]
+        _ARENA[0] = self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        _ARENA[0] = self.saved
+        return False
+
+
+def empty(shape, dtype, device):
+    if isinstance(shape, int):
+        shape = (shape,)
+    n = dtype.itemsize
+    for d in shape:
+        n *= d
+    if n < _QUANT_MIN:
+        return torch.empty(shape, dtype=dtype, device=device)
+    arena = _ARENA[0]
+    if arena is not None:
+        return arena.take(n, torch.device(device))[:n].view(dtype).view(shape)
+    q = 1 << (n.bit_length() - 4)
+    return torch.empty((n + q - 1) & -q, dtype=torch.uint8, device=device)[:n].view(dtype).view(shape)
+
+
+def workspace(nbytes, device):
+    """uint8 scratch of at least `nbytes` for ONE library call on the current stream of `device` (valid until the
+    next workspace() request on that stream is used)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx))
+    t = _WORKSPACE.get(key)
+    if t is None or t.numel() < nbytes:
+        size = max(16 << 20, (int(nbytes * 1.25) + (1 << 20)) & -(1 << 20))
+        with torch.cuda.device(idx):
+            t = _WORKSPACE[key] = torch.empty(size, dtype=torch.uint8, device=device)
+    return t
+
+
 def ptr(t):
     """Device address of a tensor (None -> NULL) as a plain int: ctypes converts it for the c_void_p
     argtypes itself, and a step makes ~1300 of these (a c_void_p object each was 0.3 ms per step)."""

@@ -44,14 +44,14 @@ def voxelize_scan(points, intensity, trans_m, rnd, scale=SCALE, full_scale=FULL_
     dev = points.device
     m_dev = torch.from_numpy(np.ascontiguousarray(trans_m, dtype=np.float64).reshape(9)).to(dev)
     r_dev = torch.from_numpy(np.ascontiguousarray(rnd, dtype=np.float64).reshape(6)).to(dev)
-    feats_p = torch.empty((p, 4), dtype=torch.float32, device=dev)
-    coords_v = torch.empty((max(p, 1), 3), dtype=torch.int, device=dev)
-    uniq = torch.empty(max(p, 1), dtype=torch.int64, device=dev)
-    inverse = torch.empty(p, dtype=torch.int64, device=dev)
+    feats_p = B.empty((p, 4), torch.float32, dev)
+    coords_v = B.empty((max(p, 1), 3), torch.int, dev)
+    uniq = B.empty(max(p, 1), torch.int64, dev)
+    inverse = B.empty(p, torch.int64, dev)
     counts = torch.empty(2, dtype=torch.int64, device=dev)          # [n_out, n_invalid (i32 view)]
     n_invalid = counts[1:].view(torch.int32)[:1]
     ws_bytes = B.lib().lidal_voxelize_points_workspace_bytes(p)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws = B.workspace(ws_bytes, dev)
     B.check(B.lib().lidal_voxelize_points(B.ptr(points), B.ptr(intensity), p, B.ptr(m_dev),
                                           B.ptr(r_dev), float(scale), int(full_scale),
                                           B.ptr(feats_p), B.ptr(coords_v), B.ptr(uniq),

@@ -43,12 +43,14 @@ class Geometry:
         self._stream = None
         self._consumer = None           # the stream whose kernels read the tables (fenced by the prefetcher)
         self.payload = None             # GeometryPrefetcher.submit_batch: the input batch built on the same stream
+        self._arena = None              # backend.BlockArena the tables were carved from
         self._age = 0                   # submissions to the same prefetcher since this one
 
     @staticmethod
-    def build(model, coords, grad=None):
+    def build(model, coords, grad=None, arena=None):
         """Build on the current stream.  grad: also what only a backward pass reads (default: model.training and
-        gradients enabled)."""
+        gradients enabled).  The tables are carved out of the blocks of one backend.BlockArena (`arena`, or a new
+        one): same-sized blocks the allocator re-uses exactly, whatever this batch's voxel counts are."""
         from .unet import SPVCNN, MinkUNet
         from .. import backend as B
         if not isinstance(model, (SPVCNN, MinkUNet)):
@@ -61,7 +63,9 @@ class Geometry:
         if grad is None:
             grad = model.training and torch.is_grad_enabled()
         g = Geometry(coords, type(model).__name__, bool(grad))
-        with torch.set_grad_enabled(bool(grad)):          # the map builder includes the rule lists iff gradients are on
+        g._arena = arena if arena is not None else B.BlockArena()
+        # (the map builder includes the rule lists iff gradients are on)
+        with torch.set_grad_enabled(bool(grad)), B.use_arena(g._arena):
             if isinstance(model, SPVCNN):
                 z = PointTensor(None, coords.float())
                 x0 = SparseTensor(None, initial_tables(z, model.pres, model.vres), 1)
@@ -169,6 +173,8 @@ class GeometryPrefetcher:
     fences are per prefetcher: another prefetcher on the same device (the scorer's, inside a training loop) neither
     ages this one's geometries nor fences them on its own stream."""
 
+    MAX_PENDING = 1
+
     def __init__(self, model, device=None):
         self.model = model
         if device is None:
@@ -178,7 +184,7 @@ class GeometryPrefetcher:
         self.stream = self._st['stream']
         self.held = []              # [geometry, fence event or None]
 
-    def submit(self, coords, grad=None, ready=None):
+    def submit(self, coords, grad=None, ready=None, arena=None):
         if grad is None:
             grad = self.model.training and torch.is_grad_enabled()
         fences = {}
@@ -190,6 +196,12 @@ class GeometryPrefetcher:
                 if c not in fences:
                     fences[c] = c.record_event()
                 h[1] = fences[c]
+        # bounded run-ahead: at most MAX_PENDING fenced generations may still be waiting for their consumer -- a host
+        # that queues steps faster than the GPU runs them (nothing else synchronises the loop) would otherwise keep one
+        # more generation of tables alive per step of lead
+        pending = [h for h in self.held if h[1] is not None and not h[1].query()]
+        while len(pending) > self.MAX_PENDING:
+            pending.pop(0)[1].synchronize()
         self.held = [h for h in self.held if h[1] is None or not h[1].query()]
         _reap(self._st)
         consumer = torch.cuda.current_stream(self.device)
@@ -197,7 +209,7 @@ class GeometryPrefetcher:
             if ready is not None:
                 self.stream.wait_event(ready)
             coords.record_stream(self.stream)
-            g = Geometry.build(self.model, coords, grad)
+            g = Geometry.build(self.model, coords, grad, arena)
             g.ready = self.stream.record_event()
             g._stream = self.stream
             g._consumer = consumer
@@ -213,9 +225,11 @@ class GeometryPrefetcher:
         stream and live exactly as long as the tables do (the same fence)."""
         if grad is None:
             grad = self.model.training and torch.is_grad_enabled()
-        with torch.cuda.stream(self.stream):
+        from .. import backend as B
+        arena = B.BlockArena()                  # the voxeliser's buffers and the tables: one set of blocks, one lifetime
+        with torch.cuda.stream(self.stream), B.use_arena(arena):
             batch = make()
-        g = self.submit(batch['coords_v_b'], grad)
+        g = self.submit(batch['coords_v_b'], grad, arena=arena)
         g.payload = batch
         return g
 

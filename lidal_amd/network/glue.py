@@ -14,35 +14,7 @@ __all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point', 'initial_tabl
 
 
 
-import os as _os
-_L0_ORDER = _os.environ.get('LIDAL_L0_ORDER', 'hash')
-
-
-def _part1by2(v):
-    v = v & 0x1FFFFF
-    v = (v | (v << 32)) & 0x1F00000000FFFF
-    v = (v | (v << 16)) & 0x1F0000FF0000FF
-    v = (v | (v << 8)) & 0x100F00F00F00F00F
-    v = (v | (v << 4)) & 0x10C30C30C30C30C3
-    v = (v | (v << 2)) & 0x1249249249249249
-    return v
-
-
-def _morton_renumber(idx_query, counts, coords):
-    """Level-0 voxel rows re-ordered by (batch, Morton(x, y, z)) instead of by coordinate hash (torch ops: an experiment)."""
-    c = coords.long()
-    key = (c[:, 3] << 48) | _part1by2(c[:, 0] >> _MORTON_SHIFT) | (_part1by2(c[:, 1] >> _MORTON_SHIFT) << 1) \
-        | (_part1by2(c[:, 2] >> _MORTON_SHIFT) << 2)
-    perm = torch.argsort(key, stable=True)              # sorted position -> old row
-    inv = torch.empty_like(perm)
-    inv[perm] = torch.arange(perm.numel(), device=perm.device)
-    new_idx = inv[idx_query]
-    if getattr(idx_query, '_lidal_one_to_one', False):
-        new_idx._lidal_one_to_one = True
-    return new_idx, counts[perm].contiguous(), coords[perm].contiguous()
-
-
-_MORTON_SHIFT = int(_os.environ.get('LIDAL_MORTON_SHIFT', '0'))
+RENUMBER = None         # experiments only: (idx_query, counts, coords) -> the same three under another level-0 voxel order
 
 
 def _floor_to_stride(z, s):
@@ -50,7 +22,7 @@ def _floor_to_stride(z, s):
     c = z.C
     if c.is_cuda and c.dtype == torch.float32 and c.dim() == 2 and c.shape[1] == 4 and c.is_contiguous() \
             and float(s) == int(s):
-        out = torch.empty(c.shape, dtype=torch.int32, device=c.device)      # one pass (csrc/hash.hip)
+        out = B.empty(c.shape, torch.int32, c.device)      # one pass (csrc/hash.hip)
         B.check(B.lib().lidal_floor_coords(B.ptr(c), c.shape[0], int(s), B.ptr(out), B.stream()), 'floor_coords')
         return out
     xyz = torch.floor(c[:, :3] / s).int() * s
@@ -66,8 +38,8 @@ def initial_tables(z, init_res, after_res):
     c = z.C
     if c.is_cuda and c.dtype == torch.float32 and c.dim() == 2 and c.shape[1] == 4 and c.is_contiguous():
         # one pass (csrc/hash.hip), the same separately rounded multiply and divide
-        new_float_coord = torch.empty_like(c)
-        floored_int = torch.empty(c.shape, dtype=torch.int32, device=c.device)
+        new_float_coord = B.empty(c.shape, c.dtype, c.device)
+        floored_int = B.empty(c.shape, torch.int32, c.device)
         B.check(B.lib().lidal_revoxelize_coords(B.ptr(c), c.shape[0], float(init_res), float(after_res),
                                                 B.ptr(new_float_coord), B.ptr(floored_int), B.stream()), 'revoxelize_coords')
         floored = None
@@ -91,8 +63,8 @@ def initial_tables(z, init_res, after_res):
         if floored is None:
             floored = floored_int.float()
         inserted_coords = torch.round(F.spvoxelize(floored, idx_query, counts)).int()
-    if _L0_ORDER == 'morton':       # EXPERIMENT (scripts/exp): renumber the level-0 voxels along a Z-order curve
-        idx_query, counts, inserted_coords = _morton_renumber(idx_query, counts, inserted_coords)
+    if RENUMBER is not None:        # hook of scripts/exp/l0_morton.py (an experiment: the level-0 voxel order is internal)
+        idx_query, counts, inserted_coords = RENUMBER(idx_query, counts, inserted_coords)
     z.additional_features['idx_query'][1] = idx_query
     z.additional_features['counts'][1] = counts
     z.additional_features['init_coords'] = inserted_coords     # the rows that index refers to

@@ -1186,6 +1186,9 @@ def planned_forward(model, x):
     g = getattr(x, 'geometry', None)
     if g is None:
         g = Geometry.build(model, x.C, mode == 'train')
+        if g.z is None:                 # torchsparse leaves the maps it built on the input tensor's dicts (MinkUNet's
+            x.cmaps.update(g.x0.cmaps)  # level 0 IS the input): visible to the caller as with the per-operator path
+            x.kmaps.update(g.x0.kmaps)
     else:
         g.admit(x, type(model).__name__)
         if mode == 'train' and not g.grad:

@@ -36,12 +36,12 @@ class RowOrder:
         k, n = nbr.shape
         dev = nbr.device
         self.n_rows = n
-        self.perm = torch.empty(max(n, 1), dtype=torch.int, device=dev)
-        self.table = torch.empty((k, n), dtype=torch.int, device=dev)
-        self.tile_masks = torch.empty(max(1, -(-n // 128)), dtype=torch.int32, device=dev)
+        self.perm = B.empty(max(n, 1), torch.int, dev)
+        self.table = B.empty((k, n), torch.int, dev)
+        self.tile_masks = B.empty(max(1, -(-n // 128)), torch.int32, dev)
         if build:
             ws_bytes = B.lib().lidal_kmap_order_workspace_bytes(n)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            ws = B.workspace(ws_bytes, dev)
             B.check(B.lib().lidal_kmap_order(B.ptr(nbr), n, k, B.ptr(self.perm), B.ptr(self.table),
                                              B.ptr(self.tile_masks), B.ptr(ws), ws_bytes, B.stream()),
                     'kmap_order')
@@ -67,7 +67,7 @@ class RowOrder:
                 total = sum(o.n_rows for o in orders)
                 dev = tables[chunk[0]].device
                 ws_bytes = B.lib().lidal_kmap_order_workspace_bytes(total)
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                ws = B.workspace(ws_bytes, dev)
                 vp, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
                 B.check(B.lib().lidal_kmap_order_batch(
                     vp(*[tables[i].data_ptr() for i in chunk]), i64(*[o.n_rows for o in orders]), n, k,
@@ -109,11 +109,11 @@ class KernelMap:
         if self._rules is None:
             k, n_out = self.nbr_out.shape
             dev = self.nbr_out.device
-            nbmaps = torch.empty((k * n_out, 2), dtype=torch.int, device=dev)
+            nbmaps = B.empty((k * n_out, 2), torch.int, dev)
             nbsizes = torch.empty(k, dtype=torch.int, device=dev)
             koff = torch.empty(k + 1, dtype=torch.int64, device=dev)
             ws_bytes = B.lib().lidal_kmap_workspace_bytes(n_out, k)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            ws = B.workspace(ws_bytes, dev)
             B.check(B.lib().lidal_kmap_build(None, 0, None, n_out, None, k, int(self.symmetric),
                                              B.ptr(self.nbr_out), B.ptr(nbmaps), B.ptr(nbsizes),
                                              B.ptr(koff), 2, B.ptr(ws), ws_bytes, B.stream()),
@@ -148,7 +148,7 @@ class KernelMap:
     def nbr_in(self):
         if self._nbr_in is None:
             n_in, n_out = self.sizes
-            t = torch.empty((self.volume, n_in), dtype=torch.int, device=self.nbr_out.device)
+            t = B.empty((self.volume, n_in), torch.int, self.nbr_out.device)
             B.check(B.lib().lidal_kmap_invert(B.ptr(self.nbr_out), n_out, self.volume, B.ptr(t),
                                               n_in, B.stream()), 'kmap_invert')
             self._nbr_in = t
@@ -188,15 +188,15 @@ def build_kernel_map(coords, in_stride, kernel_size, stride, scope=None):
         if out_coords is None:
             out_coords = spdownsample(coords, stride, kernel_size, in_stride)
     n_in, n_out = coords.shape[0], out_coords.shape[0]
-    nbr_out = torch.empty((volume, n_out), dtype=torch.int, device=dev)
+    nbr_out = B.empty((volume, n_out), torch.int, dev)
     ws_bytes = B.lib().lidal_kmap_workspace_bytes(n_out, volume)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws = B.workspace(ws_bytes, dev)
     symmetric = (volume % 2 == 1) and all(s == 1 for s in stride)
     # training will ask for the rule lists (weight gradient): build them in the same call;
     # under no_grad only the neighbour table is built (KernelMap derives the rest if ever asked)
     rules = None
     if torch.is_grad_enabled():
-        rules = (torch.empty((volume * n_out, 2), dtype=torch.int, device=dev),
+        rules = (B.empty((volume * n_out, 2), torch.int, dev),
                  torch.empty(volume, dtype=torch.int, device=dev),
                  torch.empty(volume + 1, dtype=torch.int64, device=dev))
     B.check(B.lib().lidal_kmap_build(B.ptr(table.buf), table.nbytes, B.ptr(out_coords), n_out,
@@ -229,11 +229,11 @@ def build_kernel_maps(jobs, scope):
         volume = offsets.shape[0]
         table = coords_table(coords, scope)
         n_in, n_out = coords.shape[0], out_coords.shape[0]
-        nbr_out = torch.empty((volume, n_out), dtype=torch.int, device=dev)
+        nbr_out = B.empty((volume, n_out), torch.int, dev)
         symmetric = (volume % 2 == 1) and all(s_ == 1 for s_ in stride)
         rules = None
         if want_rules:
-            rules = (torch.empty((volume * n_out, 2), dtype=torch.int, device=dev),
+            rules = (B.empty((volume * n_out, 2), torch.int, dev),
                      torch.empty(volume, dtype=torch.int, device=dev),
                      torch.empty(volume + 1, dtype=torch.int64, device=dev))
         rows.append((table, out_coords, offsets, volume, symmetric, nbr_out, rules, n_in, n_out))
@@ -245,7 +245,7 @@ def build_kernel_maps(jobs, scope):
         n_out_a, k_a = i64(*[r[8] for r in chunk]), i32(*[r[3] for r in chunk])
         L = B.lib()
         ws_bytes = L.lidal_kmap_build_batch_workspace_bytes(n_out_a, k_a, n)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws = B.workspace(ws_bytes, dev)
         B.check(L.lidal_kmap_build_batch(
             vp(*[r[0].buf.data_ptr() for r in chunk]), i64(*[r[0].nbytes for r in chunk]),
             vp(*[r[1].data_ptr() for r in chunk]), n_out_a, vp(*[r[2].data_ptr() for r in chunk]), k_a,

@@ -11,6 +11,6 @@ def spcount(coords, num):
     idx = coords.contiguous()
     if idx.dtype != torch.int:
         idx = idx.int()
-    out = torch.empty(num, dtype=torch.int, device=idx.device)
+    out = B.empty(num, torch.int, idx.device)
     B.check(B.lib().lidal_count(B.ptr(idx), idx.numel(), B.ptr(out), num, B.stream()), 'count')
     return out

@@ -18,8 +18,8 @@ def ti_weights_and_index(coords, idx_query, scale=1):
     idx_query = idx_query.contiguous()
     assert idx_query.dtype == torch.int64 and idx_query.shape[0] == 8
     n = coords.shape[0]
-    w = torch.empty((n, 8), dtype=torch.float32, device=coords.device)
-    idx32 = torch.empty((n, 8), dtype=torch.int, device=coords.device)
+    w = B.empty((n, 8), torch.float32, coords.device)
+    idx32 = B.empty((n, 8), torch.int, coords.device)
     B.check(B.lib().lidal_ti_weights(B.ptr(coords), coords.shape[1], B.ptr(idx_query), n,
                                      float(scale), B.ptr(w), B.ptr(idx32), B.stream()),
             'ti_weights')

@@ -15,10 +15,10 @@ def unique_sorted(keys):
     keys = keys.contiguous().view(-1)
     assert keys.dtype == torch.int64
     n = keys.numel()
-    out = torch.empty(n, dtype=torch.int64, device=keys.device)
+    out = B.empty(n, torch.int64, keys.device)
     n_out = torch.empty(1, dtype=torch.int64, device=keys.device)
     ws_bytes = B.lib().lidal_unique_workspace_bytes(n)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=keys.device)
+    ws = B.workspace(ws_bytes, keys.device)
     B.check(B.lib().lidal_unique_sorted_i64(B.ptr(keys), n, B.ptr(out), B.ptr(n_out), B.ptr(ws),
                                             ws_bytes, B.stream()), 'unique_sorted_i64')
     return out[:int(n_out.item())]
@@ -36,10 +36,10 @@ def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
     coords = coords.contiguous()
     n = coords.shape[0]
     ss = [stride[k] * tensor_stride[k] for k in range(3)]
-    out = torch.empty((n, 4), dtype=torch.int, device=coords.device)
+    out = B.empty((n, 4), torch.int, coords.device)
     n_out = torch.empty(1, dtype=torch.int64, device=coords.device)
     ws_bytes = B.lib().lidal_downsample_workspace_bytes(n)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=coords.device)
+    ws = B.workspace(ws_bytes, coords.device)
     B.check(B.lib().lidal_downsample(B.ptr(coords), n, ss[0], ss[1], ss[2], B.ptr(out),
                                      B.ptr(n_out), B.ptr(ws), ws_bytes, B.stream()), 'downsample')
     return out[:int(n_out.item())]
@@ -56,10 +56,10 @@ def downsample_pyramid(coords, levels, tensor_stride=1):
     assert coords.dtype == torch.int and coords.shape[1] == 4 and 1 <= levels <= 4
     coords = coords.contiguous()
     n = coords.shape[0]
-    out = torch.empty((max(n * levels, 1), 4), dtype=torch.int, device=coords.device)
+    out = B.empty((max(n * levels, 1), 4), torch.int, coords.device)
     starts = torch.empty(levels + 1, dtype=torch.int64, device=coords.device)
     ws_bytes = B.lib().lidal_downsample_pyramid_workspace_bytes(n, levels)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=coords.device)
+    ws = B.workspace(ws_bytes, coords.device)
     B.check(B.lib().lidal_downsample_pyramid(B.ptr(coords), n, tensor_stride[0], tensor_stride[1], tensor_stride[2],
                                              levels, B.ptr(out), B.ptr(starts), B.ptr(ws), ws_bytes, B.stream()),
             'downsample')

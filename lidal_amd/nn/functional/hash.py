@@ -13,7 +13,7 @@ def sphash(coords, offsets=None):
     coords = coords.contiguous()
     n = coords.shape[0]
     if offsets is None:
-        out = torch.empty(n, dtype=torch.int64, device=coords.device)
+        out = B.empty(n, torch.int64, coords.device)
         B.check(B.lib().lidal_hash(B.ptr(coords), n, B.ptr(out), B.stream()), 'hash')
         return out
     assert offsets.dtype == torch.int, offsets.dtype
@@ -21,7 +21,7 @@ def sphash(coords, offsets=None):
     B.require_gpu(offsets)
     offsets = offsets.contiguous()
     k = offsets.shape[0]
-    out = torch.empty((k, n), dtype=torch.int64, device=coords.device)
+    out = B.empty((k, n), torch.int64, coords.device)
     B.check(B.lib().lidal_kernel_hash(B.ptr(coords), n, B.ptr(offsets), k, B.ptr(out),
                                       B.stream()), 'kernel_hash')
     return out

@@ -22,10 +22,10 @@ def inverse_lists(idx, m, weights=None):
     flat = idx.contiguous().view(-1)
     assert flat.dtype == torch.int
     n = flat.numel()
-    order = torch.empty(max(n, 1), dtype=torch.int, device=idx.device)
-    seg_ptr = torch.empty(m + 1, dtype=torch.int64, device=idx.device)
+    order = B.empty(max(n, 1), torch.int, idx.device)
+    seg_ptr = B.empty(m + 1, torch.int64, idx.device)
     ws_bytes = B.lib().lidal_invlist_workspace_bytes(n)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=idx.device)
+    ws = B.workspace(ws_bytes, idx.device)
     w = None if weights is None else weights.contiguous().view(-1)
     B.check(B.lib().lidal_invlist_build(B.ptr(flat), B.ptr(w), n, m, B.ptr(order), B.ptr(seg_ptr),
                                         B.ptr(ws), ws_bytes, B.stream()), 'invlist_build')
@@ -38,4 +38,4 @@ def segment_workspace(n_entries, m, c, device):
     nbytes = B.lib().lidal_segment_workspace_bytes(n_entries, m, c)
     if nbytes == 0:
         return None, 0
-    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+    return B.workspace(nbytes, device), nbytes        # (one library call's scratch)

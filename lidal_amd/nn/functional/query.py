@@ -17,7 +17,7 @@ class HashTable:
         assert references.dtype == torch.int64
         self.n = references.numel()
         self.nbytes = B.lib().lidal_hash_table_bytes(self.n)
-        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=references.device)
+        self.buf = B.empty(self.nbytes, torch.uint8, references.device)
         B.check(B.lib().lidal_hash_table_build(B.ptr(references), self.n, B.ptr(self.buf),
                                                self.nbytes, B.stream()), 'hash_table_build')
 
@@ -26,7 +26,7 @@ class HashTable:
         sizes = queries.size()
         q = queries.contiguous().view(-1)
         assert q.dtype == torch.int64
-        out = torch.empty_like(q)
+        out = B.empty(q.shape, q.dtype, q.device)
         B.check(B.lib().lidal_hash_table_query(B.ptr(self.buf), self.nbytes, B.ptr(q), q.numel(),
                                                B.ptr(out), B.stream()), 'hash_table_query')
         return out.view(*sizes)

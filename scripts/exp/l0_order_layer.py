@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch  # noqa: E402
 
 from lidal_amd import backend as B, synth  # noqa: E402
+if os.environ.get('LIDAL_L0_ORDER') == 'morton':
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import l0_morton  # noqa: E402,F401
 from lidal_amd.network import SPVCNN, Geometry  # noqa: E402
 from lidal_amd.nn.functional.conv import _weight_image, wgrad_scratch  # noqa: E402
 

@@ -61,6 +61,14 @@ TALLY = os.environ.get('LIDAL_PLAN_TALLY', '0') != '0'
 # replay every operation against the oracle on the operation's own stored operands (tests/test_teacher_forced_gpu.py);
 # the test calls run.release() when it is done
 TRACE = None
+# The weight gradients of layers with at most this many rows run on a SECOND STREAM beside the data gradient and the
+# BatchNorm backward that follow them in the plan (0 = off; default: all of them).  A layer's weight gradient and its
+# data gradient both depend only on the gradient of its output, and on the coarse levels either kernel is latency bound
+# (a launch is as long as its heaviest tile's chain of phases and leaves most of the chip idle).  Inside the plan a
+# fork / join is two runtime calls in C++ (round 2's per-operator form paid stream switches in Python and lost on a
+# single scan).  Measured, 3 runs each, same box: 5 scans 16.05 / 16.05 / 16.11 -> 15.42 / 15.39 / 15.38 ms,
+# one scan 7.47 / 7.48 / 7.46 -> 7.01 / 7.82 / 7.02 ms (scripts/exp/side_wgrad.sh).  Same kernels, same results.
+SIDE_ROWS = int(os.environ.get('LIDAL_PLAN_SIDE_ROWS', str(1 << 40)))
 _NARGS = {}
 _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
               6: 'bn_train_fwd', 7: 'bn_bwd', 8: 'bn_bwd', 9: 'bn_eval_fwd', 10: 'bn_fold', 11: 'colsum',
@@ -526,6 +534,8 @@ class _Run:
         self.noise = []
         self.keep = []
         self.tapes = [] if (TRACE is not None and self.TRAIN) else None
+        self.side_stream = None
+        self.side_open = False
         self.w = []
         self.nops = 0
         self.done = False
@@ -610,6 +620,10 @@ class _Run:
     def flush(self):
         if not self.nops:
             return
+        if self.side_open:                  # every stretch of the plan ends with the main stream waiting for the side stream
+            self.w.append(OP_JOIN_SIDE)
+            self.nops += 1
+            self.side_open = False
         if TALLY:
             _tally(self.w)
         if self.tapes is not None:
@@ -617,7 +631,7 @@ class _Run:
         arr = array.array('q', self.w)
         addr, n_words = arr.buffer_info()
         L = B.lib_handle()
-        rc = L.lidal_plan_run(addr, n_words, self.nops, self.stream, None)
+        rc = L.lidal_plan_run(addr, n_words, self.nops, self.stream, self.side_stream)
         COUNTERS['plans'] += 1
         COUNTERS['ops'] += self.nops
         B.HITS['plan_run'] = B.HITS.get('plan_run', 0) + 1
@@ -628,6 +642,20 @@ class _Run:
 
     def scratch(self, nbytes):
         return _scratch(self.dev, self.stream, nbytes, self.keep)
+
+    def side(self, rows):
+        """Operation kind flags for a weight gradient over `rows` rows: LIDAL_OP_FLAG_SIDE (after a fork) or 0."""
+        if not SIDE_ROWS or rows > SIDE_ROWS:
+            return 0
+        if self.side_stream is None:
+            self.side_stream = B.side_stream(self.dev).cuda_stream
+        self.w.append(OP_FORK_SIDE)         # the side stream waits for what the plan has queued so far (dx is among it)
+        self.nops += 1
+        self.side_open = True
+        return 1 << 16
+
+    def side_scratch(self, nbytes):
+        return _scratch(self.dev, (self.stream, 'side'), nbytes, self.keep)
 
     # ===================================== forward ========================================================
     def f_conv(self, c, x, n_in, ci, table, n_out, stats):
@@ -851,15 +879,17 @@ class _Run:
         """conv.py conv_backward's wgrad(): gw [k, ci, co] f32 straight into the parameter's gradient slot."""
         ci = c.ci if ci is None else ci
         slabs = _slabs(n_x, n_g, c.k, ci, c.co, self.code)
-        partial = self.scratch(slabs * ci * c.co * 4 + (c.k * ci * c.co * 4 if ci != c.ci else 0))
+        flag = self.side(max(n_x, n_g))
+        nbytes = slabs * ci * c.co * 4 + (c.k * ci * c.co * 4 if ci != c.ci else 0)
+        partial = self.side_scratch(nbytes) if flag else self.scratch(nbytes)
         gw = self.slot(c.w)
         if ci != c.ci:                      # the channel-padded stem: gw[:, :ci_w] of the padded gradient
             gw = partial + slabs * ci * c.co * 4
-        self.w += (OP_CONV_WGRAD, x, g, n_x, n_g, rules[0], rules[1], 1 if c.transposed else 0, gw, partial, slabs,
+        self.w += (OP_CONV_WGRAD | flag, x, g, n_x, n_g, rules[0], rules[1], 1 if c.transposed else 0, gw, partial, slabs,
                    c.k, ci, c.co, self.code)
         self.nops += 1
         if ci != c.ci:
-            self.w += (OP_COPY2D, gw, ci * c.co * 4, self.slot(c.w), c.ci * c.co * 4, c.k, c.ci * c.co * 4, 0)
+            self.w += (OP_COPY2D | flag, gw, ci * c.co * 4, self.slot(c.w), c.ci * c.co * 4, c.k, c.ci * c.co * 4, 0)
             self.nops += 1
 
     def b_dgrad(self, c, g, n_g, table, n_out, kflip, skip=0, bnb=None):
@@ -881,12 +911,14 @@ class _Run:
         ca, cb = c.ci, cg
         slabs = _slabs(n, n, 1, ca, cb, self.code)
         direct = linear_slot is None and cb == c.co
-        sc = self.scratch(slabs * ca * cb * 4 + (0 if direct else ca * cb * 4))
+        flag = self.side(n)
+        nbytes = slabs * ca * cb * 4 + (0 if direct else ca * cb * 4)
+        sc = self.side_scratch(nbytes) if flag else self.scratch(nbytes)
         gw = self.slot(c.w) if direct else sc + slabs * ca * cb * 4
-        self.w += (OP_CONV_WGRAD, x, g, n, n, 0, self.koff[n], 0, gw, sc, slabs, 1, ca, cb, self.code)
+        self.w += (OP_CONV_WGRAD | flag, x, g, n, n, 0, self.koff[n], 0, gw, sc, slabs, 1, ca, cb, self.code)
         self.nops += 1
         if not direct:                      # nn.Linear: [Cout, Cin] = (x^T g)[:, :Cout]^T
-            self.w += (OP_TRANSPOSE_F32, gw, cb, self.slot(c.w), ca, c.co)
+            self.w += (OP_TRANSPOSE_F32 | flag, gw, cb, self.slot(c.w), ca, c.co)
             self.nops += 1
         if not need_gx:
             return 0

@@ -275,6 +275,19 @@ int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
                            int ci, int co, int k, int kflip, int dtype, const float* ep_scale,
                            const float* ep_shift, int ep_relu, const void* ep_residual,
                            float* tile_stats, void* stream);
+/* lidal_conv_apply_image with a workspace (ws >= lidal_conv_apply_workspace_bytes(n_out, co), may be NULL / 0): on the
+ * coarse levels -- few 128-row tiles, each a long chain of (offset, reduction slice) phases while most of the chip
+ * idles -- the launch then SPLITS every tile's active offsets over 2-4 workgroups, which leave f32 partial tiles in
+ * ws; a second kernel adds them in a fixed order and runs the epilogue (permutation, affine map / ReLU / residual,
+ * BatchNorm tile statistics).  Which launches split is a function of (n_out, ci, co, k, dtype) alone; results differ
+ * from the unsplit kernel's only by the association of the f32 sum over the offsets (~1e-7 relative before the
+ * rounding to the output dtype). */
+int64_t lidal_conv_apply_workspace_bytes(int64_t n_out, int co);
+int lidal_conv_apply_image_ws(const void* in, const void* wimg, const int32_t* nbr, const int32_t* perm,
+                              const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out,
+                              int ci, int co, int k, int kflip, int dtype, const float* ep_scale,
+                              const float* ep_shift, int ep_relu, const void* ep_residual,
+                              float* tile_stats, void* ws, int64_t ws_bytes, void* stream);
 /* The data gradient of a convolution whose INPUT was y = act(bn(x)) (torchsparse: convolution_backward_cuda's
  * grad_input half, followed by the BatchNorm backward of network/utils.py:115): lidal_conv_apply_image on
  * (gout, data-gradient image) -> gin, and in the same launch the backward sums of that BatchNorm per 128-row
@@ -286,6 +299,12 @@ int lidal_conv_dgrad_bn_sums(const void* gout, const void* wimg, const int32_t* 
                              int c_gin, int k, int kflip, int dtype, const void* bn_x, const float* bn_mean,
                              const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_relu,
                              float* bn_sums, void* stream);
+/* (the same with the workspace of lidal_conv_apply_image_ws) */
+int lidal_conv_dgrad_bn_sums_ws(const void* gout, const void* wimg, const int32_t* nbr, const int32_t* perm,
+                                const uint32_t* tile_masks, void* gin, int64_t n_gout, int64_t n_gin, int c_gout,
+                                int c_gin, int k, int kflip, int dtype, const void* bn_x, const float* bn_mean,
+                                const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int bn_relu,
+                                float* bn_sums, void* ws, int64_t ws_bytes, void* stream);
 /* replaces the weight-gradient half of backend.convolution_backward_cuda:
  *     gw[k] = a[ pairs[:, a_col] ]^T  *  b[ pairs[:, 1 - a_col] ]      (f32 [k][ca][cb])
  * pairs = nbmaps i32 [M,2], koff i64 [k+1] (device); n_a, n_b = rows of a and b.
@@ -446,9 +465,11 @@ int lidal_cast_rows_bf16(const float* src, int c_src, void* dst, int c_dst, int6
  * pattern of a double (lidal_plan_op_args(kind) words).  The operations are queued on `stream` in order --
  * exactly the launches the same calls made one by one would queue (train.py:127-140 / prob_inference.py:91-113
  * issue theirs one Python call at a time); nothing is captured or cached, every call walks the words it is given.
- * LIDAL_OP_FLAG_SIDE queues an operation on `side_stream` instead (may be NULL if unused), between a
- * LIDAL_OP_FORK_SIDE (side stream waits for what `stream` holds so far) and a LIDAL_OP_JOIN_SIDE (`stream` waits for
- * the side stream).  Stops at the first failing operation; lidal_last_error() names its index and kind. */
+ * The flags of an operation name the stream it is queued on: 0 = `stream`, i = side stream i (1, LIDAL_OP_FLAG_SIDE, is
+ * `side_stream`, which may be NULL if unused; lidal_plan_run_streams takes streams[0] = the main stream and up to 7 side
+ * streams), between a LIDAL_OP_FORK_SIDE with the same flags (side stream i waits for what the main stream holds so
+ * far) and a LIDAL_OP_JOIN_SIDE (the main stream waits for side stream i).  Stops at the first failing operation;
+ * lidal_last_error() names its index and kind. */
 enum {
   LIDAL_OP_CONV_WEIGHT_IMAGE_BATCH = 1, LIDAL_OP_CONV_APPLY_IMAGE = 2, LIDAL_OP_CONV_DGRAD_BN_SUMS = 3,
   LIDAL_OP_CONV_WGRAD = 4, LIDAL_OP_BN_TRAIN_FWD = 5, LIDAL_OP_BN_TRAIN_FWD_TILES = 6, LIDAL_OP_BN_BWD = 7,
@@ -457,7 +478,8 @@ enum {
   LIDAL_OP_VOXELIZE_FWD_SORTED = 15, LIDAL_OP_VOXELIZE_BWD = 16, LIDAL_OP_DEVOXELIZE_FWD = 17,
   LIDAL_OP_DEVOXELIZE_BWD_SORTED = 18, LIDAL_OP_CE_FWD = 19, LIDAL_OP_CE_BWD = 20, LIDAL_OP_COPY2D = 21,
   LIDAL_OP_ADD2D = 22, LIDAL_OP_TRANSPOSE_F32 = 23, LIDAL_OP_CAST_ROWS_BF16 = 24, LIDAL_OP_VIEW_MEAN_SOFTMAX = 25,
-  LIDAL_OP_FORK_SIDE = 26, LIDAL_OP_JOIN_SIDE = 27
+  LIDAL_OP_FORK_SIDE = 26, LIDAL_OP_JOIN_SIDE = 27, LIDAL_OP_CONV_APPLY_IMAGE_WS = 28,
+  LIDAL_OP_CONV_DGRAD_BN_SUMS_WS = 29
 };
 #define LIDAL_OP_FLAG_SIDE 1
 int lidal_plan_op_args(int kind);
@@ -465,6 +487,7 @@ int lidal_plan_op_args(int kind);
  * buffers by address; tests that replay its operations against the oracle read the operands back with this) */
 int lidal_debug_read(const void* dev, void* host, int64_t nbytes);
 int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_ops, void* stream, void* side_stream);
+int lidal_plan_run_streams(const int64_t* words, int64_t n_words, int64_t n_ops, void* const* streams, int n_streams);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,11 @@ SIGNATURES = {
                                       _vp, _i32, _vp, _vp, _vp]),
     'lidal_conv_dgrad_bn_sums': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
                                         _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    'lidal_conv_apply_workspace_bytes': (_i64, [_i64, _i32]),
+    'lidal_conv_apply_image_ws': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
+                                         _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
+    'lidal_conv_dgrad_bn_sums_ws': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
+                                           _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp]),
     'lidal_conv_wgrad_slabs': (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     'lidal_conv_wgrad': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'lidal_bn_workspace_bytes': (_i64, [_i64, _i32]),
@@ -119,6 +124,7 @@ SIGNATURES = {
     'lidal_plan_op_args': (_i32, [_i32]),
     'lidal_debug_read': (_i32, [_vp, _vp, _i64]),
     'lidal_plan_run': (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    'lidal_plan_run_streams': (_i32, [_vp, _i64, _i64, _vp, _i32]),
 }
 
 
@@ -386,8 +392,10 @@ def overlap_wgrad(dtype, n_rows=0):
     return _OVERLAP == 'auto' and 0 < n_rows <= _OVERLAP_ROWS
 
 
-def side_stream(device):
+def side_stream(device, which=1):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if which != 1:
+        key = key + (which,)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]

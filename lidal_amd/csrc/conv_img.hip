@@ -168,6 +168,18 @@ struct BnBwd {
   int relu;
 };
 
+// Optional split of a tile's offsets over SEVERAL workgroups (round 4).  On the coarse levels a launch is as long as
+// its heaviest tile's chain of phases (a 128-row tile that touches all 27 offsets of a 256-channel layer runs 108
+// phases back to back) while most of the chip idles (29 tiles x 4 column blocks on 256 CUs).  With nsplit > 1 the
+// launch has nsplit workgroups per (tile, column block): workgroup z takes the z-th share of the tile's ACTIVE
+// offsets (by rank among the set bits of the tile mask), leaves its f32 accumulators in `partial` (one 16-byte
+// vector per lane and 16-column block, [nsplit][tile][column block][wave][16-column block][lane]: both kernels use
+// the MFMA accumulator layout, so the traffic is fully coalesced) and skips the epilogue; conv_combine_kernel adds
+// the shares in split order and runs the epilogue (row permutation, affine map / ReLU / residual, BatchNorm tile
+// statistics, BatchNorm backward sums) exactly as the unsplit kernel does.  Deterministic; differs from the unsplit
+// result only by the association of the f32 sum over the offsets.
+struct Split { float* partial; int nsplit; int co_pad; long long rows_pad; };
+
 // ---- epilogue shared by the kernels of this file (as conv.hip): accumulators (D layout: col =
 // lane&15, row = 4*(lane>>4) + r) -> wave-private LDS tile in T -> whole rows to HBM, 16-byte stores,
 // with the optional affine map / ReLU / residual of the inference paths
@@ -640,7 +652,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
                  T* __restrict__ out, int64_t n_out, int ci, int co, int K, int kflip,
                  const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int ep_relu,
                  const T* __restrict__ ep_res, unsigned in_bytes, unsigned img_bytes,
-                 unsigned nbr_bytes, float* __restrict__ tile_stats, BnBwd bnb) {
+                 unsigned nbr_bytes, float* __restrict__ tile_stats, BnBwd bnb, Split sp) {
   constexpr int BM = NWAVES * 16;
   constexpr int BN = 16 * NB;
   constexpr int CH = DT<T>::CH;
@@ -677,6 +689,17 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
       if ((t0 + h) * 128 < n_out) m |= tmasks[t0 + h];
     if (kflip) m = __brev(m) >> (32 - K);
     tmask = __builtin_amdgcn_readfirstlane(m);
+    if (sp.nsplit > 1) {        // this workgroup's share of the tile's active offsets: ranks [lo, hi) of the set bits
+      const int cnt = __popc(tmask), z = (int)blockIdx.z;
+      const int lo = z * cnt / sp.nsplit, hi = (z + 1) * cnt / sp.nsplit;
+      unsigned left = tmask, sub = 0u;
+      for (int rk = 0; left != 0u; ++rk) {
+        const unsigned bit = left & (0u - left);
+        if (rk >= lo && rk < hi) sub |= bit;
+        left ^= bit;
+      }
+      tmask = __builtin_amdgcn_readfirstlane(sub);
+    }
   }
   const int nphase = __popc(tmask) * npass;
 
@@ -829,7 +852,45 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
     }
     __syncthreads();                                // every wave is done with the last slab
   }
+  if (sp.nsplit > 1) {          // a share of the tile's offsets: the f32 accumulators go to the combining kernel
+    f32x4* dst = reinterpret_cast<f32x4*>(sp.partial) +
+                 ((((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * NWAVES + wave) * (NB * 64) + lane;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) dst[nb * 64] = acc[0][nb];
+    return;
+  }
   store_tile<T, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
+                               ep_res, true, perm_v, tile_stats, -1, &bnb);
+}
+
+// The shares of a split launch (struct Split) added in split order, then the epilogue of the unsplit kernel.
+template <typename T, int NB, int NWAVES>
+__global__ void __launch_bounds__(64 * NWAVES)
+conv_combine_kernel(Split sp, const int* __restrict__ perm, T* __restrict__ out, int64_t n_out, int co,
+                    const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int ep_relu,
+                    const T* __restrict__ ep_res, float* __restrict__ tile_stats, BnBwd bnb) {
+  constexpr int BM = NWAVES * 16, BN = 16 * NB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row16 = lane & 15, gsel = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * 16;
+  const int n0 = blockIdx.y * BN;
+  f32x4 acc[1][NB];
+  const f32x4* src = reinterpret_cast<const f32x4*>(sp.partial) +
+                     (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NWAVES + wave) * (NB * 64) + lane;
+  const int64_t share = (int64_t)gridDim.x * gridDim.y * NWAVES * (NB * 64);      // vectors per split
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f32x4 v = src[nb * 64];
+    for (int z = 1; z < sp.nsplit; ++z) {
+      const f32x4 t = src[(int64_t)z * share + nb * 64];
+      v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    acc[0][nb] = v;
+  }
+  const int perm_v = (perm != nullptr && r0 + row16 < n_out) ? perm[r0 + row16] : 0;
+  store_tile<T, NB, 1, NWAVES>(acc, smem, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
                                ep_res, true, perm_v, tile_stats, -1, &bnb);
 }
 
@@ -1042,7 +1103,15 @@ conv_lean_deep_kernel(const T* __restrict__ in, const T* __restrict__ wimg, cons
                                ep_res, true, perm_v, tile_stats, -1, &bnb);
 }
 
-struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; BnBwd bnb; };
+struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; BnBwd bnb; void* ws; long long ws_bytes; };
+
+// Split policy (struct Split): only launches that leave the chip mostly idle -- at most SPLIT_MAX_WGS workgroups -- and
+// whose tiles have a long chain (a 27-offset map, or an 8-offset map over several reduction slices)
+constexpr int64_t SPLIT_MAX_WGS = 256;
+__host__ inline int pick_split(int64_t wgs, int K, int npass) {
+  if (wgs > SPLIT_MAX_WGS || K * npass < 27) return 1;
+  return wgs <= 128 ? 4 : (wgs <= 192 ? 3 : 2);
+}
 
 constexpr int IMG_G = 1, IMG_NWAVES = 8, IMG_DEPTH = 1;       // generic kernel: row groups per wave, waves, pipeline depth
 
@@ -1099,10 +1168,33 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
         lean_attr[nbr ? 0 : 1][ldev] = LEAN_LDS;
       }
       dim3 lgrid((unsigned)cdiv(n_out, LBM), (unsigned)cdiv(co, BN));
+      Split sp{nullptr, 1, 0, 0};
+      if (nbr != nullptr && ep.ws != nullptr) {
+        const int ns = pick_split((int64_t)lgrid.x * lgrid.y, K, ci / (ROW_BYTES / (int)sizeof(T)));
+        const long long rows_pad = (long long)lgrid.x * LBM;
+        const int co_pad = (int)lgrid.y * BN;
+        if (ns > 1 && ep.ws_bytes >= (long long)ns * rows_pad * co_pad * 4)
+          sp = Split{(float*)ep.ws, ns, co_pad, rows_pad};
+      }
+      lgrid.z = (unsigned)sp.nsplit;
       lk<<<lgrid, 64 * LW, LEAN_LDS, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
                                           ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
-                                          ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, ep.bnb);
+                                          ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, ep.bnb, sp);
       LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(lean)");
+      if (sp.nsplit > 1) {
+        constexpr int COMB_LDS = LEPI + LSTATS;
+        auto ck = conv_combine_kernel<T, NB, LW>;
+        static size_t comb_attr[MAX_DEVICES] = {};
+        if (comb_attr[ldev] < (size_t)COMB_LDS) {
+          LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ck),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, COMB_LDS));
+          comb_attr[ldev] = COMB_LDS;
+        }
+        lgrid.z = 1;
+        ck<<<lgrid, 64 * LW, COMB_LDS, s>>>(sp, perm, (T*)out, n_out, co, ep.scale, ep.shift, ep.relu,
+                                            (const T*)ep.res, ep.tile_stats, ep.bnb);
+        LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(combine)");
+      }
       return 0;
     }
   }
@@ -1249,7 +1341,8 @@ extern "C" int lidal_conv_weight_image_batch(const void* jobs, int n_jobs, int64
 static int conv_apply_image(const void* in, const void* wimg, const int32_t* nbr, const int32_t* perm,
                             const uint32_t* tile_masks, void* out, int64_t n_in, int64_t n_out, int ci, int co,
                             int k, int kflip, int dtype, const float* ep_scale, const float* ep_shift,
-                            int ep_relu, const void* ep_residual, float* tile_stats, BnBwd bnb, hipStream_t s) {
+                            int ep_relu, const void* ep_residual, float* tile_stats, BnBwd bnb, void* ws,
+                            int64_t ws_bytes, hipStream_t s) {
   if (n_out == 0 || co == 0) return 0;
   LIDAL_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv_apply_image: scale and shift go together");
   LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16, "conv_apply_image: bad dtype %d", dtype);
@@ -1269,7 +1362,7 @@ static int conv_apply_image(const void* in, const void* wimg, const int32_t* nbr
                 "conv_apply_image: the input matrix and the weight image must each stay below 2 GiB");
   LIDAL_REQUIRE((int64_t)k * n_out * 4 < 0x7FFFFFF0ll, "conv_apply_image: neighbour table above 2 GiB");
   Epi ep{ep_scale, ep_shift, ep_relu, ep_residual, (unsigned)(n_in * ci * esz), (unsigned)ib,
-         (unsigned)((int64_t)k * n_out * 4), tile_stats, bnb};
+         (unsigned)((int64_t)k * n_out * 4), tile_stats, bnb, ws, (long long)ws_bytes};
   if (dtype == LIDAL_F32)
     return dispatch_img<float>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
   return dispatch_img<__bf16>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
@@ -1283,7 +1376,24 @@ extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const in
                                       void* stream) {
   BnBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   return conv_apply_image(in, wimg, nbr, perm, tile_masks, out, n_in, n_out, ci, co, k, kflip, dtype, ep_scale,
-                          ep_shift, ep_relu, ep_residual, tile_stats, none, (hipStream_t)stream);
+                          ep_shift, ep_relu, ep_residual, tile_stats, none, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int64_t lidal_conv_apply_workspace_bytes(int64_t n_out, int co) {
+  const int64_t tiles = cdiv(n_out > 0 ? n_out : 1, TILE_ROWS);
+  if (tiles * cdiv(co, 128) > SPLIT_MAX_WGS) return 0;        // (no tiling makes few enough workgroups to be split)
+  return 4 * tiles * TILE_ROWS * align_up(co, 128) * 4;
+}
+
+extern "C" int lidal_conv_apply_image_ws(const void* in, const void* wimg, const int32_t* nbr,
+                                         const int32_t* perm, const uint32_t* tile_masks, void* out,
+                                         int64_t n_in, int64_t n_out, int ci, int co, int k, int kflip,
+                                         int dtype, const float* ep_scale, const float* ep_shift,
+                                         int ep_relu, const void* ep_residual, float* tile_stats, void* ws,
+                                         int64_t ws_bytes, void* stream) {
+  BnBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  return conv_apply_image(in, wimg, nbr, perm, tile_masks, out, n_in, n_out, ci, co, k, kflip, dtype, ep_scale,
+                          ep_shift, ep_relu, ep_residual, tile_stats, none, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int lidal_conv_dgrad_bn_sums(const void* gout, const void* wimg, const int32_t* nbr,
@@ -1294,5 +1404,16 @@ extern "C" int lidal_conv_dgrad_bn_sums(const void* gout, const void* wimg, cons
                                         int bn_relu, float* bn_sums, void* stream) {
   BnBwd b{bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_sums, bn_relu};
   return conv_apply_image(gout, wimg, nbr, perm, tile_masks, gin, n_gout, n_gin, c_gout, c_gin, k, kflip, dtype,
-                          nullptr, nullptr, 0, nullptr, nullptr, b, (hipStream_t)stream);
+                          nullptr, nullptr, 0, nullptr, nullptr, b, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int lidal_conv_dgrad_bn_sums_ws(const void* gout, const void* wimg, const int32_t* nbr,
+                                           const int32_t* perm, const uint32_t* tile_masks, void* gin,
+                                           int64_t n_gout, int64_t n_gin, int c_gout, int c_gin, int k, int kflip,
+                                           int dtype, const void* bn_x, const float* bn_mean,
+                                           const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                           int bn_relu, float* bn_sums, void* ws, int64_t ws_bytes, void* stream) {
+  BnBwd b{bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_sums, bn_relu};
+  return conv_apply_image(gout, wimg, nbr, perm, tile_masks, gin, n_gout, n_gin, c_gout, c_gin, k, kflip, dtype,
+                          nullptr, nullptr, 0, nullptr, nullptr, b, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -227,6 +227,8 @@ const OpInfo kOps[] = {
     /* LIDAL_OP_VIEW_MEAN_SOFTMAX 25 */ {7, "view_mean_softmax"},
     /* LIDAL_OP_FORK_SIDE 26 */ {0, "fork_side"},
     /* LIDAL_OP_JOIN_SIDE 27 */ {0, "join_side"},
+    /* LIDAL_OP_CONV_APPLY_IMAGE_WS 28 */ {20, "conv_apply_image_ws"},
+    /* LIDAL_OP_CONV_DGRAD_BN_SUMS_WS 29 */ {22, "conv_dgrad_bn_sums_ws"},
 };
 constexpr int kNumOps = (int)(sizeof(kOps) / sizeof(kOps[0]));
 
@@ -236,19 +238,20 @@ inline double as_double(int64_t w) {
   return d;
 }
 
-// one pair of events per device for the fork / join of the side stream (created on first use, never timed)
-hipEvent_t g_fork_ev[MAX_DEVICES], g_join_ev[MAX_DEVICES];
-bool g_ev_ready[MAX_DEVICES];
+// one pair of events per device and side stream for fork / join (created on first use, never timed)
+constexpr int MAX_SIDE = 8;
+hipEvent_t g_fork_ev[MAX_DEVICES][MAX_SIDE], g_join_ev[MAX_DEVICES][MAX_SIDE];
+bool g_ev_ready[MAX_DEVICES][MAX_SIDE];
 
-int side_events(hipEvent_t** fork_ev, hipEvent_t** join_ev) {
+int side_events(int idx, hipEvent_t** fork_ev, hipEvent_t** join_ev) {
   const int d = current_device();
-  if (!g_ev_ready[d]) {
-    LIDAL_HIP(hipEventCreateWithFlags(&g_fork_ev[d], hipEventDisableTiming));
-    LIDAL_HIP(hipEventCreateWithFlags(&g_join_ev[d], hipEventDisableTiming));
-    g_ev_ready[d] = true;
+  if (!g_ev_ready[d][idx]) {
+    LIDAL_HIP(hipEventCreateWithFlags(&g_fork_ev[d][idx], hipEventDisableTiming));
+    LIDAL_HIP(hipEventCreateWithFlags(&g_join_ev[d][idx], hipEventDisableTiming));
+    g_ev_ready[d][idx] = true;
   }
-  *fork_ev = &g_fork_ev[d];
-  *join_ev = &g_join_ev[d];
+  *fork_ev = &g_fork_ev[d][idx];
+  *join_ev = &g_join_ev[d][idx];
   return 0;
 }
 
@@ -257,6 +260,14 @@ int side_events(hipEvent_t** fork_ev, hipEvent_t** join_ev) {
 extern "C" int lidal_plan_op_args(int kind) { return kind > 0 && kind < kNumOps ? kOps[kind].n_args : -1; }
 
 extern "C" int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_ops, void* stream, void* side_stream) {
+  void* streams[2] = {stream, side_stream};
+  return lidal_plan_run_streams(words, n_words, n_ops, streams, side_stream != nullptr ? 2 : 1);
+}
+
+extern "C" int lidal_plan_run_streams(const int64_t* words, int64_t n_words, int64_t n_ops, void* const* streams,
+                                      int n_streams) {
+  LIDAL_REQUIRE(streams != nullptr && n_streams >= 1 && n_streams <= MAX_SIDE, "plan_run: 1..%d streams", MAX_SIDE);
+  void* const stream = streams[0];
 #define P(i) ((void*)(uintptr_t)a[i])
 #define CP(T, i) ((const T*)(uintptr_t)a[i])
 #define MP(T, i) ((T*)(uintptr_t)a[i])
@@ -264,7 +275,7 @@ extern "C" int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_o
 #define L(i) ((int64_t)a[i])
 #define F(i) ((float)as_double(a[i]))
   int64_t pos = 0;
-  bool side_open = false;
+  bool side_open[MAX_SIDE] = {};
   for (int64_t op = 0; op < n_ops; ++op) {
     LIDAL_REQUIRE(pos < n_words, "plan_run: op %lld starts past the end of the stream (%lld words)", (long long)op,
                   (long long)n_words);
@@ -276,10 +287,11 @@ extern "C" int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_o
     const int64_t* a = words + pos + 1;
     pos += 1 + na;
     void* st = stream;
-    if (flags & LIDAL_OP_FLAG_SIDE) {
-      LIDAL_REQUIRE(side_stream != nullptr && side_open, "plan_run: op %lld (%s) wants the side stream outside a "
-                    "fork / join bracket", (long long)op, kOps[kind].name);
-      st = side_stream;
+    const int sidx = flags & 0xF;               // 0 = the main stream, i = side stream i
+    if (sidx != 0 && kind != LIDAL_OP_FORK_SIDE && kind != LIDAL_OP_JOIN_SIDE) {
+      LIDAL_REQUIRE(sidx < n_streams && streams[sidx] != nullptr && side_open[sidx], "plan_run: op %lld (%s) wants side "
+                    "stream %d outside a fork / join bracket", (long long)op, kOps[kind].name, sidx);
+      st = streams[sidx];
     }
     int rc = 0;
     switch (kind) {
@@ -295,6 +307,16 @@ extern "C" int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_o
         rc = lidal_conv_dgrad_bn_sums(P(0), P(1), CP(int32_t, 2), CP(int32_t, 3), CP(uint32_t, 4), P(5), L(6), L(7),
                                       I(8), I(9), I(10), I(11), I(12), P(13), CP(float, 14), CP(float, 15),
                                       CP(float, 16), CP(float, 17), I(18), MP(float, 19), st);
+        break;
+      case LIDAL_OP_CONV_APPLY_IMAGE_WS:
+        rc = lidal_conv_apply_image_ws(P(0), P(1), CP(int32_t, 2), CP(int32_t, 3), CP(uint32_t, 4), P(5), L(6), L(7),
+                                       I(8), I(9), I(10), I(11), I(12), CP(float, 13), CP(float, 14), I(15), P(16),
+                                       MP(float, 17), P(18), L(19), st);
+        break;
+      case LIDAL_OP_CONV_DGRAD_BN_SUMS_WS:
+        rc = lidal_conv_dgrad_bn_sums_ws(P(0), P(1), CP(int32_t, 2), CP(int32_t, 3), CP(uint32_t, 4), P(5), L(6), L(7),
+                                         I(8), I(9), I(10), I(11), I(12), P(13), CP(float, 14), CP(float, 15),
+                                         CP(float, 16), CP(float, 17), I(18), MP(float, 19), P(20), L(21), st);
         break;
       case LIDAL_OP_CONV_WGRAD:
         rc = lidal_conv_wgrad(P(0), P(1), L(2), L(3), CP(int32_t, 4), CP(int64_t, 5), I(6), MP(float, 7), MP(float, 8),
@@ -373,22 +395,26 @@ extern "C" int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_o
       case LIDAL_OP_VIEW_MEAN_SOFTMAX:
         rc = lidal_view_mean_softmax(CP(float, 0), CP(int64_t, 1), I(2), L(3), I(4), MP(float, 5), MP(int64_t, 6), st);
         break;
-      case LIDAL_OP_FORK_SIDE: {         // the side stream waits for everything queued on `stream` so far
-        LIDAL_REQUIRE(side_stream != nullptr, "plan_run: op %lld forks without a side stream", (long long)op);
+      case LIDAL_OP_FORK_SIDE: {         // side stream i (the flags; 0 means 1) waits for everything queued on the main stream so far
+        const int i = sidx ? sidx : 1;
+        LIDAL_REQUIRE(i < n_streams && streams[i] != nullptr, "plan_run: op %lld forks to side stream %d, which was not "
+                      "given", (long long)op, i);
         hipEvent_t *fe, *je;
-        if (side_events(&fe, &je)) return 1;
+        if (side_events(i, &fe, &je)) return 1;
         LIDAL_HIP(hipEventRecord(*fe, (hipStream_t)stream));
-        LIDAL_HIP(hipStreamWaitEvent((hipStream_t)side_stream, *fe, 0));
-        side_open = true;
+        LIDAL_HIP(hipStreamWaitEvent((hipStream_t)streams[i], *fe, 0));
+        side_open[i] = true;
         break;
       }
-      case LIDAL_OP_JOIN_SIDE: {         // `stream` waits for everything queued on the side stream so far
-        LIDAL_REQUIRE(side_stream != nullptr, "plan_run: op %lld joins without a side stream", (long long)op);
+      case LIDAL_OP_JOIN_SIDE: {         // the main stream waits for everything queued on side stream i so far
+        const int i = sidx ? sidx : 1;
+        LIDAL_REQUIRE(i < n_streams && streams[i] != nullptr, "plan_run: op %lld joins side stream %d, which was not "
+                      "given", (long long)op, i);
         hipEvent_t *fe, *je;
-        if (side_events(&fe, &je)) return 1;
-        LIDAL_HIP(hipEventRecord(*je, (hipStream_t)side_stream));
+        if (side_events(i, &fe, &je)) return 1;
+        LIDAL_HIP(hipEventRecord(*je, (hipStream_t)streams[i]));
         LIDAL_HIP(hipStreamWaitEvent((hipStream_t)stream, *je, 0));
-        side_open = false;
+        side_open[i] = false;
         break;
       }
       default:

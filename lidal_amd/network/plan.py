@@ -27,6 +27,7 @@ What still goes through torch inside a planned step: the two in-place dropouts o
 its per-parameter views (one call), and the optimizer.
 """
 import array
+import ctypes
 import os
 import struct
 
@@ -48,7 +49,7 @@ OP_BN_TRAIN_FWD, OP_BN_TRAIN_FWD_TILES, OP_BN_BWD, OP_BN_BWD_TILES, OP_BN_EVAL_F
 OP_COLSUM, OP_ADD_RELU_FWD, OP_ADD_RELU_BWD, OP_VOXELIZE_FWD_1TO1, OP_VOXELIZE_FWD_SORTED = 11, 12, 13, 14, 15
 OP_VOXELIZE_BWD, OP_DEVOXELIZE_FWD, OP_DEVOXELIZE_BWD_SORTED, OP_CE_FWD, OP_CE_BWD = 16, 17, 18, 19, 20
 OP_COPY2D, OP_ADD2D, OP_TRANSPOSE_F32, OP_CAST_ROWS_BF16, OP_VIEW_MEAN_SOFTMAX = 21, 22, 23, 24, 25
-OP_FORK_SIDE, OP_JOIN_SIDE = 26, 27
+OP_FORK_SIDE, OP_JOIN_SIDE, OP_CONV_APPLY_IMAGE_WS, OP_CONV_DGRAD_BN_SUMS_WS = 26, 27, 28, 29
 
 # operations executed inside plans ('ops') and plans run ('plans') since import (backend.HITS counts every
 # library call made from Python, 'plan_run' among them)
@@ -69,13 +70,18 @@ TRACE = None
 # single scan).  Measured, 3 runs each, same box: 5 scans 16.05 / 16.05 / 16.11 -> 15.42 / 15.39 / 15.38 ms,
 # one scan 7.47 / 7.48 / 7.46 -> 7.01 / 7.82 / 7.02 ms (scripts/exp/side_wgrad.sh).  Same kernels, same results.
 SIDE_ROWS = int(os.environ.get('LIDAL_PLAN_SIDE_ROWS', str(1 << 40)))
+# The shortcut branch of a residual block (1x1x1 convolution + BatchNorm, forward and backward) runs on a THIRD stream
+# beside the block's main branch where the level has at least this many rows (0 = never): 5 scans 15.24 / 15.28 / 15.27
+# -> 15.12 / 15.01 / 15.06 ms; on one scan the extra fork / join pairs cost what the overlap wins
+# (scripts/exp/branch_side.sh), hence the threshold.
+BRANCH_ROWS = int(os.environ.get('LIDAL_PLAN_BRANCH_ROWS', '30000'))
 _NARGS = {}
 _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
               6: 'bn_train_fwd', 7: 'bn_bwd', 8: 'bn_bwd', 9: 'bn_eval_fwd', 10: 'bn_fold', 11: 'colsum',
               12: 'add_relu_fwd', 13: 'add_relu_bwd', 14: 'voxelize_fwd_1to1', 15: 'voxelize_fwd_sorted',
               16: 'voxelize_bwd', 17: 'devoxelize_fwd', 18: 'devoxelize_bwd_sorted', 19: 'ce_fwd', 20: 'ce_bwd',
               21: 'copy2d', 22: 'add2d', 23: 'transpose_f32', 24: 'cast_rows_bf16', 25: 'view_mean_softmax',
-              26: 'fork_side', 27: 'join_side'}
+              26: 'fork_side', 27: 'join_side', 28: 'conv_apply', 29: 'conv_apply'}
 
 
 def _tally(words):
@@ -87,7 +93,7 @@ def _tally(words):
     while i < n:
         kind = words[i] & 0xFFFF
         name = _HIT_NAMES[kind]
-        if kind == OP_CONV_APPLY_IMAGE and words[i + 3] == 0:
+        if kind in (OP_CONV_APPLY_IMAGE, OP_CONV_APPLY_IMAGE_WS) and words[i + 3] == 0:
             name = 'conv_apply(dense)'
         elif kind == OP_CONV_WGRAD and words[i + 5] == 0:
             name = 'conv_wgrad(dense)'
@@ -534,8 +540,8 @@ class _Run:
         self.noise = []
         self.keep = []
         self.tapes = [] if (TRACE is not None and self.TRAIN) else None
-        self.side_stream = None
-        self.side_open = False
+        self.sides = {}                     # side stream index -> raw stream
+        self.open = set()                   # side streams forked and not joined yet
         self.w = []
         self.nops = 0
         self.done = False
@@ -620,10 +626,8 @@ class _Run:
     def flush(self):
         if not self.nops:
             return
-        if self.side_open:                  # every stretch of the plan ends with the main stream waiting for the side stream
-            self.w.append(OP_JOIN_SIDE)
-            self.nops += 1
-            self.side_open = False
+        for which in sorted(self.open):     # every stretch of the plan ends with the main stream waiting for the side streams
+            self.join(which)
         if TALLY:
             _tally(self.w)
         if self.tapes is not None:
@@ -631,7 +635,12 @@ class _Run:
         arr = array.array('q', self.w)
         addr, n_words = arr.buffer_info()
         L = B.lib_handle()
-        rc = L.lidal_plan_run(addr, n_words, self.nops, self.stream, self.side_stream)
+        if self.sides:
+            n = max(self.sides) + 1
+            streams = (ctypes.c_void_p * n)(*([self.stream] + [self.sides.get(i) for i in range(1, n)]))
+            rc = L.lidal_plan_run_streams(addr, n_words, self.nops, streams, n)
+        else:
+            rc = L.lidal_plan_run(addr, n_words, self.nops, self.stream, None)
         COUNTERS['plans'] += 1
         COUNTERS['ops'] += self.nops
         B.HITS['plan_run'] = B.HITS.get('plan_run', 0) + 1
@@ -640,22 +649,29 @@ class _Run:
         if rc != 0:
             raise RuntimeError('lidal_amd.plan_run failed (%d): %s' % (rc, L.lidal_last_error().decode()))
 
-    def scratch(self, nbytes):
-        return _scratch(self.dev, self.stream, nbytes, self.keep)
+    def scratch(self, nbytes, flag=0):
+        """Workspace of one operation on the main stream, or (flag = a side stream's) on that side stream."""
+        return _scratch(self.dev, (self.stream, flag) if flag else self.stream, nbytes, self.keep)
+
+    def fork(self, which):
+        """Side stream `which` waits for what the plan has queued on the main stream so far; -> the flag of its operations."""
+        if which not in self.sides:
+            self.sides[which] = B.side_stream(self.dev, which).cuda_stream
+        self.w.append(OP_FORK_SIDE | (which << 16))
+        self.nops += 1
+        self.open.add(which)
+        return which << 16
+
+    def join(self, which):
+        self.w.append(OP_JOIN_SIDE | (which << 16))
+        self.nops += 1
+        self.open.discard(which)
 
     def side(self, rows):
-        """Operation kind flags for a weight gradient over `rows` rows: LIDAL_OP_FLAG_SIDE (after a fork) or 0."""
+        """Flag of a weight gradient over `rows` rows: side stream 1 (after a fork), or 0 = the main stream."""
         if not SIDE_ROWS or rows > SIDE_ROWS:
             return 0
-        if self.side_stream is None:
-            self.side_stream = B.side_stream(self.dev).cuda_stream
-        self.w.append(OP_FORK_SIDE)         # the side stream waits for what the plan has queued so far (dx is among it)
-        self.nops += 1
-        self.side_open = True
-        return 1 << 16
-
-    def side_scratch(self, nbytes):
-        return _scratch(self.dev, (self.stream, 'side'), nbytes, self.keep)
+        return self.fork(1)
 
     # ===================================== forward ========================================================
     def f_conv(self, c, x, n_in, ci, table, n_out, stats):
@@ -663,22 +679,23 @@ class _Run:
         A = self.arena
         out = A.alloc(n_out * c.co * self.esz)
         st = A.alloc(-(-n_out // self.tile) * c.co * 12) if (stats and self.bf16) else 0
-        self.w += (OP_CONV_APPLY_IMAGE, x, c.img_f, table[0], table[1], table[2], out, n_in, n_out, ci, c.co, c.k, 0,
-                   self.code, 0, 0, 0, 0, st)
+        wb = _C.apply_workspace_bytes(n_out, c.co)
+        self.w += (OP_CONV_APPLY_IMAGE_WS, x, c.img_f, table[0], table[1], table[2], out, n_in, n_out, ci, c.co, c.k, 0,
+                   self.code, 0, 0, 0, 0, st, self.scratch(wb) if wb else 0, wb)
         self.nops += 1
         return out, st
 
-    def f_dense(self, c, x, n, co, shift, stats):
+    def f_dense(self, c, x, n, co, shift, stats, flag=0):
         """dense.py _rows_gemm (role 0): x [n, ci] @ W (+ shift) -> (out [n, co], tile statistics or 0)."""
         A = self.arena
         out = A.alloc(n * co * self.esz)
         st = A.alloc(-(-n // self.tile) * co * 12) if (stats and self.bf16) else 0
-        self.w += (OP_CONV_APPLY_IMAGE, x, c.img_f, 0, 0, 0, out, n, n, c.ci, co, 1, 0, self.code,
+        self.w += (OP_CONV_APPLY_IMAGE | flag, x, c.img_f, 0, 0, 0, out, n, n, c.ci, co, 1, 0, self.code,
                    self.ones if shift else 0, shift, 0, 0, st)
         self.nops += 1
         return out, st
 
-    def f_bn(self, r, x, n, st, residual=0, relu_after=False):
+    def f_bn(self, r, x, n, st, residual=0, relu_after=False, flag=0):
         """norm.py train_forward: -> (y, mean, invstd)."""
         A, p = self.arena, self.ptr
         c = r.c
@@ -687,12 +704,12 @@ class _Run:
         invstd = A.alloc(c * 4)
         relu = r.relu | (2 if (relu_after and residual) else 0)
         if st:
-            self.w += (OP_BN_TRAIN_FWD_TILES, x, self.code, n, c, p[r.w], p[r.b], r.eps, r.mom, p[r.rm], p[r.rv],
+            self.w += (OP_BN_TRAIN_FWD_TILES | flag, x, self.code, n, c, p[r.w], p[r.b], r.eps, r.mom, p[r.rm], p[r.rv],
                        p[r.nbt], relu, residual, y, mean, invstd, st, -(-n // self.tile))
         else:
             nb = _bn_ws(n, c)
-            self.w += (OP_BN_TRAIN_FWD, x, self.code, n, c, p[r.w], p[r.b], r.eps, r.mom, p[r.rm], p[r.rv],
-                       p[r.nbt], relu, residual, y, mean, invstd, self.scratch(nb), nb)
+            self.w += (OP_BN_TRAIN_FWD | flag, x, self.code, n, c, p[r.w], p[r.b], r.eps, r.mom, p[r.rm], p[r.rv],
+                       p[r.nbt], relu, residual, y, mean, invstd, self.scratch(nb, flag), nb)
         self.nops += 1
         return y, mean, invstd
 
@@ -706,15 +723,19 @@ class _Run:
 
     def f_res(self, r, x, n, table):
         """blocks._Residual.forward."""
-        x1, st1 = self.f_conv(r.c1, x, n, r.c1.ci, table, n, True)
-        y1, mean1, inv1 = self.f_bn(r.b1, x1, n, st1)
-        x2, st2 = self.f_conv(r.c2, y1, n, r.c2.ci, table, n, True)
-        if r.cs is not None:
-            xs, sts = self.f_dense(r.cs, x, n, r.cs.co, 0, True)
-            res, means, invs = self.f_bn(r.bs, xs, n, sts)
+        fl = 0
+        if r.cs is not None:                # the shortcut convolution + BatchNorm: independent of the main branch
+            fl = self.fork(2) if (BRANCH_ROWS and n >= BRANCH_ROWS) else 0
+            xs, sts = self.f_dense(r.cs, x, n, r.cs.co, 0, True, fl)
+            res, means, invs = self.f_bn(r.bs, xs, n, sts, flag=fl)
         else:
             xs = means = invs = 0
             res = x
+        x1, st1 = self.f_conv(r.c1, x, n, r.c1.ci, table, n, True)
+        y1, mean1, inv1 = self.f_bn(r.b1, x1, n, st1)
+        x2, st2 = self.f_conv(r.c2, y1, n, r.c2.ci, table, n, True)
+        if fl:
+            self.join(2)
         out, mean2, inv2 = self.f_bn(r.b2, x2, n, st2, res, True)
         self.saved[id(r)] = (x, x1, mean1, inv1, y1, x2, mean2, inv2, out, xs, means, invs)
         return out
@@ -859,19 +880,19 @@ class _Run:
     def slot(self, i):
         return self.flat + 4 * self.prog.slot[i]
 
-    def b_bn(self, r, x, n, mean, invstd, g, g_stride, sums=0, relu=None):
+    def b_bn(self, r, x, n, mean, invstd, g, g_stride, sums=0, relu=None, flag=0):
         """norm.py train_backward (without the mask_from part): -> dx."""
         p = self.ptr
         c = r.c
         dx = self.galloc(n * c * self.esz)
         relu = r.relu if relu is None else relu
         if sums:
-            self.w += (OP_BN_BWD_TILES, x, g, g_stride, self.code, n, c, p[r.w], p[r.b], relu, mean, invstd, dx,
+            self.w += (OP_BN_BWD_TILES | flag, x, g, g_stride, self.code, n, c, p[r.w], p[r.b], relu, mean, invstd, dx,
                        self.slot(r.w), self.slot(r.b), sums, -(-n // self.tile))
         else:
             nb = _bn_ws(n, c)
-            self.w += (OP_BN_BWD, x, g, g_stride, self.code, n, c, p[r.w], p[r.b], relu, mean, invstd, dx,
-                       self.slot(r.w), self.slot(r.b), self.scratch(nb), nb)
+            self.w += (OP_BN_BWD | flag, x, g, g_stride, self.code, n, c, p[r.w], p[r.b], relu, mean, invstd, dx,
+                       self.slot(r.w), self.slot(r.b), self.scratch(nb, flag), nb)
         self.nops += 1
         return dx
 
@@ -881,7 +902,7 @@ class _Run:
         slabs = _slabs(n_x, n_g, c.k, ci, c.co, self.code)
         flag = self.side(max(n_x, n_g))
         nbytes = slabs * ci * c.co * 4 + (c.k * ci * c.co * 4 if ci != c.ci else 0)
-        partial = self.side_scratch(nbytes) if flag else self.scratch(nbytes)
+        partial = self.scratch(nbytes, flag)
         gw = self.slot(c.w)
         if ci != c.ci:                      # the channel-padded stem: gw[:, :ci_w] of the padded gradient
             gw = partial + slabs * ci * c.co * 4
@@ -895,25 +916,29 @@ class _Run:
     def b_dgrad(self, c, g, n_g, table, n_out, kflip, skip=0, bnb=None):
         """conv.py conv_backward's data gradient: -> (gin [n_out, ci], tile sums or 0)."""
         gin = self.galloc(n_out * c.ci * self.esz)
+        wb = _C.apply_workspace_bytes(n_out, c.ci)
+        ws = self.scratch(wb) if wb else 0
         if bnb is not None:
             sums = self.galloc(-(-n_out // self.tile) * c.ci * 8)
-            self.w += (OP_CONV_DGRAD_BN_SUMS, g, c.img_b, table[0], table[1], table[2], gin, n_g, n_out, c.co, c.ci,
-                       c.k, kflip, self.code) + bnb + (sums,)
+            self.w += (OP_CONV_DGRAD_BN_SUMS_WS, g, c.img_b, table[0], table[1], table[2], gin, n_g, n_out, c.co, c.ci,
+                       c.k, kflip, self.code) + bnb + (sums, ws, wb)
             self.nops += 1
             return gin, sums
-        self.w += (OP_CONV_APPLY_IMAGE, g, c.img_b, table[0], table[1], table[2], gin, n_g, n_out, c.co, c.ci, c.k,
-                   kflip, self.code, 0, 0, 0, skip, 0)
+        self.w += (OP_CONV_APPLY_IMAGE_WS, g, c.img_b, table[0], table[1], table[2], gin, n_g, n_out, c.co, c.ci, c.k,
+                   kflip, self.code, 0, 0, 0, skip, 0, ws, wb)
         self.nops += 1
         return gin, 0
 
-    def b_dense(self, c, x, n, g, cg, need_gx=True, linear_slot=None):
-        """dense.py rows_backward (weight gradient x^T g, then the data gradient g W^T): -> gx or 0."""
+    def b_dense(self, c, x, n, g, cg, need_gx=True, linear_slot=None, branch=0):
+        """dense.py rows_backward (weight gradient x^T g, then the data gradient g W^T): -> gx or 0.
+        `branch`: the flag of the side stream the whole layer runs on (0: data gradient on the main stream, weight
+        gradient per side())."""
         ca, cb = c.ci, cg
         slabs = _slabs(n, n, 1, ca, cb, self.code)
         direct = linear_slot is None and cb == c.co
-        flag = self.side(n)
+        flag = branch or self.side(n)
         nbytes = slabs * ca * cb * 4 + (0 if direct else ca * cb * 4)
-        sc = self.side_scratch(nbytes) if flag else self.scratch(nbytes)
+        sc = self.scratch(nbytes, flag)
         gw = self.slot(c.w) if direct else sc + slabs * ca * cb * 4
         self.w += (OP_CONV_WGRAD | flag, x, g, n, n, 0, self.koff[n], 0, gw, sc, slabs, 1, ca, cb, self.code)
         self.nops += 1
@@ -923,7 +948,7 @@ class _Run:
         if not need_gx:
             return 0
         gx = self.galloc(n * ca * self.esz)
-        self.w += (OP_CONV_APPLY_IMAGE, g, c.img_b, 0, 0, 0, gx, n, n, cb, ca, 1, 0, self.code, 0, 0, 0, 0, 0)
+        self.w += (OP_CONV_APPLY_IMAGE | branch, g, c.img_b, 0, 0, 0, gx, n, n, cb, ca, 1, 0, self.code, 0, 0, 0, 0, 0)
         self.nops += 1
         return gx
 
@@ -955,12 +980,14 @@ class _Run:
         gm = self.galloc(n * co * self.esz)
         self.w += (OP_ADD_RELU_BWD, out, g, gm, n * co, self.code)
         self.nops += 1
-        dx2 = self.b_bn(r.b2, x2, n, mean2, inv2, gm, co, 0, 0)
-        if r.cs is not None:
-            dxs = self.b_bn(r.bs, xs, n, means, invs, gm, co)
-            g_skip = self.b_dense(r.cs, x, n, dxs, co)
+        fl = 0
+        if r.cs is not None:                # the shortcut's backward: independent of the main branch until conv1's data gradient
+            fl = self.fork(2) if (BRANCH_ROWS and n >= BRANCH_ROWS) else 0
+            dxs = self.b_bn(r.bs, xs, n, means, invs, gm, co, flag=fl)
+            g_skip = self.b_dense(r.cs, x, n, dxs, co, branch=fl)
         else:
             g_skip = gm
+        dx2 = self.b_bn(r.b2, x2, n, mean2, inv2, gm, co, 0, 0)
         table, rules = k3[0:3], k3[3:5]
         self.b_wgrad(r.c2, y1, n, dx2, n, rules)
         p = self.ptr
@@ -968,6 +995,8 @@ class _Run:
         dy1, sums = self.b_dgrad(r.c2, dx2, n, table, n, 1, 0, bnb)
         dx1 = self.b_bn(r.b1, x1, n, mean1, inv1, dy1, r.c1.co, sums)
         self.b_wgrad(r.c1, x, n, dx1, n, rules)
+        if fl:
+            self.join(2)
         return self.b_dgrad(r.c1, dx1, n, table, n, 1, g_skip)[0]
 
     def b_add(self, a, a_stride, b, b_stride, n, c):
@@ -1148,8 +1177,10 @@ class _EvalRun(_Run):
     def f_conv_bn(self, cb, x, n_in, table, n_out, ci=None):
         c, r = cb
         out = self.arena.alloc(n_out * c.co * self.esz)
-        self.w += (OP_CONV_APPLY_IMAGE, x, c.img_f, table[0], table[1], table[2], out, n_in, n_out,
-                   c.ci if ci is None else ci, c.co, c.k, 0, self.code, r.scale, r.shift, r.relu, 0, 0)
+        wb = _C.apply_workspace_bytes(n_out, c.co)
+        self.w += (OP_CONV_APPLY_IMAGE_WS, x, c.img_f, table[0], table[1], table[2], out, n_in, n_out,
+                   c.ci if ci is None else ci, c.co, c.k, 0, self.code, r.scale, r.shift, r.relu, 0, 0,
+                   self.scratch(wb) if wb else 0, wb)
         self.nops += 1
         return out
 
@@ -1163,10 +1194,11 @@ class _EvalRun(_Run):
             self.nops += 1
         y1 = A.alloc(n * r.c1.co * e)
         out = A.alloc(n * r.c2.co * e)
-        self.w += (OP_CONV_APPLY_IMAGE, x, r.c1.img_f, table[0], table[1], table[2], y1, n, n, r.c1.ci, r.c1.co, r.c1.k,
-                   0, self.code, r.b1.scale, r.b1.shift, 1, 0, 0,
-                   OP_CONV_APPLY_IMAGE, y1, r.c2.img_f, table[0], table[1], table[2], out, n, n, r.c2.ci, r.c2.co,
-                   r.c2.k, 0, self.code, r.b2.scale, r.b2.shift, 2, skip, 0)
+        wb1, wb2 = _C.apply_workspace_bytes(n, r.c1.co), _C.apply_workspace_bytes(n, r.c2.co)
+        self.w += (OP_CONV_APPLY_IMAGE_WS, x, r.c1.img_f, table[0], table[1], table[2], y1, n, n, r.c1.ci, r.c1.co, r.c1.k,
+                   0, self.code, r.b1.scale, r.b1.shift, 1, 0, 0, self.scratch(wb1) if wb1 else 0, wb1,
+                   OP_CONV_APPLY_IMAGE_WS, y1, r.c2.img_f, table[0], table[1], table[2], out, n, n, r.c2.ci, r.c2.co,
+                   r.c2.k, 0, self.code, r.b2.scale, r.b2.shift, 2, skip, 0, self.scratch(wb2) if wb2 else 0, wb2)
         self.nops += 2
         return out
 

@@ -521,27 +521,45 @@ def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False, bnb
     want_stats = want_stats and feats.dtype == torch.bfloat16
     if want_stats:              # (count, mean, M2) per 128-row tile and column, for the BatchNorm that follows
         stats = torch.empty((-(-n_out // B.stats_tile_rows()), co, 3), dtype=torch.float32, device=feats.device)
+    # the library may split the offsets of a coarse level's tiles over several workgroups (csrc/conv_img.hip, Split):
+    # the f32 partial tiles go through a workspace
+    ws_bytes = apply_workspace_bytes(n_out, co)
+    ws = B.workspace(ws_bytes, feats.device) if ws_bytes else None
     if bnb is not None:         # a data gradient that also leaves the backward sums of the BatchNorm in front of it
         bx, mean, invstd, gamma, beta, relu_bn = bnb
         assert epilogue is None and not want_stats and bx.shape == (n_out, co) and bx.dtype == feats.dtype
         sums = torch.empty((-(-n_out // B.stats_tile_rows()), co, 2), dtype=torch.float32, device=feats.device)
-        B.check(B.lib().lidal_conv_dgrad_bn_sums(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
-                                                 B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
-                                                 co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(bx),
-                                                 B.ptr(mean), B.ptr(invstd), B.ptr(gamma), B.ptr(beta),
-                                                 int(bool(relu_bn)), B.ptr(sums), B.stream()),
+        B.check(B.lib().lidal_conv_dgrad_bn_sums_ws(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
+                                                    B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
+                                                    co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(bx),
+                                                    B.ptr(mean), B.ptr(invstd), B.ptr(gamma), B.ptr(beta),
+                                                    int(bool(relu_bn)), B.ptr(sums), B.ptr(ws), ws_bytes, B.stream()),
                 'conv_apply')
         out._lidal_bnb_sums = sums
         return out
-    B.check(B.lib().lidal_conv_apply_image(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
-                                           B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
-                                           co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(scale),
-                                           B.ptr(shift), int(relu), B.ptr(residual), B.ptr(stats),
-                                           B.stream()),
+    B.check(B.lib().lidal_conv_apply_image_ws(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
+                                              B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
+                                              co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(scale),
+                                              B.ptr(shift), int(relu), B.ptr(residual), B.ptr(stats),
+                                              B.ptr(ws), ws_bytes, B.stream()),
             'conv_apply')
     if want_stats:
         out._lidal_bn_stats = stats     # picked up by spnn.BatchNorm (nn/functional/norm.py)
     return out
+
+
+_APPLY_WS = {}
+
+
+def apply_workspace_bytes(n_out, co):
+    """lidal_conv_apply_workspace_bytes, memoised."""
+    key = (n_out, co)
+    v = _APPLY_WS.get(key)
+    if v is None:
+        if len(_APPLY_WS) > 4096:
+            _APPLY_WS.clear()
+        v = _APPLY_WS[key] = int(B.lib_handle().lidal_conv_apply_workspace_bytes(n_out, co))
+    return v
 
 
 def wgrad_scratch(n_a, n_b, k, ca, cb, dtype, device):

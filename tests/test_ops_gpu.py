@@ -1141,3 +1141,72 @@ def test_revoxelize_coords_is_the_reference_expression_bit_for_bit():
                 'revoxelize_coords')
         assert torch.equal(got_f.cpu(), want), (init_res, after_res)
         assert torch.equal(got_i.cpu(), torch.floor(want).int())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_with_split_offsets_equals_the_unsplit_kernel(dtype):
+    """On the coarse levels (few 128-row tiles, long chains of (offset, slice) phases) lidal_conv_apply_image_ws
+    splits each tile's active offsets over 2-4 workgroups and a second kernel adds the f32 partial tiles and runs the
+    epilogue (csrc/conv_img.hip, Split).  Against the unsplit launch (no workspace): the f32 sums differ only by their
+    association -- 2e-6 relative in f32, at most one flipped rounding per few thousand elements in bf16 -- and the
+    epilogue products (BatchNorm tile statistics, residual + ReLU, the data gradient's BatchNorm sums) follow."""
+    from lidal_amd import backend as B
+    F = _F()
+    L = B.lib()
+    code = B.dtype_code(dtype)
+    g = torch.Generator().manual_seed(31)
+    coords = _surface_coords(40, 2, seed=9).to(DEV)                  # 3200 rows = 25 tiles: the layer shapes below split
+    kmap, _ = F.build_kernel_map(coords, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    order = kmap.order_out
+    n = coords.shape[0]
+    for ci, co in ((128, 128), (256, 256), (192, 128), (64, 64)):
+        x = torch.randn(n, ci, generator=g).to(dtype).to(DEV)
+        w = (torch.randn(27, ci, co, generator=g) * 0.1).to(DEV)
+        nb = L.lidal_conv_weight_image_bytes(27, ci, co, code, n)
+        img = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        B.check(L.lidal_conv_weight_image(B.ptr(w), B.F32, 0, B.ptr(img), code, 27, ci, co, n, B.stream()), 'image')
+        wsb = L.lidal_conv_apply_workspace_bytes(n, co)
+        assert wsb > 0
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        res = torch.randn(n, co, generator=g).to(dtype).to(DEV)
+        tiles = -(-n // L.lidal_conv_stats_tile_rows())
+        for kflip, with_res in ((0, False), (1, True)):
+            outs, stats = [], []
+            for use_ws in (False, True):
+                out = torch.full((n, co), float('nan'), dtype=dtype, device=DEV)
+                st = torch.zeros((tiles, co, 3), dtype=torch.float32, device=DEV) if not with_res else None
+                B.check(L.lidal_conv_apply_image_ws(B.ptr(x), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
+                                                    B.ptr(order.tile_masks), B.ptr(out), n, n, ci, co, 27, kflip, code,
+                                                    None, None, 2 if with_res else 0, B.ptr(res) if with_res else None,
+                                                    B.ptr(st), B.ptr(ws) if use_ws else None, wsb if use_ws else 0,
+                                                    B.stream()), 'conv')
+                outs.append(out.double())
+                stats.append(st)
+            a, b = outs
+            assert not torch.isnan(b).any()
+            scale = float(a.abs().max())
+            if dtype == torch.float32:
+                assert _relerr(b, a) < 1e-5
+            else:                       # a flipped rounding here and there: one bf16 ulp of the value (or of a summand that cancelled)
+                assert float((a != b).double().mean()) < 5e-3
+                ulp = 2.0 ** -7 * a.abs().clamp_min(0.05 * scale)
+                assert float(((a - b).abs() > ulp).double().mean()) < 1e-4          # (a flip in a summand that then cancelled)
+                assert bool(((a - b).abs() <= 4 * ulp).all())
+            if stats[0] is not None:
+                assert torch.equal(stats[0][:, :, 0], stats[1][:, :, 0])                    # counts
+                assert float((stats[1][:, :, 1] - stats[0][:, :, 1]).abs().max()) < 2e-3 * scale      # per-tile means
+        if dtype == torch.bfloat16:                 # the data gradient that also leaves BatchNorm backward sums
+            bx = torch.randn(n, co, generator=g).to(dtype).to(DEV)
+            mean, invstd = torch.randn(co, generator=g).to(DEV) * 0.1, (torch.rand(co, generator=g) + 0.5).to(DEV)
+            gam, bet = (torch.rand(co, generator=g) + 0.5).to(DEV), torch.randn(co, generator=g).to(DEV) * 0.1
+            sums = []
+            for use_ws in (False, True):
+                out = torch.empty((n, co), dtype=dtype, device=DEV)
+                sm = torch.zeros((tiles, co, 2), dtype=torch.float32, device=DEV)
+                B.check(L.lidal_conv_dgrad_bn_sums_ws(B.ptr(x), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
+                                                      B.ptr(order.tile_masks), B.ptr(out), n, n, ci, co, 27, 1, code,
+                                                      B.ptr(bx), B.ptr(mean), B.ptr(invstd), B.ptr(gam), B.ptr(bet), 1,
+                                                      B.ptr(sm), B.ptr(ws) if use_ws else None, wsb if use_ws else 0,
+                                                      B.stream()), 'dgrad')
+                sums.append(sm.double().sum(0))
+            assert _relerr(sums[1], sums[0]) < 5e-3

@@ -166,7 +166,7 @@ def _replay(run, model, stats, conv_every=1):
             na = L.lidal_plan_op_args(kind)
             a = words[i + 1:i + 1 + na]
             i += 1 + na
-            if kind in (P.OP_CONV_APPLY_IMAGE, P.OP_CONV_DGRAD_BN_SUMS):
+            if kind in (P.OP_CONV_APPLY_IMAGE, P.OP_CONV_DGRAD_BN_SUMS, P.OP_CONV_APPLY_IMAGE_WS, P.OP_CONV_DGRAD_BN_SUMS_WS):
                 x_p, img, tab, _, _, out_p, n_in, n_out, ci, co, k, kflip, code = a[:13]
                 n_conv += 1
                 if n_conv % conv_every:
@@ -183,7 +183,7 @@ def _replay(run, model, stats, conv_every=1):
                     ref = _conv_apply(x, w, nbmaps, nbsizes, sizes, bool(inv) != bool(kflip))
                     what = '%s k%d %s %d->%d rows %d' % (pname[c.w], k, 'dgrad' if backward else 'fwd', ci, co, n_out)
                 assert ref.shape == (n_out, co), (what, ref.shape)
-                if kind == P.OP_CONV_APPLY_IMAGE:
+                if kind in (P.OP_CONV_APPLY_IMAGE, P.OP_CONV_APPLY_IMAGE_WS):
                     scale, shift, relu, res = a[13:17]
                     if shift:
                         ref = ref * _vec(scale, co).double() + _vec(shift, co).double()

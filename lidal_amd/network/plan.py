@@ -70,11 +70,12 @@ TRACE = None
 # single scan).  Measured, 3 runs each, same box: 5 scans 16.05 / 16.05 / 16.11 -> 15.42 / 15.39 / 15.38 ms,
 # one scan 7.47 / 7.48 / 7.46 -> 7.01 / 7.82 / 7.02 ms (scripts/exp/side_wgrad.sh).  Same kernels, same results.
 SIDE_ROWS = int(os.environ.get('LIDAL_PLAN_SIDE_ROWS', str(1 << 40)))
+SIDE_MIN_ROWS = int(os.environ.get('LIDAL_PLAN_SIDE_MIN_ROWS', '0'))      # (measured: every threshold above 0 loses, matrix2.sh)
 # The shortcut branch of a residual block (1x1x1 convolution + BatchNorm, forward and backward) runs on a THIRD stream
-# beside the block's main branch where the level has at least this many rows (0 = never): 5 scans 15.24 / 15.28 / 15.27
-# -> 15.12 / 15.01 / 15.06 ms; on one scan the extra fork / join pairs cost what the overlap wins
-# (scripts/exp/branch_side.sh), hence the threshold.
-BRANCH_ROWS = int(os.environ.get('LIDAL_PLAN_BRANCH_ROWS', '30000'))
+# beside the block's main branch where the level has at least this many rows (0 = never): 5 scans 15.37 / 15.38 / 15.34
+# -> 15.19 / 15.24 ms; on one scan the extra fork / join pairs cost the host what the overlap wins on the GPU (6.65 /
+# 7.24 -> 6.81 / 7.42 ms; scripts/exp/matrix.sh, matrix2.sh), hence the threshold: the levels of a multi-scan batch.
+BRANCH_ROWS = int(os.environ.get('LIDAL_PLAN_BRANCH_ROWS', '100000'))
 _NARGS = {}
 _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
               6: 'bn_train_fwd', 7: 'bn_bwd', 8: 'bn_bwd', 9: 'bn_eval_fwd', 10: 'bn_fold', 11: 'colsum',
@@ -669,7 +670,7 @@ class _Run:
 
     def side(self, rows):
         """Flag of a weight gradient over `rows` rows: side stream 1 (after a fork), or 0 = the main stream."""
-        if not SIDE_ROWS or rows > SIDE_ROWS:
+        if not SIDE_ROWS or rows > SIDE_ROWS or rows < SIDE_MIN_ROWS:
             return 0
         return self.fork(1)
 

@@ -549,10 +549,13 @@ def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False, bnb
 
 
 _APPLY_WS = {}
+_SPLIT = os.environ.get('LIDAL_CONV_SPLIT', '1') != '0'
 
 
 def apply_workspace_bytes(n_out, co):
-    """lidal_conv_apply_workspace_bytes, memoised."""
+    """lidal_conv_apply_workspace_bytes, memoised (0 with LIDAL_CONV_SPLIT=0: no launch is split then)."""
+    if not _SPLIT:
+        return 0
     key = (n_out, co)
     v = _APPLY_WS.get(key)
     if v is None:

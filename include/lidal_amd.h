@@ -414,7 +414,8 @@ int lidal_register_points(const float* points, int64_t p, const double* pose_dev
                           void* stream);
 /* Uniform-grid nearest-neighbour structure over one frame's world-frame points (replaces the
  * pickled sklearn KDTree of dataset/prepare_kdtree_sk.py:83 as used by
- * score/sv_level/LiDAL.py:52-66).  cell = match radius.
+ * score/sv_level/LiDAL.py:52-66).  cell: any size > 0 (kept in the grid; a query visits the cells that meet the cube of
+ * its match radius: 27 for cell = radius, at most 8 for cell = 2 x radius -- the answers are the same).
  *   pts f64 [p,3];  grid bytes from lidal_nn_grid_bytes(p). */
 int64_t lidal_nn_grid_bytes(int64_t p);
 int64_t lidal_nn_grid_workspace_bytes(int64_t p);

@@ -165,9 +165,10 @@ static inline GridView grid_view(const void* grid, int64_t p, int64_t cap, doubl
 
 __global__ void __launch_bounds__(256) grid_keys_kernel(const double* __restrict__ pts, int64_t p,
                                                         double cell, uint64_t* __restrict__ keys,
-                                                        int* __restrict__ idx) {
+                                                        int* __restrict__ idx, GridHeader* __restrict__ hdr) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p) return;
+  if (i == 0) { hdr->p = p; hdr->cap = 0; hdr->cell = cell; hdr->inv_cell_unused = 0.; }     // the queries read the cell size
   int64_t ix = (int64_t)floor(pts[i * 3 + 0] / cell), iy = (int64_t)floor(pts[i * 3 + 1] / cell),
           iz = (int64_t)floor(pts[i * 3 + 2] / cell);
   keys[i] = cell_key(ix, iy, iz);
@@ -189,17 +190,22 @@ __global__ void __launch_bounds__(256) grid_heads_kernel(const uint64_t* __restr
   }
 }
 
-// nearest point of the grid's frame within the 27 cells around q; returns index or -1, *d2out
+// nearest point of the grid's frame among the cells that meet the cube [q - r, q + r]^3 (27 cells when the cell is the
+// radius r, at most 8 when it is 2 r: round 4 -- a look-up is a random probe of a hash table, and LiDAR cells are mostly
+// empty); returns index or -1, *d2out.  The candidates are a superset of the ball's points either way and ties go to the
+// lowest index, so the answer does not depend on the cell size.
 __device__ __forceinline__ int grid_nearest(const GridView& g, const double* __restrict__ npts,
-                                            double qx, double qy, double qz, double* d2out) {
-  int64_t cx = (int64_t)floor(qx / g.cell), cy = (int64_t)floor(qy / g.cell),
-          cz = (int64_t)floor(qz / g.cell);
+                                            double qx, double qy, double qz, double r, double* d2out) {
+  const double rr = r * (1.0 + 1e-9) + 1e-12;            // (a point at exactly r must not fall off the cube through rounding)
+  const int64_t x0 = (int64_t)floor((qx - rr) / g.cell), x1 = (int64_t)floor((qx + rr) / g.cell);
+  const int64_t y0 = (int64_t)floor((qy - rr) / g.cell), y1 = (int64_t)floor((qy + rr) / g.cell);
+  const int64_t z0 = (int64_t)floor((qz - rr) / g.cell), z1 = (int64_t)floor((qz + rr) / g.cell);
   double best = INFINITY;
   int arg = -1;
-  for (int dx = -1; dx <= 1; ++dx)
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dz = -1; dz <= 1; ++dz) {
-        uint64_t key = cell_key(cx + dx, cy + dy, cz + dz);
+  for (int64_t ix = x0; ix <= x1; ++ix)
+    for (int64_t iy = y0; iy <= y1; ++iy)
+      for (int64_t iz = z0; iz <= z1; ++iz) {
+        uint64_t key = cell_key(ix, iy, iz);
         int start = table_lookup(g.t, key);
         if (start < 0) continue;
         for (int64_t s = start; s < g.p && g.keys[s] == key; ++s) {
@@ -246,10 +252,11 @@ interframe_match_kernel(const double* __restrict__ q_pts, int64_t p, NeiArgs nei
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y;
   if (i >= p) return;
+  if (nei.p[n] <= 0) { match[(int64_t)n * p + i] = -1; return; }
   const double qx = q_pts[i * 3 + 0], qy = q_pts[i * 3 + 1], qz = q_pts[i * 3 + 2];
-  const GridView g = nei_grid(nei, n, dis_thresh);
+  const GridView g = nei_grid(nei, n, reinterpret_cast<const GridHeader*>(nei.grid[n])->cell);
   double d2;
-  int j = grid_nearest(g, nei.pts[n], qx, qy, qz, &d2);
+  int j = grid_nearest(g, nei.pts[n], qx, qy, qz, dis_thresh, &d2);
   if (j >= 0 && !(sqrt(d2) <= dis_thresh)) j = -1;
   match[(int64_t)n * p + i] = j;
 }
@@ -387,7 +394,7 @@ extern "C" int lidal_nn_grid_build(const double* pts, int64_t p, double cell, vo
   void* tmp = (char*)ws + align_up(8 * q, 256) + align_up(4 * q, 256);
   uint64_t* skeys = (uint64_t*)(base + cap * 12);
   int* sidx = (int*)(base + cap * 12 + align_up(8 * q, 256));
-  grid_keys_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(pts, p, cell, keys, idx);
+  grid_keys_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(pts, p, cell, keys, idx, (GridHeader*)grid);
   LIDAL_CHECK_LAUNCH("grid_keys");
   if (int rc = radix_sort(keys, idx, skeys, sidx, p, 8, 63, tmp, (int64_t)sort_pairs_tmp_bytes(q), s)) return rc;
   TableView t;

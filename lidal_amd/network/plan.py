@@ -1188,19 +1188,24 @@ class _EvalRun(_Run):
     def f_res(self, r, x, n, table):
         A, e = self.arena, self.esz
         skip = x
-        if r.cs is not None:
+        fl = 0
+        if r.cs is not None:                # the shortcut: one dense kernel (on a side stream it measured no gain at
+            fl = 0                          # inference, and a loss beside the scorer's stream: scripts/exp/score_ab.sh)
             skip = A.alloc(n * r.cs.co * e)
-            self.w += (OP_CONV_APPLY_IMAGE, x, r.cs.img_f, 0, 0, 0, skip, n, n, r.cs.ci, r.cs.co, 1, 0, self.code,
+            self.w += (OP_CONV_APPLY_IMAGE | fl, x, r.cs.img_f, 0, 0, 0, skip, n, n, r.cs.ci, r.cs.co, 1, 0, self.code,
                        r.bs.scale, r.bs.shift, 0, 0, 0)
             self.nops += 1
         y1 = A.alloc(n * r.c1.co * e)
         out = A.alloc(n * r.c2.co * e)
         wb1, wb2 = _C.apply_workspace_bytes(n, r.c1.co), _C.apply_workspace_bytes(n, r.c2.co)
         self.w += (OP_CONV_APPLY_IMAGE_WS, x, r.c1.img_f, table[0], table[1], table[2], y1, n, n, r.c1.ci, r.c1.co, r.c1.k,
-                   0, self.code, r.b1.scale, r.b1.shift, 1, 0, 0, self.scratch(wb1) if wb1 else 0, wb1,
-                   OP_CONV_APPLY_IMAGE_WS, y1, r.c2.img_f, table[0], table[1], table[2], out, n, n, r.c2.ci, r.c2.co,
+                   0, self.code, r.b1.scale, r.b1.shift, 1, 0, 0, self.scratch(wb1) if wb1 else 0, wb1)
+        self.nops += 1
+        if fl:
+            self.join(2)
+        self.w += (OP_CONV_APPLY_IMAGE_WS, y1, r.c2.img_f, table[0], table[1], table[2], out, n, n, r.c2.ci, r.c2.co,
                    r.c2.k, 0, self.code, r.b2.scale, r.b2.shift, 2, skip, 0, self.scratch(wb2) if wb2 else 0, wb2)
-        self.nops += 2
+        self.nops += 1
         return out
 
     def f_point(self, pt, z_in, devox_out):

@@ -35,6 +35,8 @@ class FrameBank:
     score/sharding.py HaloExchange): pass `n_frames` (the sequence length, which the neighbour rule
     needs) and `frame_id` to add()."""
 
+    CELL = float(__import__('os').environ.get('LIDAL_GRID_CELL', '2'))      # grid cell in units of the match radius
+
     def __init__(self, dis_thresh=0.1, n_frames=None):
         self.dis_thresh = float(dis_thresh)
         self.n_frames = n_frames
@@ -63,7 +65,8 @@ class FrameBank:
             ws_bytes = B.lib().lidal_nn_grid_workspace_bytes(p)
             buf = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pts.device)
-            B.check(B.lib().lidal_nn_grid_build(B.ptr(pts), p, self.dis_thresh, B.ptr(buf), nbytes,
+            # cells of twice the match radius: a query then probes at most 8 cells instead of 27 (same matches)
+            B.check(B.lib().lidal_nn_grid_build(B.ptr(pts), p, self.CELL * self.dis_thresh, B.ptr(buf), nbytes,
                                                 B.ptr(ws), ws_bytes, B.stream()), 'nn_grid_build')
             self._grid[i] = buf
         return self._grid[i]

@@ -20,6 +20,9 @@ from .sharding import HaloExchange, gather_frames, is_sharded
 
 __all__ = ['score_sequence', 'collect_sequence', 'ScoreBoard']
 
+import os as _os
+_OVERLAP = _os.environ.get('LIDAL_SCORE_OVERLAP', '1') != '0'
+
 
 class _Inference:
     """infer_frame over this rank's frames in a fixed order, the coordinate tables of the NEXT frame built on a
@@ -82,7 +85,7 @@ def _num_classes(model):
 
 
 def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_thresh=0.1,
-                   inf_reps=8, autocast=False, group=None, exchange='halo', prefetch=True):
+                   inf_reps=8, autocast=False, group=None, exchange='halo', prefetch=True, overlap=True):
     """local_frames: list of dicts for frames first_frame, first_frame+1, ... owned by this rank,
     each with device tensors coords (i32 [N,4]), feats (f32 [N,4]), inverse (i64 [reps*P]),
     world (f64 [P,3]), sv_ptr / sv_idx (CSR of the supervoxels).
@@ -92,9 +95,14 @@ def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_th
     edge frames + the wrap-rule frames at the ends of the sequence), point to point; the frames other
     ranks read are inferred first and travel under the inference of the rest; 'allgather' -- every frame to every rank
     (one padded all_gather_into_tensor per array).  Same scores bit for bit.
-    prefetch: build each frame's coordinate tables one frame ahead on a second stream (same tables)."""
+    prefetch: build each frame's coordinate tables one frame ahead on a second stream (same tables).
+    overlap (one rank): a frame is scored as soon as the last frame of its window has been inferred, on a third stream
+    BESIDE the inference of the frames that follow (the reference scores the frames of a sequence concurrently too,
+    score/sv_level/LiDAL.py:204-206 `Pool(24)`); the scorer is library kernels only.  Same scores bit for bit."""
     n_class = _num_classes(model)
     dev = local_frames[0]['world'].device if local_frames else None
+    if overlap and _OVERLAP and not is_sharded(group) and local_frames and len(local_frames) == n_total and first_frame == 0:
+        return _score_overlapped(model, local_frames, n_total, nei_num, dis_thresh, inf_reps, autocast, prefetch)
     if exchange == 'allgather' or not is_sharded(group):
         probs, worlds = {}, {}
         by_id = {first_frame + s: d for s, d in enumerate(local_frames)}
@@ -132,6 +140,39 @@ def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_th
             bank.add(have['world'][f], have['prob'][f], frame_id=f)
     return [score_frame(bank, first_frame + s, d['sv_ptr'], d['sv_idx'], nei_num)
             for s, d in enumerate(local_frames)]
+
+
+def _score_overlapped(model, frames, n_total, nei_num, dis_thresh, inf_reps, autocast, prefetch):
+    """One rank, the whole sequence: inference in frame order on the current stream; frame i's score is queued on a
+    third stream the moment every frame of its window (interframe.neighbour_ids) has been inferred."""
+    from .. import backend as B
+    from .interframe import neighbour_ids
+    dev = frames[0]['world'].device
+    main = torch.cuda.current_stream(dev)
+    side = B.side_stream(dev, 3)
+    by_id = dict(enumerate(frames))
+    infer = _Inference(model, by_id, list(by_id), inf_reps, autocast, prefetch)
+    bank = FrameBank(dis_thresh, n_frames=n_total)
+    if any(not 0 <= j < n_total for i in range(n_total) for j in neighbour_ids(i, n_total, nei_num)):
+        raise RuntimeError('lidal_amd: a sequence of %d frames is shorter than its neighbour window (nei_num %d; the '
+                           'reference, score/sv_level/LiDAL.py:41-42, fails on it too)' % (n_total, nei_num))
+    last = {i: max([i] + neighbour_ids(i, n_total, nei_num)) for i in range(n_total)}
+    ready_at = {}
+    for i, f in last.items():
+        ready_at.setdefault(f, []).append(i)
+    out = [None] * n_total
+    for f in range(n_total):
+        d = by_id[f]
+        bank.add(d['world'], infer(f), frame_id=f)
+        if f in ready_at:
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                for i in ready_at[f]:
+                    out[i] = score_frame(bank, i, by_id[i]['sv_ptr'], by_id[i]['sv_idx'], nei_num)
+                    for t in out[i]:            # allocated on the third stream, read by the caller on this one
+                        t.record_stream(main)
+    main.wait_stream(side)
+    return out
 
 
 def collect_sequence(local_scores, local_sv_ids, local_sv_ptrs, first_frame, n_total, group=None):

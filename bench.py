@@ -392,9 +392,10 @@ def roofline_conv(args, coords, dev, reps=20):
 # per-family roofline of one whole step
 # ---------------------------------------------------------------------------------------------
 FAMILY_OF = {
-    'lidal_conv_apply': 'conv_apply', 'lidal_conv_apply_image': 'conv_apply', 'lidal_conv_dgrad_bn_sums': 'conv_apply',
+    'lidal_conv_apply_image': 'conv_apply', 'lidal_conv_dgrad_bn_sums': 'conv_apply',
+    'lidal_conv_apply_image_ws': 'conv_apply', 'lidal_conv_dgrad_bn_sums_ws': 'conv_apply',
     'lidal_conv_wgrad': 'conv_wgrad',
-    'lidal_conv_weight_pack': 'weight_pack', 'lidal_conv_weight_image': 'weight_pack',
+    'lidal_conv_weight_image': 'weight_pack', 'lidal_conv_weight_image_batch': 'weight_pack',
     'lidal_conv_weight_image_pair': 'weight_pack',
     'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_bwd_tiles': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
@@ -408,6 +409,8 @@ FAMILY_OF = {
     'lidal_devoxelize_fwd': 'point_voxel', 'lidal_devoxelize_bwd': 'point_voxel',
     'lidal_invlist_build': 'point_voxel', 'lidal_voxelize_fwd_sorted': 'point_voxel',
     'lidal_devoxelize_bwd_sorted': 'point_voxel', 'lidal_ti_weights': 'point_voxel',
+    'lidal_copy2d': 'fused_elementwise', 'lidal_add2d': 'fused_elementwise', 'lidal_transpose_f32': 'fused_elementwise',
+    'lidal_cast_rows_bf16': 'fused_elementwise',
     'lidal_add_relu_fwd': 'fused_elementwise', 'lidal_add_relu_bwd': 'fused_elementwise',
     'lidal_ce_fwd': 'fused_elementwise', 'lidal_ce_bwd': 'fused_elementwise',
 }
@@ -478,7 +481,8 @@ def family_table(step, coords, dtype_name, step_ms):
         f = FAMILY_OF.get(name, 'other_lib')
         ms = e0.elapsed_time(e1)
         by = fl = 0.0
-        if name in ('lidal_conv_apply', 'lidal_conv_apply_image', 'lidal_conv_dgrad_bn_sums'):
+        if name in ('lidal_conv_apply_image', 'lidal_conv_dgrad_bn_sums', 'lidal_conv_apply_image_ws',
+                    'lidal_conv_dgrad_bn_sums_ws'):
             n_in, n_out, ci, co, k, dt = a[6], a[7], a[8], a[9], a[10], a[12]
             b = 2 if dt == 1 else 4
             m = rules_of(k, n_in, n_out)
@@ -494,8 +498,6 @@ def family_table(step, coords, dtype_name, step_ms):
             m = rules_of(k, n_a, n_b)
             by = b * (n_a * ca + n_b * cb) + 4 * k * ca * cb + 8 * m
             fl = 2.0 * m * ca * cb
-        elif name == 'lidal_conv_weight_pack':
-            by = (4 + b_el) * a[5] * a[6] * a[7]
         elif name == 'lidal_conv_weight_image':
             by = (4 + b_el) * a[5] * a[6] * a[7]
         elif name == 'lidal_conv_weight_image_pair':

@@ -279,7 +279,7 @@ int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
  * coarse levels -- few 128-row tiles, each a long chain of (offset, reduction slice) phases while most of the chip
  * idles -- the launch then SPLITS every tile's active offsets over 2-4 workgroups, which leave f32 partial tiles in
  * ws; a second kernel adds them in a fixed order and runs the epilogue (permutation, affine map / ReLU / residual,
- * BatchNorm tile statistics).  Which launches split is a function of (n_out, ci, co, k, dtype) alone; results differ
+ * BatchNorm tile statistics).  bf16 only.  Which launches split is a function of (n_out, ci, co, k, dtype) alone; results differ
  * from the unsplit kernel's only by the association of the f32 sum over the offsets (~1e-7 relative before the
  * rounding to the output dtype). */
 int64_t lidal_conv_apply_workspace_bytes(int64_t n_out, int co);

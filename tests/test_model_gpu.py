@@ -251,11 +251,16 @@ def test_bf16_train_step_gradients_point_the_same_way(name, golden_dir):
     # (train-mode BatchNorm backward amplifies it on this 3 k-voxel fixture): measured cosines are
     # 0.9990 / 0.99998 at the last layers and 0.93-0.97 from the middle of the network down.  A wrong
     # weight gradient (transposed operand, wrong offset order, a dropped rule list) gives ~0, so:
-    # last layers cosine >= 0.998 / norm within 2 %, every other sampled parameter >= 0.9 / 25 %
-    # (the MinkUNet stem's norm has come out 13-17 % high, depending on the statistics path).
+    # last layers cosine >= 0.997 / norm within 2 %, every other sampled parameter >= 0.9 / 25 %
+    # (the MinkUNet stem's norm has come out 13-17 % high, depending on the statistics path; the last block's second
+    # convolution 0.9977-0.9990 depending on the association of the f32 sums in front of its bf16 roundings --
+    # round 4 split the offsets of small levels' tiles over workgroups, and on this 3 k-voxel fixture EVERY level is
+    # small).  This is a sanity bound on a chaotic quantity; the parity statement for the bf16 kernels is
+    # tests/test_teacher_forced_gpu.py: every operation of a whole step within one bf16 ulp of the oracle's operator
+    # applied to the operation's own operands.
     for key, cos, ratio in report:
         if key in ('classifier.0.weight', 'up4.1.1.net.3.kernel'):
-            assert cos >= 0.998 and abs(ratio - 1) <= 0.02, report
+            assert cos >= 0.997 and abs(ratio - 1) <= 0.02, report
         else:
             assert cos >= 0.9 and abs(ratio - 1) <= 0.25, report
 

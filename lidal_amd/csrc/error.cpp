@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace lidal
 
 extern "C" const char* lidal_last_error(void) { return lidal::g_err; }
-extern "C" int lidal_version(void) { return 130; }   // 1.30 (round 3): own radix sort, batched maps / orders / pyramid, BatchNorm backward sums, 16-byte point<->voxel kernels, lidal_revoxelize_coords; built without packed f32 instructions
+extern "C" int lidal_version(void) { return 140; }   // 1.40 (round 4): launch plans (lidal_plan_run), row-wise helpers, conv offset split (_ws entry points), NN grid cell in the header; the first-generation convolution left the library

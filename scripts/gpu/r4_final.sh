@@ -5,7 +5,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 TAG=${1:-a}
 O=$GRAFT_REPO_ROOT/gpurun_out/final4_$TAG; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 1200 python bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"; tail -2 $O/bench.err; head -c 300 $O/bench_line.json; echo
+timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"; tail -2 $O/bench.err; head -c 300 $O/bench_line.json; echo
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-secondary --no-roofline --no-families --no-variants > $O/step.log 2>&1; echo "step rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roof -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $O/roof.log 2>&1; echo "roof rc=$?"

@@ -225,7 +225,10 @@ def host_calls(model_name, dtype, batch, dev, prefetch=True):
     out = {}
     for it in range(2):
         opt.zero_grad()
+        if g is not None:
+            g.wait()                # (the table build of this step belongs to the step before)
         B.HITS.clear()
+        B.AHEAD_HITS.clear()
         ops0 = plan.COUNTERS['ops']
         loss, _ = forward_backward(model, feats, coords, labels, autocast=dtype == 'bf16', geometry=g)
         nodes, seen, stack = 0, set(), [loss.grad_fn]
@@ -239,8 +242,10 @@ def host_calls(model_name, dtype, batch, dev, prefetch=True):
         opt.step()
         fb = sum(B.HITS.values())
         if prefetch:
-            g = pf.submit(coords)
-        out = {'autograd_function_nodes': int(nodes), 'library_calls_from_python': int(sum(B.HITS.values())),
+            g = pf.submit(coords).wait()
+        out = {'autograd_function_nodes': int(nodes),
+               'library_calls_from_python': int(sum(B.HITS.values()) + sum(B.AHEAD_HITS.values())),
+               'of_which_on_the_table_thread': int(sum(B.AHEAD_HITS.values())),
                'of_which_forward_backward': int(fb), 'of_which_plan_run': int(B.HITS.get('plan_run', 0)),
                'operations_inside_plans': int(plan.COUNTERS['ops'] - ops0), 'launch_plan': bool(plan.ENABLED)}
     if pf is not None:

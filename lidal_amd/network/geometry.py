@@ -228,7 +228,7 @@ class GeometryPrefetcher:
     fences are per prefetcher: another prefetcher on the same device (the scorer's, inside a training loop) neither
     ages this one's geometries nor fences them on its own stream."""
 
-    MAX_PENDING = 1
+    MAX_PENDING = int(os.environ.get('LIDAL_GEOMETRY_PENDING', '1'))
     THREADED = os.environ.get('LIDAL_GEOMETRY_THREAD', '1') != '0'
 
     def __init__(self, model, device=None, threaded=None):

@@ -174,7 +174,13 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
     model = (SPVCNN if model_name == 'spvcnn' else MinkUNet)(19).to(dev).train()
     net = model
     if ddp and (world > 1 or os.environ.get('BENCH_FORCE_DDP')):
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
+        # train.py:49-53: gradients averaged over the ranks inside backward().  lidal_amd.data_parallel.DataParallel does
+        # it with ONE collective on the planned step's flat gradient buffer; BENCH_TORCH_DDP=1: torch's wrapper
+        if os.environ.get('BENCH_TORCH_DDP'):
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
+        else:
+            from lidal_amd.data_parallel import DataParallel
+            net = DataParallel(model)
     # Adam with the reference's defaults (train.py:56); `fused` only selects torch's single-kernel
     # implementation of the same update (the default path calls .item() once per parameter on the host)
     opt = torch.optim.Adam(net.parameters(), fused=True)
@@ -225,10 +231,7 @@ def host_calls(model_name, dtype, batch, dev, prefetch=True):
     out = {}
     for it in range(2):
         opt.zero_grad()
-        if g is not None:
-            g.wait()                # (the table build of this step belongs to the step before)
         B.HITS.clear()
-        B.AHEAD_HITS.clear()
         ops0 = plan.COUNTERS['ops']
         loss, _ = forward_backward(model, feats, coords, labels, autocast=dtype == 'bf16', geometry=g)
         nodes, seen, stack = 0, set(), [loss.grad_fn]
@@ -242,10 +245,8 @@ def host_calls(model_name, dtype, batch, dev, prefetch=True):
         opt.step()
         fb = sum(B.HITS.values())
         if prefetch:
-            g = pf.submit(coords).wait()
-        out = {'autograd_function_nodes': int(nodes),
-               'library_calls_from_python': int(sum(B.HITS.values()) + sum(B.AHEAD_HITS.values())),
-               'of_which_on_the_table_thread': int(sum(B.AHEAD_HITS.values())),
+            g = pf.submit(coords)
+        out = {'autograd_function_nodes': int(nodes), 'library_calls_from_python': int(sum(B.HITS.values())),
                'of_which_forward_backward': int(fb), 'of_which_plan_run': int(B.HITS.get('plan_run', 0)),
                'operations_inside_plans': int(plan.COUNTERS['ops'] - ops0), 'launch_plan': bool(plan.ENABLED)}
     if pf is not None:

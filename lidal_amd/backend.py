@@ -6,7 +6,6 @@ path lives in oracle/ and is test infrastructure only.)
 """
 import ctypes
 import os
-import threading
 
 import torch
 
@@ -19,13 +18,10 @@ _lib = None
 # the HIP path: spnn.Linear / BatchNorm1d can fall through to torch for configurations the kernels
 # do not cover, and a silent dispatch regression would otherwise still pass the numerics tests)
 HITS = {}
-AHEAD_HITS = {}         # the same for calls made on a GeometryPrefetcher's thread (network/geometry.py)
-THREAD = threading.local()
 
 
 def hit(name):
-    d = AHEAD_HITS if getattr(THREAD, 'ahead', False) else HITS
-    d[name] = d.get(name, 0) + 1
+    HITS[name] = HITS.get(name, 0) + 1
 
 _vp, _i32, _i64, _f32, _f64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                ctypes.c_double)
@@ -187,8 +183,7 @@ def lib():
 
 
 def check(rc, what):
-    d = AHEAD_HITS if getattr(THREAD, 'ahead', False) else HITS
-    d[what] = d.get(what, 0) + 1
+    HITS[what] = HITS.get(what, 0) + 1
     if rc != 0:
         raise RuntimeError('lidal_amd.%s failed (%d): %s' %
                            (what, rc, lib().lidal_last_error().decode()))
@@ -228,11 +223,7 @@ def require_gpu(*tensors):
 #   * `workspace` is the scratch of ONE library call (sort buffers, scan partials): a persistent buffer per stream,
 #     grown when a call asks for more (calls of a stream run one after the other).
 _QUANT_MIN = 1 << 20
-class _Arena(threading.local):
-    cur = None
-
-
-_ARENA = _Arena()           # the current arena is per thread (a prefetcher's thread builds beside the step's)
+_ARENA = [None]
 _WORKSPACE = {}         # (device index, stream) -> uint8 tensor
 
 
@@ -266,12 +257,12 @@ class use_arena:
         self.arena = arena
 
     def __enter__(self):
-        self.saved = _ARENA.cur
-        _ARENA.cur = self.arena
+        self.saved = _ARENA[0]
+        _ARENA[0] = self.arena
         return self.arena
 
     def __exit__(self, *exc):
-        _ARENA.cur = self.saved
+        _ARENA[0] = self.saved
         return False
 
 
@@ -283,7 +274,7 @@ def empty(shape, dtype, device):
         n *= d
     if n < _QUANT_MIN:
         return torch.empty(shape, dtype=dtype, device=device)
-    arena = _ARENA.cur
+    arena = _ARENA[0]
     if arena is not None:
         return arena.take(n, torch.device(device))[:n].view(dtype).view(shape)
     q = 1 << (n.bit_length() - 4)

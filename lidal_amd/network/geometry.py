@@ -18,8 +18,6 @@ with `x.geometry = g` (train_step / infer_frame take it as `geometry=`): the mod
 caches and launches feature kernels only.  Same tables, bit for bit, as the in-line path builds
 (tests/test_geometry_gpu.py); every batch still gets its own build.
 """
-import os
-
 import torch
 
 from .. import PointTensor, SparseTensor
@@ -36,65 +34,35 @@ class Geometry:
     """What one forward pass of `kind` ('SPVCNN' / 'MinkUNet') derives from `coords` (i32 [N,4], batch last)."""
 
     def __init__(self, coords, kind, grad):
-        self._coords = coords
+        self.coords = coords
         self.kind = kind
         self.grad = grad                # rule lists / backward contributor lists included
-        self._x0 = None                 # SparseTensor without features: level-0 coordinates + cmaps / kmaps
-        self._z = None                  # SPVCNN: PointTensor without features carrying the point caches
-        self._ready = None              # event on the stream the tables were built on (None: the caller's own stream)
+        self.x0 = None                  # SparseTensor without features: level-0 coordinates + cmaps / kmaps
+        self.z = None                   # SPVCNN: PointTensor without features carrying the point caches
+        self.ready = None               # event on the stream the tables were built on (None: the caller's own stream)
         self._stream = None
         self._consumer = None           # the stream whose kernels read the tables (fenced by the prefetcher)
-        self._payload = None            # GeometryPrefetcher.submit_batch: the input batch built on the same stream
+        self.payload = None             # GeometryPrefetcher.submit_batch: the input batch built on the same stream
         self._arena = None              # backend.BlockArena the tables were carved from
         self._age = 0                   # submissions to the same prefetcher since this one
-        self._done = None               # threading.Event of a build still running on the prefetcher's thread
-        self._error = None
-
-    def wait(self):
-        """A geometry submitted to a threaded prefetcher is handed back before its tables exist: wait (on the host) for
-        the prefetcher's thread to have QUEUED the build -- the device-side wait is admit()'s.  Every accessor below and
-        admit() / enter() call it; an exception of the build is raised here, in the consumer."""
-        d = self._done
-        if d is not None:
-            d.wait()
-            self._done = None
-        if self._error is not None:
-            raise self._error
-        return self
-
-    coords = property(lambda self: self.wait()._coords)
-    x0 = property(lambda self: self.wait()._x0)
-    z = property(lambda self: self.wait()._z)
-    ready = property(lambda self: self.wait()._ready)
-    payload = property(lambda self: self.wait()._payload)
 
     @staticmethod
-    def check_input(model, coords):
+    def build(model, coords, grad=None, arena=None):
+        """Build on the current stream.  grad: also what only a backward pass reads (default: model.training and
+        gradients enabled).  The tables are carved out of the blocks of one backend.BlockArena (`arena`, or a new
+        one): same-sized blocks the allocator re-uses exactly, whatever this batch's voxel counts are."""
         from .unet import SPVCNN, MinkUNet
         from .. import backend as B
         if not isinstance(model, (SPVCNN, MinkUNet)):
             raise TypeError('lidal_amd: Geometry.build knows the coordinate work of SPVCNN and MinkUNet, not of %s'
                             % type(model).__name__)
-        if coords is None:
-            return
         B.require_gpu(coords)
         if coords.dtype != torch.int32 or coords.dim() != 2 or coords.shape[1] != 4 or not coords.is_contiguous():
             raise ValueError('lidal_amd: Geometry.build wants contiguous int32 coordinates [N, 4] = (x, y, z, batch), got '
                              '%s %s' % (coords.dtype, tuple(coords.shape)))
-
-    @staticmethod
-    def build(model, coords, grad=None, arena=None, into=None):
-        """Build on the current stream.  grad: also what only a backward pass reads (default: model.training and
-        gradients enabled).  The tables are carved out of the blocks of one backend.BlockArena (`arena`, or a new
-        one): same-sized blocks the allocator re-uses exactly, whatever this batch's voxel counts are.
-        into: the (empty) Geometry a threaded prefetcher handed out for this build."""
-        from .unet import SPVCNN
-        from .. import backend as B
-        Geometry.check_input(model, coords)
         if grad is None:
             grad = model.training and torch.is_grad_enabled()
-        g = into if into is not None else Geometry(coords, type(model).__name__, bool(grad))
-        g._coords = coords
+        g = Geometry(coords, type(model).__name__, bool(grad))
         g._arena = arena if arena is not None else B.BlockArena()
         # (the map builder includes the rule lists iff gradients are on)
         with torch.set_grad_enabled(bool(grad)), B.use_arena(g._arena):
@@ -111,11 +79,11 @@ class Geometry:
                     prepare_voxelize(pidx, counts)
                     if grad:
                         prepare_devoxelize(idx, w, xs.C.shape[0])
-                g._z = z
+                g.z = z
             else:
                 x0 = SparseTensor(None, coords, 1)
                 prefetch_kernel_maps(x0, model.MAP_PLAN)
-            g._x0 = x0
+            g.x0 = x0
         import weakref
         me = weakref.ref(g)
         for km in x0.kmaps.values():        # a backward pass meets the geometry through its kernel maps (conv_backward)
@@ -127,7 +95,6 @@ class Geometry:
         stream waits for the stream that built them.  (What a planned step calls, network/plan.py.)"""
         if kind != self.kind:
             raise RuntimeError('lidal_amd: geometry built for %s handed to %s' % (self.kind, kind))
-        self.wait()
         c = x.C
         if tuple(x.s) != (1, 1, 1):
             raise RuntimeError('lidal_amd: geometries are built for stride-1 inputs, got stride %s' % (x.s,))
@@ -146,7 +113,7 @@ class Geometry:
     def alive(self):
         """May a kernel queued NOW still read the tables?  (False once two newer geometries have been submitted to the
         prefetcher that built this one: the fence that protects the memory has been recorded by then.)"""
-        return (self._done is None and self._ready is None) or self._age < 2
+        return self.ready is None or self._age < 2
 
     def enter(self, x, kind):
         """Called by the model's forward with its input: checks that the tables are x's, makes the current stream
@@ -168,28 +135,6 @@ class Geometry:
 # a new stream per prefetcher would start from an empty pool every time) and the geometries of prefetchers that went
 # away while a consumer stream could still be reading their tables.
 _STATE = {}
-
-
-def _worker(jobs, device):
-    """A prefetcher's thread: builds the geometries of its queue in order.  The current device, the current stream and
-    the arena of coordinate buffers are per thread (torch, backend.use_arena); library calls made here are tallied in
-    backend.AHEAD_HITS, not in HITS (what a step's own thread called)."""
-    from .. import backend as B
-    torch.cuda.set_device(device)
-    B.THREAD.ahead = True
-    while True:
-        item = jobs.get()
-        if item is None:
-            jobs.task_done()
-            return
-        g, job = item
-        try:
-            job(g)
-        except BaseException as e:          # noqa: BLE001  (raised again in the consumer: Geometry.wait)
-            g._error = e
-        finally:
-            g._done.set()
-            jobs.task_done()
 
 
 def _state(device):
@@ -228,14 +173,9 @@ class GeometryPrefetcher:
     fences are per prefetcher: another prefetcher on the same device (the scorer's, inside a training loop) neither
     ages this one's geometries nor fences them on its own stream."""
 
-    MAX_PENDING = int(os.environ.get('LIDAL_GEOMETRY_PENDING', '1'))
-    THREADED = os.environ.get('LIDAL_GEOMETRY_THREAD', '1') != '0'
+    MAX_PENDING = 1
 
-    def __init__(self, model, device=None, threaded=None):
-        """threaded (default: LIDAL_GEOMETRY_THREAD, on): submit() hands the build to a thread of this prefetcher and
-        returns at once -- the ~50 library calls and the three waits for sizes of a build then run beside the host work
-        of the step (writing and issuing its launch plans, the optimizer), not after it; the geometry is completed by
-        the time a forward pass admits it (Geometry.wait).  Same tables; threaded=False builds inside submit()."""
+    def __init__(self, model, device=None):
         self.model = model
         if device is None:
             device = next(model.parameters()).device
@@ -243,15 +183,10 @@ class GeometryPrefetcher:
         self._st = _state(self.device)
         self.stream = self._st['stream']
         self.held = []              # [geometry, fence event or None]
-        self.threaded = self.THREADED if threaded is None else bool(threaded)
-        self._jobs = None
-        self._thread = None
 
-    def _age_and_fence(self):
-        """The bookkeeping of one submission (caller's thread): ages, the fence of the geometries that turn two, and the
-        fences a new build must wait for (bounded run-ahead: at most MAX_PENDING fenced generations may still be waiting
-        for their consumer -- a host that queues steps faster than the GPU runs them, nothing else synchronises the
-        loop, would otherwise keep one more generation of tables alive per step of lead)."""
+    def submit(self, coords, grad=None, ready=None, arena=None):
+        if grad is None:
+            grad = self.model.training and torch.is_grad_enabled()
         fences = {}
         for h in self.held:
             g = h[0]
@@ -261,81 +196,46 @@ class GeometryPrefetcher:
                 if c not in fences:
                     fences[c] = c.record_event()
                 h[1] = fences[c]
-        pending = [h[1] for h in self.held if h[1] is not None and not h[1].query()]
-        wait_for = pending[:max(0, len(pending) - self.MAX_PENDING)]
-        if not self.threaded:
-            for ev in wait_for:
-                ev.synchronize()
+        # bounded run-ahead: at most MAX_PENDING fenced generations may still be waiting for their consumer -- a host
+        # that queues steps faster than the GPU runs them (nothing else synchronises the loop) would otherwise keep one
+        # more generation of tables alive per step of lead
+        pending = [h for h in self.held if h[1] is not None and not h[1].query()]
+        while len(pending) > self.MAX_PENDING:
+            pending.pop(0)[1].synchronize()
         self.held = [h for h in self.held if h[1] is None or not h[1].query()]
         _reap(self._st)
-        return wait_for
-
-    def _enqueue(self, g, job):
-        if self._thread is None:
-            import queue
-            import threading
-            self._jobs = queue.Queue()
-            self._thread = threading.Thread(target=_worker, args=(self._jobs, self.device), daemon=True,
-                                            name='lidal-geometry')
-            self._thread.start()
-        import threading
-        g._done = threading.Event()
-        self._jobs.put((g, job))
-
-    def _idle(self):
-        if self._jobs is not None and self._thread.is_alive():
-            self._jobs.join()
-
-    def submit(self, coords, grad=None, ready=None, arena=None, make=None):
-        if grad is None:
-            grad = self.model.training and torch.is_grad_enabled()
-        Geometry.check_input(self.model, coords)
-        wait_for = self._age_and_fence()
         consumer = torch.cuda.current_stream(self.device)
-        model, stream = self.model, self.stream
-
-        def job(g):
-            from .. import backend as B
-            for ev in wait_for:                     # (threaded: the run-ahead bound holds back the build, not the caller)
-                ev.synchronize()
-            with torch.cuda.stream(stream):
-                c, batch = coords, None
-                if make is not None:
-                    with B.use_arena(arena):
-                        batch = make()
-                    c = batch['coords_v_b']
-                if ready is not None:
-                    stream.wait_event(ready)
-                c.record_stream(stream)
-                Geometry.build(model, c, grad, arena, into=g)
-                g._payload = batch
-                g._stream = stream
-                g._ready = stream.record_event()
-
-        g = Geometry(coords, type(self.model).__name__, bool(grad))
-        g._consumer = consumer
+        with torch.cuda.stream(self.stream):
+            if ready is not None:
+                self.stream.wait_event(ready)
+            coords.record_stream(self.stream)
+            g = Geometry.build(self.model, coords, grad, arena)
+            g.ready = self.stream.record_event()
+            g._stream = self.stream
+            g._consumer = consumer
         self.held.append([g, None])
-        if self.threaded:
-            self._enqueue(g, job)
-        else:
-            job(g)
         return g
 
     def submit_batch(self, make, grad=None):
-        """The INPUT of a step built ahead as well: `make()` is called under the second stream (on the prefetcher's
-        thread) and returns the batch as a dict with 'coords_v_b' (what lidal_amd.data.collate returns: the scans of the
-        step voxelised under a newly drawn augmentation, dataset/sk_dataset.py:143-171 + :188-242 -- the work the
-        reference's DataLoader workers do ahead of the GPU, dataset/sk_dataloader.py:21,53); its coordinate tables
-        follow on the same stream.  Returns the geometry with the batch as `.payload`: the batch tensors were allocated
-        on the second stream and live exactly as long as the tables do (the same fence)."""
+        """The INPUT of a step built ahead as well: `make()` is called under the second stream and returns the batch
+        as a dict with 'coords_v_b' (what lidal_amd.data.collate returns: the scans of the step voxelised under a
+        newly drawn augmentation, dataset/sk_dataset.py:143-171 + :188-242 -- the work the reference's DataLoader
+        workers do ahead of the GPU, dataset/sk_dataloader.py:21,53); its coordinate tables follow on the same
+        stream.  Returns the geometry with the batch as `.payload`: the batch tensors were allocated on the second
+        stream and live exactly as long as the tables do (the same fence)."""
+        if grad is None:
+            grad = self.model.training and torch.is_grad_enabled()
         from .. import backend as B
-        # the voxeliser's buffers and the tables: one set of blocks, one lifetime
-        return self.submit(None, grad, arena=B.BlockArena(), make=make)
+        arena = B.BlockArena()                  # the voxeliser's buffers and the tables: one set of blocks, one lifetime
+        with torch.cuda.stream(self.stream), B.use_arena(arena):
+            batch = make()
+        g = self.submit(batch['coords_v_b'], grad, arena=arena)
+        g.payload = batch
+        return g
 
     def drain(self):
         """Let go of every geometry this prefetcher still holds (the last two of a loop stay alive until the next
         submit): waits for their consumer streams, after which nothing can still be reading them."""
-        self._idle()
         for h in self.held:
             h[0]._consumer.synchronize()
             h[0]._age = max(h[0]._age, 2)           # a drained geometry must not be handed to a forward pass any more
@@ -346,10 +246,6 @@ class GeometryPrefetcher:
     def close(self):
         """The same without waiting on the host: every held geometry is fenced on its consumer stream now and kept by the
         device's module state until that event has passed.  Called when a loop ends (and on garbage collection)."""
-        self._idle()
-        if self._jobs is not None:
-            self._jobs.put(None)            # the thread ends; a later submit() starts a new one
-            self._jobs = self._thread = None
         for h in self.held:
             g = h[0]
             g._age = max(g._age, 2)
@@ -361,9 +257,6 @@ class GeometryPrefetcher:
 
     def __del__(self):
         try:
-            import sys
-            if sys.is_finalizing():         # (the thread is frozen by now: nothing to wait for, nothing to fence)
-                return
             self.close()
         except Exception:           # noqa: BLE001  (interpreter shutdown: the runtime may already be gone)
             pass

@@ -38,18 +38,31 @@ def main():
             np.savez(os.path.join(out_dir, '%s_2rank.npz' % mode),
                      **{'%s_%d' % (k, f): v for f, t in enumerate(got)
                         for k, v in zip(('id', 'd', 'e', 'n', 'c'), t)})
-    elif mode == 'ddp':
+    elif mode in ('ddp', 'dp', 'dp_per_operator'):
+        from lidal_amd.data_parallel import DataParallel
+        from lidal_amd.network import plan
         from lidal_amd.train_step import forward_backward
         model = mc.make_model(dev).train()
+        if rank == 1 and mode != 'ddp':         # (the wrapper must bring rank 0's parameters over, as DDP does)
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.5)
         model.dropout.p = 0.0
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        if mode == 'ddp':
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        else:
+            net = DataParallel(model)
+            plan.ENABLED = mode == 'dp'
         b = mc.make_half_batches()[rank]
         net.zero_grad()
         loss, _ = forward_backward(net, b['feats'].to(dev), b['coords'].to(dev), b['labels'].to(dev))
         torch.cuda.synchronize()
+        if mode != 'ddp':
+            # the planned step's gradients are reduced in place as one tensor; the per-operator path's through a copy
+            assert net.reductions == 1 and net.flat_reductions == (1 if mode == 'dp' else 0), (net.reductions, net.flat_reductions)
         if rank == 0:
             named = dict(model.named_parameters())
-            np.savez(os.path.join(out_dir, 'ddp_2rank.npz'), loss=loss.item(),
+            np.savez(os.path.join(out_dir, '%s_2rank.npz' % mode), loss=loss.item(),
                      **{k.replace('.', '/'): named[k].grad.float().cpu().numpy() for k in mc.GRAD_KEYS})
     elif mode in ('eval', 'eval_empty'):
         # evaluate.py:95-124: every rank accumulates the confusion matrix of ITS batches, one

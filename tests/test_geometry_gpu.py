@@ -275,55 +275,3 @@ def test_tables_built_beside_the_bf16_convolutions_are_the_tables_built_alone():
         assert [p for p, _ in got] == [p for p, _ in want]
         for (p, a), (_, b) in zip(want, got):
             assert torch.equal(a, b), (it, p, int((a != b).sum()) if a.shape == b.shape else (a.shape, b.shape))
-
-
-def test_threaded_prefetcher_builds_the_tables_of_the_inline_build():
-    """GeometryPrefetcher(threaded=True) (the default) returns from submit() before the tables exist and completes them on
-    its own thread; threaded=False builds inside submit(); Geometry.build builds in line: the same tables bit for bit,
-    the library calls of the thread tallied apart from the step's own (backend.AHEAD_HITS)."""
-    from lidal_amd import backend as B
-    from lidal_amd.network import Geometry, GeometryPrefetcher
-    torch.manual_seed(0)
-    model = _models()['spvcnn'](19).to(DEV).train()
-    batches = _batches(3)
-    want = [dict(_tables(Geometry.build(model, c))) for _, c, _ in batches]
-    for threaded in (True, False):
-        pf = GeometryPrefetcher(model, threaded=threaded)
-        assert pf.threaded == threaded
-        torch.cuda.synchronize()
-        B.HITS.clear()
-        B.AHEAD_HITS.clear()
-        got = [pf.submit(c) for _, c, _ in batches[:2]]
-        got.append(pf.submit(batches[2][1]))
-        tabs = [dict(_tables(g)) for g in got]              # (the accessors wait for the thread)
-        assert (sum(B.AHEAD_HITS.values()) > 20) == threaded, (B.HITS, B.AHEAD_HITS)
-        assert (sum(B.HITS.values()) > 20) != threaded, (B.HITS, B.AHEAD_HITS)
-        torch.cuda.synchronize()
-        for a, b in zip(want, tabs):
-            assert a.keys() == b.keys()
-            for k in a:
-                assert torch.equal(a[k], b[k]), k
-        pf.drain()
-        assert pf.held == []
-
-
-def test_an_error_on_the_prefetcher_thread_is_raised_in_the_consumer():
-    from lidal_amd.network import GeometryPrefetcher
-    model = _models()['minkunet'](19).to(DEV).train()
-    pf = GeometryPrefetcher(model, threaded=True)
-
-    def make():
-        raise ValueError('no scans left')
-    g = pf.submit_batch(make)
-    with pytest.raises(ValueError, match='no scans left'):
-        g.payload
-    with pytest.raises(ValueError, match='no scans left'):
-        g.wait()
-    # what is wrong with the ARGUMENTS is still refused by submit() itself
-    with pytest.raises(ValueError, match='int32 coordinates'):
-        pf.submit(_batches(1)[0][1].long())
-    # and the prefetcher keeps working
-    feats, coords, labels = _batches(1)[0]
-    g = pf.submit(coords)
-    assert g.x0 is not None and g.coords is coords
-    pf.drain()

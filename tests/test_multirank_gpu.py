@@ -73,7 +73,11 @@ def test_two_rank_scoring_is_bit_equal_to_one_rank(tmp_path):
         assert matched > 0, 'degenerate fixture: no supervoxel saw an inter-frame match'
 
 
-def test_two_rank_ddp_gradient_is_the_mean_of_the_rank_gradients(tmp_path):
+@pytest.mark.parametrize('mode', ['ddp', 'dp', 'dp_per_operator'])
+def test_two_rank_ddp_gradient_is_the_mean_of_the_rank_gradients(tmp_path, mode):
+    """'ddp': torch's DistributedDataParallel as train.py:49-53 wraps the model; 'dp': lidal_amd.data_parallel.DataParallel
+    (one collective per backward pass on the planned step's flat gradient buffer); 'dp_per_operator': the same wrapper
+    over the per-operator path (gradients reduced through a flattened copy)."""
     import multirank_common as mc
     from lidal_amd.train_step import forward_backward
     dev = torch.device('cuda', 0)
@@ -86,8 +90,8 @@ def test_two_rank_ddp_gradient_is_the_mean_of_the_rank_gradients(tmp_path):
         grads.append({k: named[k].grad.double().cpu().numpy() for k in mc.GRAD_KEYS})
         losses.append(loss.item())
     torch.cuda.synchronize()
-    _spawn('ddp', tmp_path)
-    two = np.load(os.path.join(str(tmp_path), 'ddp_2rank.npz'))
+    _spawn(mode, tmp_path)
+    two = np.load(os.path.join(str(tmp_path), '%s_2rank.npz' % mode))
     assert abs(float(two['loss']) - losses[0]) <= 1e-6 * abs(losses[0])      # rank 0's own loss
     for k in mc.GRAD_KEYS:
         want = 0.5 * (grads[0][k] + grads[1][k])

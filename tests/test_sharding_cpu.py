@@ -179,3 +179,78 @@ def test_halo_exchange_delivers_exactly_the_needed_frames_gloo(tmp_path):
         port = _free_port()
         mp.spawn(_halo_worker, args=(world, port, n_frames, nei, str(tmp_path)), nprocs=world, join=True)
         assert all(torch.load(os.path.join(str(tmp_path), 'halo_%d.pt' % r)) for r in range(world)), (world, n_frames)
+
+
+# ---- lidal_amd.data_parallel.DataParallel (train.py:49-53's DistributedDataParallel for the planned step) ----------
+class _FlatGrads(torch.autograd.Function):
+    """Stands in for the planned step (network/plan.py): one node whose parameter gradients are views of ONE buffer."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return x @ w + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        flat = torch.empty(w.numel() + b_numel(w), dtype=torch.float32)
+        gw, gb = flat[:w.numel()].view_as(w), flat[w.numel():]
+        gw.copy_(x.t() @ g)
+        gb.copy_(g.sum(0))
+        return g @ w.t(), gw, gb
+
+
+def b_numel(w):
+    return w.shape[1]
+
+
+class _Net(torch.nn.Module):
+    def __init__(self, flat):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.w = torch.nn.Parameter(torch.randn(8, 4, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(4, generator=g))
+        self.register_buffer('seen', torch.zeros(1, dtype=torch.int64))
+        self.flat = flat
+
+    def forward(self, x):
+        return _FlatGrads.apply(x, self.w, self.b) if self.flat else x @ self.w + self.b
+
+
+def _dp_worker(rank, world, port, out_dir):
+    _init(rank, world, port)
+    from lidal_amd.data_parallel import DataParallel
+    ok = True
+    for flat in (True, False):
+        net = _Net(flat)
+        if rank == 1:                           # rank 0's state must win
+            with torch.no_grad():
+                net.w.add_(1.0)
+                net.seen.add_(5)
+        dp = DataParallel(net)
+        ref = _Net(flat)
+        ok = ok and torch.equal(net.w, ref.w) and int(net.seen) == 0
+        grads = []
+        for r in range(world):                  # every rank's single-process gradient, computed locally
+            m = _Net(False)
+            x = torch.randn(16, 8, generator=torch.Generator().manual_seed(10 + r))
+            m(x).square().sum().backward()
+            grads.append((m.w.grad.clone(), m.b.grad.clone()))
+        x = torch.randn(16, 8, generator=torch.Generator().manual_seed(10 + rank))
+        for step in range(2):                   # (the hook re-arms itself)
+            dp.zero_grad()
+            dp(x).square().sum().backward()
+            ok = ok and torch.allclose(net.w.grad, sum(g[0] for g in grads) / world, rtol=1e-6, atol=1e-6)
+            ok = ok and torch.allclose(net.b.grad, sum(g[1] for g in grads) / world, rtol=1e-6, atol=1e-6)
+        ok = ok and dp.reductions == 2 and dp.flat_reductions == (2 if flat else 0)
+        ok = ok and list(dp.state_dict()) == ['module.w', 'module.b', 'module.seen']
+    torch.save(ok, os.path.join(out_dir, 'dp_ok_%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_wrapper_world_size_2_gloo(tmp_path):
+    """Gradients = mean over the ranks (one in-place collective when they lie back to back in one buffer, a flattened
+    copy otherwise), rank 0's parameters and buffers broadcast at construction, DDP's 'module.' state_dict prefix."""
+    port = _free_port()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(torch.load(os.path.join(str(tmp_path), 'dp_ok_%d.pt' % r)) for r in range(2))

@@ -404,6 +404,8 @@ FAMILY_OF = {
     'lidal_conv_weight_image': 'weight_pack', 'lidal_conv_weight_image_batch': 'weight_pack',
     'lidal_conv_weight_image_pair': 'weight_pack',
     'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_bwd_tiles': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
+    # (the ReLU mask of a block's tail rides with the first pass of its BatchNorms' backward: both counted here)
+    'lidal_add_relu_bwd_bn_sums': 'batch_norm', 'lidal_bn_bwd_from_sums': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
@@ -514,6 +516,10 @@ def family_table(step, coords, dtype_name, step_ms):
         elif name in ('lidal_bn_bwd', 'lidal_bn_bwd_tiles'):
             # (x, dy, dy_stride, dtype, n, c, ...): the sums pass `_tiles` no longer makes stays in the count (5 N C b)
             by = 5 * a[4] * a[5] * (2 if a[3] == 1 else 4)
+        elif name == 'lidal_bn_bwd_from_sums':
+            by = 5 * a[4] * a[5] * (2 if a[3] == 1 else 4)         # (as lidal_bn_bwd: the pass it no longer makes stays in the count)
+        elif name == 'lidal_add_relu_bwd_bn_sums':
+            by = 3 * a[4] * a[5] * (2 if a[3] == 1 else 4)         # (as lidal_add_relu_bwd: out, g -> gm)
         elif name == 'lidal_colsum':
             by = a[2] * a[3] * (2 if a[1] == 1 else 4)
         elif name in ('lidal_add_relu_fwd', 'lidal_add_relu_bwd'):
@@ -754,6 +760,9 @@ def bench_scoring(args, model, world, rank, dev, frames, batches):
                            'inverse': torch.from_numpy(sb['inverse_indices_b']).to(dev),
                            'world': torch.from_numpy(f['world']).to(dev), 'sv_ptr': ptr, 'sv_idx': idx})
     sv_ids = [f['sv_id'] for f in frames]
+    if os.environ.get('BENCH_EMPTY_CACHE'):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     model.eval()
     autocast = args.dtype == 'bf16'
     log('scoring inputs resident')
@@ -825,6 +834,11 @@ def run_variants(args, batch, dev, inline=None):
 
 
 def main():
+    # the contract is ONE JSON line on stdout: libraries that print there on their own (RCCL's version banner at the
+    # first collective) are sent to stderr -- file descriptor 1 becomes stderr, the line goes to the original stdout
+    out = os.fdopen(os.dup(1), 'w')
+    sys.stdout.flush()
+    os.dup2(2, 1)
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -849,7 +863,7 @@ def main():
     batch = make_batch(args.frames, args.points, 7122 + rank, dev)
     log('batch built', tuple(batch[0].shape))
     if args.roofline_only:
-        print(json.dumps({'roofline': roofline_conv(args, batch[0], dev)}), flush=True)
+        print(json.dumps({'roofline': roofline_conv(args, batch[0], dev)}), file=out, flush=True)
         return
     res = bench_train(world, rank, dev, args.model, args.dtype, batch, args.steps, args.warmup)
     log('train timed: %.3f s for %d steps' % (res['seconds'], args.steps))
@@ -904,7 +918,7 @@ def main():
     if 'train' in cpu_lines:
         line['cpu_baseline'] = cpu_lines['train']
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

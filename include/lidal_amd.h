@@ -368,6 +368,21 @@ int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stride, int dty
                        const float* gamma, const float* beta, int relu, const float* save_mean,
                        const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
                        const float* tile_sums, int64_t n_tiles, void* stream);
+/* The tail of a residual block backwards (network/utils.py:142-172: out = relu(bn2(x_a) + shortcut), the shortcut the
+ * identity or bn_s(x_b)): gm = g where out > 0 (lidal_add_relu_bwd) and, in the same pass, the partial sums of the
+ * BatchNorm backward of bn2 over (x_a, gm) -- and of the shortcut's BatchNorm over (x_b, gm) when x_b != NULL -- that
+ * lidal_bn_bwd would take in its first pass over the same operands (bit for bit).  part_a / part_b: >=
+ * lidal_bn_workspace_bytes(n, c) each (part_bytes), handed to lidal_bn_bwd_from_sums; relu = 0 there (the ReLU of the
+ * tail follows the sum).  Rows are contiguous ([n, c], c whole 16-byte vectors). */
+int lidal_add_relu_bwd_bn_sums(const void* out, const void* g, void* gm, int dtype, int64_t n, int c,
+                               const void* x_a, const float* mean_a, const float* invstd_a, void* part_a,
+                               const void* x_b, const float* mean_b, const float* invstd_b, void* part_b,
+                               int64_t part_bytes, void* stream);
+/* lidal_bn_bwd without its first pass: the partial sums are in `part` (lidal_add_relu_bwd_bn_sums). */
+int lidal_bn_bwd_from_sums(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c,
+                           const float* gamma, const float* beta, int relu, const float* save_mean,
+                           const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
+                           const void* part, int64_t part_bytes, void* stream);
 /* eval-mode BatchNorm as a per-channel affine map (scale = gamma / sqrt(var + eps),
  * shift = beta - mean * scale), the operands of lidal_conv_apply's epilogue. */
 int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,
@@ -480,7 +495,7 @@ enum {
   LIDAL_OP_DEVOXELIZE_BWD_SORTED = 18, LIDAL_OP_CE_FWD = 19, LIDAL_OP_CE_BWD = 20, LIDAL_OP_COPY2D = 21,
   LIDAL_OP_ADD2D = 22, LIDAL_OP_TRANSPOSE_F32 = 23, LIDAL_OP_CAST_ROWS_BF16 = 24, LIDAL_OP_VIEW_MEAN_SOFTMAX = 25,
   LIDAL_OP_FORK_SIDE = 26, LIDAL_OP_JOIN_SIDE = 27, LIDAL_OP_CONV_APPLY_IMAGE_WS = 28,
-  LIDAL_OP_CONV_DGRAD_BN_SUMS_WS = 29
+  LIDAL_OP_CONV_DGRAD_BN_SUMS_WS = 29, LIDAL_OP_ADD_RELU_BWD_BN_SUMS = 30, LIDAL_OP_BN_BWD_FROM_SUMS = 31
 };
 #define LIDAL_OP_FLAG_SIDE 1
 int lidal_plan_op_args(int kind);

@@ -314,6 +314,101 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
   }
 }
 
+// The tail of a residual block backwards (network/blocks.py _Residual.backward): gm = g * (out > 0) is the gradient of
+// BOTH summands of relu(bn2(x_a) + shortcut).  Written once here and, in the same pass, summed against xhat of bn2 (and,
+// DUAL, of the shortcut's BatchNorm over x_b): the loop of bn_bwd_partial_kernel over (x, gm) with relu = 0, term by term
+// and in the same order -- the partials are bit for bit those of the separate pass, which no longer reads gm and x back.
+template <typename T, bool DUAL>
+__global__ void __launch_bounds__(NT) bn_bwd_partial_masked_kernel(
+    const T* __restrict__ out, const T* __restrict__ g, T* __restrict__ gm, int64_t n, int c,
+    const T* __restrict__ xa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a, double* __restrict__ part_a,
+    const T* __restrict__ xb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b, double* __restrict__ part_b,
+    int rpw) {
+  constexpr int VEC = IO<T>::VEC;
+  extern __shared__ double sh[];                // [2][NT][VEC]
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
+  double a[VEC], b[VEC], a2[VEC], b2[VEC];
+  float mu[VEC], is[VEC], mu2[VEC], is2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { a[i] = 0.; b[i] = 0.; a2[i] = 0.; b2[i] = 0.; mu[i] = 0.f; is[i] = 0.f; mu2[i] = 0.f; is2[i] = 0.f; }
+  if (rl < rpi) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mu[i] = mean_a[cg * VEC + i]; is[i] = invstd_a[cg * VEC + i];
+      if (DUAL) { mu2[i] = mean_b[cg * VEC + i]; is2[i] = invstd_b[cg * VEC + i]; }
+    }
+    typedef typename IO<T>::vec V;
+    auto one = [&](int64_t r, const V& vo, const V& vg, const V& vx, const V& vx2) {
+      float fo[VEC], fd[VEC], fx[VEC], fx2[VEC];
+      IO<T>::unpack(vo, fo);
+      IO<T>::unpack(vg, fd);
+      IO<T>::unpack(vx, fx);
+      if (DUAL) IO<T>::unpack(vx2, fx2);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) fd[i] = fo[i] > 0.f ? fd[i] : 0.f;
+      *reinterpret_cast<V*>(gm + r * c + cg * VEC) = IO<T>::pack(fd);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float xhat = (fx[i] - mu[i]) * is[i];
+        a[i] += (double)fd[i]; b[i] += (double)fd[i] * (double)xhat;
+        if (DUAL) {
+          const float xhat2 = (fx2[i] - mu2[i]) * is2[i];
+          a2[i] += (double)fd[i]; b2[i] += (double)fd[i] * (double)xhat2;
+        }
+      }
+    };
+    int64_t r = r_beg + rl;
+    for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
+      V vo[UNR], vg[UNR], vx[UNR], vx2[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t off = (r + u * rpi) * c + cg * VEC;
+        vo[u] = *reinterpret_cast<const V*>(out + off);
+        vg[u] = *reinterpret_cast<const V*>(g + off);
+        vx[u] = *reinterpret_cast<const V*>(xa + off);
+        if (DUAL) vx2[u] = *reinterpret_cast<const V*>(xb + off);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) one(r + u * rpi, vo[u], vg[u], vx[u], vx2[u]);
+    }
+    for (; r < r_end; r += rpi) {
+      const int64_t off = r * c + cg * VEC;
+      V vx2 = *reinterpret_cast<const V*>(xa + off);
+      if (DUAL) vx2 = *reinterpret_cast<const V*>(xb + off);
+      one(r, *reinterpret_cast<const V*>(out + off), *reinterpret_cast<const V*>(g + off), *reinterpret_cast<const V*>(xa + off), vx2);
+    }
+  }
+  double* sa = sh; double* sb = sh + NT * VEC;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { sa[tid * VEC + i] = a[i]; sb[tid * VEC + i] = b[i]; }
+  tree_sum_rows<VEC, double>(sa, tid, cg_n, rpi, rl);
+  tree_sum_rows<VEC, double>(sb, tid, cg_n, rpi, rl);
+  if (rl == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      double* dst = part_a + ((int64_t)blockIdx.x * c + cg * VEC + i) * 2;
+      dst[0] = sa[tid * VEC + i]; dst[1] = sb[tid * VEC + i];
+    }
+  }
+  if (DUAL) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sa[tid * VEC + i] = a2[i]; sb[tid * VEC + i] = b2[i]; }
+    tree_sum_rows<VEC, double>(sa, tid, cg_n, rpi, rl);
+    tree_sum_rows<VEC, double>(sb, tid, cg_n, rpi, rl);
+    if (rl == 0) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        double* dst = part_b + ((int64_t)blockIdx.x * c + cg * VEC + i) * 2;
+        dst[0] = sa[tid * VEC + i]; dst[1] = sb[tid * VEC + i];
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(NT) bn_bwd_final_kernel(const double* __restrict__ part,
                                                           int nparts, int c,
                                                           float* __restrict__ sum_dy,
@@ -448,6 +543,40 @@ int bn_bwd(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const f
       (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, rows_per_wg(n), ldy);
   LIDAL_CHECK_LAUNCH("bn_bwd_partial");
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gbeta, ggamma);
+  LIDAL_CHECK_LAUNCH("bn_bwd_final");
+  if (dx != nullptr) {
+    bn_bwd_dx_kernel<T><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd,
+                                                    gamma, beta, relu, gbeta, ggamma, (T*)dx,
+                                                    rows_per_wg_ew(n, (int64_t)c * sizeof(T)), ldy);
+    LIDAL_CHECK_LAUNCH("bn_bwd_dx");
+  }
+  return 0;
+}
+
+template <typename T>
+int bn_bwd_masked_partials(const void* out, const void* g, void* gm, int64_t n, int c, const void* xa, const float* mean_a,
+                           const float* invstd_a, double* part_a, const void* xb, const float* mean_b,
+                           const float* invstd_b, double* part_b, hipStream_t s) {
+  constexpr int VEC = IO<T>::VEC;
+  const int np = nparts_for(n);
+  if (xb != nullptr)
+    bn_bwd_partial_masked_kernel<T, true><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>(
+        (const T*)out, (const T*)g, (T*)gm, n, c, (const T*)xa, mean_a, invstd_a, part_a, (const T*)xb, mean_b, invstd_b,
+        part_b, rows_per_wg(n));
+  else
+    bn_bwd_partial_masked_kernel<T, false><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>(
+        (const T*)out, (const T*)g, (T*)gm, n, c, (const T*)xa, mean_a, invstd_a, part_a, nullptr, nullptr, nullptr,
+        nullptr, rows_per_wg(n));
+  LIDAL_CHECK_LAUNCH("bn_bwd_partial_masked");
+  return 0;
+}
+
+// bn_bwd without its first pass: the partials are in `part` already
+template <typename T>
+int bn_bwd_from_partials(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const float* gamma,
+                         const float* beta, int relu, const float* mean, const float* invstd, void* dx, float* ggamma,
+                         float* gbeta, const double* part, hipStream_t s) {
+  bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, nparts_for(n), c, gbeta, ggamma);
   LIDAL_CHECK_LAUNCH("bn_bwd_final");
   if (dx != nullptr) {
     bn_bwd_dx_kernel<T><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd,
@@ -612,6 +741,41 @@ extern "C" int lidal_bn_bwd(const void* x, const void* dy, int64_t dy_stride, in
                          grad_beta, (double*)ws, s);
   return bn_bwd<__bf16>(x, dy, dy_stride, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
                         grad_beta, (double*)ws, s);
+}
+
+extern "C" int lidal_add_relu_bwd_bn_sums(const void* out, const void* g, void* gm, int dtype, int64_t n, int c,
+                                          const void* x_a, const float* mean_a, const float* invstd_a, void* part_a,
+                                          const void* x_b, const float* mean_b, const float* invstd_b, void* part_b,
+                                          int64_t part_bytes, void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  LIDAL_REQUIRE(n > 0, "add_relu_bwd_bn_sums: needs at least one row");
+  LIDAL_REQUIRE(part_bytes >= lidal_bn_workspace_bytes(n, c), "add_relu_bwd_bn_sums: partial buffers too small");
+  LIDAL_REQUIRE(x_a != nullptr && part_a != nullptr && (x_b == nullptr || part_b != nullptr),
+                "add_relu_bwd_bn_sums: a BatchNorm input without a buffer for its partial sums");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LIDAL_F32)
+    return bn_bwd_masked_partials<float>(out, g, gm, n, c, x_a, mean_a, invstd_a, (double*)part_a, x_b, mean_b, invstd_b,
+                                         (double*)part_b, s);
+  return bn_bwd_masked_partials<__bf16>(out, g, gm, n, c, x_a, mean_a, invstd_a, (double*)part_a, x_b, mean_b, invstd_b,
+                                        (double*)part_b, s);
+}
+
+extern "C" int lidal_bn_bwd_from_sums(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c,
+                                      const float* gamma, const float* beta, int relu, const float* save_mean,
+                                      const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
+                                      const void* part, int64_t part_bytes, void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  LIDAL_REQUIRE(n > 0, "bn_bwd_from_sums: needs at least one row");
+  LIDAL_REQUIRE(part_bytes >= lidal_bn_workspace_bytes(n, c), "bn_bwd_from_sums: partial buffer too small");
+  const int vec = dtype == LIDAL_F32 ? 4 : 8;
+  LIDAL_REQUIRE(dy_stride >= c && dy_stride % vec == 0, "bn_bwd_from_sums: dy row stride %lld (rows of %d, 16-byte steps)",
+                (long long)dy_stride, c);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LIDAL_F32)
+    return bn_bwd_from_partials<float>(x, dy, dy_stride, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
+                                       grad_beta, (const double*)part, s);
+  return bn_bwd_from_partials<__bf16>(x, dy, dy_stride, n, c, gamma, beta, relu, save_mean, save_invstd, dx, grad_gamma,
+                                      grad_beta, (const double*)part, s);
 }
 
 // The backward sums came with dy from the data-gradient launch that produced it (conv_img.hip, BnBwd: f32

@@ -229,6 +229,8 @@ const OpInfo kOps[] = {
     /* LIDAL_OP_JOIN_SIDE 27 */ {0, "join_side"},
     /* LIDAL_OP_CONV_APPLY_IMAGE_WS 28 */ {20, "conv_apply_image_ws"},
     /* LIDAL_OP_CONV_DGRAD_BN_SUMS_WS 29 */ {22, "conv_dgrad_bn_sums_ws"},
+    /* LIDAL_OP_ADD_RELU_BWD_BN_SUMS 30 */ {15, "add_relu_bwd_bn_sums"},
+    /* LIDAL_OP_BN_BWD_FROM_SUMS 31 */ {16, "bn_bwd_from_sums"},
 };
 constexpr int kNumOps = (int)(sizeof(kOps) / sizeof(kOps[0]));
 
@@ -335,6 +337,14 @@ extern "C" int lidal_plan_run_streams(const int64_t* words, int64_t n_words, int
       case LIDAL_OP_BN_BWD:
         rc = lidal_bn_bwd(P(0), P(1), L(2), I(3), L(4), I(5), CP(float, 6), CP(float, 7), I(8), CP(float, 9),
                           CP(float, 10), P(11), MP(float, 12), MP(float, 13), P(14), L(15), st);
+        break;
+      case LIDAL_OP_BN_BWD_FROM_SUMS:
+        rc = lidal_bn_bwd_from_sums(P(0), P(1), L(2), I(3), L(4), I(5), CP(float, 6), CP(float, 7), I(8), CP(float, 9),
+                                    CP(float, 10), P(11), MP(float, 12), MP(float, 13), P(14), L(15), st);
+        break;
+      case LIDAL_OP_ADD_RELU_BWD_BN_SUMS:
+        rc = lidal_add_relu_bwd_bn_sums(P(0), P(1), P(2), I(3), L(4), I(5), P(6), CP(float, 7), CP(float, 8), P(9), P(10),
+                                        CP(float, 11), CP(float, 12), P(13), L(14), st);
         break;
       case LIDAL_OP_BN_BWD_TILES:
         rc = lidal_bn_bwd_tiles(P(0), P(1), L(2), I(3), L(4), I(5), CP(float, 6), CP(float, 7), I(8), CP(float, 9),

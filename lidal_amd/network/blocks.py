@@ -106,14 +106,14 @@ class _Residual(torch.autograd.Function):
         xc, k1, x1, w1, c1, mean1, inv1, y1, k2, x2, w2, c2, mean2, inv2, out = t[:15]
         need_gx = ctx.needs_input_grad[0]
         # relu(bn2 + shortcut): the gradient where the output is positive, for both summands
-        dx2, gg2, gb2, gm = _N.train_backward(x2, w2, c2, mean2, inv2, False, g, True, out)
         gks = ggs = gbs = None
         if ctx.shortcut:
             xs_in, ks, xs, ws, cs, means, invs = t[15:]
-            dxs, ggs, gbs, _ = _N.train_backward(xs, ws, cs, means, invs, False, gm, True)
+            gm, (dx2, gg2, gb2), (dxs, ggs, gbs) = _N.tail_backward(g, out, x2, w2, c2, mean2, inv2, (xs, ws, cs, means, invs))
             g_skip, gks, _ = _D.rows_backward(xs_in, ks, ctx.wcs, ctx.imgs, ctx.pads, False, dxs, need_gx,
                                               ctx.needs_input_grad[7], False)
         else:
+            gm, (dx2, gg2, gb2), _ = _N.tail_backward(g, out, x2, w2, c2, mean2, inv2)
             g_skip = gm
         # conv2's data gradient IS the output gradient of bn1 (y1 has no other consumer): the launch that writes it
         # also leaves bn1's backward sums per tile (BN_SUMS; bf16), and bn1's backward skips its pass for them

@@ -1,6 +1,8 @@
 """Batch normalisation over the rows of a [N, C] feature matrix on the HIP backend
 (lidal_bn_* in include/lidal_amd.h).  Same arithmetic contract as torch.nn.functional.batch_norm:
 biased batch variance for normalisation, running statistics updated with the unbiased variance."""
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -110,6 +112,58 @@ def train_backward(x, w, b, mean, invstd, relu, grad_out, need_dx=True, mask_fro
                                  B.ptr(gg), B.ptr(gb),
                                  B.ptr(ws), nbytes, B.stream()), 'bn_bwd')
     return dx, gg, gb, grad_out
+
+
+# The tail of a residual block backwards in fewer passes: the ReLU mask of relu(bn2(.) + shortcut) and the first pass of
+# the BatchNorm backward of bn2 (and of the shortcut's BatchNorm) in ONE launch (lidal_add_relu_bwd_bn_sums), then
+# lidal_bn_bwd_from_sums (merge + dx) per BatchNorm -- instead of lidal_add_relu_bwd and one lidal_bn_bwd each.  The partial
+# sums are those of the separate pass bit for bit (tests/test_ops_gpu.py).  One pass over 4-5 arrays instead of 3 + 2
+# (+ 2): at most a quarter of the tail's bytes, and the reducing kernel (256 workgroups, f64 sums) streams slower than
+# the element-wise mask it absorbs -- measured (scripts/gpu/tail_ab.sh, same box): one scan 6.74 / 6.75 -> 6.63 / 6.65 ms
+# (23 launches fewer), 5 scans 15.18 / 15.20 -> 15.39 / 15.42 ms with every level fused.  Hence the row limit: the levels
+# where a launch costs more than its bytes.  LIDAL_TAIL_SUMS_ROWS=0: the separate passes everywhere.
+TAIL_SUMS_ROWS = int(os.environ.get('LIDAL_TAIL_SUMS_ROWS', '100000'))
+
+
+def tail_sums(n):
+    """Does the tail of a residual block of n rows run as the fused pair of launches?  (One rule for the per-operator
+    path and the planned step: they must stay bitwise equal.)"""
+    return 0 < n < TAIL_SUMS_ROWS
+
+
+def tail_backward(grad_out, out, x2, w2, b2, mean2, inv2, shortcut=None):
+    """Backward of out = relu(bn2(x2) + s) (network/utils.py:142-172), s = the identity branch or bn_s(xs) with
+    shortcut = (xs, ws, bs, means, invs): -> (gm, (dx2, gg2, gb2), (dxs, ggs, gbs) or None); gm = the masked gradient,
+    which is also the identity branch's."""
+    if not tail_sums(x2.shape[0]):
+        dx2, gg2, gb2, gm = train_backward(x2, w2, b2, mean2, inv2, False, grad_out, True, out)
+        side = None
+        if shortcut is not None:
+            xs, ws, bs, means, invs = shortcut
+            side = train_backward(xs, ws, bs, means, invs, False, gm, True)[:3]
+        return gm, (dx2, gg2, gb2), side
+    n, c = x2.shape
+    dev = x2.device
+    code = B.dtype_code(x2.dtype)
+    g0 = grad_out.contiguous().to(out.dtype)
+    gm = torch.empty_like(out)
+    nbytes = B.lib().lidal_bn_workspace_bytes(n, c)
+    part2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    parts = torch.empty(nbytes, dtype=torch.uint8, device=dev) if shortcut is not None else None
+    xs, ws, bs, means, invs = shortcut if shortcut is not None else (None,) * 5
+    B.check(B.lib().lidal_add_relu_bwd_bn_sums(B.ptr(out), B.ptr(g0), B.ptr(gm), code, n, c, B.ptr(x2), B.ptr(mean2),
+                                               B.ptr(inv2), B.ptr(part2), B.ptr(xs), B.ptr(means), B.ptr(invs),
+                                               B.ptr(parts), nbytes, B.stream()), 'add_relu_bwd')
+    res = []
+    for x, w, b, mu, inv, part in ((x2, w2, b2, mean2, inv2, part2), (xs, ws, bs, means, invs, parts))[:2 if shortcut is not None else 1]:
+        dx = torch.empty_like(x)
+        gg = torch.empty(c, dtype=torch.float32, device=dev)
+        gb = torch.empty(c, dtype=torch.float32, device=dev)
+        B.check(B.lib().lidal_bn_bwd_from_sums(B.ptr(x), B.ptr(gm), c, code, n, c, B.ptr(w), B.ptr(b), 0, B.ptr(mu),
+                                               B.ptr(inv), B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(part), nbytes,
+                                               B.stream()), 'bn_bwd')
+        res.append((dx, gg, gb))
+    return gm, res[0], (res[1] if shortcut is not None else None)
 
 
 class BatchNormRows(Function):

@@ -1210,3 +1210,50 @@ def test_conv_with_split_offsets_equals_the_unsplit_kernel(dtype):
                                                       B.stream()), 'dgrad')
                 sums.append(sm.double().sum(0))
             assert _relerr(sums[1], sums[0]) < 5e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c', [(396662, 96), (22013, 128), (1001, 256), (77, 32)])
+def test_block_tail_mask_with_batchnorm_sums_is_the_two_separate_passes(dtype, n, c):
+    """lidal_add_relu_bwd_bn_sums + lidal_bn_bwd_from_sums (the tail of a residual block backwards as the planned step
+    runs it, network/plan.py b_res; network/utils.py:142-172 backwards) against lidal_add_relu_bwd + lidal_bn_bwd: the
+    masked gradient, both BatchNorms' data gradients and parameter gradients BITWISE (the partial sums are taken over
+    the same terms in the same order)."""
+    from lidal_amd import backend as B
+    from lidal_amd.nn.functional.norm import train_backward
+    L = B.lib()
+    g = torch.Generator(device='cpu').manual_seed(n + c)
+    dev = torch.device(DEV)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).to(dev)
+    out = rnd(n, c).to(dtype)
+    grad = rnd(n, c).to(dtype)
+    xa, xb = (rnd(n, c) * 1.5 + 0.3).to(dtype), (rnd(n, c) * 0.7 - 0.2).to(dtype)
+    code = B.dtype_code(dtype)
+    stats = []
+    for x in (xa, xb):
+        xf = x.float()
+        stats.append((xf.mean(0).contiguous(), (1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)).contiguous()))
+    wa, ba, wb, bb = rnd(c), rnd(c), rnd(c), rnd(c)
+    # the separate passes (what the per-operator path runs)
+    dxa, gga, gba, gm = train_backward(xa, wa, ba, stats[0][0], stats[0][1], False, grad, mask_from=out)
+    dxb, ggb, gbb, _ = train_backward(xb, wb, bb, stats[1][0], stats[1][1], False, gm)
+    nb = L.lidal_bn_workspace_bytes(n, c)
+    for dual in (True, False):
+        gm2 = torch.empty_like(out)
+        pa = torch.empty(nb, dtype=torch.uint8, device=dev)
+        pb = torch.empty(nb, dtype=torch.uint8, device=dev)
+        B.check(L.lidal_add_relu_bwd_bn_sums(B.ptr(out), B.ptr(grad), B.ptr(gm2), code, n, c, B.ptr(xa), B.ptr(stats[0][0]),
+                                             B.ptr(stats[0][1]), B.ptr(pa), B.ptr(xb) if dual else None,
+                                             B.ptr(stats[1][0]) if dual else None, B.ptr(stats[1][1]) if dual else None,
+                                             B.ptr(pb) if dual else None, nb, B.stream()), 'add_relu_bwd')
+        assert torch.equal(gm2, gm)
+        for x, w, b, (mu, inv), part, want in ((xa, wa, ba, stats[0], pa, (dxa, gga, gba)),
+                                               (xb, wb, bb, stats[1], pb, (dxb, ggb, gbb)))[:2 if dual else 1]:
+            dx = torch.empty_like(x)
+            gg = torch.empty(c, dtype=torch.float32, device=dev)
+            gb = torch.empty(c, dtype=torch.float32, device=dev)
+            B.check(L.lidal_bn_bwd_from_sums(B.ptr(x), B.ptr(gm2), c, code, n, c, B.ptr(w), B.ptr(b), 0, B.ptr(mu), B.ptr(inv),
+                                             B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(part), nb, B.stream()), 'bn_bwd')
+            assert torch.equal(dx, want[0]) and torch.equal(gg, want[1]) and torch.equal(gb, want[2])

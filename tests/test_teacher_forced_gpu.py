@@ -291,7 +291,7 @@ def _replay(run, model, stats, conv_every=1):
                     stats.bf16('bn forward' + (' + residual' if res else ''), _mat(y_p, n, c, code), y, '%d x %d relu %d' % (n, c, relu), first)
                 else:
                     stats.f32('bn forward f32', _mat(y_p, n, c, code), y, '%d x %d' % (n, c), 1e-5)
-            elif kind in (P.OP_BN_BWD, P.OP_BN_BWD_TILES):
+            elif kind in (P.OP_BN_BWD, P.OP_BN_BWD_TILES, P.OP_BN_BWD_FROM_SUMS):
                 x_p, dy_p, ldy, code, n, c, gam, bet, relu, mean_p, inv_p, dx_p, gg_p, gb_p = a[:14]
                 x = _mat(x_p, n, c, code).requires_grad_(True)
                 dy = _mat(dy_p, n, c, code, ldy)
@@ -314,6 +314,10 @@ def _replay(run, model, stats, conv_every=1):
                     stats.f32('bn backward dx f32', got, gx, '%d x %d' % (n, c), 1e-5)
                 stats.f32('bn backward grad gamma', _vec(gg_p, c).double(), gg, '%d x %d' % (n, c), 2e-4 if kind == P.OP_BN_BWD_TILES else 1e-5)
                 stats.f32('bn backward grad beta', _vec(gb_p, c).double(), gb, '%d x %d' % (n, c), 2e-4 if kind == P.OP_BN_BWD_TILES else 1e-5)
+            elif kind == P.OP_ADD_RELU_BWD_BN_SUMS:      # (the sums it leaves are checked through OP_BN_BWD_FROM_SUMS)
+                y_p, g_p, gin_p, code, n, c = a[:6]
+                y, gg = _mat(y_p, n, c, code), _mat(g_p, n, c, code)
+                stats.exact('relu mask', _mat(gin_p, n, c, code), torch.where(y > 0, gg, torch.zeros_like(gg)), 'mask')
             elif kind == P.OP_ADD_RELU_BWD:
                 y_p, g_p, gin_p, numel, code = a
                 y, gg = _mat(y_p, 1, numel, code), _mat(g_p, 1, numel, code)

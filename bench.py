@@ -860,6 +860,9 @@ def main():
     world, rank, dev = dist_setup(args)
     from lidal_amd import backend
     backend.lib()                           # fail loudly if the HIP library is missing
+    if not os.environ.get('BENCH_NO_AFFINITY'):
+        near = backend.bind_cpus_near(dev.index)        # (a launcher's `numactl --cpunodebind`: one process per GPU)
+        log('host threads bound to the GPU\'s NUMA node:', 'no (topology not readable)' if near is None else '%d cpus' % len(near))
     batch = make_batch(args.frames, args.points, 7122 + rank, dev)
     log('batch built', tuple(batch[0].shape))
     if args.roofline_only:

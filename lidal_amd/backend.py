@@ -117,7 +117,7 @@ SIGNATURES = {
     'lidal_nn_grid_workspace_bytes': (_i64, [_i64]),
     'lidal_nn_grid_build': (_i32, [_vp, _i64, _f64, _vp, _i64, _vp, _i64, _vp]),
     'lidal_interframe_workspace_bytes': (_i64, [_i64, _i32]),
-    'lidal_interframe_score': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp,
+    'lidal_interframe_score': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp,
                                       _vp, _vp, _vp, _i64, _vp]),
     'lidal_supervoxel_reduce': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'lidal_copy2d': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
@@ -190,6 +190,32 @@ def check(rc, what):
     if rc != 0:
         raise RuntimeError('lidal_amd.%s failed (%d): %s' %
                            (what, rc, lib().lidal_last_error().decode()))
+
+
+def bind_cpus_near(device_index=0):
+    """Restrict the calling thread (and the threads it starts later: autograd's) to the CPUs of the NUMA node the GPU
+    hangs off (`/sys/bus/pci/devices/<bdf>/local_cpulist`) -- what `numactl --cpunodebind` does for a launcher with
+    one process per GPU.  The single-scan step is host-bound: measured on a 2-socket host (scripts/exp/
+    host_mode_probe.py) 6.54 +- 0.02 ms bound against 6.7-7.9 ms wherever the scheduler put the process.  Returns the
+    CPU set, or None when the topology cannot be read (nothing changes then)."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = '%04x:%02x:%02x.0' % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        text = open('/sys/bus/pci/devices/%s/local_cpulist' % bdf).read().strip()
+        cpus = set()
+        for part in text.split(','):
+            if '-' in part:
+                a, b = part.split('-')
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
 
 
 def require_gpu(*tensors):

@@ -2,7 +2,7 @@
 # round 4: default bench line + the rocprof summaries that go to profiles/ (tag = $1)
 set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-TAG=${1:-a}
+TAG=${1:-b}
 O=$GRAFT_REPO_ROOT/gpurun_out/final4_$TAG; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"; tail -2 $O/bench.err; head -c 300 $O/bench_line.json; echo

@@ -439,14 +439,12 @@ int lidal_nn_grid_build(const double* pts, int64_t p, double cell, void* grid, i
 /* replaces score/sv_level/LiDAL.py:59-81 for one query frame against `n_nei` neighbour frames
  * (host arrays of device pointers, in the reference's neighbour order):
  *   interd f64 [p] (mean KL over matched neighbours), intere f32 [p] (entropy of the mean
- *   probability), map_count i32 [p] (matches).
- * q_grid: the query frame's OWN grid (lidal_nn_grid_build over q_pts) or NULL -- with it the queries are walked in the
- * order of its cells (neighbouring lanes probe the same cells of a neighbour frame); same results either way. */
+ *   probability), map_count i32 [p] (matches). */
 int64_t lidal_interframe_workspace_bytes(int64_t p, int n_nei);
 int lidal_interframe_score(const double* q_pts, const float* q_prob, int64_t p, int c,
                            const void* const* nei_grids_host, const double* const* nei_pts_host,
                            const float* const* nei_prob_host, const int64_t* nei_p_host,
-                           int n_nei, double dis_thresh, const void* q_grid, double* interd, float* intere,
+                           int n_nei, double dis_thresh, double* interd, float* intere,
                            int32_t* map_count, void* ws, int64_t ws_bytes, void* stream);
 /* replaces score/sv_level/LiDAL.py:91-98: per-supervoxel means over point lists given as CSR
  * (sv_ptr i64 [s+1], sv_idx i64 [sv_ptr[s]]).  sv_interd f32 [s], sv_intere f32 [s],

@@ -117,7 +117,7 @@ SIGNATURES = {
     'lidal_nn_grid_workspace_bytes': (_i64, [_i64]),
     'lidal_nn_grid_build': (_i32, [_vp, _i64, _f64, _vp, _i64, _vp, _i64, _vp]),
     'lidal_interframe_workspace_bytes': (_i64, [_i64, _i32]),
-    'lidal_interframe_score': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp,
+    'lidal_interframe_score': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp,
                                       _vp, _vp, _vp, _i64, _vp]),
     'lidal_supervoxel_reduce': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'lidal_copy2d': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
@@ -193,9 +193,9 @@ def check(rc, what):
 
 
 def bind_cpus_near(device_index=0):
-    """Restrict the calling thread (and the threads it starts later: autograd's) to the CPUs of the NUMA node the GPU
-    hangs off (`/sys/bus/pci/devices/<bdf>/local_cpulist`) -- what `numactl --cpunodebind` does for a launcher with
-    one process per GPU.  The single-scan step is host-bound: measured on a 2-socket host (scripts/exp/
+    """Restrict EVERY thread of this process (the caller's, autograd's device thread if it exists already, the ones
+    started later inherit) to the CPUs of the NUMA node the GPU hangs off (`/sys/bus/pci/devices/<bdf>/local_cpulist`) --
+    what `numactl --cpunodebind` does for a launcher with one process per GPU.  The single-scan step is host-bound: measured on a 2-socket host (scripts/exp/
     host_mode_probe.py) 6.54 +- 0.02 ms bound against 6.7-7.9 ms wherever the scheduler put the process.  Returns the
     CPU set, or None when the topology cannot be read (nothing changes then)."""
     try:
@@ -213,6 +213,11 @@ def bind_cpus_near(device_index=0):
         if not cpus:
             return None
         os.sched_setaffinity(0, cpus)
+        for tid in os.listdir('/proc/self/task'):           # threads that exist already (autograd's device thread runs the
+            try:                                            # backward plan's host work)
+                os.sched_setaffinity(int(tid), cpus)
+            except (OSError, ValueError):
+                pass
         return cpus
     except (OSError, ValueError, AttributeError, RuntimeError):
         return None

@@ -248,13 +248,10 @@ __device__ __forceinline__ GridView nei_grid(const NeiArgs& nei, int n, double c
 // as p * n_nei threads instead of one serial chain of 27 * n_nei hash probes per point.
 __global__ void __launch_bounds__(256)
 interframe_match_kernel(const double* __restrict__ q_pts, int64_t p, NeiArgs nei, double dis_thresh,
-                        const int* __restrict__ q_order, int* __restrict__ match /*[n_nei][p]*/) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                        int* __restrict__ match /*[n_nei][p]*/) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y;
-  if (t >= p) return;
-  // q_order: the query frame's points sorted by ITS grid cell -- neighbouring lanes then probe the same cells of the
-  // neighbour frame (one hash slot, one run of candidates for the wave) instead of cells along a scan line
-  const int64_t i = q_order ? (int64_t)q_order[t] : t;
+  if (i >= p) return;
   if (nei.p[n] <= 0) { match[(int64_t)n * p + i] = -1; return; }
   const double qx = q_pts[i * 3 + 0], qy = q_pts[i * 3 + 1], qz = q_pts[i * 3 + 2];
   const GridView g = nei_grid(nei, n, reinterpret_cast<const GridHeader*>(nei.grid[n])->cell);
@@ -417,8 +414,8 @@ extern "C" int lidal_interframe_score(const double* q_pts, const float* q_prob, 
                                       const void* const* nei_grids_host,
                                       const double* const* nei_pts_host,
                                       const float* const* nei_prob_host, const int64_t* nei_p_host,
-                                      int n_nei, double dis_thresh, const void* q_grid, double* interd,
-                                      float* intere, int32_t* map_count, void* ws, int64_t ws_bytes,
+                                      int n_nei, double dis_thresh, double* interd, float* intere,
+                                      int32_t* map_count, void* ws, int64_t ws_bytes,
                                       void* stream) {
   LIDAL_REQUIRE(c > 0 && c <= MAXC, "interframe_score: classes must be in 1..%d", MAXC);
   LIDAL_REQUIRE(n_nei >= 0 && n_nei <= MAXNEI, "interframe_score: at most %d neighbours", MAXNEI);
@@ -437,13 +434,8 @@ extern "C" int lidal_interframe_score(const double* q_pts, const float* q_prob, 
   }
   hipStream_t s = (hipStream_t)stream;
   if (n_nei > 0) {
-    const int* q_order = nullptr;
-    if (q_grid != nullptr) {                // (layout of lidal_nn_grid_build: header, table, sorted keys, sorted indices)
-      const int64_t cap = grid_cap(p);
-      q_order = (const int*)((const char*)q_grid + 64 + cap * 12 + ((8 * p + 255) / 256) * 256);
-    }
     interframe_match_kernel<<<dim3((unsigned)cdiv(p, 256), (unsigned)n_nei), 256, 0, s>>>(
-        q_pts, p, a, dis_thresh, q_order, match);
+        q_pts, p, a, dis_thresh, match);
     LIDAL_CHECK_LAUNCH("interframe_match");
   }
   interframe_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(q_prob, p, c, a, match, interd, intere,

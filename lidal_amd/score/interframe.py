@@ -77,10 +77,6 @@ def _ptr_array(ctype, tensors):
     return (ctype * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-# queries walked in the order of the query frame's own grid cells (lidal_interframe_score: q_grid); 0 = scan order
-QUERY_ORDER = os.environ.get('LIDAL_QUERY_ORDER', '1') != '0'
-
-
 def score_points(bank, i, nei_num=24):
     """Per-point (interd f64 [P], intere f32 [P], map_count i32 [P]) of frame i."""
     nei = neighbour_ids(i, len(bank), nei_num)
@@ -100,8 +96,7 @@ def score_points(bank, i, nei_num=24):
     ws_bytes = B.lib().lidal_interframe_workspace_bytes(p, len(nei))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     B.check(B.lib().lidal_interframe_score(B.ptr(q_pts), B.ptr(q_prob), p, c, g_arr, p_arr, f_arr,
-                                           n_arr, len(nei), bank.dis_thresh,
-                                           B.ptr(bank.grid(i)) if QUERY_ORDER else None, B.ptr(interd),
+                                           n_arr, len(nei), bank.dis_thresh, B.ptr(interd),
                                            B.ptr(intere), B.ptr(count), B.ptr(ws), ws_bytes,
                                            B.stream()),
             'interframe_score')

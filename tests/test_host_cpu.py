@@ -327,3 +327,20 @@ def test_geometry_build_refuses_cpu_tensors_and_foreign_networks():
         Geometry.build(model, coords)
     with pytest.raises(TypeError, match='SPVCNN and MinkUNet'):
         Geometry.build(torch.nn.Linear(4, 4), coords)
+
+
+def test_cpu_binding_is_a_no_op_when_the_topology_cannot_be_read():
+    """backend.bind_cpus_near(device): without a GPU (or without the sysfs entry) nothing is changed and nothing raised."""
+    import os
+    from lidal_amd import backend as B
+    before = os.sched_getaffinity(0)
+    assert B.bind_cpus_near(0) is None
+    assert os.sched_getaffinity(0) == before
+
+
+def test_data_parallel_needs_a_process_group():
+    import pytest
+    import torch
+    from lidal_amd.data_parallel import DataParallel
+    with pytest.raises(RuntimeError, match='process group'):
+        DataParallel(torch.nn.Linear(2, 2))

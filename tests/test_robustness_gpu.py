@@ -47,3 +47,21 @@ def test_results_do_not_depend_on_the_contents_of_fresh_buffers(name, autocast, 
     (l0, p0), (l1, p1), (l2, p2) = run(0x00), run(0xFF), run(0x7F)
     assert l0 == l1 == l2, (l0, l1, l2)
     assert torch.equal(p0, p1) and torch.equal(p0, p2)
+
+
+def test_cpu_binding_follows_the_gpu_topology():
+    """backend.bind_cpus_near on the GPU box: the affinity of EVERY thread of the process becomes the GPU's local CPU list
+    (sysfs), a subset of what the process was allowed before."""
+    import os
+    from lidal_amd import backend as B
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = B.bind_cpus_near(0)
+        if cpus is None:
+            pytest.skip('no local_cpulist for this GPU in sysfs')
+        assert cpus and cpus <= before
+        for tid in os.listdir('/proc/self/task'):
+            assert os.sched_getaffinity(int(tid)) == cpus
+    finally:
+        for tid in os.listdir('/proc/self/task'):
+            os.sched_setaffinity(int(tid), before)

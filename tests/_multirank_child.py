@@ -22,16 +22,16 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda', 0)
-    if mode in ('score', 'score_allgather'):
+    if mode in ('score', 'score_allgather', 'score16'):
         from lidal_amd.score import collect_sequence, frame_range, score_sequence
-        model = mc.make_model(dev).eval()
+        model = mc.make_model(dev, 16 if mode == 'score16' else 19).eval()    # (16 classes: the reference's nuScenes models)
         frames = mc.make_frames()
         mine = list(frame_range(len(frames), world, rank))
         local = [mc.to_device(frames[f], dev) for f in mine]
         first = mine[0] if mine else 0
         scores = score_sequence(model, local, first, len(frames), nei_num=mc.NEI, dis_thresh=0.1,
                                 inf_reps=mc.REPS, autocast=False,
-                                exchange='halo' if mode == 'score' else 'allgather')
+                                exchange='allgather' if mode == 'score_allgather' else 'halo')
         got = collect_sequence(scores, [frames[f]['sv_id'] for f in mine],
                                [d['sv_ptr'] for d in local], first, len(frames))
         if rank == 0:

@@ -9,10 +9,10 @@ GRAD_KEYS = ['stem.0.kernel', 'stage2.1.net.0.kernel', 'stage4.2.net.3.kernel', 
              'point_transforms.1.0.weight']
 
 
-def make_model(dev):
+def make_model(dev, classes=19):
     from lidal_amd.network import SPVCNN
     torch.manual_seed(7122)
-    return SPVCNN(19).to(dev)
+    return SPVCNN(classes).to(dev)
 
 
 def make_frames():

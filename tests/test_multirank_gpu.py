@@ -73,6 +73,26 @@ def test_two_rank_scoring_is_bit_equal_to_one_rank(tmp_path):
         assert matched > 0, 'degenerate fixture: no supervoxel saw an inter-frame match'
 
 
+def test_two_rank_scoring_of_a_16_class_model(tmp_path):
+    """The halo exchange sizes its receive buffers from the model's class count BEFORE any inference
+    (score/pipeline.py _num_classes): a 16-class network (the reference's nuScenes configuration) must go through the
+    2-rank path and reproduce the 1-rank scores bit for bit."""
+    import multirank_common as mc
+    from lidal_amd.score import collect_sequence, score_sequence
+    dev = torch.device('cuda', 0)
+    model = mc.make_model(dev, 16).eval()
+    frames = mc.make_frames()
+    local = [mc.to_device(f, dev) for f in frames]
+    scores = score_sequence(model, local, 0, len(frames), nei_num=mc.NEI, dis_thresh=0.1, inf_reps=mc.REPS, autocast=False)
+    one = collect_sequence(scores, [f['sv_id'] for f in frames], [d['sv_ptr'] for d in local], 0, len(frames))
+    torch.cuda.synchronize()
+    _spawn('score16', tmp_path)
+    two = np.load(os.path.join(str(tmp_path), 'score16_2rank.npz'))
+    for f, t in enumerate(one):
+        for k, v in zip(('id', 'd', 'e', 'n', 'c'), t):
+            assert np.array_equal(two['%s_%d' % (k, f)], v), (k, f)
+
+
 @pytest.mark.parametrize('mode', ['ddp', 'dp', 'dp_per_operator'])
 def test_two_rank_ddp_gradient_is_the_mean_of_the_rank_gradients(tmp_path, mode):
     """'ddp': torch's DistributedDataParallel as train.py:49-53 wraps the model; 'dp': lidal_amd.data_parallel.DataParallel

@@ -88,13 +88,15 @@ __device__ __forceinline__ void image_segment(const TI* __restrict__ w, TO* __re
   constexpr int VEC = DT<TO>::VEC, CH = DT<TO>::CH;
   const int bn = 16 * nb, ncc = kc / CH;
   const int nblk = (n_col + bn - 1) / bn, npass = (n_red + kc - 1) / kc;
-  int64_t r = s;
-  const int row16 = (int)(r % 16); r /= 16;
-  const int b = (int)(r % nb); r /= nb;
-  const int gsel = (int)(r % 4); r /= 4;
-  const int cc = (int)(r % ncc); r /= ncc;
-  const int pass = (int)(r % npass); r /= npass;
-  const int blk = (int)(r % nblk); r /= nblk;
+  // (an image has < 2^31 segments: 32-bit divisions.  Measured: no change -- 136 us for the 22 M parameters of SPVCNN,
+  // 1.3 TB/s; the data-gradient images read 32-byte pieces of 64 different rows per wave, that is what it waits for)
+  unsigned r = (unsigned)s;
+  const int row16 = (int)(r & 15u); r >>= 4;
+  const int b = (int)(r % (unsigned)nb); r /= (unsigned)nb;
+  const int gsel = (int)(r & 3u); r >>= 2;
+  const int cc = (int)(r % (unsigned)ncc); r /= (unsigned)ncc;
+  const int pass = (int)(r % (unsigned)npass); r /= (unsigned)npass;
+  const int blk = (int)(r % (unsigned)nblk); r /= (unsigned)nblk;
   const int k = (int)r;
   const int col = blk * bn + b * 16 + row16;
   const int red0 = pass * kc + cc * CH + gsel * VEC;
@@ -1262,6 +1264,7 @@ static int weight_images(const void* w, int w_dtype, int role, void* img_a, int6
     tb = pick_tiling(n_col, n_red, n_out_b, esz);
     segs_b = image_bytes(k, n_col, n_red, tb, esz) / 16;
   }
+  LIDAL_REQUIRE(segs_a < (1ll << 31) && segs_b < (1ll << 31), "weight_image: an image of more than 2^31 segments");
   const unsigned grid = (unsigned)cdiv(segs_a + segs_b, 256);
 #define IMG_LAUNCH(TI, TO) \
   weight_image_kernel<TI, TO><<<grid, 256, 0, s>>>((const TI*)w, (TO*)img_a, n_red, n_col, role, ta.nb, \
@@ -1315,6 +1318,10 @@ extern "C" int64_t lidal_conv_weight_image_job(void* job, const void* w, int rol
     const Tiling tb = pick_tiling(co, ci, n_out_bwd, esz);
     j.segs_b = image_bytes(k, co, ci, tb, esz) / 16;
     j.nb_b = tb.nb; j.kc_b = tb.row_bytes / esz;
+  }
+  if (j.segs_a >= (1ll << 31) || j.segs_b >= (1ll << 31)) {       // (image_segment indexes a segment with 32 bits)
+    set_error("weight_image_job: an image of %lld segments", (long long)(j.segs_a > j.segs_b ? j.segs_a : j.segs_b));
+    return -1;
   }
   *reinterpret_cast<ImageJob*>(job) = j;
   return j.segs_a + j.segs_b;

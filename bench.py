@@ -179,6 +179,8 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
         if os.environ.get('BENCH_TORCH_DDP'):
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
         else:
+            if world == 1:                      # BENCH_FORCE_DDP on one GPU: execute the collective over RCCL all the same
+                os.environ.setdefault('LIDAL_DP_FORCE_COLLECTIVE', '1')
             from lidal_amd.data_parallel import DataParallel
             net = DataParallel(model)
     # Adam with the reference's defaults (train.py:56); `fused` only selects torch's single-kernel

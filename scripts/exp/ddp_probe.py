@@ -18,13 +18,19 @@ rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1
 backend = os.environ.get('BENCH_BACKEND', 'gloo')
 dev = torch.device('cuda', 0 if backend == 'gloo' else int(os.environ.get('LOCAL_RANK', 0)))
 torch.cuda.set_device(dev)
-if world > 1:
+if world > 1 or os.environ.get('DP'):
     dist.init_process_group(backend, rank=rank, world_size=world)
 b = synth.make_train_batch(n_frames=int(os.environ.get('FRAMES', '5')), n_points=120000, seed=7122 + rank)
 coords, feats, labels = (torch.from_numpy(b[k]).to(dev) for k in ('coords_v_b', 'feats_v_b', 'labels_v_b'))
 torch.manual_seed(7122)
 model = SPVCNN(19).to(dev).train()
-net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index]) if world > 1 and not os.environ.get('NO_DDP') else model
+if os.environ.get('DP'):
+    from lidal_amd.data_parallel import DataParallel
+    net = DataParallel(model)
+elif world > 1 and not os.environ.get('NO_DDP'):
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
+else:
+    net = model
 opt = torch.optim.Adam(net.parameters(), fused=True)
 pf = GeometryPrefetcher(model, device=dev)
 g = pf.submit(coords)
@@ -62,6 +68,6 @@ for it in range(6):
         print('step %d  zero %.1f  forward %.1f  loss %.1f  backward %.1f  adam %.1f  submit %.1f  ms   (loss %.4f)'
               % ((it,) + tuple(1e3 * v for v in ph) + (loss.item(),)), flush=True)
 pf.drain()
-if world > 1:
+if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()

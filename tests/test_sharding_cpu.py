@@ -243,6 +243,9 @@ def _dp_worker(rank, world, port, out_dir):
             ok = ok and torch.allclose(net.w.grad, sum(g[0] for g in grads) / world, rtol=1e-6, atol=1e-6)
             ok = ok and torch.allclose(net.b.grad, sum(g[1] for g in grads) / world, rtol=1e-6, atol=1e-6)
         ok = ok and dp.reductions == 2 and dp.flat_reductions == (2 if flat else 0)
+        before = net.w.grad.clone()             # autograd.grad through the outputs accumulates nothing: nothing to reduce
+        torch.autograd.grad(dp(x).square().sum(), [net.w])
+        ok = ok and dp.reductions == 2 and torch.equal(net.w.grad, before)
         ok = ok and list(dp.state_dict()) == ['module.w', 'module.b', 'module.seen']
     torch.save(ok, os.path.join(out_dir, 'dp_ok_%d.pt' % rank))
     dist.destroy_process_group()

@@ -320,6 +320,7 @@ class _Program:
                 off = (off + 3) & -4
         self.flat_numel = off
         self.flat_exact = all(self.params[i].numel() % 4 == 0 for i in order[:-1])
+        self.flat_params = None
         self.running = [t for r, m in self.bns for t in (m.running_mean, m.running_var)]
         self.tensors = self.params + self.buffers
         self.bn_modules = [m for _, m in self.bns]
@@ -1160,10 +1161,13 @@ class _Run:
         prog = self.prog
         views = [None] * len(prog.params)
         if prog.flat_exact:
+            # one C++ call for the 161 views (split_with_sizes + a view each from Python: 0.45 ms of a host-bound step)
             order = prog.flat_order
-            parts = flat[:prog.flat_numel].split_with_sizes([prog.params[i].numel() for i in order])
+            if prog.flat_params is None:
+                prog.flat_params = [prog.params[i] for i in order]
+            parts = torch._C._nn.unflatten_dense_tensors(flat[:prog.flat_numel], prog.flat_params)
             for i, t in zip(order, parts):
-                views[i] = t.view(prog.params[i].shape)
+                views[i] = t
         else:
             for i, p in enumerate(prog.params):
                 views[i] = flat[prog.slot[i]:prog.slot[i] + p.numel()].view(p.shape)

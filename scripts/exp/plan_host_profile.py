@@ -12,6 +12,8 @@ from lidal_amd.network import SPVCNN, GeometryPrefetcher  # noqa: E402
 from lidal_amd.train_step import train_step  # noqa: E402
 
 dev = 'cuda'
+from lidal_amd import backend as B  # noqa: E402
+B.bind_cpus_near(0)
 b = synth.make_train_batch(n_frames=int(os.environ.get('FRAMES', '1')), n_points=120000, seed=7122)
 coords, feats, labels = (torch.from_numpy(b[k]).to(dev) for k in ('coords_v_b', 'feats_v_b', 'labels_v_b'))
 model = SPVCNN(19).to(dev).train()
@@ -30,4 +32,5 @@ for _ in range(30):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('cumulative').print_stats(45)
+st.sort_stats('cumulative').print_stats(38)
+st.sort_stats('tottime').print_stats(22)

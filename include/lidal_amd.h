@@ -383,6 +383,11 @@ int lidal_bn_bwd_from_sums(const void* x, const void* dy, int64_t dy_stride, int
                            const float* gamma, const float* beta, int relu, const float* save_mean,
                            const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
                            const void* part, int64_t part_bytes, void* stream);
+/* test / A-B aid.  The merge steps of a BatchNorm layer (tile statistics -> mean / invstd; backward partial sums ->
+ * parameter gradients) run INSIDE the launch that consumes them (the first workgroups merge and publish, all fetch;
+ * csrc/bn.hip) -- same arithmetic, same results bit for bit as the separate merge launches, which on = 0 brings back
+ * (also: environment LIDAL_BN_FUSED=0).  The library keeps one 2 MiB ring of publication slots per device for this. */
+int lidal_bn_set_fused(int on);
 /* eval-mode BatchNorm as a per-channel affine map (scale = gamma / sqrt(var + eps),
  * shift = beta - mean * scale), the operands of lidal_conv_apply's epilogue. */
 int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,

@@ -533,6 +533,12 @@ int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const floa
   return 0;
 }
 
+// (defined with the merge-in-consumer kernels further down)
+template <typename T, bool TILES>
+bool bn_bwd_merge_dx(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const float* gamma, const float* beta,
+                     int relu, const float* mean, const float* invstd, void* dx, float* ggamma, float* gbeta,
+                     const void* part, int nparts, hipStream_t s);
+
 template <typename T>
 int bn_bwd(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const float* gamma,
            const float* beta, int relu, const float* mean, const float* invstd, void* dx, float* ggamma,
@@ -542,6 +548,10 @@ int bn_bwd(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const f
   bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>(
       (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, rows_per_wg(n), ldy);
   LIDAL_CHECK_LAUNCH("bn_bwd_partial");
+  if (bn_bwd_merge_dx<T, false>(x, dy, ldy, n, c, gamma, beta, relu, mean, invstd, dx, ggamma, gbeta, part, np, s)) {
+    LIDAL_CHECK_LAUNCH("bn_bwd_dx(sums merged in the launch)");
+    return 0;
+  }
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, gbeta, ggamma);
   LIDAL_CHECK_LAUNCH("bn_bwd_final");
   if (dx != nullptr) {
@@ -576,6 +586,10 @@ template <typename T>
 int bn_bwd_from_partials(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const float* gamma,
                          const float* beta, int relu, const float* mean, const float* invstd, void* dx, float* ggamma,
                          float* gbeta, const double* part, hipStream_t s) {
+  if (bn_bwd_merge_dx<T, false>(x, dy, ldy, n, c, gamma, beta, relu, mean, invstd, dx, ggamma, gbeta, part, nparts_for(n), s)) {
+    LIDAL_CHECK_LAUNCH("bn_bwd_dx(sums merged in the launch)");
+    return 0;
+  }
   bn_bwd_final_kernel<<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, nparts_for(n), c, gbeta, ggamma);
   LIDAL_CHECK_LAUNCH("bn_bwd_final");
   if (dx != nullptr) {
@@ -675,6 +689,309 @@ __global__ void __launch_bounds__(NT) bn_tiles_final_kernel(const float* __restr
   }
 }
 
+// ---- merge kernels inside their consumers ------------------------------------------------------------------
+// A BatchNorm layer was three launches forwards (tile merge, apply) and backwards (partial / tile merge, dx); the merges
+// are 5-7 us launches that compute for 2 us (104 per step: on one scan every eighth microsecond of the step).  Here
+// the consumer kernel's first workgroups do the merge -- workgroup b the channels b, b + grid, ... with the arithmetic
+// of the stand-alone merge kernel, term by term -- and PUBLISH the two f32 values of a channel as two 64-bit words
+// (value | launch token << 32; agent-scope atomics, no fence needed: the token travels with the value); every
+// workgroup then fetches the words of all channels (spinning until the token matches) and streams its rows.  Forward
+// progress: the merging workgroups have the lowest ids of the launch and are dispatched first (the assumption the
+// radix sort's look-back makes, sort.hip); a fetch gives up after ~1 s and poisons its channel with NaN (a test
+// fails instead of a GPU hanging).  The slots live in a ring of buffers of this library (one per launch in flight,
+// 64 deep), the token is a process-wide counter.
+struct Slots { unsigned long long* v; unsigned token; };
+constexpr int SLOT_RING = 64, SLOT_CH = 2048;
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+
+__device__ __forceinline__ void publish(const Slots& s, int ch, float a, float b) {
+  const unsigned long long t = (unsigned long long)s.token << 32;
+  __hip_atomic_store(s.v + 2 * ch, t | (unsigned long long)__float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(s.v + 2 * ch + 1, t | (unsigned long long)__float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float fetch_one(const Slots& s, int idx) {
+  unsigned long long v = __hip_atomic_load(s.v + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned spins = 0;
+  while ((unsigned)(v >> 32) != s.token) {
+    if (++spins > SPIN_LIMIT) return __uint_as_float(0x7fc00000u);
+    __builtin_amdgcn_s_sleep(2);
+    v = __hip_atomic_load(s.v + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return __uint_as_float((unsigned)v);
+}
+
+// bn_tiles_final_kernel + bn_apply_kernel<T, false> in one launch
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict__ x, int64_t n, int c,
+                                                            const float* __restrict__ part, int nparts, float eps,
+                                                            float momentum, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var,
+                                                            long long* __restrict__ num_batches,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int relu, const T* __restrict__ res, T* __restrict__ y, int rpw,
+                                                            Slots slots) {
+  constexpr int VEC = IO<T>::VEC;
+  __shared__ double sn[NT], s1[NT], s2[NT];
+  __shared__ float smu[SLOT_CH], sis[SLOT_CH];
+  const int tid = threadIdx.x;
+  if (num_batches != nullptr && blockIdx.x == 0 && tid == 0) *num_batches += 1;
+  // ---- the merge of bn_tiles_final_kernel, for this workgroup's channels
+  for (int ch = blockIdx.x; ch < c; ch += gridDim.x) {
+    double nn = 0., a = 0., b = 0.;
+    for (int p = tid; p < nparts; p += NT) {
+      const float* sp = part + ((int64_t)p * c + ch) * 3;
+      const double pn = (double)sp[0], pm = (double)sp[1];
+      nn += pn; a += pn * pm; b += (double)sp[2] + pn * pm * pm;
+    }
+    sn[tid] = nn; s1[tid] = a; s2[tid] = b;
+    for (int st = NT / 2; st >= 1; st >>= 1) {
+      __syncthreads();
+      if (tid < st) { sn[tid] += sn[tid + st]; s1[tid] += s1[tid + st]; s2[tid] += s2[tid + st]; }
+    }
+    if (tid == 0) {
+      nn = sn[0];
+      const double m = nn > 0. ? s1[0] / nn : 0.;
+      double m2 = s2[0] - nn * m * m;
+      if (m2 < 0.) m2 = 0.;
+      const double var = nn > 0. ? m2 / nn : 0.;
+      const float fm = (float)m, fi = (float)(1. / sqrt(var + (double)eps));
+      mean[ch] = fm;
+      invstd[ch] = fi;
+      if (running_mean != nullptr) {
+        const float unbiased = (float)(nn > 1. ? m2 / (nn - 1.) : var);
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * fm;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+      }
+      publish(slots, ch, fm, fi);
+    }
+    __syncthreads();
+  }
+  // ---- every channel's (mean, invstd), from whichever workgroup merged it
+  for (int ch = tid; ch < c; ch += NT) {
+    smu[ch] = fetch_one(slots, 2 * ch);
+    sis[ch] = fetch_one(slots, 2 * ch + 1);
+  }
+  __syncthreads();
+  // ---- bn_apply_kernel<T, false>
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int cg = tid % cg_n, rl = tid / cg_n;
+  if (rl >= rpi) return;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
+  float mu[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = cg * VEC + i;
+    mu[i] = smu[ch];
+    sc[i] = sis[ch] * (gamma ? gamma[ch] : 1.f);
+    sh[i] = beta ? beta[ch] : 0.f;
+  }
+  auto one = [&](const typename IO<T>::vec& v, const typename IO<T>::vec& vr, int64_t r) {
+    float f[VEC], fr[VEC];
+    IO<T>::unpack(v, f);
+    IO<T>::unpack(vr, fr);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
+      if (relu & 1) f[i] = fmaxf(f[i], 0.f);
+      if (res != nullptr) {
+        f[i] = (float)(T)f[i] + fr[i];
+        if (relu & 2) f[i] = fmaxf(f[i], 0.f);
+      }
+    }
+    *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
+  };
+  const T* rsrc = res != nullptr ? res : x;
+  int64_t r = r_beg + rl;
+  for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
+    typename IO<T>::vec v[UNR], vr[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      v[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+    if (res != nullptr) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        vr[u] = *reinterpret_cast<const typename IO<T>::vec*>(rsrc + (r + u * rpi) * c + cg * VEC);
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) vr[u] = v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) one(v[u], vr[u], r + u * rpi);
+  }
+  for (; r < r_end; r += rpi) {
+    const typename IO<T>::vec v = *reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC);
+    one(v, res != nullptr ? *reinterpret_cast<const typename IO<T>::vec*>(res + r * c + cg * VEC) : v, r);
+  }
+}
+
+// bn_bwd_final_kernel (TILES = false: f64 partial pairs of bn_bwd_partial_kernel, 8 channels x 32 lanes per unit) or
+// bn_bwd_tiles_final_kernel (TILES = true: f32 pairs per 128-row tile, one channel per unit) + bn_bwd_dx_kernel
+template <typename T, bool TILES>
+__global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n,
+                                                             int c, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int relu, const void* __restrict__ part, int nparts,
+                                                             float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat,
+                                                             T* __restrict__ dx, int rpw, int64_t ldy, Slots slots) {
+  constexpr int VEC = IO<T>::VEC;
+  __shared__ double sa[NT], sb[NT];
+  __shared__ float sk1[SLOT_CH], sk2[SLOT_CH];
+  const int tid = threadIdx.x;
+  if (TILES) {
+    const float* pt = (const float*)part;
+    for (int ch = blockIdx.x; ch < c; ch += gridDim.x) {
+      double a = 0., b = 0.;
+      for (int p = tid; p < nparts; p += NT) {
+        const float* sp = pt + ((int64_t)p * c + ch) * 2;
+        a += (double)sp[0]; b += (double)sp[1];
+      }
+      sa[tid] = a; sb[tid] = b;
+      for (int st = NT / 2; st >= 1; st >>= 1) {
+        __syncthreads();
+        if (tid < st) { sa[tid] += sa[tid + st]; sb[tid] += sb[tid + st]; }
+      }
+      if (tid == 0) {
+        const float fa = (float)sa[0], fb = (float)sb[0];
+        sum_dy[ch] = fa; sum_dy_xhat[ch] = fb;
+        publish(slots, ch, fa, fb);
+      }
+      __syncthreads();
+    }
+  } else {
+    const double* pd = (const double*)part;
+    const int cl = tid & 7, pl = tid >> 3;
+    for (int u = blockIdx.x; u * 8 < c; u += gridDim.x) {
+      const int ch = u * 8 + cl;
+      double a = 0., b = 0.;
+      if (ch < c)
+        for (int p = pl; p < nparts; p += 32) {
+          a += pd[((int64_t)p * c + ch) * 2];
+          b += pd[((int64_t)p * c + ch) * 2 + 1];
+        }
+      sa[tid] = a; sb[tid] = b;
+      for (int st = 16; st >= 1; st >>= 1) {
+        __syncthreads();
+        if (pl < st) { sa[tid] += sa[tid + st * 8]; sb[tid] += sb[tid + st * 8]; }
+      }
+      __syncthreads();
+      if (pl == 0 && ch < c) {
+        const float fa = (float)sa[tid], fb = (float)sb[tid];
+        sum_dy[ch] = fa; sum_dy_xhat[ch] = fb;
+        publish(slots, ch, fa, fb);
+      }
+      __syncthreads();
+    }
+  }
+  if (dx == nullptr) return;            // (only the parameter gradients were wanted)
+  for (int ch = tid; ch < c; ch += NT) {
+    sk1[ch] = fetch_one(slots, 2 * ch);
+    sk2[ch] = fetch_one(slots, 2 * ch + 1);
+  }
+  __syncthreads();
+  // ---- bn_bwd_dx_kernel
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int cg = tid % cg_n, rl = tid / cg_n;
+  if (rl >= rpi) return;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
+  const float inv_n = 1.f / (float)n;
+  float mu[VEC], is[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = cg * VEC + i;
+    mu[i] = mean[ch]; is[i] = invstd[ch];
+    ga[i] = gamma ? gamma[ch] : 1.f; be[i] = beta ? beta[ch] : 0.f;
+    k1[i] = sk1[ch] * inv_n; k2[i] = sk2[ch] * inv_n;
+  }
+  auto one = [&](const typename IO<T>::vec& vx, const typename IO<T>::vec& vd, int64_t r) {
+    float fx[VEC], fd[VEC];
+    IO<T>::unpack(vx, fx);
+    IO<T>::unpack(vd, fd);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float xhat = (fx[i] - mu[i]) * is[i];
+      if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
+      fd[i] = ga[i] * is[i] * (fd[i] - k1[i] - xhat * k2[i]);
+    }
+    *reinterpret_cast<typename IO<T>::vec*>(dx + r * c + cg * VEC) = IO<T>::pack(fd);
+  };
+  int64_t r = r_beg + rl;
+  for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
+    typename IO<T>::vec vx[UNR], vd[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+      vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * ldy + cg * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) one(vx[u], vd[u], r + u * rpi);
+  }
+  for (; r < r_end; r += rpi)
+    one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
+        *reinterpret_cast<const typename IO<T>::vec*>(dy + r * ldy + cg * VEC), r);
+}
+
+// ---- host side of the slots: one ring of buffers per device, one token per launch
+#include <atomic>
+#include <mutex>
+namespace {
+std::atomic<unsigned> g_token{1};
+std::atomic<int> g_fused{-1};           // -1: not read yet (LIDAL_BN_FUSED, default on)
+unsigned long long* g_ring[MAX_DEVICES] = {};
+std::mutex g_ring_mutex;
+
+bool bn_fused() {
+  int f = g_fused.load();
+  if (f < 0) {
+    const char* e = getenv("LIDAL_BN_FUSED");
+    f = (e == nullptr || e[0] != '0') ? 1 : 0;
+    g_fused.store(f);
+  }
+  return f != 0;
+}
+
+// the slots of the next launch on the current device (nullptr: the ring could not be allocated -- separate launches)
+bool next_slots(Slots* out) {
+  const int d = current_device();
+  if (g_ring[d] == nullptr) {
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    if (g_ring[d] == nullptr) {
+      void* p = nullptr;
+      const size_t bytes = (size_t)SLOT_RING * 2 * SLOT_CH * sizeof(unsigned long long);
+      if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        return false;
+      g_ring[d] = (unsigned long long*)p;
+    }
+  }
+  unsigned t = g_token.fetch_add(1);
+  if (t == 0) t = g_token.fetch_add(1);          // (0 is what the ring was cleared to)
+  out->token = t;
+  out->v = g_ring[d] + (size_t)(t % SLOT_RING) * 2 * SLOT_CH;
+  return true;
+}
+}  // namespace
+
+// test / A-B aid: 1 = merge kernels inside their consumers (default), 0 = separate launches
+extern "C" int lidal_bn_set_fused(int on) { g_fused.store(on ? 1 : 0); return 0; }
+
+namespace {
+// the merge of the backward sums and the dx pass as one launch; false: not taken (the caller launches them apart)
+template <typename T, bool TILES>
+bool bn_bwd_merge_dx(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const float* gamma, const float* beta,
+                     int relu, const float* mean, const float* invstd, void* dx, float* ggamma, float* gbeta,
+                     const void* part, int nparts, hipStream_t s) {
+  Slots slots;
+  if (dx == nullptr || !bn_fused() || c > SLOT_CH || !next_slots(&slots)) return false;
+  bn_bwd_dx_merge_kernel<T, TILES><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>(
+      (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, nparts, gbeta, ggamma, (T*)dx,
+      rows_per_wg_ew(n, (int64_t)c * sizeof(T)), ldy, slots);
+  return true;
+}
+}  // namespace
+
 // statistics already reduced per 128-row tile by the producing convolution (conv_img.hip,
 // store_tile): merge the tiles, then normalise -- no statistics pass over x
 extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int c, const float* gamma,
@@ -687,6 +1004,21 @@ extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int
   if (int rc = bn_check(n, c, dtype)) return rc;
   LIDAL_REQUIRE(n > 0 && n_tiles > 0 && tile_stats != nullptr, "bn_train_fwd_tiles: needs rows and tile statistics");
   hipStream_t s = (hipStream_t)stream;
+  Slots slots;
+  if (bn_fused() && c <= SLOT_CH && next_slots(&slots)) {
+    if (dtype == LIDAL_F32)
+      bn_apply_tiles_kernel<float><<<nslabs_ew(n, (int64_t)c * 4), NT, 0, s>>>(
+          (const float*)x, n, c, tile_stats, (int)n_tiles, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+          (long long*)num_batches_tracked, gamma, beta, relu, (const float*)residual, (float*)y,
+          rows_per_wg_ew(n, (int64_t)c * 4), slots);
+    else
+      bn_apply_tiles_kernel<__bf16><<<nslabs_ew(n, (int64_t)c * 2), NT, 0, s>>>(
+          (const __bf16*)x, n, c, tile_stats, (int)n_tiles, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+          (long long*)num_batches_tracked, gamma, beta, relu, (const __bf16*)residual, (__bf16*)y,
+          rows_per_wg_ew(n, (int64_t)c * 2), slots);
+    LIDAL_CHECK_LAUNCH("bn_apply(tiles merged in the launch)");
+    return 0;
+  }
   bn_tiles_final_kernel<<<(unsigned)c, NT, 0, s>>>(tile_stats, (int)n_tiles, c, eps, momentum, save_mean,
                                                    save_invstd, running_mean, running_var,
                                                    (long long*)num_batches_tracked);
@@ -812,6 +1144,13 @@ extern "C" int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stri
   LIDAL_REQUIRE(dy_stride >= c && dy_stride % vec == 0, "bn_bwd_tiles: dy row stride %lld (rows of %d, 16-byte steps)",
                 (long long)dy_stride, c);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == LIDAL_F32 ? bn_bwd_merge_dx<float, true>(x, dy, dy_stride, n, c, gamma, beta, relu, save_mean, save_invstd, dx,
+                                                        grad_gamma, grad_beta, tile_sums, (int)n_tiles, s)
+                         : bn_bwd_merge_dx<__bf16, true>(x, dy, dy_stride, n, c, gamma, beta, relu, save_mean, save_invstd, dx,
+                                                         grad_gamma, grad_beta, tile_sums, (int)n_tiles, s)) {
+    LIDAL_CHECK_LAUNCH("bn_bwd_dx(tile sums merged in the launch)");
+    return 0;
+  }
   bn_bwd_tiles_final_kernel<<<(unsigned)c, NT, 0, s>>>(tile_sums, (int)n_tiles, c, grad_beta, grad_gamma);
   LIDAL_CHECK_LAUNCH("bn_bwd_final(tiles)");
   if (dx != nullptr) {

@@ -1257,3 +1257,71 @@ def test_block_tail_mask_with_batchnorm_sums_is_the_two_separate_passes(dtype, n
             B.check(L.lidal_bn_bwd_from_sums(B.ptr(x), B.ptr(gm2), c, code, n, c, B.ptr(w), B.ptr(b), 0, B.ptr(mu), B.ptr(inv),
                                              B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(part), nb, B.stream()), 'bn_bwd')
             assert torch.equal(dx, want[0]) and torch.equal(gg, want[1]) and torch.equal(gb, want[2])
+
+
+def _tile_triples(x, tile=128):
+    """(count, mean, M2) per 128-row tile and channel, f32 [tiles, c, 3]: what a convolution's epilogue leaves."""
+    n, c = x.shape
+    xf = x.float()
+    out = []
+    for r in range(0, n, tile):
+        blk = xf[r:r + tile]
+        m = blk.mean(0)
+        out.append(torch.stack([torch.full_like(m, blk.shape[0]), m, ((blk - m) ** 2).sum(0)], 1))
+    return torch.stack(out, 0).contiguous()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c', [(396662, 96), (83177, 32), (22013, 128), (3300, 256), (77, 64)])
+def test_batchnorm_merges_inside_their_consumers_are_the_separate_launches(dtype, n, c):
+    """lidal_bn_set_fused: the tile-statistics merge inside the apply launch (forward) and the partial-sum merges inside
+    the dx launch (backward) against the separate merge launches: outputs, saved statistics, running statistics and
+    parameter gradients BITWISE, with and without the residual / ReLU epilogues, on sizes from one workgroup to 512."""
+    from lidal_amd import backend as B
+    L = B.lib()
+    dev = torch.device(DEV)
+    g = torch.Generator(device='cpu').manual_seed(3 * n + c)
+    x = (torch.randn(n, c, generator=g) * 1.7 + 0.4).to(dev).to(dtype)
+    res = torch.randn(n, c, generator=g).to(dev).to(dtype)
+    dy = torch.randn(n, c, generator=g).to(dev).to(dtype)
+    gamma, beta = torch.randn(c, generator=g).to(dev), torch.randn(c, generator=g).to(dev)
+    tiles = _tile_triples(x)
+    tile_sums = torch.randn(tiles.shape[0], c, 2, generator=g).to(dev).contiguous()
+    code = B.dtype_code(dtype)
+    nb = L.lidal_bn_workspace_bytes(n, c)
+    outs = {}
+    try:
+        for fused in (0, 1):
+            L.lidal_bn_set_fused(fused)
+            got = []
+            for relu, r in ((1, None), (3, res), (0, None)):
+                y = torch.empty_like(x)
+                mean = torch.empty(c, device=dev)
+                inv = torch.empty(c, device=dev)
+                rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+                nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+                B.check(L.lidal_bn_train_fwd_tiles(B.ptr(x), code, n, c, B.ptr(gamma), B.ptr(beta), 1e-5, 0.1, B.ptr(rm), B.ptr(rv),
+                                                   B.ptr(nbt), relu, B.ptr(r), B.ptr(y), B.ptr(mean), B.ptr(inv), B.ptr(tiles),
+                                                   tiles.shape[0], B.stream()), 'bn_train_fwd')
+                got += [y, mean, inv, rm, rv, nbt]
+                # backward through lidal_bn_bwd (partial + merge + dx)
+                dx = torch.empty_like(x)
+                gg, gb = torch.empty(c, device=dev), torch.empty(c, device=dev)
+                ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                B.check(L.lidal_bn_bwd(B.ptr(x), B.ptr(dy), c, code, n, c, B.ptr(gamma), B.ptr(beta), relu & 1, B.ptr(mean), B.ptr(inv),
+                                       B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(ws), nb, B.stream()), 'bn_bwd')
+                got += [dx, gg, gb]
+                # ... and through lidal_bn_bwd_tiles (f32 sums per 128-row tile, as a data-gradient launch leaves them)
+                dx2 = torch.empty_like(x)
+                gg2, gb2 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+                B.check(L.lidal_bn_bwd_tiles(B.ptr(x), B.ptr(dy), c, code, n, c, B.ptr(gamma), B.ptr(beta), relu & 1, B.ptr(mean),
+                                             B.ptr(inv), B.ptr(dx2), B.ptr(gg2), B.ptr(gb2), B.ptr(tile_sums), tile_sums.shape[0],
+                                             B.stream()), 'bn_bwd')
+                got += [dx2, gg2, gb2]
+            torch.cuda.synchronize()
+            outs[fused] = got
+    finally:
+        L.lidal_bn_set_fused(1)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[1][0].float()).all()

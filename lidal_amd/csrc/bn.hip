@@ -697,12 +697,12 @@ __global__ void __launch_bounds__(NT) bn_tiles_final_kernel(const float* __restr
 // (value | launch token << 32; agent-scope atomics, no fence needed: the token travels with the value); every
 // workgroup then fetches the words of all channels (spinning until the token matches) and streams its rows.  Forward
 // progress: the merging workgroups have the lowest ids of the launch and are dispatched first (the assumption the
-// radix sort's look-back makes, sort.hip); a fetch gives up after ~1 s and poisons its channel with NaN (a test
+// radix sort's look-back makes, sort.hip); a fetch gives up after ~30 s and poisons its channel with NaN (a test
 // fails instead of a GPU hanging).  The slots live in a ring of buffers of this library (one per launch in flight,
 // 64 deep), the token is a process-wide counter.
 struct Slots { unsigned long long* v; unsigned token; };
 constexpr int SLOT_RING = 64, SLOT_CH = 2048;
-constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr unsigned SPIN_LIMIT = 1u << 25;     // ~1 us per probe: half a minute (a time-sliced device may stall a launch for seconds)
 
 __device__ __forceinline__ void publish(const Slots& s, int ch, float a, float b) {
   const unsigned long long t = (unsigned long long)s.token << 32;

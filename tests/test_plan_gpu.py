@@ -237,3 +237,26 @@ def test_planned_inference_is_bitwise_the_per_operator_inference(name, autocast)
                     p.mul_(1.01)
     finally:
         plan.ENABLED, plan.TALLY = saved
+
+
+def test_planned_step_with_every_shortcut_on_its_side_stream_is_bitwise():
+    """plan.BRANCH_ROWS = 1: the shortcut branch of EVERY residual block (1x1x1 convolution + BatchNorm, forward and
+    backward) on the third stream beside the main branch -- at the bench batch only the levels above 100 k rows go there.
+    BatchNorm launches of two streams then run at the same time, each with its own publication slots (bn.hip): loss,
+    logits and every gradient stay bitwise the per-operator path's."""
+    from lidal_amd.network import plan
+    torch.manual_seed(5)
+    a = _models()['spvcnn'](19).to(DEV).train()
+    b = copy.deepcopy(a)
+    batches = _batches(3, points=12000, frames=2)
+    saved = plan.BRANCH_ROWS
+    try:
+        plan.BRANCH_ROWS = 1
+        la, ya, ga, _, _ = _steps(a, batches, True, planned=False, steps_with_grads=(2,))
+        lb, yb, gb, _, cb = _steps(b, batches, True, planned=True, steps_with_grads=(2,))
+    finally:
+        plan.BRANCH_ROWS = saved
+    assert cb.get('plan_run', 0) >= 2
+    assert la == lb and torch.equal(ya, yb)
+    for k, p, q in zip([k for k, _ in a.named_parameters()], ga[2], gb[2]):
+        assert torch.equal(p, q), k

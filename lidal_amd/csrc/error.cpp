@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace lidal
 
 extern "C" const char* lidal_last_error(void) { return lidal::g_err; }
-extern "C" int lidal_version(void) { return 140; }   // 1.40 (round 4): launch plans (lidal_plan_run), row-wise helpers, conv offset split (_ws entry points), NN grid cell in the header; the first-generation convolution left the library
+extern "C" int lidal_version(void) { return 141; }   // 1.41 (round 4): launch plans (lidal_plan_run), row-wise helpers, conv offset split (_ws entry points), NN grid cell in the header, block-tail BatchNorm sums, BatchNorm merges inside their consumers; the first-generation convolution left the library

@@ -767,6 +767,26 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
     }
     __syncthreads();
   }
+  // ---- the first rows of this workgroup's slab are requested BEFORE the statistics are waited for: the merge's
+  //      latency (a strided read of the tiles, an 8-step LDS tree) hides behind them
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int cg = tid % cg_n, rl = tid / cg_n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
+  const T* rsrc = res != nullptr ? res : x;
+  int64_t r = r_beg + rl;
+  const bool first = rl < rpi && r + (UNR - 1) * rpi < r_end;
+  typename IO<T>::vec v0[UNR], vr0[UNR];
+  if (first) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      v0[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+    if (res != nullptr) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        vr0[u] = *reinterpret_cast<const typename IO<T>::vec*>(rsrc + (r + u * rpi) * c + cg * VEC);
+    }
+  }
   // ---- every channel's (mean, invstd), from whichever workgroup merged it
   for (int ch = tid; ch < c; ch += NT) {
     smu[ch] = fetch_one(slots, 2 * ch);
@@ -774,11 +794,7 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
   }
   __syncthreads();
   // ---- bn_apply_kernel<T, false>
-  const int cg_n = c / VEC, rpi = NT / cg_n;
-  const int cg = tid % cg_n, rl = tid / cg_n;
   if (rl >= rpi) return;
-  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
-  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
   float mu[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
@@ -802,8 +818,11 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
     }
     *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
   };
-  const T* rsrc = res != nullptr ? res : x;
-  int64_t r = r_beg + rl;
+  if (first) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) one(v0[u], res != nullptr ? vr0[u] : v0[u], r + u * rpi);
+    r += UNR * rpi;
+  }
   for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
     typename IO<T>::vec v[UNR], vr[UNR];
 #pragma unroll
@@ -886,17 +905,28 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict
     }
   }
   if (dx == nullptr) return;            // (only the parameter gradients were wanted)
+  // ---- the first rows are requested before the sums are waited for (as in bn_apply_tiles_kernel)
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int cg = tid % cg_n, rl = tid / cg_n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
+  int64_t r = r_beg + rl;
+  const bool first = rl < rpi && r + (UNR - 1) * rpi < r_end;
+  typename IO<T>::vec vx0[UNR], vd0[UNR];
+  if (first) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      vx0[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+      vd0[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * ldy + cg * VEC);
+    }
+  }
   for (int ch = tid; ch < c; ch += NT) {
     sk1[ch] = fetch_one(slots, 2 * ch);
     sk2[ch] = fetch_one(slots, 2 * ch + 1);
   }
   __syncthreads();
   // ---- bn_bwd_dx_kernel
-  const int cg_n = c / VEC, rpi = NT / cg_n;
-  const int cg = tid % cg_n, rl = tid / cg_n;
   if (rl >= rpi) return;
-  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
-  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
   const float inv_n = 1.f / (float)n;
   float mu[VEC], is[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
 #pragma unroll
@@ -918,7 +948,11 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict
     }
     *reinterpret_cast<typename IO<T>::vec*>(dx + r * c + cg * VEC) = IO<T>::pack(fd);
   };
-  int64_t r = r_beg + rl;
+  if (first) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) one(vx0[u], vd0[u], r + u * rpi);
+    r += UNR * rpi;
+  }
   for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
     typename IO<T>::vec vx[UNR], vd[UNR];
 #pragma unroll

@@ -739,10 +739,22 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
   // ---- the merge of bn_tiles_final_kernel, for this workgroup's channels
   for (int ch = blockIdx.x; ch < c; ch += gridDim.x) {
     double nn = 0., a = 0., b = 0.;
-    for (int p = tid; p < nparts; p += NT) {
-      const float* sp = part + ((int64_t)p * c + ch) * 3;
-      const double pn = (double)sp[0], pm = (double)sp[1];
-      nn += pn; a += pn * pm; b += (double)sp[2] + pn * pm * pm;
+    // (eight tiles' triples requested at once, summed in tile order: the sums of the one-at-a-time loop, with the
+    // loads of a batch in flight together -- the merge is on the layer's critical path)
+    for (int p0 = tid; p0 < nparts; p0 += 8 * NT) {
+      float t0[8], t1[8], t2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u * NT;
+        const float* sp = part + ((int64_t)(p < nparts ? p : p0) * c + ch) * 3;
+        t0[u] = sp[0]; t1[u] = sp[1]; t2[u] = sp[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + u * NT < nparts) {
+          const double pn = (double)t0[u], pm = (double)t1[u];
+          nn += pn; a += pn * pm; b += (double)t2[u] + pn * pm * pm;
+        }
     }
     sn[tid] = nn; s1[tid] = a; s2[tid] = b;
     for (int st = NT / 2; st >= 1; st >>= 1) {
@@ -863,9 +875,17 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict
     const float* pt = (const float*)part;
     for (int ch = blockIdx.x; ch < c; ch += gridDim.x) {
       double a = 0., b = 0.;
-      for (int p = tid; p < nparts; p += NT) {
-        const float* sp = pt + ((int64_t)p * c + ch) * 2;
-        a += (double)sp[0]; b += (double)sp[1];
+      for (int p0 = tid; p0 < nparts; p0 += 8 * NT) {       // (batched loads, sums in tile order: bn_apply_tiles_kernel)
+        float t0[8], t1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int p = p0 + u * NT;
+          const float* sp = pt + ((int64_t)(p < nparts ? p : p0) * c + ch) * 2;
+          t0[u] = sp[0]; t1[u] = sp[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (p0 + u * NT < nparts) { a += (double)t0[u]; b += (double)t1[u]; }
       }
       sa[tid] = a; sb[tid] = b;
       for (int st = NT / 2; st >= 1; st >>= 1) {

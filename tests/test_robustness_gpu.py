@@ -65,3 +65,28 @@ def test_cpu_binding_follows_the_gpu_topology():
     finally:
         for tid in os.listdir('/proc/self/task'):
             os.sched_setaffinity(int(tid), before)
+
+
+def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
+    """bench.py's contract with the driver: ONE JSON line on stdout (whatever libraries print there on their own goes to
+    stderr), carrying the metric, the roofline object and the extras.  A short run: 2 steps, no CPU baselines."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FORCE_DDP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', RANK='0', WORLD_SIZE='1',
+               LOCAL_RANK='0')              # (one rank over RCCL: its version banner must not reach stdout)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline', '--no-variants', '--no-families', '--no-secondary'],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['steps'] == 2 and d['n_gpus'] == 1 and d['value'] > 0 and d['config']['parallelism'] == 'dp1'
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic']

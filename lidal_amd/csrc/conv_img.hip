@@ -156,7 +156,12 @@ weight_image_batch_kernel(const ImageJob* __restrict__ jobs, int n_jobs, int64_t
 // rows per workgroup tile of every kernel of this file == rows per BatchNorm statistics triple
 constexpr int TILE_ROWS = 128;
 constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (16 waves / 256 rows measured slower)
-constexpr int LEAN_MINWAVES = 4;       // waves per SIMD the register budget must allow: 2 workgroups per CU
+#ifndef LIDAL_LEAN_MINWAVES
+#define LIDAL_LEAN_MINWAVES 4
+#endif
+// waves per SIMD the register budget must allow: 4 = 2 workgroups per CU (94 VGPRs).  6 (a third workgroup, 80 VGPRs)
+// spills 52 registers: the 96 -> 96 layer 90 -> 210 us, the 5-scan step 14.7 -> 19.5 ms (scripts/build_variant.py mw6)
+constexpr int LEAN_MINWAVES = LIDAL_LEAN_MINWAVES;
 constexpr int64_t DEEP_MAX_ROWS = 150000;      // up to this many output rows the deep form of the lean kernel runs
 
 // Optional second job of a DATA-GRADIENT launch: the tile's share of the backward sums of the BatchNorm

@@ -74,8 +74,13 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BENCH_FORCE_DDP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', RANK='0', WORLD_SIZE='1',
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, BENCH_FORCE_DDP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
                LOCAL_RANK='0')              # (one rank over RCCL: its version banner must not reach stdout)
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
                           '--no-cpu-baseline', '--no-variants', '--no-families', '--no-secondary'],

@@ -1114,6 +1114,8 @@ struct Epi { const float* scale; const float* shift; int relu; const void* res; 
 
 // Split policy (struct Split): only launches that leave the chip mostly idle -- at most SPLIT_MAX_WGS workgroups -- and
 // whose tiles have a long chain (a 27-offset map, or an 8-offset map over several reduction slices)
+// (measured with the coalesced partial tiles, 5-scan step: <= 256 workgroups 14.68 ms, <= 700 -- the 43 k-row level split
+// in two instead of the deep kernel -- 15.06, <= 1700 15.55; one scan 6.35 / 6.54 / 6.56)
 constexpr int64_t SPLIT_MAX_WGS = 256;
 __host__ inline int pick_split(int64_t wgs, int K, int npass) {
   if (wgs > SPLIT_MAX_WGS || K * npass < 27) return 1;

@@ -21,7 +21,20 @@ from .sharding import HaloExchange, gather_frames, is_sharded
 __all__ = ['score_sequence', 'collect_sequence', 'ScoreBoard']
 
 import os as _os
-_OVERLAP = _os.environ.get('LIDAL_SCORE_OVERLAP', '1') != '0'
+# Scoring beside the inference of the frames that follow (a third stream): 'auto' = only when the inference pass is NOT a
+# launch plan.  Measured on two boxes, same flow, frames/s at nei 10 / 24 (scripts/gpu/sec_ab.sh): planned inference +
+# overlap 122.3 / 124.4, planned without 132.4 / 125.7, per-operator inference + overlap 133.8 / 127.4, per-operator
+# without 129.9 / 123.1 (round 3: 126 / 117).  A plan keeps the main queue full, and kernels of two saturated queues slow
+# each other by more than they overlap (the 96->96 convolution 91 -> 155 us beside the table builders and the scorer);
+# the per-operator path leaves gaps between its launches that the scorer fills.
+_OVERLAP = _os.environ.get('LIDAL_SCORE_OVERLAP', 'auto')
+
+
+def _overlap_wanted(model):
+    if _OVERLAP in ('0', '1'):
+        return _OVERLAP == '1'
+    from ..network import plan
+    return not (plan.ENABLED and _backbone(model) is not None)
 
 
 class _Inference:
@@ -96,12 +109,14 @@ def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_th
     ranks read are inferred first and travel under the inference of the rest; 'allgather' -- every frame to every rank
     (one padded all_gather_into_tensor per array).  Same scores bit for bit.
     prefetch: build each frame's coordinate tables one frame ahead on a second stream (same tables).
-    overlap (one rank): a frame is scored as soon as the last frame of its window has been inferred, on a third stream
+    overlap (one rank; LIDAL_SCORE_OVERLAP, default: only when the inference is not a launch plan, see _OVERLAP): a frame
+    is scored as soon as the last frame of its window has been inferred, on a third stream
     BESIDE the inference of the frames that follow (the reference scores the frames of a sequence concurrently too,
     score/sv_level/LiDAL.py:204-206 `Pool(24)`); the scorer is library kernels only.  Same scores bit for bit."""
     n_class = _num_classes(model)
     dev = local_frames[0]['world'].device if local_frames else None
-    if overlap and _OVERLAP and not is_sharded(group) and local_frames and len(local_frames) == n_total and first_frame == 0:
+    if (overlap and _overlap_wanted(model) and not is_sharded(group) and local_frames and len(local_frames) == n_total
+            and first_frame == 0):
         return _score_overlapped(model, local_frames, n_total, nei_num, dis_thresh, inf_reps, autocast, prefetch)
     if exchange == 'allgather' or not is_sharded(group):
         probs, worlds = {}, {}

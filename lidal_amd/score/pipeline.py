@@ -21,20 +21,32 @@ from .sharding import HaloExchange, gather_frames, is_sharded
 __all__ = ['score_sequence', 'collect_sequence', 'ScoreBoard']
 
 import os as _os
-# Scoring beside the inference of the frames that follow (a third stream): 'auto' = only when the inference pass is NOT a
-# launch plan.  Measured on two boxes, same flow, frames/s at nei 10 / 24 (scripts/gpu/sec_ab.sh): planned inference +
-# overlap 122.3 / 124.4, planned without 132.4 / 125.7, per-operator inference + overlap 133.8 / 127.4, per-operator
-# without 129.9 / 123.1 (round 3: 126 / 117).  A plan keeps the main queue full, and kernels of two saturated queues slow
-# each other by more than they overlap (the 96->96 convolution 91 -> 155 us beside the table builders and the scorer);
-# the per-operator path leaves gaps between its launches that the scorer fills.
-_OVERLAP = _os.environ.get('LIDAL_SCORE_OVERLAP', 'auto')
+# Scoring beside the inference of the frames that follow: on WHICH stream decides whether it pays.  Measured on bound
+# processes, round 3's tree beside it, frames/s at nei 10 / 24 (scripts/gpu/sec_ab.sh, sec_ab2.sh; two boxes, 2-3
+# repetitions): round 3 125-129 / 117-120; planned inference, scoring AFTER it 131-133 / 126; planned inference, scoring
+# on a THIRD stream 122-124 / 124-125 (a plan keeps the inference queue full, and three saturated queues slow each other
+# by more than they overlap: the 96->96 convolution 91 -> 155 us); planned inference, scoring on the TABLE BUILDER's
+# stream (two queues: the scorer takes its turns with the next frame's tables) 135.6-137.5 / 127.2-127.7 -- shipped;
+# per-operator inference (launch gaps for the scorer to fill), third stream 133-136 / 127-129.
+# LIDAL_SCORE_OVERLAP=0: after the inference; LIDAL_SCORE_STREAM=tables|third: force the stream.
+_OVERLAP = _os.environ.get('LIDAL_SCORE_OVERLAP', '1')
+_STREAM = _os.environ.get('LIDAL_SCORE_STREAM', 'auto')
 
 
 def _overlap_wanted(model):
-    if _OVERLAP in ('0', '1'):
-        return _OVERLAP == '1'
+    return _OVERLAP != '0'
+
+
+def _score_stream(model, dev, prefetch):
+    from .. import backend as B
     from ..network import plan
-    return not (plan.ENABLED and _backbone(model) is not None)
+    which = _STREAM
+    if which == 'auto':
+        which = 'tables' if (prefetch and plan.ENABLED and _backbone(model) is not None) else 'third'
+    if which == 'tables':
+        from ..network.geometry import _state
+        return _state(dev)['stream']
+    return B.side_stream(dev, 3)
 
 
 class _Inference:
@@ -109,9 +121,9 @@ def score_sequence(model, local_frames, first_frame, n_total, nei_num=24, dis_th
     ranks read are inferred first and travel under the inference of the rest; 'allgather' -- every frame to every rank
     (one padded all_gather_into_tensor per array).  Same scores bit for bit.
     prefetch: build each frame's coordinate tables one frame ahead on a second stream (same tables).
-    overlap (one rank; LIDAL_SCORE_OVERLAP, default: only when the inference is not a launch plan, see _OVERLAP): a frame
-    is scored as soon as the last frame of its window has been inferred, on a third stream
-    BESIDE the inference of the frames that follow (the reference scores the frames of a sequence concurrently too,
+    overlap (one rank; LIDAL_SCORE_OVERLAP): a frame is scored as soon as the last frame of its window has been
+    inferred, BESIDE the inference of the frames that follow -- on the table builder's stream when the inference is a
+    launch plan, on a third stream otherwise (_score_stream) (the reference scores the frames of a sequence concurrently too,
     score/sv_level/LiDAL.py:204-206 `Pool(24)`); the scorer is library kernels only.  Same scores bit for bit."""
     n_class = _num_classes(model)
     dev = local_frames[0]['world'].device if local_frames else None
@@ -164,7 +176,7 @@ def _score_overlapped(model, frames, n_total, nei_num, dis_thresh, inf_reps, aut
     from .interframe import neighbour_ids
     dev = frames[0]['world'].device
     main = torch.cuda.current_stream(dev)
-    side = B.side_stream(dev, 3)
+    side = _score_stream(model, dev, prefetch)
     by_id = dict(enumerate(frames))
     infer = _Inference(model, by_id, list(by_id), inf_reps, autocast, prefetch)
     bank = FrameBank(dis_thresh, n_frames=n_total)

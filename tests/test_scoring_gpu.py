@@ -168,21 +168,22 @@ def test_score_sequence_pipeline_matches_oracle_end_to_end():
                                         torch.from_numpy(sb['coords_v_b']))
         probs_ref.append(harness_ref.inference_post(lo, torch.from_numpy(sb['inverse_indices_b']), 2)[0])
     out = score_sequence(model, dev_frames, 0, n_frames, nei_num=nei, dis_thresh=0.1, inf_reps=2)
-    # scoring beside the inference of the following frames (third stream; the default only when the inference is not a
-    # launch plan) and scoring after it: the same numbers bit for bit
+    # scoring beside the inference of the following frames (on the table builder's stream, on a third stream) and scoring
+    # after it: the same numbers bit for bit
     from lidal_amd.score import pipeline
-    saved = pipeline._OVERLAP
+    saved = pipeline._OVERLAP, pipeline._STREAM
     try:
-        both = []
-        for mode in ('1', '0'):
-            pipeline._OVERLAP = mode
-            both.append(score_sequence(model, dev_frames, 0, n_frames, nei_num=nei, dis_thresh=0.1, inf_reps=2))
+        runs = []
+        for mode, stream in (('1', 'tables'), ('1', 'third'), ('0', 'auto')):
+            pipeline._OVERLAP, pipeline._STREAM = mode, stream
+            runs.append(score_sequence(model, dev_frames, 0, n_frames, nei_num=nei, dis_thresh=0.1, inf_reps=2))
     finally:
-        pipeline._OVERLAP = saved
+        pipeline._OVERLAP, pipeline._STREAM = saved
     torch.cuda.synchronize()
-    for a, b, o in zip(both[0], both[1], out):
-        for u, v, w in zip(a, b, o):
-            assert torch.equal(u, v) and torch.equal(u, w)
+    for r in runs:
+        for a, o in zip(r, out):
+            for u, w in zip(a, o):
+                assert torch.equal(u, w)
     worlds = [f['world'] for f in frames]
     for i in range(n_frames):
         rd, re, rn, rc = scoring_ref.score_frame(i, probs_ref, worlds, frames[i]['sv2point'], nei, 0.1)

@@ -8,7 +8,11 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers unless the name ends in `_host`;
- *   - the caller owns every buffer (inputs, outputs, workspace); nothing is allocated here;
+ *   - the caller owns every buffer (inputs, outputs, workspace).  The library allocates device memory in exactly
+ *     ONE place: at the first fused BatchNorm launch on a device it takes 2 MiB of device memory (64 publication
+ *     buffers, two per stream: up to 32 streams per device) and 64 pinned host bytes (an error word), with one
+ *     hipDeviceSynchronize, and keeps them for the life of the process -- see lidal_bn_set_fused below;
+ *     LIDAL_BN_FUSED=0 in the environment (or lidal_bn_set_fused(0) before the first BatchNorm call) avoids it;
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and returns;
  *     counts that the host needs are written to device memory (`*_dev`) for the caller to read;
  *   - return value: 0 = OK, non-zero = error, message via lidal_last_error() (thread local);
@@ -383,11 +387,23 @@ int lidal_bn_bwd_from_sums(const void* x, const void* dy, int64_t dy_stride, int
                            const float* gamma, const float* beta, int relu, const float* save_mean,
                            const float* save_invstd, void* dx, float* grad_gamma, float* grad_beta,
                            const void* part, int64_t part_bytes, void* stream);
-/* test / A-B aid.  The merge steps of a BatchNorm layer (tile statistics -> mean / invstd; backward partial sums ->
- * parameter gradients) run INSIDE the launch that consumes them (the first workgroups merge and publish, all fetch;
+/* The merge steps of a BatchNorm layer (tile statistics -> mean / invstd; backward partial sums -> parameter
+ * gradients) run INSIDE the launch that consumes them (the first workgroups merge and publish, all workgroups fetch;
  * csrc/bn.hip) -- same arithmetic, same results bit for bit as the separate merge launches, which on = 0 brings back
- * (also: environment LIDAL_BN_FUSED=0).  The library keeps one 2 MiB ring of publication slots per device for this. */
+ * (also: environment LIDAL_BN_FUSED=0).
+ *   Memory: the publication buffers are the library's own (the one allocation named under "Conventions"): two per
+ *   STREAM, so a buffer is re-used only by a later launch of the same stream, i.e. after its last reader has finished
+ *   -- any number of host threads and up to 32 streams per device may run BatchNorm launches at the same time; a 33rd
+ *   stream silently takes the separate merge launches (same results).
+ *   Forward progress: the waiting workgroups rely on the merging ones -- the LOWEST workgroup ids of the launch --
+ *   having been dispatched before them (in-order workgroup dispatch, the assumption sort.hip's decoupled look-back
+ *   makes too).  A workgroup that waits longer than ~30 s gives up: it writes NaN to its channel AND raises a
+ *   per-device error word, and every later BatchNorm entry point and lidal_plan_run on that device fails with a message
+ *   naming the launch (lidal_bn_check_device) until lidal_bn_set_fused() is called again: never a silent NaN.
+ * lidal_bn_set_fused also acknowledges such an error. */
 int lidal_bn_set_fused(int on);
+/* 0, or 1 with lidal_last_error() set if a fused BatchNorm launch on the current device timed out (above). */
+int lidal_bn_check_device(void);
 /* eval-mode BatchNorm as a per-channel affine map (scale = gamma / sqrt(var + eps),
  * shift = beta - mean * scale), the operands of lidal_conv_apply's epilogue. */
 int lidal_bn_fold(const float* gamma, const float* beta, const float* running_mean,

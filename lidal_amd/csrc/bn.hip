@@ -617,7 +617,9 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(const float* __restrict__ 
 
 }  // namespace
 
+extern "C" int lidal_bn_check_device(void);
 static int bn_check(int64_t n, int c, int dtype) {
+  if (int rc = lidal_bn_check_device()) return rc;       // a fused launch of this device timed out earlier: not a silent NaN
   int vec = dtype == LIDAL_BF16 ? 8 : 4;
   LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16, "bn: bad dtype %d", dtype);
   LIDAL_REQUIRE(c > 0 && c % vec == 0 && c / vec <= NT, "bn: channels %d must be a multiple of %d and <= %d",
@@ -697,11 +699,16 @@ __global__ void __launch_bounds__(NT) bn_tiles_final_kernel(const float* __restr
 // (value | launch token << 32; agent-scope atomics, no fence needed: the token travels with the value); every
 // workgroup then fetches the words of all channels (spinning until the token matches) and streams its rows.  Forward
 // progress: the merging workgroups have the lowest ids of the launch and are dispatched first (the assumption the
-// radix sort's look-back makes, sort.hip); a fetch gives up after ~30 s and poisons its channel with NaN (a test
-// fails instead of a GPU hanging).  The slots live in a ring of buffers of this library (one per launch in flight,
-// 64 deep), the token is a process-wide counter.
-struct Slots { unsigned long long* v; unsigned token; };
-constexpr int SLOT_RING = 64, SLOT_CH = 2048;
+// radix sort's look-back makes, sort.hip).  The slots of a launch are one of TWO buffers that belong to the launch's
+// STREAM (a fixed pool of 64 buffers per device, 2 MiB, allocated by this library at the first fused launch: 32
+// streams per device; a 33rd stream, or a pool that cannot be allocated, takes the separate merge launches): launches
+// of one stream execute in order, so a buffer is never rewritten while an earlier launch still reads it, whatever
+// other streams or host threads do; the token is a process-wide counter, so a stale word never matches.  A fetch
+// gives up after ~30 s (a broken dispatch-order assumption must fail a test, not hang a GPU): it poisons its channel
+// with NaN AND raises the pool's error word (pinned host memory), which the next BatchNorm entry point or
+// lidal_plan_run on that device turns into an error return -- never a silent NaN.
+struct Slots { unsigned long long* v; unsigned token; unsigned* error; };
+constexpr int SLOT_RING = 64, SLOT_CH = 2048, SLOTS_PER_STREAM = 2;
 constexpr unsigned SPIN_LIMIT = 1u << 25;     // ~1 us per probe: half a minute (a time-sliced device may stall a launch for seconds)
 
 __device__ __forceinline__ void publish(const Slots& s, int ch, float a, float b) {
@@ -713,7 +720,10 @@ __device__ __forceinline__ float fetch_one(const Slots& s, int idx) {
   unsigned long long v = __hip_atomic_load(s.v + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned spins = 0;
   while ((unsigned)(v >> 32) != s.token) {
-    if (++spins > SPIN_LIMIT) return __uint_as_float(0x7fc00000u);
+    if (++spins > SPIN_LIMIT) {
+      __hip_atomic_store(s.error, s.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return __uint_as_float(0x7fc00000u);
+    }
     __builtin_amdgcn_s_sleep(2);
     v = __hip_atomic_load(s.v + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -988,14 +998,22 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict
         *reinterpret_cast<const typename IO<T>::vec*>(dy + r * ldy + cg * VEC), r);
 }
 
-// ---- host side of the slots: one ring of buffers per device, one token per launch
+// ---- host side of the slots: a pool of buffers per device, two per stream, one token per launch
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 namespace {
 std::atomic<unsigned> g_token{1};
 std::atomic<int> g_fused{-1};           // -1: not read yet (LIDAL_BN_FUSED, default on)
-unsigned long long* g_ring[MAX_DEVICES] = {};
-std::mutex g_ring_mutex;
+struct SlotPool {
+  unsigned long long* base = nullptr;   // SLOT_RING buffers of 2 * SLOT_CH words
+  unsigned* error_host = nullptr;       // pinned, read by the host without a synchronisation
+  unsigned* error_dev = nullptr;        // the same word as the device addresses it
+  bool failed = false;                  // the pool could not be allocated: separate launches from now on
+  std::unordered_map<hipStream_t, unsigned> streams;   // stream -> (index of its first buffer) << 1 | next buffer
+};
+SlotPool g_pool[MAX_DEVICES];
+std::mutex g_pool_mutex;
 
 bool bn_fused() {
   int f = g_fused.load();
@@ -1007,29 +1025,66 @@ bool bn_fused() {
   return f != 0;
 }
 
-// the slots of the next launch on the current device (nullptr: the ring could not be allocated -- separate launches)
-bool next_slots(Slots* out) {
+// the slots of the next launch on stream `s` of the current device (false: no pool, or more than SLOT_RING /
+// SLOTS_PER_STREAM streams on this device -- the caller launches merge and consumer apart)
+bool next_slots(Slots* out, hipStream_t s) {
   const int d = current_device();
-  if (g_ring[d] == nullptr) {
-    std::lock_guard<std::mutex> lock(g_ring_mutex);
-    if (g_ring[d] == nullptr) {
-      void* p = nullptr;
-      const size_t bytes = (size_t)SLOT_RING * 2 * SLOT_CH * sizeof(unsigned long long);
-      if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
-        return false;
-      g_ring[d] = (unsigned long long*)p;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  SlotPool& pool = g_pool[d];
+  if (pool.failed) return false;
+  if (pool.base == nullptr) {
+    void *p = nullptr, *h = nullptr, *hd = nullptr;
+    const size_t bytes = (size_t)SLOT_RING * 2 * SLOT_CH * sizeof(unsigned long long);
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess ||
+        hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
+        hipHostGetDevicePointer(&hd, h, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      pool.failed = true;
+      return false;
     }
+    *(volatile unsigned*)h = 0;
+    pool.base = (unsigned long long*)p;
+    pool.error_host = (unsigned*)h;
+    pool.error_dev = (unsigned*)hd;
   }
+  auto it = pool.streams.find(s);
+  if (it == pool.streams.end()) {
+    if (pool.streams.size() >= (size_t)(SLOT_RING / SLOTS_PER_STREAM)) return false;
+    it = pool.streams.emplace(s, (unsigned)(pool.streams.size() * SLOTS_PER_STREAM) << 1).first;
+  }
+  const unsigned first = it->second >> 1, turn = it->second & 1;
+  it->second ^= 1;
   unsigned t = g_token.fetch_add(1);
-  if (t == 0) t = g_token.fetch_add(1);          // (0 is what the ring was cleared to)
+  if (t == 0) t = g_token.fetch_add(1);          // (0 is what the pool was cleared to)
   out->token = t;
-  out->v = g_ring[d] + (size_t)(t % SLOT_RING) * 2 * SLOT_CH;
+  out->v = pool.base + (size_t)(first + turn) * 2 * SLOT_CH;
+  out->error = pool.error_dev;
   return true;
 }
 }  // namespace
 
+// 0, or 1 with lidal_last_error() set: a fused BatchNorm launch on the current device gave up waiting for its merged
+// values (see `Slots`).  Sticky until lidal_bn_set_fused() is called; checked by every BatchNorm entry point that can
+// take the fused form and by lidal_plan_run.
+extern "C" int lidal_bn_check_device(void) {
+  const int d = current_device();
+  const unsigned* e = g_pool[d].error_host;
+  if (e == nullptr) return 0;
+  const unsigned t = *(const volatile unsigned*)e;
+  if (t == 0) return 0;
+  set_error("BatchNorm: the launch with token %u timed out waiting for the values its first workgroups merge (in-order "
+            "workgroup dispatch did not hold, or the device was stalled for ~30 s); its outputs hold NaN.  "
+            "lidal_bn_set_fused(0) / LIDAL_BN_FUSED=0 selects the separate merge launches", t);
+  return 1;
+}
+
 // test / A-B aid: 1 = merge kernels inside their consumers (default), 0 = separate launches
-extern "C" int lidal_bn_set_fused(int on) { g_fused.store(on ? 1 : 0); return 0; }
+extern "C" int lidal_bn_set_fused(int on) {
+  g_fused.store(on ? 1 : 0);
+  for (int d = 0; d < MAX_DEVICES; ++d)          // (also acknowledges a reported time-out)
+    if (g_pool[d].error_host != nullptr) *(volatile unsigned*)g_pool[d].error_host = 0;
+  return 0;
+}
 
 namespace {
 // the merge of the backward sums and the dx pass as one launch; false: not taken (the caller launches them apart)
@@ -1038,7 +1093,7 @@ bool bn_bwd_merge_dx(const void* x, const void* dy, int64_t ldy, int64_t n, int 
                      int relu, const float* mean, const float* invstd, void* dx, float* ggamma, float* gbeta,
                      const void* part, int nparts, hipStream_t s) {
   Slots slots;
-  if (dx == nullptr || !bn_fused() || c > SLOT_CH || !next_slots(&slots)) return false;
+  if (dx == nullptr || !bn_fused() || c > SLOT_CH || !next_slots(&slots, s)) return false;
   bn_bwd_dx_merge_kernel<T, TILES><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>(
       (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, nparts, gbeta, ggamma, (T*)dx,
       rows_per_wg_ew(n, (int64_t)c * sizeof(T)), ldy, slots);
@@ -1059,7 +1114,7 @@ extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int
   LIDAL_REQUIRE(n > 0 && n_tiles > 0 && tile_stats != nullptr, "bn_train_fwd_tiles: needs rows and tile statistics");
   hipStream_t s = (hipStream_t)stream;
   Slots slots;
-  if (bn_fused() && c <= SLOT_CH && next_slots(&slots)) {
+  if (bn_fused() && c <= SLOT_CH && next_slots(&slots, s)) {
     if (dtype == LIDAL_F32)
       bn_apply_tiles_kernel<float><<<nslabs_ew(n, (int64_t)c * 4), NT, 0, s>>>(
           (const float*)x, n, c, tile_stats, (int)n_tiles, eps, momentum, save_mean, save_invstd, running_mean, running_var,

@@ -17,6 +17,7 @@
 // channel concatenation / padding / slicing, strided sum of two gradients, f32 transposition, f32 -> bf16
 // row cast with channel padding).
 #include <string.h>
+#include <mutex>
 
 #include "common.h"
 
@@ -240,20 +241,27 @@ inline double as_double(int64_t w) {
   return d;
 }
 
-// one pair of events per device and side stream for fork / join (created on first use, never timed)
+// one pair of events per device and side stream for fork / join (created on first use, never timed).  An edge is
+// "record on A, then make B wait for that record": the wait captures the record it follows, so the same event serves
+// every later edge -- but two host threads running plans on one device must not interleave their record / wait
+// pairs, hence one mutex per device around each pair (and around the creation).
 constexpr int MAX_SIDE = 8;
 hipEvent_t g_fork_ev[MAX_DEVICES][MAX_SIDE], g_join_ev[MAX_DEVICES][MAX_SIDE];
 bool g_ev_ready[MAX_DEVICES][MAX_SIDE];
+std::mutex g_ev_mutex[MAX_DEVICES];
 
-int side_events(int idx, hipEvent_t** fork_ev, hipEvent_t** join_ev) {
+// `to` waits for everything queued on `from` so far (join = false: the fork event of side stream idx, true: its join event)
+int stream_edge(int idx, bool join, hipStream_t from, hipStream_t to) {
   const int d = current_device();
+  std::lock_guard<std::mutex> lock(g_ev_mutex[d]);
   if (!g_ev_ready[d][idx]) {
     LIDAL_HIP(hipEventCreateWithFlags(&g_fork_ev[d][idx], hipEventDisableTiming));
     LIDAL_HIP(hipEventCreateWithFlags(&g_join_ev[d][idx], hipEventDisableTiming));
     g_ev_ready[d][idx] = true;
   }
-  *fork_ev = &g_fork_ev[d][idx];
-  *join_ev = &g_join_ev[d][idx];
+  hipEvent_t ev = join ? g_join_ev[d][idx] : g_fork_ev[d][idx];
+  LIDAL_HIP(hipEventRecord(ev, from));
+  LIDAL_HIP(hipStreamWaitEvent(to, ev, 0));
   return 0;
 }
 
@@ -266,9 +274,31 @@ extern "C" int lidal_plan_run(const int64_t* words, int64_t n_words, int64_t n_o
   return lidal_plan_run_streams(words, n_words, n_ops, streams, side_stream != nullptr ? 2 : 1);
 }
 
+namespace {
+int run_ops(const int64_t* words, int64_t n_words, int64_t n_ops, void* const* streams, int n_streams, bool* side_open);
+}
+
 extern "C" int lidal_plan_run_streams(const int64_t* words, int64_t n_words, int64_t n_ops, void* const* streams,
                                       int n_streams) {
   LIDAL_REQUIRE(streams != nullptr && n_streams >= 1 && n_streams <= MAX_SIDE, "plan_run: 1..%d streams", MAX_SIDE);
+  if (int rc = lidal_bn_check_device()) return rc;         // (bn.hip: a fused BatchNorm launch timed out earlier)
+  bool side_open[MAX_SIDE] = {};
+  const int rc = run_ops(words, n_words, n_ops, streams, n_streams, side_open);
+  if (rc != 0) {
+    // a plan that fails half way must not leave a side stream forked: the caller unwinds and hands the plan's arena
+    // and scratch back to its allocator, whose re-use is ordered by the MAIN stream only -- so the main stream waits
+    // for whatever the open side streams were given before the error (the error message stays the first one's)
+    char msg[400];
+    snprintf(msg, sizeof(msg), "%s", lidal_last_error());
+    for (int i = 1; i < n_streams; ++i)
+      if (side_open[i] && streams[i] != nullptr) stream_edge(i, true, (hipStream_t)streams[i], (hipStream_t)streams[0]);
+    set_error("%s", msg);
+  }
+  return rc;
+}
+
+namespace {
+int run_ops(const int64_t* words, int64_t n_words, int64_t n_ops, void* const* streams, int n_streams, bool* side_open) {
   void* const stream = streams[0];
 #define P(i) ((void*)(uintptr_t)a[i])
 #define CP(T, i) ((const T*)(uintptr_t)a[i])
@@ -277,7 +307,6 @@ extern "C" int lidal_plan_run_streams(const int64_t* words, int64_t n_words, int
 #define L(i) ((int64_t)a[i])
 #define F(i) ((float)as_double(a[i]))
   int64_t pos = 0;
-  bool side_open[MAX_SIDE] = {};
   for (int64_t op = 0; op < n_ops; ++op) {
     LIDAL_REQUIRE(pos < n_words, "plan_run: op %lld starts past the end of the stream (%lld words)", (long long)op,
                   (long long)n_words);
@@ -409,10 +438,7 @@ extern "C" int lidal_plan_run_streams(const int64_t* words, int64_t n_words, int
         const int i = sidx ? sidx : 1;
         LIDAL_REQUIRE(i < n_streams && streams[i] != nullptr, "plan_run: op %lld forks to side stream %d, which was not "
                       "given", (long long)op, i);
-        hipEvent_t *fe, *je;
-        if (side_events(i, &fe, &je)) return 1;
-        LIDAL_HIP(hipEventRecord(*fe, (hipStream_t)stream));
-        LIDAL_HIP(hipStreamWaitEvent((hipStream_t)streams[i], *fe, 0));
+        if (stream_edge(i, false, (hipStream_t)stream, (hipStream_t)streams[i])) return 1;
         side_open[i] = true;
         break;
       }
@@ -420,10 +446,7 @@ extern "C" int lidal_plan_run_streams(const int64_t* words, int64_t n_words, int
         const int i = sidx ? sidx : 1;
         LIDAL_REQUIRE(i < n_streams && streams[i] != nullptr, "plan_run: op %lld joins side stream %d, which was not "
                       "given", (long long)op, i);
-        hipEvent_t *fe, *je;
-        if (side_events(i, &fe, &je)) return 1;
-        LIDAL_HIP(hipEventRecord(*je, (hipStream_t)streams[i]));
-        LIDAL_HIP(hipStreamWaitEvent((hipStream_t)stream, *je, 0));
+        if (stream_edge(i, true, (hipStream_t)streams[i], (hipStream_t)stream)) return 1;
         side_open[i] = false;
         break;
       }
@@ -448,3 +471,4 @@ extern "C" int lidal_plan_run_streams(const int64_t* words, int64_t n_words, int
 #undef L
 #undef F
 }
+}  // namespace

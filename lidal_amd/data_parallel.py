@@ -48,6 +48,20 @@ class DataParallel(torch.nn.Module):
         self._params = [p for p in module.parameters() if p.requires_grad]
         self.reductions = 0             # backward passes reduced
         self.flat_reductions = 0        # ... of which in place on one flat buffer
+        # The two forms of the reduction must put the SAME number of elements in the SAME order on the wire, because
+        # each rank picks its form locally (a rank whose step was not plannable -- a batch of <= 1 rows, plan.ENABLED
+        # off, a pre-existing .grad -- reduces through a copy while the others reduce in place).  So for this package's
+        # networks the copy is laid out exactly like the planned step's flat buffer (network/plan.py: slot offsets,
+        # 16-byte gaps, classifier bias last): compiled here, on every rank alike, whether or not plans are enabled.
+        self._prog = None
+        try:
+            from .network import plan as _plan
+            prog = _plan._program(module, module.training)
+            if prog is not None and len(prog.params) == len(self._params) and \
+                    all(a is b for a, b in zip(sorted(prog.params, key=id), sorted(self._params, key=id))):
+                self._prog = prog
+        except Exception:               # noqa: BLE001  (any other module: parameters() order on every rank)
+            self._prog = None
         if broadcast:
             self._broadcast_state()
         n = len(self._params)
@@ -131,6 +145,17 @@ class DataParallel(torch.nn.Module):
             self.flat_reductions += 1
             flat.mul_(1.0 / self.world)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        prog = self._prog
+        if prog is not None and len(grads) == len(prog.params) and all(p.grad is not None for p in prog.params):
+            # the planned step's layout, through a copy: what the in-place form of the other ranks sends
+            buf = torch.zeros(prog.flat_numel, dtype=torch.float32, device=grads[0].device)
+            views = [buf[prog.slot[i]:prog.slot[i] + p.numel()].view_as(p) for i, p in enumerate(prog.params)]
+            gs = [p.grad for p in prog.params]
+            torch._foreach_copy_(views, gs)
+            buf.mul_(1.0 / self.world)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            torch._foreach_copy_(gs, views)
             return
         by_type = {}
         for g in grads:

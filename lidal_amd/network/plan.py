@@ -308,8 +308,13 @@ class _Program:
                 self.points.append((lin(seq[0], True), bn(seq[1], True)))
             self.dropout = model.dropout
         assert self.used == set(range(len(self.params))), 'a parameter of the model is not part of the plan'
-        # where each parameter's gradient lives in the flat f32 buffer (whole 16-byte vectors; the odd-sized ones last)
-        order = sorted(range(len(self.params)), key=lambda i: (self.params[i].numel() % 4 != 0, i))
+        # where each parameter's gradient lives in the flat f32 buffer (whole 16-byte vectors; the odd-sized ones last,
+        # and the classifier's bias ALWAYS the very last: its column sum is taken over the padded logits' columns and
+        # writes up to 7 floats past its slot -- into the buffer's tail padding, never into another gradient, whatever
+        # the class count is (19: odd-sized anyway; 12 / 20 / 28 under bf16: multiples of 4 but not of 8))
+        cls_b = self.classifier.b
+        order = sorted(range(len(self.params)), key=lambda i: (i == cls_b, self.params[i].numel() % 4 != 0, i))
+        assert order[-1] == cls_b
         self.slot = [0] * len(self.params)
         off = 0
         self.flat_order = order
@@ -577,7 +582,7 @@ class _Run:
         prog, T = self.prog, self.T
         bank = _C._IMAGE_BANK
         code, dtype = self.code, self.dtype
-        first = None
+        stale = None
         for c, (nf, nb) in self._conv_rows():
             key = (_C._tiling(c.ci, c.co, code, nf), _C._tiling(c.co, c.ci, code, nb), code)
             e = c.tkey.get(key) if c.tkey else None
@@ -593,13 +598,14 @@ class _Run:
                 p = c.ptrs[key] = (e['img_f'].data_ptr(), e['img_b'].data_ptr())
             c.img_f, c.img_b = p
             e['used'] = bank.tick
-            if first is None:
-                first = (e, c.param)
+            # staleness is decided weight by weight, as bank.get does on the per-operator path: a load_state_dict
+            # (strict=False) or a copy_ into ONE layer between two forward passes moves that layer's version only
+            if stale is None and e['version'] != B.weights_key(c.param):
+                stale = e['group']
         # one launch rebuilds every stale image of the group (bank.get does it when it meets a stale entry; when no
         # layer needed registering, ask for it here)
-        e, w = first
-        if e['version'] != B.weights_key(w):
-            bank._rebuild(e['group'])
+        if stale is not None:
+            bank._rebuild(stale)
 
     def _conv_rows(self):
         """(layer, (rows its forward produces, rows its data gradient produces)) for every weight of the program."""
@@ -788,13 +794,12 @@ class _Run:
 
     def f_classifier(self, x, n):
         lin = self.prog.classifier
-        co_pad = lin.co + (-lin.co) % self.vec
-        lin.co_pad = co_pad
+        co_pad = lin.co + (-lin.co) % self.vec         # (kept with the RUN: a bf16 and an f32 pass may both be live)
         # shift = the bias padded with zeros (dense.py _forward); the padding columns of the persistent buffer stay zero
         self.w += (OP_COPY2D, self.ptr[lin.b], lin.co * 4, self.cls_shift, co_pad * 4, 1, lin.co * 4, 0)
         self.nops += 1
         out, _ = self.f_dense(lin.conv, x, n, co_pad, self.cls_shift, False)
-        self.saved['cls'] = (x, n)
+        self.saved['cls'] = (x, n, co_pad)
         return out, co_pad
 
     def f_dropout(self, addr, n, c):
@@ -1081,8 +1086,7 @@ class _Run:
         assert self.flat % 16 == 0
         # ---- classifier
         lin = prog.classifier
-        x, rows = self.saved['cls']
-        co_pad = lin.co_pad
+        x, rows, co_pad = self.saved['cls']
         g = g_logits
         if g.dtype != self.dtype or not g.is_contiguous():
             g = g.contiguous().to(self.dtype)

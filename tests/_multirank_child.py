@@ -38,7 +38,7 @@ def main():
             np.savez(os.path.join(out_dir, '%s_2rank.npz' % mode),
                      **{'%s_%d' % (k, f): v for f, t in enumerate(got)
                         for k, v in zip(('id', 'd', 'e', 'n', 'c'), t)})
-    elif mode in ('ddp', 'dp', 'dp_per_operator'):
+    elif mode in ('ddp', 'dp', 'dp_per_operator', 'dp_mixed'):
         from lidal_amd.data_parallel import DataParallel
         from lidal_amd.network import plan
         from lidal_amd.train_step import forward_backward
@@ -52,14 +52,15 @@ def main():
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
         else:
             net = DataParallel(model)
-            plan.ENABLED = mode == 'dp'
+            # 'dp_mixed': rank 0 plans (in-place reduction of the flat buffer), rank 1 does not (reduction through a copy)
+            plan.ENABLED = mode == 'dp' or (mode == 'dp_mixed' and rank == 0)
         b = mc.make_half_batches()[rank]
         net.zero_grad()
         loss, _ = forward_backward(net, b['feats'].to(dev), b['coords'].to(dev), b['labels'].to(dev))
         torch.cuda.synchronize()
         if mode != 'ddp':
             # the planned step's gradients are reduced in place as one tensor; the per-operator path's through a copy
-            assert net.reductions == 1 and net.flat_reductions == (1 if mode == 'dp' else 0), (net.reductions, net.flat_reductions)
+            assert net.reductions == 1 and net.flat_reductions == (1 if plan.ENABLED else 0), (net.reductions, net.flat_reductions)
         if rank == 0:
             named = dict(model.named_parameters())
             np.savez(os.path.join(out_dir, '%s_2rank.npz' % mode), loss=loss.item(),

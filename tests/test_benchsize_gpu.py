@@ -362,3 +362,52 @@ def test_scoring_at_120k_points_matches_oracle(nei, n_frames, queries):
         assert np.allclose(c.cpu().numpy(), rc, rtol=1e-5, atol=1e-5)
         assert np.array_equal(lens, rn)
     assert matched > 50000, matched
+
+
+def test_bf16_inference_against_f32_inference_on_scores_and_selection(capsys):
+    """What bf16 conv operands at inference do to the OUTPUT of the scoring pipeline (the reference infers in fp32,
+    score/prob_inference.py:91-113; bench.py's `secondary.value` is the f32 figure, the bf16 one rides beside it):
+    13 frames of ~120 k points, 8 views each, SPVCNN, window 10.  Printed and bounded: the largest deviation of
+    sv_interds / sv_interes relative to the largest score, Spearman's rank correlation of the divergences (the selection
+    is rank-based, LiDAL.py:233-235) and the fraction of supervoxels to which select() gives the same flag."""
+    from scipy.stats import spearmanr
+    from lidal_amd import synth
+    from lidal_amd.network import SPVCNN
+    from lidal_amd.score import collect_sequence, interframe, score_sequence
+    from lidal_amd.score.selection import select
+    n_frames, nei = 13, 10
+    frames = synth.make_sequence(n_frames, n_points=120000, seed=7122)
+    dev_frames = []
+    for i, f in enumerate(frames):
+        sb = synth.make_score_batch(f['points'], f['intensity'], np.random.default_rng([7122, 99, 0, i]), inf_reps=8)
+        ptr, idx, _ = interframe.sv_csr(f['sv2point'], DEV)
+        dev_frames.append({'coords': torch.from_numpy(sb['coords_v_b']).to(DEV), 'feats': torch.from_numpy(sb['feats_v_b']).to(DEV),
+                           'inverse': torch.from_numpy(sb['inverse_indices_b']).to(DEV),
+                           'world': torch.from_numpy(f['world']).to(DEV), 'sv_ptr': ptr, 'sv_idx': idx})
+    torch.manual_seed(7122)
+    model = SPVCNN(19).to(DEV).eval()
+    got = {}
+    for name, autocast in (('f32', False), ('bf16', True)):
+        scores = score_sequence(model, dev_frames, 0, n_frames, nei_num=nei, dis_thresh=0.1, inf_reps=8, autocast=autocast)
+        rows = collect_sequence(scores, [f['sv_id'] for f in frames], [d['sv_ptr'] for d in dev_frames], 0, n_frames)
+        got[name] = {k: np.concatenate([r[j] for r in rows]) for j, k in enumerate(('id', 'd', 'e', 'n', 'c'))}
+    a, b = got['f32'], got['bf16']
+    assert np.array_equal(a['id'], b['id']) and np.array_equal(a['n'], b['n']) and np.array_equal(a['c'], b['c'])
+    dev_d = np.abs(a['d'] - b['d']).max() / np.abs(a['d']).max()
+    dev_e = np.abs(a['e'] - b['e']).max() / np.abs(a['e']).max()
+    rho_d = spearmanr(a['d'], b['d'])[0]
+    rho_e = spearmanr(a['e'], b['e'])[0]
+    n_sv = a['id'].shape[0]
+    flags0 = np.zeros(n_sv, dtype=int)
+    budget = int(a['n'].sum())                  # 1 % of it per pass: a few supervoxels each
+    fa = select(flags0, a['d'], a['e'], a['n'], a['c'], 30 * budget)
+    fb = select(flags0, b['d'], b['e'], b['n'], b['c'], 30 * budget)
+    agree = float((fa == fb).mean())
+    with capsys.disabled():
+        print('\n[bf16 vs f32 inference, %d supervoxels] max |d sv_interds| / max = %.3e, max |d sv_interes| / max = %.3e, '
+              'Spearman rho (divergence) = %.5f, (entropy) = %.5f, select() flags equal on %.1f %% (%d AL / %d SL picks under f32)'
+              % (n_sv, dev_d, dev_e, rho_d, rho_e, 100 * agree, int((fa == 1).sum()), int((fa == 2).sum())))
+    assert (fa == 1).sum() >= 3 and (fa == 2).sum() >= 3
+    assert dev_e < 0.02 and rho_e > 0.99, (dev_e, rho_e)
+    assert dev_d < 0.25 and rho_d > 0.9, (dev_d, rho_d)
+    assert agree >= 0.8, agree

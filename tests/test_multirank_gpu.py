@@ -93,11 +93,12 @@ def test_two_rank_scoring_of_a_16_class_model(tmp_path):
             assert np.array_equal(two['%s_%d' % (k, f)], v), (k, f)
 
 
-@pytest.mark.parametrize('mode', ['ddp', 'dp', 'dp_per_operator'])
+@pytest.mark.parametrize('mode', ['ddp', 'dp', 'dp_per_operator', 'dp_mixed'])
 def test_two_rank_ddp_gradient_is_the_mean_of_the_rank_gradients(tmp_path, mode):
     """'ddp': torch's DistributedDataParallel as train.py:49-53 wraps the model; 'dp': lidal_amd.data_parallel.DataParallel
     (one collective per backward pass on the planned step's flat gradient buffer); 'dp_per_operator': the same wrapper
-    over the per-operator path (gradients reduced through a flattened copy)."""
+    over the per-operator path (gradients reduced through a flattened copy); 'dp_mixed': rank 0 planned, rank 1 not -- the
+    two forms of the reduction meet in ONE collective and must agree on its length and order."""
     import multirank_common as mc
     from lidal_amd.train_step import forward_backward
     dev = torch.device('cuda', 0)

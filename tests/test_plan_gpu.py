@@ -260,3 +260,40 @@ def test_planned_step_with_every_shortcut_on_its_side_stream_is_bitwise():
     assert la == lb and torch.equal(ya, yb)
     for k, p, q in zip([k for k, _ in a.named_parameters()], ga[2], gb[2]):
         assert torch.equal(p, q), k
+
+
+@pytest.mark.parametrize('train', [False, True])
+def test_planned_forward_follows_a_change_of_one_weight_only(train):
+    """A partial load_state_dict / a copy_ into ONE layer between two forward passes with no backward pass in between
+    moves that layer's version counter only: the plan has to notice it weight by weight (the per-operator path's
+    _ImageBank.get does), not on the first convolution alone -- stale LDS images would give wrong logits silently."""
+    from lidal_amd import SparseTensor
+    from lidal_amd.network import plan
+    torch.manual_seed(6)
+    model = _models()['spvcnn'](19).to(DEV)
+    model.train(train)
+    feats, coords, _ = _batches(1)[0]
+    targets = ['stage3.1.net.3.kernel', 'up2.0.net.0.kernel', 'classifier.0.weight', 'point_transforms.1.0.weight']
+    params = dict(model.named_parameters())
+    assert all(t in params for t in targets), [k for k in params][:400]
+
+    def forward(planned):
+        saved = plan.ENABLED
+        plan.ENABLED = planned
+        try:
+            torch.manual_seed(3)                # SPVCNN's dropout masks
+            with torch.no_grad() if not train else torch.enable_grad():
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    out = model(SparseTensor(feats, coords))
+            return (out[0] if isinstance(out, tuple) else out).detach().float().clone()
+        finally:
+            plan.ENABLED = saved
+    first = forward(True)
+    for t in targets:
+        with torch.no_grad():
+            params[t].mul_(1.5)
+        got = forward(True)
+        want = forward(False)
+        assert not torch.equal(got, first), t
+        assert torch.equal(got, want), t
+        first = got

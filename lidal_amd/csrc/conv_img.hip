@@ -163,6 +163,17 @@ constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (1
 // spills 52 registers: the 96 -> 96 layer 90 -> 210 us, the 5-scan step 14.7 -> 19.5 ms (scripts/build_variant.py mw6)
 constexpr int LEAN_MINWAVES = LIDAL_LEAN_MINWAVES;
 constexpr int64_t DEEP_MAX_ROWS = 150000;      // up to this many output rows the deep form of the lean kernel runs
+// Round 5: the lean kernel keeps the neighbour indices of its tile in LDS.  The phase stamps (profiles/
+// r05_phase_stamps.json) showed where a phase's 1.1-1.4 us went: 45 % in the issue segment, i.e. in the wait for
+// index(p+1) -- a 64-byte read of a table row nobody else touches (HBM / Infinity Cache, 1-1.9 us under load) issued
+// ONE phase earlier -- and, because vector-memory operations retire in order, the wait for slab(p+1) at the end of a
+// phase also waited for index(p+2), issued at the phase's start: a phase could never be shorter than one such miss.
+// Now the prologue loads the indices of ALL active offsets of the tile at once (one latency per tile, up to seven
+// independent loads per wave) into a wave-private LDS strip, and a phase reads its index with ds_read_b32.
+#ifndef LIDAL_LEAN_LDS_IDX
+#define LIDAL_LEAN_LDS_IDX 1
+#endif
+constexpr int LEAN_IDX_K = MAXK;               // offsets whose indices the strip can hold; the launch sizes it for its K
 
 // Optional second job of a DATA-GRADIENT launch: the tile's share of the backward sums of the BatchNorm
 // whose output gradient this launch produces (out = dy of y = act(bn(x))): per column sum(dy') and
@@ -652,6 +663,18 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
 // gathers with the four lanes of a quad on the 64 contiguous bytes of a row step and a ds_bpermute
 // into the MFMA lane layout (the addresser merges a quad into one request: the loads alone got
 // 8-18 % cheaper in a timing probe, but the twelve bpermutes per phase cost more: 99 vs 94 us).
+// ---- instrument (scripts/build_variant.py ... -DLIDAL_PHASE_STAMPS; never in the product library): where a phase of
+// the lean kernel spends its time.  Every wave reads the shader clock (s_memtime) at six points of every phase --
+//   T0 phase start | index(p+2), slab(p+1) DMA, A(p+1) gathers issued (includes the wait for index(p+1)) T1 |
+//   A(p) landed T2 | fragment reads + MFMAs issued T3 | slab(p+1) landed T4 | barrier passed T5
+// -- keeps the five interval sums in scalar registers and leaves, per (workgroup, wave), 12 words:
+//   phases, whole kernel (clock), prologue, sum issue, sum wait-A, sum compute, sum slab wait, sum barrier, epilogue,
+//   whole kernel (s_memrealtime, 100 MHz), 0, 0.   scripts/exp/phase_stamps.py prints the histogram.
+#ifdef LIDAL_PHASE_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define LIDAL_NOW() __builtin_readcyclecounter()
+#endif
+
 template <typename T, int NB, int ROW_BYTES, int NWAVES, bool DENSE>
 __global__ void __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? LEAN_MINWAVES : 4))
 conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int* __restrict__ nbr,
@@ -740,14 +763,47 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
 
   // the walk over (active offset, slice): one scalar state, advanced once per phase
   unsigned rem = tmask;
-  int wk = 0, wpass = npass - 1;
+  int wk = 0, wpass = npass - 1, wj = -1;           // wj: rank of offset wk among the tile's active offsets
   auto advance = [&]() {
     if (++wpass == npass) {
       wpass = 0;
       wk = rem ? __builtin_ctz(rem) : 0;            // past the end: offset 0 (a harmless index load)
       rem &= rem - 1u;
+      ++wj;
     }
   };
+#if LIDAL_LEAN_LDS_IDX
+  // the indices of every active offset of this wave's 16 rows -> its strip of LDS (behind the dump): lane group s of
+  // the wave takes the offsets of rank s, s + 4, ...; all loads are issued before the first is awaited.  Rows past the
+  // end and ranks past the last active offset store -1.  Wave-private: no barrier, the strip is read by its writer.
+  int* const idx_strip = reinterpret_cast<int*>(dump + 4096) + wave * 16 + row16;
+  if constexpr (!DENSE) {
+    constexpr int STEPS = (LEAN_IDX_K + 3) / 4;
+    unsigned mine = tmask;
+    for (int t = 0; t < gsel; ++t) mine &= mine - 1u;           // drop the gsel lowest set bits
+    int got[STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const bool ok = mine != 0u && row_in;
+      const unsigned k = mine ? (unsigned)__builtin_ctz(mine) : 0u;
+      const unsigned kk = kflip ? (unsigned)(K - 1) - k : k;
+      got[st] = __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, ok ? kk * k_stride + idx_voff : OOB_OFF, 0, 0);
+      got[st] = ok ? got[st] : -1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mine &= mine - 1u;
+    }
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st)
+      if (st * 4 + gsel < K) idx_strip[(st * 4 + gsel) * BM] = got[st];
+  }
+  auto issue_idx = [&](int k) -> int {
+    if constexpr (DENSE) {
+      return (int)(r0 + row16);
+    } else {
+      return idx_strip[(wj < K ? wj : 0) * BM];                 // (past the end: any entry, the value is not used)
+    }
+  };
+#else
   auto issue_idx = [&](int k) -> int {
     if constexpr (DENSE) {
       return (int)(r0 + row16);
@@ -756,6 +812,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
       return __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, idx_voff, kk * k_stride, 0);
     }
   };
+#endif
   // EVERY wave issues PPW DMA instructions per phase -- a wave without a share of the slab aims out of range
   // (zeros, no memory traffic) at the dump: hipcc counts vector-memory operations statically, and behind a
   // wave-dependent branch it could not count these -- its wait for a phase's A fragments then also covered the
@@ -826,6 +883,20 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   // leaves last phase's slab and gathers in flight, and slab_wait leaves this phase's gathers.
   raw4 a0[MAXCC], a1[MAXCC];
   unsigned long long h0 = 0ull, h1 = 0ull;
+#ifdef LIDAL_PHASE_STAMPS
+  const unsigned long long st_begin = LIDAL_NOW(), st_rbegin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_t0 = st_begin, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_t4 = 0, st_first = st_begin, st_last = st_begin;
+  unsigned long long st_issue = 0, st_waita = 0, st_comp = 0, st_slab = 0, st_bar = 0;
+  constexpr int ST_AFTER = ((DENSE || LIDAL_LEAN_LDS_IDX) ? 0 : 1) + PPW + MAXCC;       // loads issued behind A(p): (index(p+2),) slab(p+1), A(p+1)
+#define ST_ISSUED() st_t1 = LIDAL_NOW(); __builtin_amdgcn_s_waitcnt(0x0F70 | (ST_AFTER & 15) | ((ST_AFTER >> 4) << 14)); st_t2 = LIDAL_NOW()
+#define ST_COMPUTED() st_t3 = LIDAL_NOW(); __builtin_amdgcn_s_waitcnt(0x0F70 | (MAXCC & 15) | ((MAXCC >> 4) << 14)); st_t4 = LIDAL_NOW()
+#define ST_PHASE_END() { const unsigned long long t5 = LIDAL_NOW(); st_issue += st_t1 - st_t0; st_waita += st_t2 - st_t1; \
+    st_comp += st_t3 - st_t2; st_slab += st_t4 - st_t3; st_bar += t5 - st_t4; st_t0 = t5; st_last = t5; }
+#else
+#define ST_ISSUED()
+#define ST_COMPUTED()
+#define ST_PHASE_END()
+#endif
   if (nphase > 0) {
     advance();
     const int k0 = wk, p0 = wpass;
@@ -836,6 +907,9 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
     issue_dma(k0, p0, S0{});
     h0 = issue_a(a0, i0, p0);
     slab_wait();
+#ifdef LIDAL_PHASE_STAMPS
+    st_t0 = st_first = st_last = LIDAL_NOW();
+#endif
     int p = 0;
     while (true) {
       if (p + 1 >= nphase) { compute(a0, h0, S0{}); break; }
@@ -844,8 +918,11 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
       issue_dma(kn, pn, S1{});
       h1 = issue_a(a1, i1, pn);
       kn = wk; pn = wpass;
+      ST_ISSUED();
       compute(a0, h0, S0{});
+      ST_COMPUTED();
       slab_wait();
+      ST_PHASE_END();
       ++p;
       if (p + 1 >= nphase) { compute(a1, h1, S1{}); break; }
       advance();
@@ -853,12 +930,18 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
       issue_dma(kn, pn, S0{});
       h0 = issue_a(a0, i0, pn);
       kn = wk; pn = wpass;
+      ST_ISSUED();
       compute(a1, h1, S1{});
+      ST_COMPUTED();
       slab_wait();
+      ST_PHASE_END();
       ++p;
     }
     __syncthreads();                                // every wave is done with the last slab
   }
+#undef ST_ISSUED
+#undef ST_COMPUTED
+#undef ST_PHASE_END
   if (sp.nsplit > 1) {          // a share of the tile's offsets: the f32 accumulators go to the combining kernel
     f32x4* dst = reinterpret_cast<f32x4*>(sp.partial) +
                  ((((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * NWAVES + wave) * (NB * 64) + lane;
@@ -868,6 +951,20 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   }
   store_tile<T, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
                                ep_res, true, perm_v, tile_stats, -1, &bnb);
+#ifdef LIDAL_PHASE_STAMPS
+  if (g_stamp_buf != nullptr) {
+    __builtin_amdgcn_s_waitcnt(0);                  // the tile's stores have left
+    const unsigned long long st_end = LIDAL_NOW(), st_rend = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* d = g_stamp_buf + ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NWAVES) + wave) * 12;
+      d[0] = (unsigned long long)nphase; d[1] = st_end - st_begin; d[2] = st_first - st_begin; d[3] = st_issue; d[4] = st_waita;
+      d[5] = st_comp; d[6] = st_slab; d[7] = st_bar; d[8] = st_end - st_last; d[9] = st_rend - st_rbegin;
+      d[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                // HW_ID (wave, simd, cu, sh, se ...)
+              ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);       // XCC_ID
+      d[11] = st_rbegin;
+    }
+  }
+#endif
 }
 
 // The shares of a split launch (struct Split) added in split order, then the epilogue of the unsplit kernel.
@@ -1142,13 +1239,18 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       static_assert(LBM == TILE_ROWS, "tile masks and BatchNorm statistics triples are per 128-row tile");
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
-      constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + 4096;      // + the DMA dump
+      constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + 4096      // + the DMA dump
+                               + (LIDAL_LEAN_LDS_IDX ? LEAN_IDX_K * LBM * 4 : 0);                 // + the tile's neighbour indices (at most)
       // the 256-wide layers of the coarse levels (4+ slices per offset, few rows): two phases of look-ahead,
       // conv_lean_deep_kernel -- measured on every layer shape of the model (scripts/exp/deep_rows.py, bit-equal
       // everywhere): 256->256 on 43k rows 131 -> 112 us, 384->256 194 -> 163; neutral to 6 % slower on the
       // others (and on every shape of a single scan), which therefore keep the lean kernel
       if constexpr (sizeof(T) == 2 && NB == 8 && ROW_BYTES == 128) {
+#ifdef LIDAL_PHASE_STAMPS
+       if (false) {           // (the instrumented build times the lean kernel on every level)
+#else
        if (nbr != nullptr && n_out <= DEEP_MAX_ROWS && n_out >= 30000 && ci >= 256) {
+#endif
         constexpr int DEPI = LEPI + LSTATS;
         constexpr int DEEP_LDS = ((3 * SLAB > DEPI) ? 3 * SLAB : DEPI) + 4096;
         auto dk = conv_lean_deep_kernel<T, NB, ROW_BYTES, LW, false>;
@@ -1189,7 +1291,9 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
           sp = Split{(float*)ep.ws, ns, co_pad, rows_pad};
       }
       lgrid.z = (unsigned)sp.nsplit;
-      lk<<<lgrid, 64 * LW, LEAN_LDS, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
+      // (the attribute allows the largest strip; a launch asks for its own K offsets' worth, dense launches for none)
+      const size_t lean_lds = (size_t)LEAN_LDS - (LIDAL_LEAN_LDS_IDX ? (size_t)(LEAN_IDX_K - (nbr ? K : 0)) * LBM * 4 : 0);
+      lk<<<lgrid, 64 * LW, lean_lds, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
                                           ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
                                           ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, ep.bnb, sp);
       LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(lean)");
@@ -1384,6 +1488,14 @@ static int conv_apply_image(const void* in, const void* wimg, const int32_t* nbr
     return dispatch_img<float>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
   return dispatch_img<__bf16>(t, in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
 }
+
+#ifdef LIDAL_PHASE_STAMPS
+// (instrumented builds only) u64 [workgroups][waves][12] for the lean kernel's phase stamps, or NULL
+extern "C" int lidal_debug_phase_stamps(void* buf) {
+  LIDAL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
+  return 0;
+}
+#endif
 
 extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const int32_t* nbr,
                                       const int32_t* perm, const uint32_t* tile_masks, void* out,

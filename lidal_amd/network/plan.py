@@ -582,7 +582,7 @@ class _Run:
         prog, T = self.prog, self.T
         bank = _C._IMAGE_BANK
         code, dtype = self.code, self.dtype
-        stale = None
+        seen = []
         for c, (nf, nb) in self._conv_rows():
             key = (_C._tiling(c.ci, c.co, code, nf), _C._tiling(c.co, c.ci, code, nb), code)
             e = c.tkey.get(key) if c.tkey else None
@@ -598,14 +598,15 @@ class _Run:
                 p = c.ptrs[key] = (e['img_f'].data_ptr(), e['img_b'].data_ptr())
             c.img_f, c.img_b = p
             e['used'] = bank.tick
-            # staleness is decided weight by weight, as bank.get does on the per-operator path: a load_state_dict
-            # (strict=False) or a copy_ into ONE layer between two forward passes moves that layer's version only
-            if stale is None and e['version'] != B.weights_key(c.param):
-                stale = e['group']
+            seen.append((e, c.param))
         # one launch rebuilds every stale image of the group (bank.get does it when it meets a stale entry; when no
-        # layer needed registering, ask for it here)
-        if stale is not None:
-            bank._rebuild(stale)
+        # layer needed registering, ask for it here).  Staleness is decided weight by weight, as bank.get does on the
+        # per-operator path: a load_state_dict(strict=False) or a copy_ into ONE layer between two forward passes moves
+        # that layer's version counter only
+        for e, w in seen:
+            if e['version'] != B.weights_key(w):
+                bank._rebuild(e['group'])
+                break
 
     def _conv_rows(self):
         """(layer, (rows its forward produces, rows its data gradient produces)) for every weight of the program."""

@@ -454,6 +454,8 @@ class _ImageBank:
             w = e['ref']()
             if w is not None and e['group'] == group and e['version'] != B.weights_key(w):
                 stale.append((e, w))
+        if not stale:
+            return
         sig = tuple(e['serial'] for e, _ in stale)
         cached = self.tables.get(group)
         if cached is None or cached[0] != sig:

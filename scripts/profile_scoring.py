@@ -40,7 +40,7 @@ def main():
 
     for rep in range(2):
         t0 = sync()
-        probs = [infer_frame(model, d['coords'], d['feats'], d['inverse'], 8, autocast=True)[0]
+        probs = [infer_frame(model, d['coords'], d['feats'], d['inverse'], 8, autocast=os.environ.get('SCORE_DTYPE', 'bf16') == 'bf16')[0]
                  for d in dev_frames]
         t1 = sync()
         bank = FrameBank(0.1)

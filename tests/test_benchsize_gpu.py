@@ -408,6 +408,8 @@ def test_bf16_inference_against_f32_inference_on_scores_and_selection(capsys):
               'Spearman rho (divergence) = %.5f, (entropy) = %.5f, select() flags equal on %.1f %% (%d AL / %d SL picks under f32)'
               % (n_sv, dev_d, dev_e, rho_d, rho_e, 100 * agree, int((fa == 1).sum()), int((fa == 2).sum())))
     assert (fa == 1).sum() >= 3 and (fa == 2).sum() >= 3
-    assert dev_e < 0.02 and rho_e > 0.99, (dev_e, rho_e)
-    assert dev_d < 0.25 and rho_d > 0.9, (dev_d, rho_d)
-    assert agree >= 0.8, agree
+    # measured on MI355X (randomly initialised SPVCNN: near-uniform probabilities, so the entropies hardly move; a
+    # trained network's sharper probabilities would move more): 8.6e-4 / 8.1e-8, rho 0.99999 / 0.99997, 99.6 % of flags
+    assert dev_e < 1e-4 and rho_e > 0.999, (dev_e, rho_e)
+    assert dev_d < 1e-2 and rho_d > 0.999, (dev_d, rho_d)
+    assert agree >= 0.97, agree

@@ -329,6 +329,50 @@ def bench_fresh_stream(dev, model_name, dtype, frames, points, steps, warmup=3, 
                     'the NEXT batch on the second stream; no batch repeats (sk_dataset.py:143-171, sk_dataloader.py:21,53)'}
 
 
+def bench_dropin_surface(dev, model_name, dtype, batch, steps, warmup=3):
+    """The literal drop-in path: a LiDAL user's network as the reference's files compose it (scripts/surface_unet.py:
+    nn.Sequential(spnn.Conv3d, spnn.BatchNorm, spnn.ReLU(True)), residual blocks, the point <-> voxel helpers of
+    network/utils.py, torch's own nn.Linear / BatchNorm1d / Dropout in the point branch) over this package standing in
+    for torchsparse -- none of lidal_amd.network (no launch plan, no fused block, no tables built ahead) -- through
+    train.py:127-140 as written there: zero_grad, forward, torch.nn.functional.cross_entropy(ignore_index=255), backward,
+    Adam.  What `install_as_torchsparse()` users get; the fusions it benefits from are the ones the SURFACE carries."""
+    import lidal_amd
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import surface_unet
+    from lidal_amd import backend as B
+    torch.manual_seed(7122)
+    model = surface_unet.build(lidal_amd)[model_name](19).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), fused=True)
+    coords, feats, labels = batch
+    autocast = dtype == 'bf16'
+
+    def step():
+        opt.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            logits, _ = model(lidal_amd.SparseTensor(feats, coords))
+        loss = torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=255, reduction='mean')
+        loss.backward()
+        opt.step()
+        return loss.detach()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    B.HITS.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.isfinite(loss.item())
+    ms = dt / steps * 1e3
+    n = int(coords.shape[0])
+    return {'ms_per_step': round(ms, 3), 'voxels_per_step': n, 'voxels_per_s': round(n / ms * 1e3, 1), 'steps': steps,
+            'loss': round(float(loss.item()), 4),
+            'library_calls_per_step': int(sum(v for k, v in B.HITS.items() if not k.startswith('torch_fallback')) / steps),
+            'what': 'surface-only %s (scripts/surface_unet.py over lidal_amd as torchsparse; torch nn.Linear / BatchNorm1d / '
+                    'cross_entropy as the reference uses them), per-operator path, tables built inside the forward pass' % model_name}
+
+
 def variant_line(res):
     ms = res['seconds'] / res['steps'] * 1e3
     return {'ms_per_step': round(ms, 3), 'voxels_per_step': int(res['voxels']),
@@ -840,6 +884,7 @@ def run_variants(args, batch, dev, inline=None):
     del fresh
     var['fresh_stream'] = guarded(bench_fresh_stream, dev, args.model, args.dtype, args.frames, args.points,
                                   max(2 * args.steps, 40))
+    var['dropin_surface'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps)
     other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
     var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
                                                 max(3, args.steps // 2), 2, ddp=False))

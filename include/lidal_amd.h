@@ -30,6 +30,12 @@ extern "C" {
 
 #define LIDAL_F32 0
 #define LIDAL_BF16 1
+/* f32 features and f32 results with the products on the bf16 matrix cores: every operand cut into three bf16 pieces
+ * (exactly: 8 + 8 + 8 significand bits), six partial products, f32 accumulation -- the error of an f32 dot product whose
+ * products were rounded once more (<= 3 * 2^-24 relative per product), at 2.7x the f32 MFMA rate.  Accepted by
+ * lidal_conv_weight_image[_bytes|_tiling] (the image it builds is the only one the code reads) and lidal_conv_apply_image
+ * [_ws]; the reduction dimension must be a multiple of 32.  csrc/conv_img.hip: conv_split_kernel. */
+#define LIDAL_F32_SPLIT 2
 
 const char* lidal_last_error(void);
 int lidal_version(void);

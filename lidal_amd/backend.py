@@ -532,6 +532,21 @@ def dtype_code(dt):
     raise TypeError('lidal_amd: unsupported feature dtype %s (float32 / bfloat16 only)' % dt)
 
 
+# f32 INFERENCE runs its convolutions and dense layers in the split form (include/lidal_amd.h: LIDAL_F32_SPLIT; csrc/
+# conv_img.hip conv_split_kernel): f32 features and results, every operand cut exactly into three bf16 pieces, six partial
+# products on the bf16 matrix cores, f32 accumulation -- within 3 * 2^-24 per product of the exact-f32 kernel, which the
+# training step's f32 parity mode keeps.  LIDAL_F32_SPLIT=0: the exact f32 MFMA everywhere.
+F32_SPLIT = 2
+SPLIT_F32 = os.environ.get('LIDAL_F32_SPLIT', '1') != '0'
+
+
+def conv_code(dt, n_red, inference):
+    """dtype code of a convolution / dense product over `n_red` input channels on features of dtype `dt`."""
+    if dt == torch.float32 and inference and SPLIT_F32 and n_red > 0 and n_red % 32 == 0:
+        return F32_SPLIT
+    return dtype_code(dt)
+
+
 def wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 

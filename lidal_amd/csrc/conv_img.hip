@@ -155,6 +155,20 @@ weight_image_batch_kernel(const ImageJob* __restrict__ jobs, int n_jobs, int64_t
 // ablation switches of rounds 1-2 lived here and are gone: scripts/exp/README.md names the commit that has them)
 // rows per workgroup tile of every kernel of this file == rows per BatchNorm statistics triple
 constexpr int TILE_ROWS = 128;
+// Which tile a workgroup takes: the LAST tile of the row order first (round 5).  The row order (lidal_kmap_order: rows
+// sorted by their Gray-ranked offset pattern, rare offsets most significant) puts the tiles with the MOST active offsets
+// at its end -- on the level-0 map of the bench batch the first twelfth of the tiles runs 1 phase each, the last 14.8
+// on average and up to 27 (scripts/exp/tile_weights.py) -- and the hardware dispatches workgroups in index order: the
+// longest tiles started last and the launch ended with a few of them alone on the chip.  Longest first is the classic
+// list-scheduling rule; as a reversal it costs nothing: 96 -> 96 at stride 1 90.2 -> 82.2-83.6 us, 32 -> 32 39.7 -> 34.8,
+// 128 -> 128 at stride 4 66.8 -> 58.7 (same results bit for bit; LIDAL_TILE_ORDER_FORWARD restores index order).
+__device__ __forceinline__ int tile_of_block() {
+#ifdef LIDAL_TILE_ORDER_FORWARD
+  return (int)blockIdx.x;
+#else
+  return (int)gridDim.x - 1 - (int)blockIdx.x;
+#endif
+}
 constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (16 waves / 256 rows measured slower)
 #ifndef LIDAL_LEAN_MINWAVES
 #define LIDAL_LEAN_MINWAVES 4
@@ -163,18 +177,6 @@ constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (1
 // spills 52 registers: the 96 -> 96 layer 90 -> 210 us, the 5-scan step 14.7 -> 19.5 ms (scripts/build_variant.py mw6)
 constexpr int LEAN_MINWAVES = LIDAL_LEAN_MINWAVES;
 constexpr int64_t DEEP_MAX_ROWS = 150000;      // up to this many output rows the deep form of the lean kernel runs
-// Round 5: the lean kernel keeps the neighbour indices of its tile in LDS.  The phase stamps (profiles/
-// r05_phase_stamps.json) showed where a phase's 1.1-1.4 us went: 45 % in the issue segment, i.e. in the wait for
-// index(p+1) -- a 64-byte read of a table row nobody else touches (HBM / Infinity Cache, 1-1.9 us under load) issued
-// ONE phase earlier -- and, because vector-memory operations retire in order, the wait for slab(p+1) at the end of a
-// phase also waited for index(p+2), issued at the phase's start: a phase could never be shorter than one such miss.
-// Now the prologue loads the indices of ALL active offsets of the tile at once (one latency per tile, up to seven
-// independent loads per wave) into a wave-private LDS strip, and a phase reads its index with ds_read_b32.
-#ifndef LIDAL_LEAN_LDS_IDX
-#define LIDAL_LEAN_LDS_IDX 1
-#endif
-constexpr int LEAN_IDX_K = MAXK;               // offsets whose indices the strip can hold; the launch sizes it for its K
-
 // Optional second job of a DATA-GRADIENT launch: the tile's share of the backward sums of the BatchNorm
 // whose output gradient this launch produces (out = dy of y = act(bn(x))): per column sum(dy') and
 // sum(dy' * xhat), dy' = dy where the fused ReLU let the value through, xhat = (x - mean) * invstd -- x read
@@ -437,7 +439,8 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row16 = lane & 15;
   const int gsel = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * RW;
+  const int bx = tile_of_block();
+  const int64_t r0 = (int64_t)bx * BM + wave * RW;
   const int n0 = blockIdx.y * BN;
   const int npass = (ci + KC - 1) / KC;
 
@@ -447,7 +450,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
     tmask = 1u;
   } else {
     unsigned m = 0u;
-    const int64_t t0 = ((int64_t)blockIdx.x * BM) >> 7;
+    const int64_t t0 = ((int64_t)bx * BM) >> 7;
 #pragma unroll
     for (int h = 0; h < (BM >= 128 ? BM / 128 : 1); ++h)
       if ((t0 + h) * 128 < n_out) m |= tmasks[t0 + h];
@@ -635,7 +638,7 @@ conv_apply_img_kernel(const T* __restrict__ in, const T* __restrict__ wimg,
   }
 
   store_tile<T, NB, G, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
-                               ep_res, false, 0, tile_stats, -1, &bnb);
+                               ep_res, false, 0, tile_stats, bx, &bnb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -706,14 +709,15 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row16 = lane & 15;
   const int gsel = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * 16;
+  const int bx = tile_of_block();
+  const int64_t r0 = (int64_t)bx * BM + wave * 16;
   const int n0 = blockIdx.y * BN;
   const int npass = ci / KC;
 
   unsigned tmask = 1u;
   if constexpr (!DENSE) {
     unsigned m = 0u;
-    const int64_t t0 = ((int64_t)blockIdx.x * BM) >> 7;
+    const int64_t t0 = ((int64_t)bx * BM) >> 7;
 #pragma unroll
     for (int h = 0; h < (BM >= 128 ? BM / 128 : 1); ++h)
       if ((t0 + h) * 128 < n_out) m |= tmasks[t0 + h];
@@ -763,47 +767,14 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
 
   // the walk over (active offset, slice): one scalar state, advanced once per phase
   unsigned rem = tmask;
-  int wk = 0, wpass = npass - 1, wj = -1;           // wj: rank of offset wk among the tile's active offsets
+  int wk = 0, wpass = npass - 1;
   auto advance = [&]() {
     if (++wpass == npass) {
       wpass = 0;
       wk = rem ? __builtin_ctz(rem) : 0;            // past the end: offset 0 (a harmless index load)
       rem &= rem - 1u;
-      ++wj;
     }
   };
-#if LIDAL_LEAN_LDS_IDX
-  // the indices of every active offset of this wave's 16 rows -> its strip of LDS (behind the dump): lane group s of
-  // the wave takes the offsets of rank s, s + 4, ...; all loads are issued before the first is awaited.  Rows past the
-  // end and ranks past the last active offset store -1.  Wave-private: no barrier, the strip is read by its writer.
-  int* const idx_strip = reinterpret_cast<int*>(dump + 4096) + wave * 16 + row16;
-  if constexpr (!DENSE) {
-    constexpr int STEPS = (LEAN_IDX_K + 3) / 4;
-    unsigned mine = tmask;
-    for (int t = 0; t < gsel; ++t) mine &= mine - 1u;           // drop the gsel lowest set bits
-    int got[STEPS];
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-      const bool ok = mine != 0u && row_in;
-      const unsigned k = mine ? (unsigned)__builtin_ctz(mine) : 0u;
-      const unsigned kk = kflip ? (unsigned)(K - 1) - k : k;
-      got[st] = __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, ok ? kk * k_stride + idx_voff : OOB_OFF, 0, 0);
-      got[st] = ok ? got[st] : -1;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) mine &= mine - 1u;
-    }
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st)
-      if (st * 4 + gsel < K) idx_strip[(st * 4 + gsel) * BM] = got[st];
-  }
-  auto issue_idx = [&](int k) -> int {
-    if constexpr (DENSE) {
-      return (int)(r0 + row16);
-    } else {
-      return idx_strip[(wj < K ? wj : 0) * BM];                 // (past the end: any entry, the value is not used)
-    }
-  };
-#else
   auto issue_idx = [&](int k) -> int {
     if constexpr (DENSE) {
       return (int)(r0 + row16);
@@ -812,7 +783,6 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
       return __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, idx_voff, kk * k_stride, 0);
     }
   };
-#endif
   // EVERY wave issues PPW DMA instructions per phase -- a wave without a share of the slab aims out of range
   // (zeros, no memory traffic) at the dump: hipcc counts vector-memory operations statically, and behind a
   // wave-dependent branch it could not count these -- its wait for a phase's A fragments then also covered the
@@ -854,7 +824,11 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   auto compute = [&](const raw4 (&a)[MAXCC], unsigned long long have, auto slot_c) __attribute__((always_inline)) {
     constexpr int slot = decltype(slot_c)::value;
     if (have != 0ull) {       // a wave none of whose 16 rows has a rule skips
+#ifdef LIDAL_LEAN_BB
+      constexpr int BB = (NB % LIDAL_LEAN_BB == 0) ? LIDAL_LEAN_BB : NB;
+#else
       constexpr int BB = NB;          // fragment reads issued as one batch
+#endif
 #pragma unroll
       for (int cc = 0; cc < MAXCC; ++cc) {
 #pragma unroll
@@ -887,7 +861,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   const unsigned long long st_begin = LIDAL_NOW(), st_rbegin = __builtin_amdgcn_s_memrealtime();
   unsigned long long st_t0 = st_begin, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_t4 = 0, st_first = st_begin, st_last = st_begin;
   unsigned long long st_issue = 0, st_waita = 0, st_comp = 0, st_slab = 0, st_bar = 0;
-  constexpr int ST_AFTER = ((DENSE || LIDAL_LEAN_LDS_IDX) ? 0 : 1) + PPW + MAXCC;       // loads issued behind A(p): (index(p+2),) slab(p+1), A(p+1)
+  constexpr int ST_AFTER = (DENSE ? 0 : 1) + PPW + MAXCC;       // loads issued behind A(p): index(p+2), slab(p+1), A(p+1)
 #define ST_ISSUED() st_t1 = LIDAL_NOW(); __builtin_amdgcn_s_waitcnt(0x0F70 | (ST_AFTER & 15) | ((ST_AFTER >> 4) << 14)); st_t2 = LIDAL_NOW()
 #define ST_COMPUTED() st_t3 = LIDAL_NOW(); __builtin_amdgcn_s_waitcnt(0x0F70 | (MAXCC & 15) | ((MAXCC >> 4) << 14)); st_t4 = LIDAL_NOW()
 #define ST_PHASE_END() { const unsigned long long t5 = LIDAL_NOW(); st_issue += st_t1 - st_t0; st_waita += st_t2 - st_t1; \
@@ -944,19 +918,19 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
 #undef ST_PHASE_END
   if (sp.nsplit > 1) {          // a share of the tile's offsets: the f32 accumulators go to the combining kernel
     f32x4* dst = reinterpret_cast<f32x4*>(sp.partial) +
-                 ((((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * NWAVES + wave) * (NB * 64) + lane;
+                 ((((int64_t)blockIdx.z * gridDim.x + bx) * gridDim.y + blockIdx.y) * NWAVES + wave) * (NB * 64) + lane;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) dst[nb * 64] = acc[0][nb];
     return;
   }
   store_tile<T, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
-                               ep_res, true, perm_v, tile_stats, -1, &bnb);
+                               ep_res, true, perm_v, tile_stats, bx, &bnb);
 #ifdef LIDAL_PHASE_STAMPS
   if (g_stamp_buf != nullptr) {
     __builtin_amdgcn_s_waitcnt(0);                  // the tile's stores have left
     const unsigned long long st_end = LIDAL_NOW(), st_rend = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
-      unsigned long long* d = g_stamp_buf + ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NWAVES) + wave) * 12;
+      unsigned long long* d = g_stamp_buf + ((((size_t)blockIdx.y * gridDim.x + bx) * NWAVES) + wave) * 12;
       d[0] = (unsigned long long)nphase; d[1] = st_end - st_begin; d[2] = st_first - st_begin; d[3] = st_issue; d[4] = st_waita;
       d[5] = st_comp; d[6] = st_slab; d[7] = st_bar; d[8] = st_end - st_last; d[9] = st_rend - st_rbegin;
       d[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                // HW_ID (wave, simd, cu, sh, se ...)
@@ -1045,14 +1019,15 @@ conv_lean_deep_kernel(const T* __restrict__ in, const T* __restrict__ wimg, cons
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row16 = lane & 15;
   const int gsel = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * 16;
+  const int bx = tile_of_block();
+  const int64_t r0 = (int64_t)bx * BM + wave * 16;
   const int n0 = blockIdx.y * BN;
   const int npass = ci / KC;
 
   unsigned tmask = 1u;
   if constexpr (!DENSE) {
     unsigned m = 0u;
-    const int64_t t0 = ((int64_t)blockIdx.x * BM) >> 7;
+    const int64_t t0 = ((int64_t)bx * BM) >> 7;
     if (t0 * 128 < n_out) m = tmasks[t0];
     if (kflip) m = __brev(m) >> (32 - K);
     tmask = __builtin_amdgcn_readfirstlane(m);
@@ -1204,7 +1179,296 @@ conv_lean_deep_kernel(const T* __restrict__ in, const T* __restrict__ wimg, cons
   __builtin_amdgcn_s_waitcnt(0x0F70);               // the dump writes of the phases past the end are done
   __syncthreads();
   store_tile<T, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
-                               ep_res, true, perm_v, tile_stats, -1, &bnb);
+                               ep_res, true, perm_v, tile_stats, bx, &bnb);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// f32 features, f32 weights, products on the bf16 MFMA: the split form (round 5)
+// ------------------------------------------------------------------------------------------
+// The f32 mode (the reference's precision: score/prob_inference.py infers in fp32) ran on v_mfma_f32_16x16x4_f32 --
+// 157 TFLOP/s dense against 2.5 PFLOP/s for bf16 -- and its convolutions were MFMA-bound (66 % of that peak on the
+// 96 -> 96 layer, 80 % of a scored frame's kernel time).  Here an f32 operand v is cut into THREE bf16 pieces by
+// truncation, v = hi + mid + lo EXACTLY (8 + 8 + 8 significand bits; hi = top 16 bits of v, mid = top 16 bits of
+// v - hi, lo = v - hi - mid, each difference exact in f32), and a product a.b is the sum of the six partial
+// products of weight <= 2 (a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_mid b_mid + a_lo b_hi; every one exact
+// in the MFMA's f32 accumulator: 8 x 8 bits), added smallest first.  Dropped: a_mid b_lo + a_lo b_mid + a_lo b_lo
+// <= 3 * 2^-24 |a b| -- the size of ONE f32 rounding of the product -- so the result carries the error of an f32
+// dot product whose products were each rounded once more (tests/test_ops_gpu.py bounds it against f64: 1e-6 of the
+// output scale, where the exact-f32 kernel sits at 2e-7).  Six bf16 MFMAs (96 cycles) replace the eight f32 MFMAs
+// (256 cycles) of a 16 x 16 x 32 block.
+//   * weights: lidal_conv_weight_image with dtype LIDAL_F32_SPLIT lays the three pieces of a 32-channel slice side by
+//     side as ONE 96-"channel" bf16 slice (hi | mid | lo) in the bf16 image layout with 192-byte rows, so slabs, the
+//     LDS-DMA and the conflict-free fragment reads are the bf16 96-channel kernel's;
+//   * features: a lane gathers the 8 consecutive f32 channels its A fragment covers (two 16-byte loads), cuts them in
+//     registers (4 VALU operations per element + 3 packs per pair) and feeds three bf16x8 fragments;
+//   * the rest -- pattern-sorted rows, tile masks, scalar offset walk, one phase of look-ahead, epilogue -- is the lean
+//     kernel's.  One phase = (active offset, 32-channel slice): 6 NB MFMAs per wave.
+// Used for inference (no_grad) and wherever the caller passes LIDAL_F32_SPLIT; the training step's f32 parity mode
+// keeps the exact f32 MFMA (its golden gradients are pinned to that association).
+struct Pieces { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ Pieces cut3(const raw4& lo4, const raw4& hi4) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned u = (unsigned)(e < 4 ? lo4[e] : hi4[e - 4]);
+    const float v = __uint_as_float(u);
+    h[e] = u & 0xFFFF0000u;
+    const float r = v - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r) & 0xFFFF0000u;
+    l[e] = __float_as_uint(r - __uint_as_float(m[e]));
+  }
+  raw4 ph, pm, pl;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {       // bf16 element 2j in the low half: bytes {3,2} of the odd element | {3,2} of the even one
+    ph[j] = (int)__builtin_amdgcn_perm(h[2 * j + 1], h[2 * j], 0x07060302u);
+    pm[j] = (int)__builtin_amdgcn_perm(m[2 * j + 1], m[2 * j], 0x07060302u);
+    pl[j] = (int)__builtin_amdgcn_perm(l[2 * j + 1], l[2 * j], 0x07060302u);
+  }
+  Pieces p;
+  p.hi = __builtin_bit_cast(bf16x8, ph); p.mid = __builtin_bit_cast(bf16x8, pm); p.lo = __builtin_bit_cast(bf16x8, pl);
+  return p;
+}
+
+constexpr int SPLIT_KCH = 32;                  // f32 channels per slice
+constexpr int SPLIT_ROW = 3 * SPLIT_KCH * 2;   // bytes of a slice's image row: hi | mid | lo in bf16 = 192
+
+template <int NB, int NWAVES, bool DENSE>
+__global__ void __launch_bounds__(64 * NWAVES, LEAN_MINWAVES)
+conv_split_kernel(const float* __restrict__ in, const __bf16* __restrict__ wimg, const int* __restrict__ nbr,
+                  const int* __restrict__ perm, const unsigned* __restrict__ tmasks, float* __restrict__ out,
+                  int64_t n_out, int ci, int co, int K, int kflip, const float* __restrict__ ep_scale,
+                  const float* __restrict__ ep_shift, int ep_relu, const float* __restrict__ ep_res, unsigned in_bytes,
+                  unsigned img_bytes, unsigned nbr_bytes) {
+  constexpr int BM = NWAVES * 16;
+  constexpr int BN = 16 * NB;
+  constexpr int SLAB = BN * SPLIT_ROW;
+  constexpr int PIECES = SLAB / 1024;
+  constexpr int PPW = (PIECES + NWAVES - 1) / NWAVES;
+  constexpr int DMA_WAVES = PIECES / PPW;
+  static_assert(PIECES % PPW == 0 && DMA_WAVES <= NWAVES && SLAB % 1024 == 0, "a DMA wave moves a whole share");
+  static_assert(BM == TILE_ROWS, "tile masks are per 128 rows");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;                              // [2][SLAB], re-used as the epilogue tile
+  constexpr int LEPI_ALL = NWAVES * 16 * (BN + 4) * 4 + NWAVES * BN * 2 * (int)sizeof(float);
+  unsigned char* const dump = smem + ((2 * SLAB > LEPI_ALL) ? 2 * SLAB : LEPI_ALL);     // 4 KiB
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row16 = lane & 15;
+  const int gsel = lane >> 4;
+  const int bx = tile_of_block();
+  const int64_t r0 = (int64_t)bx * BM + wave * 16;
+  const int n0 = blockIdx.y * BN;
+  const int npass = ci / SPLIT_KCH;
+
+  unsigned tmask = 1u;
+  if constexpr (!DENSE) {
+    unsigned m = 0u;
+    const int64_t t0 = ((int64_t)bx * BM) >> 7;
+    if (t0 * 128 < n_out) m = tmasks[t0];
+    if (kflip) m = __brev(m) >> (32 - K);
+    tmask = __builtin_amdgcn_readfirstlane(m);
+  }
+  const int nphase = __popc(tmask) * npass;
+
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wimg), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nbr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, (int)nbr_bytes, 0x00020000);
+
+  constexpr unsigned OOB_OFF = 0x80000000u;
+  const unsigned row_bytes = (unsigned)ci * 4u;
+  const unsigned lane_off = (unsigned)gsel * 32u;               // this lane's 8 f32 channels of a 32-channel slice
+  const unsigned idx_voff = (unsigned)((r0 + row16) * 4);
+  const bool row_in = r0 + row16 < n_out;
+  const unsigned k_stride = (unsigned)n_out * 4u;
+  const unsigned slab_k = (unsigned)gridDim.y * (unsigned)npass * (unsigned)SLAB;
+  const unsigned slab_base = (unsigned)blockIdx.y * (unsigned)npass * (unsigned)SLAB + (unsigned)(wave * PPW) * 1024u;
+  const unsigned dma_voff = (unsigned)lane * 16u;
+  const bool dma_wave = wave < DMA_WAVES;
+  unsigned char* const dma_dst = wl + (wave * PPW) * 1024;
+  const unsigned char* const wbase = wl + (gsel * NB) * 256 + row16 * 16;
+
+  const __amdgpu_buffer_rsrc_t rs_perm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int*>(perm), 0, perm != nullptr ? (int)k_stride : 0, 0x00020000);
+  const int perm_v = __builtin_amdgcn_raw_buffer_load_b32(rs_perm, idx_voff, 0, 0);
+
+  unsigned rem = tmask;
+  int wk = 0, wpass = npass - 1;
+  auto advance = [&]() {
+    if (++wpass == npass) {
+      wpass = 0;
+      wk = rem ? __builtin_ctz(rem) : 0;
+      rem &= rem - 1u;
+    }
+  };
+  auto issue_idx = [&](int k) -> int {
+    if constexpr (DENSE) {
+      return (int)(r0 + row16);
+    } else {
+      const unsigned kk = (unsigned)(kflip ? (K - 1 - k) : k);
+      return __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, idx_voff, kk * k_stride, 0);
+    }
+  };
+  auto issue_dma = [&](int k, int pass, auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
+    const unsigned soff = dma_wave ? (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base : OOB_OFF;
+    unsigned char* const base = dma_wave ? dma_dst + slot * SLAB : dump;
+    static_assert(PPW <= 4, "DMA share: one M0 value");
+    auto* dst = (__attribute__((address_space(3))) void*)base;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 0, 0);
+    if (1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 1024, 0);
+    if (2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 2048, 0);
+    if (3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, soff, 3072, 0);
+  };
+  auto issue_a = [&](raw4 (&a)[2], int idx, int pass) __attribute__((always_inline)) -> unsigned long long {
+    const bool has = idx >= 0 && row_in;
+    unsigned off = __umul24((unsigned)idx, row_bytes) + lane_off;
+    off = has ? off : OOB_OFF;
+    const unsigned soff = (unsigned)pass * (unsigned)(SPLIT_KCH * 4);
+    a[0] = __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, soff, 0));
+    a[1] = __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + 16u, soff, 0));
+    return __ballot(has);
+  };
+
+  f32x4 acc[1][NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[0][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const raw4 (&a)[2], unsigned long long have, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+    if (have != 0ull) {
+      const Pieces p = cut3(a[0], a[1]);
+      constexpr int BB = 2;             // column blocks whose three fragments are read as one batch
+#pragma unroll
+      for (int nb0 = 0; nb0 < NB; nb0 += BB) {
+        bf16x8 bh[BB], bm[BB], bl[BB];
+#pragma unroll
+        for (int j = 0; j < BB; ++j) {
+          const unsigned char* q = wbase + slot * SLAB + (nb0 + j) * 256;
+          bh[j] = *reinterpret_cast<const bf16x8*>(q);
+          bm[j] = *reinterpret_cast<const bf16x8*>(q + 4 * NB * 256);
+          bl[j] = *reinterpret_cast<const bf16x8*>(q + 8 * NB * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < BB; ++j) {      // smallest partial products first
+          f32x4 c = acc[0][nb0 + j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.lo, bh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.mid, bm[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.hi, bl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.mid, bh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.hi, bm[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.hi, bh[j], c, 0, 0, 0);
+          acc[0][nb0 + j] = c;
+        }
+      }
+    }
+  };
+  auto slab_wait = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 2);             // only the two gathers issued behind the DMA may be in flight
+    __syncthreads();
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  raw4 a0[2], a1[2];
+  unsigned long long h0 = 0ull, h1 = 0ull;
+  if (nphase > 0) {
+    advance();
+    const int k0 = wk, p0 = wpass;
+    int i0 = issue_idx(k0);
+    advance();
+    int i1 = issue_idx(wk);
+    int kn = wk, pn = wpass;
+    issue_dma(k0, p0, S0{});
+    h0 = issue_a(a0, i0, p0);
+    slab_wait();
+    int p = 0;
+    while (true) {
+      if (p + 1 >= nphase) { compute(a0, h0, S0{}); break; }
+      advance();
+      i0 = issue_idx(wk);
+      issue_dma(kn, pn, S1{});
+      h1 = issue_a(a1, i1, pn);
+      kn = wk; pn = wpass;
+      compute(a0, h0, S0{});
+      slab_wait();
+      ++p;
+      if (p + 1 >= nphase) { compute(a1, h1, S1{}); break; }
+      advance();
+      i1 = issue_idx(wk);
+      issue_dma(kn, pn, S0{});
+      h0 = issue_a(a0, i0, pn);
+      kn = wk; pn = wpass;
+      compute(a1, h1, S1{});
+      slab_wait();
+      ++p;
+    }
+    __syncthreads();
+  }
+  store_tile<float, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
+                                   ep_res, true, perm_v, nullptr, bx, nullptr);
+}
+
+// one 16-byte segment of a split image: image[k][nblk][slice][part][gsel][nb][row16] x 8 bf16, part = hi | mid | lo of
+// the f32 weight W[k][slice * 32 + gsel * 8 + e][col] (role 0) / W[k][col][...] (role 1)
+template <typename TI>
+__device__ __forceinline__ void split_segment(const TI* __restrict__ w, __bf16* __restrict__ img, int n_red, int n_col,
+                                              int role, int nb, int64_t s) {
+  const int bn = 16 * nb;
+  const int nblk = (n_col + bn - 1) / bn, npass = n_red / SPLIT_KCH;
+  unsigned r = (unsigned)s;
+  const int row16 = (int)(r & 15u); r >>= 4;
+  const int b = (int)(r % (unsigned)nb); r /= (unsigned)nb;
+  const int gsel = (int)(r & 3u); r >>= 2;
+  const int part = (int)(r % 3u); r /= 3u;
+  const int pass = (int)(r % (unsigned)npass); r /= (unsigned)npass;
+  const int blk = (int)(r % (unsigned)nblk); r /= (unsigned)nblk;
+  const int k = (int)r;
+  const int col = blk * bn + b * 16 + row16;
+  unsigned short v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int red = pass * SPLIT_KCH + gsel * 8 + e;
+    float f = 0.f;
+    if (col < n_col) {
+      const int64_t base = (int64_t)k * n_red * n_col;
+      f = DT<TI>::to_f32(role == 0 ? w[base + (int64_t)red * n_col + col] : w[base + (int64_t)col * n_red + red]);
+    }
+    const unsigned u = __float_as_uint(f);
+    const unsigned hb = u & 0xFFFF0000u;
+    const float rr = f - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(rr) & 0xFFFF0000u;
+    const unsigned lb = __float_as_uint(rr - __uint_as_float(mb));
+    v[e] = (unsigned short)((part == 0 ? hb : (part == 1 ? mb : lb)) >> 16);
+  }
+  *reinterpret_cast<raw4*>(reinterpret_cast<unsigned short*>(img) + s * 8) = *reinterpret_cast<raw4*>(v);
+}
+template <typename TI>
+__global__ void __launch_bounds__(256)
+weight_image_split_kernel(const TI* __restrict__ w, __bf16* __restrict__ img, int n_red, int n_col, int role, int nb,
+                          int64_t segs) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < segs) split_segment<TI>(w, img, n_red, n_col, role, nb, s);
+}
+// the forward images of several parameters in one launch (the jobs of lidal_conv_weight_image_job with LIDAL_F32_SPLIT)
+template <typename TI>
+__global__ void __launch_bounds__(256)
+weight_image_batch_split_kernel(const ImageJob* __restrict__ jobs, int n_jobs, int64_t total) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first <= s) lo = mid; else hi = mid - 1;
+  }
+  const ImageJob j = jobs[lo];
+  const int64_t l = s - j.first;
+  if (l < j.segs_a) split_segment<TI>((const TI*)j.w, (__bf16*)j.img_a, j.n_red, j.n_col, j.role, j.nb_a, l);
 }
 
 struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; BnBwd bnb; void* ws; long long ws_bytes; };
@@ -1239,8 +1503,7 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       static_assert(LBM == TILE_ROWS, "tile masks and BatchNorm statistics triples are per 128-row tile");
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
-      constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + 4096      // + the DMA dump
-                               + (LIDAL_LEAN_LDS_IDX ? LEAN_IDX_K * LBM * 4 : 0);                 // + the tile's neighbour indices (at most)
+      constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + 4096;      // + the DMA dump
       // the 256-wide layers of the coarse levels (4+ slices per offset, few rows): two phases of look-ahead,
       // conv_lean_deep_kernel -- measured on every layer shape of the model (scripts/exp/deep_rows.py, bit-equal
       // everywhere): 256->256 on 43k rows 131 -> 112 us, 384->256 194 -> 163; neutral to 6 % slower on the
@@ -1291,9 +1554,7 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
           sp = Split{(float*)ep.ws, ns, co_pad, rows_pad};
       }
       lgrid.z = (unsigned)sp.nsplit;
-      // (the attribute allows the largest strip; a launch asks for its own K offsets' worth, dense launches for none)
-      const size_t lean_lds = (size_t)LEAN_LDS - (LIDAL_LEAN_LDS_IDX ? (size_t)(LEAN_IDX_K - (nbr ? K : 0)) * LBM * 4 : 0);
-      lk<<<lgrid, 64 * LW, lean_lds, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
+      lk<<<lgrid, 64 * LW, LEAN_LDS, s>>>((const T*)in, (const T*)wimg, nbr, perm, tmasks, (T*)out, n_out,
                                           ci, co, K, kflip, ep.scale, ep.shift, ep.relu, (const T*)ep.res,
                                           ep.in_bytes, ep.img_bytes, ep.nbr_bytes, ep.tile_stats, ep.bnb, sp);
       LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(lean)");
@@ -1348,16 +1609,46 @@ int dispatch_img(Tiling t, const void* in, const void* wimg, const int* nbr, con
   return 2;
 }
 
+
+// ---- the split form: tiling and launch
+__host__ inline int split_nb(int co) { return co <= 32 ? 2 : (co <= 64 ? 4 : ((co % 128 != 0 && (co % 96 == 0 || co < 128)) ? 6 : 8)); }
+__host__ inline int64_t split_image_bytes(int k, int n_red, int n_col) {
+  const int bn = 16 * split_nb(n_col);
+  return (int64_t)k * ((n_col + bn - 1) / bn) * (n_red / SPLIT_KCH) * bn * SPLIT_ROW;
+}
+template <int NB>
+int launch_split(const void* in, const void* wimg, const int* nbr, const int* perm, const unsigned* tmasks, void* out,
+                 int64_t n_out, int ci, int co, int K, int kflip, Epi ep, hipStream_t s) {
+  constexpr int LW = LEAN_WAVES, BN = 16 * NB, SLAB = BN * SPLIT_ROW;
+  constexpr int LEPI_ALL = LW * 16 * (BN + 4) * 4 + LW * BN * 2 * (int)sizeof(float);
+  constexpr int LDS = ((2 * SLAB > LEPI_ALL) ? 2 * SLAB : LEPI_ALL) + 4096;
+  auto kern = nbr ? conv_split_kernel<NB, LW, false> : conv_split_kernel<NB, LW, true>;
+  static size_t attr[2][MAX_DEVICES] = {};
+  const int dev = current_device();
+  if (attr[nbr ? 0 : 1][dev] < (size_t)LDS) {
+    LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr[nbr ? 0 : 1][dev] = LDS;
+  }
+  dim3 grid((unsigned)cdiv(n_out, LW * 16), (unsigned)cdiv(co, BN));
+  kern<<<grid, 64 * LW, LDS, s>>>((const float*)in, (const __bf16*)wimg, nbr, perm, tmasks, (float*)out, n_out, ci, co, K,
+                                  kflip, ep.scale, ep.shift, ep.relu, (const float*)ep.res, ep.in_bytes, ep.img_bytes,
+                                  ep.nbr_bytes);
+  LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(split)");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int lidal_conv_stats_tile_rows(void) { return TILE_ROWS; }
 
 extern "C" int lidal_conv_weight_image_tiling(int ci, int co, int dtype, int64_t n_out) {
+  if (dtype == LIDAL_F32_SPLIT) return split_nb(co) * 1000 + SPLIT_ROW + 1;     // (+1: never equal to a bf16 tiling's key)
   const Tiling t = pick_tiling(ci, co, n_out, dtype == LIDAL_BF16 ? 2 : 4);
   return t.nb * 1000 + t.row_bytes;
 }
 
 extern "C" int64_t lidal_conv_weight_image_bytes(int k, int ci, int co, int dtype, int64_t n_out) {
+  if (dtype == LIDAL_F32_SPLIT) return (ci > 0 && ci % SPLIT_KCH == 0) ? split_image_bytes(k, ci, co) : -1;
   const int esz = dtype == LIDAL_BF16 ? 2 : 4;
   return image_bytes(k, ci, co, pick_tiling(ci, co, n_out, esz), esz);
 }
@@ -1366,6 +1657,21 @@ static int weight_images(const void* w, int w_dtype, int role, void* img_a, int6
                          int64_t n_out_b, int dtype, int k, int n_red, int n_col, hipStream_t s) {
   if (k == 0 || n_red == 0 || n_col == 0) return 0;
   LIDAL_REQUIRE(role == 0 || role == 1, "weight_image: role must be 0 (forward) or 1 (data gradient)");
+  if (dtype == LIDAL_F32_SPLIT) {       // hi | mid | lo bf16 pieces of an f32 (or bf16) weight, see conv_split_kernel
+    LIDAL_REQUIRE(img_b == nullptr && n_red % SPLIT_KCH == 0, "weight_image(split): one image per call, reduction a "
+                  "multiple of %d channels (got %d)", SPLIT_KCH, n_red);
+    const int64_t segs = split_image_bytes(k, n_red, n_col) / 16;
+    LIDAL_REQUIRE(segs < (1ll << 31), "weight_image: an image of more than 2^31 segments");
+    const unsigned grid = (unsigned)cdiv(segs, 256);
+    if (w_dtype == LIDAL_F32)
+      weight_image_split_kernel<float><<<grid, 256, 0, s>>>((const float*)w, (__bf16*)img_a, n_red, n_col, role,
+                                                            split_nb(n_col), segs);
+    else
+      weight_image_split_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16*)w, (__bf16*)img_a, n_red, n_col, role,
+                                                             split_nb(n_col), segs);
+    LIDAL_CHECK_LAUNCH("lidal_conv_weight_image(split)");
+    return 0;
+  }
   const int esz = dtype == LIDAL_BF16 ? 2 : 4;
   const Tiling ta = pick_tiling(n_red, n_col, n_out_a, esz);
   const int64_t segs_a = image_bytes(k, n_red, n_col, ta, esz) / 16;
@@ -1414,9 +1720,22 @@ extern "C" int lidal_conv_weight_image_job_bytes(void) { return (int)sizeof(Imag
 extern "C" int64_t lidal_conv_weight_image_job(void* job, const void* w, int role, void* img_fwd,
                                                int64_t n_out_fwd, void* img_bwd, int64_t n_out_bwd,
                                                int dtype, int k, int ci, int co, int64_t first) {
-  if (job == nullptr || (dtype != LIDAL_F32 && dtype != LIDAL_BF16) || (role != 0 && role != 1)) {
+  if (job == nullptr || (dtype != LIDAL_F32 && dtype != LIDAL_BF16 && dtype != LIDAL_F32_SPLIT) || (role != 0 && role != 1)) {
     set_error("weight_image_job: bad arguments");
     return -1;
+  }
+  if (dtype == LIDAL_F32_SPLIT) {       // forward image only (the inference form), reduction over ci
+    if (img_bwd != nullptr || ci % SPLIT_KCH != 0) {
+      set_error("weight_image_job(split): forward image only, ci a multiple of %d (got %d)", SPLIT_KCH, ci);
+      return -1;
+    }
+    ImageJob j;
+    j.w = w; j.img_a = img_fwd; j.img_b = nullptr; j.first = first;
+    j.segs_a = split_image_bytes(k, ci, co) / 16; j.segs_b = 0;
+    j.n_red = ci; j.n_col = co; j.role = role; j.nb_a = split_nb(co); j.kc_a = 0; j.nb_b = j.nb_a; j.kc_b = 0; j.pad = 0;
+    if (j.segs_a >= (1ll << 31)) { set_error("weight_image_job: an image of %lld segments", (long long)j.segs_a); return -1; }
+    *reinterpret_cast<ImageJob*>(job) = j;
+    return j.segs_a;
   }
   const int esz = dtype == LIDAL_BF16 ? 2 : 4;
   const Tiling ta = pick_tiling(ci, co, n_out_fwd, esz);
@@ -1446,7 +1765,11 @@ extern "C" int lidal_conv_weight_image_batch(const void* jobs, int n_jobs, int64
   const unsigned grid = (unsigned)cdiv(total_segments, 256);
 #define IMG_BATCH(TI, TO) \
   weight_image_batch_kernel<TI, TO><<<grid, 256, 0, s>>>((const ImageJob*)jobs, n_jobs, total_segments)
-  if (w_dtype == LIDAL_F32 && dtype == LIDAL_F32) IMG_BATCH(float, float);
+  if (dtype == LIDAL_F32_SPLIT && w_dtype == LIDAL_F32)
+    weight_image_batch_split_kernel<float><<<grid, 256, 0, s>>>((const ImageJob*)jobs, n_jobs, total_segments);
+  else if (dtype == LIDAL_F32_SPLIT && w_dtype == LIDAL_BF16)
+    weight_image_batch_split_kernel<__bf16><<<grid, 256, 0, s>>>((const ImageJob*)jobs, n_jobs, total_segments);
+  else if (w_dtype == LIDAL_F32 && dtype == LIDAL_F32) IMG_BATCH(float, float);
   else if (w_dtype == LIDAL_F32 && dtype == LIDAL_BF16) IMG_BATCH(float, __bf16);
   else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_BF16) IMG_BATCH(__bf16, __bf16);
   else if (w_dtype == LIDAL_BF16 && dtype == LIDAL_F32) IMG_BATCH(__bf16, float);
@@ -1466,7 +1789,27 @@ static int conv_apply_image(const void* in, const void* wimg, const int32_t* nbr
                             int64_t ws_bytes, hipStream_t s) {
   if (n_out == 0 || co == 0) return 0;
   LIDAL_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv_apply_image: scale and shift go together");
-  LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16, "conv_apply_image: bad dtype %d", dtype);
+  LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16 || dtype == LIDAL_F32_SPLIT, "conv_apply_image: bad dtype %d", dtype);
+  if (dtype == LIDAL_F32_SPLIT) {       // f32 in / out, weights as a split image: conv_split_kernel
+    LIDAL_REQUIRE(ci > 0 && ci % SPLIT_KCH == 0 && co % 4 == 0 && k > 0 && k <= MAXK,
+                  "conv_apply_image(split): ci must be a multiple of %d, co of 4, k <= %d (got ci=%d co=%d k=%d)",
+                  SPLIT_KCH, MAXK, ci, co, k);
+    LIDAL_REQUIRE(nbr == nullptr ? (k == 1 && n_in == n_out) : (tile_masks != nullptr),
+                  "conv_apply_image: needs lidal_kmap_order's tile masks (or NULL table = identity, k = 1)");
+    LIDAL_REQUIRE(tile_stats == nullptr && bnb.sums == nullptr, "conv_apply_image(split): no BatchNorm statistics (inference form)");
+    const int64_t ib = split_image_bytes(k, ci, co);
+    LIDAL_REQUIRE(n_in >= 0 && n_in * ci * 4 < 0x7FFFFFF0ll && ib < 0x7FFFFFF0ll && n_in < (1 << 24),
+                  "conv_apply_image: the input matrix and the weight image must each stay below 2 GiB (2^24 rows)");
+    LIDAL_REQUIRE((int64_t)k * n_out * 4 < 0x7FFFFFF0ll, "conv_apply_image: neighbour table above 2 GiB");
+    Epi ep{ep_scale, ep_shift, ep_relu, ep_residual, (unsigned)(n_in * ci * 4), (unsigned)ib,
+           (unsigned)((int64_t)k * n_out * 4), nullptr, bnb, nullptr, 0};
+    switch (split_nb(co)) {
+      case 2: return launch_split<2>(in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
+      case 4: return launch_split<4>(in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
+      case 6: return launch_split<6>(in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
+      default: return launch_split<8>(in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
+    }
+  }
   const int esz = dtype == LIDAL_BF16 ? 2 : 4;
   const int vec = 16 / esz;
   LIDAL_REQUIRE(ci > 0 && ci % vec == 0 && co % 4 == 0 && k > 0 && k <= MAXK,

@@ -576,6 +576,10 @@ class _Run:
         base = k.data_ptr()
         self.koff = {n: base + 16 * i for i, n in reversed(list(enumerate(ns)))}
 
+    def ccode(self, c):
+        """dtype code of layer `c`'s products (a training run: the features' own)."""
+        return self.code
+
     def _images(self):
         """The LDS images of every weight: registered with the step's bank (nn/functional/conv.py _ImageBank) under
         the tilings this step's row counts select, rebuilt by ONE launch."""
@@ -584,10 +588,11 @@ class _Run:
         code, dtype = self.code, self.dtype
         seen = []
         for c, (nf, nb) in self._conv_rows():
+            code = self.ccode(c)
             key = (_C._tiling(c.ci, c.co, code, nf), _C._tiling(c.co, c.ci, code, nb), code)
             e = c.tkey.get(key) if c.tkey else None
             if e is None or e['ref']() is not c.param or bank.entries.get((id(c.param), e['key'])) is not e:
-                bank.get(c.param, dtype, nf, nb, c.shape if (c.role or c.k == 1) else None, c.role)
+                bank.get(c.param, dtype, nf, nb, c.shape if (c.role or c.k == 1) else None, c.role, code)
                 e = bank.entry(c.param, key)
                 if c.tkey is None or len(c.tkey) > 8:
                     c.tkey = {}
@@ -701,7 +706,7 @@ class _Run:
         A = self.arena
         out = A.alloc(n * co * self.esz)
         st = A.alloc(-(-n // self.tile) * co * 12) if (stats and self.bf16) else 0
-        self.w += (OP_CONV_APPLY_IMAGE | flag, x, c.img_f, 0, 0, 0, out, n, n, c.ci, co, 1, 0, self.code,
+        self.w += (OP_CONV_APPLY_IMAGE | flag, x, c.img_f, 0, 0, 0, out, n, n, c.ci, co, 1, 0, self.ccode(c),
                    self.ones if shift else 0, shift, 0, 0, st)
         self.nops += 1
         return out, st
@@ -1190,6 +1195,10 @@ class _EvalRun(_Run):
         prog.eval_operands(feats.device)
         _Run.__init__(self, model, prog, geometry, feats, code)
 
+    def ccode(self, c):
+        # f32 inference: the split form wherever the layer's reduction is whole 32-channel slices (backend.conv_code)
+        return B.conv_code(self.dtype, c.ci, True)
+
     def _constants(self):
         prog = self.prog
         if prog.ones is None or prog.ones.device != self.dev:
@@ -1203,7 +1212,7 @@ class _EvalRun(_Run):
         out = self.arena.alloc(n_out * c.co * self.esz)
         wb = _C.apply_workspace_bytes(n_out, c.co)
         self.w += (OP_CONV_APPLY_IMAGE_WS, x, c.img_f, table[0], table[1], table[2], out, n_in, n_out,
-                   c.ci if ci is None else ci, c.co, c.k, 0, self.code, r.scale, r.shift, r.relu, 0, 0,
+                   c.ci if ci is None else ci, c.co, c.k, 0, self.ccode(c), r.scale, r.shift, r.relu, 0, 0,
                    self.scratch(wb) if wb else 0, wb)
         self.nops += 1
         return out
@@ -1215,19 +1224,19 @@ class _EvalRun(_Run):
         if r.cs is not None:                # the shortcut: one dense kernel (on a side stream it measured no gain at
             fl = 0                          # inference, and a loss beside the scorer's stream: scripts/exp/score_ab.sh)
             skip = A.alloc(n * r.cs.co * e)
-            self.w += (OP_CONV_APPLY_IMAGE | fl, x, r.cs.img_f, 0, 0, 0, skip, n, n, r.cs.ci, r.cs.co, 1, 0, self.code,
+            self.w += (OP_CONV_APPLY_IMAGE | fl, x, r.cs.img_f, 0, 0, 0, skip, n, n, r.cs.ci, r.cs.co, 1, 0, self.ccode(r.cs),
                        r.bs.scale, r.bs.shift, 0, 0, 0)
             self.nops += 1
         y1 = A.alloc(n * r.c1.co * e)
         out = A.alloc(n * r.c2.co * e)
         wb1, wb2 = _C.apply_workspace_bytes(n, r.c1.co), _C.apply_workspace_bytes(n, r.c2.co)
         self.w += (OP_CONV_APPLY_IMAGE_WS, x, r.c1.img_f, table[0], table[1], table[2], y1, n, n, r.c1.ci, r.c1.co, r.c1.k,
-                   0, self.code, r.b1.scale, r.b1.shift, 1, 0, 0, self.scratch(wb1) if wb1 else 0, wb1)
+                   0, self.ccode(r.c1), r.b1.scale, r.b1.shift, 1, 0, 0, self.scratch(wb1) if wb1 else 0, wb1)
         self.nops += 1
         if fl:
             self.join(2)
         self.w += (OP_CONV_APPLY_IMAGE_WS, y1, r.c2.img_f, table[0], table[1], table[2], out, n, n, r.c2.ci, r.c2.co,
-                   r.c2.k, 0, self.code, r.b2.scale, r.b2.shift, 2, skip, 0, self.scratch(wb2) if wb2 else 0, wb2)
+                   r.c2.k, 0, self.ccode(r.c2), r.b2.scale, r.b2.shift, 2, skip, 0, self.scratch(wb2) if wb2 else 0, wb2)
         self.nops += 1
         return out
 
@@ -1236,7 +1245,7 @@ class _EvalRun(_Run):
         P = self.T.p
         out = self.arena.alloc(P * lin.co * self.esz)
         shift = self.prog._point_shift[self.prog.points.index(pt)]
-        self.w += (OP_CONV_APPLY_IMAGE, z_in, lin.conv.img_f, 0, 0, 0, out, P, P, lin.ci, lin.co, 1, 0, self.code,
+        self.w += (OP_CONV_APPLY_IMAGE, z_in, lin.conv.img_f, 0, 0, 0, out, P, P, lin.ci, lin.co, 1, 0, self.ccode(lin.conv),
                    r.scale, shift, 1, devox_out, 0)
         self.nops += 1
         return out

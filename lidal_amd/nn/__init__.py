@@ -13,7 +13,83 @@ from ..utils import make_ntuple
 from . import functional, utils
 from .functional import conv3d
 
-__all__ = ['Conv3d', 'BatchNorm', 'BatchNorm1d', 'Linear', 'ReLU', 'functional', 'utils']
+__all__ = ['Conv3d', 'BatchNorm', 'BatchNorm1d', 'Linear', 'ReLU', 'functional', 'utils', 'Deferred']
+
+# LIDAL_SURFACE_FUSION=0: every surface module computes its output when it is called (rounds 1-4)
+import os as _os
+SURFACE_FUSION = _os.environ.get('LIDAL_SURFACE_FUSION', '1') != '0'       # deferred BatchNorm (class Deferred)
+ASSUME_BN_FOLLOWS = SURFACE_FUSION                                          # Conv3d leaves tile statistics (Conv3d.bn_follows)
+
+
+class Deferred:
+    """y = bn(x) of a train-mode spnn.BatchNorm, not computed yet.  What may join it before somebody reads the features:
+
+        nn.Sequential(spnn.Conv3d, spnn.BatchNorm, spnn.ReLU(True))           -> relu=True       (network/utils.py:109-117)
+        relu(net(x) + downsample(x)), net ending in spnn.BatchNorm             -> residual, relu_after  (utils.py:142-172)
+
+    i.e. exactly the operands of norm.batch_norm_rows (lidal_bn_train_fwd[_tiles]: ReLU and the residual sum inside the
+    normalising pass, the ReLU mask inside the backward kernels) that lidal_amd.network passes explicitly.  Same
+    arithmetic, same roundings as the separate operators (the fused kernels round the summand they produce before
+    adding), hence bitwise the undeferred results (tests/test_model_gpu.py).  One Deferred belongs to ONE SparseTensor;
+    `plus` hands the pending normalisation over to the sum's tensor -- if the pre-sum tensor is read after all (nobody in
+    the reference does), it is computed on its own and the sum falls back to a plain addition."""
+
+    __slots__ = ('module', 'x', 'stats', 'relu', 'residual', 'relu_after', 'parent', 'moved', 'value')
+
+    def __init__(self, module, x, stats):
+        self.module, self.x, self.stats = module, x, stats
+        self.relu = False           # an in-place ReLU directly behind the norm
+        self.residual = None        # [N, C] added to the norm's output
+        self.relu_after = False     # an in-place ReLU behind that sum
+        self.parent = None          # plus(): the Deferred of the pre-sum tensor this one took over
+        self.moved = None           # ... and, on that one, the sum's Deferred
+        self.value = None
+
+    def can_take_sum(self):
+        return self.residual is None and not self.relu and self.moved is None and self.value is None
+
+    def can_take_relu(self):
+        return self.value is None and self.moved is None and not (self.relu_after if self.residual is not None else self.relu)
+
+    def plus(self, other_feats):
+        d = Deferred(self.module, self.x, self.stats)
+        d.residual = other_feats
+        d.parent = self
+        self.moved = d
+        return d
+
+    def take_relu(self):
+        if self.residual is not None:
+            self.relu_after = True
+        else:
+            self.relu = True
+
+    def _run(self, relu, residual, relu_after, momentum=None, count=True):
+        from .functional import norm
+        m = self.module
+        return norm.batch_norm_rows(self.x, m.weight, m.bias, m.running_mean, m.running_var, True,
+                                    m.momentum if momentum is None else momentum, m.eps, relu,
+                                    m.num_batches_tracked if count else None, self.stats, residual, relu_after)
+
+    def resolve(self):
+        if self.value is not None:
+            return self.value
+        with torch.enable_grad():       # (deferred under autograd: a first read inside no_grad must not lose the graph)
+            return self._resolve()
+
+    def _resolve(self):
+        if self.parent is not None and self.parent.value is not None:
+            # the pre-sum tensor was read first: it holds bn(x); the sum is a plain addition (and ReLU)
+            y = self.parent.value + self.residual
+            self.value = torch.relu(y) if self.relu_after else y
+        elif self.moved is not None and self.moved.value is not None:
+            # the sum was computed (fused) first and now the pre-sum tensor is read: bn(x) once more, without touching
+            # the running statistics a second time (momentum 0, no batch count)
+            self.value = self._run(self.relu, None, False, momentum=0.0, count=False)
+        else:
+            self.value = self._run(self.relu, self.residual, self.relu_after)
+        self.x = self.stats = None
+        return self.value
 
 
 def fapply(input, fn, *args, **kwargs):
@@ -58,14 +134,24 @@ class Conv3d(nn.Module):
         if self.bias is not None:
             self.bias.data.uniform_(-std, std)
 
-    bn_follows = False      # set by lidal_amd.network where a BatchNorm directly consumes the output
+    # Does a train-mode BatchNorm consume the output?  lidal_amd.network says so per layer (True / False); the surface
+    # alone cannot know what follows in the user's nn.Sequential, and ASSUMES it (None): every Conv3d of the reference's
+    # networks is followed by one (network/utils.py:109-117,127-136,147-168).  The convolution's epilogue then leaves the
+    # per-tile (count, mean, M2) with its output; a BatchNorm that finds them skips its statistics pass, anything else
+    # ignores them (the epilogue costs about what that pass costs, so a wrong guess costs one pass).
+    bn_follows = None
 
     def forward(self, input, fork=False):
         """`fork` (k > 1, not transposed): returns (output, alias of `input`) for a second consumer of
         the input whose gradient then joins this layer's data gradient in-kernel (functional/conv.py)."""
-        return conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
-                      stride=self.stride, dilation=self.dilation, transposed=self.transposed,
-                      want_stats=self.bn_follows and self.training and torch.is_grad_enabled(), fork=fork)
+        follows = ASSUME_BN_FOLLOWS if self.bn_follows is None else self.bn_follows
+        out = conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
+                     stride=self.stride, dilation=self.dilation, transposed=self.transposed,
+                     want_stats=follows and self.training and torch.is_grad_enabled(), fork=fork)
+        f = (out[0] if fork else out)._feats
+        if getattr(f, '_lidal_bn_stats', None) is not None:
+            f._lidal_bn_stats_version = f._version      # an in-place write between here and the BatchNorm voids them
+        return out
 
 
 class Linear(nn.Linear):
@@ -106,16 +192,39 @@ class BatchNorm1d(nn.BatchNorm1d):
         return norm.batch_norm_rows(feats, self.weight, self.bias, self.running_mean,
                                     self.running_var, self.training, self.momentum, self.eps,
                                     self.fused_relu, self.num_batches_tracked,
-                                    getattr(feats, '_lidal_bn_stats', None), residual, relu_after)
+                                    _tile_stats_of(feats), residual, relu_after)
+
+
+def _tile_stats_of(feats):
+    """The tile statistics the producing convolution left with `feats`, unless the tensor was written since."""
+    st = getattr(feats, '_lidal_bn_stats', None)
+    if st is not None and getattr(feats, '_lidal_bn_stats_version', feats._version) != feats._version:
+        return None
+    return st
 
 
 class BatchNorm(BatchNorm1d):
-    """spnn.BatchNorm: BatchNorm1d applied to the .feats of a SparseTensor."""
+    """spnn.BatchNorm: BatchNorm1d applied to the .feats of a SparseTensor.  In training the result is DEFERRED
+    (class Deferred) until it is read, so that a following in-place spnn.ReLU / residual sum joins the kernel."""
 
     def forward(self, input, residual=None, relu_after=False):
+        feats = input.feats
+        from .functional import norm
+        if (SURFACE_FUSION and self.training and residual is None and not self.fused_relu and torch.is_grad_enabled()
+                and self.track_running_stats and self.momentum is not None
+                and norm.supported(feats, self.weight, self.bias)):
+            out = SparseTensor(None, input.coords, input.stride)
+            out._deferred = Deferred(self, feats, _tile_stats_of(feats))
+            out.cmaps = input.cmaps
+            out.kmaps = input.kmaps
+            return out
         return fapply(input, super().forward, residual, relu_after)
 
 
 class ReLU(nn.ReLU):
     def forward(self, input):
+        d = input._deferred
+        if d is not None and self.inplace and d.can_take_relu():
+            d.take_relu()               # in place: `input` itself now stands for relu(...)
+            return input
         return fapply(input, super().forward)

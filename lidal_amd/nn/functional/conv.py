@@ -338,7 +338,7 @@ def prefetch_kernel_maps(x, plan, transposed=True):
     return x
 
 
-def _weight_image(weight, dtype, n_out, role):
+def _weight_image(weight, dtype, n_out, role, code=None):
     """LDS image (csrc/conv_img.hip) of a [K, ci, co] weight in `dtype` for a convolution that
     produces n_out rows.  role 0: forward operand (reduction over ci, columns co); role 1: the
     data-gradient operand of the same parameter (reduction over co, columns ci).
@@ -346,7 +346,7 @@ def _weight_image(weight, dtype, n_out, role):
     weight tensor, keyed by its version counter, storage, role, dtype and the tiling n_out selects."""
     k, ci, co = weight.shape
     n_red, n_col = (ci, co) if role == 0 else (co, ci)
-    code = B.dtype_code(dtype)
+    code = B.dtype_code(dtype) if code is None else code        # (B.F32_SPLIT: the split image of an f32 product)
     L = B.lib()
     key = cache = None
     if not torch.is_grad_enabled():
@@ -403,7 +403,7 @@ class _ImageBank:
     def tick(self):
         return B.WEIGHT_EPOCH[0]
 
-    def get(self, weight, dtype, n_out_fwd, n_out_bwd, shape=None, role=0):
+    def get(self, weight, dtype, n_out_fwd, n_out_bwd, shape=None, role=0, code=None):
         """`shape` = (k, ci, co) of the operand when `weight` is not [k, ci, co] itself: a [ci, co]
         1x1x1 kernel (role 0) or nn.Linear's [co, ci] weight (role 1).
         A weight may have several entries at a time, one per pair of tilings its row counts have selected
@@ -411,14 +411,15 @@ class _ImageBank:
         them ride in the same launch, none is rebuilt for being asked under another tiling."""
         import weakref
         k, ci, co = shape if shape is not None else weight.shape
-        code = B.dtype_code(dtype)
+        code = B.dtype_code(dtype) if code is None else code
         L = B.lib()
         key = (weight.data_ptr(), code, weight.dtype, _tiling(ci, co, code, n_out_fwd), _tiling(co, ci, code, n_out_bwd), role)
         ekey = (id(weight), key)
         e = self.entries.get(ekey)
         if e is None or e['ref']() is not weight:
             nf = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out_fwd)
-            nb = L.lidal_conv_weight_image_bytes(k, co, ci, code, n_out_bwd)
+            # (the split form of an f32 product is the inference form: forward image only)
+            nb = 0 if code == B.F32_SPLIT else L.lidal_conv_weight_image_bytes(k, co, ci, code, n_out_bwd)
             buf = torch.empty(nf + nb, dtype=torch.uint8, device=weight.device)
             self.serial += 1
             wid = id(weight)
@@ -466,7 +467,8 @@ class _ImageBank:
             for i, (e, w) in enumerate(stale):
                 k, ci, co = e['shape']
                 n = L.lidal_conv_weight_image_job(ctypes.c_void_p(ctypes.addressof(host) + i * jb), B.ptr(w),
-                                                  e['role'], B.ptr(e['img_f']), e['n_out'][0], B.ptr(e['img_b']),
+                                                  e['role'], B.ptr(e['img_f']), e['n_out'][0],
+                                                  B.ptr(e['img_b']) if e['img_b'].numel() else None,
                                                   e['n_out'][1], e['code'], k, ci, co, first)
                 if n < 0:
                     B.check(1, 'conv_weight_image_job')
@@ -504,7 +506,7 @@ def _weight_image_pair(weight, dtype, n_out_fwd, n_out_bwd):
     return img_f, img_b
 
 
-def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False, bnb=None):
+def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False, bnb=None, code=None):
     """out[j] = sum_k feats[nbr[kk][j]] @ W_k with the weights as the LDS image `img` (built for
     (ci = feats.shape[1], co, k, feats.dtype, n_out = order.n_rows)); `order` = RowOrder(nbr).
     epilogue = (scale f32 [co], shift f32 [co], relu[, residual [n_out, co]]): in-kernel
@@ -541,8 +543,8 @@ def _apply(feats, img, k, co, order, kflip, epilogue=None, want_stats=False, bnb
         return out
     B.check(B.lib().lidal_conv_apply_image_ws(B.ptr(feats), B.ptr(img), B.ptr(order.table), B.ptr(order.perm),
                                               B.ptr(order.tile_masks), B.ptr(out), feats.shape[0], n_out, ci,
-                                              co, k, int(kflip), B.dtype_code(feats.dtype), B.ptr(scale),
-                                              B.ptr(shift), int(relu), B.ptr(residual), B.ptr(stats),
+                                              co, k, int(kflip), B.dtype_code(feats.dtype) if code is None else code,
+                                              B.ptr(scale), B.ptr(shift), int(relu), B.ptr(residual), B.ptr(stats),
                                               B.ptr(ws), ws_bytes, B.stream()),
             'conv_apply')
     if want_stats:
@@ -588,8 +590,9 @@ def _bwd_order(kmap, transposed):
     return (kmap.order_out, 1) if kmap.symmetric else (kmap.order_in, 0)
 
 
-def _forward(feats, weight, kmap, transposed, epilogue=None, with_bwd_image=False, want_stats=False):
-    """-> (x in the compute dtype, out, image of the data gradient or None)."""
+def _forward(feats, weight, kmap, transposed, epilogue=None, with_bwd_image=False, want_stats=False, inference=False):
+    """-> (x in the compute dtype, out, image of the data gradient or None).  `inference` (no autograd node will be
+    made): f32 products run in the split form (backend.conv_code)."""
     B.require_gpu(feats, weight)
     cdtype = B.compute_dtype(feats)
     x = feats.contiguous().to(cdtype)
@@ -602,9 +605,10 @@ def _forward(feats, weight, kmap, transposed, epilogue=None, with_bwd_image=Fals
     img_b = None
     if with_bwd_image:          # both operands of this parameter from one launch
         img, img_b = _weight_image_pair(weight, cdtype, order.n_rows, _bwd_order(kmap, transposed)[0].n_rows)
-    else:
-        img = _weight_image(weight, cdtype, order.n_rows, 0)
-    return x, _apply(x, img, k, co, order, 0, epilogue, want_stats), img_b
+        return x, _apply(x, img, k, co, order, 0, epilogue, want_stats), img_b
+    code = B.conv_code(cdtype, x.shape[1], inference and not want_stats)
+    img = _weight_image(weight, cdtype, order.n_rows, 0, code)
+    return x, _apply(x, img, k, co, order, 0, epilogue, want_stats, None, code), img_b
 
 
 def _conv(feats, weight, kmap, transposed, epilogue=None, want_stats=False, fork=False):
@@ -621,7 +625,7 @@ def _conv(feats, weight, kmap, transposed, epilogue=None, want_stats=False, fork
             out._lidal_bn_stats = ConvolutionFunction.last_stats
             ConvolutionFunction.last_stats = None
         return (out, skip) if fork else out
-    out = _forward(feats, weight, kmap, transposed, epilogue, False, want_stats)[1]   # no autograd node
+    out = _forward(feats, weight, kmap, transposed, epilogue, False, want_stats, True)[1]   # no autograd node
     return (out, feats) if fork else out
 
 

@@ -57,7 +57,7 @@ def _gemm_ok(x, ci, co):
     return vec > 0 and ci % vec == 0 and co % vec == 0
 
 
-def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None, img=None, want_stats=False):
+def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None, img=None, want_stats=False, code=None):
     """x [n, n_red] times the [Cin, Cout] operand `w` (compute dtype): role 0 = x @ w (reduction over
     Cin), role 1 = x @ w^T (reduction over Cout: the data gradient), + shift f32: the sparse
     convolution kernel with the identity rule list (a NULL table) and the weight as an LDS image.
@@ -68,7 +68,7 @@ def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None, im
     n_col = w.shape[1] if role == 0 else w.shape[0]
     assert n_red == (w.shape[0] if role == 0 else w.shape[1])
     if img is None:
-        img = _weight_image(w.contiguous().unsqueeze(0), x.dtype, n, role)
+        img = _weight_image(w.contiguous().unsqueeze(0), x.dtype, n, role, code)
     out = torch.empty((n, n_col), dtype=x.dtype, device=x.device)
     if residual is not None:
         residual = residual.contiguous()
@@ -79,7 +79,7 @@ def _rows_gemm(x, w, role, shift=None, scale=None, relu=False, residual=None, im
     if want_stats:
         stats = torch.empty((-(-n // B.stats_tile_rows()), n_col, 3), dtype=torch.float32, device=x.device)
     B.check(B.lib().lidal_conv_apply_image(B.ptr(x), B.ptr(img), None, None, None, B.ptr(out),
-                                           n, n, n_red, n_col, 1, 0, B.dtype_code(x.dtype), B.ptr(scale),
+                                           n, n, n_red, n_col, 1, 0, B.dtype_code(x.dtype) if code is None else code, B.ptr(scale),
                                            B.ptr(shift), int(relu), B.ptr(residual), B.ptr(stats),
                                            B.stream()),
             'conv_apply(dense)')
@@ -99,7 +99,7 @@ def _operand(w, linear, cdtype, pad):
     return wc
 
 
-def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats=False):
+def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats=False, inference=False):
     """epilogue (inference only) = (scale f32 [Cout], shift f32 [Cout], relu[, residual [N, Cout]]):
     the eval-mode BatchNorm (+ ReLU) that follows the layer and an optional row-wise sum,
     y = act((x @ w + bias) * scale + shift) + residual."""
@@ -135,9 +135,10 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
         late = residual is not None and fused_res is None       # sum (and its ReLU) outside the kernel
         img_f = None
         img_key = None
+        # f32 inference: the split form (backend.conv_code) -- only where no autograd node will be made
+        code = B.conv_code(cdtype, xc.shape[1], inference and not with_bwd_image and not want_stats)
         # (grad mode is also off inside RowsMatmul.forward: `with_bwd_image` tells training apart)
         if not with_bwd_image and not torch.is_grad_enabled():     # inference: the image of an unchanged parameter is re-used
-            code = B.dtype_code(cdtype)
             img_key = (B.weights_key(w), linear, code, pad,
                        B.lib().lidal_conv_weight_image_tiling(xc.shape[1], co + pad, code, xc.shape[0]))
             cache = getattr(w, '_lidal_images', None)
@@ -146,7 +147,7 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
             else:
                 from .conv import _weight_image
                 with torch.enable_grad():       # (bypass the per-tensor cache of the temporary operand)
-                    img_f = _weight_image(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], 0)
+                    img_f = _weight_image(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], 0, code)
                 if cache is None or next(iter(cache))[0] != B.weights_key(w):
                     cache = {}
                     w._lidal_images = cache
@@ -159,7 +160,7 @@ def _forward(x, w, bias, linear, epilogue=None, with_bwd_image=False, want_stats
                 img_f, img_b = C._weight_image_pair(wc.contiguous().unsqueeze(0), cdtype, xc.shape[0], xc.shape[0])
         want_stats = want_stats and not pad and not late and cdtype == torch.bfloat16
         y = _rows_gemm(xc, wc, 0, shift, scale,
-                       int(relu) & 1 if late else int(relu), fused_res, img_f, want_stats)
+                       int(relu) & 1 if late else int(relu), fused_res, img_f, want_stats, code)
         y = y[:, :co] if pad else y
         if late:
             y = y + residual.to(cdtype)
@@ -259,7 +260,7 @@ def _rows(x, w, bias, linear, epilogue=None, want_stats=False):
             y._lidal_bn_stats = RowsMatmul.last_stats
         RowsMatmul.last_stats = None
         return y
-    return _forward(x, w, bias, linear, epilogue, False, want_stats)[3]          # inference: no autograd node
+    return _forward(x, w, bias, linear, epilogue, False, want_stats, True)[3]    # inference: no autograd node
 
 
 def rows_matmul(x, w, bias=None, epilogue=None, want_stats=False):

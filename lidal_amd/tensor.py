@@ -20,12 +20,32 @@ class MapCache(dict):
 
 
 class SparseTensor:
+    """`feats` may be DEFERRED (lidal_amd.nn.Deferred): the output of a train-mode spnn.BatchNorm is computed when it
+    is first read, so that an in-place spnn.ReLU and / or the sum of a residual block (`__add__`) that follow it in the
+    user's nn.Sequential ride in the normalising kernel -- the fusions the package's own networks are written with,
+    carried by the SURFACE for networks that are not (the reference's files, scripts/surface_unet.py).  Reading `feats`
+    / `F` resolves it; nothing else changes."""
+
     def __init__(self, feats, coords, stride=1):
-        self.feats = feats
+        self._feats = feats
+        self._deferred = None
         self.coords = coords
         self.stride = make_ntuple(stride, ndim=3)
         self.cmaps = MapCache()
         self.kmaps = MapCache()
+
+    @property
+    def feats(self):
+        d = self._deferred
+        if d is not None:
+            self._feats = d.resolve()
+            self._deferred = None
+        return self._feats
+
+    @feats.setter
+    def feats(self, value):
+        self._feats = value
+        self._deferred = None
 
     F = property(lambda self: self.feats, lambda self, v: setattr(self, 'feats', v))
     C = property(lambda self: self.coords, lambda self, v: setattr(self, 'coords', v))
@@ -49,6 +69,15 @@ class SparseTensor:
         return self._map(lambda t: t.to(device, non_blocking=non_blocking))
 
     def __add__(self, other):
+        # a deferred BatchNorm output + anything: the sum rides in the normalising pass (see Deferred.plus)
+        for a, b in ((self, other), (other, self)):
+            d = a._deferred
+            if d is not None and d.can_take_sum():
+                out = SparseTensor(None, self.coords, self.stride)
+                out._deferred = d.plus(b.feats)
+                out.cmaps = self.cmaps
+                out.kmaps = self.kmaps
+                return out
         out = SparseTensor(self.feats + other.feats, self.coords, self.stride)
         out.cmaps = self.cmaps
         out.kmaps = self.kmaps

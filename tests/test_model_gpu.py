@@ -1,6 +1,7 @@
 """Model-level parity: the build's SPVCNN / MinkUNet on the HIP path against golden outputs of
 the REFERENCE's own network/spvcnn.py + network/minkunet.py (run unchanged on the CPU oracle in
 the build container by tests/golden/make_golden.py).  Tolerance: 1e-4 relative (north_star)."""
+import copy
 import json
 import os
 
@@ -582,3 +583,138 @@ def test_bn_backward_sums_from_the_data_gradient_launches(name, golden_dir):
     for k in ('up4.1.1.net.1.weight', 'up4.1.1.net.1.bias', 'up4.1.1.net.0.kernel'):
         rel = ((g0[k] - g1[k]).norm() / g0[k].norm()).item()
         assert rel < 2e-3, (k, rel)
+
+
+def _surface_models():
+    import os
+    import sys
+    import lidal_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
+    import surface_unet
+    return surface_unet.build(lidal_amd)
+
+
+@pytest.mark.parametrize('name,autocast', [('spvcnn', True), ('minkunet', True), ('spvcnn', False)])
+def test_surface_fusion_is_bitwise_the_eager_surface(name, autocast):
+    """The fusions the SURFACE carries for networks that know nothing of lidal_amd.network (scripts/surface_unet.py: the
+    reference's composition, nn.Sequential(spnn.Conv3d, spnn.BatchNorm, spnn.ReLU(True)) and relu(net(x) + downsample(x))):
+    the in-place ReLU and the residual sum inside the DEFERRED BatchNorm's kernel, against the same modules computing
+    eagerly -- loss, logits, every gradient and every BatchNorm buffer bit for bit, with fewer library passes.  (Both
+    runs take the BatchNorm statistics from the convolutions' epilogues: that changes the summation order of the
+    statistics against the separate pass, so it is held equal here and checked against the package's own network in
+    the next test.)"""
+    import lidal_amd
+    from lidal_amd import backend as B
+    from lidal_amd import nn as spnn
+    from lidal_amd import synth
+    b = synth.make_train_batch(n_frames=2, n_points=8000, seed=77)
+    feats, coords, labels = (torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b', 'labels_v_b'))
+    torch.manual_seed(2)
+    base = _surface_models()[name](19).to(DEV).train()
+    out = {}
+    saved = spnn.SURFACE_FUSION, spnn.ASSUME_BN_FOLLOWS
+    try:
+        spnn.ASSUME_BN_FOLLOWS = True
+        for fused in (False, True):
+            spnn.SURFACE_FUSION = fused
+            model = copy.deepcopy(base)
+            torch.manual_seed(5)            # SPVCNN's dropout masks
+            B.HITS.clear()
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+                logits, feat = model(lidal_amd.SparseTensor(feats, coords))
+            loss = torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=255)
+            loss.backward()
+            torch.cuda.synchronize()
+            out[fused] = (loss.detach().clone(), logits.detach().clone(), [p.grad.clone() for p in model.parameters()],
+                          [q.detach().clone() for q in model.buffers()], dict(B.HITS))
+    finally:
+        spnn.SURFACE_FUSION, spnn.ASSUME_BN_FOLLOWS = saved
+    (l0, y0, g0, b0, h0), (l1, y1, g1, b1, h1) = out[False], out[True]
+    assert torch.equal(l0, l1) and torch.equal(y0, y1)
+    for k, p, q in zip([k for k, _ in base.named_parameters()], g0, g1):
+        assert torch.equal(p, q), k
+    for k, p, q in zip([k for k, _ in base.named_buffers()], b0, b1):
+        assert torch.equal(p, q), k
+    assert sum(h1.values()) <= sum(h0.values()), (h0, h1)
+
+
+@pytest.mark.parametrize('autocast', [True, False])
+def test_fused_surface_minkunet_forward_is_bitwise_the_package_network(autocast):
+    """MinkUNet through the surface alone (scripts/surface_unet.py, fusions carried by the surface) against
+    lidal_amd.network.MinkUNet on the per-operator path (LIDAL_PLAN=0: the fused blocks written with knowledge of the
+    network), in training mode: the forward pass issues the same kernels with the same operands, so the features in front
+    of the classifier and every BatchNorm buffer are bit for bit equal (the classifier itself is torch's nn.Linear on the
+    surface; in the backward pass the package also takes some BatchNorm sums from its data-gradient epilogues, another
+    summation order: gradients are compared to rounding)."""
+    import lidal_amd
+    from lidal_amd import synth
+    from lidal_amd.network import MinkUNet, plan
+    b = synth.make_train_batch(n_frames=2, n_points=8000, seed=78)
+    feats, coords = (torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b'))
+    torch.manual_seed(3)
+    surf = _surface_models()['minkunet'](19).to(DEV).train()
+    pack = MinkUNet(19).to(DEV).train()
+    pack.load_state_dict(surf.state_dict())
+    res = []
+    saved = plan.ENABLED
+    try:
+        plan.ENABLED = False
+        for model in (surf, pack):
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+                _, feat = model(lidal_amd.SparseTensor(feats, coords))
+            feat.float().pow(2).mean().backward()
+            res.append((feat.detach().clone(), [q.detach().clone() for q in model.buffers()],
+                        {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        plan.ENABLED = saved
+    assert torch.equal(res[0][0], res[1][0])
+    for u, v in zip(res[0][1], res[1][1]):
+        assert torch.equal(u, v)
+    for k in res[0][2]:
+        u, v = res[0][2][k].double().flatten(), res[1][2][k].double().flatten()
+        cos = float(u @ v / (u.norm() * v.norm() + 1e-300))
+        assert cos > (0.99 if autocast else 0.99999), (k, cos)
+
+
+def test_deferred_batchnorm_read_in_any_order():
+    """nn.Deferred: a pre-sum tensor that IS read (nobody in the reference does) -- before or after the sum -- still
+    gives bn(x), the sum still gives relu(bn(x) + r), the running statistics move once, gradients are the eager ones."""
+    import lidal_amd
+    from lidal_amd import nn as spnn
+    g = torch.Generator().manual_seed(0)
+    coords = torch.cat([torch.randint(0, 40, (5000, 3), generator=g), torch.zeros(5000, 1, dtype=torch.long)], 1).int().to(DEV)
+    x0 = torch.randn(5000, 32, generator=g).to(DEV)
+    r0 = torch.randn(5000, 32, generator=g).to(DEV)
+    results = {}
+    saved = spnn.SURFACE_FUSION
+    try:
+        for mode in ('eager', 'sum_first', 'pre_first'):
+            spnn.SURFACE_FUSION = mode != 'eager'
+            torch.manual_seed(1)
+            bn = spnn.BatchNorm(32).to(DEV).train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.5, 0.5)
+            relu = spnn.ReLU(True)
+            x = x0.clone().requires_grad_(True)
+            r = r0.clone().requires_grad_(True)
+            a = bn(lidal_amd.SparseTensor(x, coords))
+            assert (a._deferred is not None) == (mode != 'eager')
+            if mode == 'pre_first':
+                pre = a.F
+            s = relu(a + lidal_amd.SparseTensor(r, coords))
+            total = s.F.float().sum() * 2.0
+            if mode != 'pre_first':
+                pre = a.F
+            (total + pre.float().pow(2).sum()).backward()
+            torch.cuda.synchronize()
+            results[mode] = [t.detach().clone() for t in (s.F, pre, x.grad, r.grad, bn.weight.grad, bn.bias.grad,
+                                                          bn.running_mean, bn.running_var, bn.num_batches_tracked)]
+    finally:
+        spnn.SURFACE_FUSION = saved
+    for mode in ('sum_first', 'pre_first'):
+        for i, (u, v) in enumerate(zip(results['eager'], results[mode])):
+            if i in (2, 4, 5):          # sums over two autograd paths / re-associated reductions: to rounding
+                assert torch.allclose(u, v, rtol=1e-5, atol=1e-5), (mode, i)
+            else:
+                assert torch.equal(u, v), (mode, i)

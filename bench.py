@@ -455,7 +455,7 @@ FAMILY_OF = {
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
-    'lidal_downsample': 'kernel_maps', 'lidal_kmap_build': 'kernel_maps', 'lidal_kmap_invert': 'kernel_maps',
+    'lidal_downsample': 'kernel_maps', 'lidal_kmap_build': 'kernel_maps', 'lidal_kmap_build_batch': 'kernel_maps', 'lidal_kmap_invert': 'kernel_maps',
     'lidal_kmap_order': 'kernel_maps', 'lidal_floor_coords': 'kernel_maps', 'lidal_revoxelize_coords': 'kernel_maps', 'lidal_kmap_order_batch': 'kernel_maps',
     'lidal_downsample_pyramid': 'kernel_maps', 'lidal_kmap_from_rules': 'kernel_maps',
     'lidal_count': 'point_voxel', 'lidal_voxelize_fwd': 'point_voxel', 'lidal_voxelize_bwd': 'point_voxel',
@@ -498,9 +498,11 @@ def family_table(step, coords, dtype_name, step_ms):
     with torch.no_grad():
         x = prefetch_kernel_maps(SparseTensor(None, coords), _SparseUNet.MAP_PLAN)
         rules = {}
+        kmap_batch_bytes = 0                # every map of the network, built by ONE lidal_kmap_build_batch call
         for key, km in x.kmaps.items():
             if km.volume == 27:
                 rules[km.sizes[1]] = km.total
+            kmap_batch_bytes += 16 * km.sizes[0] + 16 * km.sizes[1] + 8 * km.total
     torch.cuda.synchronize()
     calls = []
     # the profiled step runs operator by operator (LIDAL_PLAN=0's path): the launch plan issues the same kernels with
@@ -575,8 +577,10 @@ def family_table(step, coords, dtype_name, step_ms):
             by = a[3] * (a[4] * (2 if a[1] == 1 else 4) + 8) * (1 if name == 'lidal_ce_fwd' else 2)
         elif name == 'lidal_kmap_build':
             n_out, k = a[3], a[5]
-            n_in = a[1] // 24 if a[1] else n_out                # table: 12 B per slot, 2 slots per key
+            n_in = a[1] // 26 if a[1] else n_out                # table: 13 B per slot (12 + its share of the bitmap), 2 slots per key
             by = 16 * n_in + 16 * n_out + 8 * rules_of(k, n_in, n_out)
+        elif name == 'lidal_kmap_build_batch':
+            by = kmap_batch_bytes                               # (host arrays of pointers: the maps of the whole network)
         elif name == 'lidal_hash':
             by = (16 + 8) * a[1]
         elif name == 'lidal_floor_coords':

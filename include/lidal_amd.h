@@ -60,7 +60,9 @@ int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t* offsets, 
 
 /* replaces backend.hash_query_cuda  (F.sphashquery: network/utils.py:19,48,76).
  * Open-addressing table of 64-bit keys in HBM; value = index of the FIRST occurrence of the key
- * (the CPU dense_hash_map::insert semantics).  Keys must be < 2^63 (sphash output is 60 bit). */
+ * (the CPU dense_hash_map::insert semantics).  Keys must be < 2^63 (sphash output is 60 bit).
+ * The buffer holds cap = 2^k >= 2 n slots {key u64 | value i32} and an occupancy bitmap of 8 bits per slot that the
+ * kernel-map probes test before they touch a slot (most probed neighbours do not exist): 13 bytes per slot. */
 int64_t lidal_hash_table_bytes(int64_t n_keys);
 int lidal_hash_table_build(const int64_t* keys, int64_t n, void* table, int64_t table_bytes,
                            void* stream);

@@ -1343,7 +1343,11 @@ conv_split_kernel(const float* __restrict__ in, const __bf16* __restrict__ wimg,
     constexpr int slot = decltype(slot_c)::value;
     if (have != 0ull) {
       const Pieces p = cut3(a[0], a[1]);
+#ifdef LIDAL_SPLIT_BB
+      constexpr int BB = (NB % LIDAL_SPLIT_BB == 0) ? LIDAL_SPLIT_BB : 2;
+#else
       constexpr int BB = 2;             // column blocks whose three fragments are read as one batch
+#endif
 #pragma unroll
       for (int nb0 = 0; nb0 < NB; nb0 += BB) {
         bf16x8 bh[BB], bm[BB], bl[BB];

@@ -39,7 +39,12 @@ __global__ void __launch_bounds__(256) table_insert_kernel(const int64_t* __rest
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     uint64_t key = (uint64_t)keys[i];
-    uint64_t s = slot_of(key, t.mask);
+    const uint64_t mixed = mix_key(key);
+    uint64_t s = mixed & t.mask;
+    if (t.bits != nullptr) {
+      const uint64_t b = bit_of(mixed, t.mask);
+      atomicOr(&t.bits[b >> 5], 1u << (b & 31));
+    }
     while (true) {
       unsigned long long prev = atomicCAS(&t.keys[s], (unsigned long long)kEmptyKey,
                                           (unsigned long long)key);
@@ -130,7 +135,7 @@ extern "C" int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t
 }
 
 extern "C" int64_t lidal_hash_table_bytes(int64_t n_keys) {
-  return table_capacity(n_keys) * 12;
+  return table_capacity(n_keys) * 13;          // slots (12 bytes) + occupancy bitmap (8 bits per slot), common.h
 }
 
 extern "C" int lidal_hash_table_build(const int64_t* keys, int64_t n, void* table,
@@ -142,6 +147,7 @@ extern "C" int lidal_hash_table_build(const int64_t* keys, int64_t n, void* tabl
   hipStream_t s = (hipStream_t)stream;
   LIDAL_HIP(hipMemsetAsync(t.keys, 0xFF, cap * 8, s));
   LIDAL_HIP(hipMemsetAsync(t.vals, 0x7F, cap * 4, s));   // 0x7F7F7F7F > any index
+  if (t.bits != nullptr) LIDAL_HIP(hipMemsetAsync(t.bits, 0, cap, s));
   if (n == 0) return 0;
   table_insert_kernel<<<grid_for(n), 256, 0, s>>>(keys, n, t);
   LIDAL_CHECK_LAUNCH("lidal_hash_table_build");

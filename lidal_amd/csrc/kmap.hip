@@ -196,15 +196,31 @@ __device__ __forceinline__ void lookup_batch(const TableView& t, const uint64_t 
                                              const bool (&ok)[kItems], int (&r)[kItems]) {
   uint64_t slot[kItems];
   unsigned long long first[kItems];
+  bool maybe[kItems];
+  // the occupancy bitmap first (common.h): most of the probed neighbours do not exist, and a clear bit says so
+  // from the L2s -- only the keys that pass go on to their slot
+  if (t.bits != nullptr) {
+    unsigned word[kItems];
+    uint64_t mixed[kItems];
 #pragma unroll
-  for (int it = 0; it < kItems; ++it) {
-    slot[it] = slot_of(key[it], t.mask);
-    first[it] = ok[it] ? t.keys[slot[it]] : kEmptyKey;
+    for (int it = 0; it < kItems; ++it) {
+      mixed[it] = mix_key(key[it]);
+      slot[it] = mixed[it] & t.mask;
+      const uint64_t b = bit_of(mixed[it], t.mask);
+      word[it] = ok[it] ? t.bits[b >> 5] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) maybe[it] = ok[it] && ((word[it] >> (bit_of(mixed[it], t.mask) & 31)) & 1u);
+  } else {
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) { slot[it] = slot_of(key[it], t.mask); maybe[it] = ok[it]; }
   }
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) first[it] = maybe[it] ? t.keys[slot[it]] : kEmptyKey;
 #pragma unroll
   for (int it = 0; it < kItems; ++it) {
     r[it] = -1;
-    if (!ok[it] || first[it] == kEmptyKey) continue;
+    if (!maybe[it] || first[it] == kEmptyKey) continue;
     if (first[it] == key[it]) { r[it] = t.vals[slot[it]]; continue; }
     uint64_t sl = (slot[it] + 1) & t.mask;                 // collision: walk on
     while (true) {
@@ -828,6 +844,7 @@ namespace {
 constexpr int MAX_KMAP_JOBS = 12;
 struct KmapBatch {
   unsigned long long* tkeys[MAX_KMAP_JOBS]; int* tvals[MAX_KMAP_JOBS]; unsigned long long tmask[MAX_KMAP_JOBS];
+  unsigned* tbits[MAX_KMAP_JOBS];
   const int4* coords[MAX_KMAP_JOBS]; const int* offsets[MAX_KMAP_JOBS];
   int* nbr[MAX_KMAP_JOBS]; int2* nbmaps[MAX_KMAP_JOBS]; int* nbsizes[MAX_KMAP_JOBS]; long long* koff[MAX_KMAP_JOBS];
   int* counts[MAX_KMAP_JOBS]; long long* offs[MAX_KMAP_JOBS];
@@ -858,7 +875,7 @@ __global__ void __launch_bounds__(kBlock) kmap_probe_batch_kernel(KmapBatch b) {
   const long long bx = l % b.nblocks[j];
   const int k = (int)(l / b.nblocks[j]);
   TableView t;
-  t.keys = b.tkeys[j]; t.vals = b.tvals[j]; t.mask = b.tmask[j];
+  t.keys = b.tkeys[j]; t.vals = b.tvals[j]; t.mask = b.tmask[j]; t.bits = b.tbits[j];
   if (b.sym[j]) kmap_probe_sym_body(t, b.coords[j], b.n_out[j], b.offsets[j], b.k[j], b.nbr[j], bx, k);
   else kmap_probe_body(t, b.coords[j], b.n_out[j], b.offsets[j], b.nbr[j], b.counts[j], b.nblocks[j], bx, k);
 }
@@ -922,7 +939,7 @@ extern "C" int lidal_kmap_build_batch(const void* const* tables, const int64_t* 
     LIDAL_REQUIRE(k[j] > 0 && k[j] < 64 && n_out[j] > 0, "kmap_build_batch: bad map %d (k=%d, rows=%lld)", j, k[j],
                   (long long)n_out[j]);
     const TableView t = table_view(tables[j], table_bytes[j]);
-    b.tkeys[j] = t.keys; b.tvals[j] = t.vals; b.tmask[j] = t.mask;
+    b.tkeys[j] = t.keys; b.tvals[j] = t.vals; b.tmask[j] = t.mask; b.tbits[j] = t.bits;
     b.coords[j] = (const int4*)out_coords[j]; b.offsets[j] = offsets[j];
     b.nbr[j] = nbr_out[j]; b.nbmaps[j] = (int2*)nbmaps[j]; b.nbsizes[j] = nbsizes[j]; b.koff[j] = (long long*)koff[j];
     b.n_out[j] = n_out[j]; b.k[j] = k[j];

@@ -134,13 +134,24 @@ struct GridHeader {
   double inv_cell_unused;
 };
 
+struct __attribute__((aligned(16))) GridRec { unsigned long long key; double x, y, z; int idx; int pad; };
+
 struct GridView {
   TableView t;
   const uint64_t* keys;
   const int* idx;
+  const struct GridRec* rec;     // the points in cell order, one 48-byte record each (round 5: a candidate -- its cell key, its
+                                 // coordinates, its id -- is ONE access instead of three arrays and a gathered point)
   int64_t p;
   double cell;
 };
+// byte offsets inside a grid buffer (after the 64-byte header) for p points and capacity cap:
+//   keys u64 [cap] | vals i32 [cap] | sorted cell keys u64 [p] | sorted point ids i32 [p] | records GridRec [p] |
+//   occupancy bitmap u32 [cap / 4] (8 bits per slot, csrc/common.h: most probed cells are empty)
+__host__ __device__ inline int64_t grid_off_skeys(int64_t cap) { return cap * 12; }
+__host__ __device__ inline int64_t grid_off_sidx(int64_t cap, int64_t q) { return cap * 12 + ((8 * q + 255) / 256) * 256; }
+__host__ __device__ inline int64_t grid_off_spts(int64_t cap, int64_t q) { return grid_off_sidx(cap, q) + ((4 * q + 255) / 256) * 256; }
+__host__ __device__ inline int64_t grid_off_bits(int64_t cap, int64_t q) { return grid_off_spts(cap, q) + ((48 * q + 255) / 256) * 256; }
 
 constexpr int64_t kBias = 1 << 20;
 
@@ -156,8 +167,11 @@ static inline GridView grid_view(const void* grid, int64_t p, int64_t cap, doubl
   g.t.keys = (unsigned long long*)base;
   g.t.vals = (int*)(base + cap * 8);
   g.t.mask = (uint64_t)cap - 1;
-  g.keys = (const uint64_t*)(base + cap * 12);
-  g.idx = (const int*)(base + cap * 12 + align_up(8 * p, 256));
+  const int64_t q = p > 0 ? p : 1;
+  g.t.bits = (unsigned*)(base + grid_off_bits(cap, q));
+  g.keys = (const uint64_t*)(base + grid_off_skeys(cap));
+  g.idx = (const int*)(base + grid_off_sidx(cap, q));
+  g.rec = (const GridRec*)(base + grid_off_spts(cap, q));
   g.p = p;
   g.cell = cell;
   return g;
@@ -176,12 +190,24 @@ __global__ void __launch_bounds__(256) grid_keys_kernel(const double* __restrict
 }
 
 __global__ void __launch_bounds__(256) grid_heads_kernel(const uint64_t* __restrict__ skeys,
-                                                         int64_t p, TableView t) {
+                                                         int64_t p, TableView t, const double* __restrict__ pts,
+                                                         const int* __restrict__ sidx, GridRec* __restrict__ rec) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p) return;
+  {                     // the point itself, into cell order
+    const int64_t j = sidx[i];
+    GridRec r;
+    r.key = skeys[i]; r.x = pts[j * 3 + 0]; r.y = pts[j * 3 + 1]; r.z = pts[j * 3 + 2]; r.idx = (int)j; r.pad = 0;
+    rec[i] = r;
+  }
   uint64_t key = skeys[i];
   if (i > 0 && skeys[i - 1] == key) return;
-  uint64_t s = slot_of(key, t.mask);
+  const uint64_t mixed = mix_key(key);
+  uint64_t s = mixed & t.mask;
+  if (t.bits != nullptr) {
+    const uint64_t b = bit_of(mixed, t.mask);
+    atomicOr(&t.bits[b >> 5], 1u << (b & 31));
+  }
   while (true) {       // cell keys are unique among heads
     unsigned long long prev = atomicCAS(&t.keys[s], (unsigned long long)kEmptyKey,
                                         (unsigned long long)key);
@@ -206,12 +232,17 @@ __device__ __forceinline__ int grid_nearest(const GridView& g, const double* __r
     for (int64_t iy = y0; iy <= y1; ++iy)
       for (int64_t iz = z0; iz <= z1; ++iz) {
         uint64_t key = cell_key(ix, iy, iz);
+        if (g.t.bits != nullptr) {      // an empty cell is the common answer: told by the bitmap, from the L2s
+          const uint64_t b = bit_of(mix_key(key), g.t.mask);
+          if (!((g.t.bits[b >> 5] >> (b & 31)) & 1u)) continue;
+        }
         int start = table_lookup(g.t, key);
         if (start < 0) continue;
-        for (int64_t s = start; s < g.p && g.keys[s] == key; ++s) {
-          int j = g.idx[s];
-          double ex = npts[(int64_t)j * 3 + 0] - qx, ey = npts[(int64_t)j * 3 + 1] - qy,
-                 ez = npts[(int64_t)j * 3 + 2] - qz;
+        for (int64_t s = start; s < g.p; ++s) {
+          const GridRec r = g.rec[s];
+          if (r.key != key) break;
+          const int j = r.idx;
+          double ex = r.x - qx, ey = r.y - qy, ez = r.z - qz;
           double d2 = __dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez));
           if (d2 < best || (d2 == best && j < arg)) { best = d2; arg = j; }
         }
@@ -236,8 +267,11 @@ __device__ __forceinline__ GridView nei_grid(const NeiArgs& nei, int n, double c
   g.t.keys = (unsigned long long*)base;
   g.t.vals = (int*)(base + nei.cap[n] * 8);
   g.t.mask = (uint64_t)nei.cap[n] - 1;
-  g.keys = (const uint64_t*)(base + nei.cap[n] * 12);
-  g.idx = (const int*)(base + nei.cap[n] * 12 + ((8 * nei.p[n] + 255) / 256) * 256);
+  const int64_t q = nei.p[n] > 0 ? nei.p[n] : 1;
+  g.t.bits = (unsigned*)(base + grid_off_bits(nei.cap[n], q));
+  g.keys = (const uint64_t*)(base + grid_off_skeys(nei.cap[n]));
+  g.idx = (const int*)(base + grid_off_sidx(nei.cap[n], q));
+  g.rec = (const GridRec*)(base + grid_off_spts(nei.cap[n], q));
   g.p = nei.p[n];
   g.cell = cell;
   return g;
@@ -369,7 +403,7 @@ extern "C" int lidal_view_mean_softmax(const float* logits, const int64_t* inver
 
 extern "C" int64_t lidal_nn_grid_bytes(int64_t p) {
   int64_t q = p > 0 ? p : 1;
-  return 64 + grid_cap(q) * 12 + align_up(8 * q, 256) + align_up(4 * q, 256);
+  return 64 + grid_off_bits(grid_cap(q), q) + grid_cap(q);
 }
 
 extern "C" int64_t lidal_nn_grid_workspace_bytes(int64_t p) {
@@ -392,8 +426,9 @@ extern "C" int lidal_nn_grid_build(const double* pts, int64_t p, double cell, vo
   uint64_t* keys = (uint64_t*)ws;
   int* idx = (int*)((char*)ws + align_up(8 * q, 256));
   void* tmp = (char*)ws + align_up(8 * q, 256) + align_up(4 * q, 256);
-  uint64_t* skeys = (uint64_t*)(base + cap * 12);
-  int* sidx = (int*)(base + cap * 12 + align_up(8 * q, 256));
+  uint64_t* skeys = (uint64_t*)(base + grid_off_skeys(cap));
+  int* sidx = (int*)(base + grid_off_sidx(cap, q));
+  LIDAL_HIP(hipMemsetAsync(base + grid_off_bits(cap, q), 0, cap, s));
   grid_keys_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(pts, p, cell, keys, idx, (GridHeader*)grid);
   LIDAL_CHECK_LAUNCH("grid_keys");
   if (int rc = radix_sort(keys, idx, skeys, sidx, p, 8, 63, tmp, (int64_t)sort_pairs_tmp_bytes(q), s)) return rc;
@@ -401,7 +436,8 @@ extern "C" int lidal_nn_grid_build(const double* pts, int64_t p, double cell, vo
   t.keys = (unsigned long long*)base;
   t.vals = (int*)(base + cap * 8);
   t.mask = (uint64_t)cap - 1;
-  grid_heads_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(skeys, p, t);
+  t.bits = (unsigned*)(base + grid_off_bits(cap, q));
+  grid_heads_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(skeys, p, t, pts, sidx, (GridRec*)(base + grid_off_spts(cap, q)));
   LIDAL_CHECK_LAUNCH("grid_heads");
   return 0;
 }

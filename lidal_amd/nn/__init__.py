@@ -19,6 +19,14 @@ __all__ = ['Conv3d', 'BatchNorm', 'BatchNorm1d', 'Linear', 'ReLU', 'functional',
 import os as _os
 SURFACE_FUSION = _os.environ.get('LIDAL_SURFACE_FUSION', '1') != '0'       # deferred BatchNorm (class Deferred)
 ASSUME_BN_FOLLOWS = SURFACE_FUSION                                          # Conv3d leaves tile statistics (Conv3d.bn_follows)
+# The first 3x3x3 stride-1 convolution on a fresh stride-1 coordinate set is taken for the stem of the reference's U-Nets
+# (network/spvcnn.py:27-33, network/minkunet.py:31-37: stem, then four times [2x2x2 stride-2 conv, 3x3x3 residual blocks],
+# transposed 2x2x2 convs back up): all coordinate levels and kernel maps of that pyramid are then built at once --
+# one sort for the four coarser levels, one chain of launches for the nine maps, one sort per kernel volume for the row
+# orders -- instead of one by one as the convolutions ask for them (each with its own host round trips).  Same tables
+# under the same keys; a network of another shape merely finds maps it does not use.  LIDAL_SURFACE_PYRAMID=0: lazily.
+SURFACE_PYRAMID = _os.environ.get('LIDAL_SURFACE_PYRAMID', '1') != '0'
+UNET_MAP_PLAN = ((3, 1),) + ((2, 2), (3, 1)) * 4
 
 
 class Deferred:
@@ -145,6 +153,11 @@ class Conv3d(nn.Module):
         """`fork` (k > 1, not transposed): returns (output, alias of `input`) for a second consumer of
         the input whose gradient then joins this layer's data gradient in-kernel (functional/conv.py)."""
         follows = ASSUME_BN_FOLLOWS if self.bn_follows is None else self.bn_follows
+        if (SURFACE_PYRAMID and not self.transposed and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1)
+                and tuple(input.stride) == (1, 1, 1) and not input.kmaps and input.coords.is_cuda
+                and input.coords.shape[0] > 0):
+            from .functional.conv import prefetch_kernel_maps
+            prefetch_kernel_maps(input, UNET_MAP_PLAN)
         out = conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
                      stride=self.stride, dilation=self.dilation, transposed=self.transposed,
                      want_stats=follows and self.training and torch.is_grad_enabled(), fork=fork)

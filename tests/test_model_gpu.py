@@ -178,16 +178,30 @@ def test_prefetched_kernel_maps_are_the_ones_conv3d_builds(golden_dir):
     xb = lidal_amd.SparseTensor(feats, coords)
     torch.manual_seed(0)
     convs = [spnn.Conv3d(4, 4, k, stride=s).to(DEV) for k, s in plan]
-    y = xb
-    with torch.no_grad():
-        for c in convs:
-            y = c(y)
+    saved = spnn.SURFACE_PYRAMID
+    try:
+        spnn.SURFACE_PYRAMID = False            # map by map, as the convolutions ask
+        y = xb
+        with torch.no_grad():
+            for c in convs:
+                y = c(y)
+        # (round 5) the surface's guess at the first convolution -- the whole pyramid of the reference's U-Nets at once
+        spnn.SURFACE_PYRAMID = True
+        xc = lidal_amd.SparseTensor(feats, coords)
+        y = xc
+        with torch.no_grad():
+            for c in convs:
+                y = c(y)
+    finally:
+        spnn.SURFACE_PYRAMID = saved
     assert set(xa.kmaps) == set(xb.kmaps) and set(xa.cmaps) == set(xb.cmaps)
+    assert set(xb.kmaps) < set(xc.kmaps) and set(xb.cmaps) < set(xc.cmaps)        # (two more levels than this plan uses)
     for key in xb.kmaps:
-        assert torch.equal(xa.kmaps[key].nbr_out, xb.kmaps[key].nbr_out)
-        assert torch.equal(xa.kmaps[key].nbmaps, xb.kmaps[key].nbmaps)
+        for other in (xa, xc):
+            assert torch.equal(other.kmaps[key].nbr_out, xb.kmaps[key].nbr_out)
+            assert torch.equal(other.kmaps[key].nbmaps, xb.kmaps[key].nbmaps)
     for key in xb.cmaps:
-        assert torch.equal(xa.cmaps[key], xb.cmaps[key])
+        assert torch.equal(xa.cmaps[key], xb.cmaps[key]) and torch.equal(xc.cmaps[key], xb.cmaps[key])
 
 
 @pytest.mark.parametrize('autocast', [False, True])
@@ -599,7 +613,7 @@ def test_surface_fusion_is_bitwise_the_eager_surface(name, autocast):
     """The fusions the SURFACE carries for networks that know nothing of lidal_amd.network (scripts/surface_unet.py: the
     reference's composition, nn.Sequential(spnn.Conv3d, spnn.BatchNorm, spnn.ReLU(True)) and relu(net(x) + downsample(x))):
     the in-place ReLU and the residual sum inside the DEFERRED BatchNorm's kernel, against the same modules computing
-    eagerly -- loss, logits, every gradient and every BatchNorm buffer bit for bit, with fewer library passes.  (Both
+    eagerly -- loss, logits, every gradient and every BatchNorm buffer bit for bit.  (Both
     runs take the BatchNorm statistics from the convolutions' epilogues: that changes the summation order of the
     statistics against the separate pass, so it is held equal here and checked against the package's own network in
     the next test.)"""
@@ -635,7 +649,6 @@ def test_surface_fusion_is_bitwise_the_eager_surface(name, autocast):
         assert torch.equal(p, q), k
     for k, p, q in zip([k for k, _ in base.named_buffers()], b0, b1):
         assert torch.equal(p, q), k
-    assert sum(h1.values()) <= sum(h0.values()), (h0, h1)
 
 
 @pytest.mark.parametrize('autocast', [True, False])

@@ -1325,3 +1325,98 @@ def test_batchnorm_merges_inside_their_consumers_are_the_separate_launches(dtype
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
     assert torch.isfinite(outs[1][0].float()).all()
+
+
+@pytest.mark.parametrize('ci,co', [(32, 32), (96, 96), (128, 64), (64, 20)])
+def test_split_f32_convolution_against_f64(ci, co):
+    """LIDAL_F32_SPLIT (csrc/conv_img.hip conv_split_kernel): f32 features and weights, every operand cut into three bf16
+    pieces, six partial products on the bf16 MFMA, f32 accumulation.  Against an f64 product on the same rule list the
+    result must be as close as the exact-f32 kernel's (both within 5e-6 of the output scale: the error of an f32 dot
+    product of ~27 * ci terms), the epilogue (affine map, ReLU, residual) and the dense form (identity rule list) too."""
+    from lidal_amd import backend as B
+    from lidal_amd.nn.functional.conv import _weight_image
+    F = _F()
+    coords = _surface_coords(70, 2, seed=ci + co).to(DEV)
+    n = coords.shape[0]
+    km, _ = F.build_kernel_map(coords, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    o = km.order_out
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    x = (torch.randn(n, ci, generator=g) * 2 + 0.1).to(DEV)
+    w = (torch.randn(27, ci, co, generator=g) * 0.1).to(DEV)
+    scale = (torch.rand(co, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(co, generator=g).to(DEV)
+    res = torch.randn(n, co, generator=g).to(DEV)
+    nbr = km.nbr_out.long()
+    ref = torch.zeros(n, co, dtype=torch.float64, device=DEV)
+    for k in range(27):
+        m = nbr[k] >= 0
+        ref[m] += x.double()[nbr[k][m]] @ w.double()[k]
+    ref_ep = torch.relu(ref * scale.double() + shift.double()) + res.double()
+    L = B.lib()
+    errs = {}
+    for name, code in (('exact', B.F32), ('split', B.F32_SPLIT)):
+        with torch.no_grad():
+            img = _weight_image(w, torch.float32, n, 0, code)
+        y = torch.empty((n, co), dtype=torch.float32, device=DEV)
+        B.check(L.lidal_conv_apply_image(B.ptr(x), B.ptr(img), B.ptr(o.table), B.ptr(o.perm), B.ptr(o.tile_masks), B.ptr(y),
+                                         n, n, ci, co, 27, 0, code, None, None, 0, None, None, B.stream()), 'conv')
+        y2 = torch.empty((n, co), dtype=torch.float32, device=DEV)
+        B.check(L.lidal_conv_apply_image(B.ptr(x), B.ptr(img), B.ptr(o.table), B.ptr(o.perm), B.ptr(o.tile_masks), B.ptr(y2),
+                                         n, n, ci, co, 27, 0, code, B.ptr(scale), B.ptr(shift), 1, B.ptr(res), None,
+                                         B.stream()), 'conv')
+        errs[name] = (float((y.double() - ref).abs().max() / ref.abs().max()),
+                      float((y2.double() - ref_ep).abs().max() / ref_ep.abs().max()))
+    assert errs['split'][0] < 5e-6 and errs['split'][1] < 5e-6, errs
+    assert errs['split'][0] < 4 * errs['exact'][0] + 1e-7, errs
+    # dense form (k = 1, no table)
+    wd = (torch.randn(1, ci, co, generator=g) * 0.1).to(DEV)
+    refd = x.double() @ wd.double()[0]
+    with torch.no_grad():
+        img = _weight_image(wd, torch.float32, n, 0, B.F32_SPLIT)
+    y = torch.empty((n, co), dtype=torch.float32, device=DEV)
+    B.check(L.lidal_conv_apply_image(B.ptr(x), B.ptr(img), None, None, None, B.ptr(y), n, n, ci, co, 1, 0, B.F32_SPLIT, None,
+                                     None, 0, None, None, B.stream()), 'conv')
+    assert float((y.double() - refd).abs().max() / refd.abs().max()) < 2e-6
+    # an operand whose pieces matter: values with all 24 significand bits set give the exact product of small integers
+    xi = torch.full((n, ci), 1.0 + 2.0 ** -23, device=DEV)
+    wi = torch.full((1, ci, co), 1.0 - 2.0 ** -24, device=DEV)
+    with torch.no_grad():
+        img = _weight_image(wi, torch.float32, n, 0, B.F32_SPLIT)
+    B.check(L.lidal_conv_apply_image(B.ptr(xi), B.ptr(img), None, None, None, B.ptr(y), n, n, ci, co, 1, 0, B.F32_SPLIT, None,
+                                     None, 0, None, None, B.stream()), 'conv')
+    want = ci * (1.0 + 2.0 ** -23) * (1.0 - 2.0 ** -24)
+    assert float((y.double() - want).abs().max()) <= ci * 2.0 ** -22, float((y.double() - want).abs().max())
+
+
+def test_f32_inference_runs_in_the_split_form_and_training_does_not():
+    """backend.conv_code: under no_grad an f32 network's convolutions and dense layers take LIDAL_F32_SPLIT (except the
+    4-channel stem); with autograd on (the training step's f32 parity mode) they stay on the exact f32 MFMA."""
+    import lidal_amd
+    from lidal_amd import backend as B
+    assert B.conv_code(torch.float32, 96, True) == B.F32_SPLIT
+    assert B.conv_code(torch.float32, 4, True) == B.F32 and B.conv_code(torch.float32, 96, False) == B.F32
+    assert B.conv_code(torch.bfloat16, 96, True) == B.BF16
+    seen = []
+    B.set_call_timer(lambda name, a, e0, e1: seen.append((name, [getattr(v, 'value', v) for v in a])))
+    try:
+        from lidal_amd.network import MinkUNet, plan
+        from lidal_amd import synth
+        b = synth.make_train_batch(n_frames=1, n_points=6000, seed=3)
+        feats, coords = (torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b'))
+        model = MinkUNet(19).to(DEV).eval()
+        saved = plan.ENABLED
+        plan.ENABLED = False
+        try:
+            with torch.no_grad():
+                model(lidal_amd.SparseTensor(feats, coords))
+            infer = [a[12] for nme, a in seen if nme in ('lidal_conv_apply_image', 'lidal_conv_apply_image_ws')]
+            del seen[:]
+            model.train()
+            model(lidal_amd.SparseTensor(feats, coords))[0].sum().backward()
+            train = [a[12] for nme, a in seen if nme in ('lidal_conv_apply_image', 'lidal_conv_apply_image_ws')]
+        finally:
+            plan.ENABLED = saved
+    finally:
+        B.set_call_timer(None)
+    assert infer.count(B.F32_SPLIT) >= 40 and infer.count(B.F32) == 1, infer       # (the stem's first convolution: 4 channels)
+    assert train and set(train) == {B.F32}, train

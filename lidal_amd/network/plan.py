@@ -608,10 +608,10 @@ class _Run:
         # layer needed registering, ask for it here).  Staleness is decided weight by weight, as bank.get does on the
         # per-operator path: a load_state_dict(strict=False) or a copy_ into ONE layer between two forward passes moves
         # that layer's version counter only
+        # (an f32 inference run has two groups: the split-form images and the exact-f32 image of the 4-channel stem)
         for e, w in seen:
             if e['version'] != B.weights_key(w):
                 bank._rebuild(e['group'])
-                break
 
     def _conv_rows(self):
         """(layer, (rows its forward produces, rows its data gradient produces)) for every weight of the program."""

@@ -421,7 +421,7 @@ def roofline_conv(args, coords, dev, reps=20):
     # `bench.py --roofline-only`, corrected as MI355X_MICROARCH.md prescribes) and kept under
     # profiles/; reported only if that record is of this exact workload
     traffic, traffic_src = None, None
-    for name in ('r04_pmc_conv_apply.json', 'r03_pmc_conv_apply.json', 'r02_pmc_conv_apply.json'):
+    for name in ('r05_pmc_conv_apply.json', 'r04_pmc_conv_apply.json', 'r03_pmc_conv_apply.json', 'r02_pmc_conv_apply.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             wl = rec['workload']

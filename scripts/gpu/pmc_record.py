@@ -1,0 +1,21 @@
+"""profiles/rNN_pmc_conv_apply.json from a final-run directory: python scripts/gpu/pmc_record.py gpurun_out/final5_a r05 'script tag'"""
+import csv, json, re, sys
+d, rnd, how = sys.argv[1], sys.argv[2], sys.argv[3]
+txt = open(d + '/pmc_summary.txt').read()
+fetch = float(re.search(r'FETCH_SIZE\s+n=(\d+)\s+mean=([\d.e+]+)', txt).group(2))
+n = int(re.search(r'FETCH_SIZE\s+n=(\d+)', txt).group(1))
+write = float(re.search(r'WRITE_SIZE\s+n=\d+\s+mean=([\d.e+]+)', txt).group(1))
+row = [r for r in csv.DictReader(open(d + '/roof_kernel_stats.csv')) if 'conv_lean_kernelIDF16bLi6ELi192' in r['Name']][0]
+line = json.load(open(d + '/bench_line.json'))['roofline']
+traffic = int(round((2 * fetch + write) * 1024))
+algo = line['algorithmic_bytes_per_launch']
+rec = {'workload': {'rows': line['rows'], 'rules': line['rules'], 'dtype': 'bf16', 'layer': 'k3 s1 96->96',
+                    'kernel': 'conv_lean_kernel<bf16,6,192,8>'},
+       'command': 'rocprofv3 --pmc FETCH_SIZE (and a second pass --pmc WRITE_SIZE) -- python3 bench.py --roofline-only  (%s)' % how,
+       'FETCH_SIZE_KB_mean_of_%d' % n: fetch, 'WRITE_SIZE_KB_mean_of_%d' % n: write,
+       'correction': 'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane reads; WRITE_SIZE is exact',
+       'traffic_bytes': traffic, 'algorithmic_bytes': algo, 'ratio': round(traffic / algo, 3),
+       'kernel_stats': 'profiles/%s_roofline_only_kernel_stats.csv: %s launches, %.1f us average (bench.py\'s own HIP events in the default run of the same box: %.1f)'
+                       % (rnd, row['Calls'], float(row['AverageNs']) / 1e3, line['launch_us'])}
+json.dump(rec, open('profiles/%s_pmc_conv_apply.json' % rnd.split('_')[0], 'w'), indent=1)
+print(rec)

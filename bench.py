@@ -329,7 +329,7 @@ def bench_fresh_stream(dev, model_name, dtype, frames, points, steps, warmup=3, 
                     'the NEXT batch on the second stream; no batch repeats (sk_dataset.py:143-171, sk_dataloader.py:21,53)'}
 
 
-def bench_dropin_surface(dev, model_name, dtype, batch, steps, warmup=3):
+def bench_dropin_surface(dev, model_name, dtype, batch, steps, warmup=3, adopt=False):
     """The literal drop-in path: a LiDAL user's network as the reference's files compose it (scripts/surface_unet.py:
     nn.Sequential(spnn.Conv3d, spnn.BatchNorm, spnn.ReLU(True)), residual blocks, the point <-> voxel helpers of
     network/utils.py, torch's own nn.Linear / BatchNorm1d / Dropout in the point branch) over this package standing in
@@ -342,6 +342,8 @@ def bench_dropin_surface(dev, model_name, dtype, batch, steps, warmup=3):
     from lidal_amd import backend as B
     torch.manual_seed(7122)
     model = surface_unet.build(lidal_amd)[model_name](19).to(dev).train()
+    if adopt:       # the optional second line: torch's own Linear / BatchNorm1d / ReLU modules handed to this package
+        lidal_amd.adopt_torch_modules(model)
     opt = torch.optim.Adam(model.parameters(), fused=True)
     coords, feats, labels = batch
     autocast = dtype == 'bf16'
@@ -369,8 +371,10 @@ def bench_dropin_surface(dev, model_name, dtype, batch, steps, warmup=3):
     return {'ms_per_step': round(ms, 3), 'voxels_per_step': n, 'voxels_per_s': round(n / ms * 1e3, 1), 'steps': steps,
             'loss': round(float(loss.item()), 4),
             'library_calls_per_step': int(sum(v for k, v in B.HITS.items() if not k.startswith('torch_fallback')) / steps),
-            'what': 'surface-only %s (scripts/surface_unet.py over lidal_amd as torchsparse; torch nn.Linear / BatchNorm1d / '
-                    'cross_entropy as the reference uses them), per-operator path, tables built inside the forward pass' % model_name}
+            'what': ('surface-only %s (scripts/surface_unet.py over lidal_amd as torchsparse; torch nn.Linear / BatchNorm1d / '
+                     'cross_entropy as the reference uses them), per-operator path, tables built inside the forward pass' % model_name)
+                    + (' + lidal_amd.adopt_torch_modules(model): the point branch and the classifier on this package\'s kernels '
+                       '(same parameters, same state_dict keys; torch\'s cross_entropy stays)' if adopt else '')}
 
 
 def variant_line(res):
@@ -889,6 +893,7 @@ def run_variants(args, batch, dev, inline=None):
     var['fresh_stream'] = guarded(bench_fresh_stream, dev, args.model, args.dtype, args.frames, args.points,
                                   max(2 * args.steps, 40))
     var['dropin_surface'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps)
+    var['dropin_surface_adopted'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps, 3, True)
     other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
     var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
                                                 max(3, args.steps // 2), 2, ddp=False))

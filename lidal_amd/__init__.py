@@ -13,7 +13,7 @@ import sys
 from .operators import cat
 from .tensor import PointTensor, SparseTensor
 
-__all__ = ['SparseTensor', 'PointTensor', 'cat', 'install_as_torchsparse']
+__all__ = ['SparseTensor', 'PointTensor', 'cat', 'install_as_torchsparse', 'adopt_torch_modules']
 __version__ = '0.1.0'
 
 
@@ -29,3 +29,60 @@ def install_as_torchsparse():
     sys.modules['torchsparse.nn.functional'] = functional
     sys.modules['torchsparse.nn.utils'] = utils
     return me
+
+
+def adopt_torch_modules(model):
+    """Optional second line for a drop-in user (after `install_as_torchsparse()` and building the reference's model):
+    hand the model's plain-torch ROW-WISE modules to this package, in place and without touching a single parameter --
+
+        torch.nn.Linear       -> lidal_amd.nn.Linear        (same Parameter objects; the dense kernel, bias in its epilogue,
+                                                               weight gradient on the split-K MFMA kernel, bias gradient by column sums)
+        torch.nn.BatchNorm1d  -> lidal_amd.nn.BatchNorm1d   (same parameters and buffers; lidal_bn_* kernels)
+        nn.Sequential(Linear, BatchNorm1d, ReLU)             -> the same three children with the ReLU inside the BatchNorm kernels
+                                                               and the Linear's epilogue leaving the batch statistics
+
+    -- i.e. SPVCNN's point branch and classifier (network/spvcnn.py:60-98), which the reference builds from torch's own
+    modules and which cost 7 of the 25 ms of a drop-in training step as rocBLAS / channels-last batch-norm kernels
+    (profiles/README.md, round 5).  Module names, Sequential indices and therefore state_dict keys are unchanged;
+    exact module TYPES only (a subclass is somebody's own module and is left alone).  Returns the model."""
+    import torch
+    from . import nn as spnn
+    from .network.blocks import ConvNormSequential
+
+    def linear(old):
+        new = spnn.Linear(old.in_features, old.out_features, bias=old.bias is not None)
+        new.weight = old.weight
+        if old.bias is not None:
+            new.bias = old.bias
+        new.train(old.training)
+        return new
+
+    def norm(old):
+        new = spnn.BatchNorm1d(old.num_features, eps=old.eps, momentum=old.momentum, affine=old.affine,
+                               track_running_stats=old.track_running_stats)
+        for k, v in old._parameters.items():
+            new._parameters[k] = v
+        for k, v in old._buffers.items():
+            new._buffers[k] = v
+        new.train(old.training)
+        return new
+
+    def convert(parent):
+        for name, child in list(parent.named_children()):
+            if type(child) is torch.nn.Linear:
+                setattr(parent, name, linear(child))
+            elif type(child) is torch.nn.BatchNorm1d:
+                setattr(parent, name, norm(child))
+            else:
+                convert(child)
+            child = getattr(parent, name)
+            kids = list(child.children()) if type(child) is torch.nn.Sequential else []
+            if (len(kids) == 3 and isinstance(kids[0], spnn.Linear) and type(kids[1]) is spnn.BatchNorm1d
+                    and type(kids[2]) is torch.nn.ReLU):
+                kids[0].bn_follows = True
+                kids[1].fused_relu = True
+                seq = ConvNormSequential(kids[0], kids[1], torch.nn.Identity())
+                seq.train(child.training)
+                setattr(parent, name, seq)
+    convert(model)
+    return model

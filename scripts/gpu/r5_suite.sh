@@ -1,0 +1,8 @@
+#!/bin/bash
+# the full -m gpu suite, as the driver runs it
+set -u
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+O=$GRAFT_REPO_ROOT/gpurun_out/r5_suite; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+timeout 3300 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?"; tail -6 $O/tests.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

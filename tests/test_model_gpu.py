@@ -765,11 +765,10 @@ def test_adopted_torch_modules_keep_parameters_and_results(autocast):
     tol = 2e-2 if autocast else 1e-5
     assert abs(out[0][0] - out[1][0]) <= tol * abs(out[0][0])
     assert (out[0][1] - out[1][1]).abs().max() <= tol * out[0][1].abs().max()
-    largest = max(float(g.norm()) for g in out[0][2].values())
     for k in out[0][2]:
         u, v = out[0][2][k].flatten(), out[1][2][k].flatten()
-        if float(u.norm()) < 1e-6 * largest and float(v.norm()) < 1e-6 * largest:
-            continue            # (the bias of a Linear in front of a train-mode BatchNorm: its true gradient is zero)
+        if k.startswith('point_transforms.') and k.endswith('.0.bias'):
+            continue            # (the bias of a Linear in front of a train-mode BatchNorm: its true gradient is zero, both are noise)
         cos = float(u @ v / (u.norm() * v.norm() + 1e-300))
         assert cos > (0.98 if autocast else 0.9999), (k, cos)
         # (end-to-end f32 gradients of the randomly initialised 49-layer net move by 1e-4 .. 1e-3 under ANY change of a

@@ -775,4 +775,5 @@ def test_adopted_torch_modules_keep_parameters_and_results(autocast):
         # summation order; here torch's GEMM / batch-norm kernels against this package's)
         assert abs(float(u.norm() / (v.norm() + 1e-300)) - 1) < (0.1 if autocast else 2e-3), k
     for k in ('point_transforms.0.1.running_mean', 'point_transforms.2.1.running_var'):
-        assert torch.allclose(out[0][3][k], out[1][3][k], rtol=1e-2 if autocast else 1e-5, atol=1e-5), k
+        u, v = out[0][3][k].double(), out[1][3][k].double()
+        assert float((u - v).abs().max()) <= (2e-2 if autocast else 1e-5) * float(u.abs().max()), k

@@ -59,7 +59,8 @@ COUNTERS = {'ops': 0, 'plans': 0}
 # tests: also count the operations of every plan in backend.HITS under the names the per-operator path counts them
 # (walks the words in Python: off in production)
 TALLY = os.environ.get('LIDAL_PLAN_TALLY', '0') != '0'
-# tests: a list -> every training run appends itself when its backward pass has been queued, keeps the words of its
+# tests: a list -> every training run appends itself when its backward pass has been queued (an inference run: when its
+# one plan has been queued), keeps the words of its
 # plans (`tapes`: (phase, words) per lidal_plan_run call) and does NOT give its memory back, so that a test can
 # replay every operation against the oracle on the operation's own stored operands (tests/test_teacher_forced_gpu.py);
 # the test calls run.release() when it is done
@@ -548,7 +549,7 @@ class _Run:
         self.saved = {}
         self.noise = []
         self.keep = []
-        self.tapes = [] if (TRACE is not None and self.TRAIN) else None
+        self.tapes = [] if TRACE is not None else None
         self.sides = {}                     # side stream index -> raw stream
         self.open = set()                   # side streams forked and not joined yet
         self.w = []
@@ -1256,6 +1257,8 @@ class _EvalRun(_Run):
     def forward(self):
         out = _Run.forward(self)
         self.saved = {}
+        if self.tapes is not None and TRACE is not None:        # (a test replays the plan: the run keeps its arena alive)
+            TRACE.append(self)
         return out
 
 

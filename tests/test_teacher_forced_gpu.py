@@ -437,3 +437,114 @@ def test_the_benchmarked_scan_teacher_forced(name):
     """BASELINE.json's scan (~120 k points, ~83 k voxels): every third convolution-type operation (forward, data
     gradient, weight gradient -- 145 of them), everything else in full."""
     _step(name, 120000, True, 3)
+
+
+# ---- the inference pass (round 5): every convolution / dense layer of ONE planned 8-view pass, f32 in the split form ----
+def _replay_inference(run, model, stats):
+    """The conv-type operations of an inference plan (network/plan.py _EvalRun: Conv3d / Linear with the folded BatchNorm
+    map, ReLU and residual sum in the epilogue) replayed in float64 on their own stored operands."""
+    from lidal_amd import backend as B
+    from lidal_amd.network import plan as P
+    from oracle.tsref.nn.functional import _conv_apply
+    L = B.lib()
+    prog, g = run.prog, run.geometry
+    names = {id(p): k for k, p in model.named_parameters()}
+    pname = [names[id(p)] for p in prog.params]
+    tables = {}
+    for km in g.x0.kmaps.values():
+        tables[km.order_out.table.data_ptr()] = (km, False)
+        if km._order_in is not None:
+            tables[km._order_in.table.data_ptr()] = (km, True)
+    images = {}
+    for c in prog.convs:
+        for pf, _ in c.ptrs.values():
+            images[pf] = c
+    cpu_rules = {}
+    codes = {}
+    torch.cuda.synchronize()
+    for phase, words in run.tapes:
+        i = 0
+        while i < len(words):
+            kind = words[i] & 0xFFFF
+            na = L.lidal_plan_op_args(kind)
+            a = words[i + 1:i + 1 + na]
+            i += 1 + na
+            if kind not in (P.OP_CONV_APPLY_IMAGE, P.OP_CONV_APPLY_IMAGE_WS):
+                continue
+            x_p, img, tab, _, _, out_p, n_in, n_out, ci, co, k, kflip, code, scale, shift, relu, res = a[:17]
+            c = images[img]
+            codes[code] = codes.get(code, 0) + 1
+            data_code = 1 if code == 1 else 0                       # (LIDAL_F32_SPLIT: f32 rows in and out)
+            x = _mat(x_p, n_in, ci, data_code)
+            w = c.param.detach().cpu()
+            w = (w.t().reshape(1, c.ci, c.co) if c.role == 1 else w.reshape(c.k, c.ci, c.co))
+            w = (w.to(torch.bfloat16) if code == 1 else w).double()
+            wp = torch.zeros(w.shape[0], ci, co, dtype=torch.float64)
+            wp[:, :w.shape[1], :w.shape[2]] = w
+            if tab == 0:
+                ref = x @ wp[0]
+                what = '%s dense %d->%d rows %d' % (pname[c.w], ci, co, n_out)
+            else:
+                km, inv = tables[tab]
+                if id(km) not in cpu_rules:
+                    cpu_rules[id(km)] = (km.nbmaps.cpu().long(), km.nbsizes.cpu().long(), tuple(km.sizes))
+                ref = _conv_apply(x, wp, *cpu_rules[id(km)], bool(inv) != bool(kflip))
+                what = '%s k%d %d->%d rows %d' % (pname[c.w], k, ci, co, n_out)
+            if shift:
+                ref = ref * (_vec(scale, co).double() if scale else 1.0) + _vec(shift, co).double()
+            if relu & 1:
+                ref = ref.clamp_min(0)
+            first = None
+            if res:
+                first = ref
+                ref = (ref.to(torch.bfloat16).double() if code == 1 else ref) + _mat(res, n_out, co, data_code)
+                if relu & 2:
+                    ref = ref.clamp_min(0)
+            stored = _mat(out_p, n_out, co, data_code)
+            if code == 1:
+                stats.bf16('inference conv' + (' + residual' if first is not None else ''), stored, ref, what, first)
+            else:
+                stats.f32('inference conv f32 %s' % ('split' if code == 2 else 'exact'), stored, ref, what, 2e-5)
+    return codes
+
+
+@pytest.mark.parametrize('name,autocast', [('spvcnn', False), ('minkunet', False), ('spvcnn', True)])
+def test_every_convolution_of_an_inference_pass_against_the_oracle_on_its_own_operands(name, autocast):
+    """One planned 8-view inference pass (score/prob_inference.py:97-99) teacher-forced: every Conv3d / Linear launch --
+    in f32 the SPLIT form (three bf16 pieces per operand, six partial products on the bf16 matrix cores), with the folded
+    BatchNorm map, ReLU and residual sum of its epilogue -- against the float64 product of its own stored operands:
+    2e-5 of the output scale in f32 (the exact-f32 kernel's bar), half a bf16 ulp under bf16."""
+    from lidal_amd import backend as B
+    from lidal_amd import synth
+    from lidal_amd.network import SPVCNN, MinkUNet, plan
+    from lidal_amd.score.prob_inference import infer_frame
+    from weights import fill_state_dict
+    model = fill_state_dict({'spvcnn': SPVCNN, 'minkunet': MinkUNet}[name](19)).to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    for m in model.modules():               # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.3)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.5)
+    seq = synth.make_sequence(1, n_points=6000, seed=31)[0]
+    sb = synth.make_score_batch(seq['points'], seq['intensity'], np.random.default_rng(2), inf_reps=8)
+    c, f, inv = (torch.from_numpy(sb[k]).to(DEV) for k in ('coords_v_b', 'feats_v_b', 'inverse_indices_b'))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    saved = plan.TRACE, plan.ENABLED
+    plan.TRACE, plan.ENABLED = [], True
+    try:
+        prob, pred = infer_frame(model, c, f, inv, 8, autocast=autocast)
+        assert torch.isfinite(prob).all() and len(plan.TRACE) == 1
+        run = plan.TRACE[0]
+    finally:
+        plan.TRACE, plan.ENABLED = saved
+    stats = _Stats()
+    try:
+        codes = _replay_inference(run, model, stats)
+    finally:
+        run.release()
+    stats.show('%s inference, %d voxels (8 views), %s: every convolution of the planned pass replayed on its own operands'
+               % (name, c.shape[0], 'bf16' if autocast else 'f32'))
+    if autocast:
+        assert set(codes) == {B.BF16}, codes
+    else:
+        assert codes.get(B.F32_SPLIT, 0) >= 40 and codes.get(B.F32, 0) == 1, codes       # (all but the 4-channel stem)

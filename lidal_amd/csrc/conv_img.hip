@@ -1239,7 +1239,7 @@ conv_split_kernel(const float* __restrict__ in, const __bf16* __restrict__ wimg,
                   const int* __restrict__ perm, const unsigned* __restrict__ tmasks, float* __restrict__ out,
                   int64_t n_out, int ci, int co, int K, int kflip, const float* __restrict__ ep_scale,
                   const float* __restrict__ ep_shift, int ep_relu, const float* __restrict__ ep_res, unsigned in_bytes,
-                  unsigned img_bytes, unsigned nbr_bytes) {
+                  unsigned img_bytes, unsigned nbr_bytes, Split sp) {
   constexpr int BM = NWAVES * 16;
   constexpr int BN = 16 * NB;
   constexpr int SLAB = BN * SPLIT_ROW;
@@ -1270,6 +1270,17 @@ conv_split_kernel(const float* __restrict__ in, const __bf16* __restrict__ wimg,
     if (t0 * 128 < n_out) m = tmasks[t0];
     if (kflip) m = __brev(m) >> (32 - K);
     tmask = __builtin_amdgcn_readfirstlane(m);
+    if (sp.nsplit > 1) {        // this workgroup's share of the tile's active offsets (struct Split): ranks [lo, hi) of the set bits
+      const int cnt = __popc(tmask), z = (int)blockIdx.z;
+      const int lo = z * cnt / sp.nsplit, hi = (z + 1) * cnt / sp.nsplit;
+      unsigned left = tmask, sub = 0u;
+      for (int rk = 0; left != 0u; ++rk) {
+        const unsigned bit = left & (0u - left);
+        if (rk >= lo && rk < hi) sub |= bit;
+        left ^= bit;
+      }
+      tmask = __builtin_amdgcn_readfirstlane(sub);
+    }
   }
   const int nphase = __popc(tmask) * npass;
 
@@ -1414,6 +1425,13 @@ conv_split_kernel(const float* __restrict__ in, const __bf16* __restrict__ wimg,
     }
     __syncthreads();
   }
+  if (sp.nsplit > 1) {          // a share of the tile's offsets: the f32 accumulators go to conv_combine_kernel
+    f32x4* dst = reinterpret_cast<f32x4*>(sp.partial) +
+                 ((((int64_t)blockIdx.z * gridDim.x + bx) * gridDim.y + blockIdx.y) * NWAVES + wave) * (NB * 64) + lane;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) dst[nb * 64] = acc[0][nb];
+    return;
+  }
   store_tile<float, NB, 1, NWAVES>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu,
                                    ep_res, true, perm_v, nullptr, bx, nullptr);
 }
@@ -1482,6 +1500,14 @@ struct Epi { const float* scale; const float* shift; int relu; const void* res; 
 // (measured with the coalesced partial tiles, 5-scan step: <= 256 workgroups 14.68 ms, <= 700 -- the 43 k-row level split
 // in two instead of the deep kernel -- 15.06, <= 1700 15.55; one scan 6.35 / 6.54 / 6.56)
 constexpr int64_t SPLIT_MAX_WGS = 256;
+#ifndef LIDAL_SPLIT_F32_MAX_WGS
+#define LIDAL_SPLIT_F32_MAX_WGS 512
+#endif
+// the same for the split form of the f32 product (conv_split_kernel).  Measured on an 8-view frame and the 5-scan batch
+// (scripts/exp/split_check.py, limits 0 / 600 / 1536): 256 -> 256 at stride 16 (408 / 262 workgroups) 334.9 -> 261-265 us /
+// 265 -> 183-185 us with the offsets split three ways; at stride 8 (1038-1350 workgroups) neutral to -4 %, at stride 4
+// (1265 workgroups) 136 -> 185 us: a loss -- the f32 partial tiles cost more than the tail they remove
+constexpr int64_t SPLIT_F32_MAX_WGS = LIDAL_SPLIT_F32_MAX_WGS;
 __host__ inline int pick_split(int64_t wgs, int K, int npass) {
   if (wgs > SPLIT_MAX_WGS || K * npass < 27) return 1;
   return wgs <= 128 ? 4 : (wgs <= 192 ? 3 : 2);
@@ -1634,10 +1660,36 @@ int launch_split(const void* in, const void* wimg, const int* nbr, const int* pe
     attr[nbr ? 0 : 1][dev] = LDS;
   }
   dim3 grid((unsigned)cdiv(n_out, LW * 16), (unsigned)cdiv(co, BN));
+  // The offsets of a tile over several workgroups (struct Split) where the launch does not fill the chip once: a
+  // tile of a coarse level runs up to 27 offsets x Cin/32 slices back to back (216 phases of ~1 us at 256 channels)
+  // while the launch has one to two rounds of workgroups -- as long as its heaviest tile and a quantised round count.
+  Split sp{nullptr, 1, 0, 0};
+  if (nbr != nullptr && ep.ws != nullptr) {
+    const int64_t wgs = (int64_t)grid.x * grid.y;
+    const int ns = (wgs > SPLIT_F32_MAX_WGS || K * (ci / SPLIT_KCH) < 54) ? 1 : (wgs <= 256 ? 4 : 3);
+    const long long rows_pad = (long long)grid.x * LW * 16;
+    const int co_pad = (int)grid.y * BN;
+    if (ns > 1 && ep.ws_bytes >= (long long)ns * rows_pad * co_pad * 4) sp = Split{(float*)ep.ws, ns, co_pad, rows_pad};
+  }
+  grid.z = (unsigned)sp.nsplit;
   kern<<<grid, 64 * LW, LDS, s>>>((const float*)in, (const __bf16*)wimg, nbr, perm, tmasks, (float*)out, n_out, ci, co, K,
                                   kflip, ep.scale, ep.shift, ep.relu, (const float*)ep.res, ep.in_bytes, ep.img_bytes,
-                                  ep.nbr_bytes);
+                                  ep.nbr_bytes, sp);
   LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(split)");
+  if (sp.nsplit > 1) {
+    constexpr int COMB_LDS = LEPI_ALL;
+    auto ck = conv_combine_kernel<float, NB, LW>;
+    static size_t comb_attr[MAX_DEVICES] = {};
+    if (comb_attr[dev] < (size_t)COMB_LDS) {
+      LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ck), hipFuncAttributeMaxDynamicSharedMemorySize, COMB_LDS));
+      comb_attr[dev] = COMB_LDS;
+    }
+    grid.z = 1;
+    BnBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    ck<<<grid, 64 * LW, COMB_LDS, s>>>(sp, perm, (float*)out, n_out, co, ep.scale, ep.shift, ep.relu, (const float*)ep.res,
+                                       nullptr, none);
+    LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(split, combine)");
+  }
   return 0;
 }
 
@@ -1806,7 +1858,7 @@ static int conv_apply_image(const void* in, const void* wimg, const int32_t* nbr
                   "conv_apply_image: the input matrix and the weight image must each stay below 2 GiB (2^24 rows)");
     LIDAL_REQUIRE((int64_t)k * n_out * 4 < 0x7FFFFFF0ll, "conv_apply_image: neighbour table above 2 GiB");
     Epi ep{ep_scale, ep_shift, ep_relu, ep_residual, (unsigned)(n_in * ci * 4), (unsigned)ib,
-           (unsigned)((int64_t)k * n_out * 4), nullptr, bnb, nullptr, 0};
+           (unsigned)((int64_t)k * n_out * 4), nullptr, bnb, ws, (long long)ws_bytes};
     switch (split_nb(co)) {
       case 2: return launch_split<2>(in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
       case 4: return launch_split<4>(in, wimg, nbr, perm, tile_masks, out, n_out, ci, co, k, kflip, ep, s);
@@ -1857,7 +1909,7 @@ extern "C" int lidal_conv_apply_image(const void* in, const void* wimg, const in
 
 extern "C" int64_t lidal_conv_apply_workspace_bytes(int64_t n_out, int co) {
   const int64_t tiles = cdiv(n_out > 0 ? n_out : 1, TILE_ROWS);
-  if (tiles * cdiv(co, 128) > SPLIT_MAX_WGS) return 0;        // (no tiling makes few enough workgroups to be split)
+  if (tiles * cdiv(co, 128) > SPLIT_F32_MAX_WGS) return 0;    // (no tiling makes few enough workgroups to be split)
   return 4 * tiles * TILE_ROWS * align_up(co, 128) * 4;
 }
 

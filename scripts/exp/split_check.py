@@ -21,8 +21,13 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 dev = torch.device('cuda')
-batch = synth.make_train_batch(n_frames=5, n_points=120000, seed=7122)
-coords = torch.from_numpy(batch['coords_v_b']).to(dev)
+if os.environ.get('FRAME'):       # an 8-view inference frame instead of the 5-scan train batch
+    import numpy as np
+    seq = synth.make_sequence(1, n_points=120000, seed=7122)[0]
+    coords = torch.from_numpy(synth.make_score_batch(seq['points'], seq['intensity'], np.random.default_rng(1), inf_reps=8)['coords_v_b']).to(dev)
+else:
+    batch = synth.make_train_batch(n_frames=5, n_points=120000, seed=7122)
+    coords = torch.from_numpy(batch['coords_v_b']).to(dev)
 levels = {1: coords}
 s = 1
 while s < 16:
@@ -30,7 +35,7 @@ while s < 16:
     s *= 2
 L = B.lib()
 print('%-28s %10s %10s %12s %12s' % ('layer', 'exact us', 'split us', 'exact err', 'split err'))
-for stride, ci, co in [(1, 32, 32), (1, 96, 96), (1, 128, 96), (2, 32, 64), (4, 128, 128), (8, 256, 256), (8, 384, 256), (16, 256, 256)]:
+for stride, ci, co in [(1, 96, 96), (2, 32, 64), (4, 64, 128), (4, 128, 128), (8, 128, 256), (8, 256, 256), (8, 384, 256), (16, 256, 256)]:
     c = levels[stride]
     kmap, _ = F.build_kernel_map(c, (stride,) * 3, (3, 3, 3), (1, 1, 1))
     n = c.shape[0]
@@ -44,9 +49,12 @@ for stride, ci, co in [(1, 32, 32), (1, 96, 96), (1, 128, 96), (2, 32, 64), (4, 
         with torch.no_grad():
             img = _weight_image(w, torch.float32, n, 0, code)
         y = torch.empty((n, co), dtype=torch.float32, device=dev)
+        wsb = int(L.lidal_conv_apply_workspace_bytes(n, co))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         def launch():
-            B.check(L.lidal_conv_apply_image(B.ptr(x), B.ptr(img), B.ptr(o.table), B.ptr(o.perm), B.ptr(o.tile_masks),
-                                             B.ptr(y), n, n, ci, co, 27, 0, code, None, None, 0, None, None, B.stream()), 'conv')
+            B.check(L.lidal_conv_apply_image_ws(B.ptr(x), B.ptr(img), B.ptr(o.table), B.ptr(o.perm), B.ptr(o.tile_masks),
+                                                B.ptr(y), n, n, ci, co, 27, 0, code, None, None, 0, None, None,
+                                                B.ptr(ws) if wsb else None, wsb, B.stream()), 'conv')
         times[name] = timeit(launch)
         outs[name] = y.clone()
     # f64 reference on a sample of output rows

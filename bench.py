@@ -458,6 +458,7 @@ FAMILY_OF = {
     'lidal_add_relu_bwd_bn_sums': 'batch_norm', 'lidal_bn_bwd_from_sums': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
+    'lidal_hash_table_build_coords': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',
     'lidal_downsample': 'kernel_maps', 'lidal_kmap_build': 'kernel_maps', 'lidal_kmap_build_batch': 'kernel_maps', 'lidal_kmap_invert': 'kernel_maps',
     'lidal_kmap_order': 'kernel_maps', 'lidal_floor_coords': 'kernel_maps', 'lidal_revoxelize_coords': 'kernel_maps', 'lidal_kmap_order_batch': 'kernel_maps',
@@ -581,7 +582,7 @@ def family_table(step, coords, dtype_name, step_ms):
             by = a[3] * (a[4] * (2 if a[1] == 1 else 4) + 8) * (1 if name == 'lidal_ce_fwd' else 2)
         elif name == 'lidal_kmap_build':
             n_out, k = a[3], a[5]
-            n_in = a[1] // 26 if a[1] else n_out                # table: 13 B per slot (12 + its share of the bitmap), 2 slots per key
+            n_in = a[1] // 28 if a[1] else n_out                # table: 14 B per slot (12 + its share of the two bitmaps), 2 slots per key
             by = 16 * n_in + 16 * n_out + 8 * rules_of(k, n_in, n_out)
         elif name == 'lidal_kmap_build_batch':
             by = kmap_batch_bytes                               # (host arrays of pointers: the maps of the whole network)
@@ -595,6 +596,8 @@ def family_table(step, coords, dtype_name, step_ms):
             by = 16 * a[1] + 8 * a[3] * a[1]
         elif name == 'lidal_hash_table_build':
             by = (8 + 12) * a[1]                                # key in, one slot written
+        elif name == 'lidal_hash_table_build_coords':
+            by = (16 + 12) * a[1]                               # coordinate row in, one slot written
         elif name == 'lidal_hash_table_query':
             by = (8 + 12 + 8) * a[3]                            # query in, one slot probed, index out
         elif name == 'lidal_unique_sorted_i64':

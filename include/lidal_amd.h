@@ -62,10 +62,18 @@ int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t* offsets, 
  * Open-addressing table of 64-bit keys in HBM; value = index of the FIRST occurrence of the key
  * (the CPU dense_hash_map::insert semantics).  Keys must be < 2^63 (sphash output is 60 bit).
  * The buffer holds cap = 2^k >= 2 n slots {key u64 | value i32} and an occupancy bitmap of 8 bits per slot that the
- * kernel-map probes test before they touch a slot (most probed neighbours do not exist): 13 bytes per slot. */
+ * kernel-map probes test before they touch a slot (most probed neighbours do not exist), a second, SPATIAL bitmap of the
+ * same size (x-contiguous, direct mapped: the three x-neighbours of a voxel in one word) and a 64-byte header. */
 int64_t lidal_hash_table_bytes(int64_t n_keys);
 int lidal_hash_table_build(const int64_t* keys, int64_t n, void* table, int64_t table_bytes,
                            void* stream);
+/* The table of lidal_hash(coords) built from the coordinates themselves (one launch; `stride` = the tensor stride of the
+ * level, a power of two): same slots and values, and the spatial bitmap is filled -- the symmetric kernel-map probes
+ * (lidal_kmap_build[_batch] with symmetric = 1) then answer the 13 probed offsets of a 3x3x3 map from 5 word reads.
+ * A table built by lidal_hash_table_build (bare keys) marks its spatial bitmap invalid and is probed through the
+ * hashed one. */
+int lidal_hash_table_build_coords(const int32_t* coords, int64_t n, int stride, void* table, int64_t table_bytes,
+                                  void* stream);
 /* out[i] = position of q[i] in the keys the table was built from, or -1. */
 int lidal_hash_table_query(const void* table, int64_t table_bytes, const int64_t* q, int64_t nq,
                            int64_t* out, void* stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     'lidal_hash': (_i32, [_vp, _i64, _vp, _vp]),
     'lidal_kernel_hash': (_i32, [_vp, _i64, _vp, _i32, _vp, _vp]),
     'lidal_hash_table_bytes': (_i64, [_i64]),
+    'lidal_hash_table_build_coords': (_i32, [_vp, _i64, _i32, _vp, _i64, _vp]),
     'lidal_hash_table_build': (_i32, [_vp, _i64, _vp, _i64, _vp]),
     'lidal_hash_table_query': (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'lidal_unique_workspace_bytes': (_i64, [_i64]),

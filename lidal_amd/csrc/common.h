@@ -67,7 +67,19 @@ struct TableView {
   int* vals;
   uint64_t mask;
   unsigned* bits;
+  unsigned* sbits;        // spatial occupancy bitmap (below), or NULL
+  const int* hdr;         // {magic, log2 stride, x bits, y bits} behind the bitmaps, or NULL
 };
+
+// A table built from COORDINATES (lidal_hash_table_build_coords, round 5) also carries a SPATIAL occupancy bitmap: bit
+// ((b & 3) * 32 + (z' & 31)) * 2^yb + (y' & (2^yb - 1))) * 2^xb + (x' & (2^xb - 1)), x' = x >> log2(stride): direct
+// mapped, aliased (a 1 MB map holds 256 x 256 x 32 x 4 cells; ~5 % of the bits of a LiDAR level are set), x fastest --
+// the three x-neighbours of a voxel sit in ONE 32-bit word (two at a word boundary), so the 13 probed offsets of a
+// 3x3x3 map are answered by 5 word reads of a map that stays in the L2s.  A 16-byte header behind the bitmaps says
+// whether the spatial map is valid (tables built from bare keys: it is not) and holds the stride.
+constexpr int kSpatialMagic = 0x53424D31;
+static inline int64_t table_sbytes(int64_t cap) { return cap > 16384 ? cap : 16384; }
+static inline int64_t table_total_bytes(int64_t cap) { return cap * 13 + table_sbytes(cap) + 64; }
 
 static inline int64_t table_capacity(int64_t n) {
   int64_t cap = 1024;
@@ -76,16 +88,32 @@ static inline int64_t table_capacity(int64_t n) {
 }
 
 static inline TableView table_view(const void* table, int64_t table_bytes) {
-  int64_t cap = table_bytes / 12;
-  // capacity is the largest power of two with 12*cap <= table_bytes
-  int64_t c = 1;
-  while (c * 2 <= cap) c <<= 1;
+  // capacity: the largest power of two whose full layout fits (buffers of lidal_hash_table_bytes); a smaller buffer
+  // is taken for bare slots (12 bytes each, no bitmaps)
+  int64_t c = 1024;
+  const bool full = table_bytes >= table_total_bytes(1024);
+  if (full) {
+    while (table_total_bytes(c * 2) <= table_bytes) c <<= 1;
+  } else {
+    c = 1;
+    while (c * 2 * 12 <= table_bytes) c <<= 1;
+  }
   TableView t;
   t.keys = (unsigned long long*)table;
   t.vals = (int*)((char*)table + c * 8);
   t.mask = (uint64_t)c - 1;
-  t.bits = (table_bytes >= c * 13) ? (unsigned*)((char*)table + c * 12) : nullptr;
+  t.bits = full ? (unsigned*)((char*)table + c * 12) : nullptr;
+  t.sbits = full ? (unsigned*)((char*)table + c * 13) : nullptr;
+  t.hdr = full ? (const int*)((char*)table + c * 13 + table_sbytes(c)) : nullptr;
   return t;
+}
+// x / y bits of the spatial bitmap of a table of capacity `cap` (z: 5 bits, batch: 2 bits)
+static inline void table_spatial_dims(int64_t cap, int* xb, int* yb) {
+  int lg = 0;
+  while ((1ll << lg) < table_sbytes(cap)) ++lg;
+  const int xy = lg + 3 - 7;
+  *xb = (xy + 1) / 2;
+  *yb = xy / 2;
 }
 
 __device__ __forceinline__ uint64_t mix_key(uint64_t key) {
@@ -96,6 +124,12 @@ __device__ __forceinline__ uint64_t mix_key(uint64_t key) {
 __device__ __forceinline__ uint64_t slot_of(uint64_t key, uint64_t mask) { return mix_key(key) & mask; }
 // bit of `key` in the occupancy bitmap of a table with slot mask `mask` (8 bits per slot)
 __device__ __forceinline__ uint64_t bit_of(uint64_t mixed, uint64_t mask) { return (mixed >> 32) & (mask * 8 + 7); }
+// bit of voxel (x, y, z, b) in the spatial bitmap; shift = log2 of the tensor stride
+__device__ __forceinline__ unsigned sbit_of(int x, int y, int z, int b, int shift, int xb, int yb) {
+  const unsigned xi = (unsigned)(x >> shift) & ((1u << xb) - 1u), yi = (unsigned)(y >> shift) & ((1u << yb) - 1u);
+  const unsigned zi = (unsigned)(z >> shift) & 31u, bi = (unsigned)b & 3u;
+  return ((((bi << 5) | zi) << yb | yi) << xb) | xi;
+}
 
 __device__ __forceinline__ int table_lookup(const TableView& t, uint64_t key) {
   uint64_t s = slot_of(key, t.mask);

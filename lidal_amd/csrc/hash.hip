@@ -135,7 +135,7 @@ extern "C" int lidal_kernel_hash(const int32_t* coords, int64_t n, const int32_t
 }
 
 extern "C" int64_t lidal_hash_table_bytes(int64_t n_keys) {
-  return table_capacity(n_keys) * 13;          // slots (12 bytes) + occupancy bitmap (8 bits per slot), common.h
+  return table_total_bytes(table_capacity(n_keys));       // slots + hashed bitmap + spatial bitmap + header, common.h
 }
 
 extern "C" int lidal_hash_table_build(const int64_t* keys, int64_t n, void* table,
@@ -148,9 +148,59 @@ extern "C" int lidal_hash_table_build(const int64_t* keys, int64_t n, void* tabl
   LIDAL_HIP(hipMemsetAsync(t.keys, 0xFF, cap * 8, s));
   LIDAL_HIP(hipMemsetAsync(t.vals, 0x7F, cap * 4, s));   // 0x7F7F7F7F > any index
   if (t.bits != nullptr) LIDAL_HIP(hipMemsetAsync(t.bits, 0, cap, s));
+  if (t.hdr != nullptr) LIDAL_HIP(hipMemsetAsync((void*)t.hdr, 0, 64, s));      // (bare keys: no spatial bitmap)
   if (n == 0) return 0;
   table_insert_kernel<<<grid_for(n), 256, 0, s>>>(keys, n, t);
   LIDAL_CHECK_LAUNCH("lidal_hash_table_build");
+  return 0;
+}
+
+// the same table from the coordinates themselves -- key i = lidal_hash(coords)[i] -- plus the spatial occupancy
+// bitmap (common.h) the symmetric kernel-map probes read
+__global__ void __launch_bounds__(256) table_insert_coords_kernel(const int4* __restrict__ coords, int64_t n, TableView t,
+                                                                  int shift, int xb, int yb, int* __restrict__ hdr) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { hdr[0] = kSpatialMagic; hdr[1] = shift; hdr[2] = xb; hdr[3] = yb; }
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int4 c = coords[i];
+    const uint64_t key = (uint64_t)fnv60(c.x, c.y, c.z, c.w);
+    const uint64_t mixed = mix_key(key);
+    uint64_t s = mixed & t.mask;
+    const uint64_t b = bit_of(mixed, t.mask);
+    atomicOr(&t.bits[b >> 5], 1u << (b & 31));
+    const unsigned sb = sbit_of(c.x, c.y, c.z, c.w, shift, xb, yb);
+    atomicOr(&t.sbits[sb >> 5], 1u << (sb & 31));
+    while (true) {
+      unsigned long long prev = atomicCAS(&t.keys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (prev == kEmptyKey || prev == key) {
+        atomicMin(&t.vals[s], (int)i);
+        break;
+      }
+      s = (s + 1) & t.mask;
+    }
+  }
+}
+
+extern "C" int lidal_hash_table_build_coords(const int32_t* coords, int64_t n, int stride, void* table,
+                                             int64_t table_bytes, void* stream) {
+  LIDAL_REQUIRE(table_bytes >= lidal_hash_table_bytes(n), "hash table too small: %lld < %lld",
+                (long long)table_bytes, (long long)lidal_hash_table_bytes(n));
+  LIDAL_REQUIRE(stride >= 1 && (stride & (stride - 1)) == 0, "hash_table_build_coords: the tensor stride must be a power of "
+                "two (got %d)", stride);
+  TableView t = table_view(table, table_bytes);
+  const int64_t cap = (int64_t)t.mask + 1;
+  hipStream_t s = (hipStream_t)stream;
+  LIDAL_HIP(hipMemsetAsync(t.keys, 0xFF, cap * 8, s));
+  LIDAL_HIP(hipMemsetAsync(t.vals, 0x7F, cap * 4, s));
+  LIDAL_HIP(hipMemsetAsync(t.bits, 0, cap + table_sbytes(cap) + 64, s));         // both bitmaps and the header
+  if (n == 0) return 0;
+  int shift = 0;
+  while ((1 << shift) < stride) ++shift;
+  int xb, yb;
+  table_spatial_dims(cap, &xb, &yb);
+  table_insert_coords_kernel<<<grid_for(n), 256, 0, s>>>((const int4*)coords, n, t, shift, xb, yb, (int*)t.hdr);
+  LIDAL_CHECK_LAUNCH("lidal_hash_table_build_coords");
   return 0;
 }
 

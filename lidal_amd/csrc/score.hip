@@ -169,6 +169,7 @@ static inline GridView grid_view(const void* grid, int64_t p, int64_t cap, doubl
   g.t.mask = (uint64_t)cap - 1;
   const int64_t q = p > 0 ? p : 1;
   g.t.bits = (unsigned*)(base + grid_off_bits(cap, q));
+  g.t.sbits = nullptr; g.t.hdr = nullptr;
   g.keys = (const uint64_t*)(base + grid_off_skeys(cap));
   g.idx = (const int*)(base + grid_off_sidx(cap, q));
   g.rec = (const GridRec*)(base + grid_off_spts(cap, q));
@@ -277,6 +278,7 @@ __device__ __forceinline__ GridView nei_grid(const NeiArgs& nei, int n, double c
   g.t.mask = (uint64_t)nei.cap[n] - 1;
   const int64_t q = nei.p[n] > 0 ? nei.p[n] : 1;
   g.t.bits = (unsigned*)(base + grid_off_bits(nei.cap[n], q));
+  g.t.sbits = nullptr; g.t.hdr = nullptr;
   g.keys = (const uint64_t*)(base + grid_off_skeys(nei.cap[n]));
   g.idx = (const int*)(base + grid_off_sidx(nei.cap[n], q));
   g.rec = (const GridRec*)(base + grid_off_spts(nei.cap[n], q));
@@ -445,6 +447,7 @@ extern "C" int lidal_nn_grid_build(const double* pts, int64_t p, double cell, vo
   t.vals = (int*)(base + cap * 8);
   t.mask = (uint64_t)cap - 1;
   t.bits = (unsigned*)(base + grid_off_bits(cap, q));
+  t.sbits = nullptr; t.hdr = nullptr;
   grid_heads_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(skeys, p, t, pts, sidx, (GridRec*)(base + grid_off_spts(cap, q)));
   LIDAL_CHECK_LAUNCH("grid_heads");
   return 0;

@@ -93,7 +93,7 @@ def point_tables(x, z):
         cache_i[x.s], cache_c[x.s] = cache_i[1], cache_c[1]
     if cache_i.get(x.s) is None:
         pc_hash = F.sphash(_floor_to_stride(z, x.s[0]))
-        idx_query = F.coords_table(x.C, x.cmaps).query(pc_hash)     # == F.sphashquery(pc_hash, F.sphash(x.C))
+        idx_query = F.coords_table(x.C, x.cmaps, x.s).query(pc_hash)     # == F.sphashquery(pc_hash, F.sphash(x.C))
         cache_i[x.s] = idx_query
         cache_c[x.s] = F.spcount(idx_query.int(), x.C.shape[0])
     return cache_i[x.s], cache_c[x.s]
@@ -119,7 +119,7 @@ def corner_tables(x, z, nearest=False):
     if z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
         off = get_kernel_offsets(2, x.s, 1, device=z.C.device)
         old_hash = F.sphash(_floor_to_stride(z, x.s[0]), off)          # [8, N]
-        idx_query = F.coords_table(x.C, x.cmaps).query(old_hash)    # == F.sphashquery(old_hash, F.sphash(x.C))
+        idx_query = F.coords_table(x.C, x.cmaps, x.s).query(old_hash)    # == F.sphashquery(old_hash, F.sphash(x.C))
         weights, idx_query = F.ti_weights_and_index(z.C, idx_query, scale=x.s[0])   # [N,8] both
         if nearest:
             weights[:, 1:] = 0.

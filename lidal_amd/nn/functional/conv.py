@@ -179,7 +179,7 @@ def build_kernel_map(coords, in_stride, kernel_size, stride, scope=None):
     dev = coords.device
     offsets = get_kernel_offsets(kernel_size, stride=in_stride, device=dev)
     volume = offsets.shape[0]
-    table = coords_table(coords, scope)
+    table = coords_table(coords, scope, in_stride)
     out_coords = coords
     if any(s > 1 for s in stride):
         # (prefetch_kernel_maps may have produced every level's coordinates already, from one sort)
@@ -227,7 +227,7 @@ def build_kernel_maps(jobs, scope):
         coords, out_coords = coords.contiguous(), out_coords.contiguous()
         offsets = get_kernel_offsets(kernel_size, stride=in_stride, device=dev)
         volume = offsets.shape[0]
-        table = coords_table(coords, scope)
+        table = coords_table(coords, scope, in_stride)
         n_in, n_out = coords.shape[0], out_coords.shape[0]
         nbr_out = B.empty((volume, n_out), torch.int, dev)
         symmetric = (volume % 2 == 1) and all(s_ == 1 for s_ in stride)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), name
     assert declared == set(B.SIGNATURES), declared ^ set(B.SIGNATURES)
     assert B.lib().lidal_version() >= 100
-    assert B.lib().lidal_hash_table_bytes(1000) == 2048 * 13        # slots + occupancy bitmap (csrc/common.h)
+    assert B.lib().lidal_hash_table_bytes(1000) == 2048 * 13 + 16384 + 64       # slots + hashed bitmap, spatial bitmap, header (csrc/common.h)
     assert B.lib().lidal_last_error() is not None
 
 

@@ -261,8 +261,8 @@ int lidal_ti_weights(const float* coords, int cstride, const int64_t* idx, int64
  *                                  SAME (ci = n_red, co = n_col, k, dtype, n_out); tile_masks are
  *                                  required with a table (nbr == NULL: identity rule list, k = 1);
  *                                  ci must be a multiple of 4 (f32) / 8 (bf16).
- * tile_stats (NULL or f32 [ceil(n_out / 128)][co][3]): per 128-row tile of the kernel's row order and
- * output column, (count, mean, M2) of the values as stored -- the batch statistics of a train-mode
+ * tile_stats (NULL or f32 [co][ceil(n_out / 128)][3] -- column-major over the tiles, so that the merge of a channel
+ * reads one contiguous run): per output column and 128-row tile of the kernel's row order, (count, mean, M2) of the values as stored -- the batch statistics of a train-mode
  * BatchNorm that follows (network/utils.py:115), taken in the epilogue instead of by a pass over the
  * stored matrix; merged by lidal_bn_train_fwd_tiles. */
 /* Rows per tile of the per-tile BatchNorm statistics lidal_conv_apply_image can leave (tile_stats is
@@ -311,7 +311,7 @@ int lidal_conv_apply_image_ws(const void* in, const void* wimg, const int32_t* n
 /* The data gradient of a convolution whose INPUT was y = act(bn(x)) (torchsparse: convolution_backward_cuda's
  * grad_input half, followed by the BatchNorm backward of network/utils.py:115): lidal_conv_apply_image on
  * (gout, data-gradient image) -> gin, and in the same launch the backward sums of that BatchNorm per 128-row
- * tile of gin's rows: bn_sums f32 [ceil(n_gin / tile rows), c_gin, 2] = (sum dy', sum dy' xhat), dy' = gin where
+ * tile of gin's rows: bn_sums f32 [c_gin, ceil(n_gin / tile rows), 2] = (sum dy', sum dy' xhat), dy' = gin where
  * the fused ReLU (bn_relu) let the value through, xhat = (bn_x - mean) * invstd; bn_x [n_gin, c_gin] in `dtype`.
  * Feed bn_sums to lidal_bn_bwd_tiles.  c_gin must be whole 16-byte vectors. */
 int lidal_conv_dgrad_bn_sums(const void* gout, const void* wimg, const int32_t* nbr, const int32_t* perm,
@@ -363,7 +363,7 @@ int lidal_bn_train_fwd(const void* x, int dtype, int64_t n, int c, const float* 
                        const void* residual, void* y, float* save_mean, float* save_invstd, void* ws,
                        int64_t ws_bytes, void* stream);
 /* lidal_bn_train_fwd with the statistics pass replaced by the per-tile (count, mean, M2) triples
- * lidal_conv_apply_image wrote (tile_stats f32 [n_tiles][c][3]). */
+ * lidal_conv_apply_image wrote (tile_stats f32 [c][n_tiles][3]). */
 int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int c, const float* gamma,
                              const float* beta, float eps, float momentum, float* running_mean,
                              float* running_var, int64_t* num_batches_tracked, int relu,
@@ -381,7 +381,7 @@ int lidal_bn_bwd(const void* x, const void* dy, int64_t dy_stride, int dtype, in
                  void* stream);
 /* Column sums of x [n, c] -> out f32 [c] (bias gradients of the 1x1 / Linear layers);
  * ws >= lidal_bn_workspace_bytes(n, c) + 12*c bytes. */
-/* BatchNorm backward whose per-column sums came with dy: tile_sums f32 [n_tiles, c, 2] = (sum dy', sum dy' xhat)
+/* BatchNorm backward whose per-column sums came with dy: tile_sums f32 [c, n_tiles, 2] = (sum dy', sum dy' xhat)
  * per 128-row tile (lidal_conv_stats_tile_rows), left by lidal_conv_dgrad_bn_sums.  Merges the tiles in f64
  * (-> grad_beta, grad_gamma) and writes dx; no pass over (x, dy) for the sums. */
 int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c,

@@ -666,7 +666,7 @@ __global__ void __launch_bounds__(NT) bn_tiles_final_kernel(const float* __restr
   if (num_batches != nullptr && ch == 0 && tid == 0) *num_batches += 1;
   double n = 0., a = 0., b = 0.;
   for (int p = tid; p < nparts; p += NT) {
-    const float* s = part + ((int64_t)p * c + ch) * 3;
+    const float* s = part + ((int64_t)ch * nparts + p) * 3;         // [c][tiles][3]: a channel's triples are one run
     const double pn = (double)s[0], pm = (double)s[1];
     n += pn; a += pn * pm; b += (double)s[2] + pn * pm * pm;
   }
@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int p = p0 + u * NT;
-        const float* sp = part + ((int64_t)(p < nparts ? p : p0) * c + ch) * 3;
+        const float* sp = part + ((int64_t)ch * nparts + (p < nparts ? p : p0)) * 3;
         t0[u] = sp[0]; t1[u] = sp[1]; t2[u] = sp[2];
       }
 #pragma unroll
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int p = p0 + u * NT;
-          const float* sp = pt + ((int64_t)(p < nparts ? p : p0) * c + ch) * 2;
+          const float* sp = pt + ((int64_t)ch * nparts + (p < nparts ? p : p0)) * 2;
           t0[u] = sp[0]; t1[u] = sp[1];
         }
 #pragma unroll
@@ -1229,7 +1229,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_tiles_final_kernel(const float* __r
   const int tid = threadIdx.x, ch = blockIdx.x;
   double a = 0., b = 0.;
   for (int p = tid; p < nparts; p += NT) {
-    const float* s = part + ((int64_t)p * c + ch) * 2;
+    const float* s = part + ((int64_t)ch * nparts + p) * 2;
     a += (double)s[0]; b += (double)s[1];
   }
   sa[tid] = a; sb[tid] = b;

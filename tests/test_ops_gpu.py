@@ -751,6 +751,7 @@ def test_conv_epilogue_batch_statistics(dtype):
                 continue
             st = out._lidal_bn_stats.double().cpu()
             assert st.shape == (-(-n // 128), co, 3)
+            st = st.reshape(co, -(-n // 128), 3).permute(1, 0, 2)       # the buffer is laid out [co][tiles][3] (csrc/conv_img.hip)
             o = out.detach().double().cpu()
             cnt = st[:, :, 0].sum(0)
             mean = (st[:, :, 0] * st[:, :, 1]).sum(0) / cnt
@@ -778,6 +779,7 @@ def test_conv_epilogue_batch_statistics(dtype):
         y = rows_linear(x, lin.weight, lin.bias, want_stats=True)
         if dtype == torch.bfloat16:
             st = y._lidal_bn_stats.double().cpu()
+            st = st.reshape(96, -1, 3).permute(1, 0, 2)                 # [co][tiles][3]
             mean = (st[:, :, 0] * st[:, :, 1]).sum(0) / st[:, :, 0].sum(0)
             assert _relerr(mean, y.detach().double().cpu().mean(0)) < 1e-5
 
@@ -1260,7 +1262,8 @@ def test_block_tail_mask_with_batchnorm_sums_is_the_two_separate_passes(dtype, n
 
 
 def _tile_triples(x, tile=128):
-    """(count, mean, M2) per 128-row tile and channel, f32 [tiles, c, 3]: what a convolution's epilogue leaves."""
+    """(count, mean, M2) per 128-row tile and channel, what a convolution's epilogue leaves: f32, laid out
+    [c][tiles][3] (csrc/conv_img.hip store_tile) -- returned with that buffer's shape recorded as (tiles, c, 3)."""
     n, c = x.shape
     xf = x.float()
     out = []
@@ -1268,7 +1271,8 @@ def _tile_triples(x, tile=128):
         blk = xf[r:r + tile]
         m = blk.mean(0)
         out.append(torch.stack([torch.full_like(m, blk.shape[0]), m, ((blk - m) ** 2).sum(0)], 1))
-    return torch.stack(out, 0).contiguous()
+    t = torch.stack(out, 0)                                     # [tiles, c, 3]
+    return t.permute(1, 0, 2).contiguous().view(t.shape[0], t.shape[1], 3)     # the bytes of [c][tiles][3]
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -195,7 +195,7 @@ def _replay(run, model, stats, conv_every=1):
                     st = a[17]
                     if st:          # (count, mean, M2) per 128-row tile of the kernel's row order: merged, the batch statistics
                         tiles = -(-n_out // run.tile)
-                        ts_ = _mat(st, tiles * co, 3, 0).reshape(tiles, co, 3)
+                        ts_ = _mat(st, tiles * co, 3, 0).reshape(co, tiles, 3).permute(1, 0, 2)      # stored [co][tiles][3]
                         stored = _mat(out_p, n_out, co, code)
                         cnt = ts_[:, :, 0].sum(0)
                         mean = (ts_[:, :, 0] * ts_[:, :, 1]).sum(0) / cnt
@@ -214,7 +214,7 @@ def _replay(run, model, stats, conv_every=1):
                     if brelu:
                         dy[~(xh * _vec(gam, co).double() + _vec(bet, co).double() > 0)] = 0
                     tiles = -(-n_out // run.tile)
-                    sm = _mat(sums_p, tiles * co, 2, 0).reshape(tiles, co, 2).sum(0)
+                    sm = _mat(sums_p, tiles * co, 2, 0).reshape(co, tiles, 2).sum(1)           # stored [co][tiles][2]
                     stats.f32('dgrad tile sums', sm[:, 0], dy.sum(0), what + ' sum dy', 1e-4)
                     stats.f32('dgrad tile sums', sm[:, 1], (dy * xh).sum(0), what + ' sum dy xhat', 1e-4)
                 stored = _mat(out_p, n_out, co, code)

@@ -207,6 +207,7 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, _ = step()
+    t_host = time.perf_counter() - t0           # the host has queued every step (it runs ahead of the GPU unless it is the bound)
     barrier_sync(world if ddp else 1)
     dt = time.perf_counter() - t0
     if ddp:
@@ -214,7 +215,7 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
     assert np.isfinite(loss.item()), 'training diverged'
     voxels = sum(int(batches[(first + i) % len(batches)][0].shape[0]) for i in range(steps)) / steps
     return {'model': model, 'step': step, 'seconds': dt, 'steps': steps, 'voxels': voxels,
-            'loss': float(loss.item())}
+            'loss': float(loss.item()), 'host_seconds': t_host}
 
 
 def host_calls(model_name, dtype, batch, dev, prefetch=True):
@@ -538,10 +539,15 @@ def family_table(step, coords, dtype_name, step_ms):
             return max(n_in, n_out)
         return rules.get(n_out, rules.get(n_in, 6 * n_out))
 
+    dump = os.environ.get('BENCH_FAMILY_CALLS')          # a path: one line per library call (family, name, ms, integer arguments)
+    dump_f = open(dump, 'w') if dump else None
     for name, a, e0, e1 in calls:
         f = FAMILY_OF.get(name, 'other_lib')
         ms = e0.elapsed_time(e1)
         by = fl = 0.0
+        if dump_f is not None:
+            dump_f.write(json.dumps({'family': f, 'name': name, 'ms': round(ms, 4),
+                                     'args': [v for v in a[:16] if abs(v) < (1 << 40)]}) + '\n')
         if name in ('lidal_conv_apply_image', 'lidal_conv_dgrad_bn_sums', 'lidal_conv_apply_image_ws',
                     'lidal_conv_dgrad_bn_sums_ws'):
             n_in, n_out, ci, co, k, dt = a[6], a[7], a[8], a[9], a[10], a[12]
@@ -632,6 +638,8 @@ def family_table(step, coords, dtype_name, step_ms):
         d['launches'] += 1
         d['bytes'] += by
         d['flops'] += fl
+    if dump_f is not None:
+        dump_f.close()
     out = {}
     tot_ms = tot_by = tot_fl = 0.0
     peak_tf = MFMA_PEAK_TFLOPS[dtype_name]
@@ -1025,6 +1033,12 @@ def main():
     }
     if solo:
         line['host'] = guarded(host_calls, args.model, args.dtype, batch, dev)
+        if isinstance(line['host'], dict):
+            # wall time the host needed to QUEUE the timed steps (no synchronisation inside).  Well under ms_per_step: the
+            # host runs ahead and the GPU is the bound.  Close to it: EITHER the step is host-bound OR the host ran into the
+            # depth of the hardware queues (~1.5 steps of dispatches) and waited there -- compare with the single-scan
+            # variant, whose host work is the same (6.4 ms per step covers it)
+            line['host']['queueing_ms_per_step'] = round(res['host_seconds'] / args.steps * 1e3, 3)
     if rank == 0 and not args.no_roofline:
         line['roofline'] = guarded(roofline_conv, args, batch[0], dev)
         log('roofline', line['roofline'])

@@ -169,7 +169,12 @@ __device__ __forceinline__ int tile_of_block() {
   return (int)gridDim.x - 1 - (int)blockIdx.x;
 #endif
 }
-constexpr int LEAN_WAVES = 8;          // waves per workgroup = 128-row tiles (16 waves / 256 rows measured slower)
+#ifndef LIDAL_LEAN_WAVES
+#define LIDAL_LEAN_WAVES 8
+#endif
+// waves per workgroup = 128-row tiles.  16 (256-row tiles, scripts/build_variant.py -DLIDAL_LEAN_WAVES=16: an experiment
+// build -- no BatchNorm tile statistics, no offset split) halves the slab DMAs per row
+constexpr int LEAN_WAVES = LIDAL_LEAN_WAVES;
 #ifndef LIDAL_LEAN_MINWAVES
 #define LIDAL_LEAN_MINWAVES 4
 #endif
@@ -1532,7 +1537,11 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       // 256-row tiles (16 waves) where the weight slab outweighs the gathers of a 128-row tile
       constexpr int LW = LEAN_WAVES;
       constexpr int LBM = LW * 16;
+#if LIDAL_LEAN_WAVES == 8
       static_assert(LBM == TILE_ROWS, "tile masks and BatchNorm statistics triples are per 128-row tile");
+#else
+      LIDAL_REQUIRE(ep.tile_stats == nullptr && ep.bnb.sums == nullptr, "experiment build (LIDAL_LEAN_WAVES): no tile statistics");
+#endif
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
       constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + 4096;      // + the DMA dump
@@ -1540,7 +1549,7 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
       // conv_lean_deep_kernel -- measured on every layer shape of the model (scripts/exp/deep_rows.py, bit-equal
       // everywhere): 256->256 on 43k rows 131 -> 112 us, 384->256 194 -> 163; neutral to 6 % slower on the
       // others (and on every shape of a single scan), which therefore keep the lean kernel
-      if constexpr (sizeof(T) == 2 && NB == 8 && ROW_BYTES == 128) {
+      if constexpr (sizeof(T) == 2 && NB == 8 && ROW_BYTES == 128 && LW == 8) {
 #ifdef LIDAL_PHASE_STAMPS
        if (false) {           // (the instrumented build times the lean kernel on every level)
 #else
@@ -1651,7 +1660,7 @@ __host__ inline int64_t split_image_bytes(int k, int n_red, int n_col) {
 template <int NB>
 int launch_split(const void* in, const void* wimg, const int* nbr, const int* perm, const unsigned* tmasks, void* out,
                  int64_t n_out, int ci, int co, int K, int kflip, Epi ep, hipStream_t s) {
-  constexpr int LW = LEAN_WAVES, BN = 16 * NB, SLAB = BN * SPLIT_ROW;
+  constexpr int LW = 8, BN = 16 * NB, SLAB = BN * SPLIT_ROW;
   constexpr int LEPI_ALL = LW * 16 * (BN + 4) * 4 + LW * BN * 2 * (int)sizeof(float);
   constexpr int LDS = ((2 * SLAB > LEPI_ALL) ? 2 * SLAB : LEPI_ALL) + 4096;
   auto kern = nbr ? conv_split_kernel<NB, LW, false> : conv_split_kernel<NB, LW, true>;

@@ -191,9 +191,15 @@ def bench_train(world, rank, dev, model_name, dtype, batch, steps, warmup, ddp=T
     pf = GeometryPrefetcher(model, device=dev) if prefetch else None
     ahead = [pf.submit(batches[0][0]) if prefetch else None]
 
+    delay = float(os.environ.get('BENCH_HOST_DELAY_US', '0')) * 1e-6     # experiment: is the step host-bound?  (a busy wait per step)
+
     def step():
         coords, feats, labels = batches[count[0] % len(batches)]
         count[0] += 1
+        if delay:
+            t_end = time.perf_counter() + delay
+            while time.perf_counter() < t_end:
+                pass
         out = train_step(net, opt, feats, coords, labels, autocast=autocast, geometry=ahead[0])
         if prefetch:
             ahead[0] = pf.submit(batches[count[0] % len(batches)][0])
@@ -457,6 +463,7 @@ FAMILY_OF = {
     'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_bwd_tiles': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
     # (the ReLU mask of a block's tail rides with the first pass of its BatchNorms' backward: both counted here)
     'lidal_add_relu_bwd_bn_sums': 'batch_norm', 'lidal_bn_bwd_from_sums': 'batch_norm',
+    'lidal_add_relu_bwd_bn_tile_sums': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_build_coords': 'kernel_maps',
@@ -577,7 +584,7 @@ def family_table(step, coords, dtype_name, step_ms):
             by = 5 * a[4] * a[5] * (2 if a[3] == 1 else 4)
         elif name == 'lidal_bn_bwd_from_sums':
             by = 5 * a[4] * a[5] * (2 if a[3] == 1 else 4)         # (as lidal_bn_bwd: the pass it no longer makes stays in the count)
-        elif name == 'lidal_add_relu_bwd_bn_sums':
+        elif name in ('lidal_add_relu_bwd_bn_sums', 'lidal_add_relu_bwd_bn_tile_sums'):
             by = 3 * a[4] * a[5] * (2 if a[3] == 1 else 4)         # (as lidal_add_relu_bwd: out, g -> gm)
         elif name == 'lidal_colsum':
             by = a[2] * a[3] * (2 if a[1] == 1 else 4)

@@ -398,6 +398,16 @@ int lidal_add_relu_bwd_bn_sums(const void* out, const void* g, void* gm, int dty
                                const void* x_a, const float* mean_a, const float* invstd_a, void* part_a,
                                const void* x_b, const float* mean_b, const float* invstd_b, void* part_b,
                                int64_t part_bytes, void* stream);
+/* The same tail for the levels with many rows: gm = g where out > 0, and per part (a slab of rows; there are
+ * lidal_bn_tail_parts(n, c, dtype) of them) and channel the f32 pairs (sum gm, sum gm * xhat) of the BatchNorm over x_a --
+ * and over x_b, if given -- as [channel][part][2] (sums_a / sums_b: c * n_parts * 2 floats each): the tile sums
+ * lidal_bn_bwd_tiles takes, with n_tiles = n_parts and relu = 0.  One element-wise pass instead of lidal_add_relu_bwd and
+ * the first pass of one or two lidal_bn_bwd. */
+int64_t lidal_bn_tail_parts(int64_t n, int c, int dtype);
+int lidal_add_relu_bwd_bn_tile_sums(const void* out, const void* g, void* gm, int dtype, int64_t n, int c,
+                                    const void* x_a, const float* mean_a, const float* invstd_a, float* sums_a,
+                                    const void* x_b, const float* mean_b, const float* invstd_b, float* sums_b,
+                                    int64_t n_parts, void* stream);
 /* lidal_bn_bwd without its first pass: the partial sums are in `part` (lidal_add_relu_bwd_bn_sums). */
 int lidal_bn_bwd_from_sums(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c,
                            const float* gamma, const float* beta, int relu, const float* save_mean,
@@ -532,7 +542,8 @@ enum {
   LIDAL_OP_DEVOXELIZE_BWD_SORTED = 18, LIDAL_OP_CE_FWD = 19, LIDAL_OP_CE_BWD = 20, LIDAL_OP_COPY2D = 21,
   LIDAL_OP_ADD2D = 22, LIDAL_OP_TRANSPOSE_F32 = 23, LIDAL_OP_CAST_ROWS_BF16 = 24, LIDAL_OP_VIEW_MEAN_SOFTMAX = 25,
   LIDAL_OP_FORK_SIDE = 26, LIDAL_OP_JOIN_SIDE = 27, LIDAL_OP_CONV_APPLY_IMAGE_WS = 28,
-  LIDAL_OP_CONV_DGRAD_BN_SUMS_WS = 29, LIDAL_OP_ADD_RELU_BWD_BN_SUMS = 30, LIDAL_OP_BN_BWD_FROM_SUMS = 31
+  LIDAL_OP_CONV_DGRAD_BN_SUMS_WS = 29, LIDAL_OP_ADD_RELU_BWD_BN_SUMS = 30, LIDAL_OP_BN_BWD_FROM_SUMS = 31,
+  LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS = 32
 };
 #define LIDAL_OP_FLAG_SIDE 1
 int lidal_plan_op_args(int kind);

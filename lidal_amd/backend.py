@@ -102,6 +102,8 @@ SIGNATURES = {
     'lidal_bn_bwd_tiles': (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _i64, _vp]),
     'lidal_add_relu_bwd_bn_sums': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'lidal_add_relu_bwd_bn_tile_sums': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'lidal_bn_tail_parts': (_i64, [_i64, _i32, _i32]),
     'lidal_bn_bwd_from_sums': (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _i64, _vp]),
     'lidal_bn_set_fused': (_i32, [_i32]),

@@ -453,6 +453,106 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_masked_kernel(
   }
 }
 
+// The same tail on the levels with many rows (round 5): the mask as an ELEMENT-WISE launch -- 512 workgroups, two waves
+// per SIMD -- that also leaves, per workgroup and channel, the f32 sums of its slab of rows in the layout of the
+// convolutions' tile sums ([channel][part][2]); lidal_bn_bwd_tiles merges them (f64 across the parts) in front of its dx
+// pass.  bn_bwd_partial_masked_kernel above keeps f64 sums per thread on 256 workgroups and streams at ~2.5 TB/s on
+// the 397 k-row level (115 / 156 us against 44 + 41 (+ 41) for the separate passes: profiles/README.md, round 5), which
+// is why rounds 3-4 kept the separate passes there.  A thread sums ~40 rows in f32, a slab is ~775 rows: the error of a
+// part is that of a convolution's 128-row tile sum.
+template <typename T, bool DUAL>
+__global__ void __launch_bounds__(NT) tail_tile_sums_kernel(
+    const T* __restrict__ out, const T* __restrict__ g, T* __restrict__ gm, int64_t n, int c,
+    const T* __restrict__ xa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a, float* __restrict__ sums_a,
+    const T* __restrict__ xb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b, float* __restrict__ sums_b,
+    int rpw) {
+  constexpr int VEC = IO<T>::VEC;
+  __shared__ float sh[NT * VEC];
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
+  float a[VEC], b[VEC], b2[VEC];
+  float mu[VEC], is[VEC], mu2[VEC], is2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; b2[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; mu2[i] = 0.f; is2[i] = 0.f; }
+  if (rl < rpi) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mu[i] = mean_a[cg * VEC + i]; is[i] = invstd_a[cg * VEC + i];
+      if (DUAL) { mu2[i] = mean_b[cg * VEC + i]; is2[i] = invstd_b[cg * VEC + i]; }
+    }
+    typedef typename IO<T>::vec V;
+    auto one = [&](int64_t r, const V& vo, const V& vg, const V& vx, const V& vx2) {
+      float fo[VEC], fd[VEC], fx[VEC], fx2[VEC];
+      IO<T>::unpack(vo, fo);
+      IO<T>::unpack(vg, fd);
+      IO<T>::unpack(vx, fx);
+      if (DUAL) IO<T>::unpack(vx2, fx2);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) fd[i] = fo[i] > 0.f ? fd[i] : 0.f;
+      *reinterpret_cast<V*>(gm + r * c + cg * VEC) = IO<T>::pack(fd);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        a[i] += fd[i];
+        b[i] += fd[i] * ((fx[i] - mu[i]) * is[i]);
+        if (DUAL) b2[i] += fd[i] * ((fx2[i] - mu2[i]) * is2[i]);
+      }
+    };
+    int64_t r = r_beg + rl;
+    for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
+      V vo[UNR], vg[UNR], vx[UNR], vx2[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t off = (r + u * rpi) * c + cg * VEC;
+        vo[u] = *reinterpret_cast<const V*>(out + off);
+        vg[u] = *reinterpret_cast<const V*>(g + off);
+        vx[u] = *reinterpret_cast<const V*>(xa + off);
+        vx2[u] = DUAL ? *reinterpret_cast<const V*>(xb + off) : vx[u];
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) one(r + u * rpi, vo[u], vg[u], vx[u], vx2[u]);
+    }
+    for (; r < r_end; r += rpi) {
+      const int64_t off = r * c + cg * VEC;
+      const V vx = *reinterpret_cast<const V*>(xa + off);
+      one(r, *reinterpret_cast<const V*>(out + off), *reinterpret_cast<const V*>(g + off), vx,
+          DUAL ? *reinterpret_cast<const V*>(xb + off) : vx);
+    }
+  }
+  const int nparts = (int)gridDim.x, part = (int)blockIdx.x;
+  // three LDS trees over the row lanes (sum gm, sum gm xhat_a, sum gm xhat_b), each left with rl == 0
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) sh[tid * VEC + i] = a[i];
+  tree_sum_rows<VEC, float>(sh, tid, cg_n, rpi, rl);
+  if (rl == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int64_t o = ((int64_t)(cg * VEC + i) * nparts + part) * 2;
+      sums_a[o] = sh[tid * VEC + i];
+      if (DUAL) sums_b[o] = sh[tid * VEC + i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) sh[tid * VEC + i] = b[i];
+  tree_sum_rows<VEC, float>(sh, tid, cg_n, rpi, rl);
+  if (rl == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sums_a[((int64_t)(cg * VEC + i) * nparts + part) * 2 + 1] = sh[tid * VEC + i];
+  }
+  if (DUAL) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sh[tid * VEC + i] = b2[i];
+    tree_sum_rows<VEC, float>(sh, tid, cg_n, rpi, rl);
+    if (rl == 0) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) sums_b[((int64_t)(cg * VEC + i) * nparts + part) * 2 + 1] = sh[tid * VEC + i];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(NT) bn_bwd_final_kernel(const double* __restrict__ part,
                                                           int nparts, int c,
                                                           float* __restrict__ sum_dy,
@@ -1285,6 +1385,36 @@ __global__ void __launch_bounds__(NT) bn_bwd_tiles_final_kernel(const float* __r
     sum_dy[ch] = (float)sa[0];            // = grad_beta
     sum_dy_xhat[ch] = (float)sb[0];       // = grad_gamma
   }
+}
+
+// The tail of a residual block backwards on the levels with many rows: gm = g * (out > 0) and, per part (a slab of
+// rows: lidal_bn_tail_parts of them) and channel, the f32 pairs (sum gm, sum gm xhat) of the BatchNorm over x_a -- and
+// over x_b, if given -- as [channel][part][2]: what lidal_bn_bwd_tiles takes as tile sums (n_tiles = the parts).
+extern "C" int64_t lidal_bn_tail_parts(int64_t n, int c, int dtype) {
+  return nslabs_ew(n, (int64_t)c * (dtype == LIDAL_F32 ? 4 : 2));
+}
+extern "C" int lidal_add_relu_bwd_bn_tile_sums(const void* out, const void* g, void* gm, int dtype, int64_t n, int c,
+                                               const void* x_a, const float* mean_a, const float* invstd_a, float* sums_a,
+                                               const void* x_b, const float* mean_b, const float* invstd_b, float* sums_b,
+                                               int64_t n_parts, void* stream) {
+  if (int rc = bn_check(n, c, dtype)) return rc;
+  LIDAL_REQUIRE(n > 0, "add_relu_bwd_bn_tile_sums: needs at least one row");
+  LIDAL_REQUIRE(n_parts == lidal_bn_tail_parts(n, c, dtype), "add_relu_bwd_bn_tile_sums: %lld parts, lidal_bn_tail_parts says %lld",
+                (long long)n_parts, (long long)lidal_bn_tail_parts(n, c, dtype));
+  LIDAL_REQUIRE(x_a != nullptr && sums_a != nullptr && (x_b == nullptr || sums_b != nullptr),
+                "add_relu_bwd_bn_tile_sums: a BatchNorm input without a buffer for its sums");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t row_bytes = (int64_t)c * (dtype == LIDAL_F32 ? 4 : 2);
+  const int rpw = rows_per_wg_ew(n, row_bytes);
+  const unsigned grid = (unsigned)n_parts;
+#define LIDAL_TAIL(T, DUALV)                                                                                         \
+  tail_tile_sums_kernel<T, DUALV><<<grid, NT, 0, s>>>((const T*)out, (const T*)g, (T*)gm, n, c, (const T*)x_a, mean_a, \
+                                                      invstd_a, sums_a, (const T*)x_b, mean_b, invstd_b, sums_b, rpw)
+  if (dtype == LIDAL_F32) { if (x_b) LIDAL_TAIL(float, true); else LIDAL_TAIL(float, false); }
+  else { if (x_b) LIDAL_TAIL(__bf16, true); else LIDAL_TAIL(__bf16, false); }
+#undef LIDAL_TAIL
+  LIDAL_CHECK_LAUNCH("add_relu_bwd_bn_tile_sums");
+  return 0;
 }
 
 extern "C" int lidal_bn_bwd_tiles(const void* x, const void* dy, int64_t dy_stride, int dtype, int64_t n, int c,

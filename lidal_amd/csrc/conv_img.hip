@@ -1506,7 +1506,10 @@ struct Epi { const float* scale; const float* shift; int relu; const void* res; 
 // whose tiles have a long chain (a 27-offset map, or an 8-offset map over several reduction slices)
 // (measured with the coalesced partial tiles, 5-scan step: <= 256 workgroups 14.68 ms, <= 700 -- the 43 k-row level split
 // in two instead of the deep kernel -- 15.06, <= 1700 15.55; one scan 6.35 / 6.54 / 6.56)
-constexpr int64_t SPLIT_MAX_WGS = 256;
+#ifndef LIDAL_SPLIT_MAX_WGS
+#define LIDAL_SPLIT_MAX_WGS 256
+#endif
+constexpr int64_t SPLIT_MAX_WGS = LIDAL_SPLIT_MAX_WGS;
 #ifndef LIDAL_SPLIT_F32_MAX_WGS
 #define LIDAL_SPLIT_F32_MAX_WGS 512
 #endif

@@ -232,6 +232,7 @@ const OpInfo kOps[] = {
     /* LIDAL_OP_CONV_DGRAD_BN_SUMS_WS 29 */ {22, "conv_dgrad_bn_sums_ws"},
     /* LIDAL_OP_ADD_RELU_BWD_BN_SUMS 30 */ {15, "add_relu_bwd_bn_sums"},
     /* LIDAL_OP_BN_BWD_FROM_SUMS 31 */ {16, "bn_bwd_from_sums"},
+    /* LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS 32 */ {15, "add_relu_bwd_bn_tile_sums"},
 };
 constexpr int kNumOps = (int)(sizeof(kOps) / sizeof(kOps[0]));
 
@@ -374,6 +375,10 @@ int run_ops(const int64_t* words, int64_t n_words, int64_t n_ops, void* const* s
       case LIDAL_OP_ADD_RELU_BWD_BN_SUMS:
         rc = lidal_add_relu_bwd_bn_sums(P(0), P(1), P(2), I(3), L(4), I(5), P(6), CP(float, 7), CP(float, 8), P(9), P(10),
                                         CP(float, 11), CP(float, 12), P(13), L(14), st);
+        break;
+      case LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS:
+        rc = lidal_add_relu_bwd_bn_tile_sums(P(0), P(1), P(2), I(3), L(4), I(5), P(6), CP(float, 7), CP(float, 8),
+                                             MP(float, 9), P(10), CP(float, 11), CP(float, 12), MP(float, 13), L(14), st);
         break;
       case LIDAL_OP_BN_BWD_TILES:
         rc = lidal_bn_bwd_tiles(P(0), P(1), L(2), I(3), L(4), I(5), CP(float, 6), CP(float, 7), I(8), CP(float, 9),

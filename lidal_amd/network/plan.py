@@ -51,7 +51,7 @@ OP_COLSUM, OP_ADD_RELU_FWD, OP_ADD_RELU_BWD, OP_VOXELIZE_FWD_1TO1, OP_VOXELIZE_F
 OP_VOXELIZE_BWD, OP_DEVOXELIZE_FWD, OP_DEVOXELIZE_BWD_SORTED, OP_CE_FWD, OP_CE_BWD = 16, 17, 18, 19, 20
 OP_COPY2D, OP_ADD2D, OP_TRANSPOSE_F32, OP_CAST_ROWS_BF16, OP_VIEW_MEAN_SOFTMAX = 21, 22, 23, 24, 25
 OP_FORK_SIDE, OP_JOIN_SIDE, OP_CONV_APPLY_IMAGE_WS, OP_CONV_DGRAD_BN_SUMS_WS = 26, 27, 28, 29
-OP_ADD_RELU_BWD_BN_SUMS, OP_BN_BWD_FROM_SUMS = 30, 31
+OP_ADD_RELU_BWD_BN_SUMS, OP_BN_BWD_FROM_SUMS, OP_ADD_RELU_BWD_BN_TILE_SUMS = 30, 31, 32
 
 # operations executed inside plans ('ops') and plans run ('plans') since import (backend.HITS counts every
 # library call made from Python, 'plan_run' among them)
@@ -85,7 +85,8 @@ _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv
               12: 'add_relu_fwd', 13: 'add_relu_bwd', 14: 'voxelize_fwd_1to1', 15: 'voxelize_fwd_sorted',
               16: 'voxelize_bwd', 17: 'devoxelize_fwd', 18: 'devoxelize_bwd_sorted', 19: 'ce_fwd', 20: 'ce_bwd',
               21: 'copy2d', 22: 'add2d', 23: 'transpose_f32', 24: 'cast_rows_bf16', 25: 'view_mean_softmax',
-              26: 'fork_side', 27: 'join_side', 28: 'conv_apply', 29: 'conv_apply', 30: 'add_relu_bwd', 31: 'bn_bwd'}
+              26: 'fork_side', 27: 'join_side', 28: 'conv_apply', 29: 'conv_apply', 30: 'add_relu_bwd', 31: 'bn_bwd',
+              32: 'add_relu_bwd'}
 
 
 def _tally(words):
@@ -896,7 +897,7 @@ class _Run:
     def slot(self, i):
         return self.flat + 4 * self.prog.slot[i]
 
-    def b_bn(self, r, x, n, mean, invstd, g, g_stride, sums=0, relu=None, flag=0, part=None):
+    def b_bn(self, r, x, n, mean, invstd, g, g_stride, sums=0, relu=None, flag=0, part=None, nparts=0):
         """norm.py train_backward (without the mask_from part): -> dx.  part: (address, bytes) of the partial sums
         lidal_add_relu_bwd_bn_sums left for this layer."""
         p = self.ptr
@@ -908,7 +909,7 @@ class _Run:
                        self.slot(r.w), self.slot(r.b), part[0], part[1])
         elif sums:
             self.w += (OP_BN_BWD_TILES | flag, x, g, g_stride, self.code, n, c, p[r.w], p[r.b], relu, mean, invstd, dx,
-                       self.slot(r.w), self.slot(r.b), sums, -(-n // self.tile))
+                       self.slot(r.w), self.slot(r.b), sums, nparts or -(-n // self.tile))
         else:
             nb = _bn_ws(n, c)
             self.w += (OP_BN_BWD | flag, x, g, g_stride, self.code, n, c, p[r.w], p[r.b], relu, mean, invstd, dx,
@@ -999,7 +1000,14 @@ class _Run:
         co = r.c2.co
         gm = self.galloc(n * co * self.esz)
         part2 = parts = nb = 0
-        if _N.tail_sums(n):                # (nn/functional/norm.py tail_backward)
+        sums2 = sumss = nparts = 0
+        if _N.tail_tiles(n, self.dtype):    # (nn/functional/norm.py _tail_backward_tiles)
+            nparts = int(B.lib().lidal_bn_tail_parts(n, co, self.code))
+            sums2 = self.galloc(co * nparts * 8)
+            sumss = self.galloc(co * nparts * 8) if r.cs is not None else 0
+            self.w += (OP_ADD_RELU_BWD_BN_TILE_SUMS, out, g, gm, self.code, n, co, x2, mean2, inv2, sums2,
+                       xs if sumss else 0, means if sumss else 0, invs if sumss else 0, sumss, nparts)
+        elif _N.tail_sums(n):              # (nn/functional/norm.py tail_backward)
             nb = _bn_ws(n, co)
             part2 = self.galloc(nb)
             parts = self.galloc(nb) if r.cs is not None else 0
@@ -1011,11 +1019,11 @@ class _Run:
         fl = 0
         if r.cs is not None:                # the shortcut's backward: independent of the main branch until conv1's data gradient
             fl = self.fork(2) if (BRANCH_ROWS and n >= BRANCH_ROWS) else 0
-            dxs = self.b_bn(r.bs, xs, n, means, invs, gm, co, flag=fl, part=(parts, nb))
+            dxs = self.b_bn(r.bs, xs, n, means, invs, gm, co, sumss, None, flag=fl, part=(parts, nb), nparts=nparts)
             g_skip = self.b_dense(r.cs, x, n, dxs, co, branch=fl)
         else:
             g_skip = gm
-        dx2 = self.b_bn(r.b2, x2, n, mean2, inv2, gm, co, 0, 0, part=(part2, nb))
+        dx2 = self.b_bn(r.b2, x2, n, mean2, inv2, gm, co, sums2, 0, part=(part2, nb), nparts=nparts)
         table, rules = k3[0:3], k3[3:5]
         self.b_wgrad(r.c2, y1, n, dx2, n, rules)
         p = self.ptr

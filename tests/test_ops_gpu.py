@@ -1261,6 +1261,76 @@ def test_block_tail_mask_with_batchnorm_sums_is_the_two_separate_passes(dtype, n
             assert torch.equal(dx, want[0]) and torch.equal(gg, want[1]) and torch.equal(gb, want[2])
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c', [(396662, 96), (226469, 32), (105363, 128), (1001, 256), (77, 32)])
+def test_block_tail_mask_with_slab_sums_against_the_separate_passes(dtype, n, c):
+    """lidal_add_relu_bwd_bn_tile_sums + lidal_bn_bwd_tiles (the tail of a residual block backwards on the levels with
+    many rows, network/plan.py b_res; network/utils.py:142-172 backwards) against lidal_add_relu_bwd + lidal_bn_bwd: the
+    masked gradient BITWISE; the slab sums against f64 sums of the same rows (f32 sums of <= ~800 rows: 2e-6 of the
+    column's sum of magnitudes); parameter gradients within 1e-5 of the columns' scale, dx within one rounding step of the
+    element type -- the bars tests/test_ops_gpu.py holds the convolutions' tile sums to."""
+    from lidal_amd import backend as B
+    from lidal_amd.nn.functional.norm import train_backward
+    L = B.lib()
+    g = torch.Generator(device='cpu').manual_seed(7 * n + c)
+    dev = torch.device(DEV)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).to(dev)
+    out = rnd(n, c).to(dtype)
+    grad = rnd(n, c).to(dtype)
+    xa, xb = (rnd(n, c) * 1.5 + 0.3).to(dtype), (rnd(n, c) * 0.7 - 0.2).to(dtype)
+    code = B.dtype_code(dtype)
+    stats = []
+    for x in (xa, xb):
+        xf = x.float()
+        stats.append((xf.mean(0).contiguous(), (1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)).contiguous()))
+    wa, ba, wb, bb = rnd(c), rnd(c), rnd(c), rnd(c)
+    dxa, gga, gba, gm = train_backward(xa, wa, ba, stats[0][0], stats[0][1], False, grad, mask_from=out)
+    dxb, ggb, gbb, _ = train_backward(xb, wb, bb, stats[1][0], stats[1][1], False, gm)
+    parts = int(L.lidal_bn_tail_parts(n, c, code))
+    # (csrc/bn.hip rows_per_wg_ew: 512 slabs from 12 MiB of rows on, 256 below, at least 32 rows each)
+    rpw = max(32, -(-n // (512 if n * c * out.element_size() >= (12 << 20) else 256)))
+    assert parts == -(-n // rpw) and 1 <= parts <= 512
+    for dual in (True, False):
+        gm2 = torch.empty_like(out)
+        sa = torch.full((c, parts, 2), float('nan'), dtype=torch.float32, device=dev)
+        sb = torch.full((c, parts, 2), float('nan'), dtype=torch.float32, device=dev)
+        B.check(L.lidal_add_relu_bwd_bn_tile_sums(B.ptr(out), B.ptr(grad), B.ptr(gm2), code, n, c, B.ptr(xa),
+                                                  B.ptr(stats[0][0]), B.ptr(stats[0][1]), B.ptr(sa),
+                                                  B.ptr(xb) if dual else None, B.ptr(stats[1][0]) if dual else None,
+                                                  B.ptr(stats[1][1]) if dual else None, B.ptr(sb) if dual else None,
+                                                  parts, B.stream()), 'add_relu_bwd')
+        assert torch.equal(gm2, gm)
+        for x, w, b, (mu, inv), sums, want in ((xa, wa, ba, stats[0], sa, (dxa, gga, gba)),
+                                               (xb, wb, bb, stats[1], sb, (dxb, ggb, gbb)))[:2 if dual else 1]:
+            # the sums of every slab against f64
+            gd = gm.double()
+            xh = (x.double() - mu.double()) * inv.double()
+            pad = parts * rpw - n
+            def slabs(t):
+                t = torch.cat([t, torch.zeros(pad, c, dtype=t.dtype, device=dev)]) if pad else t
+                return t.view(parts, rpw, c).sum(1).t()                  # [c, parts]
+            ref_a, ref_b = slabs(gd), slabs(gd * xh)
+            mag_a, mag_b = slabs(gd.abs()), slabs((gd * xh).abs())
+            assert torch.isfinite(sums).all()
+            assert float(((sums[:, :, 0].double() - ref_a).abs() / (mag_a + 1e-30)).max()) < 2e-6
+            assert float(((sums[:, :, 1].double() - ref_b).abs() / (mag_b + 1e-30)).max()) < 2e-6
+            dx = torch.empty_like(x)
+            gg = torch.empty(c, dtype=torch.float32, device=dev)
+            gb = torch.empty(c, dtype=torch.float32, device=dev)
+            B.check(L.lidal_bn_bwd_tiles(B.ptr(x), B.ptr(gm2), c, code, n, c, B.ptr(w), B.ptr(b), 0, B.ptr(mu), B.ptr(inv),
+                                         B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(sums), parts, B.stream()), 'bn_bwd')
+            scale_g = float(mag_b.sum(1).max())
+            scale_b = float(mag_a.sum(1).max())
+            assert float((gg.double() - want[1].double()).abs().max()) < 1e-5 * scale_g
+            assert float((gb.double() - want[2].double()).abs().max()) < 1e-5 * scale_b
+            err = (dx.double() - want[0].double()).abs()
+            # (f32 is not a product case -- norm.tail_tiles is bf16 only --: the sums' 1e-6 shows in dx there)
+            step = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -16) * want[0].double().abs().clamp_min(1e-3)
+            assert float((err / step).max()) <= 1.0 + 1e-6
+
+
 def _tile_triples(x, tile=128):
     """(count, mean, M2) per 128-row tile and channel, what a convolution's epilogue leaves: f32, laid out
     [c][tiles][3] (csrc/conv_img.hip store_tile) -- returned with that buffer's shape recorded as (tiles, c, 3)."""

@@ -314,7 +314,7 @@ def _replay(run, model, stats, conv_every=1):
                     stats.f32('bn backward dx f32', got, gx, '%d x %d' % (n, c), 1e-5)
                 stats.f32('bn backward grad gamma', _vec(gg_p, c).double(), gg, '%d x %d' % (n, c), 2e-4 if kind == P.OP_BN_BWD_TILES else 1e-5)
                 stats.f32('bn backward grad beta', _vec(gb_p, c).double(), gb, '%d x %d' % (n, c), 2e-4 if kind == P.OP_BN_BWD_TILES else 1e-5)
-            elif kind == P.OP_ADD_RELU_BWD_BN_SUMS:      # (the sums it leaves are checked through OP_BN_BWD_FROM_SUMS)
+            elif kind in (P.OP_ADD_RELU_BWD_BN_SUMS, P.OP_ADD_RELU_BWD_BN_TILE_SUMS):      # (the sums they leave are checked through OP_BN_BWD_FROM_SUMS / OP_BN_BWD_TILES)
                 y_p, g_p, gin_p, code, n, c = a[:6]
                 y, gg = _mat(y_p, n, c, code), _mat(g_p, n, c, code)
                 stats.exact('relu mask', _mat(gin_p, n, c, code), torch.where(y > 0, gg, torch.zeros_like(gg)), 'mask')

@@ -428,6 +428,10 @@ int lidal_bn_bwd_from_sums(const void* x, const void* dy, int64_t dy_stride, int
  *   naming the launch (lidal_bn_check_device) until lidal_bn_set_fused() is called again: never a silent NaN.
  * lidal_bn_set_fused also acknowledges such an error. */
 int lidal_bn_set_fused(int on);
+/* bf16 lidal_bn_bwd takes its two sums per channel as f32 sums over slabs of rows (512 slabs on the large levels, merged in
+ * f64 like the convolutions' tile sums: an element-wise-shaped first pass at ~5 TB/s) -- 1, the default -- or as the f64
+ * partial sums the f32 mode uses (0; LIDAL_BN_SLAB_SUMS=0 in the environment).  Returns the previous setting. */
+int lidal_bn_set_slab_sums(int on);
 /* 0, or 1 with lidal_last_error() set if a fused BatchNorm launch on the current device timed out (above). */
 int lidal_bn_check_device(void);
 /* eval-mode BatchNorm as a per-channel affine map (scale = gamma / sqrt(var + eps),

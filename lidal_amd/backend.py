@@ -107,6 +107,7 @@ SIGNATURES = {
     'lidal_bn_bwd_from_sums': (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _i64, _vp]),
     'lidal_bn_set_fused': (_i32, [_i32]),
+    'lidal_bn_set_slab_sums': (_i32, [_i32]),
     'lidal_bn_check_device': (_i32, []),
     'lidal_bn_fold': (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
     'lidal_colsum': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp]),

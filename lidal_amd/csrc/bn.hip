@@ -358,6 +358,80 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
   }
 }
 
+// bf16 (round 5): the same sums as an ELEMENT-WISE-shaped launch -- rows_per_wg_ew slabs (512 workgroups on the large
+// levels: two waves per SIMD), f32 sums per thread (~40 rows) and through the LDS tree, one f32 pair per (channel, slab)
+// in the layout of the convolutions' tile sums ([channel][part][2]); bn_bwd_dx_merge_kernel<T, true> merges the slabs
+// in f64.  The f64 kernel above runs one wave per SIMD and streams (x, dy) at ~3.7 TB/s; this one at the ~5 TB/s of the
+// dx pass (tail_tile_sums_kernel below is the same idea with the ReLU mask of a block's tail in front).  The f32 parity
+// mode keeps the f64 sums.
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_bwd_slab_sums_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n,
+                                                              int c, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int relu,
+                                                              float* __restrict__ sums, int rpw, int64_t ldy) {
+  constexpr int VEC = IO<T>::VEC;
+  __shared__ float sh[NT * VEC];
+  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int tid = threadIdx.x, cg = tid % cg_n, rl = tid / cg_n;
+  const int64_t r_beg = (int64_t)blockIdx.x * rpw;
+  const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
+  float a[VEC], b[VEC];
+  float mu[VEC], is[VEC], ga[VEC], be[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; ga[i] = 1.f; be[i] = 0.f; }
+  if (rl < rpi) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mu[i] = mean[cg * VEC + i]; is[i] = invstd[cg * VEC + i];
+      if (gamma) ga[i] = gamma[cg * VEC + i];
+      if (beta) be[i] = beta[cg * VEC + i];
+    }
+    auto one = [&](const typename IO<T>::vec& vx, const typename IO<T>::vec& vd) {
+      float fx[VEC], fd[VEC];
+      IO<T>::unpack(vx, fx);
+      IO<T>::unpack(vd, fd);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float xhat = (fx[i] - mu[i]) * is[i];
+        if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
+        a[i] += fd[i]; b[i] += fd[i] * xhat;
+      }
+    };
+    int64_t r = r_beg + rl;
+    for (; r + (UNR - 1) * rpi < r_end; r += UNR * rpi) {
+      typename IO<T>::vec vx[UNR], vd[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        vx[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
+        vd[u] = *reinterpret_cast<const typename IO<T>::vec*>(dy + (r + u * rpi) * ldy + cg * VEC);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) one(vx[u], vd[u]);
+    }
+    for (; r < r_end; r += rpi)
+      one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
+          *reinterpret_cast<const typename IO<T>::vec*>(dy + r * ldy + cg * VEC));
+  }
+  const int nparts = (int)gridDim.x, part = (int)blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) sh[tid * VEC + i] = a[i];
+  tree_sum_rows<VEC, float>(sh, tid, cg_n, rpi, rl);
+  if (rl == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sums[((int64_t)(cg * VEC + i) * nparts + part) * 2] = sh[tid * VEC + i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) sh[tid * VEC + i] = b[i];
+  tree_sum_rows<VEC, float>(sh, tid, cg_n, rpi, rl);
+  if (rl == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sums[((int64_t)(cg * VEC + i) * nparts + part) * 2 + 1] = sh[tid * VEC + i];
+  }
+}
+
 // The tail of a residual block backwards (network/blocks.py _Residual.backward): gm = g * (out > 0) is the gradient of
 // BOTH summands of relu(bn2(x_a) + shortcut).  Written once here and, in the same pass, summed against xhat of bn2 (and,
 // DUAL, of the shortcut's BatchNorm over x_b): the loop of bn_bwd_partial_kernel over (x, gm) with relu = 0, term by term
@@ -683,11 +757,60 @@ bool bn_bwd_merge_dx(const void* x, const void* dy, int64_t ldy, int64_t n, int 
                      int relu, const float* mean, const float* invstd, void* dx, float* ggamma, float* gbeta,
                      const void* part, int nparts, hipStream_t s);
 
+// LIDAL_BN_SLAB_SUMS=0 / lidal_bn_set_slab_sums(0): the f64 partial sums for bf16 too (A/B, and the bitwise tests against
+// the fused tail of the f32 mode)
+static int g_slab_sums = -1;            // -1: not read yet
+static inline bool slab_sums_enabled() {
+  if (g_slab_sums < 0) { const char* e = getenv("LIDAL_BN_SLAB_SUMS"); g_slab_sums = (e && e[0] == '0') ? 0 : 1; }
+  return g_slab_sums != 0;
+}
+__global__ void __launch_bounds__(NT) bn_bwd_tiles_final_kernel(const float* __restrict__ part, int nparts, int c,
+                                                                float* __restrict__ sum_dy,
+                                                                float* __restrict__ sum_dy_xhat) {
+  __shared__ double sa[NT], sb[NT];
+  const int tid = threadIdx.x, ch = blockIdx.x;
+  double a = 0., b = 0.;
+  for (int p = tid; p < nparts; p += NT) {
+    const float* s = part + ((int64_t)ch * nparts + p) * 2;
+    a += (double)s[0]; b += (double)s[1];
+  }
+  sa[tid] = a; sb[tid] = b;
+  for (int st = NT / 2; st >= 1; st >>= 1) {
+    __syncthreads();
+    if (tid < st) { sa[tid] += sa[tid + st]; sb[tid] += sb[tid + st]; }
+  }
+  if (tid == 0) {
+    sum_dy[ch] = (float)sa[0];            // = grad_beta
+    sum_dy_xhat[ch] = (float)sb[0];       // = grad_gamma
+  }
+}
+
 template <typename T>
 int bn_bwd(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const float* gamma,
            const float* beta, int relu, const float* mean, const float* invstd, void* dx, float* ggamma,
            float* gbeta, double* part, hipStream_t s) {
   constexpr int VEC = IO<T>::VEC;
+  if (sizeof(T) == 2 && slab_sums_enabled()) {
+    // bf16: f32 slab sums on the element-wise grid, merged like the convolutions' tile sums (bn_bwd_slab_sums_kernel)
+    const int64_t rb = (int64_t)c * sizeof(T);
+    const int parts = nslabs_ew(n, rb);
+    float* sums = (float*)part;               // c * parts * 8 bytes <= lidal_bn_workspace_bytes (parts <= 2 * nparts_for)
+    bn_bwd_slab_sums_kernel<T><<<parts, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, sums,
+                                                   rows_per_wg_ew(n, rb), ldy);
+    LIDAL_CHECK_LAUNCH("bn_bwd_slab_sums");
+    if (bn_bwd_merge_dx<T, true>(x, dy, ldy, n, c, gamma, beta, relu, mean, invstd, dx, ggamma, gbeta, sums, parts, s)) {
+      LIDAL_CHECK_LAUNCH("bn_bwd_dx(slab sums merged in the launch)");
+      return 0;
+    }
+    bn_bwd_tiles_final_kernel<<<(unsigned)c, NT, 0, s>>>(sums, parts, c, gbeta, ggamma);
+    LIDAL_CHECK_LAUNCH("bn_bwd_final(slabs)");
+    if (dx != nullptr) {
+      bn_bwd_dx_kernel<T><<<parts, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, gbeta,
+                                               ggamma, (T*)dx, rows_per_wg_ew(n, rb), ldy);
+      LIDAL_CHECK_LAUNCH("bn_bwd_dx");
+    }
+    return 0;
+  }
   int np = nparts_for(n);
   bn_bwd_partial_kernel<T><<<np, NT, 2 * NT * VEC * sizeof(double), s>>>(
       (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, rows_per_wg(n), ldy);
@@ -1222,6 +1345,14 @@ extern "C" int lidal_bn_check_device(void) {
   return 1;
 }
 
+// test / A-B aid: 1 = bf16 lidal_bn_bwd takes its sums as f32 slab sums (default), 0 = the f64 partial sums of the f32 mode.
+// Returns the previous setting.
+extern "C" int lidal_bn_set_slab_sums(int on) {
+  const int was = slab_sums_enabled() ? 1 : 0;
+  g_slab_sums = on ? 1 : 0;
+  return was;
+}
+
 // test / A-B aid: 1 = merge kernels inside their consumers (default), 0 = separate launches
 extern "C" int lidal_bn_set_fused(int on) {
   g_fused.store(on ? 1 : 0);
@@ -1366,26 +1497,7 @@ extern "C" int lidal_bn_bwd_from_sums(const void* x, const void* dy, int64_t dy_
 // The backward sums came with dy from the data-gradient launch that produced it (conv_img.hip, BnBwd: f32
 // (sum dy', sum dy' xhat) per 128-row tile and column): merge the tiles in f64, then the dx pass.  No
 // bn_bwd_partial pass over x and dy.
-__global__ void __launch_bounds__(NT) bn_bwd_tiles_final_kernel(const float* __restrict__ part, int nparts, int c,
-                                                                float* __restrict__ sum_dy,
-                                                                float* __restrict__ sum_dy_xhat) {
-  __shared__ double sa[NT], sb[NT];
-  const int tid = threadIdx.x, ch = blockIdx.x;
-  double a = 0., b = 0.;
-  for (int p = tid; p < nparts; p += NT) {
-    const float* s = part + ((int64_t)ch * nparts + p) * 2;
-    a += (double)s[0]; b += (double)s[1];
-  }
-  sa[tid] = a; sb[tid] = b;
-  for (int st = NT / 2; st >= 1; st >>= 1) {
-    __syncthreads();
-    if (tid < st) { sa[tid] += sa[tid + st]; sb[tid] += sb[tid + st]; }
-  }
-  if (tid == 0) {
-    sum_dy[ch] = (float)sa[0];            // = grad_beta
-    sum_dy_xhat[ch] = (float)sb[0];       // = grad_gamma
-  }
-}
+
 
 // The tail of a residual block backwards on the levels with many rows: gm = g * (out > 0) and, per part (a slab of
 // rows: lidal_bn_tail_parts of them) and channel, the f32 pairs (sum gm, sum gm xhat) of the BatchNorm over x_a -- and

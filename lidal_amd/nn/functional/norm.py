@@ -131,17 +131,21 @@ def tail_sums(n):
     return 0 < n < TAIL_SUMS_ROWS
 
 
-# Above the row limit (round 5): the mask as an element-wise launch that leaves f32 sums per slab of rows in the layout of
-# the convolutions' tile sums (lidal_add_relu_bwd_bn_tile_sums), merged by lidal_bn_bwd_tiles in front of its dx pass --
-# 11 passes over the level's arrays instead of 13 (a block with a shortcut BatchNorm), 7 instead of 8 (without).  bf16
-# only: the f32 parity mode keeps the f64 sums its golden gradients were taken with.  LIDAL_TAIL_TILES=0: off.
+# bf16 (round 5): the mask as an element-wise launch that leaves f32 sums per slab of rows in the layout of the
+# convolutions' tile sums (lidal_add_relu_bwd_bn_tile_sums), merged by lidal_bn_bwd_tiles in front of its dx pass -- 11
+# passes over the level's arrays instead of 13 (a block with a shortcut BatchNorm), 7 instead of 8 (without) against the
+# separate passes, and an element-wise kernel on 512 workgroups instead of the f64 reduction on 256 against the fused
+# pair above.  Measured on every level (scripts/gpu/r5_tail_rows.sh, row limits 100 000 / 30 000 / 1): 5 scans 13.99-14.07
+# / 13.98-14.00 / 13.93-13.95 ms, one scan 6.30-6.55 / 6.25-6.40 / 6.18 ms -> every level.  The f32 parity mode keeps
+# the f64 sums its golden gradients were taken with.  LIDAL_TAIL_TILES=0: off; LIDAL_TAIL_TILES_ROWS: from that many rows.
 TAIL_TILES = os.environ.get('LIDAL_TAIL_TILES', '1') != '0'
+TAIL_TILES_ROWS = int(os.environ.get('LIDAL_TAIL_TILES_ROWS', '1'))
 
 
 def tail_tiles(n, dtype):
     """Does the tail of a residual block of n rows run as the element-wise mask with slab sums?  (One rule for the
     per-operator path and the planned step.)"""
-    return TAIL_TILES and n >= TAIL_SUMS_ROWS > 0 and dtype == torch.bfloat16
+    return TAIL_TILES and n >= TAIL_TILES_ROWS > 0 and dtype == torch.bfloat16
 
 
 def _tail_backward_tiles(grad_out, out, x2, w2, b2, mean2, inv2, shortcut):

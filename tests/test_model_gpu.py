@@ -582,7 +582,10 @@ def test_bn_backward_sums_from_the_data_gradient_launches(name, golden_dir):
     finally:
         blocks.BN_SUMS = saved
     (l0, g0, h0), (l1, g1, h1) = runs
-    assert h0 == 0 and h1 == 16, (h0, h1)           # bn1 of the 16 residual blocks
+    # bn1 of the 16 residual blocks; under bf16 the tails of the blocks take slab sums through the same entry point
+    # whatever BN_SUMS says (norm.tail_tiles: bn2 of 16 blocks + the shortcut BatchNorm of those that change width)
+    from lidal_amd.nn.functional import norm as _norm
+    assert h1 - h0 == 16 and (h0 > 16 if _norm.TAIL_TILES else h0 == 0), (h0, h1)
     assert l0 == l1                                 # the forward pass is untouched
     # The operator-level test (test_ops_gpu.py) holds the sums to 1e-5 and the data gradient bitwise.  End to end,
     # this 3 k-voxel fixture amplifies any last-bit change of a BatchNorm sum through bf16 storage and 49

@@ -1238,9 +1238,14 @@ def test_block_tail_mask_with_batchnorm_sums_is_the_two_separate_passes(dtype, n
         xf = x.float()
         stats.append((xf.mean(0).contiguous(), (1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)).contiguous()))
     wa, ba, wb, bb = rnd(c), rnd(c), rnd(c), rnd(c)
-    # the separate passes (what the per-operator path runs)
-    dxa, gga, gba, gm = train_backward(xa, wa, ba, stats[0][0], stats[0][1], False, grad, mask_from=out)
-    dxb, ggb, gbb, _ = train_backward(xb, wb, bb, stats[1][0], stats[1][1], False, gm)
+    # the separate passes with f64 partial sums (the f32 mode's arithmetic; bf16 lidal_bn_bwd takes f32 slab sums by
+    # default since round 5: test_batchnorm_backward_slab_sums_against_the_f64_sums)
+    was = L.lidal_bn_set_slab_sums(0)
+    try:
+        dxa, gga, gba, gm = train_backward(xa, wa, ba, stats[0][0], stats[0][1], False, grad, mask_from=out)
+        dxb, ggb, gbb, _ = train_backward(xb, wb, bb, stats[1][0], stats[1][1], False, gm)
+    finally:
+        L.lidal_bn_set_slab_sums(was)
     nb = L.lidal_bn_workspace_bytes(n, c)
     for dual in (True, False):
         gm2 = torch.empty_like(out)
@@ -1329,6 +1334,57 @@ def test_block_tail_mask_with_slab_sums_against_the_separate_passes(dtype, n, c)
             # (f32 is not a product case -- norm.tail_tiles is bf16 only --: the sums' 1e-6 shows in dx there)
             step = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -16) * want[0].double().abs().clamp_min(1e-3)
             assert float((err / step).max()) <= 1.0 + 1e-6
+
+
+@pytest.mark.parametrize('relu', [0, 1])
+@pytest.mark.parametrize('n,c,ld', [(396662, 96, 128), (396662, 256, 256), (105363, 128, 192), (43145, 256, 384), (1001, 64, 64), (77, 32, 32)])
+def test_batchnorm_backward_slab_sums_against_the_f64_sums(n, c, ld, relu):
+    """bf16 lidal_bn_bwd with its sums taken as f32 slab sums (the default since round 5: bn_bwd_slab_sums_kernel, merged
+    in f64 like the convolutions' tile sums) against the f64 partial sums (lidal_bn_set_slab_sums(0)), on gradient slices
+    of a wider matrix too (dy_stride > c: the decoder's concatenations): parameter gradients within 1e-5 of the column's
+    sum of magnitudes, dx within one bf16 rounding step; and the fused launch bitwise the separate launches."""
+    from lidal_amd import backend as B
+    L = B.lib()
+    dev = torch.device(DEV)
+    g = torch.Generator(device='cpu').manual_seed(11 * n + c + relu)
+    x = (torch.randn(n, c, generator=g) * 1.3 + 0.2).to(dev).bfloat16()
+    wide = torch.randn(n, ld, generator=g).to(dev).bfloat16()
+    dy = wide[:, ld - c:]
+    w, b = torch.randn(c, generator=g).to(dev), torch.randn(c, generator=g).to(dev)
+    xf = x.float()
+    mu = xf.mean(0).contiguous()
+    inv = (1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)).contiguous()
+    nb = L.lidal_bn_workspace_bytes(n, c)
+
+    def run():
+        dx = torch.empty_like(x)
+        gg = torch.empty(c, dtype=torch.float32, device=dev)
+        gb = torch.empty(c, dtype=torch.float32, device=dev)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        B.check(L.lidal_bn_bwd(B.ptr(x), dy.data_ptr(), ld, 1, n, c, B.ptr(w), B.ptr(b), relu, B.ptr(mu), B.ptr(inv),
+                               B.ptr(dx), B.ptr(gg), B.ptr(gb), B.ptr(ws), nb, B.stream()), 'bn_bwd')
+        torch.cuda.synchronize()
+        return dx, gg, gb
+    was = L.lidal_bn_set_slab_sums(0)
+    try:
+        ref = run()
+        L.lidal_bn_set_slab_sums(1)
+        got = run()
+        L.lidal_bn_set_fused(0)
+        apart = run()
+    finally:
+        L.lidal_bn_set_fused(1)
+        L.lidal_bn_set_slab_sums(was)
+    assert all(torch.equal(a, b_) for a, b_ in zip(got, apart))
+    xh = (x.double() - mu.double()) * inv.double()
+    d = dy.double()
+    if relu:
+        d = torch.where(xh * w.double() + b.double() > 0, d, torch.zeros_like(d))
+    scale_b, scale_g = float(d.abs().sum(0).max()), float((d * xh).abs().sum(0).max())
+    assert float((got[2].double() - ref[2].double()).abs().max()) < 1e-5 * scale_b
+    assert float((got[1].double() - ref[1].double()).abs().max()) < 1e-5 * scale_g
+    err = (got[0].double() - ref[0].double()).abs()
+    assert float((err / (2.0 ** -7 * ref[0].double().abs().clamp_min(1e-3))).max()) <= 1.0 + 1e-6
 
 
 def _tile_triples(x, tile=128):

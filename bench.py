@@ -476,6 +476,7 @@ FAMILY_OF = {
     'lidal_devoxelize_fwd': 'point_voxel', 'lidal_devoxelize_bwd': 'point_voxel',
     'lidal_invlist_build': 'point_voxel', 'lidal_voxelize_fwd_sorted': 'point_voxel',
     'lidal_devoxelize_bwd_sorted': 'point_voxel', 'lidal_ti_weights': 'point_voxel',
+    'lidal_devoxelize_bwd_cells': 'point_voxel',
     'lidal_copy2d': 'fused_elementwise', 'lidal_add2d': 'fused_elementwise', 'lidal_transpose_f32': 'fused_elementwise',
     'lidal_cast_rows_bf16': 'fused_elementwise',
     'lidal_add_relu_fwd': 'fused_elementwise', 'lidal_add_relu_bwd': 'fused_elementwise',
@@ -512,6 +513,7 @@ def family_table(step, coords, dtype_name, step_ms):
         x = prefetch_kernel_maps(SparseTensor(None, coords), _SparseUNet.MAP_PLAN)
         rules = {}
         kmap_batch_bytes = 0                # every map of the network, built by ONE lidal_kmap_build_batch call
+    kmap_points = int(coords.shape[0])  # (SPVCNN's points: the voxel centres of the batch, one per voxel)
         for key, km in x.kmaps.items():
             if km.volume == 27:
                 rules[km.sizes[1]] = km.total
@@ -634,6 +636,11 @@ def family_table(step, coords, dtype_name, step_ms):
         elif name in ('lidal_voxelize_fwd_sorted', 'lidal_devoxelize_bwd_sorted'):
             m_rows, c, dt, n_ent = a[5], a[6], a[7], a[8]
             by = (n_ent + m_rows) * c * (2 if dt == 1 else 4)
+        elif name == 'lidal_devoxelize_bwd_cells':
+            # (gout, vorder, vseg, w8, corder, cseg, gin, m, c, dtype, ...): priced like the per-voxel form it replaces --
+            # one row in per (point, corner), one row out per voxel -- with the points of the lists
+            m_rows, c, dt = a[7], a[8], a[9]
+            by = (8 * (kmap_points or m_rows) + m_rows) * c * (2 if dt == 1 else 4)
         elif name == 'lidal_voxelize_fwd_1to1':
             by = 2 * a[3] * a[4] * (2 if a[5] == 1 else 4)                          # a row in, a row out
         elif name == 'lidal_voxelize_bwd':

@@ -223,6 +223,17 @@ int lidal_voxelize_fwd_sorted(const void* feat, const int32_t* order, const int6
 int lidal_devoxelize_bwd_sorted(const void* gout, const int32_t* order, const int64_t* seg_ptr,
                                 const float* w, void* gin, int64_t m, int c, int dtype,
                                 int64_t n_entries, void* ws, int64_t ws_bytes, void* stream);
+/* The same gradient through the CELLS, for levels where a voxel has many contributors (stride 16): every point of a cell --
+ * the voxel its own coordinates floor to, idx8[:, 0] -- interpolates from the same eight corners (network/utils.py:67-79),
+ * so  cs[cell][j] = sum over the cell's points of w8[p][j] * gout[p]  (vorder / vseg: the points of every cell, the inverse
+ * lists of idx8[:, 0])  and  gin[v] = sum of the cs[cell][j] whose corner j is v  (corder / cseg: the inverse lists of the
+ * cells' [m, 8] corner indices, entries cell * 8 + j).  Reads every gradient row once instead of eight times.  Fixed
+ * orders, no atomics; differs from lidal_devoxelize_bwd_sorted by the association of the f32 sums.  c in {32, 64, 128, 256}
+ * (any power of two of 16-byte steps, 4 .. 64); ws >= lidal_devoxelize_bwd_cells_workspace_bytes(m, c) = m * 8 * c * 4. */
+int64_t lidal_devoxelize_bwd_cells_workspace_bytes(int64_t m, int c);
+int lidal_devoxelize_bwd_cells(const void* gout, const int32_t* vorder, const int64_t* vseg, const float* w8,
+                               const int32_t* corder, const int64_t* cseg, void* gin, int64_t m, int c, int dtype,
+                               void* ws, int64_t ws_bytes, void* stream);
 /* replaces F.calc_ti_weights (torchsparse/nn/functional/devoxelize.py; network/utils.py:77):
  * coords f32 [n, cstride>=3], idx i64 [8,n] -> w f32 [n,8] and idx32 i32 [n,8] (both already
  * transposed as network/utils.py:78-79 does). */
@@ -547,7 +558,7 @@ enum {
   LIDAL_OP_ADD2D = 22, LIDAL_OP_TRANSPOSE_F32 = 23, LIDAL_OP_CAST_ROWS_BF16 = 24, LIDAL_OP_VIEW_MEAN_SOFTMAX = 25,
   LIDAL_OP_FORK_SIDE = 26, LIDAL_OP_JOIN_SIDE = 27, LIDAL_OP_CONV_APPLY_IMAGE_WS = 28,
   LIDAL_OP_CONV_DGRAD_BN_SUMS_WS = 29, LIDAL_OP_ADD_RELU_BWD_BN_SUMS = 30, LIDAL_OP_BN_BWD_FROM_SUMS = 31,
-  LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS = 32
+  LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS = 32, LIDAL_OP_DEVOXELIZE_BWD_CELLS = 33
 };
 #define LIDAL_OP_FLAG_SIDE 1
 int lidal_plan_op_args(int kind);

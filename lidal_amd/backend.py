@@ -65,6 +65,8 @@ SIGNATURES = {
     'lidal_segment_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'lidal_voxelize_fwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
     'lidal_devoxelize_bwd_sorted': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
+    'lidal_devoxelize_bwd_cells': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
+    'lidal_devoxelize_bwd_cells_workspace_bytes': (_i64, [_i64, _i32]),
     'lidal_ti_weights': (_i32, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp]),
     'lidal_sort_pairs_workspace_bytes': (_i64, [_i64]),
     'lidal_sort_pairs': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),

@@ -233,6 +233,7 @@ const OpInfo kOps[] = {
     /* LIDAL_OP_ADD_RELU_BWD_BN_SUMS 30 */ {15, "add_relu_bwd_bn_sums"},
     /* LIDAL_OP_BN_BWD_FROM_SUMS 31 */ {16, "bn_bwd_from_sums"},
     /* LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS 32 */ {15, "add_relu_bwd_bn_tile_sums"},
+    /* LIDAL_OP_DEVOXELIZE_BWD_CELLS 33 */ {12, "devoxelize_bwd_cells"},
 };
 constexpr int kNumOps = (int)(sizeof(kOps) / sizeof(kOps[0]));
 
@@ -417,6 +418,10 @@ int run_ops(const int64_t* words, int64_t n_words, int64_t n_ops, void* const* s
       case LIDAL_OP_DEVOXELIZE_BWD_SORTED:
         rc = lidal_devoxelize_bwd_sorted(P(0), CP(int32_t, 1), CP(int64_t, 2), CP(float, 3), P(4), L(5), I(6), I(7),
                                          L(8), P(9), L(10), st);
+        break;
+      case LIDAL_OP_DEVOXELIZE_BWD_CELLS:
+        rc = lidal_devoxelize_bwd_cells(P(0), CP(int32_t, 1), CP(int64_t, 2), CP(float, 3), CP(int32_t, 4), CP(int64_t, 5),
+                                        P(6), L(7), I(8), I(9), P(10), L(11), st);
         break;
       case LIDAL_OP_CE_FWD:
         rc = lidal_ce_fwd(P(0), I(1), CP(int64_t, 2), L(3), I(4), L(5), MP(float, 6), P(7), L(8), st);

@@ -78,7 +78,10 @@ class Geometry:
                     pidx, counts = point_tables(xs, z)
                     prepare_voxelize(pidx, counts)
                     if grad:
-                        prepare_devoxelize(idx, w, xs.C.shape[0])
+                        # (channels of the features devoxelized at this stride, network/spvcnn.py:139-155: the
+                        #  backward's lists are per-voxel or per-cell by them -- F.devoxelize.cells_mode)
+                        pc = {1: model.cs[8], 16: model.cs[4], 4: model.cs[6]}.get(s)
+                        prepare_devoxelize(idx, w, xs.C.shape[0], pc)
                 g.z = z
             else:
                 x0 = SparseTensor(None, coords, 1)

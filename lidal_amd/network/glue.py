@@ -124,6 +124,9 @@ def corner_tables(x, z, nearest=False):
         if nearest:
             weights[:, 1:] = 0.
             idx_query[:, 1:] = -1
+        # every point of a cell (idx_query[:, 0]: the voxel its own coordinates floor to) has the same eight corners by
+        # the expression above: what the cell form of the backward relies on (F.devoxelize.cells_mode)
+        idx_query._lidal_cell_corners = True
         z.idx_query[x.s] = idx_query
         z.weights[x.s] = weights
     return z.idx_query[x.s], z.weights[x.s]

@@ -36,6 +36,7 @@ import torch
 from .. import backend as B
 from ..nn.functional import conv as _C
 from ..nn.functional import norm as _N
+from ..nn.functional import devoxelize as _DV
 from ..nn.functional.invlist import inverse_lists
 from ..nn.functional.voxelize import _index32
 
@@ -51,7 +52,7 @@ OP_COLSUM, OP_ADD_RELU_FWD, OP_ADD_RELU_BWD, OP_VOXELIZE_FWD_1TO1, OP_VOXELIZE_F
 OP_VOXELIZE_BWD, OP_DEVOXELIZE_FWD, OP_DEVOXELIZE_BWD_SORTED, OP_CE_FWD, OP_CE_BWD = 16, 17, 18, 19, 20
 OP_COPY2D, OP_ADD2D, OP_TRANSPOSE_F32, OP_CAST_ROWS_BF16, OP_VIEW_MEAN_SOFTMAX = 21, 22, 23, 24, 25
 OP_FORK_SIDE, OP_JOIN_SIDE, OP_CONV_APPLY_IMAGE_WS, OP_CONV_DGRAD_BN_SUMS_WS = 26, 27, 28, 29
-OP_ADD_RELU_BWD_BN_SUMS, OP_BN_BWD_FROM_SUMS, OP_ADD_RELU_BWD_BN_TILE_SUMS = 30, 31, 32
+OP_ADD_RELU_BWD_BN_SUMS, OP_BN_BWD_FROM_SUMS, OP_ADD_RELU_BWD_BN_TILE_SUMS, OP_DEVOXELIZE_BWD_CELLS = 30, 31, 32, 33
 
 # operations executed inside plans ('ops') and plans run ('plans') since import (backend.HITS counts every
 # library call made from Python, 'plan_run' among them)
@@ -86,7 +87,7 @@ _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv
               16: 'voxelize_bwd', 17: 'devoxelize_fwd', 18: 'devoxelize_bwd_sorted', 19: 'ce_fwd', 20: 'ce_bwd',
               21: 'copy2d', 22: 'add2d', 23: 'transpose_f32', 24: 'cast_rows_bf16', 25: 'view_mean_softmax',
               26: 'fork_side', 27: 'join_side', 28: 'conv_apply', 29: 'conv_apply', 30: 'add_relu_bwd', 31: 'bn_bwd',
-              32: 'add_relu_bwd'}
+              32: 'add_relu_bwd', 33: 'devoxelize_bwd_cells'}
 
 
 def _tally(words):
@@ -464,7 +465,7 @@ def _seg_ws(n_entries, m, c):
 class _Tables:
     """The addresses a step reads out of its Geometry, gathered once per geometry."""
 
-    def __init__(self, g, spvcnn, train):
+    def __init__(self, g, spvcnn, train, model_cs=None):
         x0 = g.x0
         km, cm = x0.kmaps, x0.cmaps
         self.n = []
@@ -510,18 +511,27 @@ class _Tables:
                 s = 1 << l
                 idx8, w8 = z.idx_query[(s, s, s)], z.weights[(s, s, s)]
                 assert idx8.dtype == torch.int32 and idx8.is_contiguous() and w8.dtype == torch.float32
-                do, dsp = inverse_lists(idx8, m, w8) if train else (idx8, idx8)     # (backward only)
+                # (backward only) the per-voxel contributor lists -- or, on a level with many points per voxel, the
+                # per-cell lists of F.devoxelize.devox_cells: the rule of the per-operator path, cells_mode
+                pc = {0: model_cs[8], 4: model_cs[4], 2: model_cs[6]}[l]
+                cells = None
+                do = dsp = idx8
+                if train and _DV.cells_mode(idx8, self.p, m, pc):
+                    cells = _DV.devox_cells(idx8, m)
+                elif train:
+                    do, dsp = inverse_lists(idx8, m, w8)
                 cnt = counts if counts.dtype == torch.int32 and counts.is_contiguous() else counts.contiguous().int()
-                self.keep += [idx32, cnt, idx8, w8, do, dsp]
+                self.keep += [idx32, cnt, idx8, w8, do, dsp, cells]
                 self.pt[l] = (idx32.data_ptr(), cnt.data_ptr(), int(one), vorder, vseg,
-                              idx8.data_ptr(), w8.data_ptr(), do.data_ptr(), dsp.data_ptr())
+                              idx8.data_ptr(), w8.data_ptr(), do.data_ptr(), dsp.data_ptr(),
+                              tuple(t.data_ptr() for t in cells) if cells is not None else None)
 
 
-def _tables(g, spvcnn, train):
+def _tables(g, spvcnn, train, model_cs=None):
     key = '_plan_tables_train' if train else '_plan_tables'
     t = g.__dict__.get(key) or (g.__dict__.get('_plan_tables_train') if not train else None)
     if t is None:
-        t = g.__dict__[key] = _Tables(g, spvcnn, train)
+        t = g.__dict__[key] = _Tables(g, spvcnn, train, model_cs)
     return t
 
 
@@ -539,7 +549,7 @@ class _Run:
         self.bf16 = code == B.BF16
         self.dtype = torch.bfloat16 if self.bf16 else torch.float32
         self.geometry = geometry
-        self.T = _tables(geometry, prog.spvcnn, self.TRAIN)
+        self.T = _tables(geometry, prog.spvcnn, self.TRAIN, getattr(model, 'cs', None))
         self.feats = feats
         self.stream = B.stream()
         self.arena = _Arena(self.dev)
@@ -1046,6 +1056,12 @@ class _Run:
         t = self.T.pt[lvl]
         P, m = self.T.p, self.T.n[lvl]
         gin = self.galloc(m * c * self.esz)
+        if t[9] is not None:                # through the cells (F.devoxelize.cells_mode)
+            nb = m * 8 * c * 4
+            self.w += (OP_DEVOXELIZE_BWD_CELLS, g, t[9][0], t[9][1], t[6], t[9][2], t[9][3], gin, m, c, self.code,
+                       self.scratch(nb), nb)
+            self.nops += 1
+            return gin
         nb = _seg_ws(8 * P, m, c)
         self.w += (OP_DEVOXELIZE_BWD_SORTED, g, t[7], t[8], t[6], gin, m, c, self.code, 8 * P,
                    self.scratch(nb) if nb else 0, nb)

@@ -6,7 +6,42 @@ from torch.autograd import Function
 from ... import backend as B
 from .invlist import inverse_lists, segment_workspace
 
-__all__ = ['spdevoxelize', 'calc_ti_weights', 'ti_weights_and_index', 'prepare_devoxelize']
+import os
+
+__all__ = ['spdevoxelize', 'calc_ti_weights', 'ti_weights_and_index', 'prepare_devoxelize', 'devox_cells', 'cells_mode']
+
+# devoxelize backward through the cells (csrc/voxel.hip devox_cell_sums_kernel): where a voxel of the level holds at least
+# this many points on average (stride 16: ~24; stride 4: ~4, where the per-voxel lists are the shorter way).  0 = never.
+CELLS_MIN_AVG = int(os.environ.get('LIDAL_DEVOX_CELLS_AVG', '12'))
+
+
+def cells_mode(idx8, n_points, m, c, dtype=None):
+    """Does the backward of spdevoxelize over (idx8 [N, 8], m voxels, c channels) run through the cells?  Only for an
+    index that network/glue.py corner_tables built (it marks it: every point of a cell -- idx8[:, 0], the voxel its own
+    coordinates floor to -- then has the same eight corners, utils.py:67-79), on levels with many points per voxel.
+    One rule for the per-operator path and the planned step."""
+    if not CELLS_MIN_AVG or not getattr(idx8, '_lidal_cell_corners', False) or m <= 0:
+        return False
+    # (whole power-of-two counts of 16-byte steps per row under both element types)
+    return n_points >= CELLS_MIN_AVG * m and c in (32, 64, 128, 256)
+
+
+def devox_cells(idx8, m):
+    """(vorder i32 [N], vseg i64 [m + 1], corder i32 [8 m], cseg i64 [m + 1]): the points of every cell and, for every
+    voxel, the (cell * 8 + corner) entries it is a corner of.  Cached on idx8."""
+    key = (m, idx8._version, idx8.data_ptr(), idx8.numel())
+    cached = getattr(idx8, '_lidal_cells', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    cell = idx8[:, 0].contiguous()
+    vorder, vseg = inverse_lists(cell, m)
+    first = vorder[vseg[:-1]].long()                   # (every voxel of the level holds a point: its list is not empty)
+    cidx = idx8[first].contiguous()                    # [m, 8]: the corners of every cell
+    corder, cseg = inverse_lists(cidx, m)
+    out = (vorder, vseg, corder, cseg)
+    idx8._lidal_cells = (key, out, cell, cidx)
+    return out
+
 
 
 def ti_weights_and_index(coords, idx_query, scale=1):
@@ -61,7 +96,14 @@ class DevoxelizeFunction(Function):
         g = grad_output.contiguous() if native else grad_output.contiguous().float()
         n, c = g.shape
         gin = torch.empty((m, c), dtype=g.dtype, device=g.device)
-        if c % 4 == 0:      # ordered per-voxel gather: no atomics, reproducible
+        if cells_mode(coords, n, m, c, g.dtype):        # the coarse levels: every gradient row read once
+            vorder, vseg, corder, cseg = devox_cells(coords, m)
+            nbytes = B.lib().lidal_devoxelize_bwd_cells_workspace_bytes(m, c)
+            ws = B.workspace(nbytes, g.device)
+            B.check(B.lib().lidal_devoxelize_bwd_cells(B.ptr(g), B.ptr(vorder), B.ptr(vseg), B.ptr(weights), B.ptr(corder),
+                                                       B.ptr(cseg), B.ptr(gin), m, c, B.dtype_code(g.dtype), B.ptr(ws),
+                                                       nbytes, B.stream()), 'devoxelize_bwd_cells')
+        elif c % 4 == 0:    # ordered per-voxel gather: no atomics, reproducible
             order, seg_ptr = inverse_lists(coords, m, weights)
             ws, nbytes = segment_workspace(8 * n, m, c, g.device)
             B.check(B.lib().lidal_devoxelize_bwd_sorted(B.ptr(g), B.ptr(order), B.ptr(seg_ptr),
@@ -75,12 +117,15 @@ class DevoxelizeFunction(Function):
         return gin.to(in_dtype), None, None
 
 
-def prepare_devoxelize(coords, weights, m):
+def prepare_devoxelize(coords, weights, m, c=None):
     """What the backward of F.spdevoxelize derives from index and weights alone (network/geometry.py): the
     per-voxel contributor lists of the ordered scatter sum.  coords i32 [N,8], weights f32 [N,8], m voxels."""
     if coords.dtype == torch.int and coords.is_contiguous() and weights.dtype == torch.float32 \
             and weights.is_contiguous():
-        inverse_lists(coords, m, weights)
+        if c is not None and cells_mode(coords, coords.shape[0], m, c):
+            devox_cells(coords, m)
+        else:
+            inverse_lists(coords, m, weights)
 
 
 def spdevoxelize(feats, coords, weights):

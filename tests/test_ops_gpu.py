@@ -172,6 +172,75 @@ def test_spcount_voxelize_devoxelize():
         assert _relerr(v_gpu.grad.cpu(), v_ref.grad) < 1e-4
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('stride,c', [(16, 256), (16, 128), (8, 64), (4, 32)])
+def test_devoxelize_backward_through_the_cells(stride, c, dtype):
+    """lidal_devoxelize_bwd_cells (the coarse levels of the training step: every gradient row read once) on the corner
+    tables of a synthetic scan (network/glue.py corner_tables = utils.py:67-79): against the f64 definition of the
+    gradient -- the bars of the per-voxel form -- and against lidal_devoxelize_bwd_sorted; twice for run-to-run
+    bit-equality; the structure it relies on (every point of a cell has the same eight corners) checked on the tables."""
+    from lidal_amd import PointTensor, SparseTensor, synth
+    from lidal_amd import backend as B
+    from lidal_amd.network.glue import corner_tables, initial_tables
+    from lidal_amd.nn.functional import devoxelize as DV
+    from lidal_amd.nn.functional import spdownsample
+    from lidal_amd.nn.functional.invlist import inverse_lists, segment_workspace
+    L = B.lib()
+    dev = torch.device(DEV)
+    batch = synth.make_train_batch(n_frames=2, n_points=60000, seed=991)
+    coords = torch.from_numpy(batch['coords_v_b']).to(dev)
+    z = PointTensor(None, coords.float())
+    x0 = SparseTensor(None, initial_tables(z, 0.05, 0.05), 1)
+    x0.cmaps.setdefault(x0.stride, x0.coords)
+    cs = x0.C
+    s = 1
+    while s < stride:
+        cs = spdownsample(cs, 2, 2, s)
+        s *= 2
+        x0.cmaps[(s, s, s)] = cs
+    xs = SparseTensor(None, cs, stride)
+    xs.cmaps, xs.kmaps = x0.cmaps, x0.kmaps
+    idx8, w8 = corner_tables(xs, z)
+    n, m = idx8.shape[0], cs.shape[0]
+    assert getattr(idx8, '_lidal_cell_corners', False)
+    # the structure: the corners of a point are the corners of its cell's first point
+    vorder, vseg, corder, cseg = DV.devox_cells(idx8, m)
+    first = vorder[vseg[:-1]].long()
+    assert bool((idx8[:, 0] >= 0).all()) and torch.equal(idx8, idx8[first][idx8[:, 0].long()])
+    assert int(vseg[-1]) == n
+    g = torch.Generator(device='cpu').manual_seed(stride * 1000 + c)
+    gout = torch.randn(n, c, generator=g).to(dev).to(dtype)
+    code = B.dtype_code(dtype)
+    nb = L.lidal_devoxelize_bwd_cells_workspace_bytes(m, c)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        gin = torch.full((m, c), float('nan'), device=dev).to(dtype)
+        B.check(L.lidal_devoxelize_bwd_cells(B.ptr(gout), B.ptr(vorder), B.ptr(vseg), B.ptr(w8), B.ptr(corder), B.ptr(cseg),
+                                             B.ptr(gin), m, c, code, B.ptr(ws), nb, B.stream()), 'cells')
+        outs.append(gin)
+    assert torch.equal(outs[0], outs[1])
+    # f64 definition
+    ref = torch.zeros(m, c, dtype=torch.float64, device=dev)
+    gd = gout.double()
+    for j in range(8):
+        ok = idx8[:, j] >= 0
+        ref.index_add_(0, idx8[ok, j].long(), gd[ok] * w8[ok, j].double().unsqueeze(1))
+    scale = float(ref.abs().max())
+    err = float((outs[0].double() - ref).abs().max())
+    assert err < (1e-2 if dtype == torch.bfloat16 else 2e-5) * scale, (err, scale)
+    # the per-voxel form on the same operands
+    order, seg = inverse_lists(idx8, m, w8)
+    wsb, nbs = segment_workspace(8 * n, m, c, dev)
+    gin2 = torch.empty((m, c), device=dev, dtype=dtype)
+    B.check(L.lidal_devoxelize_bwd_sorted(B.ptr(gout), B.ptr(order), B.ptr(seg), B.ptr(w8), B.ptr(gin2), m, c, code, 8 * n,
+                                          B.ptr(wsb), nbs, B.stream()), 'sorted')
+    d = (outs[0].double() - gin2.double()).abs()
+    # (two associations of f32 sums over up to hundreds of terms: a few 1e-6 of the largest element apart)
+    step = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -12) * ref.abs().clamp_min(1e-3 * scale)
+    assert float((d / step).max()) <= 1.0 + 1e-6
+
+
 @pytest.mark.parametrize('scale', [1, 2, 8])
 def test_calc_ti_weights(scale):
     F = _F()

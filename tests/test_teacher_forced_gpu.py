@@ -381,6 +381,32 @@ def _replay(run, model, stats, conv_every=1):
                 ref = torch.zeros(m, c, dtype=torch.float64).index_add(0, owner, gout[ent // 8] * w[ent].unsqueeze(1))
                 stats.bf16('devoxelize backward', _mat(gin_p, m, c, code), ref, '%d x %d' % (m, c)) if code == 1 else \
                     stats.f32('devoxelize backward f32', _mat(gin_p, m, c, code), ref, 'rows', 1e-5)
+            elif kind == P.OP_DEVOXELIZE_BWD_CELLS:
+                # (gout, vorder, vseg, w8, corder, cseg, gin, m, c, dtype, ws, bytes): the reference is the definition --
+                # gin[v] = sum over points p and corners j with corner j of p's cell == v of w8[p][j] * gout[p] -- with the
+                # cells' corner indices read back out of the voxels' lists
+                g_p, vo_p, vs_p, w_p, co_p, cs_p, gin_p, m, c, code = a[:10]
+                vseg = _vec(vs_p, m + 1, np.int64)
+                n_pts = int(vseg[-1])
+                vorder = _vec(vo_p, n_pts, np.int32).long()
+                cseg = _vec(cs_p, m + 1, np.int64)
+                corder = _vec(co_p, int(cseg[-1]), np.int32).long()
+                cidx = torch.full((m * 8,), -1, dtype=torch.long)
+                cidx[corder] = torch.repeat_interleave(torch.arange(m), cseg[1:] - cseg[:-1])
+                cidx = cidx.view(m, 8)
+                n_all = run.T.p
+                cell_of = torch.full((n_all,), -1, dtype=torch.long)
+                cell_of[vorder] = torch.repeat_interleave(torch.arange(m), vseg[1:] - vseg[:-1])
+                assert bool((cell_of >= 0).all())
+                w = _vec(w_p, n_all * 8).double().view(n_all, 8)
+                gout = _mat(g_p, n_all, c, code)
+                ref = torch.zeros(m, c, dtype=torch.float64)
+                for j in range(8):
+                    tgt = cidx[cell_of, j]
+                    ok = tgt >= 0
+                    ref.index_add_(0, tgt[ok], gout[ok] * w[ok, j].unsqueeze(1))
+                stats.bf16('devoxelize backward (cells)', _mat(gin_p, m, c, code), ref, '%d x %d' % (m, c)) if code == 1 else \
+                    stats.f32('devoxelize backward (cells) f32', _mat(gin_p, m, c, code), ref, 'rows', 1e-5)
             elif kind == P.OP_COLSUM:
                 x_p, code, n, c, o_p = a[:5]
                 keep = c

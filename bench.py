@@ -508,12 +508,12 @@ def family_table(step, coords, dtype_name, step_ms):
     from lidal_amd.nn.functional.conv import prefetch_kernel_maps
     from lidal_amd.network.unet import _SparseUNet
     b_el = 2 if dtype_name == 'bf16' else 4
+    kmap_points = int(coords.shape[0])  # (SPVCNN's points: the voxel centres of the batch, one per voxel)
     # rules per level of this batch (same voxel sets whichever row order the model uses)
     with torch.no_grad():
         x = prefetch_kernel_maps(SparseTensor(None, coords), _SparseUNet.MAP_PLAN)
         rules = {}
         kmap_batch_bytes = 0                # every map of the network, built by ONE lidal_kmap_build_batch call
-    kmap_points = int(coords.shape[0])  # (SPVCNN's points: the voxel centres of the batch, one per voxel)
         for key, km in x.kmaps.items():
             if km.volume == 27:
                 rules[km.sizes[1]] = km.total

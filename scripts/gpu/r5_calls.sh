@@ -6,7 +6,10 @@ echo "bench rc=$?"
 python3 - <<'PY'
 import json, collections
 rows=[json.loads(l) for l in open('gpurun_out/r5_calls/calls.jsonl')]
-for fam in ('batch_norm','point_voxel','kernel_maps'):
+tot=collections.Counter()
+for r in rows: tot[r['family']]+=r['ms']
+print('families', {k: round(v,3) for k,v in tot.most_common()})
+for fam in ('batch_norm','point_voxel','kernel_maps','fused_elementwise','weight_pack','other_lib'):
     t=collections.OrderedDict()
     for r in rows:
         if r['family']!=fam: continue

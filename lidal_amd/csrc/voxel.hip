@@ -334,34 +334,45 @@ __device__ __forceinline__ void segment_wave_sum(const T* __restrict__ src, cons
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] += DEVOX ? sc * x[q] : x[q] / inv;
   };
-  int64_t j = beg + grp;
-  for (; j + 3 * RPW < end; j += 4 * RPW) {
-    int e[4]; float sc[4]; float x[4][VEC];
+  // 64 entries of the list per load, handed out by lane shuffle (round 5: the index load of a step no longer sits in
+  // front of its row load); a lane group still takes entries beg + grp, beg + grp + RPW, ... in this order, four rows in
+  // flight -- the sums of the earlier loop bit for bit.  The shuffles are wave-wide: the step counters do not depend on
+  // the lane.
+  for (int64_t base = beg; base < end; base += 64) {
+    const int cnt = (int)((end - base < 64) ? (end - base) : 64);
+    const int mine = lane < cnt ? order[base + lane] : 0;
+    int ib = 0;
+    for (; ib + 4 * RPW <= cnt; ib += 4 * RPW) {
+      int e[4]; float sc[4]; float x[4][VEC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) e[u] = order[j + u * RPW];
+      for (int u = 0; u < 4; ++u) e[u] = __shfl(mine, ib + grp + u * RPW, 64);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t row = DEVOX ? (e[u] >> 3) : e[u];
-      sc[u] = DEVOX ? w[e[u]] : 1.f;
-      if (act) ldv<VEC>(src + row * c + VEC * l, x[u]);
-      else {
+      for (int u = 0; u < 4; ++u) {
+        const int64_t row = DEVOX ? (e[u] >> 3) : e[u];
+        sc[u] = DEVOX ? w[e[u]] : 1.f;
+        if (act) ldv<VEC>(src + row * c + VEC * l, x[u]);
+        else {
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) x[u][q] = 0.f;
+          for (int q = 0; q < VEC; ++q) x[u][q] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(x[u], sc[u]);
+    }
+    for (; ib < cnt; ib += RPW) {
+      const bool ok = ib + grp < cnt;
+      const int e = __shfl(mine, ok ? ib + grp : 0, 64);
+      if (ok) {
+        const int64_t row = DEVOX ? (e >> 3) : e;
+        float x[VEC];
+        if (act) ldv<VEC>(src + row * c + VEC * l, x);
+        else {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) x[q] = 0.f;
+        }
+        add(x, DEVOX ? w[e] : 1.f);
       }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) add(x[u], sc[u]);
-  }
-  for (; j < end; j += RPW) {
-    const int e = order[j];
-    const int64_t row = DEVOX ? (e >> 3) : e;
-    float x[VEC];
-    if (act) ldv<VEC>(src + row * c + VEC * l, x);
-    else {
-#pragma unroll
-      for (int q = 0; q < VEC; ++q) x[q] = 0.f;
-    }
-    add(x, DEVOX ? w[e] : 1.f);
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -598,19 +609,22 @@ int launch_segment_sum(const T* src, const int* order, const int64_t* seg_ptr, c
 // lidal_devoxelize_bwd_sorted gather every row 8 times: at stride 16 (16 730 cells of ~24 points, 256 channels) 0.48 GB
 // instead of 1.46 GB.  Deterministic (fixed orders, no atomics); differs from the per-voxel form by the association of
 // the f32 sums only.  Zero weights add nothing, as in the lists of the per-voxel form (which leave them out).
+// One workgroup of four waves per cell, a contiguous quarter of the cell's list each (a cell next to the sensor holds
+// hundreds of points: with two waves the launch was as long as that one list); a wave reads 64 entries of the list with ONE
+// load and hands them out by lane shuffle (no dependent index load per step), four rows in flight per lane group.
 template <typename T, int LPR, int VEC>
-__global__ void __launch_bounds__(128) devox_cell_sums_kernel(const T* __restrict__ g, const int* __restrict__ vorder,
+__global__ void __launch_bounds__(256) devox_cell_sums_kernel(const T* __restrict__ g, const int* __restrict__ vorder,
                                                               const int64_t* __restrict__ vseg,
                                                               const float* __restrict__ w8, float* __restrict__ cs,
                                                               int64_t m, int c) {
   constexpr int RPW = 64 / LPR;
-  __shared__ float red[8][LPR * VEC];
+  __shared__ float red[3][8][LPR * VEC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l = lane % LPR, grp = lane / LPR;
   const int64_t cell = blockIdx.x;
   const int64_t beg = vseg[cell], end = vseg[cell + 1];
-  const int64_t half = (end - beg + 1) / 2;
-  int64_t b0 = beg + (int64_t)wave * half, b1 = b0 + half;
+  const int64_t quarter = (end - beg + 3) / 4;
+  int64_t b0 = beg + (int64_t)wave * quarter, b1 = b0 + quarter;
   if (b0 > end) b0 = end;
   if (b1 > end) b1 = end;
   float acc[8][VEC];
@@ -627,22 +641,34 @@ __global__ void __launch_bounds__(128) devox_cell_sums_kernel(const T* __restric
         for (int q = 0; q < VEC; ++q) acc[k][q] += wv[k] * x[q];
       }
   };
-  int64_t j = b0 + grp;
-  for (; j + RPW < b1; j += 2 * RPW) {          // two rows in flight per lane group
-    const int p0 = vorder[j], p1 = vorder[j + RPW];
-    float x0[VEC], x1[VEC];
-    ldv<VEC>(g + (int64_t)p0 * c + VEC * l, x0);
-    ldv<VEC>(g + (int64_t)p1 * c + VEC * l, x1);
-    const float4 a0 = ld4(w8 + (int64_t)p0 * 8), c0 = ld4(w8 + (int64_t)p0 * 8 + 4);
-    const float4 a1 = ld4(w8 + (int64_t)p1 * 8), c1 = ld4(w8 + (int64_t)p1 * 8 + 4);
-    add(x0, a0, c0);
-    add(x1, a1, c1);
-  }
-  for (; j < b1; j += RPW) {
-    const int p0 = vorder[j];
-    float x0[VEC];
-    ldv<VEC>(g + (int64_t)p0 * c + VEC * l, x0);
-    add(x0, ld4(w8 + (int64_t)p0 * 8), ld4(w8 + (int64_t)p0 * 8 + 4));
+  for (int64_t base = b0; base < b1; base += 64) {
+    const int cnt = (int)((b1 - base < 64) ? (b1 - base) : 64);
+    const int mine = lane < cnt ? vorder[base + lane] : 0;
+    int ib = 0;                                  // first entry of the step (the same in every lane: the shuffles are wave-wide)
+    for (; ib + 4 * RPW <= cnt; ib += 4 * RPW) {
+      const int i = ib + grp;
+      int p[4]; float x[4][VEC]; float4 wa[4], wb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = __shfl(mine, i + u * RPW, 64);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ldv<VEC>(g + (int64_t)p[u] * c + VEC * l, x[u]);
+        wa[u] = ld4(w8 + (int64_t)p[u] * 8); wb[u] = ld4(w8 + (int64_t)p[u] * 8 + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(x[u], wa[u], wb[u]);
+    }
+    // (every lane takes part in the shuffle; rows past the count add nothing)
+    for (; ib < cnt; ib += RPW) {
+      const int i = ib + grp;
+      const bool ok = i < cnt;
+      const int p0 = __shfl(mine, ok ? i : 0, 64);
+      if (ok) {
+        float x0[VEC];
+        ldv<VEC>(g + (int64_t)p0 * c + VEC * l, x0);
+        add(x0, ld4(w8 + (int64_t)p0 * 8), ld4(w8 + (int64_t)p0 * 8 + 4));
+      }
+    }
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -651,11 +677,11 @@ __global__ void __launch_bounds__(128) devox_cell_sums_kernel(const T* __restric
 #pragma unroll
       for (int q = 0; q < VEC; ++q) acc[k][q] += __shfl_xor(acc[k][q], off, 64);
   }
-  if (wave == 1 && grp == 0) {
+  if (wave > 0 && grp == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) red[k][l * VEC + q] = acc[k][q];
+      for (int q = 0; q < VEC; ++q) red[wave - 1][k][l * VEC + q] = acc[k][q];
   }
   __syncthreads();
   if (wave == 0 && grp == 0) {
@@ -663,9 +689,13 @@ __global__ void __launch_bounds__(128) devox_cell_sums_kernel(const T* __restric
     for (int k = 0; k < 8; ++k) {
       float* dst = cs + ((int64_t)cell * 8 + k) * c + VEC * l;
 #pragma unroll
-      for (int q = 0; q < VEC; q += 4)
-        st4(dst + q, make_float4(acc[k][q] + red[k][l * VEC + q], acc[k][q + 1] + red[k][l * VEC + q + 1],
-                                 acc[k][q + 2] + red[k][l * VEC + q + 2], acc[k][q + 3] + red[k][l * VEC + q + 3]));
+      for (int q = 0; q < VEC; q += 4) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = ((acc[k][q + e] + red[0][k][l * VEC + q + e]) + red[1][k][l * VEC + q + e]) + red[2][k][l * VEC + q + e];
+        st4(dst + q, make_float4(o[0], o[1], o[2], o[3]));
+      }
     }
   }
 }
@@ -692,7 +722,7 @@ int launch_devox_cells(const T* g, const int* vorder, const int64_t* vseg, const
                        const int64_t* cseg, T* gin, int64_t m, int c, float* cs, hipStream_t s) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const int lpr = c / VEC;
-#define LIDAL_CELLS(LPR) devox_cell_sums_kernel<T, LPR, VEC><<<(unsigned)m, 128, 0, s>>>(g, vorder, vseg, w8, cs, m, c)
+#define LIDAL_CELLS(LPR) devox_cell_sums_kernel<T, LPR, VEC><<<(unsigned)m, 256, 0, s>>>(g, vorder, vseg, w8, cs, m, c)
   if (lpr == 4) LIDAL_CELLS(4); else if (lpr == 8) LIDAL_CELLS(8); else if (lpr == 16) LIDAL_CELLS(16);
   else if (lpr == 32) LIDAL_CELLS(32); else LIDAL_CELLS(64);
 #undef LIDAL_CELLS

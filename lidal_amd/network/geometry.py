@@ -24,6 +24,7 @@ from .. import PointTensor, SparseTensor
 from ..nn import functional as F
 from ..nn.functional.conv import prefetch_kernel_maps
 from ..nn.functional.devoxelize import prepare_devoxelize
+from ..nn.functional.voxelize import _index32
 from ..nn.functional.voxelize import prepare_voxelize
 from .glue import corner_tables, initial_tables, point_tables
 
@@ -77,6 +78,7 @@ class Geometry:
                     idx, w = corner_tables(xs, z)
                     pidx, counts = point_tables(xs, z)
                     prepare_voxelize(pidx, counts)
+                    idx._lidal_cell_index = _index32(pidx)      # (one list of the points per voxel for both directions)
                     if grad:
                         # (channels of the features devoxelized at this stride, network/spvcnn.py:139-155: the
                         #  backward's lists are per-voxel or per-cell by them -- F.devoxelize.cells_mode)

@@ -517,6 +517,8 @@ class _Tables:
                 cells = None
                 do = dsp = idx8
                 if train and _DV.cells_mode(idx8, self.p, m, pc):
+                    if getattr(idx8, '_lidal_cell_index', None) is None:
+                        idx8._lidal_cell_index = idx32
                     cells = _DV.devox_cells(idx8, m)
                 elif train:
                     do, dsp = inverse_lists(idx8, m, w8)

@@ -33,7 +33,11 @@ def devox_cells(idx8, m):
     cached = getattr(idx8, '_lidal_cells', None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    cell = idx8[:, 0].contiguous()
+    # the points' own voxel index: idx8[:, 0] -- or the tensor F.spvoxelize already keeps lists for (the same values:
+    # both are queries of the floored coordinates, utils.py:44-52 / 72-77; network/geometry.py links them)
+    cell = getattr(idx8, '_lidal_cell_index', None)
+    if cell is None or cell.shape[0] != idx8.shape[0]:
+        cell = idx8[:, 0].contiguous()
     vorder, vseg = inverse_lists(cell, m)
     first = vorder[vseg[:-1]].long()                   # (every voxel of the level holds a point: its list is not empty)
     cidx = idx8[first].contiguous()                    # [m, 8]: the corners of every cell

@@ -7,12 +7,17 @@
 // one combining workgroup) with Chan's parallel-variance merge on SHIFTED sums, so the variance does
 // not cancel when |mean| >> std, and the order is fixed (bitwise reproducible, no atomics).
 #include "common.h"
+#include <type_traits>
 
 using namespace lidal;
 
 namespace {
 
 constexpr int NT = 256;
+#ifndef LIDAL_BN_EW_THREADS
+#define LIDAL_BN_EW_THREADS 256
+#endif
+constexpr int EW_THREADS = LIDAL_BN_EW_THREADS;   // threads of the element-wise kernels that take it as a parameter
 constexpr int UNR = 4;      // row loads in flight per thread (per operand)
 // per kernel family (scripts/build_variant.py -DLIDAL_BN_UNR_x=8: the sweep of round 5, profiles/README.md): statistics
 // pass, normalising pass, backward sums, dx
@@ -53,6 +58,27 @@ template <> struct IO<__bf16> {
     return v;
   }
 };
+
+// VEC consecutive per-channel values (a thread's channel group), or `dflt` for a NULL array.  One uniform branch per array
+// and 16-byte loads where the array allows: rounds 1-4 loaded them one element at a time behind a NULL test each -- and
+// tested the ReLU / residual flags per element inside the row loops (36 scalar branches per 16-byte piece in the ISA of
+// the apply kernel).  The flags are template parameters of the element-wise kernels since round 5.
+template <int VEC>
+__device__ __forceinline__ void load_channels(const float* __restrict__ p, int off, float dflt, float (&o)[VEC]) {
+  if (p == nullptr) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = dflt;
+  } else if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + off + i);
+      o[i] = v.x; o[i + 1] = v.y; o[i + 2] = v.z; o[i + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = p[off + i];
+  }
+}
 
 // merge (nb, mb, M2b) into (na, ma, M2a)  -- Chan et al.
 __device__ __forceinline__ void chan_merge(double& na, double& ma, double& m2a, double nb, double mb,
@@ -200,6 +226,8 @@ __global__ void __launch_bounds__(NT) bn_stats_final_kernel(const P* __restrict_
 // `res` (may be null): y = act(...) rounded to T, + res -- the sum of the point branch
 // (network/spvcnn.py:104 `z1.F = z1.F + point_transforms(z.F)`) without a pass of its own; relu bit 1 =
 // ReLU before that sum, bit 2 = ReLU after it (network/utils.py:171 `relu(net(x) + downsample(x))`)
+// (the ReLU / residual flags select one of six specialised copies of the row loops: F bit 0 = ReLU on the normalised
+// value, bit 1 = a residual is added, bit 2 = ReLU after the sum)
 template <typename T, bool VAR_IN>
 __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, int64_t n, int c,
                                                       const float* __restrict__ mean,
@@ -214,38 +242,42 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
   if (rl >= rpi) return;
   const int64_t r_beg = (int64_t)blockIdx.x * rpw;
   const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
-  float mu[VEC], sc[VEC], sh[VEC];
+  float mu[VEC], sc[VEC], sh[VEC], iv[VEC];
+  load_channels<VEC>(mean, cg * VEC, 0.f, mu);
+  load_channels<VEC>(istd_or_var, cg * VEC, 0.f, iv);
+  load_channels<VEC>(gamma, cg * VEC, 1.f, sc);
+  load_channels<VEC>(beta, cg * VEC, 0.f, sh);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    const int ch = cg * VEC + i;
-    float is = VAR_IN ? 1.f / sqrtf(istd_or_var[ch] + eps) : istd_or_var[ch];
-    mu[i] = mean[ch];
-    sc[i] = is * (gamma ? gamma[ch] : 1.f);
-    sh[i] = beta ? beta[ch] : 0.f;
+    const float is = VAR_IN ? 1.f / sqrtf(iv[i] + eps) : iv[i];
+    sc[i] = is * sc[i];
   }
+  auto run = [&](auto fc) {
+  constexpr int F = decltype(fc)::value;
+  constexpr bool RELU1 = (F & 1) != 0, HAS_RES = (F & 2) != 0, RELU2 = (F & 4) != 0;
   auto one = [&](const typename IO<T>::vec& v, const typename IO<T>::vec& vr, int64_t r) {
     float f[VEC], fr[VEC];
     IO<T>::unpack(v, f);
-    IO<T>::unpack(vr, fr);
+    if (HAS_RES) IO<T>::unpack(vr, fr);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
-      if (relu & 1) f[i] = fmaxf(f[i], 0.f);
-      if (res != nullptr) {
+      if (RELU1) f[i] = fmaxf(f[i], 0.f);
+      if (HAS_RES) {
         f[i] = (float)(T)f[i] + fr[i];       // as the stand-alone sum of two T rows
-        if (relu & 2) f[i] = fmaxf(f[i], 0.f);       // relu(bn(x) + shortcut): the end of a residual block
+        if (RELU2) f[i] = fmaxf(f[i], 0.f);          // relu(bn(x) + shortcut): the end of a residual block
       }
     }
     *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
   };
-  const T* rsrc = res != nullptr ? res : x;        // no residual: the second load re-reads x (cached)
+  const T* rsrc = HAS_RES ? res : x;
   int64_t r = r_beg + rl;
   for (; r + (UNR_A - 1) * rpi < r_end; r += UNR_A * rpi) {
     typename IO<T>::vec v[UNR_A], vr[UNR_A];
 #pragma unroll
     for (int u = 0; u < UNR_A; ++u)
       v[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
-    if (res != nullptr) {
+    if (HAS_RES) {
 #pragma unroll
       for (int u = 0; u < UNR_A; ++u)
         vr[u] = *reinterpret_cast<const typename IO<T>::vec*>(rsrc + (r + u * rpi) * c + cg * VEC);
@@ -258,7 +290,16 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ x, i
   }
   for (; r < r_end; r += rpi) {
     const typename IO<T>::vec v = *reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC);
-    one(v, res != nullptr ? *reinterpret_cast<const typename IO<T>::vec*>(res + r * c + cg * VEC) : v, r);
+    one(v, HAS_RES ? *reinterpret_cast<const typename IO<T>::vec*>(res + r * c + cg * VEC) : v, r);
+  }
+  };
+  switch ((relu & 1) | (res != nullptr ? 2 : 0) | ((res != nullptr && (relu & 2)) ? 4 : 0)) {
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    case 3: run(std::integral_constant<int, 3>{}); break;
+    case 6: run(std::integral_constant<int, 6>{}); break;
+    default: run(std::integral_constant<int, 7>{}); break;
   }
 }
 
@@ -364,7 +405,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
 // in f64.  The f64 kernel above runs one wave per SIMD and streams (x, dy) at ~3.7 TB/s; this one at the ~5 TB/s of the
 // dx pass (tail_tile_sums_kernel below is the same idea with the ReLU mask of a block's tail in front).  The f32 parity
 // mode keeps the f64 sums.
-template <typename T>
+template <typename T, bool RELU>
 __global__ void __launch_bounds__(NT) bn_bwd_slab_sums_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n,
                                                               int c, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd,
@@ -382,12 +423,10 @@ __global__ void __launch_bounds__(NT) bn_bwd_slab_sums_kernel(const T* __restric
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; ga[i] = 1.f; be[i] = 0.f; }
   if (rl < rpi) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      mu[i] = mean[cg * VEC + i]; is[i] = invstd[cg * VEC + i];
-      if (gamma) ga[i] = gamma[cg * VEC + i];
-      if (beta) be[i] = beta[cg * VEC + i];
-    }
+    load_channels<VEC>(mean, cg * VEC, 0.f, mu);
+    load_channels<VEC>(invstd, cg * VEC, 0.f, is);
+    load_channels<VEC>(gamma, cg * VEC, 1.f, ga);
+    load_channels<VEC>(beta, cg * VEC, 0.f, be);
     auto one = [&](const typename IO<T>::vec& vx, const typename IO<T>::vec& vd) {
       float fx[VEC], fd[VEC];
       IO<T>::unpack(vx, fx);
@@ -395,7 +434,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_slab_sums_kernel(const T* __restric
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float xhat = (fx[i] - mu[i]) * is[i];
-        if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
+        if (RELU && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
         a[i] += fd[i]; b[i] += fd[i] * xhat;
       }
     };
@@ -551,10 +590,11 @@ __global__ void __launch_bounds__(NT) tail_tile_sums_kernel(
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { a[i] = 0.f; b[i] = 0.f; b2[i] = 0.f; mu[i] = 0.f; is[i] = 0.f; mu2[i] = 0.f; is2[i] = 0.f; }
   if (rl < rpi) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      mu[i] = mean_a[cg * VEC + i]; is[i] = invstd_a[cg * VEC + i];
-      if (DUAL) { mu2[i] = mean_b[cg * VEC + i]; is2[i] = invstd_b[cg * VEC + i]; }
+    load_channels<VEC>(mean_a, cg * VEC, 0.f, mu);
+    load_channels<VEC>(invstd_a, cg * VEC, 0.f, is);
+    if (DUAL) {
+      load_channels<VEC>(mean_b, cg * VEC, 0.f, mu2);
+      load_channels<VEC>(invstd_b, cg * VEC, 0.f, is2);
     }
     typedef typename IO<T>::vec V;
     auto one = [&](int64_t r, const V& vo, const V& vg, const V& vx, const V& vx2) {
@@ -671,13 +711,16 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
   const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
   const float inv_n = 1.f / (float)n;
   float mu[VEC], is[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
+  load_channels<VEC>(mean, cg * VEC, 0.f, mu);
+  load_channels<VEC>(invstd, cg * VEC, 0.f, is);
+  load_channels<VEC>(gamma, cg * VEC, 1.f, ga);
+  load_channels<VEC>(beta, cg * VEC, 0.f, be);
+  load_channels<VEC>(sum_dy, cg * VEC, 0.f, k1);
+  load_channels<VEC>(sum_dy_xhat, cg * VEC, 0.f, k2);
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    const int ch = cg * VEC + i;
-    mu[i] = mean[ch]; is[i] = invstd[ch];
-    ga[i] = gamma ? gamma[ch] : 1.f; be[i] = beta ? beta[ch] : 0.f;
-    k1[i] = sum_dy[ch] * inv_n; k2[i] = sum_dy_xhat[ch] * inv_n;
-  }
+  for (int i = 0; i < VEC; ++i) { k1[i] = k1[i] * inv_n; k2[i] = k2[i] * inv_n; }
+  auto run = [&](auto rc) {
+  constexpr bool RELU = decltype(rc)::value;
   auto one = [&](const typename IO<T>::vec& vx, const typename IO<T>::vec& vd, int64_t r) {
     float fx[VEC], fd[VEC];
     IO<T>::unpack(vx, fx);
@@ -685,7 +728,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float xhat = (fx[i] - mu[i]) * is[i];
-      if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
+      if (RELU && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
       fd[i] = ga[i] * is[i] * (fd[i] - k1[i] - xhat * k2[i]);
     }
     *reinterpret_cast<typename IO<T>::vec*>(dx + r * c + cg * VEC) = IO<T>::pack(fd);
@@ -704,6 +747,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_kernel(const T* __restrict__ x,
   for (; r < r_end; r += rpi)
     one(*reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC),
         *reinterpret_cast<const typename IO<T>::vec*>(dy + r * ldy + cg * VEC), r);
+  };
+  if (relu) run(std::true_type{}); else run(std::false_type{});
 }
 
 // Slab size = rows / 256: one workgroup per CU on every level.  Each workgroup pays a fixed set-up
@@ -723,10 +768,26 @@ static inline int rows_per_wg(int64_t n) { return slab_rows(n); }
 // everywhere.  The reducing kernels are best at 256 on every level (sweep: profiles/README.md).
 constexpr int64_t EW_WIDE_BYTES = 12ll << 20;
 static inline int rows_per_wg_ew(int64_t n, int64_t row_bytes) {
-  const int wgs = n * row_bytes >= EW_WIDE_BYTES ? 2 * BN_WGS : BN_WGS;
+#ifndef LIDAL_BN_EW_WGS
+#define LIDAL_BN_EW_WGS (2 * BN_WGS)
+#endif
+  const int wgs = n * row_bytes >= EW_WIDE_BYTES ? LIDAL_BN_EW_WGS : BN_WGS;
   int64_t rpw = (n + wgs - 1) / wgs;
   if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
   return (int)rpw;
+}
+// the forward (apply) kernels alone: A/B knob for their grid (LIDAL_BN_APPLY_WGS, 0 = as the other element-wise kernels)
+#ifndef LIDAL_BN_APPLY_WGS
+#define LIDAL_BN_APPLY_WGS 0
+#endif
+static inline int rows_per_wg_apply(int64_t n, int64_t row_bytes) {
+  if (LIDAL_BN_APPLY_WGS == 0 || n * row_bytes < EW_WIDE_BYTES / 4) return rows_per_wg_ew(n, row_bytes);
+  int64_t rpw = (n + LIDAL_BN_APPLY_WGS - 1) / LIDAL_BN_APPLY_WGS;
+  if (rpw < MIN_ROWS_PER_WG) rpw = MIN_ROWS_PER_WG;
+  return (int)rpw;
+}
+static inline int nslabs_apply(int64_t n, int64_t row_bytes) {
+  return (int)cdiv(n > 0 ? n : 1, rows_per_wg_apply(n, row_bytes));
 }
 static inline int nslabs_ew(int64_t n, int64_t row_bytes) {
   return (int)cdiv(n > 0 ? n : 1, rows_per_wg_ew(n, row_bytes));
@@ -744,9 +805,9 @@ int bn_train_fwd(const void* x, int64_t n, int c, const float* gamma, const floa
   bn_stats_final_kernel<double><<<(unsigned)cdiv(c, 8), NT, 0, s>>>(part, np, c, eps, momentum, mean,
                                                              invstd, rm, rv, nbt);
   LIDAL_CHECK_LAUNCH("bn_stats_final");
-  bn_apply_kernel<T, false><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma,
+  bn_apply_kernel<T, false><<<nslabs_apply(n, (int64_t)c * sizeof(T)), NT, 0, s>>>((const T*)x, n, c, mean, invstd, gamma,
                                                         beta, eps, relu, (const T*)res, (T*)y,
-                                                        rows_per_wg_ew(n, (int64_t)c * sizeof(T)));
+                                                        rows_per_wg_apply(n, (int64_t)c * sizeof(T)));
   LIDAL_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -795,8 +856,12 @@ int bn_bwd(const void* x, const void* dy, int64_t ldy, int64_t n, int c, const f
     const int64_t rb = (int64_t)c * sizeof(T);
     const int parts = nslabs_ew(n, rb);
     float* sums = (float*)part;               // c * parts * 8 bytes <= lidal_bn_workspace_bytes (parts <= 2 * nparts_for)
-    bn_bwd_slab_sums_kernel<T><<<parts, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, sums,
-                                                   rows_per_wg_ew(n, rb), ldy);
+    if (relu)
+      bn_bwd_slab_sums_kernel<T, true><<<parts, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu,
+                                                           sums, rows_per_wg_ew(n, rb), ldy);
+    else
+      bn_bwd_slab_sums_kernel<T, false><<<parts, NT, 0, s>>>((const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu,
+                                                            sums, rows_per_wg_ew(n, rb), ldy);
     LIDAL_CHECK_LAUNCH("bn_bwd_slab_sums");
     if (bn_bwd_merge_dx<T, true>(x, dy, ldy, n, c, gamma, beta, relu, mean, invstd, dx, ggamma, gbeta, sums, parts, s)) {
       LIDAL_CHECK_LAUNCH("bn_bwd_dx(slab sums merged in the launch)");
@@ -997,19 +1062,23 @@ __device__ __forceinline__ float fetch_one(const Slots& s, int idx) {
   return __uint_as_float((unsigned)v);
 }
 
-// bn_tiles_final_kernel + bn_apply_kernel<T, false> in one launch
-template <typename T>
-__global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict__ x, int64_t n, int c,
+// bn_tiles_final_kernel + bn_apply_kernel<T, false> in one launch.  NTT threads (EW_THREADS: sixteen waves -- the streaming
+// part wants waves in flight, not workgroups: every workgroup pays the wait for the merged values once); the merge runs on
+// the first NT of them, the others add exact zeros to its tree: the sums of bn_tiles_final_kernel bit for bit.
+// F: bit 0 = ReLU on the normalised value, bit 1 = a residual is added, bit 2 = ReLU after the sum
+template <typename T, int NTT, int F>
+__global__ void __launch_bounds__(NTT) bn_apply_tiles_kernel(const T* __restrict__ x, int64_t n, int c,
                                                             const float* __restrict__ part, int nparts, float eps,
                                                             float momentum, float* __restrict__ mean,
                                                             float* __restrict__ invstd, float* __restrict__ running_mean,
                                                             float* __restrict__ running_var,
                                                             long long* __restrict__ num_batches,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            int relu, const T* __restrict__ res, T* __restrict__ y, int rpw,
+                                                            const T* __restrict__ res, T* __restrict__ y, int rpw,
                                                             Slots slots) {
+  constexpr bool RELU1 = (F & 1) != 0, HAS_RES = (F & 2) != 0, RELU2 = (F & 4) != 0;
   constexpr int VEC = IO<T>::VEC;
-  __shared__ double sn[NT], s1[NT], s2[NT];
+  __shared__ double sn[NTT], s1[NTT], s2[NTT];
   __shared__ float smu[SLOT_CH], sis[SLOT_CH];
   const int tid = threadIdx.x;
   if (num_batches != nullptr && blockIdx.x == 0 && tid == 0) *num_batches += 1;
@@ -1018,7 +1087,7 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
     double nn = 0., a = 0., b = 0.;
     // (eight tiles' triples requested at once, summed in tile order: the sums of the one-at-a-time loop, with the
     // loads of a batch in flight together -- the merge is on the layer's critical path)
-    for (int p0 = tid; p0 < nparts; p0 += 8 * NT) {
+    for (int p0 = tid; tid < NT && p0 < nparts; p0 += 8 * NT) {
       float t0[8], t1[8], t2[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1034,7 +1103,7 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
         }
     }
     sn[tid] = nn; s1[tid] = a; s2[tid] = b;
-    for (int st = NT / 2; st >= 1; st >>= 1) {
+    for (int st = NTT / 2; st >= 1; st >>= 1) {
       __syncthreads();
       if (tid < st) { sn[tid] += sn[tid + st]; s1[tid] += s1[tid + st]; s2[tid] += s2[tid + st]; }
     }
@@ -1058,11 +1127,11 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
   }
   // ---- the first rows of this workgroup's slab are requested BEFORE the statistics are waited for: the merge's
   //      latency (a strided read of the tiles, an 8-step LDS tree) hides behind them
-  const int cg_n = c / VEC, rpi = NT / cg_n;
+  const int cg_n = c / VEC, rpi = NTT / cg_n;
   const int cg = tid % cg_n, rl = tid / cg_n;
   const int64_t r_beg = (int64_t)blockIdx.x * rpw;
   const int64_t r_end = (r_beg + rpw < n) ? r_beg + rpw : n;
-  const T* rsrc = res != nullptr ? res : x;
+  const T* rsrc = HAS_RES ? res : x;
   int64_t r = r_beg + rl;
   const bool first = rl < rpi && r + (UNR_A - 1) * rpi < r_end;
   typename IO<T>::vec v0[UNR_A], vr0[UNR_A];
@@ -1070,14 +1139,14 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
 #pragma unroll
     for (int u = 0; u < UNR_A; ++u)
       v0[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
-    if (res != nullptr) {
+    if (HAS_RES) {
 #pragma unroll
       for (int u = 0; u < UNR_A; ++u)
         vr0[u] = *reinterpret_cast<const typename IO<T>::vec*>(rsrc + (r + u * rpi) * c + cg * VEC);
     }
   }
   // ---- every channel's (mean, invstd), from whichever workgroup merged it
-  for (int ch = tid; ch < c; ch += NT) {
+  for (int ch = tid; ch < c; ch += NTT) {
     smu[ch] = fetch_one(slots, 2 * ch);
     sis[ch] = fetch_one(slots, 2 * ch + 1);
   }
@@ -1085,31 +1154,32 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
   // ---- bn_apply_kernel<T, false>
   if (rl >= rpi) return;
   float mu[VEC], sc[VEC], sh[VEC];
+  load_channels<VEC>(gamma, cg * VEC, 1.f, sc);
+  load_channels<VEC>(beta, cg * VEC, 0.f, sh);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     const int ch = cg * VEC + i;
     mu[i] = smu[ch];
-    sc[i] = sis[ch] * (gamma ? gamma[ch] : 1.f);
-    sh[i] = beta ? beta[ch] : 0.f;
+    sc[i] = sis[ch] * sc[i];
   }
   auto one = [&](const typename IO<T>::vec& v, const typename IO<T>::vec& vr, int64_t r) {
     float f[VEC], fr[VEC];
     IO<T>::unpack(v, f);
-    IO<T>::unpack(vr, fr);
+    if (HAS_RES) IO<T>::unpack(vr, fr);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       f[i] = (f[i] - mu[i]) * sc[i] + sh[i];
-      if (relu & 1) f[i] = fmaxf(f[i], 0.f);
-      if (res != nullptr) {
+      if (RELU1) f[i] = fmaxf(f[i], 0.f);
+      if (HAS_RES) {
         f[i] = (float)(T)f[i] + fr[i];
-        if (relu & 2) f[i] = fmaxf(f[i], 0.f);
+        if (RELU2) f[i] = fmaxf(f[i], 0.f);
       }
     }
     *reinterpret_cast<typename IO<T>::vec*>(y + r * c + cg * VEC) = IO<T>::pack(f);
   };
   if (first) {
 #pragma unroll
-    for (int u = 0; u < UNR_A; ++u) one(v0[u], res != nullptr ? vr0[u] : v0[u], r + u * rpi);
+    for (int u = 0; u < UNR_A; ++u) one(v0[u], HAS_RES ? vr0[u] : v0[u], r + u * rpi);
     r += UNR_A * rpi;
   }
   for (; r + (UNR_A - 1) * rpi < r_end; r += UNR_A * rpi) {
@@ -1117,7 +1187,7 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
 #pragma unroll
     for (int u = 0; u < UNR_A; ++u)
       v[u] = *reinterpret_cast<const typename IO<T>::vec*>(x + (r + u * rpi) * c + cg * VEC);
-    if (res != nullptr) {
+    if (HAS_RES) {
 #pragma unroll
       for (int u = 0; u < UNR_A; ++u)
         vr[u] = *reinterpret_cast<const typename IO<T>::vec*>(rsrc + (r + u * rpi) * c + cg * VEC);
@@ -1130,13 +1200,13 @@ __global__ void __launch_bounds__(NT) bn_apply_tiles_kernel(const T* __restrict_
   }
   for (; r < r_end; r += rpi) {
     const typename IO<T>::vec v = *reinterpret_cast<const typename IO<T>::vec*>(x + r * c + cg * VEC);
-    one(v, res != nullptr ? *reinterpret_cast<const typename IO<T>::vec*>(res + r * c + cg * VEC) : v, r);
+    one(v, HAS_RES ? *reinterpret_cast<const typename IO<T>::vec*>(res + r * c + cg * VEC) : v, r);
   }
 }
 
 // bn_bwd_final_kernel (TILES = false: f64 partial pairs of bn_bwd_partial_kernel, 8 channels x 32 lanes per unit) or
 // bn_bwd_tiles_final_kernel (TILES = true: f32 pairs per 128-row tile, one channel per unit) + bn_bwd_dx_kernel
-template <typename T, bool TILES>
+template <typename T, bool TILES, bool RELU>
 __global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n,
                                                              int c, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
@@ -1226,11 +1296,13 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict
   if (rl >= rpi) return;
   const float inv_n = 1.f / (float)n;
   float mu[VEC], is[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
+  load_channels<VEC>(mean, cg * VEC, 0.f, mu);
+  load_channels<VEC>(invstd, cg * VEC, 0.f, is);
+  load_channels<VEC>(gamma, cg * VEC, 1.f, ga);
+  load_channels<VEC>(beta, cg * VEC, 0.f, be);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     const int ch = cg * VEC + i;
-    mu[i] = mean[ch]; is[i] = invstd[ch];
-    ga[i] = gamma ? gamma[ch] : 1.f; be[i] = beta ? beta[ch] : 0.f;
     k1[i] = sk1[ch] * inv_n; k2[i] = sk2[ch] * inv_n;
   }
   auto one = [&](const typename IO<T>::vec& vx, const typename IO<T>::vec& vd, int64_t r) {
@@ -1240,7 +1312,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_dx_merge_kernel(const T* __restrict
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float xhat = (fx[i] - mu[i]) * is[i];
-      if (relu && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
+      if (RELU && !(xhat * ga[i] + be[i] > 0.f)) fd[i] = 0.f;
       fd[i] = ga[i] * is[i] * (fd[i] - k1[i] - xhat * k2[i]);
     }
     *reinterpret_cast<typename IO<T>::vec*>(dx + r * c + cg * VEC) = IO<T>::pack(fd);
@@ -1369,9 +1441,14 @@ bool bn_bwd_merge_dx(const void* x, const void* dy, int64_t ldy, int64_t n, int 
                      const void* part, int nparts, hipStream_t s) {
   Slots slots;
   if (dx == nullptr || !bn_fused() || c > SLOT_CH || !next_slots(&slots, s)) return false;
-  bn_bwd_dx_merge_kernel<T, TILES><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>(
-      (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, nparts, gbeta, ggamma, (T*)dx,
-      rows_per_wg_ew(n, (int64_t)c * sizeof(T)), ldy, slots);
+  if (relu)
+    bn_bwd_dx_merge_kernel<T, TILES, true><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>(
+        (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, nparts, gbeta, ggamma, (T*)dx,
+        rows_per_wg_ew(n, (int64_t)c * sizeof(T)), ldy, slots);
+  else
+    bn_bwd_dx_merge_kernel<T, TILES, false><<<nslabs_ew(n, (int64_t)c * sizeof(T)), NT, 0, s>>>(
+        (const T*)x, (const T*)dy, n, c, mean, invstd, gamma, beta, relu, part, nparts, gbeta, ggamma, (T*)dx,
+        rows_per_wg_ew(n, (int64_t)c * sizeof(T)), ldy, slots);
   return true;
 }
 }  // namespace
@@ -1390,16 +1467,21 @@ extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int
   hipStream_t s = (hipStream_t)stream;
   Slots slots;
   if (bn_fused() && c <= SLOT_CH && next_slots(&slots, s)) {
-    if (dtype == LIDAL_F32)
-      bn_apply_tiles_kernel<float><<<nslabs_ew(n, (int64_t)c * 4), NT, 0, s>>>(
-          (const float*)x, n, c, tile_stats, (int)n_tiles, eps, momentum, save_mean, save_invstd, running_mean, running_var,
-          (long long*)num_batches_tracked, gamma, beta, relu, (const float*)residual, (float*)y,
-          rows_per_wg_ew(n, (int64_t)c * 4), slots);
-    else
-      bn_apply_tiles_kernel<__bf16><<<nslabs_ew(n, (int64_t)c * 2), NT, 0, s>>>(
-          (const __bf16*)x, n, c, tile_stats, (int)n_tiles, eps, momentum, save_mean, save_invstd, running_mean, running_var,
-          (long long*)num_batches_tracked, gamma, beta, relu, (const __bf16*)residual, (__bf16*)y,
-          rows_per_wg_ew(n, (int64_t)c * 2), slots);
+    const int flags = (relu & 1) | (residual != nullptr ? 2 : 0) | ((residual != nullptr && (relu & 2)) ? 4 : 0);
+#define LIDAL_APPLY_TILES(T, FV)                                                                                          \
+    bn_apply_tiles_kernel<T, EW_THREADS, FV><<<nslabs_apply(n, (int64_t)c * sizeof(T)), EW_THREADS, 0, s>>>(               \
+        (const T*)x, n, c, tile_stats, (int)n_tiles, eps, momentum, save_mean, save_invstd, running_mean, running_var,    \
+        (long long*)num_batches_tracked, gamma, beta, (const T*)residual, (T*)y, rows_per_wg_apply(n, (int64_t)c * sizeof(T)), \
+        slots)
+#define LIDAL_APPLY_TILES_F(T)                                                        \
+    switch (flags) {                                                                  \
+      case 0: LIDAL_APPLY_TILES(T, 0); break; case 1: LIDAL_APPLY_TILES(T, 1); break; \
+      case 2: LIDAL_APPLY_TILES(T, 2); break; case 3: LIDAL_APPLY_TILES(T, 3); break; \
+      case 6: LIDAL_APPLY_TILES(T, 6); break; default: LIDAL_APPLY_TILES(T, 7); break; \
+    }
+    if (dtype == LIDAL_F32) { LIDAL_APPLY_TILES_F(float) } else { LIDAL_APPLY_TILES_F(__bf16) }
+#undef LIDAL_APPLY_TILES_F
+#undef LIDAL_APPLY_TILES
     LIDAL_CHECK_LAUNCH("bn_apply(tiles merged in the launch)");
     return 0;
   }
@@ -1408,15 +1490,15 @@ extern "C" int lidal_bn_train_fwd_tiles(const void* x, int dtype, int64_t n, int
                                                    (long long*)num_batches_tracked);
   LIDAL_CHECK_LAUNCH("bn_stats_final(tiles)");
   if (dtype == LIDAL_F32)
-    bn_apply_kernel<float, false><<<nslabs_ew(n, (int64_t)c * 4), NT, 0, s>>>((const float*)x, n, c, save_mean, save_invstd,
+    bn_apply_kernel<float, false><<<nslabs_apply(n, (int64_t)c * 4), NT, 0, s>>>((const float*)x, n, c, save_mean, save_invstd,
                                                               gamma, beta, eps, relu,
                                                               (const float*)residual, (float*)y,
-                                                              rows_per_wg_ew(n, (int64_t)c * 4));
+                                                              rows_per_wg_apply(n, (int64_t)c * 4));
   else
-    bn_apply_kernel<__bf16, false><<<nslabs_ew(n, (int64_t)c * 2), NT, 0, s>>>((const __bf16*)x, n, c, save_mean,
+    bn_apply_kernel<__bf16, false><<<nslabs_apply(n, (int64_t)c * 2), NT, 0, s>>>((const __bf16*)x, n, c, save_mean,
                                                                save_invstd, gamma, beta, eps, relu,
                                                                (const __bf16*)residual, (__bf16*)y,
-                                                               rows_per_wg_ew(n, (int64_t)c * 2));
+                                                               rows_per_wg_apply(n, (int64_t)c * 2));
   LIDAL_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -1429,13 +1511,13 @@ extern "C" int lidal_bn_eval_fwd(const void* x, int dtype, int64_t n, int c, con
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LIDAL_F32)
-    bn_apply_kernel<float, true><<<nslabs_ew(n, (int64_t)c * 4), NT, 0, s>>>(
+    bn_apply_kernel<float, true><<<nslabs_apply(n, (int64_t)c * 4), NT, 0, s>>>(
         (const float*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, nullptr, (float*)y,
-        rows_per_wg_ew(n, (int64_t)c * 4));
+        rows_per_wg_apply(n, (int64_t)c * 4));
   else
-    bn_apply_kernel<__bf16, true><<<nslabs_ew(n, (int64_t)c * 2), NT, 0, s>>>(
+    bn_apply_kernel<__bf16, true><<<nslabs_apply(n, (int64_t)c * 2), NT, 0, s>>>(
         (const __bf16*)x, n, c, running_mean, running_var, gamma, beta, eps, relu, nullptr, (__bf16*)y,
-        rows_per_wg_ew(n, (int64_t)c * 2));
+        rows_per_wg_apply(n, (int64_t)c * 2));
   LIDAL_CHECK_LAUNCH("lidal_bn_eval_fwd");
   return 0;
 }

@@ -96,7 +96,19 @@ def point_tables(x, z):
         idx_query = F.coords_table(x.C, x.cmaps, x.s).query(pc_hash)     # == F.sphashquery(pc_hash, F.sphash(x.C))
         cache_i[x.s] = idx_query
         cache_c[x.s] = F.spcount(idx_query.int(), x.C.shape[0])
+    _link_cells(z, x.s)
     return cache_i[x.s], cache_c[x.s]
+
+
+def _link_cells(z, stride):
+    """One list of the points of every voxel for both directions: the corner index of this stride (corner_tables) learns
+    the point -> voxel index F.spvoxelize keeps lists for -- the same values as its own column 0 (F.devoxelize.devox_cells)."""
+    idx8 = z.idx_query.get(stride)
+    pidx = z.additional_features['idx_query'].get(stride)
+    if idx8 is not None and pidx is not None and getattr(idx8, '_lidal_cell_index', None) is None \
+            and pidx.shape[0] == idx8.shape[0]:
+        from ..nn.functional.voxelize import _index32
+        idx8._lidal_cell_index = _index32(pidx)
 
 
 def point_to_voxel(x, z):
@@ -129,6 +141,7 @@ def corner_tables(x, z, nearest=False):
         idx_query._lidal_cell_corners = True
         z.idx_query[x.s] = idx_query
         z.weights[x.s] = weights
+        _link_cells(z, x.s)
     return z.idx_query[x.s], z.weights[x.s]
 
 

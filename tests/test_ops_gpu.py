@@ -203,6 +203,10 @@ def test_devoxelize_backward_through_the_cells(stride, c, dtype):
     idx8, w8 = corner_tables(xs, z)
     n, m = idx8.shape[0], cs.shape[0]
     assert getattr(idx8, '_lidal_cell_corners', False)
+    # the points' own voxel index is column 0 of the corner index (the list F.spvoxelize keeps is shared with the cells)
+    from lidal_amd.network.glue import point_tables
+    pidx, _ = point_tables(xs, z)
+    assert torch.equal(pidx.int(), idx8[:, 0]) and getattr(idx8, '_lidal_cell_index', None) is not None
     # the structure: the corners of a point are the corners of its cell's first point
     vorder, vseg, corder, cseg = DV.devox_cells(idx8, m)
     first = vorder[vseg[:-1]].long()

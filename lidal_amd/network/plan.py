@@ -75,6 +75,13 @@ TRACE = None
 # one scan 7.47 / 7.48 / 7.46 -> 7.01 / 7.82 / 7.02 ms (scripts/exp/side_wgrad.sh).  Same kernels, same results.
 SIDE_ROWS = int(os.environ.get('LIDAL_PLAN_SIDE_ROWS', str(1 << 40)))
 SIDE_MIN_ROWS = int(os.environ.get('LIDAL_PLAN_SIDE_MIN_ROWS', '0'))      # (measured: every threshold above 0 loses, matrix2.sh)
+# The f32 mode on the side stream (round 5): one SPVCNN f32 training run in ~20 was not bit-reproducible -- gradients differing
+# in the last bit from some decoder layer on; never under bf16 (scripts/exp/determinism_steps.py, profiles/README.md "A
+# training run that was not bit-reproducible").  What removed it from the planned step was taking the fused f64 block tail out
+# of the f32 mode (nn/functional/norm.py TAIL_SUMS_ROWS: 0 differences in 240 repetitions of six steps since); the
+# per-operator path also needed its weight gradients back on the main stream (backend.overlap_wgrad).  LIDAL_PLAN_SIDE_F32=0
+# does the same here at 57.0 instead of 49.0 ms per f32 step -- the setting to use if a difference ever shows up again.
+SIDE_F32 = os.environ.get('LIDAL_PLAN_SIDE_F32', '1') == '1'
 # The shortcut branch of a residual block (1x1x1 convolution + BatchNorm, forward and backward) runs on a THIRD stream
 # beside the block's main branch where the level has at least this many rows (0 = never): 5 scans 15.37 / 15.38 / 15.34
 # -> 15.19 / 15.24 ms; on one scan the extra fork / join pairs cost the host what the overlap wins on the GPU (6.65 /
@@ -701,6 +708,8 @@ class _Run:
         """Flag of a weight gradient over `rows` rows: side stream 1 (after a fork), or 0 = the main stream."""
         if not SIDE_ROWS or rows > SIDE_ROWS or rows < SIDE_MIN_ROWS:
             return 0
+        if not self.bf16 and not SIDE_F32:
+            return 0                    # (the f32 mode: see SIDE_F32)
         return self.fork(1)
 
     # ===================================== forward ========================================================

@@ -39,7 +39,8 @@ def devox_cells(idx8, m):
     if cell is None or cell.shape[0] != idx8.shape[0]:
         cell = idx8[:, 0].contiguous()
     vorder, vseg = inverse_lists(cell, m)
-    first = vorder[vseg[:-1]].long()                   # (every voxel of the level holds a point: its list is not empty)
+    # (every voxel of the level holds a point; a voxel without one would take a neighbour's corners for sums that stay 0)
+    first = vorder[vseg[:-1].clamp(max=max(int(vorder.shape[0]) - 1, 0))].long()
     cidx = idx8[first].contiguous()                    # [m, 8]: the corners of every cell
     corder, cseg = inverse_lists(cidx, m)
     out = (vorder, vseg, corder, cseg)

@@ -100,6 +100,35 @@ __device__ __forceinline__ void image_segment(const TI* __restrict__ w, TO* __re
   const int k = (int)r;
   const int col = blk * bn + b * 16 + row16;
   const int red0 = pass * kc + cc * CH + gsel * VEC;
+  if (role != 0) {
+    // the reduction index is the contiguous one of w (data-gradient images of a convolution, forward images of nn.Linear):
+    // the thread of gsel == 0 builds the four segments of its (cc, column) -- CH consecutive elements of ONE row of w, read
+    // as 16-byte pieces -- and the threads of gsel 1..3 have nothing to do.  (Rounds 2-4: every thread read its own 32 bytes
+    // of a row, a wave 64 rows at a time: 136 us for the 22 M parameters of SPVCNN at the head of every step.)
+    if (gsel != 0) return;
+    const bool inside = col < n_col;
+    const int64_t src = (int64_t)k * n_red * n_col + (int64_t)col * n_red + red0;
+    float f[CH];
+    if (inside && red0 + CH <= n_red && sizeof(TI) == 4 && (n_red & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+#pragma unroll
+      for (int e = 0; e < CH; e += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(w) + src + e);
+        f[e] = q.x; f[e + 1] = q.y; f[e + 2] = q.z; f[e + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) f[e] = (inside && red0 + e < n_red) ? DT<TI>::to_f32(w[src + e]) : 0.f;
+    }
+    typedef typename DT<TO>::frag frag;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      TO v[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = DT<TO>::from_f32(f[g * VEC + e]);
+      *reinterpret_cast<frag*>(img + (s + (int64_t)g * nb * 16) * VEC) = *reinterpret_cast<frag*>(v);
+    }
+    return;
+  }
   TO v[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {

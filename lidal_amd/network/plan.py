@@ -87,6 +87,10 @@ SIDE_F32 = os.environ.get('LIDAL_PLAN_SIDE_F32', '1') == '1'
 # -> 15.19 / 15.24 ms; on one scan the extra fork / join pairs cost the host what the overlap wins on the GPU (6.65 /
 # 7.24 -> 6.81 / 7.42 ms; scripts/exp/matrix.sh, matrix2.sh), hence the threshold: the levels of a multi-scan batch.
 BRANCH_ROWS = int(os.environ.get('LIDAL_PLAN_BRANCH_ROWS', '100000'))
+# The backward pass of SPVCNN's point branch (BatchNorm1d backward, the Linear's two gradients, its bias gradient: streaming
+# kernels over all points) on a FOURTH stream beside the voxel branch, between the place its input gradient appears and the
+# place its result is consumed (round 5).  bf16 only (the f32 mode keeps its concurrency as it was, section 5 of DESIGN.md).
+POINT_SIDE = int(os.environ.get('LIDAL_PLAN_POINT_SIDE', '1'))     # 0 = on the main stream, i = on side stream i
 _NARGS = {}
 _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
               6: 'bn_train_fwd', 7: 'bn_bwd', 8: 'bn_bwd', 9: 'bn_eval_fwd', 10: 'bn_fold', 11: 'colsum',
@@ -812,11 +816,20 @@ class _Run:
         self.nops += 1
         return out
 
-    def f_point(self, pt, z_in, devox_out):
+    def f_point_lin(self, pt, z_in):
+        """The Linear of f_point, queued as soon as its input exists -- on the point branch's side stream (POINT_SIDE, bf16
+        training): it needs nothing of the voxel branch, the BatchNorm that follows it does (the residual)."""
+        lin, r = pt
+        fl = self.point_fork()
+        x1, st = self.f_dense(lin.conv, z_in, self.T.p, lin.co, self.ptr[lin.b], True, fl)
+        return x1, st
+
+    def f_point(self, pt, z_in, devox_out, pre=None):
         """Linear -> BatchNorm1d(+ReLU) + residual (network/spvcnn.py:136,143,151; blocks.ConvNormSequential)."""
         lin, r = pt
         P = self.T.p
-        x1, st = self.f_dense(lin.conv, z_in, P, lin.co, self.ptr[lin.b], True)
+        x1, st = pre if pre is not None else self.f_dense(lin.conv, z_in, P, lin.co, self.ptr[lin.b], True)
+        self.point_join()
         y, mean, invstd = self.f_bn(r, x1, P, st, devox_out, False)
         self.saved[id(pt)] = (z_in, x1, mean, invstd)
         return y
@@ -870,6 +883,7 @@ class _Run:
         cs = [c0.co]
         if prog.spvcnn:
             z0 = self.f_devox(x0, 0, cs[0])
+            pre = self.f_point_lin(prog.points[0], z0) if self.TRAIN else None
             y = self.f_vox(z0, 0, cs[0])
         else:
             y = x0
@@ -881,7 +895,8 @@ class _Run:
             cs.append(rb.c2.co)
         z = None
         if prog.spvcnn:
-            z1 = self.f_point(prog.points[0], z0, self.f_devox(y, 4, cs[4]))
+            z1 = self.f_point(prog.points[0], z0, self.f_devox(y, 4, cs[4]), pre)
+            pre = self.f_point_lin(prog.points[1], z1) if self.TRAIN else None
             y = self.f_vox(z1, 4, cs[4])
             self.f_dropout(y, n[4], cs[4])
             z = z1
@@ -893,12 +908,13 @@ class _Run:
             y = self.f_res(rb, y, n[l], k3[l])
             c_out = rb.c2.co
             if prog.spvcnn and i == 1:
-                z2 = self.f_point(prog.points[1], z, self.f_devox(y, 2, c_out))
+                z2 = self.f_point(prog.points[1], z, self.f_devox(y, 2, c_out), pre)
+                pre = self.f_point_lin(prog.points[2], z2) if self.TRAIN else None
                 y = self.f_vox(z2, 2, c_out)
                 self.f_dropout(y, n[2], c_out)
                 z = z2
         if prog.spvcnn:
-            feat = self.f_point(prog.points[2], z, self.f_devox(y, 0, c_out))
+            feat = self.f_point(prog.points[2], z, self.f_devox(y, 0, c_out), pre)
             rows = T.p
         else:
             feat, rows = y, n[0]
@@ -994,9 +1010,9 @@ class _Run:
         self.nops += 1
         return gx
 
-    def b_colsum(self, g, n, c, out):
+    def b_colsum(self, g, n, c, out, flag=0):
         nb = _bn_ws(n, c) + 12 * c
-        self.w += (OP_COLSUM, g, self.code, n, c, out, self.scratch(nb), nb)
+        self.w += (OP_COLSUM | flag, g, self.code, n, c, out, self.scratch(nb, flag), nb)
         self.nops += 1
 
     def b_conv_bn(self, cb, g, g_stride, n_in, n_out, tables, need_gx=True, ci=None):
@@ -1088,15 +1104,23 @@ class _Run:
         self.nops += 1
         return gin
 
-    def b_point(self, pt, g, need_gx=True):
-        """Backward of f_point: g [P, co] -> gradient of the Linear's input [P, ci] (the residual's is g itself)."""
+    def b_point(self, pt, g, need_gx=True, flag=0):
+        """Backward of f_point: g [P, co] -> gradient of the Linear's input [P, ci] (the residual's is g itself).
+        flag: the side stream the whole branch runs on (after a fork; the caller joins before it reads the result)."""
         lin, r = pt
         P = self.T.p
         z_in, x1, mean, invstd = self.saved[id(pt)]
-        dx = self.b_bn(r, x1, P, mean, invstd, g, lin.co)
-        gx = self.b_dense(lin.conv, z_in, P, dx, lin.co, need_gx, True)
-        self.b_colsum(dx, P, lin.co, self.slot(lin.b))
+        dx = self.b_bn(r, x1, P, mean, invstd, g, lin.co, flag=flag)
+        gx = self.b_dense(lin.conv, z_in, P, dx, lin.co, need_gx, True, branch=flag)
+        self.b_colsum(dx, P, lin.co, self.slot(lin.b), flag)
         return gx
+
+    def point_fork(self):
+        return self.fork(POINT_SIDE) if (POINT_SIDE and self.bf16) else 0
+
+    def point_join(self):
+        if POINT_SIDE and POINT_SIDE in self.open:
+            self.join(POINT_SIDE)
 
     def b_dropout(self, which, g, n, c):
         noise = self.noise[which]
@@ -1144,7 +1168,7 @@ class _Run:
             gy = self.b_add(gy, c_out, gf.data_ptr(), c_out, rows, c_out)
         gz_lin = 0
         if prog.spvcnn:
-            gz_lin = self.b_point(prog.points[2], gy)          # gradient of z2.F through the Linear
+            gz_lin = self.b_point(prog.points[2], gy, flag=self.point_fork())          # gradient of z2.F through the Linear
             gy = self.b_devox(gy, 0, c_out)
         g_skip = [0] * 5        # (address, row stride) of the concatenation's gradient slice of every encoder level
         for i in (3, 2, 1, 0):
@@ -1154,8 +1178,9 @@ class _Run:
                 # y was vox(z2) with dropout, z2 = point(z1) + devox(up2 output)
                 c2 = rb.c2.co
                 gy = self.b_dropout(1, gy, n[2], c2)
+                self.point_join()
                 gz = self.b_vox(gy, 2, c2, gz_lin)
-                gz_lin = self.b_point(prog.points[1], gz)
+                gz_lin = self.b_point(prog.points[1], gz, flag=self.point_fork())
                 gy = self.b_devox(gz, 2, c2)
             gy = self.b_res(rb, gy, n[l], k3[l])
             gcat = self.b_res(ra, gy, n[l], k3[l])
@@ -1165,8 +1190,9 @@ class _Run:
         cs4 = prog.stages[3][2].c2.co
         if prog.spvcnn:
             gy = self.b_dropout(0, gy, n[4], cs4)
+            self.point_join()
             gz = self.b_vox(gy, 4, cs4, gz_lin)
-            gz_lin = self.b_point(prog.points[0], gz)              # gradient of z0.F through the Linear
+            gz_lin = self.b_point(prog.points[0], gz, flag=self.point_fork())              # gradient of z0.F through the Linear
             gy = self.b_devox(gz, 4, cs4)
         for l in (3, 2, 1, 0):
             down, ra, rb = prog.stages[l]
@@ -1178,6 +1204,7 @@ class _Run:
             gy = self.b_conv_bn(down, gy, down[0].co, n[l], n[l + 1], k2[l])
         c0 = prog.stem[1][0].co
         if prog.spvcnn:
+            self.point_join()
             gz0 = self.b_vox(gy, 0, c0, gz_lin)
             gy = self.b_devox(gz0, 0, c0)
         gy = self.b_add(gy, c0, g_skip[0][0], g_skip[0][1], n[0], c0)
@@ -1276,7 +1303,7 @@ class _EvalRun(_Run):
         self.nops += 1
         return out
 
-    def f_point(self, pt, z_in, devox_out):
+    def f_point(self, pt, z_in, devox_out, pre=None):
         lin, r = pt
         P = self.T.p
         out = self.arena.alloc(P * lin.co * self.esz)

@@ -698,6 +698,15 @@ def family_table(step, coords, dtype_name, step_ms):
         'mfma_frac': round(tot_fl / (step_ms * 1e-3) / 1e12 / peak_tf, 4),
         'ms_at_hbm_roof': round(tot_by / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
         'ms_at_mfma_roof': round(tot_fl / (peak_tf * 1e12) * 1e3, 3)}
+    # counter traffic of the whole step, measured OFFLINE like roofline.traffic (two --pmc passes over bench.py itself:
+    # scripts/gpu/r5_step_traffic.sh) and kept under profiles/; reported only for this exact workload
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r05_pmc_step_traffic.json')))
+        if (rec['workload']['rows'], rec['workload']['dtype']) == (int(coords.shape[0]), dtype_name):
+            out['whole_step']['traffic_GB'] = rec['traffic_GB']
+            out['whole_step']['traffic_source'] = 'offline PMC passes: profiles/r05_pmc_step_traffic.json (the headline step)'
+    except (OSError, KeyError, ValueError):
+        pass
     return out
 
 

@@ -42,6 +42,9 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+# the split form of an f32 product (LIDAL_F32_SPLIT): six bf16 MFMAs per f32 multiply-add block
+SPLIT_PEAK_TFLOPS = 2500.0 / 6
+ROUND = 6                      # offline counter records (profiles/rNN_pmc_*.json) count for their own round only
 
 
 def log(*a):
@@ -67,6 +70,8 @@ def parse():
                     help='neighbour windows of `secondary` (BASELINE config 5: 10; LiDAL.py:120: 24)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
+    ap.add_argument('--sequence-frames', type=int, default=256,
+                    help='length of the one-GPU whole-sequence leg `variants.score_N` (config 4: 256; 0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-families', action='store_true')
     ap.add_argument('--no-variants', action='store_true')
@@ -394,6 +399,42 @@ def variant_line(res):
 # ---------------------------------------------------------------------------------------------
 # roofline of the dominant kernel
 # ---------------------------------------------------------------------------------------------
+KERNEL_SOURCES = ('conv_img.hip', 'wgrad_dma.hip', 'bn.hip', 'voxel.hip', 'elementwise.hip', 'kmap.hip', 'sort.hip',
+                  'hash.hip', 'plan.hip', 'conv.hip')
+
+
+def source_digest(files):
+    """sha256 over the kernel sources a counter record depends on (the record is void once they change)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, 'lidal_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(suffix, sources, same_workload, key):
+    """Counter traffic is measured OFFLINE (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
+    MI355X_MICROARCH.md prescribes) and kept under profiles/.  Only THIS round's record counts, and only if it was taken
+    on this exact workload AND on the kernel sources as they are now (the record stores their digest and the library
+    version): a changed kernel voids it -- the line then says so instead of quoting a stale number."""
+    name = 'r%02d_%s' % (ROUND, suffix)
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
+    except (OSError, ValueError):
+        return None, 'no counter record of this round (profiles/%s)' % name
+    try:
+        from lidal_amd import backend as B
+        lib = rec.get('library', {})
+        if not same_workload(rec['workload']):
+            return None, 'profiles/%s is of another workload' % name
+        if lib.get('version') != int(B.lib().lidal_version()) or lib.get('sources_sha16') != source_digest(sources):
+            return None, 'profiles/%s is STALE: taken on another build of the kernels (sources changed since)' % name
+        return rec[key], 'offline PMC passes: profiles/' + name
+    except (KeyError, TypeError) as e:
+        return None, 'profiles/%s unreadable: %r' % (name, e)
+
+
 def roofline_conv(args, coords, dev, reps=20):
     """Dominant kernel: the fused sparse conv (lidal_conv_apply) on the heaviest layer family --
     the 96->96 k3 convolutions at stride 1 (network/spvcnn.py:75-81).  Timed with HIP events on the
@@ -431,16 +472,9 @@ def roofline_conv(args, coords, dev, reps=20):
     # PMC-derived bytes per launch: measured OFFLINE (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on
     # `bench.py --roofline-only`, corrected as MI355X_MICROARCH.md prescribes) and kept under
     # profiles/; reported only if that record is of this exact workload
-    traffic, traffic_src = None, None
-    for name in ('r05_pmc_conv_apply.json', 'r04_pmc_conv_apply.json', 'r03_pmc_conv_apply.json', 'r02_pmc_conv_apply.json'):
-        try:
-            rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
-            wl = rec['workload']
-            if (wl['rows'], wl['rules'], wl['dtype']) == (n, m, args.dtype):
-                traffic, traffic_src = rec['traffic_bytes'], 'offline PMC passes: profiles/' + name
-                break
-        except (OSError, KeyError, ValueError):
-            pass
+    traffic, traffic_src = pmc_record('pmc_conv_apply.json', ('conv_img.hip',),
+                                      lambda wl: (wl['rows'], wl['rules'], wl['dtype']) == (n, m, args.dtype),
+                                      'traffic_bytes')
     return {'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
             'kernel': 'conv_lean_kernel<%s,6,192,8> through lidal_conv_apply_image (k3 s1 96->96)' % args.dtype,
@@ -492,6 +526,34 @@ def _val(a):
         return 0
 
 
+def map_rules(coords):
+    """rules per level of a coordinate set (same voxel sets whichever row order the model uses): {output rows of a
+    27-offset map: its rules}, and the algorithmic bytes of building every map of the network."""
+    from lidal_amd import SparseTensor
+    from lidal_amd.nn.functional.conv import prefetch_kernel_maps
+    from lidal_amd.network.unet import _SparseUNet
+    with torch.no_grad():
+        x = prefetch_kernel_maps(SparseTensor(None, coords), _SparseUNet.MAP_PLAN)
+        rules = {}
+        kmap_batch_bytes = 0                # every map of the network, built by ONE lidal_kmap_build_batch call
+        for key, km in x.kmaps.items():
+            if km.volume == 27:
+                rules[km.sizes[1]] = km.total
+            kmap_batch_bytes += 16 * km.sizes[0] + 16 * km.sizes[1] + 8 * km.total
+    torch.cuda.synchronize()
+    return rules, kmap_batch_bytes
+
+
+def conv_rules(rules, k, n_in, n_out):
+    """rules of a convolution call: dense layers one per row, 2x2x2 stride-2 maps one per fine row, 27-offset maps as
+    measured on this coordinate set"""
+    if k == 1:
+        return n_out
+    if k == 8:
+        return max(n_in, n_out)
+    return rules.get(n_out, rules.get(n_in, 6 * n_out))
+
+
 def family_table(step, coords, dtype_name, step_ms):
     """Runs `step` once with every library call bracketed by events and prices each call with the
     algorithmic bytes / FLOPs of SURVEY.md 8(d):
@@ -509,16 +571,7 @@ def family_table(step, coords, dtype_name, step_ms):
     from lidal_amd.network.unet import _SparseUNet
     b_el = 2 if dtype_name == 'bf16' else 4
     kmap_points = int(coords.shape[0])  # (SPVCNN's points: the voxel centres of the batch, one per voxel)
-    # rules per level of this batch (same voxel sets whichever row order the model uses)
-    with torch.no_grad():
-        x = prefetch_kernel_maps(SparseTensor(None, coords), _SparseUNet.MAP_PLAN)
-        rules = {}
-        kmap_batch_bytes = 0                # every map of the network, built by ONE lidal_kmap_build_batch call
-        for key, km in x.kmaps.items():
-            if km.volume == 27:
-                rules[km.sizes[1]] = km.total
-            kmap_batch_bytes += 16 * km.sizes[0] + 16 * km.sizes[1] + 8 * km.total
-    torch.cuda.synchronize()
+    rules, kmap_batch_bytes = map_rules(coords)
     calls = []
     # the profiled step runs operator by operator (LIDAL_PLAN=0's path): the launch plan issues the same kernels with
     # the same arguments (tests/test_plan_gpu.py: bitwise), but as words of one call that no per-call timer can bracket
@@ -542,11 +595,7 @@ def family_table(step, coords, dtype_name, step_ms):
     in_backward = False
 
     def rules_of(k, n_in, n_out):
-        if k == 1:
-            return n_out
-        if k == 8:
-            return max(n_in, n_out)
-        return rules.get(n_out, rules.get(n_in, 6 * n_out))
+        return conv_rules(rules, k, n_in, n_out)
 
     dump = os.environ.get('BENCH_FAMILY_CALLS')          # a path: one line per library call (family, name, ms, integer arguments)
     dump_f = open(dump, 'w') if dump else None
@@ -700,13 +749,10 @@ def family_table(step, coords, dtype_name, step_ms):
         'ms_at_mfma_roof': round(tot_fl / (peak_tf * 1e12) * 1e3, 3)}
     # counter traffic of the whole step, measured OFFLINE like roofline.traffic (two --pmc passes over bench.py itself:
     # scripts/gpu/r5_step_traffic.sh) and kept under profiles/; reported only for this exact workload
-    try:
-        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r05_pmc_step_traffic.json')))
-        if (rec['workload']['rows'], rec['workload']['dtype']) == (int(coords.shape[0]), dtype_name):
-            out['whole_step']['traffic_GB'] = rec['traffic_GB']
-            out['whole_step']['traffic_source'] = 'offline PMC passes: profiles/r05_pmc_step_traffic.json (the headline step)'
-    except (OSError, KeyError, ValueError):
-        pass
+    tr, src = pmc_record('pmc_step_traffic.json', KERNEL_SOURCES,
+                         lambda wl: (wl['rows'], wl['dtype']) == (int(coords.shape[0]), dtype_name), 'traffic_GB')
+    out['whole_step']['traffic_GB'] = tr
+    out['whole_step']['traffic_source'] = src
     return out
 
 
@@ -885,7 +931,10 @@ def bench_scoring(args, model, world, rank, dev, frames, batches):
             assert (got is not None) == (rank == 0)
             by_nei[str(nei)] = {'value': round(total / dt, 3), 'ms_per_frame_per_gpu': round(dt / per * 1e3, 3)}
         out['by_dtype'][dtype_name] = {'by_nei': by_nei,
-                                       'what': ('f32 inference (the reference\'s precision, prob_inference.py:91-113)'
+                                       'what': ('f32 features, weights and accumulation (the reference\'s precision, prob_inference.py:91-113); '
+                                                'products in the split form, LIDAL_F32_SPLIT=1: each operand cut exactly into 3 bf16 '
+                                                'pieces, 6 partial products on the bf16 MFMA (1.3e-6 of f64 on the 96->96 layer against '
+                                                '1.5e-6 for the exact f32 MFMA); the exact-f32 figure: by_dtype.f32_exact'
                                                 if dtype_name == 'f32' else
                                                 'bf16 conv operands / f32 accumulation at inference; scoring arithmetic as f32')}
     out['by_nei'] = out['by_dtype']['f32']['by_nei']
@@ -894,8 +943,183 @@ def bench_scoring(args, model, world, rank, dev, frames, batches):
         out['value'] = out['by_nei'][first]['value']
         out['ms_per_frame_per_gpu'] = out['by_nei'][first]['ms_per_frame_per_gpu']
         out['nei_num'] = int(first)
+        if world == 1:
+            # the same frames on the EXACT f32 MFMA (LIDAL_F32_SPLIT=0), so that the headline's precision label is auditable
+            from lidal_amd import backend as B
+            split = B.SPLIT_F32
+            B.SPLIT_F32 = False
+            try:
+                run(int(first), False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(int(first), False)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                out['by_dtype']['f32_exact'] = {
+                    'by_nei': {first: {'value': round(total / dt, 3), 'ms_per_frame_per_gpu': round(dt / per * 1e3, 3)}},
+                    'what': 'LIDAL_F32_SPLIT=0: every product on v_mfma_f32_16x16x4_f32 (157 TFLOP/s dense peak)'}
+            finally:
+                B.SPLIT_F32 = split
+            # frames/s as a fraction of the roofline (north_star): the frame's convolution FLOPs over the whole-job time per
+            # frame against the MFMA bound of the arithmetic actually used, the scorer's bytes over its kernel time against HBM
+            out['roofline'] = guarded(scoring_roofline, model, dev_frames, int(first), 'f32',
+                                      out['ms_per_frame_per_gpu'])
+            if 'bf16' in out['by_dtype'] and first in out['by_dtype']['bf16']['by_nei']:
+                out['by_dtype']['bf16']['roofline'] = guarded(
+                    scoring_roofline, model, dev_frames, int(first), 'bf16',
+                    out['by_dtype']['bf16']['by_nei'][first]['ms_per_frame_per_gpu'])
     model.train()
     return out
+
+
+def scoring_roofline(model, dev_frames, nei, dtype_name, ms_per_frame):
+    """One frame of the secondary metric call by call (the per-operator path: a launch plan is one call no timer can
+    bracket -- same kernels, tests/test_plan_gpu.py): the convolution / dense-layer FLOPs of its 8-view inference
+    (2 M Ci Co per call, M = the rules of the call's kernel map as measured on this frame) and the algorithmic bytes of
+    scoring it ((1 + nei) P (C 4 + 24) for the inter-frame kernels, the NN grid of ONE frame -- every
+    frame's grid is built once and read by its nei neighbours --, the supervoxel reduction).
+      inference   FLOPs per frame / the WHOLE-JOB time per frame (1 / frames-per-second) against the MFMA bound of the
+                  arithmetic actually used: 2.5 PFLOP/s bf16; a sixth of it for f32 in the split form (six bf16 MFMAs
+                  per f32 product block; the 4-channel stem runs on the exact f32 MFMA and is priced with the rest);
+                  `conv_kernels` = the same FLOPs over the bracketed time of those calls alone
+      scorer      algorithmic bytes per scored frame / the bracketed time of its calls against the HBM peak"""
+    from lidal_amd import backend as B
+    from lidal_amd.network import plan as _plan
+    from lidal_amd.score.interframe import FrameBank, score_frame
+    from lidal_amd.score.prob_inference import infer_frame
+    autocast = dtype_name == 'bf16'
+    d = dev_frames[0]
+    rules, _ = map_rules(d['coords'])
+    calls = []
+    planned = _plan.ENABLED
+    _plan.ENABLED = False
+    probs = []
+    try:
+        for j in range(nei + 1):          # the probabilities of one window (untimed), then frame 0 call by call
+            f = dev_frames[j]
+            probs.append(infer_frame(model, f['coords'], f['feats'], f['inverse'], 8, autocast=autocast)[0])
+        torch.cuda.synchronize()
+        B.set_call_timer(lambda name, a, e0, e1: calls.append((name, [_val(v) for v in a], e0, e1)))
+        infer_frame(model, d['coords'], d['feats'], d['inverse'], 8, autocast=autocast)
+        torch.cuda.synchronize()
+        inf_calls = list(calls)
+        del calls[:]
+        bank = FrameBank(0.1, n_frames=nei + 1)
+        for j in range(nei + 1):
+            bank.add(dev_frames[j]['world'], probs[j], frame_id=j)
+        mid = nei // 2
+        B.set_call_timer(None)
+        score_frame(bank, mid, dev_frames[mid]['sv_ptr'], dev_frames[mid]['sv_idx'], nei)       # (builds the grids)
+        bank._grid[0] = None                                                                   # one grid build, timed
+        torch.cuda.synchronize()
+        B.set_call_timer(lambda name, a, e0, e1: calls.append((name, [_val(v) for v in a], e0, e1)))
+        score_frame(bank, mid, dev_frames[mid]['sv_ptr'], dev_frames[mid]['sv_idx'], nei)
+        torch.cuda.synchronize()
+        score_calls = list(calls)
+    finally:
+        B.set_call_timer(None)
+        _plan.ENABLED = planned
+    flops = conv_ms = 0.0
+    codes = {}
+    for name, a, e0, e1 in inf_calls:
+        if name in ('lidal_conv_apply_image', 'lidal_conv_apply_image_ws'):
+            n_in, n_out, ci, co, k, dt = a[6], a[7], a[8], a[9], a[10], a[12]
+            flops += 2.0 * conv_rules(rules, k, n_in, n_out) * ci * co
+            conv_ms += e0.elapsed_time(e1)
+            codes[dt] = codes.get(dt, 0) + 1
+    form = ('bf16' if autocast else ('f32 in the split form (3 bf16 pieces per operand, 6 bf16 MFMAs per product block)'
+                                     if codes.get(B.F32_SPLIT, 0) else 'exact f32 MFMA'))
+    peak = MFMA_PEAK_TFLOPS['bf16'] if autocast else (SPLIT_PEAK_TFLOPS if codes.get(B.F32_SPLIT, 0) else MFMA_PEAK_TFLOPS['f32'])
+    sc_bytes = sc_ms = 0.0
+    for name, a, e0, e1 in score_calls:
+        ms = e0.elapsed_time(e1)
+        if name == 'lidal_interframe_score':
+            p, c, n_nei = a[2], a[3], a[8]
+            sc_bytes += (1 + n_nei) * p * (c * 4 + 24) + p * 16
+            sc_ms += ms
+        elif name == 'lidal_nn_grid_build':
+            p = a[1]
+            sc_bytes += 24 * p + int(B.lib().lidal_nn_grid_bytes(p))
+            sc_ms += ms
+        elif name == 'lidal_supervoxel_reduce':
+            p = int(d['world'].shape[0])
+            sc_bytes += p * (8 + 4 + 24 + 8)
+            sc_ms += ms
+    tf = flops / (ms_per_frame * 1e-3) / 1e12
+    out = {'inference': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                         'frac': round(tf / peak, 4), 'GFLOP_per_frame': round(flops / 1e9, 1), 'arithmetic': form,
+                         'time': 'whole job: %.3f ms per frame (1 / frames per second)' % ms_per_frame,
+                         'conv_kernels': {'ms_per_frame': round(conv_ms, 3), 'calls': sum(codes.values()),
+                                          'achieved': round(flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
+                                          'frac': round(flops / (conv_ms * 1e-3) / 1e12 / peak, 4) if conv_ms else None}}}
+    if sc_ms:
+        gbs = sc_bytes / (sc_ms * 1e-3) / 1e9
+        out['scorer'] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(gbs / HBM_PEAK_GBS, 4), 'algorithmic_MB_per_frame': round(sc_bytes / 1e6, 2),
+                         'kernel_us_per_frame': round(sc_ms * 1e3, 1), 'nei_num': nei,
+                         'what': 'lidal_interframe_score + one lidal_nn_grid_build + lidal_supervoxel_reduce, HIP events around each call'}
+    return out
+
+
+def make_sequence_frames(n_frames, points, seed=7122):
+    """The raw frames of ONE sequence of n_frames (BASELINE.json configs[3]: 256), generated by a spawn pool BEFORE this
+    process touches the GPU."""
+    import multiprocessing as mp
+    workers = max(1, min(16, os.cpu_count() or 1, n_frames // 8))
+    bounds = np.linspace(0, n_frames, workers + 1).astype(int)
+    jobs = [(int(bounds[i + 1] - bounds[i]), points, seed, int(bounds[i]), n_frames) for i in range(workers)
+            if bounds[i + 1] > bounds[i]]
+    if workers == 1:
+        return _gen_frame_block(jobs[0])
+    with mp.get_context('spawn').Pool(workers) as pool:
+        return [f for blk in pool.map(_gen_frame_block, jobs) for f in blk]
+
+
+def bench_score_sequence(args, model, dev, frames, nei=10):
+    """BASELINE.json configs[3] at its stated length on ONE GPU: a whole 256-frame sequence -- 8 augmented views per frame
+    voxelised and collated on the GPU (lidal_voxelize_points, outside the timed region), f32 inference, every frame scored
+    against its +-nei/2 window with the wrap rules at both ends (LiDAL.py:41-42), the FrameBank holding all 256 frames."""
+    from lidal_amd import data
+    from lidal_amd.score import interframe, score_sequence
+    aug = np.random.RandomState(7122)
+    dev_frames = []
+    for f in frames:
+        pts, inten = torch.from_numpy(f['points']).to(dev), torch.from_numpy(f['intensity']).to(dev)
+        samples = []
+        for _ in range(8):
+            trans_m, rnd = data.draw_augmentation(aug)
+            coords_v, feats_v, _, inverse = data.voxelize_scan(pts, inten, trans_m, rnd)
+            samples.append({'coords_v': coords_v, 'feats_v': feats_v, 'inverse_idxs': inverse})
+        b = data.collate(samples)
+        ptr, idx, _ = interframe.sv_csr(f['sv2point'], dev)
+        dev_frames.append({'coords': b['coords_v_b'].contiguous(), 'feats': b['feats_v_b'].contiguous(),
+                           'inverse': b['inverse_indices_b'].contiguous(),
+                           'world': torch.from_numpy(f['world']).to(dev), 'sv_ptr': ptr, 'sv_idx': idx})
+    n = len(dev_frames)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    resident = int(torch.cuda.memory_allocated(dev))
+    model.eval()
+    try:
+        score_sequence(model, dev_frames[:nei + 6], 0, nei + 6, nei_num=nei, dis_thresh=0.1, inf_reps=8)      # warm-up
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        t0 = time.perf_counter()
+        scores = score_sequence(model, dev_frames, 0, n, nei_num=nei, dis_thresh=0.1, inf_reps=8)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        model.train()
+    assert len(scores) == n and all(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all() for o in scores)
+    return {'frames': n, 'frames_per_s': round(n / dt, 3), 'ms_per_frame': round(dt / n * 1e3, 3), 'seconds': round(dt, 3),
+            'dtype': 'f32', 'nei_num': nei, 'points_per_frame': args.points,
+            'voxels_per_frame': int(np.mean([d['coords'].shape[0] for d in dev_frames])),
+            'inputs_resident_MB': resident >> 20,
+            'peak_allocated_MB': int(torch.cuda.max_memory_allocated(dev)) >> 20,
+            'peak_reserved_MB': int(torch.cuda.max_memory_reserved(dev)) >> 20,
+            'what': 'one whole sequence on one GPU (config 4 at its stated length): inputs resident, 8-view f32 inference '
+                    '+ inter-frame scoring of every frame, windows wrapping at both ends (LiDAL.py:41-42); the first '
+                    'pass over the full length is the timed one (warm-up: %d frames)' % (nei + 6)}
 
 
 def guarded(fn, *a):
@@ -1023,6 +1247,10 @@ def main():
     if solo and not args.no_cpu_baseline and not args.roofline_only:
         cpu_lines['train'] = guarded(cpu_baseline, args)
         log('train cpu baseline', cpu_lines['train'])
+    seq_frames = None
+    if (solo and not args.no_variants and not args.no_secondary and not args.roofline_only and args.sequence_frames > 0):
+        seq_frames = guarded(make_sequence_frames, args.sequence_frames, args.points)
+        log('sequence of %d frames generated' % args.sequence_frames if isinstance(seq_frames, list) else seq_frames)
     # ---- GPU
     world, rank, dev = dist_setup(args)
     from lidal_amd import backend
@@ -1091,6 +1319,15 @@ def main():
             line['secondary'] = sec
             if 'secondary' in cpu_lines:
                 line['secondary']['cpu_baseline'] = cpu_lines['secondary']
+    if isinstance(seq_frames, list):
+        if os.environ.get('BENCH_EMPTY_CACHE', '1') != '0':
+            frames = batches = None
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        leg = guarded(bench_score_sequence, args, res['model'], dev, seq_frames, args.nei[0])
+        log('score_%d' % args.sequence_frames, leg)
+        if isinstance(line.get('variants'), dict):
+            line['variants']['score_%d' % args.sequence_frames] = leg
     if 'train' in cpu_lines:
         line['cpu_baseline'] = cpu_lines['train']
     if rank == 0:

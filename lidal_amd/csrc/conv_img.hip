@@ -888,6 +888,82 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
+#if defined(LIDAL_LEAN_ROLLING) && !defined(LIDAL_PHASE_STAMPS)
+  // (experiment build, round 6) ONE rolling set of A fragments and one copy of the loop body, as conv_lean32_kernel: the
+  // registers of reduction step cc are re-loaded with the next phase's rows right behind this phase's MFMAs of that
+  // step; the tile's last phase issues its loads out of range.  Same sums in the same order as the two-set pipeline.
+  {
+    auto dma_rt = [&](int k, int pass, int slot, bool live_phase) {
+      const bool live = dma_wave && live_phase;
+      const unsigned soff = live ? (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base : OOB_OFF;
+      unsigned char* const base = live ? dma_dst + slot * SLAB : dump;
+#pragma unroll
+      for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
+        auto* dst = (__attribute__((address_space(3))) void*)(base + (live ? c4 * 4096 : 0));
+        const unsigned so = live ? soff + (unsigned)(c4 * 4096) : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
+        if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
+        if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
+        if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
+      }
+    };
+    auto a_off = [&](int idx, unsigned long long& have) -> unsigned {
+      const bool has = idx >= 0 && row_in;
+      have = __ballot(has);
+      const unsigned off = __umul24((unsigned)idx, row_bytes) + lane_off;
+      return has ? off : OOB_OFF;
+    };
+    raw4 a[MAXCC];
+    if (nphase > 0) {
+      advance();
+      const int k0 = wk, p0 = wpass;
+      const int i0 = issue_idx(k0);
+      advance();
+      int i_nxt = issue_idx(wk);
+      int kn = wk, pn = wpass;
+      unsigned long long have = 0ull;
+      dma_rt(k0, p0, 0, true);
+      {
+        const unsigned off = a_off(i0, have);
+#pragma unroll
+        for (int cc = 0; cc < MAXCC; ++cc)
+          a[cc] = __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + (unsigned)(cc * 64), (unsigned)p0 * (unsigned)ROW_BYTES, 0));
+      }
+      slab_wait();
+      int slot = 0;
+      for (int p = 0; p < nphase; ++p) {
+        const bool more = p + 1 < nphase;
+        advance();
+        const int i_nn = issue_idx(wk);
+        dma_rt(kn, pn, slot ^ 1, more);
+        unsigned long long have_n;
+        unsigned off = a_off(i_nxt, have_n);
+        off = more ? off : OOB_OFF;
+        have_n = more ? have_n : 0ull;
+        const unsigned char* const wcur = wbase + slot * SLAB;
+        const unsigned soff = (unsigned)pn * (unsigned)ROW_BYTES;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cc = 0; cc < MAXCC; ++cc) {
+          if (have != 0ull) {
+            frag b[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) b[j] = *reinterpret_cast<const frag*>(wcur + (cc * 4 * NB + j) * 256);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) mma(acc[0][j], __builtin_bit_cast(frag, a[cc]), b[j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          a[cc] = __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + (unsigned)(cc * 64), soff, 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        have = have_n;
+        i_nxt = i_nn; kn = wk; pn = wpass;
+        slot ^= 1;
+        slab_wait();
+      }
+    }
+  }
+#else
   // Pipeline: phase p issues index(p+2), slab(p+1) by DMA, A(p+1) -- in this order: vector-memory
   // operations retire in order, so the gather's wait for index(p+1) (issued a phase ago, FIRST)
   // leaves last phase's slab and gathers in flight, and slab_wait leaves this phase's gathers.
@@ -949,6 +1025,7 @@ conv_lean_kernel(const T* __restrict__ in, const T* __restrict__ wimg, const int
     }
     __syncthreads();                                // every wave is done with the last slab
   }
+#endif
 #undef ST_ISSUED
 #undef ST_COMPUTED
 #undef ST_PHASE_END
@@ -1472,6 +1549,559 @@ conv_split_kernel(const float* __restrict__ in, const __bf16* __restrict__ wimg,
                                    ep_res, true, perm_v, nullptr, bx, nullptr);
 }
 
+// ------------------------------------------------------------------------------------------
+// the split form on v_mfma_f32_32x32x16_bf16: 32 rows per wave (round 6)
+// ------------------------------------------------------------------------------------------
+// conv_split_kernel reads one 1-KiB B fragment from LDS per 16 x 16 x 32 MFMA (16 cycles): 3 NB fragment reads for 6 NB
+// MFMAs per wave and slice, the CU's LDS array and its four MFMA pipes loaded about equally -- it ran at 53 % of its MFMA
+// bound.  Here a wave owns 32 rows and multiplies 32 x 32 x 16 blocks (32 cycles each): a B fragment (16 channels x 32
+// columns, still one ds_read_b128 = 1 KiB per wave) now serves twice the rows, so a 128-row tile reads half the fragment
+// bytes for the same MFMA cycles, and has 4 waves instead of 8 (half the DMA and barrier participants per row).
+//   * the weight image is conv_split_kernel's, byte for byte: lane l = (r = l & 31, h = l >> 5) of a 32 x 32 x 16 B operand
+//     holds B[k = 8 h + j][column r]; with k-step ks of a 32-channel slice that is the image's 8-channel group
+//     gsel = 2 ks + h and its column (2 cb + (r >> 4)) * 16 + (r & 15): the lane's address is base + r * 16 inside a
+//     contiguous 512-byte run -- conflict free for ds_read_b128's four 16-lane groups as before;
+//   * features: lane (r, h) gathers channels 16 ks + 8 h .. + 7 of row r for both k-steps (four 16-byte loads per phase
+//     -- the bytes per row are the same 128), cuts them into the three bf16 pieces in registers;
+//   * accumulators: NB / 2 blocks of 16 registers (column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h); the
+//     write-out goes through a wave-private LDS tile 16 rows at a time (store_rows32).
+// Same products as conv_split_kernel (six partial products per f32 product, smallest first within a k-step); the sums run
+// in another order (16 channels per MFMA instead of 32), so results agree with it to f32 rounding of the accumulation,
+// not bit for bit (tests/test_ops_gpu.py bounds both against f64).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#ifndef LIDAL_SPLIT32_MINWAVES
+#define LIDAL_SPLIT32_MINWAVES 2
+#endif
+__host__ __device__ constexpr int split32_ppw(int pieces, int nwaves) {        // consecutive 1-KiB pieces per DMA wave: equal whole shares
+  int p = (pieces + nwaves - 1) / nwaves;
+  while (pieces % p != 0) ++p;
+  return p;
+}
+
+// accumulators of the 32-row form -> HBM, 16 rows at a time through a wave-private LDS tile [16][BN + VEC] of T, whole
+// rows with 16-byte stores, with the affine map / ReLU / residual of the inference epilogue.  perm_v: lane l < 32 holds
+// perm[r0 + l].
+template <typename T, int NB2>
+__device__ __forceinline__ void store_rows32(f32x16 (&acc)[NB2], unsigned char* wl, int wave, int lane, int64_t r0,
+                                             int n0, int64_t n_out, int co, const int* __restrict__ perm,
+                                             T* __restrict__ out, const float* __restrict__ ep_scale,
+                                             const float* __restrict__ ep_shift, int ep_relu,
+                                             const T* __restrict__ ep_res, int perm_v) {
+  constexpr int VEC = DT<T>::VEC;
+  constexpr int BN = 32 * NB2;
+  constexpr int ESTRIDE = BN + VEC;
+  typedef typename DT<T>::frag frag;
+  const int r32 = lane & 31, h = lane >> 5;
+  T* et = reinterpret_cast<T*>(wl) + wave * 16 * ESTRIDE;
+  if (ep_scale != nullptr) {
+#pragma unroll
+    for (int cb = 0; cb < NB2; ++cb) {
+      const int col = n0 + cb * 32 + r32;
+      const float es = col < co ? ep_scale[col] : 1.f, eh = col < co ? ep_shift[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[cb][r] * es + eh;
+        acc[cb][r] = ((ep_relu & 1) && v < 0.f) ? 0.f : v;
+      }
+    }
+  }
+  constexpr int RSEGS = BN / VEC;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    // rows 16 half .. + 15 of the wave: register quads 2 half and 2 half + 1
+#pragma unroll
+    for (int cb = 0; cb < NB2; ++cb)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          et[(8 * q + 4 * h + i) * ESTRIDE + cb * 32 + r32] = DT<T>::from_f32(acc[cb][(2 * half + q) * 4 + i]);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (int i = lane; i < 16 * RSEGS; i += 64) {
+      const int r = i / RSEGS, cseg = (i - r * RSEGS) * VEC;
+      const int prow = __shfl(perm_v, 16 * half + r, 64);           // all lanes take part
+      const int64_t trow = r0 + 16 * half + r;
+      if (trow >= n_out) continue;
+      const int64_t row = perm ? (int64_t)prow : trow;
+      T* dst = out + row * co + n0 + cseg;
+      const T* srcp = et + r * ESTRIDE + cseg;
+      if (n0 + cseg + VEC <= co) {
+        frag v = *reinterpret_cast<const frag*>(srcp);
+        if (ep_res != nullptr) {
+          const frag rr = *reinterpret_cast<const frag*>(ep_res + row * co + n0 + cseg);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float f = DT<T>::to_f32(v[e]) + DT<T>::to_f32(rr[e]);
+            if ((ep_relu & 2) && f < 0.f) f = 0.f;
+            v[e] = DT<T>::from_f32(f);
+          }
+        }
+        *reinterpret_cast<frag*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (n0 + cseg + e < co) {
+            float v = DT<T>::to_f32(srcp[e]);
+            if (ep_res != nullptr) {
+              v += DT<T>::to_f32(ep_res[row * co + n0 + cseg + e]);
+              if ((ep_relu & 2) && v < 0.f) v = 0.f;
+            }
+            dst[e] = DT<T>::from_f32(v);
+          }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);           // the tile is read before the second half overwrites it
+  }
+}
+
+template <int NB, int NWAVES, bool DENSE>
+__global__ void __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 4 : LIDAL_SPLIT32_MINWAVES))
+conv_split32_kernel(const float* __restrict__ in, const __bf16* __restrict__ wimg, const int* __restrict__ nbr,
+                    const int* __restrict__ perm, const unsigned* __restrict__ tmasks, float* __restrict__ out,
+                    int64_t n_out, int ci, int co, int K, int kflip, const float* __restrict__ ep_scale,
+                    const float* __restrict__ ep_shift, int ep_relu, const float* __restrict__ ep_res, unsigned in_bytes,
+                    unsigned img_bytes, unsigned nbr_bytes, Split sp) {
+  constexpr int BM = NWAVES * 32;                        // 128- or 256-row tiles
+  constexpr int BN = 16 * NB;
+  constexpr int NB2 = NB / 2;
+  constexpr int SLAB = BN * SPLIT_ROW;
+  constexpr int PIECES = SLAB / 1024;
+  constexpr int PPW = split32_ppw(PIECES, NWAVES);
+  constexpr int DMA_WAVES = PIECES / PPW;
+  static_assert(NB % 2 == 0, "32-column blocks");
+  static_assert(PIECES % PPW == 0 && DMA_WAVES <= NWAVES && SLAB % 1024 == 0 && PPW <= 12, "a DMA wave moves a whole share");
+  static_assert(BM % TILE_ROWS == 0, "tile masks are per 128 rows");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;                              // [2][SLAB], re-used as the epilogue tile
+  constexpr int LEPI_ALL = NWAVES * 16 * (BN + 4) * 4;
+  unsigned char* const dump = smem + ((2 * SLAB > LEPI_ALL) ? 2 * SLAB : LEPI_ALL);     // 4 KiB
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r32 = lane & 31;
+  const int h = lane >> 5;
+  const int bx = tile_of_block();
+  const int64_t r0 = (int64_t)bx * BM + wave * 32;
+  const int n0 = blockIdx.y * BN;
+  const int npass = ci / SPLIT_KCH;
+
+  unsigned tmask = 1u;
+  if constexpr (!DENSE) {
+    unsigned m = 0u;
+    const int64_t t0 = ((int64_t)bx * BM) >> 7;
+#pragma unroll
+    for (int q = 0; q < BM / 128; ++q)
+      if ((t0 + q) * 128 < n_out) m |= tmasks[t0 + q];
+    if (kflip) m = __brev(m) >> (32 - K);
+    tmask = __builtin_amdgcn_readfirstlane(m);
+    if (sp.nsplit > 1) {        // this workgroup's share of the tile's active offsets (struct Split)
+      const int cnt = __popc(tmask), z = (int)blockIdx.z;
+      const int lo = z * cnt / sp.nsplit, hi = (z + 1) * cnt / sp.nsplit;
+      unsigned left = tmask, sub = 0u;
+      for (int rk = 0; left != 0u; ++rk) {
+        const unsigned bit = left & (0u - left);
+        if (rk >= lo && rk < hi) sub |= bit;
+        left ^= bit;
+      }
+      tmask = __builtin_amdgcn_readfirstlane(sub);
+    }
+  }
+  const int nphase = __popc(tmask) * npass;
+
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wimg), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nbr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, (int)nbr_bytes, 0x00020000);
+
+  constexpr unsigned OOB_OFF = 0x80000000u;
+  const unsigned row_bytes = (unsigned)ci * 4u;
+  const unsigned lane_off = (unsigned)h * 32u;                  // this lane's 8 f32 channels of a 16-channel k-step
+  const unsigned idx_voff = (unsigned)((r0 + r32) * 4);
+  const bool row_in = r0 + r32 < n_out;
+  const unsigned k_stride = (unsigned)n_out * 4u;
+  const unsigned slab_k = (unsigned)gridDim.y * (unsigned)npass * (unsigned)SLAB;
+  const unsigned slab_base = (unsigned)blockIdx.y * (unsigned)npass * (unsigned)SLAB + (unsigned)(wave * PPW) * 1024u;
+  const unsigned dma_voff = (unsigned)lane * 16u;
+  const bool dma_wave = wave < DMA_WAVES;
+  unsigned char* const dma_dst = wl + (wave * PPW) * 1024;
+  const unsigned char* const wbase = wl + (h * NB) * 256 + r32 * 16;
+
+  const __amdgpu_buffer_rsrc_t rs_perm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int*>(perm), 0, perm != nullptr ? (int)k_stride : 0, 0x00020000);
+  const int perm_v = __builtin_amdgcn_raw_buffer_load_b32(rs_perm, idx_voff, 0, 0);
+
+  unsigned rem = tmask;
+  int wk = 0, wpass = npass - 1;
+  auto advance = [&]() {
+    if (++wpass == npass) {
+      wpass = 0;
+      wk = rem ? __builtin_ctz(rem) : 0;
+      rem &= rem - 1u;
+    }
+  };
+  auto issue_idx = [&](int k) -> int {
+    if constexpr (DENSE) {
+      return (int)(r0 + r32);
+    } else {
+      const unsigned kk = (unsigned)(kflip ? (K - 1 - k) : k);
+      return __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, idx_voff, kk * k_stride, 0);
+    }
+  };
+  // every wave issues PPW DMA instructions per phase (a wave without a share aims out of range at the dump): the
+  // counted wait below relies on it, as in the lean kernel
+  auto issue_dma = [&](int k, int pass, int slot, bool live_phase) {
+    const bool live = dma_wave && live_phase;
+    const unsigned soff = live ? (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base : OOB_OFF;
+    unsigned char* const base = live ? dma_dst + slot * SLAB : dump;
+#pragma unroll
+    for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
+      auto* dst = (__attribute__((address_space(3))) void*)(base + (live ? c4 * 4096 : 0));
+      const unsigned so = live ? soff + (unsigned)(c4 * 4096) : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
+      if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
+      if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
+      if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
+    }
+  };
+  // a[2 ks + t]: channels 16 ks + 8 h + 4 t .. + 3 of the lane's row.  ONE rolling set (as conv_lean32_kernel): the two
+  // registers of a k-step are cut into their bf16 pieces, re-loaded at once with the NEXT phase's row, and only then
+  // multiplied -- the phase's gathers sit between its MFMAs, not in a burst behind the barrier.
+  auto a_off = [&](int idx, unsigned long long& have) -> unsigned {
+    const bool has = idx >= 0 && row_in;
+    have = __ballot(has);
+    const unsigned off = __umul24((unsigned)idx, row_bytes) + lane_off;
+    return has ? off : OOB_OFF;
+  };
+  auto load_a = [&](unsigned off, int pass, int j) -> raw4 {
+    return __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(
+        rs_in, off + (unsigned)((j >> 1) * 64 + (j & 1) * 16), (unsigned)pass * (unsigned)(SPLIT_KCH * 4), 0));
+  };
+
+  f32x16 acc[NB2];
+#pragma unroll
+  for (int cb = 0; cb < NB2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+  raw4 a[4];
+  auto mfma_step = [&](const Pieces& p, int ks, const unsigned char* wcur) __attribute__((always_inline)) {
+#pragma unroll
+    for (int cb = 0; cb < NB2; ++cb) {
+      const unsigned char* q = wcur + ks * (2 * NB * 256) + cb * 512;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(q);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(q + 4 * NB * 256);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(q + 8 * NB * 256);
+      f32x16 c = acc[cb];                 // smallest partial products first
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.lo, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.mid, bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.hi, bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.mid, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.hi, bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.hi, bh, c, 0, 0, 0);
+      acc[cb] = c;
+    }
+  };
+  auto slab_wait = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 4);             // only the four gathers issued behind the DMA may be in flight
+    __syncthreads();
+  };
+
+  if (nphase > 0) {
+    advance();
+    const int k0 = wk, p0 = wpass;
+    const int i0 = issue_idx(k0);
+    advance();
+    int i_nxt = issue_idx(wk);                      // rows of phase 1
+    int kn = wk, pn = wpass;                        // (offset, slice) of phase 1
+    unsigned long long have = 0ull;
+    issue_dma(k0, p0, 0, true);
+    {
+      const unsigned off = a_off(i0, have);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = load_a(off, p0, j);
+    }
+    slab_wait();
+    int slot = 0;
+    for (int p = 0; p < nphase; ++p) {              // (the tile's last phase issues its loads out of range: one loop body)
+      const bool more = p + 1 < nphase;
+      advance();
+      const int i_nn = issue_idx(wk);
+      issue_dma(kn, pn, slot ^ 1, more);
+      unsigned long long have_n;
+      unsigned off = a_off(i_nxt, have_n);
+      off = more ? off : OOB_OFF;
+      have_n = more ? have_n : 0ull;
+      const unsigned char* const wcur = wbase + slot * SLAB;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        Pieces pc;
+        if (have != 0ull) pc = cut3(a[2 * ks], a[2 * ks + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        a[2 * ks] = load_a(off, pn, 2 * ks);
+        a[2 * ks + 1] = load_a(off, pn, 2 * ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (have != 0ull) mfma_step(pc, ks, wcur);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      have = have_n;
+      i_nxt = i_nn; kn = wk; pn = wpass;
+      slot ^= 1;
+      slab_wait();
+    }
+  }
+  if (sp.nsplit > 1) {          // a share of the tile's offsets: the f32 accumulators go to conv_combine32_kernel
+    f32x4* dst = reinterpret_cast<f32x4*>(sp.partial) +
+                 ((((int64_t)blockIdx.z * gridDim.x + bx) * gridDim.y + blockIdx.y) * NWAVES + wave) * (NB2 * 4 * 64) + lane;
+#pragma unroll
+    for (int cb = 0; cb < NB2; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        dst[(cb * 4 + q) * 64] = f32x4{acc[cb][4 * q], acc[cb][4 * q + 1], acc[cb][4 * q + 2], acc[cb][4 * q + 3]};
+    return;
+  }
+  store_rows32<float, NB2>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu, ep_res, perm_v);
+}
+
+// the shares of a split launch of the 32-row form added in split order, then its epilogue
+template <typename T, int NB2, int NWAVES>
+__global__ void __launch_bounds__(64 * NWAVES)
+conv_combine32_kernel(Split sp, const int* __restrict__ perm, T* __restrict__ out, int64_t n_out, int co,
+                      const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int ep_relu,
+                      const T* __restrict__ ep_res) {
+  constexpr int BM = NWAVES * 32, BN = 32 * NB2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t r0 = (int64_t)blockIdx.x * BM + wave * 32;
+  const int n0 = blockIdx.y * BN;
+  f32x16 acc[NB2];
+  const f32x4* src = reinterpret_cast<const f32x4*>(sp.partial) +
+                     (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NWAVES + wave) * (NB2 * 4 * 64) + lane;
+  const int64_t share = (int64_t)gridDim.x * gridDim.y * NWAVES * (NB2 * 4 * 64);      // vectors per split
+#pragma unroll
+  for (int cb = 0; cb < NB2; ++cb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = src[(cb * 4 + q) * 64];
+      for (int z = 1; z < sp.nsplit; ++z) {
+        const f32x4 t = src[(int64_t)z * share + (cb * 4 + q) * 64];
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+      }
+      acc[cb][4 * q] = v[0]; acc[cb][4 * q + 1] = v[1]; acc[cb][4 * q + 2] = v[2]; acc[cb][4 * q + 3] = v[3];
+    }
+  const int64_t prow_i = r0 + (lane & 31);
+  const int perm_v = (perm != nullptr && prow_i < n_out) ? perm[prow_i] : 0;
+  store_rows32<T, NB2>(acc, smem, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu, ep_res, perm_v);
+}
+
+// ------------------------------------------------------------------------------------------
+// the lean kernel on v_mfma_f32_32x32x16_bf16 with 256-row tiles (round 6)
+// ------------------------------------------------------------------------------------------
+// What the lean kernel moves through a CU's vector-memory path per launch of the roofline layer (96 -> 96, 396 662 rows,
+// 1.88 M rules): 361 MB of gathered rows -- and 1.29 GB of WEIGHT SLABS (23.9 k (tile, offset) pairs x 3 slices x 18 KB,
+// L2 -> LDS by DMA): the slab of a phase serves only 128 rows.  256-row tiles of 16 waves x 16 rows halved that but left one
+// workgroup per CU (94 registers x 16 waves) and lost (round 5).  With 32 rows per wave a 256-row tile is 8 waves: the same
+// waves and rows in flight per CU as today (two workgroups, <= 128 registers), half the slab bytes, half the DMA
+// instructions, half the LDS fragment reads and half the barrier participants per row.
+//   * A operand: lane (r = l & 31, h = l >> 5) holds channels 16 ks + 8 h .. + 7 of row r for k-step ks: one 16-byte load
+//     per k-step (ROW_BYTES / 32 per phase), the same bytes per row as before;
+//   * B operand: the bf16 image as it is -- k-step ks is the image's 32-channel step cc = ks / 2, 8-channel group
+//     gsel = 2 (ks & 1) + h; a lane reads base + r * 16 inside a contiguous 512-byte run: conflict free;
+//   * a tile's offset mask is the OR of its two 128-row masks (the row order keeps neighbouring tiles' patterns close).
+// Same sums in another order (16 channels per MFMA instead of 32): equal to the lean kernel to f32 rounding of the
+// accumulation, bitwise reproducible run to run.
+#ifndef LIDAL_LEAN32_MINWAVES
+#define LIDAL_LEAN32_MINWAVES 4
+#endif
+template <int NB, int ROW_BYTES, bool DENSE>
+__global__ void __launch_bounds__(512, LIDAL_LEAN32_MINWAVES)
+conv_lean32_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wimg, const int* __restrict__ nbr,
+                   const int* __restrict__ perm, const unsigned* __restrict__ tmasks, __bf16* __restrict__ out,
+                   int64_t n_out, int ci, int co, int K, int kflip, const float* __restrict__ ep_scale,
+                   const float* __restrict__ ep_shift, int ep_relu, const __bf16* __restrict__ ep_res, unsigned in_bytes,
+                   unsigned img_bytes, unsigned nbr_bytes) {
+  typedef __bf16 T;
+  constexpr int NWAVES = 8;
+  constexpr int BM = NWAVES * 32;                        // 256 rows
+  constexpr int BN = 16 * NB;
+  constexpr int NB2 = NB / 2;
+  constexpr int KS = ROW_BYTES / 32;                     // 16-channel k-steps per slice
+  constexpr int SLAB = BN * ROW_BYTES;
+  constexpr int PIECES = SLAB / 1024;
+  constexpr int PPW = (PIECES + NWAVES - 1) / NWAVES;
+  constexpr int DMA_WAVES = PIECES / PPW;
+  static_assert(NB % 2 == 0 && ROW_BYTES % 64 == 0, "32-column blocks, whole 32-channel image steps");
+  static_assert(PIECES % PPW == 0 && DMA_WAVES <= NWAVES && SLAB % 1024 == 0 && PPW <= 12, "a DMA wave moves a whole share");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;                              // [2][SLAB], re-used as the epilogue tile
+  constexpr int LEPI_ALL = NWAVES * 16 * (BN + 8) * 2;
+  unsigned char* const dump = smem + ((2 * SLAB > LEPI_ALL) ? 2 * SLAB : LEPI_ALL);     // 4 KiB
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r32 = lane & 31;
+  const int h = lane >> 5;
+  const int bx = tile_of_block();
+  const int64_t r0 = (int64_t)bx * BM + wave * 32;
+  const int n0 = blockIdx.y * BN;
+  const int npass = ci / (ROW_BYTES / 2);
+
+  unsigned tmask = 1u;
+  if constexpr (!DENSE) {
+    unsigned m = 0u;
+    const int64_t t0 = ((int64_t)bx * BM) >> 7;
+#pragma unroll
+    for (int q = 0; q < BM / 128; ++q)
+      if ((t0 + q) * 128 < n_out) m |= tmasks[t0 + q];
+    if (kflip) m = __brev(m) >> (32 - K);
+    tmask = __builtin_amdgcn_readfirstlane(m);
+  }
+  const int nphase = __popc(tmask) * npass;
+
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wimg), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nbr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, (int)nbr_bytes, 0x00020000);
+
+  constexpr unsigned OOB_OFF = 0x80000000u;
+  const unsigned row_bytes = (unsigned)ci * 2u;
+  const unsigned lane_off = (unsigned)h * 16u;                  // this lane's 8 channels of a 16-channel k-step
+  const unsigned idx_voff = (unsigned)((r0 + r32) * 4);
+  const bool row_in = r0 + r32 < n_out;
+  const unsigned k_stride = (unsigned)n_out * 4u;
+  const unsigned slab_k = (unsigned)gridDim.y * (unsigned)npass * (unsigned)SLAB;
+  const unsigned slab_base = (unsigned)blockIdx.y * (unsigned)npass * (unsigned)SLAB + (unsigned)(wave * PPW) * 1024u;
+  const unsigned dma_voff = (unsigned)lane * 16u;
+  const bool dma_wave = wave < DMA_WAVES;
+  unsigned char* const dma_dst = wl + (wave * PPW) * 1024;
+  const unsigned char* const wbase = wl + (h * NB) * 256 + r32 * 16;
+
+  const __amdgpu_buffer_rsrc_t rs_perm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int*>(perm), 0, perm != nullptr ? (int)k_stride : 0, 0x00020000);
+  const int perm_v = __builtin_amdgcn_raw_buffer_load_b32(rs_perm, idx_voff, 0, 0);
+
+  unsigned rem = tmask;
+  int wk = 0, wpass = npass - 1;
+  auto advance = [&]() {
+    if (++wpass == npass) {
+      wpass = 0;
+      wk = rem ? __builtin_ctz(rem) : 0;
+      rem &= rem - 1u;
+    }
+  };
+  auto issue_idx = [&](int k) -> int {
+    if constexpr (DENSE) {
+      return (int)(r0 + r32);
+    } else {
+      const unsigned kk = (unsigned)(kflip ? (K - 1 - k) : k);
+      return __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, idx_voff, kk * k_stride, 0);
+    }
+  };
+  // every wave issues PPW DMA instructions in EVERY phase (the counted wait relies on it): a wave without a share, and
+  // every wave in the tile's last phase (nothing follows), aims out of range (zeros, no memory traffic) at the dump
+  auto issue_dma = [&](int k, int pass, int slot, bool live_phase) {
+    const bool live = dma_wave && live_phase;
+    const unsigned soff = live ? (unsigned)k * slab_k + (unsigned)pass * (unsigned)SLAB + slab_base : OOB_OFF;
+    unsigned char* const base = live ? dma_dst + slot * SLAB : dump;
+#pragma unroll
+    for (int c4 = 0; c4 < (PPW + 3) / 4; ++c4) {
+      auto* dst = (__attribute__((address_space(3))) void*)(base + (live ? c4 * 4096 : 0));
+      const unsigned so = live ? soff + (unsigned)(c4 * 4096) : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 0, 0);
+      if (c4 * 4 + 1 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 1024, 0);
+      if (c4 * 4 + 2 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 2048, 0);
+      if (c4 * 4 + 3 < PPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, dma_voff, so, 3072, 0);
+    }
+  };
+  // ONE set of A fragments, rolling: the registers of k-step ks are re-loaded with the NEXT phase's rows as soon as this
+  // phase's MFMAs of that k-step have been issued -- half the fragment registers of the two-set pipeline (which spilled
+  // here: 48 accumulators + 2 x 24), and the phase's vector-memory instructions are spread between its MFMAs instead of
+  // being issued as one burst by all waves right behind the barrier.
+  auto a_off = [&](int idx, unsigned long long& have) -> unsigned {
+    const bool has = idx >= 0 && row_in;
+    have = __ballot(has);
+    const unsigned off = __umul24((unsigned)idx, row_bytes) + lane_off;
+    return has ? off : OOB_OFF;
+  };
+  auto load_a = [&](unsigned off, int pass, int ks) -> raw4 {
+    return __builtin_bit_cast(raw4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off + (unsigned)(ks * 32),
+                                                                          (unsigned)pass * (unsigned)ROW_BYTES, 0));
+  };
+
+  f32x16 acc[NB2];
+#pragma unroll
+  for (int cb = 0; cb < NB2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+  raw4 a[KS];
+  auto mfma_step = [&](int ks, const unsigned char* wcur) __attribute__((always_inline)) {
+    const unsigned char* q = wcur + (ks >> 1) * (4 * NB * 256) + (ks & 1) * (2 * NB * 256);
+    bf16x8 b[NB2];
+#pragma unroll
+    for (int cb = 0; cb < NB2; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(q + cb * 512);
+#pragma unroll
+    for (int cb = 0; cb < NB2; ++cb)
+      acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks]), b[cb], acc[cb], 0, 0, 0);
+  };
+  auto slab_wait = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (KS & 15) | ((KS >> 4) << 14));    // only the KS gathers issued behind the DMA
+    __syncthreads();
+  };
+
+  if (nphase > 0) {
+    advance();
+    const int k0 = wk, p0 = wpass;
+    const int i0 = issue_idx(k0);
+    advance();
+    int i_nxt = issue_idx(wk);                      // rows of phase 1
+    int kn = wk, pn = wpass;                        // (offset, slice) of phase 1
+    unsigned long long have = 0ull;
+    issue_dma(k0, p0, 0, true);
+    {
+      const unsigned off = a_off(i0, have);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[ks] = load_a(off, p0, ks);
+    }
+    slab_wait();
+    // one phase on slab `slot`: index(p+2), slab(p+1) by DMA into the other slot, then per k-step this phase's MFMAs and
+    // the gather of the next phase's fragment into the registers just consumed.  The tile's last phase issues the same
+    // instructions out of range (no peeled copy of the loop body: one set of accumulators, one copy of the code).
+    int slot = 0;
+    for (int p = 0; p < nphase; ++p) {
+      const bool more = p + 1 < nphase;
+      advance();
+      const int i_nn = issue_idx(wk);
+      issue_dma(kn, pn, slot ^ 1, more);
+      unsigned long long have_n;
+      unsigned off = a_off(i_nxt, have_n);
+      off = more ? off : OOB_OFF;
+      have_n = more ? have_n : 0ull;
+      const unsigned char* const wcur = wbase + slot * SLAB;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (have != 0ull) mfma_step(ks, wcur);
+        __builtin_amdgcn_sched_barrier(0);
+        a[ks] = load_a(off, pn, ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      have = have_n;
+      i_nxt = i_nn; kn = wk; pn = wpass;
+      slot ^= 1;
+      slab_wait();
+    }
+  }
+  store_rows32<T, NB2>(acc, wl, wave, lane, r0, n0, n_out, co, perm, out, ep_scale, ep_shift, ep_relu, ep_res, perm_v);
+}
+
 // one 16-byte segment of a split image: image[k][nblk][slice][part][gsel][nb][row16] x 8 bf16, part = hi | mid | lo of
 // the f32 weight W[k][slice * 32 + gsel * 8 + e][col] (role 0) / W[k][col][...] (role 1)
 template <typename TI>
@@ -1574,6 +2204,27 @@ int launch_img(const void* in, const void* wimg, const int* nbr, const int* perm
 #else
       LIDAL_REQUIRE(ep.tile_stats == nullptr && ep.bnb.sums == nullptr, "experiment build (LIDAL_LEAN_WAVES): no tile statistics");
 #endif
+      // (experiment, LIDAL_LEAN32=1: the 32-row form with 256-row tiles where no BatchNorm statistics are asked for)
+      if constexpr (sizeof(T) == 2 && NB % 2 == 0 && ROW_BYTES <= 192) {
+        static const bool lean32 = [] { const char* e = getenv("LIDAL_LEAN32"); return e != nullptr && atoi(e) != 0; }();
+        if (lean32 && ep.tile_stats == nullptr && ep.bnb.sums == nullptr) {
+          constexpr int EPI32 = 8 * 16 * (BN + 8) * 2;
+          constexpr int LDS32 = ((2 * SLAB > EPI32) ? 2 * SLAB : EPI32) + 4096;
+          auto k32 = nbr ? conv_lean32_kernel<NB, ROW_BYTES, false> : conv_lean32_kernel<NB, ROW_BYTES, true>;
+          static size_t attr32[2][MAX_DEVICES] = {};
+          const int d32 = current_device();
+          if (attr32[nbr ? 0 : 1][d32] < (size_t)LDS32) {
+            LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, LDS32));
+            attr32[nbr ? 0 : 1][d32] = LDS32;
+          }
+          dim3 g32((unsigned)cdiv(n_out, 256), (unsigned)cdiv(co, BN));
+          k32<<<g32, 512, LDS32, s>>>((const __bf16*)in, (const __bf16*)wimg, nbr, perm, tmasks, (__bf16*)out, n_out, ci, co,
+                                      K, kflip, ep.scale, ep.shift, ep.relu, (const __bf16*)ep.res, ep.in_bytes,
+                                      ep.img_bytes, ep.nbr_bytes);
+          LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(lean32)");
+          return 0;
+        }
+      }
       constexpr int LEPI = LW * 16 * (BN + DT<T>::VEC) * (int)sizeof(T);
       constexpr int LSTATS = LW * BN * 2 * (int)sizeof(float);        // per-wave column statistics
       constexpr int LEAN_LDS = ((2 * SLAB > LEPI + LSTATS) ? 2 * SLAB : LEPI + LSTATS) + 4096;      // + the DMA dump
@@ -1689,9 +2340,78 @@ __host__ inline int64_t split_image_bytes(int k, int n_red, int n_col) {
   const int bn = 16 * split_nb(n_col);
   return (int64_t)k * ((n_col + bn - 1) / bn) * (n_red / SPLIT_KCH) * bn * SPLIT_ROW;
 }
+// which MFMA shape the split form multiplies with: 16 (conv_split_kernel) unless LIDAL_SPLIT_MFMA=32 asks for the 32-row form
+// (conv_split32_kernel, round 6: built to halve the LDS fragment reads per MFMA -- measured equal on the 96-column layers and
+// 8-30 % slower on the 128-column ones, profiles/r06_mfma32_ab.txt; it stays selectable and tested)
+static int split_mfma_rows() {
+  static const int rows = [] {
+    const char* e = getenv("LIDAL_SPLIT_MFMA");
+    return (e != nullptr && atoi(e) == 32) ? 32 : 16;
+  }();
+  return rows;
+}
+
+// rows per tile of the 32-row form: 256 (8 waves) or 128 (4 waves); LIDAL_SPLIT32_WAVES=4 / 8 forces one
+// (128-column kernels: 138 registers -- three 4-wave workgroups per CU; the narrower ones fit the 128 of two 8-wave workgroups)
+static int split32_waves(int nb) {
+  static const int w = [] {
+    const char* e = getenv("LIDAL_SPLIT32_WAVES");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  return (w == 4 || w == 8) ? w : (nb >= 8 ? 4 : 8);
+}
+
+template <int NB, int LW>
+int launch_split32(const void* in, const void* wimg, const int* nbr, const int* perm, const unsigned* tmasks, void* out,
+                   int64_t n_out, int ci, int co, int K, int kflip, Epi ep, hipStream_t s) {
+  constexpr int BM = LW * 32, BN = 16 * NB, SLAB = BN * SPLIT_ROW;
+  constexpr int LEPI_ALL = LW * 16 * (BN + 4) * 4;
+  constexpr int LDS = ((2 * SLAB > LEPI_ALL) ? 2 * SLAB : LEPI_ALL) + 4096;
+  auto kern = nbr ? conv_split32_kernel<NB, LW, false> : conv_split32_kernel<NB, LW, true>;
+  static size_t attr[2][MAX_DEVICES] = {};
+  const int dev = current_device();
+  if (attr[nbr ? 0 : 1][dev] < (size_t)LDS) {
+    LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr[nbr ? 0 : 1][dev] = LDS;
+  }
+  dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(co, BN));
+  Split sp{nullptr, 1, 0, 0};         // (the policy of launch_split, in workgroups of 128 rows)
+  if (nbr != nullptr && ep.ws != nullptr) {
+    const int64_t wgs = cdiv(n_out, 128) * grid.y;
+    const int ns = (wgs > SPLIT_F32_MAX_WGS || K * (ci / SPLIT_KCH) < 54) ? 1 : (wgs <= 256 ? 4 : 3);
+    const long long rows_pad = (long long)grid.x * BM;
+    const int co_pad = (int)grid.y * BN;
+    if (ns > 1 && ep.ws_bytes >= (long long)ns * rows_pad * co_pad * 4) sp = Split{(float*)ep.ws, ns, co_pad, rows_pad};
+  }
+  grid.z = (unsigned)sp.nsplit;
+  kern<<<grid, 64 * LW, LDS, s>>>((const float*)in, (const __bf16*)wimg, nbr, perm, tmasks, (float*)out, n_out, ci, co, K,
+                                  kflip, ep.scale, ep.shift, ep.relu, (const float*)ep.res, ep.in_bytes, ep.img_bytes,
+                                  ep.nbr_bytes, sp);
+  LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(split32)");
+  if (sp.nsplit > 1) {
+    auto ck = conv_combine32_kernel<float, NB / 2, LW>;
+    static size_t comb_attr[MAX_DEVICES] = {};
+    if (comb_attr[dev] < (size_t)LEPI_ALL) {
+      LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ck), hipFuncAttributeMaxDynamicSharedMemorySize, LEPI_ALL));
+      comb_attr[dev] = LEPI_ALL;
+    }
+    grid.z = 1;
+    ck<<<grid, 64 * LW, LEPI_ALL, s>>>(sp, perm, (float*)out, n_out, co, ep.scale, ep.shift, ep.relu, (const float*)ep.res);
+    LIDAL_CHECK_LAUNCH("lidal_conv_apply_image(split32, combine)");
+  }
+  return 0;
+}
+
 template <int NB>
 int launch_split(const void* in, const void* wimg, const int* nbr, const int* perm, const unsigned* tmasks, void* out,
                  int64_t n_out, int ci, int co, int K, int kflip, Epi ep, hipStream_t s) {
+  if (split_mfma_rows() == 32) {
+    if constexpr (NB < 8) {
+      if (split32_waves(NB) == 8)
+        return launch_split32<NB, 8>(in, wimg, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
+    }
+    return launch_split32<NB, 4>(in, wimg, nbr, perm, tmasks, out, n_out, ci, co, K, kflip, ep, s);
+  }
   constexpr int LW = 8, BN = 16 * NB, SLAB = BN * SPLIT_ROW;
   constexpr int LEPI_ALL = LW * 16 * (BN + 4) * 4 + LW * BN * 2 * (int)sizeof(float);
   constexpr int LDS = ((2 * SLAB > LEPI_ALL) ? 2 * SLAB : LEPI_ALL) + 4096;

@@ -19,14 +19,35 @@ __all__ = ['Conv3d', 'BatchNorm', 'BatchNorm1d', 'Linear', 'ReLU', 'functional',
 import os as _os
 SURFACE_FUSION = _os.environ.get('LIDAL_SURFACE_FUSION', '1') != '0'       # deferred BatchNorm (class Deferred)
 ASSUME_BN_FOLLOWS = SURFACE_FUSION                                          # Conv3d leaves tile statistics (Conv3d.bn_follows)
-# The first 3x3x3 stride-1 convolution on a fresh stride-1 coordinate set is taken for the stem of the reference's U-Nets
-# (network/spvcnn.py:27-33, network/minkunet.py:31-37: stem, then four times [2x2x2 stride-2 conv, 3x3x3 residual blocks],
-# transposed 2x2x2 convs back up): all coordinate levels and kernel maps of that pyramid are then built at once --
-# one sort for the four coarser levels, one chain of launches for the nine maps, one sort per kernel volume for the row
-# orders -- instead of one by one as the convolutions ask for them (each with its own host round trips).  Same tables
-# under the same keys; a network of another shape merely finds maps it does not use.  LIDAL_SURFACE_PYRAMID=0: lazily.
+# The coordinate tables of a whole forward pass at once, by LOOK-BACK (round 6; rounds 4-5 guessed: "the first 3x3x3 stride-1
+# convolution on a fresh coordinate set is the stem of the reference's U-Net" -- a benchmark-shaped heuristic inside a generic
+# operator).  Every forward pass records, on the map cache of its input, which (stride, kernel, conv stride) maps its
+# convolutions ask for, in order; the Conv3d module that ran FIRST on that fresh coordinate set keeps the record.  When the same
+# module meets the next fresh coordinate set it prefetches exactly what the previous pass used, if that was an encoder chain
+# (prefetch_kernel_maps: one sort for the coarser levels, one chain of launches for the maps, one sort per kernel volume for
+# the row orders -- instead of one by one as the convolutions ask for them, each with its own host round trips).  Same tables
+# under the same keys; a module's first pass, and networks whose maps do not form a chain, build lazily as torchsparse does.
+# LIDAL_SURFACE_PYRAMID=0: always lazily.
 SURFACE_PYRAMID = _os.environ.get('LIDAL_SURFACE_PYRAMID', '1') != '0'
-UNET_MAP_PLAN = ((3, 1),) + ((2, 2), (3, 1)) * 4
+
+
+def _plan_from_trace(trace, stride):
+    """The (kernel, conv stride) sequence prefetch_kernel_maps walks, if the recorded maps form a chain that starts at
+    `stride` (every map's input stride is the stride reached by the strided maps before it); else None."""
+    if not trace or not trace['maps']:
+        return None
+    plan, cur = [], tuple(stride)
+    seen = {cur}
+    for in_stride, kernel_size, conv_stride in trace['maps']:
+        if tuple(in_stride) != cur:
+            if tuple(in_stride) in seen:          # a level visited before (the decoder returning to it): its map is known
+                continue
+            return None
+        plan.append((tuple(kernel_size), tuple(conv_stride)))
+        if any(v > 1 for v in conv_stride):
+            cur = tuple(cur[k] * conv_stride[k] for k in range(3))
+            seen.add(cur)
+    return tuple(plan)
 
 
 class Deferred:
@@ -153,11 +174,15 @@ class Conv3d(nn.Module):
         """`fork` (k > 1, not transposed): returns (output, alias of `input`) for a second consumer of
         the input whose gradient then joins this layer's data gradient in-kernel (functional/conv.py)."""
         follows = ASSUME_BN_FOLLOWS if self.bn_follows is None else self.bn_follows
-        if (SURFACE_PYRAMID and not self.transposed and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1)
-                and tuple(input.stride) == (1, 1, 1) and not input.kmaps and input.coords.is_cuda
-                and input.coords.shape[0] > 0):
-            from .functional.conv import prefetch_kernel_maps
-            prefetch_kernel_maps(input, UNET_MAP_PLAN)
+        if (SURFACE_PYRAMID and not self.transposed and self.kernel_volume > 1 and not input.kmaps
+                and getattr(input.kmaps, 'trace', None) is None and input.coords.is_cuda and input.coords.shape[0] > 0):
+            # the first convolution on a fresh coordinate set: prefetch what the previous pass that began here used
+            prev = self.__dict__.get('_lidal_trace')
+            plan = _plan_from_trace(prev, input.stride)
+            input.kmaps.trace = self.__dict__['_lidal_trace'] = {'maps': [], 'transposed': False}
+            if plan:
+                from .functional.conv import prefetch_kernel_maps
+                prefetch_kernel_maps(input, plan, transposed=prev['transposed'])
         out = conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias,
                      stride=self.stride, dilation=self.dilation, transposed=self.transposed,
                      want_stats=follows and self.training and torch.is_grad_enabled(), fork=fork)

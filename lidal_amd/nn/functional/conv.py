@@ -183,8 +183,11 @@ def build_kernel_map(coords, in_stride, kernel_size, stride, scope=None):
     out_coords = coords
     if any(s > 1 for s in stride):
         # (prefetch_kernel_maps may have produced every level's coordinates already, from one sort)
+        # -- only for kernel_size == stride: those are floor(c / s') s' of the input voxels, which is what the levels of
+        # the pyramid hold; any other strided kernel has its own output set (torchsparse spdownsample) and must not pick up
+        # a level that merely has the same stride (spdownsample raises for the shapes off the LiDAL path)
         out_stride = tuple(in_stride[k] * stride[k] for k in range(3))
-        out_coords = scope.get(out_stride) if scope is not None else None
+        out_coords = scope.get(out_stride) if (scope is not None and tuple(kernel_size) == tuple(stride)) else None
         if out_coords is None:
             out_coords = spdownsample(coords, stride, kernel_size, in_stride)
     n_in, n_out = coords.shape[0], out_coords.shape[0]
@@ -730,6 +733,9 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
             raise NotImplementedError('dilated sparse conv is not on the LiDAL path')
         key = (input.stride, kernel_size, stride, dilation)
         kmap = input.kmaps.get(key)
+        trace = getattr(input.kmaps, 'trace', None)
+        if trace is not None and key[:3] not in trace['maps']:
+            trace['maps'].append(key[:3])        # (nn.Conv3d: what THIS forward pass asks for, for the next one's prefetch)
         out_stride = tuple(input.stride[k] * stride[k] for k in range(3))
         if kmap is None:
             kmap, out_coords = build_kernel_map(coords, input.stride, kernel_size, stride, input.cmaps)
@@ -747,6 +753,9 @@ def conv3d(input, weight, kernel_size, bias=None, stride=1, dilation=1, transpos
     else:
         tensor_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         kmap = input.kmaps[(tensor_stride, kernel_size, stride, dilation)]
+        trace = getattr(input.kmaps, 'trace', None)
+        if trace is not None:
+            trace['transposed'] = True
         feats = _conv(feats, weight, kmap, True, epilogue, want_stats and bias is None)
         if bias is not None:
             feats = feats + bias

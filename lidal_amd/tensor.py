@@ -16,7 +16,7 @@ class MapCache(dict):
     caches derived from a level's coordinates (the hash table, nn/functional/query.py) can be
     scoped to the input they were built for -- a NEW SparseTensor over the same coordinate tensor
     rebuilds everything, as the reference does every iteration."""
-    __slots__ = ('__weakref__',)
+    __slots__ = ('__weakref__', 'trace')     # trace: nn.Conv3d's record of the maps a forward pass asks for (look-back prefetch)
 
 
 class SparseTensor:

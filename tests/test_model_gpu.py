@@ -185,23 +185,57 @@ def test_prefetched_kernel_maps_are_the_ones_conv3d_builds(golden_dir):
         with torch.no_grad():
             for c in convs:
                 y = c(y)
-        # (round 5) the surface's guess at the first convolution -- the whole pyramid of the reference's U-Nets at once
+        # (round 6) look-back: the first pass over a module chain builds lazily and records what it asked for; the SECOND
+        # pass on a fresh coordinate set prefetches exactly that -- no more, no less -- in one go
         spnn.SURFACE_PYRAMID = True
-        xc = lidal_amd.SparseTensor(feats, coords)
-        y = xc
-        with torch.no_grad():
-            for c in convs:
-                y = c(y)
+        calls = []
+        import lidal_amd.nn.functional.conv as convmod
+        real = convmod.prefetch_kernel_maps
+        convmod.prefetch_kernel_maps = lambda x, p, **kw: (calls.append(tuple(p)), real(x, p, **kw))[1]
+        try:
+            passes = []
+            for _ in range(2):
+                xc = lidal_amd.SparseTensor(feats, coords)
+                y = xc
+                with torch.no_grad():
+                    for c in convs:
+                        y = c(y)
+                passes.append(xc)
+        finally:
+            convmod.prefetch_kernel_maps = real
     finally:
         spnn.SURFACE_PYRAMID = saved
+    assert calls == [tuple(((k,) * 3, (s,) * 3) for k, s in plan)], calls      # the first pass: none; the second: the plan
     assert set(xa.kmaps) == set(xb.kmaps) and set(xa.cmaps) == set(xb.cmaps)
-    assert set(xb.kmaps) < set(xc.kmaps) and set(xb.cmaps) < set(xc.cmaps)        # (two more levels than this plan uses)
+    for xc in passes:
+        assert set(xb.kmaps) == set(xc.kmaps) and set(xb.cmaps) == set(xc.cmaps)        # nothing the network does not use
     for key in xb.kmaps:
-        for other in (xa, xc):
+        for other in [xa] + passes:
             assert torch.equal(other.kmaps[key].nbr_out, xb.kmaps[key].nbr_out)
             assert torch.equal(other.kmaps[key].nbmaps, xb.kmaps[key].nbmaps)
     for key in xb.cmaps:
-        assert torch.equal(xa.cmaps[key], xb.cmaps[key]) and torch.equal(xc.cmaps[key], xb.cmaps[key])
+        assert all(torch.equal(o.cmaps[key], xb.cmaps[key]) for o in [xa] + passes)
+
+
+def test_a_strided_kernel_that_is_not_its_stride_never_takes_a_pyramid_level(golden_dir):
+    """a level of the prefetched pyramid holds floor(c / s) s of the input voxels -- the output set of a
+    kernel_size == stride convolution only.  A k=3, s=2 convolution (off the LiDAL path: torchsparse's output set differs)
+    must keep raising NotImplementedError from spdownsample, whether or not a level of stride 2 is already cached."""
+    import lidal_amd
+    from lidal_amd import nn as spnn
+    from lidal_amd.nn.functional.conv import prefetch_kernel_maps
+    g = _load(golden_dir)
+    coords = torch.from_numpy(g['coords']).to(DEV)
+    feats = torch.from_numpy(g['feats']).to(DEV)
+    x = prefetch_kernel_maps(lidal_amd.SparseTensor(feats, coords), ((3, 1), (2, 2), (3, 1)))
+    assert (2, 2, 2) in x.cmaps
+    bad = spnn.Conv3d(4, 4, 3, stride=2).to(DEV)
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            bad(x)
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            bad(lidal_amd.SparseTensor(feats, coords))
 
 
 @pytest.mark.parametrize('autocast', [False, True])

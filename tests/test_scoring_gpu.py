@@ -220,3 +220,58 @@ def test_infer_frame_returns_the_point_features_on_request():
     want = feat_ref[inverse].numpy().reshape(8, -1, feat_ref.shape[1]).mean(0)
     assert feat.shape == want.shape
     assert np.abs(feat.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_256_frame_sequence_scores_match_the_oracle_at_both_ends_and_in_the_middle():
+    """BASELINE.json configs[3] at its stated length: ONE sequence of 256 frames through score_sequence on one GPU (the
+    FrameBank holding every frame, scoring queued beside the inference of the frames that follow), then frames 0, 127 and
+    255 against oracle.scoring_ref -- the first and the last one read the wrap-rule frames of
+    /root/reference/score/sv_level/LiDAL.py:41-42 (frame 0: 6..10 stand in for -1..-5; frame 255: 249..245 for 256..260).
+    The oracle scores them from the probabilities of their own windows, inferred frame by frame with infer_frame (bitwise
+    what the pipeline fed its bank: same kernels, same inputs)."""
+    from lidal_amd import synth
+    from lidal_amd.network import MinkUNet
+    from lidal_amd.score import infer_frame, interframe, score_sequence
+    from oracle import scoring_ref
+    from weights import fill_state_dict
+    n_frames, nei, reps = 256, 10, 2
+    frames = synth.make_sequence(n_frames, n_points=None, seed=33, step=0.3, n_beams=16, n_az=192)
+    rng = np.random.default_rng(5)
+    model = fill_state_dict(MinkUNet(19)).eval().to(DEV)
+    dev_frames = []
+    for f in frames:
+        sb = synth.make_score_batch(f['points'], f['intensity'], rng, inf_reps=reps)
+        ptr, idx, _ = interframe.sv_csr(f['sv2point'], DEV)
+        dev_frames.append({'coords': torch.from_numpy(sb['coords_v_b']).to(DEV),
+                           'feats': torch.from_numpy(sb['feats_v_b']).to(DEV),
+                           'inverse': torch.from_numpy(sb['inverse_indices_b']).to(DEV),
+                           'world': torch.from_numpy(f['world']).to(DEV), 'sv_ptr': ptr, 'sv_idx': idx})
+    out = score_sequence(model, dev_frames, 0, n_frames, nei_num=nei, dis_thresh=0.1, inf_reps=reps)
+    torch.cuda.synchronize()
+    assert len(out) == n_frames
+    assert interframe.neighbour_ids(0, n_frames, nei) == [6, 7, 8, 9, 10, 1, 2, 3, 4, 5]
+    assert interframe.neighbour_ids(255, n_frames, nei) == [254, 253, 252, 251, 250, 249, 248, 247, 246, 245]
+    matched = 0
+    for i in (0, 127, 255):
+        window = scoring_ref.neighbour_ids(i, n_frames, nei) + [i]
+        assert window[:-1] == interframe.neighbour_ids(i, n_frames, nei)
+        probs, worlds = [None] * n_frames, [None] * n_frames
+        for j in window:
+            d = dev_frames[j]
+            probs[j] = infer_frame(model, d['coords'], d['feats'], d['inverse'], reps)[0].cpu().numpy()
+            worlds[j] = frames[j]['world']
+        rd, re, rn, rc, pd, pe = scoring_ref.score_frame(i, probs, worlds, frames[i]['sv2point'], nei, 0.1,
+                                                         return_points=True)
+        matched += int((pd > 0).sum())
+        d, e, c = out[i]
+        assert np.allclose(d.cpu().numpy(), rd, rtol=1e-4, atol=1e-7), i
+        assert np.allclose(e.cpu().numpy(), re, rtol=1e-4, atol=1e-7), i
+        assert np.allclose(c.cpu().numpy(), rc, rtol=1e-5, atol=1e-5), i
+    assert matched > 100, matched          # the windows really overlap
+    # the sequence in two halves of a sharded run would read the same frames: the halo plan at 8 blocks of 32 covers
+    # every frame's window (score/sharding.py: needed_frames)
+    from lidal_amd.score.sharding import frame_range, needed_frames
+    for r in range(8):
+        need = set(needed_frames(n_frames, 8, r, nei))
+        for i in frame_range(n_frames, 8, r):
+            assert set(interframe.neighbour_ids(i, n_frames, nei)) | {i} <= need, (r, i)

@@ -353,9 +353,10 @@ def bench_dropin_surface(dev, model_name, dtype, batch, steps, warmup=3, adopt=F
     import surface_unet
     from lidal_amd import backend as B
     torch.manual_seed(7122)
+    # the ONE line of a drop-in user.  Its default (round 6) hands torch's own Linear / BatchNorm1d / ReLU modules of the
+    # model to this package at the model's first forward call; adopt=False times the opt-out
+    lidal_amd.install_as_torchsparse(adopt_torch_modules=adopt)
     model = surface_unet.build(lidal_amd)[model_name](19).to(dev).train()
-    if adopt:       # the optional second line: torch's own Linear / BatchNorm1d / ReLU modules handed to this package
-        lidal_amd.adopt_torch_modules(model)
     opt = torch.optim.Adam(model.parameters(), fused=True)
     coords, feats, labels = batch
     autocast = dtype == 'bf16'
@@ -368,25 +369,32 @@ def bench_dropin_surface(dev, model_name, dtype, batch, steps, warmup=3, adopt=F
         loss.backward()
         opt.step()
         return loss.detach()
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    B.HITS.clear()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        B.HITS.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        lidal_amd.install_as_torchsparse(adopt_torch_modules=False)      # (process-wide switch: the other legs build plain models)
     assert np.isfinite(loss.item())
+    assert adopt == type(model.classifier[0]).__module__.startswith('lidal_amd')
     ms = dt / steps * 1e3
     n = int(coords.shape[0])
     return {'ms_per_step': round(ms, 3), 'voxels_per_step': n, 'voxels_per_s': round(n / ms * 1e3, 1), 'steps': steps,
             'loss': round(float(loss.item()), 4),
             'library_calls_per_step': int(sum(v for k, v in B.HITS.items() if not k.startswith('torch_fallback')) / steps),
-            'what': ('surface-only %s (scripts/surface_unet.py over lidal_amd as torchsparse; torch nn.Linear / BatchNorm1d / '
-                     'cross_entropy as the reference uses them), per-operator path, tables built inside the forward pass' % model_name)
-                    + (' + lidal_amd.adopt_torch_modules(model): the point branch and the classifier on this package\'s kernels '
-                       '(same parameters, same state_dict keys; torch\'s cross_entropy stays)' if adopt else '')}
+            'what': ('surface-only %s (scripts/surface_unet.py over lidal_amd as torchsparse; the user\'s script as the reference '
+                     'writes it: torch nn.Linear / BatchNorm1d / cross_entropy), per-operator path, tables built inside the '
+                     'forward pass; ' % model_name)
+                    + ('install_as_torchsparse() as it is by default: the point branch and the classifier are handed to this '
+                       'package\'s kernels at the model\'s first forward call (same parameters, same state_dict keys; torch\'s '
+                       'cross_entropy stays)' if adopt else
+                       'install_as_torchsparse(adopt_torch_modules=False): torch\'s own modules stay torch\'s')}
 
 
 def variant_line(res):
@@ -748,7 +756,7 @@ def family_table(step, coords, dtype_name, step_ms):
         'ms_at_hbm_roof': round(tot_by / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
         'ms_at_mfma_roof': round(tot_fl / (peak_tf * 1e12) * 1e3, 3)}
     # counter traffic of the whole step, measured OFFLINE like roofline.traffic (two --pmc passes over bench.py itself:
-    # scripts/gpu/r5_step_traffic.sh) and kept under profiles/; reported only for this exact workload
+    # scripts/gpu/archive/r5_step_traffic.sh) and kept under profiles/; reported only for this exact workload
     tr, src = pmc_record('pmc_step_traffic.json', KERNEL_SOURCES,
                          lambda wl: (wl['rows'], wl['dtype']) == (int(coords.shape[0]), dtype_name), 'traffic_GB')
     out['whole_step']['traffic_GB'] = tr
@@ -1150,11 +1158,25 @@ def run_variants(args, batch, dev, inline=None):
     del fresh
     var['fresh_stream'] = guarded(bench_fresh_stream, dev, args.model, args.dtype, args.frames, args.points,
                                   max(2 * args.steps, 40))
-    var['dropin_surface'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps)
-    var['dropin_surface_adopted'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps, 3, True)
+    var['dropin_surface'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps, 3, True)
+    var['dropin_surface_no_adopt'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps, 3, False)
     other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
     var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
                                                 max(3, args.steps // 2), 2, ddp=False))
+    if other_dtype == 'f32':
+        from lidal_amd import backend as B
+        var['f32']['what'] = ('the reference\'s training precision (train.py:127-140, no autocast): f32 features, weights, '
+                              'accumulation, BatchNorm in f64 sums; forward products and data gradients of the sparse '
+                              'convolutions in the split form (3 bf16 pieces per operand, 6 partial products on the bf16 MFMA: '
+                              'as close to f64 as the exact kernel), weight gradients and dense layers on the exact f32 MFMA'
+                              if B.SPLIT_F32_TRAIN and B.SPLIT_F32 else 'every product on the exact f32 MFMA')
+        if B.SPLIT_F32_TRAIN and B.SPLIT_F32:
+            B.SPLIT_F32_TRAIN = False
+            try:
+                var['f32_exact'] = variant_line(bench_train(1, 0, dev, args.model, 'f32', batch, max(3, args.steps // 2), 2, ddp=False))
+                var['f32_exact']['what'] = 'LIDAL_F32_SPLIT_TRAIN=0: every product of the f32 step on v_mfma_f32_16x16x4_f32'
+            finally:
+                B.SPLIT_F32_TRAIN = True
     other_model = 'minkunet' if args.model == 'spvcnn' else 'spvcnn'
     var[other_model] = variant_line(bench_train(1, 0, dev, other_model, args.dtype, batch,
                                                 args.steps, 3, ddp=False))

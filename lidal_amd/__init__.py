@@ -17,10 +17,18 @@ __all__ = ['SparseTensor', 'PointTensor', 'cat', 'install_as_torchsparse', 'adop
 __version__ = '0.1.0'
 
 
-def install_as_torchsparse():
+def install_as_torchsparse(adopt_torch_modules=None):
     """Alias this package as `torchsparse` (+ .nn, .nn.functional, .nn.utils) in sys.modules so
     the reference's network/spvcnn.py, network/minkunet.py, network/utils.py, train.py and
-    score/prob_inference.py import it unchanged."""
+    score/prob_inference.py import it unchanged.
+
+    adopt_torch_modules (default: on; False or LIDAL_AUTO_ADOPT=0 opts out): a model built afterwards from this
+    package's Conv3d modules has its plain-torch row-wise modules (exact-type nn.Linear / nn.BatchNorm1d, and
+    nn.Sequential(Linear, BatchNorm1d, ReLU) groups -- SPVCNN's point branch and classifier, network/spvcnn.py:60-98)
+    handed to this package at its FIRST forward call, exactly as the explicit `adopt_torch_modules(model)` does: same
+    Parameter objects, same buffers, same state_dict keys, nothing in the user's script changes (round 6; the drop-in
+    step 24.6 -> 18.8 ms at 5 scans)."""
+    import os
     from . import nn
     from .nn import functional, utils
     me = sys.modules[__name__]
@@ -28,7 +36,50 @@ def install_as_torchsparse():
     sys.modules['torchsparse.nn'] = nn
     sys.modules['torchsparse.nn.functional'] = functional
     sys.modules['torchsparse.nn.utils'] = utils
+    if adopt_torch_modules is None:
+        adopt_torch_modules = os.environ.get('LIDAL_AUTO_ADOPT', '1') != '0'
+    _AUTO['on'] = bool(adopt_torch_modules)
+    if not _AUTO['on']:
+        _AUTO['pending'].clear()
+        _disarm()
     return me
+
+
+# ---- adoption at the first forward call (install_as_torchsparse) ----------------------------------------------------
+# Every nn.Conv3d constructed while the switch is on is noted as pending and arms ONE global forward pre-hook; the first
+# module called whose tree holds pending convolutions -- the user's model: a root's pre-hook runs before its children's --
+# is adopted and the hook removed again (a global hook puts every nn.Module call on torch's slow path, so it must not
+# outlive its one job).  Building another model later arms it again.
+import weakref as _weakref
+
+_AUTO = {'on': False, 'pending': _weakref.WeakSet(), 'handle': None}
+
+
+def _note_conv3d(module):
+    if _AUTO['on']:
+        _AUTO['pending'].add(module)
+        if _AUTO['handle'] is None:
+            import torch
+            _AUTO['handle'] = torch.nn.modules.module.register_module_forward_pre_hook(_adopt_hook)
+
+
+def _disarm():
+    if _AUTO['handle'] is not None:
+        _AUTO['handle'].remove()
+        _AUTO['handle'] = None
+
+
+def _adopt_hook(module, args):
+    pending = _AUTO['pending']
+    if len(pending):
+        mine = [m for m in module.modules() if m in pending]
+        if mine:
+            adopt_torch_modules(module)
+            for m in mine:
+                pending.discard(m)
+    if not len(pending):
+        _disarm()
+    return None
 
 
 def adopt_torch_modules(model):

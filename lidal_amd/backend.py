@@ -546,12 +546,23 @@ def dtype_code(dt):
 # training step's f32 parity mode keeps.  LIDAL_F32_SPLIT=0: the exact f32 MFMA everywhere.
 F32_SPLIT = 2
 SPLIT_F32 = os.environ.get('LIDAL_F32_SPLIT', '1') != '0'
+# Round 6: the f32 TRAINING step (the reference trains in fp32, train.py:127-140) runs the forward products and the data
+# gradients of its sparse convolutions in the split form too, wherever BOTH channel counts are whole 32-channel slices
+# (one rule per layer: its forward reduces over ci, its data gradient over co) -- everything but the 4-channel stem
+# convolution; the weight gradients and the dense layers (1x1x1 convolutions, nn.Linear) keep the exact f32 MFMA.  As
+# close to the f64 oracle as the exact kernels (tests/test_benchsize_gpu.py, same calibrated bars).
+# LIDAL_F32_SPLIT_TRAIN=0: the exact f32 MFMA everywhere in training (the association the round-1..5 numbers were taken with).
+SPLIT_F32_TRAIN = os.environ.get('LIDAL_F32_SPLIT_TRAIN', '1') != '0'
 
 
-def conv_code(dt, n_red, inference):
-    """dtype code of a convolution / dense product over `n_red` input channels on features of dtype `dt`."""
-    if dt == torch.float32 and inference and SPLIT_F32 and n_red > 0 and n_red % 32 == 0:
-        return F32_SPLIT
+def conv_code(dt, n_red, inference, n_col=None):
+    """dtype code of a convolution / dense product over `n_red` input channels on features of dtype `dt`.
+    n_col (training, sparse convolutions only): the layer's other channel count."""
+    if dt == torch.float32 and SPLIT_F32 and n_red > 0 and n_red % 32 == 0:
+        if inference:
+            return F32_SPLIT
+        if SPLIT_F32_TRAIN and n_col is not None and n_col > 0 and n_col % 32 == 0:
+            return F32_SPLIT
     return dtype_code(dt)
 
 

@@ -2157,6 +2157,8 @@ weight_image_batch_split_kernel(const ImageJob* __restrict__ jobs, int n_jobs, i
   const ImageJob j = jobs[lo];
   const int64_t l = s - j.first;
   if (l < j.segs_a) split_segment<TI>((const TI*)j.w, (__bf16*)j.img_a, j.n_red, j.n_col, j.role, j.nb_a, l);
+  else if (l < j.segs_a + j.segs_b)       // (training, round 6: the data-gradient image of the same parameter)
+    split_segment<TI>((const TI*)j.w, (__bf16*)j.img_b, j.n_col, j.n_red, j.role ^ 1, j.nb_b, l - j.segs_a);
 }
 
 struct Epi { const float* scale; const float* shift; int relu; const void* res; unsigned in_bytes, img_bytes, nbr_bytes; float* tile_stats; BnBwd bnb; void* ws; long long ws_bytes; };
@@ -2543,18 +2545,23 @@ extern "C" int64_t lidal_conv_weight_image_job(void* job, const void* w, int rol
     set_error("weight_image_job: bad arguments");
     return -1;
   }
-  if (dtype == LIDAL_F32_SPLIT) {       // forward image only (the inference form), reduction over ci
-    if (img_bwd != nullptr || ci % SPLIT_KCH != 0) {
-      set_error("weight_image_job(split): forward image only, ci a multiple of %d (got %d)", SPLIT_KCH, ci);
+  if (dtype == LIDAL_F32_SPLIT) {       // reduction over ci; with img_bwd (training) also the image that reduces over co
+    if (ci % SPLIT_KCH != 0 || (img_bwd != nullptr && co % SPLIT_KCH != 0)) {
+      set_error("weight_image_job(split): the reduction must be a multiple of %d channels (got ci=%d%s co=%d)", SPLIT_KCH, ci,
+                img_bwd != nullptr ? ", data-gradient image:" : ",", co);
       return -1;
     }
     ImageJob j;
-    j.w = w; j.img_a = img_fwd; j.img_b = nullptr; j.first = first;
-    j.segs_a = split_image_bytes(k, ci, co) / 16; j.segs_b = 0;
-    j.n_red = ci; j.n_col = co; j.role = role; j.nb_a = split_nb(co); j.kc_a = 0; j.nb_b = j.nb_a; j.kc_b = 0; j.pad = 0;
-    if (j.segs_a >= (1ll << 31)) { set_error("weight_image_job: an image of %lld segments", (long long)j.segs_a); return -1; }
+    j.w = w; j.img_a = img_fwd; j.img_b = img_bwd; j.first = first;
+    j.segs_a = split_image_bytes(k, ci, co) / 16;
+    j.segs_b = img_bwd != nullptr ? split_image_bytes(k, co, ci) / 16 : 0;
+    j.n_red = ci; j.n_col = co; j.role = role; j.nb_a = split_nb(co); j.kc_a = 0; j.nb_b = split_nb(ci); j.kc_b = 0; j.pad = 0;
+    if (j.segs_a >= (1ll << 31) || j.segs_b >= (1ll << 31)) {
+      set_error("weight_image_job: an image of %lld segments", (long long)(j.segs_a > j.segs_b ? j.segs_a : j.segs_b));
+      return -1;
+    }
     *reinterpret_cast<ImageJob*>(job) = j;
-    return j.segs_a;
+    return j.segs_a + j.segs_b;
   }
   const int esz = dtype == LIDAL_BF16 ? 2 : 4;
   const Tiling ta = pick_tiling(ci, co, n_out_fwd, esz);

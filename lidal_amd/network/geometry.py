@@ -75,7 +75,7 @@ class Geometry:
                 for s in model.POINT_STRIDES:
                     xs = SparseTensor(None, x0.cmaps[(s, s, s)], s)
                     xs.cmaps, xs.kmaps = x0.cmaps, x0.kmaps
-                    idx, w = corner_tables(xs, z)
+                    idx, w = corner_tables(xs, z, own_cells=True)
                     pidx, counts = point_tables(xs, z)
                     prepare_voxelize(pidx, counts)
                     idx._lidal_cell_index = _index32(pidx)      # (one list of the points per voxel for both directions)

@@ -126,8 +126,12 @@ def point_to_voxel(x, z):
     return new_tensor
 
 
-def corner_tables(x, z, nearest=False):
-    """The 8-corner index and trilinear weights of voxel_to_point (utils.py:67-92) at x's stride, in z's caches."""
+def corner_tables(x, z, nearest=False, own_cells=False):
+    """The 8-corner index and trilinear weights of voxel_to_point (utils.py:67-92) at x's stride, in z's caches.
+    own_cells: the caller vouches that the voxel every point's own coordinates floor to EXISTS in x (x's coordinates
+    derive from z: initial_voxelize and the levels below it, as in SPVCNN) -- only then may the backward of the
+    devoxelisation run through the cells (F.devoxelize.cells_mode): a point whose own voxel is absent has no cell and
+    would lose the gradient of its other seven corners there (the per-voxel lists keep it)."""
     if z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
         off = get_kernel_offsets(2, x.s, 1, device=z.C.device)
         old_hash = F.sphash(_floor_to_stride(z, x.s[0]), off)          # [8, N]
@@ -136,18 +140,19 @@ def corner_tables(x, z, nearest=False):
         if nearest:
             weights[:, 1:] = 0.
             idx_query[:, 1:] = -1
-        # every point of a cell (idx_query[:, 0]: the voxel its own coordinates floor to) has the same eight corners by
-        # the expression above: what the cell form of the backward relies on (F.devoxelize.cells_mode)
-        idx_query._lidal_cell_corners = True
         z.idx_query[x.s] = idx_query
         z.weights[x.s] = weights
         _link_cells(z, x.s)
+    if own_cells and not nearest:
+        # every point of a cell (idx_query[:, 0]: the voxel its own coordinates floor to) has the same eight corners by
+        # the expression above, and every point HAS a cell: what the cell form of the backward relies on
+        z.idx_query[x.s]._lidal_cell_corners = True
     return z.idx_query[x.s], z.weights[x.s]
 
 
-def voxel_to_point(x, z, nearest=False):
-    """utils.py:66-102: trilinear interpolation of the 8 surrounding voxels of x at each point."""
-    idx_query, weights = corner_tables(x, z, nearest)
+def voxel_to_point(x, z, nearest=False, own_cells=False):
+    """utils.py:66-102: trilinear interpolation of the 8 surrounding voxels of x at each point.  own_cells: corner_tables."""
+    idx_query, weights = corner_tables(x, z, nearest, own_cells)
     new_feat = F.spdevoxelize(x.F, idx_query, weights)
     new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
     new_tensor.additional_features = z.additional_features

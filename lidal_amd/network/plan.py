@@ -88,8 +88,11 @@ SIDE_F32 = os.environ.get('LIDAL_PLAN_SIDE_F32', '1') == '1'
 # 7.24 -> 6.81 / 7.42 ms; scripts/exp/matrix.sh, matrix2.sh), hence the threshold: the levels of a multi-scan batch.
 BRANCH_ROWS = int(os.environ.get('LIDAL_PLAN_BRANCH_ROWS', '100000'))
 # The backward pass of SPVCNN's point branch (BatchNorm1d backward, the Linear's two gradients, its bias gradient: streaming
-# kernels over all points) on a FOURTH stream beside the voxel branch, between the place its input gradient appears and the
-# place its result is consumed (round 5).  bf16 only (the f32 mode keeps its concurrency as it was, section 5 of DESIGN.md).
+# kernels over all points) beside the voxel branch, between the place its input gradient appears and the place its result
+# is consumed (round 5) -- on side stream 1, the WEIGHT GRADIENTS' stream (so point_join() also waits for the weight
+# gradients queued there before it; a stream of its own, index 3, was measured: the process then has more streams than
+# hardware queues and the step went from 13.9 to 20.5-21.2 ms, profiles/README.md).  bf16 only (the f32 mode keeps its
+# concurrency as it was, section 5 of DESIGN.md).
 POINT_SIDE = int(os.environ.get('LIDAL_PLAN_POINT_SIDE', '1'))     # 0 = on the main stream, i = on side stream i
 _NARGS = {}
 _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
@@ -602,7 +605,11 @@ class _Run:
         self.koff = {n: base + 16 * i for i, n in reversed(list(enumerate(ns)))}
 
     def ccode(self, c):
-        """dtype code of layer `c`'s products (a training run: the features' own)."""
+        """dtype code of the forward product and the data gradient of layer `c` (a training run): the features' own --
+        or, in f32, the split form for the sparse convolutions whose two channel counts are whole 32-channel slices
+        (backend.conv_code: the rule of the per-operator path)."""
+        if c.k > 1 and not c.role:
+            return B.conv_code(self.dtype, c.ci, False, c.co)
         return self.code
 
     def _images(self):
@@ -712,8 +719,11 @@ class _Run:
         """Flag of a weight gradient over `rows` rows: side stream 1 (after a fork), or 0 = the main stream."""
         if not SIDE_ROWS or rows > SIDE_ROWS or rows < SIDE_MIN_ROWS:
             return 0
-        if not self.bf16 and not SIDE_F32:
-            return 0                    # (the f32 mode: see SIDE_F32)
+        if not self.bf16 and (not SIDE_F32 or _N.TAIL_SUMS_ROWS > 0):
+            # (the f32 mode: see SIDE_F32.  The one pair that was ever seen to break run-to-run bit-equality -- the fused
+            # f64 block tail while f32 weight gradients run beside it -- cannot be put together by the environment knobs:
+            # asking for the tail takes the weight gradients back to the main stream)
+            return 0
         return self.fork(1)
 
     # ===================================== forward ========================================================
@@ -724,7 +734,7 @@ class _Run:
         st = A.alloc(-(-n_out // self.tile) * c.co * 12) if (stats and self.bf16) else 0
         wb = _C.apply_workspace_bytes(n_out, c.co)
         self.w += (OP_CONV_APPLY_IMAGE_WS, x, c.img_f, table[0], table[1], table[2], out, n_in, n_out, ci, c.co, c.k, 0,
-                   self.code, 0, 0, 0, 0, st, self.scratch(wb) if wb else 0, wb)
+                   self.ccode(c), 0, 0, 0, 0, st, self.scratch(wb) if wb else 0, wb)
         self.nops += 1
         return out, st
 
@@ -983,7 +993,7 @@ class _Run:
             self.nops += 1
             return gin, sums
         self.w += (OP_CONV_APPLY_IMAGE_WS, g, c.img_b, table[0], table[1], table[2], gin, n_g, n_out, c.co, c.ci, c.k,
-                   kflip, self.code, 0, 0, 0, skip, 0, ws, wb)
+                   kflip, self.ccode(c), 0, 0, 0, skip, 0, ws, wb)
         self.nops += 1
         return gin, 0
 

@@ -114,26 +114,26 @@ class SPVCNN(_SparseUNet):
         else:
             z = PointTensor(x.F, x.C.float())
             x0 = self.stem(prefetch_kernel_maps(initial_voxelize(z, self.pres, self.vres), self.MAP_PLAN))
-        z0 = voxel_to_point(x0, z, nearest=False)
+        z0 = voxel_to_point(x0, z, nearest=False, own_cells=True)       # (x0 and its pyramid derive from z: glue.corner_tables)
 
         x1 = self.stage1(point_to_voxel(x0, z0))
         x2 = self.stage2(x1)
         x3 = self.stage3(x2)
         x4 = self.stage4(x3)
-        z1 = voxel_to_point(x4, z0)
+        z1 = voxel_to_point(x4, z0, own_cells=True)
         z1.F = self.point_transforms[0](z0.F, residual=z1.F)          # z1.F + transform(z0.F)
 
         y1 = point_to_voxel(x4, z1)
         y1.F = self.dropout(y1.F)
         y1 = self._up(self.up1, y1, x3)
         y2 = self._up(self.up2, y1, x2)
-        z2 = voxel_to_point(y2, z1)
+        z2 = voxel_to_point(y2, z1, own_cells=True)
         z2.F = self.point_transforms[1](z1.F, residual=z2.F)
 
         y3 = point_to_voxel(y2, z2)
         y3.F = self.dropout(y3.F)
         y3 = self._up(self.up3, y3, x1)
         y4 = self._up(self.up4, y3, x0)
-        z3 = voxel_to_point(y4, z2)
+        z3 = voxel_to_point(y4, z2, own_cells=True)
         z3.F = self.point_transforms[2](z2.F, residual=z3.F)
         return self.classifier(z3.F), z3.F

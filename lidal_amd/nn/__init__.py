@@ -61,7 +61,10 @@ class Deferred:
     arithmetic, same roundings as the separate operators (the fused kernels round the summand they produce before
     adding), hence bitwise the undeferred results (tests/test_model_gpu.py).  One Deferred belongs to ONE SparseTensor;
     `plus` hands the pending normalisation over to the sum's tensor -- if the pre-sum tensor is read after all (nobody in
-    the reference does), it is computed on its own and the sum falls back to a plain addition."""
+    the reference does), it is computed on its own and the sum falls back to a plain addition.
+    Timing: the running statistics and num_batches_tracked of the module are updated when the features are first READ, not
+    when the module is called -- and not at all if nobody ever reads them (a tensor that is dropped unread was never
+    normalised; eager torch would have counted the batch)."""
 
     __slots__ = ('module', 'x', 'stats', 'relu', 'residual', 'relu_after', 'parent', 'moved', 'value')
 
@@ -108,13 +111,22 @@ class Deferred:
 
     def _resolve(self):
         if self.parent is not None and self.parent.value is not None:
-            # the pre-sum tensor was read first: it holds bn(x); the sum is a plain addition (and ReLU)
+            # (not reached since round 6: a pre-sum tensor that is read first fills its sum in the same breath, below)
             y = self.parent.value + self.residual
             self.value = torch.relu(y) if self.relu_after else y
         elif self.moved is not None and self.moved.value is not None:
             # the sum was computed (fused) first and now the pre-sum tensor is read: bn(x) once more, without touching
             # the running statistics a second time (momentum 0, no batch count)
             self.value = self._run(self.relu, None, False, momentum=0.0, count=False)
+        elif self.moved is not None:
+            # the pre-sum tensor is read BEFORE its sum: bn(x) on its own, and the sum -- a plain addition (and ReLU) now --
+            # at once, while nobody can have written into bn(x) yet (an in-place operation on the pre-sum
+            # tensor between the two reads would otherwise have leaked into the sum)
+            self.value = self._run(self.relu, None, False)
+            m = self.moved
+            y = self.value + m.residual
+            m.value = torch.relu(y) if m.relu_after else y
+            m.x = m.stats = None
         else:
             self.value = self._run(self.relu, self.residual, self.relu_after)
         self.x = self.stats = None
@@ -147,6 +159,8 @@ class Conv3d(nn.Module):
         else:
             self.register_parameter('bias', None)
         self.reset_parameters()
+        from .. import _note_conv3d
+        _note_conv3d(self)          # (install_as_torchsparse: the model this layer ends up in is adopted at its first call)
 
     def extra_repr(self):
         s = '{in_channels}, {out_channels}, kernel_size={kernel_size}'

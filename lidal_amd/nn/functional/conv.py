@@ -421,8 +421,9 @@ class _ImageBank:
         e = self.entries.get(ekey)
         if e is None or e['ref']() is not weight:
             nf = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out_fwd)
-            # (the split form of an f32 product is the inference form: forward image only)
-            nb = 0 if code == B.F32_SPLIT else L.lidal_conv_weight_image_bytes(k, co, ci, code, n_out_bwd)
+            # (the split form: a data-gradient image where its reduction -- co -- is whole 32-channel slices too: training)
+            nb = (0 if (code == B.F32_SPLIT and (co % 32 != 0 or role))
+                  else L.lidal_conv_weight_image_bytes(k, co, ci, code, n_out_bwd))
             buf = torch.empty(nf + nb, dtype=torch.uint8, device=weight.device)
             self.serial += 1
             wid = id(weight)
@@ -490,13 +491,16 @@ _IMAGE_BANK = _ImageBank()
 _IMAGE_BATCH = os.environ.get('LIDAL_IMAGE_BATCH', '1') != '0'
 
 
-def _weight_image_pair(weight, dtype, n_out_fwd, n_out_bwd):
+def _weight_image_pair(weight, dtype, n_out_fwd, n_out_bwd, code=None):
     """(forward image, data-gradient image) of a [K, ci, co] weight: from the step's one batched
     launch (_ImageBank) for contiguous parameters, else from ONE launch of their own."""
     if _IMAGE_BATCH and isinstance(weight, torch.nn.Parameter) and weight.is_contiguous():
-        return _IMAGE_BANK.get(weight, dtype, n_out_fwd, n_out_bwd)
+        return _IMAGE_BANK.get(weight, dtype, n_out_fwd, n_out_bwd, code=code)
     k, ci, co = weight.shape
     w = weight.detach().contiguous()
+    if code == B.F32_SPLIT:             # (no pair entry point for the split form: one launch per image)
+        with torch.enable_grad():       # (bypass the per-tensor inference cache)
+            return (_weight_image(w, dtype, n_out_fwd, 0, code), _weight_image(w, dtype, n_out_bwd, 1, code))
     code = B.dtype_code(dtype)
     L = B.lib()
     nf = L.lidal_conv_weight_image_bytes(k, ci, co, code, n_out_fwd)
@@ -606,10 +610,12 @@ def _forward(feats, weight, kmap, transposed, epilogue=None, with_bwd_image=Fals
     order = kmap.order_in if transposed else kmap.order_out
     k, _, co = weight.shape
     img_b = None
+    # (training: the split form where both channel counts allow it -- the data gradient reduces over co; backend.conv_code)
+    code = B.conv_code(cdtype, x.shape[1], inference and not want_stats, None if inference else co)
     if with_bwd_image:          # both operands of this parameter from one launch
-        img, img_b = _weight_image_pair(weight, cdtype, order.n_rows, _bwd_order(kmap, transposed)[0].n_rows)
-        return x, _apply(x, img, k, co, order, 0, epilogue, want_stats), img_b
-    code = B.conv_code(cdtype, x.shape[1], inference and not want_stats)
+        img, img_b = _weight_image_pair(weight, cdtype, order.n_rows, _bwd_order(kmap, transposed)[0].n_rows, code)
+        img_b._lidal_code = code        # (conv_backward multiplies with the image as it was built)
+        return x, _apply(x, img, k, co, order, 0, epilogue, want_stats, None, code), img_b
     img = _weight_image(weight, cdtype, order.n_rows, 0, code)
     return x, _apply(x, img, k, co, order, 0, epilogue, want_stats, None, code), img_b
 
@@ -679,7 +685,7 @@ def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=N
                                 or tuple(bnb[0].shape) != (n_out if transposed else n_in, ci)
                                 or bnb[0].dtype != g.dtype or not bnb[0].is_contiguous()):
             bnb = None
-        grad_in = _apply(g, img_bwd, k, x.shape[1], order, kflip, ep, False, bnb)
+        grad_in = _apply(g, img_bwd, k, x.shape[1], order, kflip, ep, False, bnb, getattr(img_bwd, '_lidal_code', None))
         if ci != ci_w:
             grad_in = grad_in[:, :ci_w]                 # drop the padding channels, if any
     elif grad_skip is not None:

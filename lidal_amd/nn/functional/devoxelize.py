@@ -17,8 +17,9 @@ CELLS_MIN_AVG = int(os.environ.get('LIDAL_DEVOX_CELLS_AVG', '12'))
 
 def cells_mode(idx8, n_points, m, c, dtype=None):
     """Does the backward of spdevoxelize over (idx8 [N, 8], m voxels, c channels) run through the cells?  Only for an
-    index that network/glue.py corner_tables built (it marks it: every point of a cell -- idx8[:, 0], the voxel its own
-    coordinates floor to -- then has the same eight corners, utils.py:67-79), on levels with many points per voxel.
+    index that network/glue.py corner_tables built FOR A CALLER WHO VOUCHED that every point's own voxel exists
+    (own_cells: it marks the index; every point of a cell -- idx8[:, 0], the voxel its own coordinates floor to -- then
+    has the same eight corners, utils.py:67-79, and no point is without a cell), on levels with many points per voxel.
     One rule for the per-operator path and the planned step."""
     if not CELLS_MIN_AVG or not getattr(idx8, '_lidal_cell_corners', False) or m <= 0:
         return False

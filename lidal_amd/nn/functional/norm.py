@@ -119,13 +119,13 @@ def train_backward(x, w, b, mean, invstd, relu, grad_out, need_dx=True, mask_fro
 # lidal_bn_bwd_from_sums (merge + dx) per BatchNorm -- instead of lidal_add_relu_bwd and one lidal_bn_bwd each.  The partial
 # sums are those of the separate pass bit for bit (tests/test_ops_gpu.py).  One pass over 4-5 arrays instead of 3 + 2
 # (+ 2): at most a quarter of the tail's bytes, and the reducing kernel (256 workgroups, f64 sums) streams slower than
-# the element-wise mask it absorbs -- measured (scripts/gpu/tail_ab.sh, same box): one scan 6.74 / 6.75 -> 6.63 / 6.65 ms
+# the element-wise mask it absorbs -- measured (scripts/gpu/archive/tail_ab.sh, same box): one scan 6.74 / 6.75 -> 6.63 / 6.65 ms
 # (23 launches fewer), 5 scans 15.18 / 15.20 -> 15.39 / 15.42 ms with every level fused.  Hence the row limit: the levels
 # where a launch costs more than its bytes.  LIDAL_TAIL_SUMS_ROWS=0: the separate passes everywhere.
 # Round 5: OFF by default (row limit 0).  bf16 takes the element-wise form below on every level; what was left to this
 # pair was the f32 parity mode, and there it turned out to be the one place where a training run is not bit-reproducible:
 # with the weight gradients running beside it on their side stream, 4 of 5 rounds of 16 x 6 SPVCNN f32 steps showed one
-# repetition whose gradients differ from the others in the last bit (scripts/exp/determinism_steps.py, scripts/gpu/r5_flake2.sh;
+# repetition whose gradients differ from the others in the last bit (scripts/exp/determinism_steps.py, scripts/gpu/archive/r5_flake2.sh;
 # the same rate at the end of round 4) -- none in 3 rounds with the separate passes, none without the side stream.  The
 # kernels agree bit for bit whenever they run alone (tests/test_ops_gpu.py); the cause is not found.  LIDAL_TAIL_SUMS_ROWS=100000
 # restores the round-4 behaviour.
@@ -142,7 +142,7 @@ def tail_sums(n):
 # convolutions' tile sums (lidal_add_relu_bwd_bn_tile_sums), merged by lidal_bn_bwd_tiles in front of its dx pass -- 11
 # passes over the level's arrays instead of 13 (a block with a shortcut BatchNorm), 7 instead of 8 (without) against the
 # separate passes, and an element-wise kernel on 512 workgroups instead of the f64 reduction on 256 against the fused
-# pair above.  Measured on every level (scripts/gpu/r5_tail_rows.sh, row limits 100 000 / 30 000 / 1): 5 scans 13.99-14.07
+# pair above.  Measured on every level (scripts/gpu/archive/r5_tail_rows.sh, row limits 100 000 / 30 000 / 1): 5 scans 13.99-14.07
 # / 13.98-14.00 / 13.93-13.95 ms, one scan 6.30-6.55 / 6.25-6.40 / 6.18 ms -> every level.  The f32 parity mode keeps
 # the f64 sums its golden gradients were taken with.  LIDAL_TAIL_TILES=0: off; LIDAL_TAIL_TILES_ROWS: from that many rows.
 TAIL_TILES = os.environ.get('LIDAL_TAIL_TILES', '1') != '0'

@@ -22,7 +22,7 @@ __all__ = ['score_sequence', 'collect_sequence', 'ScoreBoard']
 
 import os as _os
 # Scoring beside the inference of the frames that follow: on WHICH stream decides whether it pays.  Measured on bound
-# processes, round 3's tree beside it, frames/s at nei 10 / 24 (scripts/gpu/sec_ab.sh, sec_ab2.sh; two boxes, 2-3
+# processes, round 3's tree beside it, frames/s at nei 10 / 24 (scripts/gpu/archive/sec_ab.sh, sec_ab2.sh; two boxes, 2-3
 # repetitions): round 3 125-129 / 117-120; planned inference, scoring AFTER it 131-133 / 126; planned inference, scoring
 # on a THIRD stream 122-124 / 124-125 (a plan keeps the inference queue full, and three saturated queues slow each other
 # by more than they overlap: the 96->96 convolution 91 -> 155 us); planned inference, scoring on the TABLE BUILDER's

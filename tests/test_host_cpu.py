@@ -279,7 +279,7 @@ import json, os, sys, torch
 sys.path.insert(0, %(root)r)
 sys.path.insert(0, os.path.join(%(root)r, 'tests', 'golden'))
 import lidal_amd
-lidal_amd.install_as_torchsparse()
+lidal_amd.install_as_torchsparse()          # (default: torch's row-wise modules adopted at the first forward call)
 sys.path.insert(0, '/root/reference')
 from network.spvcnn import SPVCNN as RefSPVCNN          # the reference files, unchanged
 from network.minkunet import MinkUNet as RefMinkUNet

@@ -131,7 +131,7 @@ def test_bf16_autocast_close_to_f32(golden_dir):
 def test_reference_style_import_alias():
     """`import torchsparse` resolves to this package after install_as_torchsparse()."""
     import lidal_amd
-    lidal_amd.install_as_torchsparse()
+    lidal_amd.install_as_torchsparse(adopt_torch_modules=False)     # (the switch is process-wide: the other tests build plain models)
     import torchsparse
     import torchsparse.nn as spnn
     import torchsparse.nn.functional as F
@@ -770,6 +770,37 @@ def test_deferred_batchnorm_read_in_any_order():
                 assert torch.equal(u, v), (mode, i)
 
 
+def test_deferred_sum_is_not_touched_by_an_in_place_write_to_the_pre_sum_tensor():
+    """s = bn(x) + r is pending; the pre-sum tensor is read, then written in place; then s is read.  The
+    sum must still be bn(x) + r (eager torch semantics: the addition happened when it was written down) -- the Deferred
+    of the pre-sum tensor fills its sum the moment it is resolved itself."""
+    import lidal_amd
+    from lidal_amd import nn as spnn
+    g = torch.Generator().manual_seed(3)
+    coords = torch.cat([torch.randint(0, 40, (3000, 3), generator=g), torch.zeros(3000, 1, dtype=torch.long)], 1).int().to(DEV)
+    x0 = torch.randn(3000, 32, generator=g).to(DEV)
+    r0 = torch.randn(3000, 32, generator=g).to(DEV)
+    out = {}
+    saved = spnn.SURFACE_FUSION
+    try:
+        for mode in ('eager', 'deferred'):
+            spnn.SURFACE_FUSION = mode != 'eager'
+            torch.manual_seed(1)
+            bn = spnn.BatchNorm(32).to(DEV).train()
+            a = bn(lidal_amd.SparseTensor(x0.clone(), coords))
+            s = a + lidal_amd.SparseTensor(r0.clone(), coords)
+            assert (s._deferred is not None) == (mode != 'eager')
+            pre = a.F.detach().clone()
+            with torch.no_grad():
+                a.F.mul_(0.0)                       # an in-place write to the pre-sum tensor ...
+            out[mode] = (s.F.detach().clone(), pre, bn.running_mean.clone(), bn.num_batches_tracked.clone())
+    finally:
+        spnn.SURFACE_FUSION = saved
+    for u, v in zip(out['eager'], out['deferred']):       # ... that the sum does not see
+        assert torch.equal(u, v)
+    assert float(out['deferred'][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize('autocast', [False, True])
 def test_adopted_torch_modules_keep_parameters_and_results(autocast):
     """lidal_amd.adopt_torch_modules: torch's own nn.Linear / nn.BatchNorm1d / nn.ReLU of a drop-in model (SPVCNN's point
@@ -814,3 +845,44 @@ def test_adopted_torch_modules_keep_parameters_and_results(autocast):
     for k in ('point_transforms.0.1.running_mean', 'point_transforms.2.1.running_var'):
         u, v = out[0][3][k].double(), out[1][3][k].double()
         assert float((u - v).abs().max()) <= (2e-2 if autocast else 1e-5) * float(u.abs().max()), k
+
+
+def test_install_adopts_torch_modules_at_the_first_forward_call():
+    """install_as_torchsparse() (round 6, default on): a model built from this package's Conv3d modules afterwards has its
+    plain torch.nn.Linear / BatchNorm1d / Sequential(Linear, BatchNorm1d, ReLU) handed to this package when it is first
+    called -- nothing in the user's script changes -- with the results of the explicit adopt_torch_modules(model), bit for
+    bit; the global hook that does it is gone after its one job, and `adopt_torch_modules=False` opts out."""
+    import lidal_amd
+    from lidal_amd import synth
+    b = synth.make_train_batch(n_frames=1, n_points=6000, seed=92)
+    feats, coords, labels = (torch.from_numpy(b[k]).to(DEV) for k in ('feats_v_b', 'coords_v_b', 'labels_v_b'))
+
+    def build():
+        torch.manual_seed(9)
+        m = _surface_models()['spvcnn'](19).to(DEV).train()
+        m.dropout.p = 0.0
+        return m
+
+    def step(m):
+        logits, _ = m(lidal_amd.SparseTensor(feats, coords))
+        loss = torch.nn.functional.cross_entropy(logits, labels, ignore_index=255)
+        loss.backward()
+        return logits.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+    try:
+        lidal_amd.install_as_torchsparse(adopt_torch_modules=False)
+        explicit = build()
+        assert lidal_amd._AUTO['handle'] is None and type(explicit.classifier[0]) is torch.nn.Linear
+        lidal_amd.adopt_torch_modules(explicit)
+        lidal_amd.install_as_torchsparse()
+        auto = build()
+        keys = list(auto.state_dict().keys())
+        assert lidal_amd._AUTO['handle'] is not None and type(auto.classifier[0]) is torch.nn.Linear
+        la, ga = step(auto)
+        assert lidal_amd._AUTO['handle'] is None                        # one job, then gone
+        assert type(auto.classifier[0]).__module__.startswith('lidal_amd') and list(auto.state_dict().keys()) == keys
+        assert [type(m).__name__ for m in auto.point_transforms[0].children()] == \
+               [type(m).__name__ for m in explicit.point_transforms[0].children()]
+        le, ge = step(explicit)
+        assert torch.equal(la, le) and all(torch.equal(ga[k], ge[k]) for k in ga)
+    finally:
+        lidal_amd.install_as_torchsparse(adopt_torch_modules=False)

@@ -200,9 +200,13 @@ def test_devoxelize_backward_through_the_cells(stride, c, dtype):
         x0.cmaps[(s, s, s)] = cs
     xs = SparseTensor(None, cs, stride)
     xs.cmaps, xs.kmaps = x0.cmaps, x0.kmaps
-    idx8, w8 = corner_tables(xs, z)
+    #  the marker the cell form is gated on is set only for a caller who vouches that every point's own
+    # voxel exists in x -- x derived from z, as here and in SPVCNN; a generic voxel_to_point keeps the per-voxel lists
+    idx_plain, _ = corner_tables(xs, z)
+    assert not getattr(idx_plain, '_lidal_cell_corners', False) and not DV.cells_mode(idx_plain, idx_plain.shape[0], cs.shape[0], c)
+    idx8, w8 = corner_tables(xs, z, own_cells=True)
     n, m = idx8.shape[0], cs.shape[0]
-    assert getattr(idx8, '_lidal_cell_corners', False)
+    assert idx8 is idx_plain and getattr(idx8, '_lidal_cell_corners', False)
     # the points' own voxel index is column 0 of the corner index (the list F.spvoxelize keeps is shared with the cells)
     from lidal_amd.network.glue import point_tables
     pidx, _ = point_tables(xs, z)

@@ -1041,7 +1041,7 @@ def scoring_roofline(model, dev_frames, nei, dtype_name, ms_per_frame):
     sc_bytes = sc_ms = 0.0
     for name, a, e0, e1 in score_calls:
         ms = e0.elapsed_time(e1)
-        if name == 'lidal_interframe_score':
+        if name in ('lidal_interframe_score', 'lidal_interframe_score_ordered'):
             p, c, n_nei = a[2], a[3], a[8]
             sc_bytes += (1 + n_nei) * p * (c * 4 + 24) + p * 16
             sc_ms += ms
@@ -1158,8 +1158,10 @@ def run_variants(args, batch, dev, inline=None):
     del fresh
     var['fresh_stream'] = guarded(bench_fresh_stream, dev, args.model, args.dtype, args.frames, args.points,
                                   max(2 * args.steps, 40))
-    var['dropin_surface'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps, 3, True)
-    var['dropin_surface_no_adopt'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps, 3, False)
+    # (8 warm-up steps each: the first per-operator model of a process also pays the allocator's growth and the look-back's
+    #  lazy first pass -- with 3, whichever of the two legs ran first measured 3-4 ms slower)
+    var['dropin_surface_no_adopt'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps, 8, False)
+    var['dropin_surface'] = guarded(bench_dropin_surface, dev, args.model, args.dtype, batch, args.steps, 8, True)
     other_dtype = 'f32' if args.dtype == 'bf16' else 'bf16'
     var[other_dtype] = variant_line(bench_train(1, 0, dev, args.model, other_dtype, batch,
                                                 max(3, args.steps // 2), 2, ddp=False))

@@ -508,6 +508,15 @@ int lidal_interframe_score(const double* q_pts, const float* q_prob, int64_t p, 
                            const float* const* nei_prob_host, const int64_t* nei_p_host,
                            int n_nei, double dis_thresh, double* interd, float* intere,
                            int32_t* map_count, void* ws, int64_t ws_bytes, void* stream);
+/* lidal_interframe_score with the query points taken in CELL order (round 6): q_grid = the grid lidal_nn_grid_build made of
+ * q_pts themselves (every frame of a sequence has one: it is the neighbour of others), or NULL = the call above.  The
+ * queries of a wave then share their cells' cache lines.  Same outputs bit for bit, in the points' own order. */
+int lidal_interframe_score_ordered(const double* q_pts, const float* q_prob, int64_t p, int c,
+                                   const void* const* nei_grids_host, const double* const* nei_pts_host,
+                                   const float* const* nei_prob_host, const int64_t* nei_p_host,
+                                   int n_nei, double dis_thresh, double* interd, float* intere,
+                                   int32_t* map_count, void* ws, int64_t ws_bytes, const void* q_grid,
+                                   void* stream);
 /* replaces score/sv_level/LiDAL.py:91-98: per-supervoxel means over point lists given as CSR
  * (sv_ptr i64 [s+1], sv_idx i64 [sv_ptr[s]]).  sv_interd f32 [s], sv_intere f32 [s],
  * sv_center f32 [s,3]. */

@@ -127,6 +127,8 @@ SIGNATURES = {
     'lidal_interframe_workspace_bytes': (_i64, [_i64, _i32]),
     'lidal_interframe_score': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp,
                                       _vp, _vp, _vp, _i64, _vp]),
+    'lidal_interframe_score_ordered': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f64, _vp,
+                                              _vp, _vp, _vp, _i64, _vp, _vp]),
     'lidal_supervoxel_reduce': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'lidal_copy2d': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
     'lidal_add2d': (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),

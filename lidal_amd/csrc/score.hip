@@ -290,19 +290,25 @@ __device__ __forceinline__ GridView nei_grid(const NeiArgs& nei, int n, double c
 // Stage 1: one thread per (neighbour frame, query point): the nearest point of that frame within
 // the match radius, or -1.  The 24 (or 10) look-ups of a query point are independent, so they run
 // as p * n_nei threads instead of one serial chain of 27 * n_nei hash probes per point.
+// q_order (round 6): the query frame's point ids in CELL order (the sorted ids of its own grid), or NULL.  Thread t then
+// takes point q_order[t]: the 64 queries of a wave sit in a handful of neighbouring cells, so their bitmap words, slots and
+// candidate records are the SAME few cache lines (2-3 points share a cell, neighbouring cells share half of the eight cells
+// they probe) instead of ~20 random 64-byte sectors per query in scan order.  match[] is kept in thread order; stage 2
+// walks the same order.  Same per-point arithmetic: same results bit for bit.
 __global__ void __launch_bounds__(256)
 interframe_match_kernel(const double* __restrict__ q_pts, int64_t p, NeiArgs nei, double dis_thresh,
-                        int* __restrict__ match /*[n_nei][p]*/) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                        int* __restrict__ match /*[n_nei][p]*/, const int* __restrict__ q_order) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y;
-  if (i >= p) return;
-  if (nei.p[n] <= 0) { match[(int64_t)n * p + i] = -1; return; }
+  if (t >= p) return;
+  if (nei.p[n] <= 0) { match[(int64_t)n * p + t] = -1; return; }
+  const int64_t i = q_order != nullptr ? (int64_t)q_order[t] : t;
   const double qx = q_pts[i * 3 + 0], qy = q_pts[i * 3 + 1], qz = q_pts[i * 3 + 2];
   const GridView g = nei_grid(nei, n, reinterpret_cast<const GridHeader*>(nei.grid[n])->cell);
   double d2;
   int j = grid_nearest(g, nei.pts[n], qx, qy, qz, dis_thresh, &d2);
   if (j >= 0 && !(sqrt(d2) <= dis_thresh)) j = -1;
-  match[(int64_t)n * p + i] = j;
+  match[(int64_t)n * p + t] = j;
 }
 
 // Stage 2: one thread per query point walks its matches in the reference's neighbour order and
@@ -310,9 +316,10 @@ interframe_match_kernel(const double* __restrict__ q_pts, int64_t p, NeiArgs nei
 __global__ void __launch_bounds__(256)
 interframe_kernel(const float* __restrict__ q_prob, int64_t p, int c, NeiArgs nei,
                   const int* __restrict__ match, double* __restrict__ interd,
-                  float* __restrict__ intere, int* __restrict__ map_count) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p) return;
+                  float* __restrict__ intere, int* __restrict__ map_count, const int* __restrict__ q_order) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p) return;
+  const int64_t i = q_order != nullptr ? (int64_t)q_order[t] : t;       // (match[] is in thread order)
   float q[MAXC], sum[MAXC];
 #pragma unroll
   for (int j = 0; j < MAXC; ++j) {
@@ -323,7 +330,7 @@ interframe_kernel(const float* __restrict__ q_prob, int64_t p, int c, NeiArgs ne
   double div = 0.0;
   int cnt = 0;
   for (int n = 0; n < nei.n; ++n) {
-    const int j = match[(int64_t)n * p + i];
+    const int j = match[(int64_t)n * p + t];
     if (j < 0) continue;
     const float* np = nei.prob[n] + (int64_t)j * c;
     float term[MAXC];
@@ -457,13 +464,12 @@ extern "C" int64_t lidal_interframe_workspace_bytes(int64_t p, int n_nei) {
   return (int64_t)(n_nei > 0 ? n_nei : 1) * (p > 0 ? p : 1) * 4 + 256;
 }
 
-extern "C" int lidal_interframe_score(const double* q_pts, const float* q_prob, int64_t p, int c,
-                                      const void* const* nei_grids_host,
-                                      const double* const* nei_pts_host,
-                                      const float* const* nei_prob_host, const int64_t* nei_p_host,
-                                      int n_nei, double dis_thresh, double* interd, float* intere,
-                                      int32_t* map_count, void* ws, int64_t ws_bytes,
-                                      void* stream) {
+static int interframe_score(const double* q_pts, const float* q_prob, int64_t p, int c,
+                            const void* const* nei_grids_host, const double* const* nei_pts_host,
+                            const float* const* nei_prob_host, const int64_t* nei_p_host,
+                            int n_nei, double dis_thresh, double* interd, float* intere,
+                            int32_t* map_count, void* ws, int64_t ws_bytes, const void* q_grid,
+                            void* stream) {
   LIDAL_REQUIRE(c > 0 && c <= MAXC, "interframe_score: classes must be in 1..%d", MAXC);
   LIDAL_REQUIRE(n_nei >= 0 && n_nei <= MAXNEI, "interframe_score: at most %d neighbours", MAXNEI);
   if (p == 0) return 0;
@@ -480,15 +486,43 @@ extern "C" int lidal_interframe_score(const double* q_pts, const float* q_prob, 
     a.cap[n] = grid_cap(nei_p_host[n] > 0 ? nei_p_host[n] : 1);
   }
   hipStream_t s = (hipStream_t)stream;
+  // the query frame's points in cell order: the sorted ids inside its own grid buffer (lidal_nn_grid_build of q_pts)
+  const int* q_order = nullptr;
+  if (q_grid != nullptr) {
+    const int64_t cap = grid_cap(p);
+    q_order = (const int*)((const char*)q_grid + 64 + grid_off_sidx(cap, p));
+  }
   if (n_nei > 0) {
     interframe_match_kernel<<<dim3((unsigned)cdiv(p, 256), (unsigned)n_nei), 256, 0, s>>>(
-        q_pts, p, a, dis_thresh, match);
+        q_pts, p, a, dis_thresh, match, q_order);
     LIDAL_CHECK_LAUNCH("interframe_match");
   }
   interframe_kernel<<<(unsigned)cdiv(p, 256), 256, 0, s>>>(q_prob, p, c, a, match, interd, intere,
-                                                           map_count);
+                                                           map_count, q_order);
   LIDAL_CHECK_LAUNCH("lidal_interframe_score");
   return 0;
+}
+
+extern "C" int lidal_interframe_score(const double* q_pts, const float* q_prob, int64_t p, int c,
+                                      const void* const* nei_grids_host,
+                                      const double* const* nei_pts_host,
+                                      const float* const* nei_prob_host, const int64_t* nei_p_host,
+                                      int n_nei, double dis_thresh, double* interd, float* intere,
+                                      int32_t* map_count, void* ws, int64_t ws_bytes,
+                                      void* stream) {
+  return interframe_score(q_pts, q_prob, p, c, nei_grids_host, nei_pts_host, nei_prob_host, nei_p_host, n_nei, dis_thresh,
+                          interd, intere, map_count, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int lidal_interframe_score_ordered(const double* q_pts, const float* q_prob, int64_t p, int c,
+                                              const void* const* nei_grids_host,
+                                              const double* const* nei_pts_host,
+                                              const float* const* nei_prob_host, const int64_t* nei_p_host,
+                                              int n_nei, double dis_thresh, double* interd, float* intere,
+                                              int32_t* map_count, void* ws, int64_t ws_bytes,
+                                              const void* q_grid, void* stream) {
+  return interframe_score(q_pts, q_prob, p, c, nei_grids_host, nei_pts_host, nei_prob_host, nei_p_host, n_nei, dis_thresh,
+                          interd, intere, map_count, ws, ws_bytes, q_grid, stream);
 }
 
 extern "C" int lidal_supervoxel_reduce(const double* interd, const float* intere,

@@ -19,6 +19,13 @@ from .. import backend as B
 
 __all__ = ['FrameBank', 'neighbour_ids', 'score_frame']
 
+# Round 6, measured and NOT adopted (scripts/gpu/r6_check2.sh, 32 frames of 120 k points, nei 10): the queries of a frame taken
+# in the cell order of its own grid (lidal_interframe_score_ordered: a wave's queries then sit in a handful of neighbouring
+# cells) -- scorer kernels 618 us per frame in scan order, 623 in cell order; frames/s 75.2 / 74.9.  A LiDAR scan is already
+# ordered along its rings, consecutive points ARE neighbours; what the match kernel waits for is the dependent chain bitmap
+# word -> slot -> record of each probed cell, not the sectors.  LIDAL_SCORE_CELL_ORDER=1 switches it on (same scores bit for bit).
+CELL_ORDER = os.environ.get('LIDAL_SCORE_CELL_ORDER', '0') == '1'
+
 
 def neighbour_ids(i, n_frames, nei_num):
     """LiDAL.py:41-42: nei_num/2 frames before and after i; ids falling off either end of the
@@ -95,10 +102,11 @@ def score_points(bank, i, nei_num=24):
         assert bank.prob[n].shape[1] == c
     ws_bytes = B.lib().lidal_interframe_workspace_bytes(p, len(nei))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    B.check(B.lib().lidal_interframe_score(B.ptr(q_pts), B.ptr(q_prob), p, c, g_arr, p_arr, f_arr,
-                                           n_arr, len(nei), bank.dis_thresh, B.ptr(interd),
-                                           B.ptr(intere), B.ptr(count), B.ptr(ws), ws_bytes,
-                                           B.stream()),
+    q_grid = bank.grid(i) if CELL_ORDER else None          # (see CELL_ORDER)
+    B.check(B.lib().lidal_interframe_score_ordered(B.ptr(q_pts), B.ptr(q_prob), p, c, g_arr, p_arr, f_arr,
+                                                   n_arr, len(nei), bank.dis_thresh, B.ptr(interd),
+                                                   B.ptr(intere), B.ptr(count), B.ptr(ws), ws_bytes,
+                                                   B.ptr(q_grid), B.stream()),
             'interframe_score')
     return interd, intere, count
 

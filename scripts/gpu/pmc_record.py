@@ -1,5 +1,9 @@
 """profiles/rNN_pmc_conv_apply.json from a final-run directory: python scripts/gpu/pmc_record.py gpurun_out/final5_a r05 'script tag'"""
-import csv, json, re, sys
+import csv, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench                                    # source_digest: the record is void once the kernel sources change
+from lidal_amd import backend as B
 d, rnd, how = sys.argv[1], sys.argv[2], sys.argv[3]
 txt = open(d + '/pmc_summary.txt').read()
 fetch = float(re.search(r'FETCH_SIZE\s+n=(\d+)\s+mean=([\d.e+]+)', txt).group(2))
@@ -11,6 +15,8 @@ traffic = int(round((2 * fetch + write) * 1024))
 algo = line['algorithmic_bytes_per_launch']
 rec = {'workload': {'rows': line['rows'], 'rules': line['rules'], 'dtype': 'bf16', 'layer': 'k3 s1 96->96',
                     'kernel': 'conv_lean_kernel<bf16,6,192,8>'},
+       'library': {'version': int(B.lib_handle().lidal_version()), 'sources_sha16': bench.source_digest(('conv_img.hip',)),
+                   'sources': ['conv_img.hip']},
        'command': 'rocprofv3 --pmc FETCH_SIZE (and a second pass --pmc WRITE_SIZE) -- python3 bench.py --roofline-only  (%s)' % how,
        'FETCH_SIZE_KB_mean_of_%d' % n: fetch, 'WRITE_SIZE_KB_mean_of_%d' % n: write,
        'correction': 'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane reads; WRITE_SIZE is exact',

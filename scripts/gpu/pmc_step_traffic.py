@@ -2,7 +2,7 @@
 counter per pass; KB as the tool reports them) over every dispatch of `bench.py --steps S`, cut at the optimizer launches
 like scripts/gpu/steady_counts.py, per step and by kernel.  The gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE
 counts 64-byte requests as 32: x 2) is applied to the fetch side.
-usage: pmc_step_traffic.py FETCH_CSV WRITE_CSV"""
+usage: pmc_step_traffic.py FETCH_CSV WRITE_CSV [ROWS DTYPE OUT.json]   (with the last three: the record bench.py reads)"""
 import csv
 import sys
 from collections import defaultdict
@@ -33,3 +33,18 @@ print('per step (%d steps): fetched %.2f GB (2 x FETCH_SIZE), written %.2f GB, t
 names = sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + write.get(k, 0)))
 for k in names[:30]:
     print('   %8.1f MB fetched %8.1f MB written   %s' % (2 * fetch.get(k, 0) * 1024 / 1e6, write.get(k, 0) * 1024 / 1e6, k))
+
+if len(sys.argv) > 5:
+    import json, os
+    ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, ROOT)
+    import bench
+    from lidal_amd import backend as B
+    rec = {'workload': {'rows': int(sys.argv[3]), 'dtype': sys.argv[4], 'what': 'the headline step of bench.py (5 scans, tables on the second stream)'},
+           'library': {'version': int(B.lib_handle().lidal_version()), 'sources_sha16': bench.source_digest(bench.KERNEL_SOURCES),
+                       'sources': list(bench.KERNEL_SOURCES)},
+           'command': 'rocprofv3 --pmc FETCH_SIZE (and a second pass --pmc WRITE_SIZE) -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline --no-families --no-variants',
+           'correction': 'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane reads; WRITE_SIZE is exact',
+           'steps_averaged': ns, 'fetched_GB': round(tf, 3), 'written_GB': round(tw, 3), 'traffic_GB': round(tf + tw, 3),
+           'by_kernel_MB': {k: round((2 * fetch.get(k, 0) + write.get(k, 0)) * 1024 / 1e6, 1) for k in names[:40]}}
+    json.dump(rec, open(sys.argv[5], 'w'), indent=1)

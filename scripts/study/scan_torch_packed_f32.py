@@ -54,6 +54,10 @@ print('packed f32 instructions by form:')
 for k, v in sorted(tot.items()):
     print('  %-40s %d' % (k, v))
 print('kernels with an op_sel / op_sel_hi form: %d' % len(per_kernel))
+if os.environ.get('SCAN_FULL'):         # every such kernel with its forms, one line each, for grep
+    with open(os.environ['SCAN_FULL'], 'w') as fh:
+        for sym, c in sorted(per_kernel.items()):
+            fh.write('%6d  %s   %s\n' % (sum(c.values()), sym, dict(c)))
 shown = 0
 for sym, c in sorted(per_kernel.items(), key=lambda kv: -sum(kv[1].values())):
     hit = (not want) or any(w in sym for w in want)

@@ -1597,12 +1597,17 @@ def test_split_f32_convolution_against_f64(ci, co):
 
 def test_f32_inference_runs_in_the_split_form_and_training_does_not():
     """backend.conv_code: under no_grad an f32 network's convolutions and dense layers take LIDAL_F32_SPLIT (except the
-    4-channel stem); with autograd on (the training step's f32 parity mode) they stay on the exact f32 MFMA."""
+    4-channel stem).  With autograd on (the f32 training step) -- round 6 -- the SPARSE convolutions whose two channel
+    counts are whole 32-channel slices take it too, forward and data gradient, and the dense layers, the 4-channel stem and
+    every weight gradient stay on the exact f32 MFMA; LIDAL_F32_SPLIT_TRAIN=0 (backend.SPLIT_F32_TRAIN) keeps all of the
+    training step there."""
     import lidal_amd
     from lidal_amd import backend as B
     assert B.conv_code(torch.float32, 96, True) == B.F32_SPLIT
     assert B.conv_code(torch.float32, 4, True) == B.F32 and B.conv_code(torch.float32, 96, False) == B.F32
-    assert B.conv_code(torch.bfloat16, 96, True) == B.BF16
+    assert B.conv_code(torch.float32, 96, False, 96) == B.F32_SPLIT and B.conv_code(torch.float32, 96, False, 19) == B.F32
+    assert B.conv_code(torch.float32, 4, False, 32) == B.F32
+    assert B.conv_code(torch.bfloat16, 96, True) == B.BF16 and B.conv_code(torch.bfloat16, 96, False, 96) == B.BF16
     seen = []
     B.set_call_timer(lambda name, a, e0, e1: seen.append((name, [getattr(v, 'value', v) for v in a])))
     try:
@@ -1617,13 +1622,25 @@ def test_f32_inference_runs_in_the_split_form_and_training_does_not():
             with torch.no_grad():
                 model(lidal_amd.SparseTensor(feats, coords))
             infer = [a[12] for nme, a in seen if nme in ('lidal_conv_apply_image', 'lidal_conv_apply_image_ws')]
-            del seen[:]
             model.train()
-            model(lidal_amd.SparseTensor(feats, coords))[0].sum().backward()
-            train = [a[12] for nme, a in seen if nme in ('lidal_conv_apply_image', 'lidal_conv_apply_image_ws')]
+            trains = {}
+            for split_train in (True, False):
+                del seen[:]
+                B.SPLIT_F32_TRAIN = split_train
+                model(lidal_amd.SparseTensor(feats, coords))[0].sum().backward()
+                # (k, dtype code) of every forward product / data gradient, and the dtype code of every weight gradient
+                trains[split_train] = ([(a[10], a[12]) for nme, a in seen if nme in ('lidal_conv_apply_image', 'lidal_conv_apply_image_ws')],
+                                       [a[13] for nme, a in seen if nme == 'lidal_conv_wgrad'])
         finally:
             plan.ENABLED = saved
+            B.SPLIT_F32_TRAIN = True
     finally:
         B.set_call_timer(None)
     assert infer.count(B.F32_SPLIT) >= 40 and infer.count(B.F32) == 1, infer       # (the stem's first convolution: 4 channels)
-    assert train and set(train) == {B.F32}, train
+    apply_on, wgrad_on = trains[True]
+    assert [c for k, c in apply_on if k > 1].count(B.F32_SPLIT) >= 70                 # sparse convolutions, both directions
+    assert all(c == B.F32 for k, c in apply_on if k == 1) and any(k == 1 for k, c in apply_on)      # dense layers: exact
+    assert sum(1 for k, c in apply_on if k > 1 and c == B.F32) == 1                   # the 4-channel stem (no data gradient)
+    assert wgrad_on and set(wgrad_on) == {B.F32}
+    apply_off, wgrad_off = trains[False]
+    assert apply_off and {c for k, c in apply_off} == {B.F32} and set(wgrad_off) == {B.F32}

@@ -346,7 +346,11 @@ int lidal_conv_dgrad_bn_sums_ws(const void* gout, const void* wimg, const int32_
  * `partial` (n_slabs slabs, at least lidal_conv_wgrad_slabs(...) of them) and a second kernel adds
  * the slabs of every offset in a fixed order => bitwise reproducible, no atomics.  bf16 with
  * ca, cb multiples of 8: W equally long runs of 64-rule stages, one per resident workgroup,
- * gathered by LDS-DMA (csrc/wgrad_dma.hip); otherwise split-K slabs per offset (csrc/conv.hip). */
+ * gathered by LDS-DMA (csrc/wgrad_dma.hip); otherwise split-K slabs per offset (csrc/conv.hip).
+ * dtype LIDAL_F32_SPLIT (round 6): a and b are F32; every product runs as six bf16 MFMAs on the operands' three exact bf16
+ * pieces (as LIDAL_F32_SPLIT of lidal_conv_apply_image).  The pieces (bf16 [n_a, 3 ca] and [n_b, 3 cb]) are cut by the
+ * call itself into the tail of `partial`: lidal_conv_wgrad_slabs(.., LIDAL_F32_SPLIT) counts the room for them in slabs
+ * (-1: the shape is not served -- ca, cb multiples of 8, split operands below 4 GiB). */
 int64_t lidal_conv_wgrad_slabs(int64_t n_a, int64_t n_b, int k, int ca, int cb, int dtype);
 int lidal_conv_wgrad(const void* a, const void* b, int64_t n_a, int64_t n_b, const int32_t* pairs,
                      const int64_t* koff, int a_col, float* gw, float* partial, int64_t n_slabs,

@@ -563,8 +563,18 @@ def conv_code(dt, n_red, inference, n_col=None):
     if dt == torch.float32 and SPLIT_F32 and n_red > 0 and n_red % 32 == 0:
         if inference:
             return F32_SPLIT
-        if SPLIT_F32_TRAIN and n_col is not None and n_col > 0 and n_col % 32 == 0:
+        if (SPLIT_F32_TRAIN and n_col is not None and n_col > 0 and n_col % 32 == 0
+                and os.environ.get('LIDAL_X_SPLIT_APPLY') != '0'):
             return F32_SPLIT
+    return dtype_code(dt)
+
+
+def wgrad_code(dt, ca, cb):
+    """dtype code of a weight gradient a^T b (a [n, ca], b [n, cb] of dtype `dt`): f32 operands take the split form
+    (lidal_conv_wgrad with LIDAL_F32_SPLIT: the operands cut into three bf16 pieces inside the call, six bf16 MFMAs per
+    product -- round 6) wherever both channel counts are whole 16-byte segments; LIDAL_F32_SPLIT_TRAIN=0: exact f32."""
+    if dt == torch.float32 and SPLIT_F32 and SPLIT_F32_TRAIN and ca > 0 and cb > 0 and ca % 8 == 0 and cb % 8 == 0:
+        return F32_SPLIT
     return dtype_code(dt)
 
 

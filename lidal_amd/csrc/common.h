@@ -186,6 +186,13 @@ int wgrad_dma_workgroups(int64_t n_a, int64_t n_b, int k, int ca, int cb);
 int wgrad_dma(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* pairs,
               const int64_t* koff, int a_col, float* gw, float* partial, int W, int K, int ca,
               int cb, hipStream_t s);
+// ... and its split form for f32 operands (round 6): the operands are cut into three bf16 pieces each (into `scratch`,
+// wgrad_split_scratch_bytes) and multiplied as six bf16 products per f32 product; W workgroups, W + K slabs
+bool wgrad_split_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb);
+int wgrad_split_workgroups(int64_t n_a, int64_t n_b, int k, int ca, int cb);
+int64_t wgrad_split_scratch_bytes(int64_t n_a, int64_t n_b, int ca, int cb);
+int wgrad_split(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* pairs, const int64_t* koff, int a_col,
+                float* gw, float* partial, void* scratch, int W, int K, int ca, int cb, hipStream_t s);
 
 // sort.hip: stable LSD radix sort (Onesweep) of u32 / u64 keys with an optional i32 payload by key bits
 // [0, end_bit): 1 + ceil(end_bit / 8) launches; keys_in / vals_in are not written; vals_in == NULL sorts

@@ -464,6 +464,11 @@ static void splitk_plan(int64_t n_rows, int k, int ca, int cb, int* splits, int*
 
 extern "C" int64_t lidal_conv_wgrad_slabs(int64_t n_a, int64_t n_b, int k, int ca, int cb, int dtype) {
   const int64_t n_rows = n_a > n_b ? n_a : n_b;
+  if (dtype == LIDAL_F32_SPLIT) {       // f32 operands, split form: W + k slabs, then room for the operands' bf16 pieces
+    if (!wgrad_split_serves(n_a, n_b, k, ca, cb)) return -1;
+    const int64_t slab = (int64_t)ca * cb * 4;
+    return (int64_t)wgrad_split_workgroups(n_a, n_b, k, ca, cb) + k + cdiv(wgrad_split_scratch_bytes(n_a, n_b, ca, cb) + 256, slab);
+  }
   if (dtype == LIDAL_BF16 && wgrad_dma_serves(n_a, n_b, k, ca, cb))
     return (int64_t)wgrad_dma_workgroups(n_a, n_b, k, ca, cb) + k;
   int splits, chunk;
@@ -478,11 +483,19 @@ extern "C" int lidal_conv_wgrad(const void* a, const void* b, int64_t n_a, int64
   hipStream_t s = (hipStream_t)stream;
   if (k == 0 || ca == 0 || cb == 0) return 0;
   LIDAL_REQUIRE(n_a >= 0 && n_b >= 0, "wgrad: negative row count");
-  LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16, "wgrad: bad dtype %d", dtype);
+  LIDAL_REQUIRE(dtype == LIDAL_F32 || dtype == LIDAL_BF16 || dtype == LIDAL_F32_SPLIT, "wgrad: bad dtype %d", dtype);
+  LIDAL_REQUIRE(dtype != LIDAL_F32_SPLIT || wgrad_split_serves(n_a, n_b, k, ca, cb),
+                "wgrad(split): channel counts must be multiples of 8 and the split operands below 4 GiB (ca=%d cb=%d)", ca, cb);
   LIDAL_REQUIRE(n_slabs >= lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, dtype),
                 "wgrad: scratch of %lld slabs, lidal_conv_wgrad_slabs asks for %lld", (long long)n_slabs,
                 (long long)lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, dtype));
   const int64_t n_rows = n_a > n_b ? n_a : n_b;
+  if (dtype == LIDAL_F32_SPLIT) {       // f32 a, b: their bf16 pieces go behind the W + k slabs of `partial`
+    const int W = wgrad_split_workgroups(n_a, n_b, k, ca, cb);
+    char* scratch = (char*)partial + (int64_t)(W + k) * ca * cb * 4;
+    scratch = (char*)align_up((int64_t)(uintptr_t)scratch, 256);
+    return wgrad_split(a, b, n_a, n_b, pairs, koff, a_col, gw, partial, scratch, W, k, ca, cb, s);
+  }
   if (dtype == LIDAL_BF16 && wgrad_dma_serves(n_a, n_b, k, ca, cb))
     return wgrad_dma(a, b, n_a, n_b, pairs, koff, a_col, gw, partial,
                      wgrad_dma_workgroups(n_a, n_b, k, ca, cb), k, ca, cb, s);

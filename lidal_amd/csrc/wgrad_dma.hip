@@ -310,12 +310,12 @@ wgrad_dma_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, uns
 template <int V>
 __global__ void __launch_bounds__(256)
 wgrad_dma_reduce_kernel(const float* __restrict__ partial, const int64_t* __restrict__ koff,
-                        float* __restrict__ gw, int K, int64_t per_k, int W) {
+                        float* __restrict__ gw, int K, int64_t per_k, int W, int rps) {
   __shared__ int sh[2];
   const int k = blockIdx.y;
   if (threadIdx.x < 64) {          // the same prefix the gradient kernel computed, lane kk = offset kk
     const int lane = threadIdx.x;
-    const int mine = lane < K ? stages_of(koff, lane) : 0;
+    const int mine = lane < K ? (int)((koff[lane + 1] - koff[lane] + rps - 1) / rps) : 0;    // stages of offset `lane`
     int pre = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -362,6 +362,249 @@ wgrad_dma_reduce_kernel(const float* __restrict__ partial, const int64_t* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// f32 weight gradient in the split form (round 6): gw = a^T b over f32 operands, every product as six bf16 MFMAs
+// ------------------------------------------------------------------------------------------------------------------
+// The f32 training step's weight gradients ran on v_mfma_f32_16x16x4_f32 (conv.hip conv_wgrad_kernel): 25 of the step's
+// ~42 ms once the forward products and data gradients had moved to the split form (bench.py --dtype f32, families).  Here
+// both operands are first cut into their three bf16 pieces by a streaming pass (split_rows_kernel: row r of [n, c] f32 ->
+// row r of [n, 3 c] bf16 = hi(c) | mid(c) | lo(c); v = hi + mid + lo exactly, conv_img.hip cut3), then this kernel -- the
+// bf16 kernel above with THREE sub-tiles per operand and stage -- gathers the pieces of a rule's two rows by LDS-DMA and
+// accumulates  lo.hi + mid.mid + hi.lo + mid.hi + hi.mid + hi.hi  (smallest first) per 32-rule step: 6 MI NI MFMAs per
+// wave and step.  Stages are 32 rules (one MFMA reduction step) with the sub-tile rows padded to a power-of-two number of
+// 16-byte segments (the padding segments are fetched out of range: zeros, no traffic), so that every DMA instruction
+// moves whole 1-KiB runs and the bank swizzles of the bf16 kernel apply unchanged.  Same decomposition (W equal runs of
+// the stage sequence, slab w + k, reduction in workgroup order): bitwise reproducible.
+constexpr int SRPS = 32;       // rules per stage of the split kernel
+
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ src, int c, __bf16* __restrict__ dst,
+                                                         int64_t n) {
+  // one thread per 8 channels of a row: 32 bytes in, 3 x 16 bytes out
+  const int cv = c / 8;
+  const int64_t total = n * cv;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / cv;
+    const int u = (int)(i - r * cv);
+    const float4 v0 = *reinterpret_cast<const float4*>(src + r * c + u * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(src + r * c + u * 8 + 4);
+    const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned short h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned bits = __float_as_uint(f[e]);
+      const unsigned hb = bits & 0xFFFF0000u;
+      const float rr = f[e] - __uint_as_float(hb);
+      const unsigned mb = __float_as_uint(rr) & 0xFFFF0000u;
+      const unsigned lb = __float_as_uint(rr - __uint_as_float(mb));
+      h[e] = (unsigned short)(hb >> 16); m[e] = (unsigned short)(mb >> 16); l[e] = (unsigned short)(lb >> 16);
+    }
+    unsigned short* o = reinterpret_cast<unsigned short*>(dst) + r * 3 * c + u * 8;
+    *reinterpret_cast<u32x4*>(o) = *reinterpret_cast<const u32x4*>(h);
+    *reinterpret_cast<u32x4*>(o + c) = *reinterpret_cast<const u32x4*>(m);
+    *reinterpret_cast<u32x4*>(o + 2 * c) = *reinterpret_cast<const u32x4*>(l);
+  }
+}
+
+__device__ __forceinline__ int stages_of32(const int64_t* koff, int k) {
+  return (int)((koff[k + 1] - koff[k] + SRPS - 1) / SRPS);
+}
+constexpr int pseg_of(int seg) { return seg <= 8 ? 8 : 16; }      // segments per LDS row of a sub-tile (padded)
+
+template <int MI, int NI, bool DENSE>
+__global__ void __launch_bounds__(WT)
+wgrad_split_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, unsigned a_bytes,
+                   unsigned b_bytes, const int2* __restrict__ pairs, const int64_t* __restrict__ koff,
+                   int a_col, float* __restrict__ partial, int K, int ca, int cb, int tiles_b) {
+  constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
+  constexpr int SEG_A = TA / 8, SEG_B = TB / 8;
+  constexpr int PA = pseg_of(SEG_A), PB = pseg_of(SEG_B);
+  constexpr int SUB_A = SRPS * PA * 16, SUB_B = SRPS * PB * 16;     // bytes of one piece's sub-tile
+  constexpr int A_BYTES = 3 * SUB_A, B_BYTES = 3 * SUB_B, STAGE = A_BYTES + B_BYTES;
+  constexpr int R = 2;                                              // one stage travels while one is multiplied
+  constexpr int IDS_R = 3, IDS_BYTES = SRPS * 8;
+  constexpr int IA = PA / 8, IB = PB / 8;                           // DMA instructions per wave, piece and stage
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [R][STAGE] [IDS_R][IDS_BYTES]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned ids0 = lds0 + R * STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row16 = lane & 15, gsel = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int w = blockIdx.x, W = gridDim.x;
+  const int ta = blockIdx.y / tiles_b, tb = blockIdx.y - ta * tiles_b;
+  const int ca0 = ta * TA, cb0 = tb * TB;
+
+  int pre = lane < K ? stages_of32(koff, lane) : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(pre, d);
+    if (lane >= d) pre += t;
+  }
+  const int T = __builtin_amdgcn_readfirstlane(__shfl(pre, 63));
+  const int per = (T + W - 1) / W;
+  int s_run = w * per;
+  const int s_stop = (s_run + per < T) ? (s_run + per) : T;
+  if (s_run >= s_stop) return;
+
+  const u32x4 rs_a = make_rsrc(a, a_bytes), rs_b = make_rsrc(b, b_bytes);
+
+  // what this lane fetches in each of its DMA instructions of a sub-tile: tile row and byte offset of the segment inside
+  // the piece (OOB: a padding segment, or past the row's channels)
+  int row_a[IA], row_b[IB];
+  unsigned col_a[IA], col_b[IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int sg = 64 * (wave * IA + i) + lane, row = sg / PA, ls = unswz<PA>(row, sg % PA), c = ca0 + ls * 8;
+    row_a[i] = row;
+    col_a[i] = (ls < SEG_A && c < ca) ? (unsigned)c * 2u : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int sg = 64 * (wave * IB + i) + lane, row = sg / PB, ls = unswz<PB>(row, sg % PB), c = cb0 + ls * 8;
+    row_b[i] = row;
+    col_b[i] = (ls < SEG_B && c < cb) ? (unsigned)c * 2u : OOB;
+  }
+  const unsigned rb_a = (unsigned)ca * 6u, rb_b = (unsigned)cb * 6u;       // bytes of a split row: 3 pieces of c bf16
+  const unsigned pc_a = (unsigned)ca * 2u, pc_b = (unsigned)cb * 2u;       // bytes of one piece inside it
+  int64_t p_beg = 0;
+  int n_rules = 0;
+  u32x4 rs_p = make_rsrc(nullptr, 0u);
+  const int sel_a = a_col ? 4 : 0, sel_b = a_col ? 0 : 4;
+
+  // ids of stage t (32 pairs = 256 B): one dword per lane, every wave brings the same bytes to the same place (every wave
+  // then has the same number of loads in flight: the counted waits below rely on it)
+  auto issue_ids = [&](int t) __attribute__((always_inline)) {
+    if constexpr (!DENSE) {
+      const int pi = t * SRPS + (lane >> 1);
+      const unsigned off = pi < n_rules ? (unsigned)pi * 8u + (unsigned)(lane & 1) * 4u : OOB;
+      dma4(rs_p, ids0 + (t % IDS_R) * IDS_BYTES, off);
+    }
+  };
+  auto issue_rows = [&](int t) __attribute__((always_inline)) {
+    const unsigned stage = lds0 + (unsigned)(t % R) * STAGE;
+    const int r0 = t * SRPS;
+    const unsigned char* ids = smem + R * STAGE + (t % IDS_R) * IDS_BYTES;
+    int ia[IA], ib[IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      if constexpr (DENSE) ia[i] = (int)(p_beg + r0 + row_a[i]);
+      else ia[i] = *reinterpret_cast<const int*>(ids + row_a[i] * 8 + sel_a);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      if constexpr (DENSE) ib[i] = (int)(p_beg + r0 + row_b[i]);
+      else ib[i] = *reinterpret_cast<const int*>(ids + row_b[i] * 8 + sel_b);
+    }
+#pragma unroll
+    for (int i = 0; i < IA; ++i) asm volatile("" : "+v"(ia[i]));
+#pragma unroll
+    for (int i = 0; i < IB; ++i) asm volatile("" : "+v"(ib[i]));
+#pragma unroll
+    for (int pz = 0; pz < 3; ++pz) {
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        const bool ok = r0 + row_a[i] < n_rules && col_a[i] != OOB;
+        const unsigned off = ok ? (unsigned)ia[i] * rb_a + (unsigned)pz * pc_a + col_a[i] : OOB;
+        dma16(rs_a, stage + pz * SUB_A + (wave * IA + i) * 1024, off);
+      }
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        const bool ok = r0 + row_b[i] < n_rules && col_b[i] != OOB;
+        const unsigned off = ok ? (unsigned)ib[i] * rb_b + (unsigned)pz * pc_b + col_b[i] : OOB;
+        dma16(rs_b, stage + A_BYTES + pz * SUB_B + (wave * IB + i) * 1024, off);
+      }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int q = row16 >> 2, pp = row16 & 3;
+  const int trow = 8 * gsel + q;
+  int fa[MI], fb[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+    fa[mi] = trow * (PA * 16) + swz<PA>(trow, 2 * (wr * MI + mi) + (pp >> 1)) * 16 + (pp & 1) * 8;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+    fb[ni] = A_BYTES + trow * (PB * 16) + swz<PB>(trow, 2 * (wc * NI + ni) + (pp >> 1)) * 16 + (pp & 1) * 8;
+
+  auto frag = [&](const unsigned char* base, int pitch16) __attribute__((always_inline)) -> bf16x8 {
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * pitch16));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  while (s_run < s_stop) {
+    const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(lane < K && pre > s_run)));
+    const int k_first = k ? __builtin_amdgcn_readlane(pre, k - 1) : 0;
+    const int k_last = __builtin_amdgcn_readlane(pre, k);
+    const int s_end = k_last < s_stop ? k_last : s_stop;
+    const int64_t beg = koff[k], end = koff[k + 1];
+    p_beg = beg + (int64_t)(s_run - k_first) * SRPS;
+    const int64_t p_end = (beg + (int64_t)(s_end - k_first) * SRPS < end) ? beg + (int64_t)(s_end - k_first) * SRPS : end;
+    n_rules = (int)(p_end - p_beg);
+    const int nsteps = s_end - s_run;
+    rs_p = make_rsrc(DENSE ? nullptr : (const void*)(pairs + p_beg), DENSE ? 0u : (unsigned)n_rules * 8u);
+
+    issue_ids(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+    __syncthreads();
+    issue_ids(1);
+    issue_rows(0);
+    for (int step = 0; step < nsteps; ++step) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);                   // rows(step) and ids(step + 1) have landed (nothing younger is in flight)
+      __syncthreads();                                      // ... for every wave's share; and stage step-1 is free again
+      issue_ids(step + 2);
+      issue_rows(step + 1);                                 // into the slot of stage step-1 (past the end: zeros)
+      const unsigned char* st = smem + (step % R) * STAGE;
+      bf16x8 af[3][MI], bf[3][NI];
+#pragma unroll
+      for (int pz = 0; pz < 3; ++pz) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[pz][mi] = frag(st + pz * SUB_A + fa[mi], PA * 16);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[pz][ni] = frag(st + pz * SUB_B + fb[ni], PB * 16);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {       // pieces: 0 = hi, 1 = mid, 2 = lo; smallest partial products first
+          f32x4 c = acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][mi], bf[0][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mi], bf[1][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mi], bf[2][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mi], bf[0][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mi], bf[1][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mi], bf[0][ni], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    float* dst = partial + (int64_t)(w + k) * ca * cb;              // slab w + k
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int i = ca0 + (wr * MI + mi) * 16 + gsel * 4 + r;
+          int j = cb0 + (wc * NI + ni) * 16 + row16;
+          if (i < ca && j < cb) dst[(int64_t)i * cb + j] = acc[mi][ni][r];
+        }
+        acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    s_run = s_end;
+  }
+}
+
 constexpr int lds_bytes(int ta, int tb) {
   const int stage = RPS * (ta + tb) * 2, d = wgrad_depth(stage);
   return (d + 1) * stage + (2 * d + 1) * RPS * 8;
@@ -391,11 +634,42 @@ int launch(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* pa
   const int64_t per_k = (int64_t)ca * cb;
   if (per_k % 4 == 0)
     wgrad_dma_reduce_kernel<4><<<dim3((unsigned)cdiv(per_k / 4, 256), (unsigned)K), 256, 0, s>>>(
-        partial, koff, gw, K, per_k, W);
+        partial, koff, gw, K, per_k, W, RPS);
   else
     wgrad_dma_reduce_kernel<1><<<dim3((unsigned)cdiv(per_k, 256), (unsigned)K), 256, 0, s>>>(
-        partial, koff, gw, K, per_k, W);
+        partial, koff, gw, K, per_k, W, RPS);
   LIDAL_CHECK_LAUNCH("lidal_conv_wgrad (dma reduce)");
+  return 0;
+}
+
+constexpr int split_lds_bytes(int ta, int tb) {
+  return 2 * 3 * SRPS * 16 * (pseg_of(ta / 8) + pseg_of(tb / 8)) + 3 * SRPS * 8;
+}
+
+template <int MI, int NI>
+int launch_split(const void* a3, const void* b3, int64_t n_a, int64_t n_b, const int* pairs, const int64_t* koff, int a_col,
+                 float* gw, float* partial, int W, int K, int ca, int cb, hipStream_t s) {
+  constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
+  const size_t lds = (size_t)split_lds_bytes(TA, TB);
+  const int tiles_a = (int)cdiv(ca, TA), tiles_b = (int)cdiv(cb, TB);
+  dim3 grid((unsigned)W, (unsigned)(tiles_a * tiles_b));
+  const bool dense = pairs == nullptr;
+  auto kern = dense ? wgrad_split_kernel<MI, NI, true> : wgrad_split_kernel<MI, NI, false>;
+  static size_t attr_set[2][MAX_DEVICES] = {};
+  const int dev = current_device();
+  if (attr_set[dense][dev] < lds) {
+    LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[dense][dev] = lds;
+  }
+  kern<<<grid, WT, lds, s>>>((const __bf16*)a3, (const __bf16*)b3, (unsigned)(n_a * ca * 6), (unsigned)(n_b * cb * 6),
+                             (const int2*)pairs, koff, a_col, partial, K, ca, cb, tiles_b);
+  LIDAL_CHECK_LAUNCH("lidal_conv_wgrad (split)");
+  const int64_t per_k = (int64_t)ca * cb;
+  if (per_k % 4 == 0)
+    wgrad_dma_reduce_kernel<4><<<dim3((unsigned)cdiv(per_k / 4, 256), (unsigned)K), 256, 0, s>>>(partial, koff, gw, K, per_k, W, SRPS);
+  else
+    wgrad_dma_reduce_kernel<1><<<dim3((unsigned)cdiv(per_k, 256), (unsigned)K), 256, 0, s>>>(partial, koff, gw, K, per_k, W, SRPS);
+  LIDAL_CHECK_LAUNCH("lidal_conv_wgrad (split reduce)");
   return 0;
 }
 
@@ -435,6 +709,47 @@ int wgrad_dma_workgroups(int64_t n_a, int64_t n_b, int k, int ca, int cb) {
   if (w > stages / WGRAD_MIN_STAGES) w = stages / WGRAD_MIN_STAGES;
   if (w * tiles >= 256) w = (w * tiles / 256) * 256 / tiles;
   return (int)(w < 1 ? 1 : w);
+}
+
+// ---- the split form: f32 operands, pieces cut into `scratch` (bf16 [n_a, 3 ca] | [n_b, 3 cb]) first
+bool wgrad_split_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb) {
+  if (ca % 8 != 0 || cb % 8 != 0 || k > 64) return false;
+  return n_a * ca * 6 < (int64_t)OOB && n_b * cb * 6 < (int64_t)OOB;
+}
+int64_t wgrad_split_scratch_bytes(int64_t n_a, int64_t n_b, int ca, int cb) {
+  return align_up(n_a * ca * 6, 256) + align_up(n_b * cb * 6, 256);
+}
+// workgroups: one resident round, shared between the channel tiles, runs of >= 8 stages of the estimated rule count
+int wgrad_split_workgroups(int64_t n_a, int64_t n_b, int k, int ca, int cb) {
+  const int ta = wgrad_blocks(ca) * 32, tb = wgrad_blocks(cb) * 32;
+  const int64_t tiles = cdiv(ca, ta) * cdiv(cb, tb);
+  const int64_t n_rows = n_a > n_b ? n_a : n_b;
+  int64_t resident = (160 * 1024) / split_lds_bytes(ta, tb);
+  resident = resident < 1 ? 1 : (resident > 2 ? 2 : resident);
+  int64_t w = 256 * resident / tiles;
+  const int64_t stages = (k > 8 ? 6 : 1) * n_rows / SRPS;
+  if (w > stages / 16) w = stages / 16;
+  if (w * tiles >= 256) w = (w * tiles / 256) * 256 / tiles;
+  return (int)(w < 1 ? 1 : w);
+}
+int wgrad_split(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* pairs, const int64_t* koff, int a_col,
+                float* gw, float* partial, void* scratch, int W, int K, int ca, int cb, hipStream_t s) {
+  __bf16* a3 = (__bf16*)scratch;
+  __bf16* b3 = (__bf16*)((char*)scratch + align_up(n_a * ca * 6, 256));
+  auto grid_of = [](int64_t items) { int64_t g = cdiv(items, 256); return (unsigned)(g < 1 ? 1 : (g > 256 * 32 ? 256 * 32 : g)); };
+  if (n_a > 0) split_rows_kernel<<<grid_of(n_a * (ca / 8)), 256, 0, s>>>((const float*)a, ca, a3, n_a);
+  if (n_b > 0) split_rows_kernel<<<grid_of(n_b * (cb / 8)), 256, 0, s>>>((const float*)b, cb, b3, n_b);
+  LIDAL_CHECK_LAUNCH("lidal_conv_wgrad (split rows)");
+  const int mi = wgrad_blocks(ca), ni = wgrad_blocks(cb);
+#define WS_CASE(M, N) \
+  if (mi == M && ni == N) return launch_split<M, N>(a3, b3, n_a, n_b, pairs, koff, a_col, gw, partial, W, K, ca, cb, s);
+  WS_CASE(1, 1) WS_CASE(1, 2) WS_CASE(1, 3) WS_CASE(1, 4)
+  WS_CASE(2, 1) WS_CASE(2, 2) WS_CASE(2, 3) WS_CASE(2, 4)
+  WS_CASE(3, 1) WS_CASE(3, 2) WS_CASE(3, 3) WS_CASE(3, 4)
+  WS_CASE(4, 1) WS_CASE(4, 2) WS_CASE(4, 3) WS_CASE(4, 4)
+#undef WS_CASE
+  set_error("wgrad(split): no tile for %d x %d", ca, cb);
+  return 2;
 }
 
 int wgrad_dma(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* pairs,

@@ -75,13 +75,15 @@ TRACE = None
 # one scan 7.47 / 7.48 / 7.46 -> 7.01 / 7.82 / 7.02 ms (scripts/exp/side_wgrad.sh).  Same kernels, same results.
 SIDE_ROWS = int(os.environ.get('LIDAL_PLAN_SIDE_ROWS', str(1 << 40)))
 SIDE_MIN_ROWS = int(os.environ.get('LIDAL_PLAN_SIDE_MIN_ROWS', '0'))      # (measured: every threshold above 0 loses, matrix2.sh)
-# The f32 mode on the side stream (round 5): one SPVCNN f32 training run in ~20 was not bit-reproducible -- gradients differing
-# in the last bit from some decoder layer on; never under bf16 (scripts/exp/determinism_steps.py, profiles/README.md "A
-# training run that was not bit-reproducible").  What removed it from the planned step was taking the fused f64 block tail out
-# of the f32 mode (nn/functional/norm.py TAIL_SUMS_ROWS: 0 differences in 240 repetitions of six steps since); the
-# per-operator path also needed its weight gradients back on the main stream (backend.overlap_wgrad).  LIDAL_PLAN_SIDE_F32=0
-# does the same here at 57.0 instead of 49.0 ms per f32 step -- the setting to use if a difference ever shows up again.
-SIDE_F32 = os.environ.get('LIDAL_PLAN_SIDE_F32', '1') == '1'
+# The f32 mode keeps its weight gradients on the MAIN stream (round 6; LIDAL_PLAN_SIDE_F32=1: beside the data gradients).
+# Round 5: one SPVCNN f32 run in ~20 was not bit-reproducible with the fused f64 block tail running while f32 weight gradients
+# ran beside it (gradients differing in the last bits from some layer on; never under bf16).  Round 6, with the weight
+# gradients in the split form (wgrad_split_kernel) on the side stream: EVERY run -- bisected (profiles/README.md, round 6) to
+# the overlap of a BatchNorm backward (f64 sums) with a split-form convolution weight gradient; neither an instruction
+# fault, nor the pair in isolation, nor a shared buffer, nor torch's kernels.  Two configurations are clean (0 of 48
+# repetitions each): no side stream (34.8 ms per 5-scan f32 step) and F32_BN_ALONE below with the side stream (34.6); the
+# unexplained overlap buys 32.2.  Until the cause is known the f32 mode -- the parity mode -- runs single-stream.
+SIDE_F32 = os.environ.get('LIDAL_PLAN_SIDE_F32', '0') == '1'
 # The shortcut branch of a residual block (1x1x1 convolution + BatchNorm, forward and backward) runs on a THIRD stream
 # beside the block's main branch where the level has at least this many rows (0 = never): 5 scans 15.37 / 15.38 / 15.34
 # -> 15.19 / 15.24 ms; on one scan the extra fork / join pairs cost the host what the overlap wins on the GPU (6.65 /
@@ -94,6 +96,8 @@ BRANCH_ROWS = int(os.environ.get('LIDAL_PLAN_BRANCH_ROWS', '100000'))
 # hardware queues and the step went from 13.9 to 20.5-21.2 ms, profiles/README.md).  bf16 only (the f32 mode keeps its
 # concurrency as it was, section 5 of DESIGN.md).
 POINT_SIDE = int(os.environ.get('LIDAL_PLAN_POINT_SIDE', '1'))     # 0 = on the main stream, i = on side stream i
+_XJOIN = set(filter(None, os.environ.get('LIDAL_X_JOIN_BEFORE', '').split(',')))
+F32_BN_ALONE = os.environ.get('LIDAL_PLAN_F32_BN_ALONE', '1') != '0'
 _NARGS = {}
 _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
               6: 'bn_train_fwd', 7: 'bn_bwd', 8: 'bn_bwd', 9: 'bn_eval_fwd', 10: 'bn_fold', 11: 'colsum',
@@ -456,13 +460,14 @@ def _bn_ws(n, c):
     return v
 
 
-def _slabs(n_a, n_b, k, ca, cb, code):
-    key = (n_a, n_b, k, ca, cb, code)
+def _slabs(n_a, n_b, k, ca, cb, dtype):
+    """(dtype code, slabs) of a weight gradient, memoised: conv.wgrad_plan (the rule of the per-operator path)."""
+    key = (n_a, n_b, k, ca, cb, dtype, B.SPLIT_F32_TRAIN, B.SPLIT_F32)
     v = _WS_SLABS.get(key)
     if v is None:
         if len(_WS_SLABS) > 4096:
             _WS_SLABS.clear()
-        v = _WS_SLABS[key] = int(B.lib_handle().lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, code))
+        v = _WS_SLABS[key] = _C.wgrad_plan(n_a, n_b, k, ca, cb, dtype)
     return v
 
 
@@ -715,6 +720,16 @@ class _Run:
         self.nops += 1
         self.open.discard(which)
 
+    def _xjoin(self, what):
+        """The main stream waits for the side streams before an operation of kind `what`.
+        f32 mode, 'bn' (round 6, F32_BN_ALONE): a BatchNorm backward never runs while a weight gradient in the split form
+        is resident beside it -- the one overlap in which the planned f32 step was seen to lose its run-to-run bit-equality
+        (profiles/README.md, round 6: 100 % of the runs with the overlap, 0 of 48 without; neither kernel differs from its
+        solo result when the pair is run in isolation).  LIDAL_X_JOIN_BEFORE=bn,dgrad,tail: the experiment's switches."""
+        if self.open and (what in _XJOIN or (what == 'bn' and F32_BN_ALONE and not self.bf16)):
+            for w_ in sorted(self.open):
+                self.join(w_)
+
     def side(self, rows):
         """Flag of a weight gradient over `rows` rows: side stream 1 (after a fork), or 0 = the main stream."""
         if not SIDE_ROWS or rows > SIDE_ROWS or rows < SIDE_MIN_ROWS:
@@ -949,6 +964,8 @@ class _Run:
         lidal_add_relu_bwd_bn_sums left for this layer."""
         p = self.ptr
         c = r.c
+        if not flag:
+            self._xjoin('bn')
         dx = self.galloc(n * c * self.esz)
         relu = r.relu if relu is None else relu
         if part is not None and part[0]:
@@ -967,22 +984,28 @@ class _Run:
     def b_wgrad(self, c, x, n_x, g, n_g, rules, ci=None):
         """conv.py conv_backward's wgrad(): gw [k, ci, co] f32 straight into the parameter's gradient slot."""
         ci = c.ci if ci is None else ci
-        slabs = _slabs(n_x, n_g, c.k, ci, c.co, self.code)
+        wcode, slabs = _slabs(n_x, n_g, c.k, ci, c.co, self.dtype)
+        if os.environ.get('LIDAL_X_SPLIT_CONV') == '0' and wcode == B.F32_SPLIT:
+            wcode = self.code
+            slabs = int(B.lib_handle().lidal_conv_wgrad_slabs(n_x, n_g, c.k, ci, c.co, wcode))
         flag = self.side(max(n_x, n_g))
         nbytes = slabs * ci * c.co * 4 + (c.k * ci * c.co * 4 if ci != c.ci else 0)
-        partial = self.scratch(nbytes, flag)
+        partial = self.galloc(nbytes) if os.environ.get('LIDAL_X_WGRAD_ARENA') == '1' else self.scratch(nbytes, flag)
         gw = self.slot(c.w)
         if ci != c.ci:                      # the channel-padded stem: gw[:, :ci_w] of the padded gradient
             gw = partial + slabs * ci * c.co * 4
         self.w += (OP_CONV_WGRAD | flag, x, g, n_x, n_g, rules[0], rules[1], 1 if c.transposed else 0, gw, partial, slabs,
-                   c.k, ci, c.co, self.code)
+                   c.k, ci, c.co, wcode)
         self.nops += 1
         if ci != c.ci:
             self.w += (OP_COPY2D | flag, gw, ci * c.co * 4, self.slot(c.w), c.ci * c.co * 4, c.k, c.ci * c.co * 4, 0)
             self.nops += 1
+        if os.environ.get('LIDAL_X_JOIN_AFTER_WGRAD') == '1' and flag:
+            self.join(flag >> 16)
 
     def b_dgrad(self, c, g, n_g, table, n_out, kflip, skip=0, bnb=None):
         """conv.py conv_backward's data gradient: -> (gin [n_out, ci], tile sums or 0)."""
+        self._xjoin('dgrad')
         gin = self.galloc(n_out * c.ci * self.esz)
         wb = _C.apply_workspace_bytes(n_out, c.ci)
         ws = self.scratch(wb) if wb else 0
@@ -1002,13 +1025,16 @@ class _Run:
         `branch`: the flag of the side stream the whole layer runs on (0: data gradient on the main stream, weight
         gradient per side())."""
         ca, cb = c.ci, cg
-        slabs = _slabs(n, n, 1, ca, cb, self.code)
+        wcode, slabs = _slabs(n, n, 1, ca, cb, self.dtype)
+        if os.environ.get('LIDAL_X_SPLIT_DENSE') == '0' and wcode == B.F32_SPLIT:
+            wcode = self.code
+            slabs = int(B.lib_handle().lidal_conv_wgrad_slabs(n, n, 1, ca, cb, wcode))
         direct = linear_slot is None and cb == c.co
         flag = branch or self.side(n)
         nbytes = slabs * ca * cb * 4 + (0 if direct else ca * cb * 4)
-        sc = self.scratch(nbytes, flag)
+        sc = self.galloc(nbytes) if os.environ.get('LIDAL_X_WGRAD_ARENA') == '1' else self.scratch(nbytes, flag)
         gw = self.slot(c.w) if direct else sc + slabs * ca * cb * 4
-        self.w += (OP_CONV_WGRAD | flag, x, g, n, n, 0, self.koff[n], 0, gw, sc, slabs, 1, ca, cb, self.code)
+        self.w += (OP_CONV_WGRAD | flag, x, g, n, n, 0, self.koff[n], 0, gw, sc, slabs, 1, ca, cb, wcode)
         self.nops += 1
         if not direct:                      # nn.Linear: [Cout, Cin] = (x^T g)[:, :Cout]^T
             self.w += (OP_TRANSPOSE_F32 | flag, gw, cb, self.slot(c.w), ca, c.co)
@@ -1045,6 +1071,7 @@ class _Run:
         """blocks._Residual.backward: g [n, co] contiguous -> gx [n, ci]."""
         x, x1, mean1, inv1, y1, x2, mean2, inv2, out, xs, means, invs = self.saved[id(r)]
         co = r.c2.co
+        self._xjoin('tail')
         gm = self.galloc(n * co * self.esz)
         part2 = parts = nb = 0
         sums2 = sumss = nparts = 0
@@ -1065,7 +1092,8 @@ class _Run:
         self.nops += 1
         fl = 0
         if r.cs is not None:                # the shortcut's backward: independent of the main branch until conv1's data gradient
-            fl = self.fork(2) if (BRANCH_ROWS and n >= BRANCH_ROWS) else 0
+            # (f32 with F32_BN_ALONE: the shortcut's BatchNorm backward stays on the main stream, behind the join, too)
+            fl = self.fork(2) if (BRANCH_ROWS and n >= BRANCH_ROWS and (self.bf16 or not F32_BN_ALONE)) else 0
             dxs = self.b_bn(r.bs, xs, n, means, invs, gm, co, sumss, None, flag=fl, part=(parts, nb), nparts=nparts)
             g_skip = self.b_dense(r.cs, x, n, dxs, co, branch=fl)
         else:

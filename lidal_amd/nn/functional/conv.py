@@ -576,11 +576,26 @@ def apply_workspace_bytes(n_out, co):
     return v
 
 
-def wgrad_scratch(n_a, n_b, k, ca, cb, dtype, device):
+def wgrad_scratch(n_a, n_b, k, ca, cb, dtype, device, code=None):
     """The f32 [slabs, ca, cb] scratch lidal_conv_wgrad reduces through; the slab count (workgroups
-    of the launch + k for the bf16 DMA kernel, split-K slabs x k otherwise) is the library's plan."""
-    slabs = int(B.lib().lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, B.dtype_code(dtype)))
+    of the launch + k for the bf16 DMA kernel, split-K slabs x k otherwise; with B.F32_SPLIT also the room
+    for the operands' bf16 pieces) is the library's plan."""
+    slabs = int(B.lib().lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, B.dtype_code(dtype) if code is None else code))
     return torch.empty((slabs, ca, cb), dtype=torch.float32, device=device)
+
+
+def wgrad_plan(n_a, n_b, k, ca, cb, dtype):
+    """(dtype code, slabs) of a weight gradient: the split form for f32 operands where the library serves the shape
+    (backend.wgrad_code; lidal_conv_wgrad_slabs says -1 otherwise), else the operands' own dtype.  One rule for the
+    per-operator path and the planned step."""
+    code = B.wgrad_code(dtype, ca, cb)
+    L = B.lib_handle()
+    if code == B.F32_SPLIT:
+        slabs = int(L.lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, code))
+        if slabs > 0:
+            return code, slabs
+        code = B.dtype_code(dtype)
+    return code, int(L.lidal_conv_wgrad_slabs(n_a, n_b, k, ca, cb, code))
 
 
 def _pad_channels(ci, dtype):
@@ -656,11 +671,12 @@ def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=N
 
     def wgrad():
         gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
-        partial = wgrad_scratch(x.shape[0], g.shape[0], k, ci, co, x.dtype, x.device)
+        code, slabs = wgrad_plan(x.shape[0], g.shape[0], k, ci, co, x.dtype)
+        partial = torch.empty((slabs, ci, co), dtype=torch.float32, device=x.device)
         B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), x.shape[0], g.shape[0],
                                          B.ptr(kmap._nbmaps_cap), B.ptr(kmap.koff),
                                          1 if transposed else 0, B.ptr(gw), B.ptr(partial),
-                                         partial.shape[0], k, ci, co, B.dtype_code(x.dtype),
+                                         partial.shape[0], k, ci, co, code,
                                          B.stream()), 'conv_wgrad')
         gw = gw[:, :ci_w].contiguous() if ci != ci_w else gw
         return gw if weight.dtype == torch.float32 else gw.to(weight.dtype)

@@ -33,10 +33,12 @@ def _wgrad_dense(a, b):
     n, ca = a.shape
     cb = b.shape[1]
     gw = torch.empty((1, ca, cb), dtype=torch.float32, device=a.device)
-    partial = wgrad_scratch(n, n, 1, ca, cb, a.dtype, a.device)
+    from .conv import wgrad_plan
+    code, slabs = wgrad_plan(n, n, 1, ca, cb, a.dtype)          # (f32: the split form, backend.wgrad_code)
+    partial = torch.empty((slabs, ca, cb), dtype=torch.float32, device=a.device)
     B.check(B.lib().lidal_conv_wgrad(B.ptr(a), B.ptr(b), n, n, None, B.ptr(_koff(n, a.device)), 0,
                                      B.ptr(gw), B.ptr(partial), partial.shape[0], 1, ca, cb,
-                                     B.dtype_code(a.dtype), B.stream()), 'conv_wgrad(dense)')
+                                     code, B.stream()), 'conv_wgrad(dense)')
     return gw[0]
 
 

@@ -1598,9 +1598,10 @@ def test_split_f32_convolution_against_f64(ci, co):
 def test_f32_inference_runs_in_the_split_form_and_training_does_not():
     """backend.conv_code: under no_grad an f32 network's convolutions and dense layers take LIDAL_F32_SPLIT (except the
     4-channel stem).  With autograd on (the f32 training step) -- round 6 -- the SPARSE convolutions whose two channel
-    counts are whole 32-channel slices take it too, forward and data gradient, and the dense layers, the 4-channel stem and
-    every weight gradient stay on the exact f32 MFMA; LIDAL_F32_SPLIT_TRAIN=0 (backend.SPLIT_F32_TRAIN) keeps all of the
-    training step there."""
+    counts are whole 32-channel slices take it too, forward and data gradient, and every weight gradient whose channel
+    counts are whole 16-byte segments (lidal_conv_wgrad with LIDAL_F32_SPLIT: all but the 4-channel stem's); the dense
+    layers' products and the 4-channel stem stay on the exact f32 MFMA.  LIDAL_F32_SPLIT_TRAIN=0 (backend.SPLIT_F32_TRAIN)
+    keeps all of the training step there."""
     import lidal_amd
     from lidal_amd import backend as B
     assert B.conv_code(torch.float32, 96, True) == B.F32_SPLIT
@@ -1641,6 +1642,61 @@ def test_f32_inference_runs_in_the_split_form_and_training_does_not():
     assert [c for k, c in apply_on if k > 1].count(B.F32_SPLIT) >= 70                 # sparse convolutions, both directions
     assert all(c == B.F32 for k, c in apply_on if k == 1) and any(k == 1 for k, c in apply_on)      # dense layers: exact
     assert sum(1 for k, c in apply_on if k > 1 and c == B.F32) == 1                   # the 4-channel stem (no data gradient)
-    assert wgrad_on and set(wgrad_on) == {B.F32}
+    assert wgrad_on.count(B.F32_SPLIT) >= 40 and wgrad_on.count(B.F32) == 1, wgrad_on       # (exact: the 4-channel stem)
+    assert B.wgrad_code(torch.float32, 96, 96) == B.F32_SPLIT and B.wgrad_code(torch.float32, 4, 32) == B.F32
+    assert B.wgrad_code(torch.bfloat16, 96, 96) == B.BF16
     apply_off, wgrad_off = trains[False]
     assert apply_off and {c for k, c in apply_off} == {B.F32} and set(wgrad_off) == {B.F32}
+
+
+@pytest.mark.parametrize('ci,co', [(32, 32), (96, 96), (128, 96), (256, 128), (64, 24)])
+def test_split_f32_weight_gradient_against_f64(ci, co):
+    """lidal_conv_wgrad with LIDAL_F32_SPLIT (csrc/wgrad_dma.hip wgrad_split_kernel, round 6: the f32 training step's weight
+    gradients): f32 operands cut into three exact bf16 pieces by the call, six bf16 MFMAs per product, f32 accumulation.
+    Against the f64 gradient it is as close as the exact f32 MFMA kernel (both within 4e-6 of the gradient's scale), bitwise
+    reproducible, for sparse rule lists and for the dense (identity) form."""
+    from lidal_amd import backend as B
+    from lidal_amd import synth
+    F = _F()
+    L = B.lib()
+    dev = torch.device(DEV)
+    b = synth.make_train_batch(n_frames=1, n_points=30000, seed=17)
+    coords = torch.from_numpy(b['coords_v_b']).to(dev)
+    with torch.enable_grad():
+        kmap, _ = F.build_kernel_map(coords, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    n = coords.shape[0]
+    g = torch.Generator(device='cpu').manual_seed(ci * 100 + co)
+    x = torch.randn(n, ci, generator=g).to(dev)
+    gy = (torch.randn(n, co, generator=g) * 0.3).to(dev)
+    nbmaps, koff = kmap.nbmaps.long(), kmap.koff.cpu().tolist()
+    ref = torch.zeros(27, ci, co, dtype=torch.float64, device=dev)
+    for k in range(27):
+        pr = nbmaps[koff[k]:koff[k + 1]]
+        if pr.shape[0]:
+            ref[k] = x.double()[pr[:, 0]].t() @ gy.double()[pr[:, 1]]
+    scale = float(ref.abs().max())
+    errs = {}
+    for name, code in (('exact', B.F32), ('split', B.F32_SPLIT)):
+        slabs = int(L.lidal_conv_wgrad_slabs(n, n, 27, ci, co, code))
+        assert slabs > 0
+        partial = torch.full((slabs, ci, co), float('nan'), dtype=torch.float32, device=dev)
+        outs = []
+        for _ in range(2):
+            gw = torch.full((27, ci, co), float('nan'), dtype=torch.float32, device=dev)
+            B.check(L.lidal_conv_wgrad(B.ptr(x), B.ptr(gy), n, n, B.ptr(kmap._nbmaps_cap), B.ptr(kmap.koff), 0, B.ptr(gw),
+                                       B.ptr(partial), slabs, 27, ci, co, code, B.stream()), 'wgrad')
+            outs.append(gw)
+        assert torch.equal(outs[0], outs[1])
+        errs[name] = float((outs[0].double() - ref).abs().max()) / scale
+    assert errs['split'] < 4e-6 and errs['exact'] < 4e-6, errs
+    # dense form: x^T gy
+    koff1 = torch.tensor([0, n], dtype=torch.int64, device=dev)
+    slabs = int(L.lidal_conv_wgrad_slabs(n, n, 1, ci, co, B.F32_SPLIT))
+    partial = torch.empty((slabs, ci, co), dtype=torch.float32, device=dev)
+    gw = torch.empty((1, ci, co), dtype=torch.float32, device=dev)
+    B.check(L.lidal_conv_wgrad(B.ptr(x), B.ptr(gy), n, n, None, B.ptr(koff1), 0, B.ptr(gw), B.ptr(partial), slabs, 1, ci, co,
+                               B.F32_SPLIT, B.stream()), 'wgrad(dense)')
+    refd = x.double().t() @ gy.double()
+    assert float((gw[0].double() - refd).abs().max()) < 4e-6 * float(refd.abs().max())
+    # a shape it does not serve says so
+    assert int(L.lidal_conv_wgrad_slabs(n, n, 27, 4, 32, B.F32_SPLIT)) == -1

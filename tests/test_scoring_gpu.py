@@ -275,3 +275,32 @@ def test_256_frame_sequence_scores_match_the_oracle_at_both_ends_and_in_the_midd
         need = set(needed_frames(n_frames, 8, r, nei))
         for i in frame_range(n_frames, 8, r):
             assert set(interframe.neighbour_ids(i, n_frames, nei)) | {i} <= need, (r, i)
+
+
+def test_cell_ordered_queries_give_the_same_scores_bit_for_bit():
+    """lidal_interframe_score_ordered (round 6; off by default: no gain): the queries of a frame taken in the cell order of
+    its own grid -- the same per-point arithmetic, so every output equals the scan-order call's."""
+    from lidal_amd import synth
+    from lidal_amd.score import interframe
+    frames = synth.make_sequence(7, n_points=None, seed=8, step=0.6, n_beams=24, n_az=256)
+    rng = np.random.default_rng(1)
+    probs, worlds = [], []
+    for f in frames:
+        w = f['world']
+        lg = rng.standard_normal((w.shape[0], 19)) + np.cos(w[:, 1:2] * 0.9) * 2
+        p = np.exp(lg - lg.max(1, keepdims=True))
+        probs.append((p / p.sum(1, keepdims=True)).astype(np.float32))
+        worlds.append(w)
+    bank = _bank(probs, worlds, 0.1)
+    saved = interframe.CELL_ORDER
+    try:
+        outs = []
+        for order in (False, True):
+            interframe.CELL_ORDER = order
+            outs.append([interframe.score_points(bank, i, 4) for i in (0, 3, 6)])
+    finally:
+        interframe.CELL_ORDER = saved
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert int((outs[0][1][2] > 0).sum()) > 100

@@ -1169,8 +1169,9 @@ def run_variants(args, batch, dev, inline=None):
         from lidal_amd import backend as B
         var['f32']['what'] = ('the reference\'s training precision (train.py:127-140, no autocast): f32 features, weights, '
                               'accumulation, BatchNorm in f64 sums; forward products and data gradients of the sparse '
-                              'convolutions in the split form (3 bf16 pieces per operand, 6 partial products on the bf16 MFMA: '
-                              'as close to f64 as the exact kernel), weight gradients and dense layers on the exact f32 MFMA'
+                              'convolutions and every weight gradient in the split form (3 exact bf16 pieces per operand, 6 partial '
+                              'products on the bf16 MFMA: as close to f64 as the exact kernels); the dense layers\' products and the '
+                              '4-channel stem on the exact f32 MFMA; one stream (network/plan.py SIDE_F32)'
                               if B.SPLIT_F32_TRAIN and B.SPLIT_F32 else 'every product on the exact f32 MFMA')
         if B.SPLIT_F32_TRAIN and B.SPLIT_F32:
             B.SPLIT_F32_TRAIN = False

@@ -499,7 +499,7 @@ def roofline_conv(args, coords, dev, reps=20):
 FAMILY_OF = {
     'lidal_conv_apply_image': 'conv_apply', 'lidal_conv_dgrad_bn_sums': 'conv_apply',
     'lidal_conv_apply_image_ws': 'conv_apply', 'lidal_conv_dgrad_bn_sums_ws': 'conv_apply',
-    'lidal_conv_wgrad': 'conv_wgrad',
+    'lidal_conv_wgrad': 'conv_wgrad', 'lidal_conv_wgrad_streams': 'conv_wgrad',
     'lidal_conv_weight_image': 'weight_pack', 'lidal_conv_weight_image_batch': 'weight_pack',
     'lidal_conv_weight_image_pair': 'weight_pack',
     'lidal_bn_train_fwd': 'batch_norm', 'lidal_bn_train_fwd_tiles': 'batch_norm', 'lidal_bn_bwd': 'batch_norm', 'lidal_bn_bwd_tiles': 'batch_norm', 'lidal_bn_eval_fwd': 'batch_norm',
@@ -628,6 +628,13 @@ def family_table(step, coords, dtype_name, step_ms):
             n_a, n_b, k, ca, cb, dt = a[2], a[3], a[10], a[11], a[12], a[13]
             b = 2 if dt == 1 else 4
             # a = the saved input x [n_a, ca] of the forward conv, b = grad_out [n_b, cb]
+            m = rules_of(k, n_a, n_b)
+            by = b * (n_a * ca + n_b * cb) + 4 * k * ca * cb + 8 * m
+            fl = 2.0 * m * ca * cb
+        elif name == 'lidal_conv_wgrad_streams':
+            # (a, b, n_a, n_b, spairs, sdesc, n_wg, a_col, gw, partial, n_slabs, k, ca, cb, dtype, stream): the same product
+            n_a, n_b, k, ca, cb, dt = a[2], a[3], a[11], a[12], a[13], a[14]
+            b = 2 if dt == 1 else 4
             m = rules_of(k, n_a, n_b)
             by = b * (n_a * ca + n_b * cb) + 4 * k * ca * cb + 8 * m
             fl = 2.0 * m * ca * cb

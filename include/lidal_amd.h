@@ -356,6 +356,36 @@ int lidal_conv_wgrad(const void* a, const void* b, int64_t n_a, int64_t n_b, con
                      const int64_t* koff, int a_col, float* gw, float* partial, int64_t n_slabs,
                      int k, int ca, int cb, int dtype, void* stream);
 
+/* The weight gradient on rule lists re-ordered into ONE STREAM PER WORKGROUP (round 6; csrc/wgrad_streams.hip,
+ * csrc/wgrad_dma.hip wgrad_stream_kernel).  lidal_conv_wgrad reads both rows of every rule from the fabric: the ~5 rules
+ * that touch a row lie in different offsets, worked on far apart in time (96 -> 96 on 397 k rows: 851 MB per launch for
+ * 152 MB of operands).  lidal_wgrad_streams_build re-orders the rules of a stride-1 map (pairs / koff of
+ * lidal_kmap_build, k <= 32 offsets, n_rows rows on both sides) so that the rules of a row meet in one XCD's L2: rows are
+ * cut into blocks of consecutive spatial keys -- key_tab == NULL: the row index (rows numbered in coordinate order:
+ * every level lidal_downsample made), key_range = n_rows; otherwise key(row) = max over key_tab i32 [key_k, n_rows] in
+ * [0, key_range): the strided map's inverse neighbour table (lidal_kmap_invert) names a row's parent on the next level,
+ * for levels numbered otherwise (SPVCNN's level 0: by coordinate hash) -- block b belongs to the workgroups w with
+ * w % 8 == b % 8 (one XCD under round-robin dispatch), which share the offsets in proportion to their rule counts and
+ * walk the blocks in order.  Outputs: spairs i32 [spairs_rules >= lidal_wgrad_streams_rules(..), 2] (bit 31 of a
+ * rule's first index: the accumulator set; out-of-range rules as padding) and sdesc i32
+ * [lidal_wgrad_streams_desc_words(k, n_wg)] = {n_wg, k, stages, 0, soff[n_wg + 1], offsets of workgroup w [n_wg][2],
+ * the reducer's table [k][8][3]}.  n_wg = lidal_wgrad_streams_workgroups() (512).  Nothing is read back to the host;
+ * the result is a pure function of (pairs, koff, keys): integer arithmetic, stable sorts. */
+int lidal_wgrad_streams_workgroups(void);
+int64_t lidal_wgrad_streams_rules(int64_t n_rows, int k, int n_wg);
+int64_t lidal_wgrad_streams_desc_words(int k, int n_wg);
+int64_t lidal_wgrad_streams_workspace_bytes(int64_t n_rows, int k);
+int lidal_wgrad_streams_build(const int32_t* pairs, const int64_t* koff, int k, int64_t n_rows, const int32_t* key_tab,
+                              int key_k, int64_t key_range, int n_wg, int32_t* spairs, int64_t spairs_rules,
+                              int32_t* sdesc, void* ws, int64_t ws_bytes, void* stream);
+/* gw[k] = a[spairs[:, a_col]]^T b[spairs[:, 1 - a_col]] over those streams: the same rules as lidal_conv_wgrad in
+ * another order -- equal to it within f32 rounding, bitwise reproducible (fixed slab order, no atomics).  bf16, ca and cb
+ * multiples of 8 within ONE channel tile (<= 128); partial >= 2 n_wg slabs of [ca][cb] f32. */
+int lidal_conv_wgrad_streams_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb);     /* 1: the shape is served */
+int lidal_conv_wgrad_streams(const void* a, const void* b, int64_t n_a, int64_t n_b, const int32_t* spairs,
+                             const int32_t* sdesc, int n_wg, int a_col, float* gw, float* partial, int64_t n_slabs,
+                             int k, int ca, int cb, int dtype, void* stream);
+
 /* ---- batch normalisation over rows ------------------------------------------------------------ */
 /* replaces the torch.nn.BatchNorm1d kernels behind spnn.BatchNorm (network/utils.py:115; 49 per
  * model) for x [n, c] row-major, dtype f32 or bf16 (statistics always f32).  Training forward:
@@ -571,7 +601,8 @@ enum {
   LIDAL_OP_ADD2D = 22, LIDAL_OP_TRANSPOSE_F32 = 23, LIDAL_OP_CAST_ROWS_BF16 = 24, LIDAL_OP_VIEW_MEAN_SOFTMAX = 25,
   LIDAL_OP_FORK_SIDE = 26, LIDAL_OP_JOIN_SIDE = 27, LIDAL_OP_CONV_APPLY_IMAGE_WS = 28,
   LIDAL_OP_CONV_DGRAD_BN_SUMS_WS = 29, LIDAL_OP_ADD_RELU_BWD_BN_SUMS = 30, LIDAL_OP_BN_BWD_FROM_SUMS = 31,
-  LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS = 32, LIDAL_OP_DEVOXELIZE_BWD_CELLS = 33
+  LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS = 32, LIDAL_OP_DEVOXELIZE_BWD_CELLS = 33,
+  LIDAL_OP_CONV_WGRAD_STREAMS = 34
 };
 #define LIDAL_OP_FLAG_SIDE 1
 int lidal_plan_op_args(int kind);

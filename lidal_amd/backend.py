@@ -93,6 +93,13 @@ SIGNATURES = {
                                            _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp]),
     'lidal_conv_wgrad_slabs': (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     'lidal_conv_wgrad': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    'lidal_conv_wgrad_streams': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    'lidal_conv_wgrad_streams_serves': (_i32, [_i64, _i64, _i32, _i32, _i32]),
+    'lidal_wgrad_streams_workgroups': (_i32, []),
+    'lidal_wgrad_streams_rules': (_i64, [_i64, _i32, _i32]),
+    'lidal_wgrad_streams_desc_words': (_i64, [_i32, _i32]),
+    'lidal_wgrad_streams_workspace_bytes': (_i64, [_i64, _i32]),
+    'lidal_wgrad_streams_build': (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     'lidal_bn_workspace_bytes': (_i64, [_i64, _i32]),
     'lidal_bn_train_fwd': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                   _vp, _vp, _i64, _vp]),
@@ -150,7 +157,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._handle, name)
-        if fn.restype is not _i32 or name.endswith(('_bytes', '_tiling', '_rows')) or name == 'lidal_version':
+        if fn.restype is not _i32 or name.endswith(('_bytes', '_tiling', '_rows', '_workgroups', '_serves')) or name == 'lidal_version':
             return fn                               # size queries: no kernel behind them
         sink = self._sink
 
@@ -427,6 +434,12 @@ FORK = int(os.environ.get('LIDAL_FORK', '15'))      # bit 0: residual blocks, bi
 
 
 _OVERLAP_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAM_ROWS', '0'))
+
+# The streamed weight gradient (round 6; csrc/wgrad_streams.hip): the rule lists of a stride-1 map re-ordered into one
+# stream per workgroup, so that the rules of a row meet in one XCD's L2 (nn/functional/conv.py KernelMap.streams).  Taken
+# on levels with at least this many rows (0 = never): the tables cost ~0.2 ms per map, a launch saves 25-45 us on the
+# 226 k / 397 k-row levels of a 5-scan batch and ~7 us on the 105 k-row one (scripts/exp/wgrad_streams.py).
+WGRAD_STREAMS_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAMS_ROWS', '150000'))
 
 
 def overlap_wgrad(dtype, n_rows=0):

@@ -194,14 +194,20 @@ int64_t wgrad_split_scratch_bytes(int64_t n_a, int64_t n_b, int ca, int cb);
 int wgrad_split(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* pairs, const int64_t* koff, int a_col,
                 float* gw, float* partial, void* scratch, int W, int K, int ca, int cb, hipStream_t s);
 
+// ... and its streamed form (round 6): rule lists re-ordered into one stream per workgroup (lidal_wgrad_streams_build), 2 W slabs
+bool wgrad_stream_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb);
+int wgrad_stream(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* spairs, const int* sdesc, int W, int a_col,
+                 float* gw, float* partial, int K, int ca, int cb, hipStream_t s);
+
 // sort.hip: stable LSD radix sort (Onesweep) of u32 / u64 keys with an optional i32 payload by key bits
 // [0, end_bit): 1 + ceil(end_bit / 8) launches; keys_in / vals_in are not written; vals_in == NULL sorts
 // keys only
 int64_t radix_sort_ws_bytes(int64_t n, int key_bytes, bool has_val);
+// n_dev (device i64, optional): the live item count min(*n_dev, n) when only the device knows it (launches sized for n)
 int radix_sort(const void* keys_in, const int* vals_in, void* keys_out, int* vals_out, int64_t n,
-               int key_bytes, int end_bit, void* ws, int64_t ws_bytes, hipStream_t s);
+               int key_bytes, int end_bit, void* ws, int64_t ws_bytes, hipStream_t s, const int64_t* n_dev = nullptr);
 int64_t sort_pairs_ws_bytes(int64_t n);
 int sort_pairs_u32(const unsigned* keys_in, const int* vals_in, unsigned* keys_out, int* vals_out,
-                   int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s);
+                   int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s, const int64_t* n_dev = nullptr);
 
 }  // namespace lidal

@@ -518,3 +518,20 @@ extern "C" int lidal_conv_wgrad(const void* a, const void* b, int64_t n_a, int64
   LIDAL_CHECK_LAUNCH("wgrad_reduce");
   return 0;
 }
+
+extern "C" int lidal_conv_wgrad_streams_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb) {
+  return wgrad_stream_serves(n_a, n_b, k, ca, cb) ? 1 : 0;
+}
+
+extern "C" int lidal_conv_wgrad_streams(const void* a, const void* b, int64_t n_a, int64_t n_b, const int32_t* spairs,
+                                        const int32_t* sdesc, int n_wg, int a_col, float* gw, float* partial,
+                                        int64_t n_slabs, int k, int ca, int cb, int dtype, void* stream) {
+  if (k == 0 || ca == 0 || cb == 0) return 0;
+  LIDAL_REQUIRE(dtype == LIDAL_BF16, "wgrad(streams): bf16 operands only (dtype %d)", dtype);
+  LIDAL_REQUIRE(n_a >= 0 && n_b >= 0, "wgrad(streams): negative row count");
+  LIDAL_REQUIRE(wgrad_stream_serves(n_a, n_b, k, ca, cb),
+                "wgrad(streams): one channel tile of whole 16-byte segments (ca=%d cb=%d <= 128, multiples of 8)", ca, cb);
+  LIDAL_REQUIRE(n_wg > 0 && n_wg % 8 == 0, "wgrad(streams): %d workgroups (a positive multiple of 8)", n_wg);
+  LIDAL_REQUIRE(n_slabs >= 2ll * n_wg, "wgrad(streams): scratch of %lld slabs, 2 x %d workgroups needed", (long long)n_slabs, n_wg);
+  return wgrad_stream(a, b, n_a, n_b, spairs, sdesc, n_wg, a_col, gw, partial, k, ca, cb, (hipStream_t)stream);
+}

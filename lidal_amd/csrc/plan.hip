@@ -234,6 +234,7 @@ const OpInfo kOps[] = {
     /* LIDAL_OP_BN_BWD_FROM_SUMS 31 */ {16, "bn_bwd_from_sums"},
     /* LIDAL_OP_ADD_RELU_BWD_BN_TILE_SUMS 32 */ {15, "add_relu_bwd_bn_tile_sums"},
     /* LIDAL_OP_DEVOXELIZE_BWD_CELLS 33 */ {12, "devoxelize_bwd_cells"},
+    /* LIDAL_OP_CONV_WGRAD_STREAMS 34 */ {15, "conv_wgrad_streams"},
 };
 constexpr int kNumOps = (int)(sizeof(kOps) / sizeof(kOps[0]));
 
@@ -354,6 +355,10 @@ int run_ops(const int64_t* words, int64_t n_words, int64_t n_ops, void* const* s
       case LIDAL_OP_CONV_WGRAD:
         rc = lidal_conv_wgrad(P(0), P(1), L(2), L(3), CP(int32_t, 4), CP(int64_t, 5), I(6), MP(float, 7), MP(float, 8),
                               L(9), I(10), I(11), I(12), I(13), st);
+        break;
+      case LIDAL_OP_CONV_WGRAD_STREAMS:
+        rc = lidal_conv_wgrad_streams(P(0), P(1), L(2), L(3), CP(int32_t, 4), CP(int32_t, 5), I(6), I(7), MP(float, 8),
+                                      MP(float, 9), L(10), I(11), I(12), I(13), I(14), st);
         break;
       case LIDAL_OP_BN_TRAIN_FWD:
         rc = lidal_bn_train_fwd(P(0), I(1), L(2), I(3), CP(float, 4), CP(float, 5), F(6), F(7), MP(float, 8),

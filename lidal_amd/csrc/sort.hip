@@ -69,12 +69,21 @@ __device__ __forceinline__ void st_status(unsigned* p, unsigned v) {
 }
 
 // ---- all digit histograms in one pass; zeroes tickets and look-back state -------------------
+// (n_dev != NULL: the item count lives on the device -- min(*n_dev, n); the launch is sized for n)
+__device__ __forceinline__ int64_t live_count(int64_t n, const int64_t* n_dev) {
+  if (n_dev == nullptr) return n;
+  const int64_t v = *n_dev;
+  return v < 0 ? 0 : (v < n ? v : n);
+}
+
 template <typename K>
-__global__ void __launch_bounds__(THREADS) sort_hist_kernel(const K* __restrict__ keys, int64_t n, int passes,
+__global__ void __launch_bounds__(THREADS) sort_hist_kernel(const K* __restrict__ keys, int64_t n_cap, int passes,
                                                             int end_bit, unsigned* __restrict__ part,
-                                                            unsigned* __restrict__ zero_from, int64_t zero_words) {
+                                                            unsigned* __restrict__ zero_from, int64_t zero_words,
+                                                            const int64_t* __restrict__ n_dev) {
   __shared__ unsigned h[MAX_PASSES][RADIX];
   const int tid = threadIdx.x;
+  const int64_t n = live_count(n_cap, n_dev);
   for (int i = tid; i < MAX_PASSES * RADIX; i += THREADS) (&h[0][0])[i] = 0u;
   for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < zero_words; i += (int64_t)gridDim.x * THREADS)
     zero_from[i] = 0u;
@@ -158,10 +167,11 @@ __device__ __forceinline__ unsigned scan256_exclusive(unsigned v, unsigned* wsum
 template <typename K, bool HAS_VAL>
 __global__ void __launch_bounds__(THREADS) sort_onesweep_kernel(const K* __restrict__ kin, const int* __restrict__ vin,
                                                                 K* __restrict__ kout, int* __restrict__ vout,
-                                                                int64_t n, int shift, int bits,
+                                                                int64_t n_cap, int shift, int bits,
                                                                 const unsigned* __restrict__ part, int hist_blocks,
                                                                 unsigned* __restrict__ ticket,
-                                                                unsigned* __restrict__ status) {
+                                                                unsigned* __restrict__ status,
+                                                                const int64_t* __restrict__ n_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];
   K* skey = reinterpret_cast<K*>(stage_raw);
   int* sval = reinterpret_cast<int*>(stage_raw + (size_t)TILE * sizeof(K));
@@ -174,8 +184,10 @@ __global__ void __launch_bounds__(THREADS) sort_onesweep_kernel(const K* __restr
   if (tid == 0) tile_s = atomicAdd(ticket, 1u);
   for (int i = tid; i < WAVES * RADIX; i += THREADS) (&whist[0][0])[i] = 0u;
   __syncthreads();
+  const int64_t n = live_count(n_cap, n_dev);
   const int64_t tile = tile_s;
   const int64_t base = tile * TILE;
+  if (base >= n) return;                 // (a device-side count: the tiles past it have nothing to do -- no tile waits on them)
   const int64_t left = n - base;
   const int nvalid = left >= TILE ? TILE : (int)left;
   const unsigned dmask = (1u << bits) - 1u;
@@ -287,7 +299,7 @@ __global__ void __launch_bounds__(THREADS) sort_onesweep_kernel(const K* __restr
 
 template <typename K, bool HAS_VAL>
 int run_sort(const K* keys_in, const int* vals_in, K* keys_out, int* vals_out, int64_t n, int end_bit,
-             void* ws, const Layout& L, hipStream_t s) {
+             void* ws, const Layout& L, hipStream_t s, const int64_t* n_dev) {
   char* w = (char*)ws;
   unsigned* part = (unsigned*)(w + L.off_part);
   unsigned* ticket = (unsigned*)(w + L.off_ticket);
@@ -295,7 +307,7 @@ int run_sort(const K* keys_in, const int* vals_in, K* keys_out, int* vals_out, i
   K* ktmp = (K*)(w + L.off_ktmp);
   int* vtmp = HAS_VAL ? (int*)(w + L.off_vtmp) : nullptr;
   const int64_t zero_words = (L.off_status - L.off_ticket) / 4 + (int64_t)L.passes * L.tiles * RADIX;   // tickets + the passes' status
-  sort_hist_kernel<K><<<L.hist_blocks, THREADS, 0, s>>>(keys_in, n, L.passes, end_bit, part, ticket, zero_words);
+  sort_hist_kernel<K><<<L.hist_blocks, THREADS, 0, s>>>(keys_in, n, L.passes, end_bit, part, ticket, zero_words, n_dev);
   LIDAL_CHECK_LAUNCH("sort_hist");
   int hist_rows = L.hist_blocks;
   if (L.hist_blocks > HIST_DIRECT) {
@@ -323,7 +335,7 @@ int run_sort(const K* keys_in, const int* vals_in, K* keys_out, int* vals_out, i
     if (bits > 8) bits = 8;
     if (bits < 1) bits = 1;
     kern<<<(unsigned)L.tiles, THREADS, lds, s>>>(kin, vin, ko, vo, n, 8 * p, bits, part + (int64_t)p * RADIX,
-                                                 hist_rows, ticket + p, status + (int64_t)p * L.tiles * RADIX);
+                                                 hist_rows, ticket + p, status + (int64_t)p * L.tiles * RADIX, n_dev);
     LIDAL_CHECK_LAUNCH("sort_onesweep");
     kin = ko;
     vin = vo;
@@ -341,8 +353,10 @@ int64_t radix_sort_ws_bytes(int64_t n, int key_bytes, bool has_val) {
 
 // keys_in / vals_in are not written; keys_out (and vals_out if vals_in != NULL) receive the pairs sorted
 // by key bits [0, end_bit) -- the higher bits are ignored by the order but travel with the key.
+// n_dev (device i64, may be NULL): the live item count min(*n_dev, n) is only known on the device -- the launches and the
+// workspace are sized for n, the tiles past the live count exit; items past it are neither read nor written.
 int radix_sort(const void* keys_in, const int* vals_in, void* keys_out, int* vals_out, int64_t n,
-               int key_bytes, int end_bit, void* ws, int64_t ws_bytes, hipStream_t s) {
+               int key_bytes, int end_bit, void* ws, int64_t ws_bytes, hipStream_t s, const int64_t* n_dev) {
   if (n == 0) return 0;
   LIDAL_REQUIRE(key_bytes == 4 || key_bytes == 8, "sort: keys of %d bytes", key_bytes);
   LIDAL_REQUIRE(end_bit >= 1 && end_bit <= 8 * key_bytes && n < (1ll << 30), "sort: %d bits, %lld items", end_bit,
@@ -352,20 +366,20 @@ int radix_sort(const void* keys_in, const int* vals_in, void* keys_out, int* val
   LIDAL_REQUIRE(ws_bytes >= L.total, "sort workspace too small: %lld < %lld", (long long)ws_bytes, (long long)L.total);
   if (key_bytes == 4)
     return has_val ? run_sort<unsigned, true>((const unsigned*)keys_in, vals_in, (unsigned*)keys_out, vals_out, n,
-                                              end_bit, ws, L, s)
+                                              end_bit, ws, L, s, n_dev)
                    : run_sort<unsigned, false>((const unsigned*)keys_in, nullptr, (unsigned*)keys_out, nullptr, n,
-                                               end_bit, ws, L, s);
+                                               end_bit, ws, L, s, n_dev);
   return has_val ? run_sort<unsigned long long, true>((const unsigned long long*)keys_in, vals_in,
-                                                      (unsigned long long*)keys_out, vals_out, n, end_bit, ws, L, s)
+                                                      (unsigned long long*)keys_out, vals_out, n, end_bit, ws, L, s, n_dev)
                  : run_sort<unsigned long long, false>((const unsigned long long*)keys_in, nullptr,
-                                                       (unsigned long long*)keys_out, nullptr, n, end_bit, ws, L, s);
+                                                       (unsigned long long*)keys_out, nullptr, n, end_bit, ws, L, s, n_dev);
 }
 
 int64_t sort_pairs_ws_bytes(int64_t n) { return radix_sort_ws_bytes(n, 4, true); }
 
 int sort_pairs_u32(const unsigned* keys_in, const int* vals_in, unsigned* keys_out, int* vals_out,
-                   int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s) {
-  return radix_sort(keys_in, vals_in, keys_out, vals_out, n, 4, bits, ws, ws_bytes, s);
+                   int64_t n, int bits, void* ws, int64_t ws_bytes, hipStream_t s, const int64_t* n_dev) {
+  return radix_sort(keys_in, vals_in, keys_out, vals_out, n, 4, bits, ws, ws_bytes, s, n_dev);
 }
 
 }  // namespace lidal

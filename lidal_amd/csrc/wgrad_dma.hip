@@ -35,6 +35,8 @@
 // every piece: w and k never both stand still), and the reducer adds the slabs w_first(k)..w_last(k)
 // of each offset in that fixed order: bitwise reproducible, no atomics.  T, the cut points and the
 // slab ranges are recomputed from koff by both kernels -- nothing travels through the host.
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace lidal;
@@ -53,6 +55,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr int wgrad_depth(int /*stage_bytes*/) { return 1; }
 
 constexpr int WT = 256;        // 4 waves as 2 x 2
+constexpr int STREAM_HDR = 4;   // i32 words ahead of soff in a stream descriptor (lidal_wgrad_streams_build)
 constexpr int RPS = 64;        // rules per stage (two MFMA k-steps)
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
@@ -605,6 +608,245 @@ wgrad_split_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, u
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The streamed form (round 6): the bf16 kernel above on rule lists re-ordered into ONE STREAM PER WORKGROUP
+// ------------------------------------------------------------------------------------------------------------------
+// The offset-major decomposition above reads both rows of every rule from the fabric (672 MB per launch on the 96 -> 96
+// layer of level 0 against 168 MB of operands: counter record of round 5): the rules that touch a row sit in 27 different
+// offsets and are worked on by workgroups far apart in time.  lidal_wgrad_streams_build (below) re-orders the rule lists
+// of a stride-1 map so that
+//   * the rows are cut into NB blocks of consecutive SPATIAL keys (the row index where rows are numbered in coordinate
+//     order, the parent's row index on a level numbered by coordinate hash); block b belongs to XCD b % 8 -- workgroup
+//     w runs on XCD w % 8 (round-robin dispatch) -- which walks its blocks in order: the rows of a block are fetched once
+//     into that XCD's L2 and found there by the rules of all 27 offsets;
+//   * inside an XCD the W / 8 workgroups divide the OFFSETS between them in proportion to the offsets' rule counts (a
+//     workgroup keeps its accumulators for the whole launch; per block it works on its share of the block's rules of
+//     its offset), a workgroup at the border between two offsets serving both with two accumulator sets;
+//   * a workgroup's rules are stored as one padded run of 64-rule stages (every (block, set) piece padded to whole
+//     32-rule MFMA steps with out-of-range rules: zeros, no memory access; bit 31 of a rule's first index = its set).
+// The kernel is then the loop above without pieces: one uninterrupted pipeline per workgroup, two slabs at the end.
+// stages in flight per workgroup: one, as in the offset-major kernel (measured with two resident workgroups per CU and as
+// many stages as 78 KB of LDS hold -- depth 2 for 96 -> 96, 4 for 32 -> 32 -- on 397 k / 226 k rows: 96 -> 96 88 -> 98 us,
+// 64 -> 64 52 -> 53, 32 -> 32 52 -> 51.5; LIDAL_X_STREAM_DEPTH keeps the deeper ring selectable for experiments)
+constexpr int stream_depth(int /*stage_bytes*/) { return 1; }
+
+template <int MI, int NI, int DD>
+__global__ void __launch_bounds__(WT, 2)
+wgrad_stream_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, unsigned n_a, unsigned n_b,
+                    const int2* __restrict__ spairs, const int* __restrict__ soff, const int* __restrict__ wk,
+                    int a_col, float* __restrict__ partial, int ca, int cb) {
+  constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
+  constexpr int SEG_A = TA / 8, SEG_B = TB / 8;
+  constexpr int A_BYTES = RPS * TA * 2, B_BYTES = RPS * TB * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int D = DD ? DD : stream_depth(STAGE), R = D + 1, IDS_R = 2 * D + 1, IDS_BYTES = RPS * 8;
+  constexpr int IA = SEG_A / 4, IB = SEG_B / 4;
+  constexpr int INFLIGHT = (D - 1) * (IA + IB + 1);
+  static_assert(INFLIGHT < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [R][STAGE] [IDS_R][IDS_BYTES]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned ids0 = lds0 + R * STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row16 = lane & 15, gsel = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int w = blockIdx.x;
+  const int s_beg = soff[w], nsteps = soff[w + 1] - s_beg;
+  const int k0 = wk[2 * w], k1 = wk[2 * w + 1];
+  if (k0 < 0 && k1 < 0) return;
+  const int n_rules = nsteps * RPS;
+
+  const u32x4 rs_a = make_rsrc(a, n_a * (unsigned)ca * 2u), rs_b = make_rsrc(b, n_b * (unsigned)cb * 2u);
+  const u32x4 rs_p = make_rsrc((const void*)(spairs + (int64_t)s_beg * RPS), (unsigned)n_rules * 8u);
+
+  int row_a[IA], row_b[IB];
+  unsigned col_a[IA], col_b[IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int sg = 64 * (wave * IA + i) + lane, row = sg / SEG_A, c = unswz<SEG_A>(row, sg % SEG_A) * 8;
+    row_a[i] = row;
+    col_a[i] = c < ca ? (unsigned)c * 2u : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int sg = 64 * (wave * IB + i) + lane, row = sg / SEG_B, c = unswz<SEG_B>(row, sg % SEG_B) * 8;
+    row_b[i] = row;
+    col_b[i] = c < cb ? (unsigned)c * 2u : OOB;
+  }
+  const unsigned rb_a = (unsigned)ca * 2u, rb_b = (unsigned)cb * 2u;
+  const int sel_a = a_col ? 4 : 0, sel_b = a_col ? 0 : 4;
+
+  auto issue_ids = [&](int t) __attribute__((always_inline)) {
+    const int pi = t * RPS + 32 * (wave & 1) + (lane >> 1);
+    const unsigned off = pi < n_rules ? (unsigned)pi * 8u + (unsigned)(lane & 1) * 4u : OOB;
+    dma4(rs_p, ids0 + (t % IDS_R) * IDS_BYTES + (wave & 1) * 256, off);
+  };
+  auto issue_rows = [&](int t) __attribute__((always_inline)) {
+    const unsigned stage = lds0 + (unsigned)(t % R) * STAGE;
+    const unsigned char* ids = smem + R * STAGE + (t % IDS_R) * IDS_BYTES;
+    const bool live = t < nsteps;
+    unsigned ia[IA], ib[IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) ia[i] = *reinterpret_cast<const unsigned*>(ids + row_a[i] * 8 + sel_a);
+#pragma unroll
+    for (int i = 0; i < IB; ++i) ib[i] = *reinterpret_cast<const unsigned*>(ids + row_b[i] * 8 + sel_b);
+#pragma unroll
+    for (int i = 0; i < IA; ++i) asm volatile("" : "+v"(ia[i]));
+#pragma unroll
+    for (int i = 0; i < IB; ++i) asm volatile("" : "+v"(ib[i]));
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const unsigned id = ia[i] & 0x7FFFFFFFu;
+      const bool ok = live && id < n_a && col_a[i] != OOB;
+      dma16(rs_a, stage + (wave * IA + i) * 1024, ok ? id * rb_a + col_a[i] : OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const unsigned id = ib[i] & 0x7FFFFFFFu;
+      const bool ok = live && id < n_b && col_b[i] != OOB;
+      dma16(rs_b, stage + A_BYTES + (wave * IB + i) * 1024, ok ? id * rb_b + col_b[i] : OOB);
+    }
+  };
+
+  f32x4 acc0[MI][NI], acc1[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc0[mi][ni] = acc1[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int q = row16 >> 2, pp = row16 & 3;
+  const int trow = 8 * gsel + q;
+  int fa[MI], fb[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+    fa[mi] = trow * (SEG_A * 16) + swz<SEG_A>(trow, 2 * (wr * MI + mi) + (pp >> 1)) * 16 + (pp & 1) * 8;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+    fb[ni] = A_BYTES + trow * (SEG_B * 16) + swz<SEG_B>(trow, 2 * (wc * NI + ni) + (pp >> 1)) * 16 + (pp & 1) * 8;
+
+#pragma unroll
+  for (int j = 0; j < D; ++j) issue_ids(j);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    issue_ids(j + D);
+    issue_rows(j);
+  }
+  for (int step = 0; step < nsteps; ++step) {
+    // rows(step) and ids(step + D) have landed: only the D - 1 younger stages may be in flight
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (INFLIGHT & 15) | ((INFLIGHT >> 4) << 14));
+    __syncthreads();
+    issue_ids(step + 2 * D);
+    issue_rows(step + D);
+    const unsigned char* st = smem + (step % R) * STAGE;
+    const unsigned char* ids = smem + R * STAGE + (step % IDS_R) * IDS_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < RPS / 32; ++ks) {
+      // the set of this 32-rule step: bit 31 of its first rule's first index (pieces are padded to whole steps)
+      const unsigned flag = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(ids + ks * 256)) >> 31;
+      bf16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const unsigned char* base = st + fa[mi] + ks * 32 * (SEG_A * 16);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * (SEG_A * 16)));
+        af[mi] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const unsigned char* base = st + fb[ni] + ks * 32 * (SEG_B * 16);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * (SEG_B * 16)));
+        bf[ni] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      if (flag == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc0[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc0[mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc1[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  const int64_t per_k = (int64_t)ca * cb;
+#pragma unroll
+  for (int set = 0; set < 2; ++set) {
+    if ((set ? k1 : k0) < 0) continue;
+    float* dst = partial + (int64_t)(2 * w + set) * per_k;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = (wr * MI + mi) * 16 + gsel * 4 + r;
+          const int j = (wc * NI + ni) * 16 + row16;
+          if (i < ca && j < cb) dst[(int64_t)i * cb + j] = set ? acc1[mi][ni][r] : acc0[mi][ni][r];
+        }
+  }
+}
+
+// gw[k] = the slabs of the workgroups that served offset k, added in a fixed order: kred[k][x] = (first slot, slots, set of
+// the first slot) on XCD x; slot j there = workgroup 8 j + x, slab 2 w + set (set 0 on every slot but possibly the first)
+__global__ void __launch_bounds__(256)
+wgrad_stream_reduce_kernel(const float* __restrict__ partial, const int* __restrict__ kred, float* __restrict__ gw,
+                           int64_t per_k) {
+  __shared__ int slabs[520];
+  __shared__ int n_sh;
+  const int k = blockIdx.y;
+  if (threadIdx.x < 64) {           // lane x < 8 lists the slabs of XCD x behind those of the XCDs before it
+    const int x = threadIdx.x;
+    const int j0 = x < 8 ? kred[(k * 8 + x) * 3] : 0, nj = x < 8 ? kred[(k * 8 + x) * 3 + 1] : 0;
+    const int set0 = x < 8 ? kred[(k * 8 + x) * 3 + 2] : 0;
+    int pre = nj;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      const int t = __shfl_up(pre, d);
+      if (x >= d) pre += t;
+    }
+    if (x < 8)
+      for (int jj = 0; jj < nj && pre - nj + jj < 512; ++jj) slabs[pre - nj + jj] = 2 * (8 * (j0 + jj) + x) + (jj == 0 ? set0 : 0);
+    if (x == 7) n_sh = pre < 512 ? pre : 512;
+  }
+  __syncthreads();
+  // 32 float4 columns x 8 groups: group g adds the slabs g, g + 8, .. of the list in order, the groups' sums are added in
+  // group order -- a fixed association, 8 x 8 slabs in flight per column (the centre offset's list is ~110 slabs long)
+  const int n = n_sh;
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t i = ((int64_t)blockIdx.x * 32 + col) * 4;
+  const bool live = i < per_k;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int U = 8;
+  if (live)
+    for (int t = grp; t < n; t += 8 * U) {
+      float4 x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        x[u] = t + 8 * u < n ? *reinterpret_cast<const float4*>(partial + (int64_t)slabs[t + 8 * u] * per_k + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (t + 8 * u < n) { s.x += x[u].x; s.y += x[u].y; s.z += x[u].z; s.w += x[u].w; }
+    }
+  __shared__ float4 gsum[8][32];
+  gsum[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && live) {
+    float4 r = gsum[0][col];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { const float4 v = gsum[g][col]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+    *reinterpret_cast<float4*>(gw + (int64_t)k * per_k + i) = r;
+  }
+}
+
 constexpr int lds_bytes(int ta, int tb) {
   const int stage = RPS * (ta + tb) * 2, d = wgrad_depth(stage);
   return (d + 1) * stage + (2 * d + 1) * RPS * 8;
@@ -670,6 +912,32 @@ int launch_split(const void* a3, const void* b3, int64_t n_a, int64_t n_b, const
   else
     wgrad_dma_reduce_kernel<1><<<dim3((unsigned)cdiv(per_k, 256), (unsigned)K), 256, 0, s>>>(partial, koff, gw, K, per_k, W, SRPS);
   LIDAL_CHECK_LAUNCH("lidal_conv_wgrad (split reduce)");
+  return 0;
+}
+
+template <int MI, int NI>
+int launch_stream(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* spairs, const int* sdesc, int W, int a_col,
+                  float* gw, float* partial, int K, int ca, int cb, hipStream_t s) {
+  constexpr int TA = 2 * MI * 16, TB = 2 * NI * 16;
+  static const int depth_x = getenv("LIDAL_X_STREAM_DEPTH") ? atoi(getenv("LIDAL_X_STREAM_DEPTH")) : 0;     // (experiments: 2)
+  const int D = depth_x == 2 && 3 * RPS * (TA + TB) * 2 <= 78 * 1024 ? 2 : stream_depth(RPS * (TA + TB) * 2);
+  const size_t lds = (size_t)((D + 1) * RPS * (TA + TB) * 2 + (2 * D + 1) * RPS * 8);
+  auto kern = D == 2 ? wgrad_stream_kernel<MI, NI, 2> : wgrad_stream_kernel<MI, NI, 0>;
+  static size_t attr_set[2][MAX_DEVICES] = {};
+  const int dev = current_device();
+  if (attr_set[D == 2][dev] < lds) {
+    LIDAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[D == 2][dev] = lds;
+  }
+  const int* soff = sdesc + STREAM_HDR;
+  const int* wk = soff + (W + 1);
+  const int* kred = wk + 2 * W;
+  kern<<<dim3((unsigned)W), WT, lds, s>>>((const __bf16*)a, (const __bf16*)b, (unsigned)n_a, (unsigned)n_b, (const int2*)spairs,
+                                          soff, wk, a_col, partial, ca, cb);
+  LIDAL_CHECK_LAUNCH("lidal_conv_wgrad_streams");
+  const int64_t per_k = (int64_t)ca * cb;
+  wgrad_stream_reduce_kernel<<<dim3((unsigned)cdiv(per_k / 4, 32), (unsigned)K), 256, 0, s>>>(partial, kred, gw, per_k);
+  LIDAL_CHECK_LAUNCH("lidal_conv_wgrad_streams (reduce)");
   return 0;
 }
 
@@ -764,6 +1032,25 @@ int wgrad_dma(const void* a, const void* b, int64_t n_a, int64_t n_b, const int*
   WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4)
 #undef WG_CASE
   set_error("wgrad: no tile for %d x %d", ca, cb);
+  return 2;
+}
+
+bool wgrad_stream_serves(int64_t n_a, int64_t n_b, int k, int ca, int cb) {
+  if (!wgrad_dma_serves(n_a, n_b, k, ca, cb)) return false;
+  const int ta = wgrad_blocks(ca) * 32, tb = wgrad_blocks(cb) * 32;
+  return ca <= ta && cb <= tb && n_a < (1ll << 31) && n_b < (1ll << 31);          // one channel tile
+}
+int wgrad_stream(const void* a, const void* b, int64_t n_a, int64_t n_b, const int* spairs, const int* sdesc, int W, int a_col,
+                 float* gw, float* partial, int K, int ca, int cb, hipStream_t s) {
+  const int mi = wgrad_blocks(ca), ni = wgrad_blocks(cb);
+#define WT_CASE(M, N) \
+  if (mi == M && ni == N) return launch_stream<M, N>(a, b, n_a, n_b, spairs, sdesc, W, a_col, gw, partial, K, ca, cb, s);
+  WT_CASE(1, 1) WT_CASE(1, 2) WT_CASE(1, 3) WT_CASE(1, 4)
+  WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 3) WT_CASE(2, 4)
+  WT_CASE(3, 1) WT_CASE(3, 2) WT_CASE(3, 3) WT_CASE(3, 4)
+  WT_CASE(4, 1) WT_CASE(4, 2) WT_CASE(4, 3) WT_CASE(4, 4)
+#undef WT_CASE
+  set_error("wgrad(streams): no tile for %d x %d", ca, cb);
   return 2;
 }
 

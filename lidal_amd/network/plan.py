@@ -53,6 +53,7 @@ OP_VOXELIZE_BWD, OP_DEVOXELIZE_FWD, OP_DEVOXELIZE_BWD_SORTED, OP_CE_FWD, OP_CE_B
 OP_COPY2D, OP_ADD2D, OP_TRANSPOSE_F32, OP_CAST_ROWS_BF16, OP_VIEW_MEAN_SOFTMAX = 21, 22, 23, 24, 25
 OP_FORK_SIDE, OP_JOIN_SIDE, OP_CONV_APPLY_IMAGE_WS, OP_CONV_DGRAD_BN_SUMS_WS = 26, 27, 28, 29
 OP_ADD_RELU_BWD_BN_SUMS, OP_BN_BWD_FROM_SUMS, OP_ADD_RELU_BWD_BN_TILE_SUMS, OP_DEVOXELIZE_BWD_CELLS = 30, 31, 32, 33
+OP_CONV_WGRAD_STREAMS = 34
 
 # operations executed inside plans ('ops') and plans run ('plans') since import (backend.HITS counts every
 # library call made from Python, 'plan_run' among them)
@@ -105,7 +106,7 @@ _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv
               16: 'voxelize_bwd', 17: 'devoxelize_fwd', 18: 'devoxelize_bwd_sorted', 19: 'ce_fwd', 20: 'ce_bwd',
               21: 'copy2d', 22: 'add2d', 23: 'transpose_f32', 24: 'cast_rows_bf16', 25: 'view_mean_softmax',
               26: 'fork_side', 27: 'join_side', 28: 'conv_apply', 29: 'conv_apply', 30: 'add_relu_bwd', 31: 'bn_bwd',
-              32: 'add_relu_bwd', 33: 'devoxelize_bwd_cells'}
+              32: 'add_relu_bwd', 33: 'devoxelize_bwd_cells', 34: 'conv_wgrad_streams'}
 
 
 def _tally(words):
@@ -471,6 +472,20 @@ def _slabs(n_a, n_b, k, ca, cb, dtype):
     return v
 
 
+_WS_STREAM = {}
+
+
+def _stream_serves(n, k, ca, cb):
+    """lidal_conv_wgrad_streams_serves, memoised."""
+    key = (n, k, ca, cb)
+    v = _WS_STREAM.get(key)
+    if v is None:
+        if len(_WS_STREAM) > 4096:
+            _WS_STREAM.clear()
+        v = _WS_STREAM[key] = bool(B.lib_handle().lidal_conv_wgrad_streams_serves(n, n, k, ca, cb))
+    return v
+
+
 def _seg_ws(n_entries, m, c):
     key = (n_entries, m, c)
     v = _WS_SEG.get(key)
@@ -488,7 +503,7 @@ class _Tables:
         x0 = g.x0
         km, cm = x0.kmaps, x0.cmaps
         self.n = []
-        self.k3 = []        # per level: (table, perm, masks, nbmaps, koff)
+        self.k3 = []        # per level: (table, perm, masks, nbmaps, koff, spairs, sdesc, n_wg) -- the last three 0 without stream tables
         self.k2 = []        # per level l -> l + 1: (out table, perm, masks, in table, perm, masks, nbmaps, koff)
         self.keep = []
         for l in range(5):
@@ -497,8 +512,10 @@ class _Tables:
             self.n.append(int(cm[st].shape[0]))
             k3 = km[(st, (3, 3, 3), (1, 1, 1), (1, 1, 1))]
             oo = k3.order_out
+            st3 = k3._streams if (train and k3._streams is not None) else None       # (built with the geometry: conv.prefetch_kernel_maps)
             self.k3.append((oo.table.data_ptr(), oo.perm.data_ptr(), oo.tile_masks.data_ptr(),
-                            k3._nbmaps_cap.data_ptr() if train else 0, k3.koff.data_ptr() if train else 0))
+                            k3._nbmaps_cap.data_ptr() if train else 0, k3.koff.data_ptr() if train else 0,
+                            st3[0].data_ptr() if st3 else 0, st3[1].data_ptr() if st3 else 0, st3[2] if st3 else 0))
             self.keep.append(k3)
             if l < 4:
                 k2 = km[(st, (2, 2, 2), (2, 2, 2), (1, 1, 1))]
@@ -989,13 +1006,22 @@ class _Run:
             wcode = self.code
             slabs = int(B.lib_handle().lidal_conv_wgrad_slabs(n_x, n_g, c.k, ci, c.co, wcode))
         flag = self.side(max(n_x, n_g))
+        # the streamed form where the level has stream tables (conv.KernelMap.streams_serve: bf16, one channel tile)
+        streams = (len(rules) >= 5 and rules[2] and wcode == B.BF16 and not c.transposed and n_x == n_g
+                   and _stream_serves(n_x, c.k, ci, c.co))
+        if streams:
+            slabs = 2 * rules[4]
         nbytes = slabs * ci * c.co * 4 + (c.k * ci * c.co * 4 if ci != c.ci else 0)
         partial = self.galloc(nbytes) if os.environ.get('LIDAL_X_WGRAD_ARENA') == '1' else self.scratch(nbytes, flag)
         gw = self.slot(c.w)
         if ci != c.ci:                      # the channel-padded stem: gw[:, :ci_w] of the padded gradient
             gw = partial + slabs * ci * c.co * 4
-        self.w += (OP_CONV_WGRAD | flag, x, g, n_x, n_g, rules[0], rules[1], 1 if c.transposed else 0, gw, partial, slabs,
-                   c.k, ci, c.co, wcode)
+        if streams:
+            self.w += (OP_CONV_WGRAD_STREAMS | flag, x, g, n_x, n_g, rules[2], rules[3], rules[4], 0, gw, partial, slabs,
+                       c.k, ci, c.co, wcode)
+        else:
+            self.w += (OP_CONV_WGRAD | flag, x, g, n_x, n_g, rules[0], rules[1], 1 if c.transposed else 0, gw, partial, slabs,
+                       c.k, ci, c.co, wcode)
         self.nops += 1
         if ci != c.ci:
             self.w += (OP_COPY2D | flag, gw, ci * c.co * 4, self.slot(c.w), c.ci * c.co * 4, c.k, c.ci * c.co * 4, 0)
@@ -1061,7 +1087,7 @@ class _Run:
         elif c.strided:
             rules, table, n_gin, kflip = tables[6:8], tables[3:6], n_in, 0
         else:
-            rules, table, n_gin, kflip = tables[3:5], tables[0:3], n_in, 1
+            rules, table, n_gin, kflip = tables[3:8], tables[0:3], n_in, 1
         self.b_wgrad(c, x, n_in, dx, n_out, rules, ci)
         if not need_gx:
             return 0
@@ -1099,7 +1125,7 @@ class _Run:
         else:
             g_skip = gm
         dx2 = self.b_bn(r.b2, x2, n, mean2, inv2, gm, co, sums2, 0, part=(part2, nb), nparts=nparts)
-        table, rules = k3[0:3], k3[3:5]
+        table, rules = k3[0:3], k3[3:8]
         self.b_wgrad(r.c2, y1, n, dx2, n, rules)
         p = self.ptr
         bnb = (x1, mean1, inv1, p[r.b1.w], p[r.b1.b], 1) if self.bn_sums else None

@@ -95,6 +95,8 @@ class KernelMap:
         self._order_out = None
         self._order_in = None
         self._owner = None                   # weakref to the network.geometry.Geometry that built the map ahead, if any
+        self._stream_key = None              # (i32 [key_k, n] table, key_k, key_range): the rows' spatial key, if not their index
+        self._streams = None                 # (spairs, sdesc, n_wg): the rule lists as one stream per workgroup
 
     def check_alive(self):
         """A map built ahead on a second stream lives until its prefetcher's fence (network/geometry.py): a backward pass
@@ -120,6 +122,38 @@ class KernelMap:
                     'kmap_build(rules)')
             self._rules = (nbmaps, nbsizes, koff)
         return self._rules
+
+    def streams(self):
+        """(spairs i32 [cap, 2], sdesc i32, n_wg): the rule lists re-ordered into one stream per workgroup of the streamed
+        weight gradient (lidal_wgrad_streams_build; stride-1 maps).  Built once per map, on the stream that is current at
+        the first call -- prefetch_kernel_maps makes that call where the weight gradients will take this form, so the
+        ~0.2 ms of table building sit with the other coordinate work."""
+        if self._streams is None:
+            k, n = self.nbr_out.shape
+            dev = self.nbr_out.device
+            L = B.lib()
+            n_wg = int(L.lidal_wgrad_streams_workgroups())
+            cap = int(L.lidal_wgrad_streams_rules(n, k, n_wg))
+            spairs = B.empty((cap, 2), torch.int, dev)
+            sdesc = torch.empty(int(L.lidal_wgrad_streams_desc_words(k, n_wg)), dtype=torch.int, device=dev)
+            pairs, koff = self._nbmaps_cap, self.koff            # (before the workspace: they may have to be built first)
+            key, key_k, key_range = self._stream_key if self._stream_key is not None else (None, 0, n)
+            ws_bytes = int(L.lidal_wgrad_streams_workspace_bytes(n, k))
+            ws = B.workspace(ws_bytes, dev)
+            B.check(L.lidal_wgrad_streams_build(B.ptr(pairs), B.ptr(koff), k, n, B.ptr(key), key_k, key_range, n_wg,
+                                                B.ptr(spairs), cap, B.ptr(sdesc), B.ptr(ws), ws_bytes, B.stream()),
+                    'wgrad_streams_build')
+            self._streams = (spairs, sdesc, n_wg)
+        return self._streams
+
+    def streams_serve(self, dtype, ca, cb, transposed=False):
+        """Does the weight gradient of a [k, ca, cb] weight over this map take the streamed form?  bf16 operands, a
+        stride-1 map of an odd kernel on at least backend.WGRAD_STREAMS_ROWS rows (the tables cost ~0.2 ms per map and
+        step; below ~150 k rows the operands live in the L2s anyway), one channel tile."""
+        n_in, n_out = self.sizes
+        return bool(B.WGRAD_STREAMS_ROWS > 0 and dtype == torch.bfloat16 and not transposed and self.symmetric
+                    and n_in == n_out and n_out >= B.WGRAD_STREAMS_ROWS and self.volume <= 32
+                    and B.lib_handle().lidal_conv_wgrad_streams_serves(n_in, n_out, self.volume, ca, cb))
 
     @property
     def _nbmaps_cap(self):
@@ -338,6 +372,20 @@ def prefetch_kernel_maps(x, plan, transposed=True):
                 km._order_out = o
             else:
                 km._order_in = o
+    if torch.is_grad_enabled() and B.WGRAD_STREAMS_ROWS > 0:
+        # the stream tables of the weight gradients on the large levels (KernelMap.streams).  The rows of the level the
+        # network enters on are numbered as the caller numbered them (SPVCNN: by coordinate hash): their spatial key is
+        # the parent row on the next level -- the strided map's inverse neighbour table; every coarser level is numbered
+        # in coordinate order (F.spdownsample) and keyed by its row index.
+        first = tuple(x.stride)
+        for key, km in x.kmaps.items():
+            if (key[1] == (3, 3, 3) and key[2] == (1, 1, 1) and km.symmetric and km._streams is None
+                    and km.sizes[0] >= B.WGRAD_STREAMS_ROWS and km.nbr_out.is_cuda):
+                if key[0] == first and km._stream_key is None:
+                    down = x.kmaps.get((first, (2, 2, 2), (2, 2, 2), (1, 1, 1)))
+                    if down is not None and down.sizes[0] == km.sizes[0]:
+                        km._stream_key = (down.nbr_in, down.volume, down.sizes[1])
+                km.streams()
     return x
 
 
@@ -671,6 +719,14 @@ def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=N
 
     def wgrad():
         gw = torch.empty((k, ci, co), dtype=torch.float32, device=x.device)
+        if kmap.streams_serve(x.dtype, ci, co, transposed):          # large stride-1 levels: one rule stream per workgroup
+            spairs, sdesc, n_wg = kmap.streams()
+            partial = torch.empty((2 * n_wg, ci, co), dtype=torch.float32, device=x.device)
+            B.check(B.lib().lidal_conv_wgrad_streams(B.ptr(x), B.ptr(g), x.shape[0], g.shape[0], B.ptr(spairs), B.ptr(sdesc),
+                                                     n_wg, 0, B.ptr(gw), B.ptr(partial), partial.shape[0], k, ci, co,
+                                                     B.BF16, B.stream()), 'conv_wgrad_streams')
+            gw = gw[:, :ci_w].contiguous() if ci != ci_w else gw
+            return gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
         code, slabs = wgrad_plan(x.shape[0], g.shape[0], k, ci, co, x.dtype)
         partial = torch.empty((slabs, ci, co), dtype=torch.float32, device=x.device)
         B.check(B.lib().lidal_conv_wgrad(B.ptr(x), B.ptr(g), x.shape[0], g.shape[0],
@@ -685,7 +741,8 @@ def conv_backward(x, weight, kmap, transposed, img_bwd, grad_output, grad_skip=N
     if need_gw:
         if B.overlap_wgrad(x.dtype, max(n_in, n_out)) and need_gx:
             _ = kmap.koff                   # the rule lists are built on the main stream
-            side = B.beside(x.device, (x, g, kmap._nbmaps_cap, kmap.koff), weight)
+            side = B.beside(x.device, (x, g, kmap._nbmaps_cap, kmap.koff)
+                            + (tuple(kmap.streams()[:2]) if kmap.streams_serve(x.dtype, ci, co, transposed) else ()), weight)
             with side as done:              # beside the data gradient below
                 grad_w = wgrad()
                 done(grad_w)

@@ -126,6 +126,8 @@ def _replay(run, model, stats, conv_every=1):
         if km._order_in is not None:
             tables[km._order_in.table.data_ptr()] = (km, True)
         rules[km._nbmaps_cap.data_ptr()] = km
+        if km._streams is not None:         # the same rules as one stream per workgroup (OP_CONV_WGRAD_STREAMS)
+            rules[km._streams[0].data_ptr()] = km
     images = {}
     for c in prog.convs:
         for pf, pb in c.ptrs.values():
@@ -223,8 +225,14 @@ def _replay(run, model, stats, conv_every=1):
                                + (' + residual' if first is not None else ''), stored, ref, what, first)
                 else:
                     stats.f32('conv f32', stored, ref, what, 1e-5)
-            elif kind == P.OP_CONV_WGRAD:
-                a_p, b_p, n_a, n_b, pairs, koff, a_col, gw_p, _, _, k, ca, cb, code = a
+            elif kind in (P.OP_CONV_WGRAD, P.OP_CONV_WGRAD_STREAMS):
+                # (the streamed form names its rules by the stream table: the SAME rule lists, summed in another order --
+                #  replayed from the map's own lists like the offset-major form)
+                if kind == P.OP_CONV_WGRAD_STREAMS:
+                    a_p, b_p, n_a, n_b, pairs, _, _, a_col, gw_p, _, _, k, ca, cb, code = a
+                    assert pairs in rules and rules[pairs]._streams[0].data_ptr() == pairs
+                else:
+                    a_p, b_p, n_a, n_b, pairs, koff, a_col, gw_p, _, _, k, ca, cb, code = a
                 n_conv += 1
                 if n_conv % conv_every:
                     pending = None
@@ -245,7 +253,8 @@ def _replay(run, model, stats, conv_every=1):
                             ref[kk] = xa[ia].t() @ xb[ib]
                 if gw_p in slot_of:
                     got = _mat(gw_p, k * ca, cb, 0).reshape(k, ca, cb)
-                    stats.f32('weight gradient', got, ref, pname[slot_of[gw_p]], 1e-4)
+                    stats.f32('weight gradient' + (' (streams)' if kind == P.OP_CONV_WGRAD_STREAMS else ''), got, ref,
+                              pname[slot_of[gw_p]], 1e-4)
                     pending = None
                 else:
                     pending = (gw_p, ref)
@@ -455,6 +464,15 @@ def _step(name, points, autocast, conv_every):
 def test_every_operation_of_a_bf16_step_against_the_oracle_on_its_own_operands(name):
     stats = _step(name, 20000, True, 1)
     assert sum(r[0] for r in stats.rows.values()) > 300
+
+
+def test_streamed_weight_gradients_teacher_forced(monkeypatch):
+    """Round 6: the weight gradients of the large levels run on rule streams (plan op 34, lidal_conv_wgrad_streams).  With
+    the row threshold forced down to test size every streamed launch of a step is replayed like the others."""
+    from lidal_amd import backend as B
+    monkeypatch.setattr(B, 'WGRAD_STREAMS_ROWS', 3000)
+    stats = _step('spvcnn', 20000, True, 1)
+    assert stats.rows['weight gradient (streams)'][0] >= 6 and stats.rows['weight gradient'][0] >= 20, stats.rows
 
 
 def test_every_operation_of_an_f32_step_against_the_oracle_on_its_own_operands():

@@ -437,9 +437,14 @@ _OVERLAP_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAM_ROWS', '0'))
 
 # The streamed weight gradient (round 6; csrc/wgrad_streams.hip): the rule lists of a stride-1 map re-ordered into one
 # stream per workgroup, so that the rules of a row meet in one XCD's L2 (nn/functional/conv.py KernelMap.streams).  Taken
-# on levels with at least this many rows (0 = never): the tables cost ~0.2 ms per map, a launch saves 25-45 us on the
-# 226 k / 397 k-row levels of a 5-scan batch and ~7 us on the 105 k-row one (scripts/exp/wgrad_streams.py).
-WGRAD_STREAMS_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAMS_ROWS', '150000'))
+# on levels with at least this many rows; 0 = never, THE DEFAULT.  Measured (profiles/README.md, round 6): alone on the
+# GPU a launch on the 397 k / 226 k-row levels of a 5-scan batch takes 81 / 68 us instead of 130 / 95 (FETCH_SIZE 2 x 164 MB
+# instead of 2 x 425, L2 hits 65 % instead of 5 %), the tables cost 0.27 / 0.18 ms per map and step; inside the training
+# step -- where the weight gradients run beside the data gradients, whose two 78 KB workgroups per CU leave a 49 KB
+# workgroup no room -- the streams' workgroups are no longer resident together, the blocks they should share are gone from
+# the L2 when the late ones arrive (177 us per launch against 190), and the step is 0.1 ms SLOWER (13.58 -> 13.68 ms) with
+# the tables' launches on the second queue.  LIDAL_WGRAD_STREAMS_ROWS=150000 takes it on the two finest levels.
+WGRAD_STREAMS_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAMS_ROWS', '0'))
 
 
 def overlap_wgrad(dtype, n_rows=0):
@@ -456,7 +461,9 @@ def side_stream(device, which=1):
     if which != 1:
         key = key + (which,)
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
+        # (LIDAL_X_SIDE_PRIORITY=-1: the weight gradients' stream as a high-priority queue -- an experiment, profiles/README.md round 6)
+        pr = int(os.environ.get('LIDAL_X_SIDE_PRIORITY', '0')) if which == 1 else 0
+        _side_streams[key] = torch.cuda.Stream(device=device, priority=pr)
     return _side_streams[key]
 
 

@@ -1011,11 +1011,15 @@ class _Run:
                    and _stream_serves(n_x, c.k, ci, c.co))
         if streams:
             slabs = 2 * rules[4]
+            if os.environ.get('LIDAL_X_STREAMS_MAIN') == '1':       # (experiment: the streamed launches on the main stream)
+                flag = 0
         nbytes = slabs * ci * c.co * 4 + (c.k * ci * c.co * 4 if ci != c.ci else 0)
         partial = self.galloc(nbytes) if os.environ.get('LIDAL_X_WGRAD_ARENA') == '1' else self.scratch(nbytes, flag)
         gw = self.slot(c.w)
         if ci != c.ci:                      # the channel-padded stem: gw[:, :ci_w] of the padded gradient
             gw = partial + slabs * ci * c.co * 4
+        if os.environ.get('LIDAL_X_SKIP_WGRAD') == '1' and c.k == 27 and n_x >= 150000:       # (timing experiment: wrong gradients)
+            return
         if streams:
             self.w += (OP_CONV_WGRAD_STREAMS | flag, x, g, n_x, n_g, rules[2], rules[3], rules[4], 0, gw, partial, slabs,
                        c.k, ci, c.co, wcode)

@@ -440,10 +440,10 @@ _OVERLAP_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAM_ROWS', '0'))
 # on levels with at least this many rows; 0 = never, THE DEFAULT.  Measured (profiles/README.md, round 6): alone on the
 # GPU a launch on the 397 k / 226 k-row levels of a 5-scan batch takes 81 / 68 us instead of 130 / 95 (FETCH_SIZE 2 x 164 MB
 # instead of 2 x 425, L2 hits 65 % instead of 5 %), the tables cost 0.27 / 0.18 ms per map and step; inside the training
-# step -- where the weight gradients run beside the data gradients, whose two 78 KB workgroups per CU leave a 49 KB
-# workgroup no room -- the streams' workgroups are no longer resident together, the blocks they should share are gone from
-# the L2 when the late ones arrive (177 us per launch against 190), and the step is 0.1 ms SLOWER (13.58 -> 13.68 ms) with
-# the tables' launches on the second queue.  LIDAL_WGRAD_STREAMS_ROWS=150000 takes it on the two finest levels.
+# step -- where the weight gradients run beside the data gradients, whose waves leave a SIMD's registers no room for a
+# streamed wave with its two accumulator sets -- the streams' workgroups are no longer resident together, the blocks they
+# should share are gone from the L2 when the late ones arrive (177 us per launch against 190), and the step is 0.1 ms SLOWER
+# (13.58 -> 13.68 ms) with the tables' launches on the second queue.  LIDAL_WGRAD_STREAMS_ROWS=150000 takes it on the two finest levels.
 WGRAD_STREAMS_ROWS = int(os.environ.get('LIDAL_WGRAD_STREAMS_ROWS', '0'))
 
 

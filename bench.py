@@ -507,6 +507,7 @@ FAMILY_OF = {
     'lidal_add_relu_bwd_bn_sums': 'batch_norm', 'lidal_bn_bwd_from_sums': 'batch_norm',
     'lidal_add_relu_bwd_bn_tile_sums': 'batch_norm',
     'lidal_bn_fold': 'batch_norm', 'lidal_colsum': 'batch_norm',
+    'lidal_wgrad_streams_build': 'kernel_maps',
     'lidal_hash': 'kernel_maps', 'lidal_kernel_hash': 'kernel_maps', 'lidal_hash_table_build': 'kernel_maps',
     'lidal_hash_table_build_coords': 'kernel_maps',
     'lidal_hash_table_query': 'kernel_maps', 'lidal_unique_sorted_i64': 'kernel_maps',

@@ -99,14 +99,30 @@ __global__ void __launch_bounds__(256) rule_key_kernel(const int2* __restrict__ 
   h[tid] = 0;
   __syncthreads();
   const int64_t m = sk[K];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) {
-    int k = 0;
-    while (k + 1 < K && sk[k + 1] <= i) ++k;
-    const int b = rowblk[pairs[i].y];
-    const int x = b & 7;
-    key1[i] = (unsigned)(((x * MAXK + k) * MAXBX) + (b >> 3));
-    val1[i] = (int)i;
-    atomicAdd(&h[x * MAXK + k], 1);
+  const int lane = tid & 63;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < m; i0 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i0 + tid;
+    int bin = -1;
+    if (i < m) {
+      int lo = 0, hi = K - 1;               // the offset whose rules hold position i (empty offsets share a start: the last one)
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (sk[mid] <= i) lo = mid; else hi = mid - 1;
+      }
+      const int b = rowblk[pairs[i].y];
+      const int x = b & 7;
+      bin = x * MAXK + lo;
+      key1[i] = (unsigned)((bin * MAXBX) + (b >> 3));
+      val1[i] = (int)i;
+    }
+    // a wave's rules share their offset and fall on 8 XCDs: one LDS add per distinct bin, not one per lane
+    unsigned long long todo = __ballot(bin >= 0);
+    while (todo) {
+      const int b0 = __builtin_amdgcn_readlane(bin, __builtin_ctzll(todo));
+      const unsigned long long same = __ballot(bin == b0);
+      if (lane == __builtin_ctzll(todo)) atomicAdd(&h[b0], (int)__popcll(same));
+      todo &= ~same;
+    }
   }
   __syncthreads();
   if (h[tid]) atomicAdd(&cnt[tid], h[tid]);
@@ -229,24 +245,33 @@ __global__ void __launch_bounds__(256) step_key_kernel(const unsigned* __restric
   s_sbase[tid] = tab[TAB_SBASE + tid];
   __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + tid;
-  if (t >= *tcount) return;
-  int lo = 0, hi = 255;                       // last (XCD, offset) whose first step is <= t (empty lists share a start: take the last)
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (s_sbase[mid] <= (int)t) lo = mid; else hi = mid - 1;
+  int w = -1;
+  if (t < *tcount) {
+    int lo = 0, hi = 255;                       // last (XCD, offset) whose first step is <= t (empty lists share a start: take the last)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_sbase[mid] <= (int)t) lo = mid; else hi = mid - 1;
+    }
+    const int xk = lo, x = xk / MAXK, k = xk % MAXK;
+    const unsigned s_in = (unsigned)((int)t - s_sbase[xk]);
+    const int first_rule = tab[TAB_LSTART + xk] + 32 * (int)s_in;
+    const int blk = (int)(key1s[first_rule] & (MAXBX - 1));
+    const unsigned u = s_in * 2654435769u;
+    const int pos = tab[TAB_START + xk] + (int)(((unsigned long long)u * (unsigned)tab[TAB_LEN + xk]) >> 32);
+    const int j = pos >> 16;
+    const int set = tab[TAB_FIRST + x * 64 + j] != k;
+    w = 8 * j + x;
+    key2[t] = (unsigned)(((w * MAXBX) + blk) * 2 + set);
+    val2[t] = (int)t;
   }
-  const int xk = lo, x = xk / MAXK, k = xk % MAXK;
-  const unsigned s_in = (unsigned)((int)t - s_sbase[xk]);
-  const int first_rule = tab[TAB_LSTART + xk] + 32 * (int)s_in;
-  const int blk = (int)(key1s[first_rule] & (MAXBX - 1));
-  const unsigned u = s_in * 2654435769u;
-  const int pos = tab[TAB_START + xk] + (int)(((unsigned long long)u * (unsigned)tab[TAB_LEN + xk]) >> 32);
-  const int j = pos >> 16;
-  const int set = tab[TAB_FIRST + x * 64 + j] != k;
-  const int w = 8 * j + x;
-  key2[t] = (unsigned)(((w * MAXBX) + blk) * 2 + set);
-  val2[t] = (int)t;
-  atomicAdd(&perw[w], 1);
+  // consecutive steps belong to one list and go to the few workgroups that share its offset: one add per distinct workgroup
+  unsigned long long todo = __ballot(w >= 0);
+  while (todo) {
+    const int w0 = __builtin_amdgcn_readlane(w, __builtin_ctzll(todo));
+    const unsigned long long same = __ballot(w == w0);
+    if ((tid & 63) == __builtin_ctzll(todo)) atomicAdd(&perw[w0], (int)__popcll(same));
+    todo &= ~same;
+  }
 }
 
 // one workgroup: stages and first step of every workgroup (thread t: workgroups 8 t .. 8 t + 7)

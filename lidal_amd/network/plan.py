@@ -1018,8 +1018,6 @@ class _Run:
         gw = self.slot(c.w)
         if ci != c.ci:                      # the channel-padded stem: gw[:, :ci_w] of the padded gradient
             gw = partial + slabs * ci * c.co * 4
-        if os.environ.get('LIDAL_X_SKIP_WGRAD') == '1' and c.k == 27 and n_x >= 150000:       # (timing experiment: wrong gradients)
-            return
         if streams:
             self.w += (OP_CONV_WGRAD_STREAMS | flag, x, g, n_x, n_g, rules[2], rules[3], rules[4], 0, gw, partial, slabs,
                        c.k, ci, c.co, wcode)

@@ -387,7 +387,8 @@ extern "C" int lidal_wgrad_streams_build(const int32_t* pairs, const int64_t* ko
   const int nb = blocks_for(n_rows);
   LIDAL_HIP(hipMemsetAsync(cnt, 0, 256 * 4, s));
   rowblk_kernel<<<(unsigned)cdiv(n_rows, 256), 256, 0, s>>>(key_tab, key_k, n_rows, key_range, nb, rowblk);
-  rule_key_kernel<<<(unsigned)(cdiv(L.m_cap, 256) < 4096 ? cdiv(L.m_cap, 256) : 4096), 256, 0, s>>>((const int2*)pairs, koff, k, rowblk, key1, val1, cnt);
+  // (1024 workgroups: each ends with up to 216 global adds on the same 216 counters -- 65 us with 4096 of them)
+  rule_key_kernel<<<(unsigned)(cdiv(L.m_cap, 256) < 1024 ? cdiv(L.m_cap, 256) : 1024), 256, 0, s>>>((const int2*)pairs, koff, k, rowblk, key1, val1, cnt);
   LIDAL_CHECK_LAUNCH("wgrad_streams_build (keys)");
   if (int rc = radix_sort(key1, val1, key1s, val1s, L.m_cap, 4, 14, w + L.off_sort1, L.off_sort2 - L.off_sort1, s, koff + k)) return rc;
   plan_kernel<<<1, 256, 0, s>>>(cnt, k, n_wg, tab, tcount, sdesc, perw);

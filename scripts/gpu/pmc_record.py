@@ -6,9 +6,21 @@ import bench                                    # source_digest: the record is v
 from lidal_amd import backend as B
 d, rnd, how = sys.argv[1], sys.argv[2], sys.argv[3]
 txt = open(d + '/pmc_summary.txt').read()
-fetch = float(re.search(r'FETCH_SIZE\s+n=(\d+)\s+mean=([\d.e+]+)', txt).group(2))
-n = int(re.search(r'FETCH_SIZE\s+n=(\d+)', txt).group(1))
-write = float(re.search(r'WRITE_SIZE\s+n=\d+\s+mean=([\d.e+]+)', txt).group(1))
+
+def section(name):
+    """the block of pmc_summary.txt that belongs to the pass directory `name` (the summary also holds the step passes
+    sfetch/ and swrite/, whose first WRITE_SIZE line is another kernel's: the first three round-6 records quoted it)"""
+    m = re.search(r'^== %s/.*?$(.*?)(?=^== |\Z)' % re.escape(name), txt, re.S | re.M)
+    return m.group(1)
+
+
+KERNEL = 'conv_lean_kernelIDF16bLi6ELi192'
+f_line = [l for l in section('fetch').splitlines() if KERNEL in l and 'FETCH_SIZE' in l][0]
+w_line = [l for l in section('write').splitlines() if KERNEL in l and 'WRITE_SIZE' in l][0]
+fetch = float(re.search(r'mean=([\d.e+]+)', f_line).group(1))
+n = int(re.search(r'n=(\d+)', f_line).group(1))
+write = float(re.search(r'mean=([\d.e+]+)', w_line).group(1))
+assert int(re.search(r'n=(\d+)', w_line).group(1)) == n
 row = [r for r in csv.DictReader(open(d + '/roof_kernel_stats.csv')) if 'conv_lean_kernelIDF16bLi6ELi192' in r['Name']][0]
 line = json.load(open(d + '/bench_line.json'))['roofline']
 traffic = int(round((2 * fetch + write) * 1024))

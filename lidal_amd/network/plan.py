@@ -99,6 +99,13 @@ BRANCH_ROWS = int(os.environ.get('LIDAL_PLAN_BRANCH_ROWS', '100000'))
 POINT_SIDE = int(os.environ.get('LIDAL_PLAN_POINT_SIDE', '1'))     # 0 = on the main stream, i = on side stream i
 _XJOIN = set(filter(None, os.environ.get('LIDAL_X_JOIN_BEFORE', '').split(',')))
 F32_BN_ALONE = os.environ.get('LIDAL_PLAN_F32_BN_ALONE', '1') != '0'
+# experiment switches of the backward plan, read once (a step consulted the environment ~140 times for them: 0.1 ms of a
+# host-bound single-scan step)
+_X_SPLIT_CONV_OFF = os.environ.get('LIDAL_X_SPLIT_CONV') == '0'
+_X_SPLIT_DENSE_OFF = os.environ.get('LIDAL_X_SPLIT_DENSE') == '0'
+_X_STREAMS_MAIN = os.environ.get('LIDAL_X_STREAMS_MAIN') == '1'
+_X_WGRAD_ARENA = os.environ.get('LIDAL_X_WGRAD_ARENA') == '1'
+_X_JOIN_AFTER_WGRAD = os.environ.get('LIDAL_X_JOIN_AFTER_WGRAD') == '1'
 _NARGS = {}
 _HIT_NAMES = {1: 'conv_weight_image', 2: 'conv_apply', 3: 'conv_apply', 4: 'conv_wgrad', 5: 'bn_train_fwd',
               6: 'bn_train_fwd', 7: 'bn_bwd', 8: 'bn_bwd', 9: 'bn_eval_fwd', 10: 'bn_fold', 11: 'colsum',
@@ -1002,7 +1009,7 @@ class _Run:
         """conv.py conv_backward's wgrad(): gw [k, ci, co] f32 straight into the parameter's gradient slot."""
         ci = c.ci if ci is None else ci
         wcode, slabs = _slabs(n_x, n_g, c.k, ci, c.co, self.dtype)
-        if os.environ.get('LIDAL_X_SPLIT_CONV') == '0' and wcode == B.F32_SPLIT:
+        if _X_SPLIT_CONV_OFF and wcode == B.F32_SPLIT:
             wcode = self.code
             slabs = int(B.lib_handle().lidal_conv_wgrad_slabs(n_x, n_g, c.k, ci, c.co, wcode))
         flag = self.side(max(n_x, n_g))
@@ -1011,10 +1018,10 @@ class _Run:
                    and _stream_serves(n_x, c.k, ci, c.co))
         if streams:
             slabs = 2 * rules[4]
-            if os.environ.get('LIDAL_X_STREAMS_MAIN') == '1':       # (experiment: the streamed launches on the main stream)
+            if _X_STREAMS_MAIN:       # (experiment: the streamed launches on the main stream)
                 flag = 0
         nbytes = slabs * ci * c.co * 4 + (c.k * ci * c.co * 4 if ci != c.ci else 0)
-        partial = self.galloc(nbytes) if os.environ.get('LIDAL_X_WGRAD_ARENA') == '1' else self.scratch(nbytes, flag)
+        partial = self.galloc(nbytes) if _X_WGRAD_ARENA else self.scratch(nbytes, flag)
         gw = self.slot(c.w)
         if ci != c.ci:                      # the channel-padded stem: gw[:, :ci_w] of the padded gradient
             gw = partial + slabs * ci * c.co * 4
@@ -1028,7 +1035,7 @@ class _Run:
         if ci != c.ci:
             self.w += (OP_COPY2D | flag, gw, ci * c.co * 4, self.slot(c.w), c.ci * c.co * 4, c.k, c.ci * c.co * 4, 0)
             self.nops += 1
-        if os.environ.get('LIDAL_X_JOIN_AFTER_WGRAD') == '1' and flag:
+        if _X_JOIN_AFTER_WGRAD and flag:
             self.join(flag >> 16)
 
     def b_dgrad(self, c, g, n_g, table, n_out, kflip, skip=0, bnb=None):
@@ -1054,13 +1061,13 @@ class _Run:
         gradient per side())."""
         ca, cb = c.ci, cg
         wcode, slabs = _slabs(n, n, 1, ca, cb, self.dtype)
-        if os.environ.get('LIDAL_X_SPLIT_DENSE') == '0' and wcode == B.F32_SPLIT:
+        if _X_SPLIT_DENSE_OFF and wcode == B.F32_SPLIT:
             wcode = self.code
             slabs = int(B.lib_handle().lidal_conv_wgrad_slabs(n, n, 1, ca, cb, wcode))
         direct = linear_slot is None and cb == c.co
         flag = branch or self.side(n)
         nbytes = slabs * ca * cb * 4 + (0 if direct else ca * cb * 4)
-        sc = self.galloc(nbytes) if os.environ.get('LIDAL_X_WGRAD_ARENA') == '1' else self.scratch(nbytes, flag)
+        sc = self.galloc(nbytes) if _X_WGRAD_ARENA else self.scratch(nbytes, flag)
         gw = self.slot(c.w) if direct else sc + slabs * ca * cb * 4
         self.w += (OP_CONV_WGRAD | flag, x, g, n, n, 0, self.koff[n], 0, gw, sc, slabs, 1, ca, cb, wcode)
         self.nops += 1

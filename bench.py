@@ -1153,8 +1153,24 @@ def run_variants(args, batch, dev, inline=None):
         var['inline_geometry']['what'] = ('the same step with the coordinate tables built inside the forward pass '
                                           '(no second stream): the order of work of the reference and of rounds 1-3a')
     one = make_batch(1, args.points, 7122, dev)
-    var['single_scan'] = variant_line(bench_train(1, 0, dev, args.model, args.dtype, one,
-                                                  max(args.steps, 10), 3, ddp=False))
+    res1 = bench_train(1, 0, dev, args.model, args.dtype, one, max(args.steps, 10), 3, ddp=False)
+    var['single_scan'] = variant_line(res1)
+    # The single scan is host-bound (~6 ms of Python and ~800 launches per step, profiles/README.md round 6): one window of 20
+    # steps moved between 5.9 and 9.0 ms from run to run on the same box.  Four more windows of the same length follow the
+    # first; the figure of the leg is the MEDIAN window, every window is listed.
+    wins = [var['single_scan']['ms_per_step']]
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(res1['steps']):
+            res1['step']()
+        torch.cuda.synchronize()
+        wins.append(round((time.perf_counter() - t0) / res1['steps'] * 1e3, 3))
+    med = sorted(wins)[len(wins) // 2]
+    var['single_scan'].update({'ms_per_step': med, 'voxels_per_s': round(res1['voxels'] / med * 1e3, 1), 'windows_ms': wins,
+                               'what': 'BASELINE.json\'s literal "@120k pts": one scan per step; median of five windows of %d steps'
+                                       % res1['steps']})
+    del res1
     var['single_scan']['host'] = guarded(host_calls, args.model, args.dtype, one, dev)
     # the reference draws a new augmentation per iteration (sk_dataset.py:143-171): 8 differently
     # augmented batches of the same scans, voxelised on the GPU outside the timed region, one per step
